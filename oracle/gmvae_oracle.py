@@ -1,0 +1,377 @@
+"""NumPy restatement of the reference hot path (test infrastructure, see __init__).
+
+Every function cites the reference lines it follows (paths are relative to the
+upstream repo's ``scripts/`` directory).  ``dtype`` selects fp64 (truth) or
+fp32 (stand-in for the reference's CPU TF path).  Noise (``eps``, ``u``) and
+parameters are explicit inputs: TF's Philox streams cannot be reproduced.
+
+Row convention for the IWAE extension (not in the
+reference): sample-dependent tensors have R = B*S rows, row r = b*S + s.
+At S == 1 everything below is the reference's single-sample ELBO.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+MODEL_VAE = 0
+MODEL_VAE_GMP = 1
+MODEL_GMVAE = 2
+MODEL_NAMES = {"vae": MODEL_VAE, "vae_gmp": MODEL_VAE_GMP, "gmvae": MODEL_GMVAE}
+
+LOG_2PI = math.log(2.0 * math.pi)
+TINY_F32 = float(np.finfo(np.float32).tiny)  # RelaxedOneHotCategorical uniform minval
+
+__all__ = [
+    "MODEL_VAE", "MODEL_VAE_GMP", "MODEL_GMVAE", "MODEL_NAMES", "Dims",
+    "param_specs", "param_layout", "init_params", "pack", "unpack",
+    "softplus", "sigmoid", "forward", "loss_and_grads", "adam_tf_step",
+    "train_step", "make_inputs", "flops_per_step", "cluster_acc", "TINY_F32",
+]
+
+
+@dataclass
+class Dims:
+    """Problem sizes + the hyper-parameters runners.py:78-101 binds."""
+    D: int = 784
+    L: int = 8                       # run_gmvae.py:17 latent_size
+    K: int = 10                      # run_gmvae.py:23 mixture_components
+    hidden: Sequence[int] = (64,)    # [hidden_size]*num_layers, runners.py:83
+    S: int = 1                       # IWAE samples (build extension)
+    sigma_min: float = 0.0           # runners.py:84
+    raw_sigma_bias: float = 0.5      # runners.py:85
+    temperature: float = 1.0         # runners.py:86
+    gen_bias_init: float = 0.0       # gmvae.py:285 / vae.py:199
+
+
+# --------------------------------------------------------------------------
+# parameters (SURVEY.md A.1 creation order; names = TF variable names, 5.4)
+# --------------------------------------------------------------------------
+def _mlp_specs(name: str, n_in: int, hidden: Sequence[int], n_out: int):
+    dims = [n_in] + list(hidden) + [n_out]
+    out = []
+    for i in range(len(dims) - 1):
+        out.append((f"{name}_fcnet/linear_{i}/w", (dims[i], dims[i + 1])))
+        out.append((f"{name}_fcnet/linear_{i}/b", (dims[i + 1],)))
+    return out
+
+
+def param_specs(model: int, d: Dims) -> List[Tuple[str, Tuple[int, ...]]]:
+    h = list(d.hidden)
+    if model == MODEL_GMVAE:
+        # gmvae.py:238,243,246,251 -- variables are created at first call.
+        return (_mlp_specs("encoder_y", d.D, h, d.K)
+                + _mlp_specs("prior_gmm", d.K, [], 2 * d.L)      # gmvae.py:321-327
+                + _mlp_specs("encoder_gmm", d.D + d.K, h, 2 * d.L)
+                + _mlp_specs("decoder", d.L, h, d.D))
+    specs = []
+    if model == MODEL_VAE_GMP:
+        specs += [("loc", (d.K, d.L)), ("raw_scale_diag", (d.K, d.L)),
+                  ("mixture_logits", (d.K,))]                   # vae.py:233-238
+    return specs + _mlp_specs("encoder", d.D, h, 2 * d.L) + _mlp_specs("decoder", d.L, h, d.D)
+
+
+def param_layout(model: int, d: Dims, align: int = 4):
+    """Flat fp32 buffer layout: every tensor starts on a 16-byte boundary."""
+    off, out, real = 0, [], 0
+    for name, shape in param_specs(model, d):
+        n = int(np.prod(shape))
+        out.append((name, shape, off))
+        real += n
+        off += (n + align - 1) // align * align
+    return out, off, real
+
+
+def init_params(model: int, d: Dims, rng: np.random.Generator, dtype=np.float64) -> Dict[str, np.ndarray]:
+    """base.py:12 Xavier-uniform weights / zero biases; tf.get_variable default
+    (Glorot-uniform) for the VAE_GMP prior variables (vae.py:233-238)."""
+    p = {}
+    for name, shape in param_specs(model, d):
+        if name.endswith("/b"):
+            p[name] = np.zeros(shape, dtype)
+        else:
+            fan_in, fan_out = (shape[0], shape[1]) if len(shape) == 2 else (shape[0], shape[0])
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            p[name] = rng.uniform(-lim, lim, size=shape).astype(dtype)
+    return p
+
+
+def pack(model: int, d: Dims, params: Dict[str, np.ndarray], dtype=np.float32) -> np.ndarray:
+    lay, P, _ = param_layout(model, d)
+    flat = np.zeros(P, dtype)
+    for name, shape, off in lay:
+        flat[off:off + int(np.prod(shape))] = np.asarray(params[name], dtype).ravel()
+    return flat
+
+
+def unpack(model: int, d: Dims, flat: np.ndarray) -> Dict[str, np.ndarray]:
+    lay, _, _ = param_layout(model, d)
+    return {name: np.array(flat[off:off + int(np.prod(shape))]).reshape(shape) for name, shape, off in lay}
+
+
+# --------------------------------------------------------------------------
+# elementwise pieces
+# --------------------------------------------------------------------------
+def softplus(x):
+    """Overflow-safe tf.nn.softplus: max(x,0) + log1p(exp(-|x|))."""
+    return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
+
+
+def sigmoid(x):
+    e = np.exp(-np.abs(x))
+    return np.where(x >= 0, 1.0 / (1.0 + e), e / (1.0 + e))
+
+
+def _log_softmax(a):
+    m = a.max(axis=-1, keepdims=True)
+    s = a - m
+    return s - np.log(np.exp(s).sum(axis=-1, keepdims=True))
+
+
+def _mlp_fwd(p, name, n_layers, x):
+    """snt.nets.MLP, activate_final=False, relu hidden (base.py:47-60).
+    Returns output and the list of layer inputs [h_0 .. h_n]."""
+    hs = [x]
+    h = x
+    for i in range(n_layers):
+        h = h @ p[f"{name}_fcnet/linear_{i}/w"] + p[f"{name}_fcnet/linear_{i}/b"]
+        if i < n_layers - 1:
+            h = np.maximum(h, 0)
+            hs.append(h)
+    return h, hs
+
+
+def _mlp_bwd(p, g, name, n_layers, hs, dout, need_dx=True):
+    """Closed-form backward of _mlp_fwd.  hs[i] is the input
+    of layer i; hs[i>0] is post-ReLU so the mask is hs[i] > 0."""
+    d = dout
+    for i in reversed(range(n_layers)):
+        g[f"{name}_fcnet/linear_{i}/w"] = hs[i].T @ d
+        g[f"{name}_fcnet/linear_{i}/b"] = d.sum(axis=0)
+        if i > 0 or need_dx:
+            d = d @ p[f"{name}_fcnet/linear_{i}/w"].T
+            if i > 0:
+                d = d * (hs[i] > 0)
+    return d
+
+
+def _normal_head(out, L, c, smin):
+    """base.py:66-72: split, sigma = max(softplus(raw + c), sigma_min)."""
+    mu, raw = out[:, :L], out[:, L:]
+    sp = softplus(raw + c)
+    return mu, np.maximum(sp, smin), raw
+
+
+def _mvn_logprob(z, mu, sigma):
+    """MultivariateNormalDiag.log_prob (A7): computed from z, not eps."""
+    e = (z - mu) / sigma
+    return (-0.5 * e * e - 0.5 * LOG_2PI).sum(axis=1) - np.log(sigma).sum(axis=1)
+
+
+# --------------------------------------------------------------------------
+# forward
+# --------------------------------------------------------------------------
+def forward(model: int, d: Dims, p: Dict[str, np.ndarray], x: np.ndarray,
+            eps: np.ndarray, u: Optional[np.ndarray] = None, dtype=np.float64):
+    """gmvae.py:238-267 / vae.py:167-185.  x: bool/uint8 [B,D]; eps [B*S,L];
+    u [B*S,K] (GMVAE only).  Returns a cache dict (all intermediates)."""
+    p = {k: np.asarray(v, dtype) for k, v in p.items()}
+    xf = np.asarray(x).astype(dtype)                       # gmvae.py:86,104 / vae.py:75
+    B, S, L, K = x.shape[0], d.S, d.L, d.K
+    R = B * S
+    nl = len(d.hidden) + 1
+    c, smin = dtype(d.raw_sigma_bias), dtype(d.sigma_min)
+    eps = np.asarray(eps, dtype).reshape(R, L)
+    xr = np.repeat(xf, S, axis=0) if S > 1 else xf         # row r = b*S + s
+    C: Dict[str, object] = {"B": B, "R": R, "xf": xf, "xr": xr, "eps": eps}
+
+    if model == MODEL_GMVAE:
+        T = dtype(d.temperature)
+        u = np.asarray(u, dtype).reshape(R, K)
+        logits, hs_y = _mlp_fwd(p, "encoder_y", nl, xf)            # gmvae.py:238
+        g = -np.log(-np.log(u))                                    # A9 Gumbel
+        a = (np.repeat(logits, S, axis=0) + g) / T
+        y = np.exp(_log_softmax(a))                                # gmvae.py:240
+        lnpi = _log_softmax(logits)
+        pi = np.exp(lnpi)
+        nent_b = (pi * lnpi).sum(axis=1)                           # gmvae.py:262, utils.py:165-170
+        pp = y @ p["prior_gmm_fcnet/linear_0/w"] + p["prior_gmm_fcnet/linear_0/b"]  # gmvae.py:243
+        mu_p, sig_p, raw_p = _normal_head(pp, L, c, smin)
+        qp, hs_g = _mlp_fwd(p, "encoder_gmm", nl, np.concatenate([xr, y], axis=1))  # gmvae.py:246, base.py:66
+        C.update(logits=logits, hs_y=hs_y, y=y, pi=pi, lnpi=lnpi, nent_b=nent_b, pp=pp,
+                 mu_p=mu_p, sig_p=sig_p, raw_p=raw_p, hs_g=hs_g, gumbel=g)
+        enc_name = "encoder_gmm"
+    else:
+        qp, hs_e = _mlp_fwd(p, "encoder", nl, xf)                  # vae.py:170
+        if S > 1:
+            qp = np.repeat(qp, S, axis=0)
+        C.update(hs_e=hs_e)
+        nent_b = np.zeros(B, dtype)
+        enc_name = "encoder"
+    mu_q, sig_q, raw_q = _normal_head(qp, L, c, smin)
+    z = mu_q + sig_q * eps                                         # A6, gmvae.py:248 / vae.py:171
+    logq = _mvn_logprob(z, mu_q, sig_q)
+
+    if model == MODEL_GMVAE:
+        logp = _mvn_logprob(z, mu_p, sig_p)                        # gmvae.py:258
+    elif model == MODEL_VAE:
+        logp = (-0.5 * z * z - 0.5 * LOG_2PI).sum(axis=1)          # vae.py:247-250
+    else:                                                          # vae.py:240-244 MixtureSameFamily
+        loc, s = p["loc"], softplus(p["raw_scale_diag"])
+        lnw = _log_softmax(p["mixture_logits"])
+        t = (z[:, None, :] - loc[None]) / s[None]                  # [R,K,L]
+        lnN = (-0.5 * t * t - 0.5 * LOG_2PI).sum(axis=2) - np.log(s).sum(axis=1)[None]
+        comp = lnw[None] + lnN
+        m = comp.max(axis=1, keepdims=True)
+        logp = (m + np.log(np.exp(comp - m).sum(axis=1, keepdims=True)))[:, 0]
+        C.update(resp=np.exp(comp - logp[:, None]), gmp_t=t, gmp_s=s, lnw=lnw)
+
+    lam, hs_d = _mlp_fwd(p, "decoder", nl, z)                      # gmvae.py:251 / vae.py:174
+    lam = lam + dtype(d.gen_bias_init)                             # base.py:135
+    logpx = (xr * lam - softplus(lam)).sum(axis=1)                 # A8, gmvae.py:254
+
+    nent_r = np.repeat(nent_b, S) if S > 1 else nent_b
+    logw = logpx + logp - logq - nent_r                            # A15; S=1: -loss_b
+    if S == 1:
+        rw = np.ones(R, dtype)
+        bound = logw
+    else:
+        lw = logw.reshape(B, S)
+        m = lw.max(axis=1, keepdims=True)
+        bound = (m[:, 0] + np.log(np.exp(lw - m).sum(axis=1))) - math.log(S)
+        rw = np.exp(lw - (bound + math.log(S))[:, None]).reshape(R)
+    C.update(enc_name=enc_name, qp=qp, mu_q=mu_q, sig_q=sig_q, raw_q=raw_q, z=z, logq=logq,
+             logp=logp, lam=lam, hs_d=hs_d, logpx=logpx, logw=logw, rw=rw, bound=bound,
+             nll=-logpx.mean(), kl=(logq - logp).mean(), nent=nent_b.mean(),
+             loss=-bound.mean())
+    return C
+
+
+# --------------------------------------------------------------------------
+# backward (SURVEY.md 8(a) A12 closed form; checked against fp64 autograd in
+# tests/test_oracle.py)
+# --------------------------------------------------------------------------
+def loss_and_grads(model: int, d: Dims, p, x, eps, u=None, dtype=np.float64):
+    p = {k: np.asarray(v, dtype) for k, v in p.items()}
+    C = forward(model, d, p, x, eps, u, dtype)
+    B, R, S, L, K = C["B"], C["R"], d.S, d.L, d.K
+    nl = len(d.hidden) + 1
+    c, smin = dtype(d.raw_sigma_bias), dtype(d.sigma_min)
+    g: Dict[str, np.ndarray] = {}
+    w = (C["rw"] / B)[:, None]                                     # per-row weight incl. batch mean
+    z, mu_q, sig_q, eps_ = C["z"], C["mu_q"], C["sig_q"], C["eps"]
+
+    dlam = w * (sigmoid(C["lam"]) - C["xr"])
+    dz_dec = _mlp_bwd(p, g, "decoder", nl, C["hs_d"], dlam)
+
+    if model == MODEL_GMVAE:
+        t = (z - C["mu_p"]) / C["sig_p"]
+        dprior_z = w * t / C["sig_p"]
+    elif model == MODEL_VAE:
+        dprior_z = w * z
+    else:
+        r, t, s = C["resp"], C["gmp_t"], C["gmp_s"]                # [R,K], [R,K,L], [K,L]
+        dprior_z = w * (r[:, :, None] * t / s[None]).sum(axis=1)
+        wr = (w * r)[:, :, None]
+        g["loc"] = -(wr * t / s[None]).sum(axis=0)
+        ds = (wr * (1.0 - t * t) / s[None]).sum(axis=0)
+        g["raw_scale_diag"] = ds * sigmoid(p["raw_scale_diag"])
+        g["mixture_logits"] = -(w * (r - np.exp(C["lnw"])[None])).sum(axis=0)
+
+    dmu_q = dz_dec + dprior_z
+    dsig_q = dmu_q * eps_ - w / sig_q
+    draw_q = dsig_q * sigmoid(C["raw_q"] + c) * (softplus(C["raw_q"] + c) > smin)
+    dqp = np.concatenate([dmu_q, draw_q], axis=1)
+
+    if model == MODEL_GMVAE:
+        dmu_p = -w * t / C["sig_p"]
+        dsig_p = w * (1.0 - t * t) / C["sig_p"]
+        draw_p = dsig_p * sigmoid(C["raw_p"] + c) * (softplus(C["raw_p"] + c) > smin)
+        dpp = np.concatenate([dmu_p, draw_p], axis=1)
+        g["prior_gmm_fcnet/linear_0/w"] = C["y"].T @ dpp
+        g["prior_gmm_fcnet/linear_0/b"] = dpp.sum(axis=0)
+        dxy = _mlp_bwd(p, g, "encoder_gmm", nl, C["hs_g"], dqp)    # [R, D+K]
+        dy = dxy[:, d.D:] + dpp @ p["prior_gmm_fcnet/linear_0/w"].T
+        y = C["y"]
+        da = y * (dy - (y * dy).sum(axis=1, keepdims=True))
+        dl = (da / dtype(d.temperature)).reshape(B, S, K).sum(axis=1)
+        pi, lnpi = C["pi"], C["lnpi"]
+        dl = dl + (pi * (lnpi - C["nent_b"][:, None])) / B
+        _mlp_bwd(p, g, "encoder_y", nl, C["hs_y"], dl, need_dx=False)
+    else:
+        dq_b = dqp.reshape(B, S, 2 * L).sum(axis=1) if S > 1 else dqp
+        _mlp_bwd(p, g, "encoder", nl, C["hs_e"], dq_b, need_dx=False)
+    C["dlam"], C["dqp"] = dlam, dqp
+    return C, g
+
+
+# --------------------------------------------------------------------------
+# optimiser: TF1 AdamOptimizer (runners.py:181-183), SURVEY.md A13
+# --------------------------------------------------------------------------
+def adam_tf_step(theta, m, v, grad, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, dtype=np.float32):
+    """t is the 1-based step count AFTER increment.  eps is added to the
+    UN-corrected sqrt(v) (torch.optim.Adam differs)."""
+    dt = dtype
+    lr_t = dt(lr) * np.sqrt(dt(1) - dt(b2) ** dt(t)) / (dt(1) - dt(b1) ** dt(t))
+    m = dt(b1) * m + dt(1 - b1) * grad
+    v = dt(b2) * v + dt(1 - b2) * grad * grad
+    theta = theta - lr_t * m / (np.sqrt(v) + dt(eps))
+    return theta.astype(dt), m.astype(dt), v.astype(dt)
+
+
+def train_step(model, d, flat, m, v, t, x, eps, u=None, lr=1e-3, dtype=np.float32):
+    """One full reference step on the flat buffer: fwd + bwd + TF-Adam."""
+    p = unpack(model, d, flat)
+    C, g = loss_and_grads(model, d, p, x, eps, u, dtype)
+    gflat = pack(model, d, g, dtype)
+    flat, m, v = adam_tf_step(flat.astype(dtype), m, v, gflat, t, lr=lr, dtype=dtype)
+    return flat, m, v, C, gflat
+
+
+# --------------------------------------------------------------------------
+# synthetic inputs (SURVEY.md 8(d) / BASELINE.md section 4)
+# --------------------------------------------------------------------------
+def make_inputs(d: Dims, B: int, model: int = MODEL_GMVAE, seed_x=1234, seed_noise=42):
+    x = (np.random.default_rng(seed_x).random((B, d.D)) < 0.87).astype(np.uint8)
+    rn = np.random.default_rng(seed_noise)
+    eps = rn.standard_normal((B * d.S, d.L)).astype(np.float32)
+    u = rn.uniform(TINY_F32, 1.0, (B * d.S, d.K)).astype(np.float32)
+    u = np.clip(u, TINY_F32, np.nextafter(np.float32(1), np.float32(0)))
+    return x, eps, (u if model == MODEL_GMVAE else None)
+
+
+def flops_per_step(model: int, d: Dims, B: int) -> float:
+    """SURVEY.md A.1 FLOP rule: 2*(fwd + dW + dX MACs), x-input dX excluded."""
+    def mac(n_in, n_out):
+        dims = [n_in] + list(d.hidden) + [n_out]
+        return sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+    h0, S = d.hidden[0], d.S
+    if model == MODEL_GMVAE:
+        fwd = mac(d.D, d.K) + S * (d.K * 2 * d.L + mac(d.D + d.K, 2 * d.L) + mac(d.L, d.D))
+        dx = fwd - d.D * h0 * (1 + S)
+    else:
+        fwd = mac(d.D, 2 * d.L) + S * mac(d.L, d.D)
+        dx = fwd - d.D * h0
+    return 2.0 * B * (2 * fwd + dx)
+
+
+def cluster_acc(logits: np.ndarray, labels: np.ndarray, K: int) -> float:
+    """utils.py:173-191 (with utils.py:156-162 mode_tensor): argmax cluster ->
+    majority label -> match rate.  Ties in the mode: tf.unique_with_counts
+    keeps first-occurrence order and argmax takes the first maximum."""
+    preds = np.argmax(logits, axis=1)
+    real = np.zeros(len(preds), np.float32)
+    for k in range(K):
+        idx = preds == k
+        lab = labels[idx]
+        if lab.size == 0:
+            mode = 0.0
+        else:
+            uniq, first, cnt = np.unique(lab, return_index=True, return_counts=True)
+            order = np.argsort(first, kind="stable")
+            mode = float(uniq[order][np.argmax(cnt[order])])
+        real += idx.astype(np.float32) * mode
+    return float(np.mean(real == labels.astype(np.float32)))
