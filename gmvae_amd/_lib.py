@@ -1,0 +1,127 @@
+"""ctypes binding of libgmvae_hip.so (the C ABI declared in include/gmvae_hip.h).
+
+There is NO CPU fallback: if the shared library is missing this module raises,
+and every op that needs the GPU raises when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgmvae_hip.so")
+
+MAX_HIDDEN = 8
+TAIL = 8
+MODEL_VAE, MODEL_VAE_GMP, MODEL_GMVAE = 0, 1, 2
+MODEL_IDS = {"vae": MODEL_VAE, "vae_gmp": MODEL_VAE_GMP, "gmvae": MODEL_GMVAE}
+NET_ENCODER_Y, NET_PRIOR_GMM, NET_ENCODER_GMM, NET_DECODER, NET_ENCODER = range(5)
+
+ERRORS = {-1: "GMVAE_E_NULL", -2: "GMVAE_E_DIMS", -3: "GMVAE_E_MODEL", -4: "GMVAE_E_ALIGN",
+          -5: "GMVAE_E_NET", -6: "GMVAE_E_SMALL"}
+
+
+class GmvaeDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("D", C.c_int32), ("L", C.c_int32), ("K", C.c_int32), ("S", C.c_int32),
+                ("n_hidden", C.c_int32), ("hidden", C.c_int32 * MAX_HIDDEN),
+                ("sigma_min", C.c_float), ("raw_sigma_bias", C.c_float), ("temperature", C.c_float),
+                ("gen_bias_init", C.c_float)]
+
+
+class GmvaeParamEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("rows", C.c_int32), ("cols", C.c_int32), ("offset", C.c_uint64)]
+
+
+class GmvaeError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -m gmvae_amd.build` (or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, i32, f32 = C.c_void_p, C.c_uint64, C.c_int, C.c_float
+    dp = C.POINTER(GmvaeDims)
+    sigs = {
+        "gmvae_abi_version": ([], i32),
+        "gmvae_param_count": ([dp, i32, C.POINTER(u64), C.POINTER(u64)], i32),
+        "gmvae_param_layout": ([dp, i32, C.POINTER(GmvaeParamEntry), i32, C.POINTER(i32)], i32),
+        "gmvae_workspace_bytes": ([dp, i32, C.POINTER(u64)], i32),
+        "gmvae_step": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, u64, vp, vp], i32),
+        "gmvae_forward": ([dp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, u64, vp], i32),
+        "adam_tf_step": ([vp, vp, vp, vp, u64, f32, f32, f32, f32, u64, vp, f32, vp, vp], i32),
+        "gmvae_mlp_forward": ([dp, i32, i32, vp, i32, vp, i32, vp, vp, vp, vp], i32),
+        "gmvae_noise_fill": ([vp, u64, vp, u64, u64, u64, vp, vp], i32),
+        "gmvae_cluster_acc": ([vp, vp, i32, i32, i32, vp, vp, vp], i32),
+        "gmvae_gemm_test": ([vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+        "gmvae_step_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),
+    }
+    for name, (args, res) in sigs.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.argtypes = args
+        fn.restype = res
+    return lib, sorted(sigs)
+
+
+lib, EXPORTS = _load()
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise GmvaeError(f"{what}: {ERRORS.get(rc, rc)}")
+    raise GmvaeError(f"{what}: hipError_t {rc}")
+
+
+def make_dims(B, D, L, K, hidden, S=1, sigma_min=0.0, raw_sigma_bias=0.5, temperature=1.0, gen_bias_init=0.0):
+    hidden = list(hidden)
+    if len(hidden) > MAX_HIDDEN:
+        raise ValueError(f"at most {MAX_HIDDEN} hidden layers")
+    d = GmvaeDims()
+    d.B, d.D, d.L, d.K, d.S, d.n_hidden = int(B), int(D), int(L), int(K), int(S), len(hidden)
+    for i, h in enumerate(hidden):
+        d.hidden[i] = int(h)
+    d.sigma_min, d.raw_sigma_bias = float(sigma_min), float(raw_sigma_bias)
+    d.temperature, d.gen_bias_init = float(temperature), float(gen_bias_init)
+    return d
+
+
+def param_count(dims, model):
+    pp, pr = C.c_uint64(), C.c_uint64()
+    check(lib.gmvae_param_count(C.byref(dims), model, C.byref(pp), C.byref(pr)), "gmvae_param_count")
+    return pp.value, pr.value
+
+
+def param_layout(dims, model):
+    """[(name, (rows, cols), offset)] in the reference's variable-creation order."""
+    n = C.c_int()
+    check(lib.gmvae_param_layout(C.byref(dims), model, None, 0, C.byref(n)), "gmvae_param_layout")
+    arr = (GmvaeParamEntry * n.value)()
+    check(lib.gmvae_param_layout(C.byref(dims), model, arr, n.value, C.byref(n)), "gmvae_param_layout")
+    return [(e.name.decode(), (e.rows, e.cols), int(e.offset)) for e in arr]
+
+
+def workspace_bytes(dims, model):
+    b = C.c_uint64()
+    check(lib.gmvae_workspace_bytes(C.byref(dims), model, C.byref(b)), "gmvae_workspace_bytes")
+    return b.value
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise GmvaeError("no HIP device visible: gmvae_amd has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

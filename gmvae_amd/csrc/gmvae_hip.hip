@@ -1,0 +1,770 @@
+// libgmvae_hip.so -- C ABI (include/gmvae_hip.h) and the host-side schedule of
+// the VAE / VAE_GMP / GMVAE ELBO training step on gfx950.
+//
+// The step is a fixed sequence of "levels"; every level is ONE kernel launch:
+// either a grouped fp32-MFMA GEMM (gemm.hpp) that executes all independent
+// matrix products of that dependency level, or a row-local kernel
+// (kernels.hpp).  Nothing here allocates or synchronises; everything is
+// enqueued on the caller's stream and is hipGraph-capturable.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/gmvae_hip.h"
+#include "gemm.hpp"
+#include "kernels.hpp"
+
+using namespace gmvae;
+
+namespace {
+
+constexpr int MAXH = GMVAE_MAX_HIDDEN;
+constexpr int NS_MAX = 16;
+constexpr int MAX_LEVELS = 96;
+
+// ------------------------------------------------------------------ layout
+struct NetL {
+  int nl = 0;                 // number of Linear layers
+  int dim[MAXH + 2] = {0};    // dim[i] -> dim[i+1]
+  uint64_t w[MAXH + 1] = {0}, b[MAXH + 1] = {0};
+};
+struct Layout {
+  NetL ency, prior, encg, dec, enc;
+  uint64_t loc = 0, rawscale = 0, mixlog = 0, P_pad = 0, P_real = 0;
+  int n = 0;
+  GmvaeParamEntry e[64];
+};
+
+static uint64_t pad4(uint64_t n) { return (n + 3) / 4 * 4; }
+
+static void add_entry(Layout& L, const char* name, int rows, int cols, uint64_t& off_out) {
+  GmvaeParamEntry& e = L.e[L.n++];
+  snprintf(e.name, sizeof(e.name), "%s", name);
+  e.rows = rows;
+  e.cols = cols;
+  e.offset = L.P_pad;
+  off_out = L.P_pad;
+  L.P_real += (uint64_t)rows * cols;
+  L.P_pad += pad4((uint64_t)rows * cols);
+}
+
+static void add_net(Layout& L, NetL& net, const char* name, int n_in, const int* hidden, int nh, int n_out) {
+  net.nl = nh + 1;
+  net.dim[0] = n_in;
+  for (int i = 0; i < nh; ++i) net.dim[i + 1] = hidden[i];
+  net.dim[nh + 1] = n_out;
+  char buf[64];
+  for (int i = 0; i < net.nl; ++i) {
+    snprintf(buf, sizeof(buf), "%s_fcnet/linear_%d/w", name, i);
+    add_entry(L, buf, net.dim[i], net.dim[i + 1], net.w[i]);
+    snprintf(buf, sizeof(buf), "%s_fcnet/linear_%d/b", name, i);
+    add_entry(L, buf, 1, net.dim[i + 1], net.b[i]);
+  }
+}
+
+static int check_dims(const GmvaeDims* d, int model) {
+  if (!d) return GMVAE_E_NULL;
+  if (model < 0 || model > 2) return GMVAE_E_MODEL;
+  if (d->B < 1 || d->D < 1 || d->L < 1 || d->K < 1 || d->S < 1) return GMVAE_E_DIMS;
+  if (d->n_hidden < 0 || d->n_hidden > MAXH) return GMVAE_E_DIMS;
+  for (int i = 0; i < d->n_hidden; ++i)
+    if (d->hidden[i] < 1) return GMVAE_E_DIMS;
+  if (model == GMVAE_MODEL_VAE_GMP && (d->K > 64 || (2LL * d->K * (d->L | 1) + 64 + 4LL * 64 * d->L) * 4 > 150 * 1024))
+    return GMVAE_E_DIMS;
+  if ((long long)d->B * d->S > (1LL << 30)) return GMVAE_E_DIMS;
+  return 0;
+}
+
+// Variable-creation order of the reference: GMVAE: encoder_y,
+// prior_gmm, encoder_gmm, decoder (gmvae.py:238,243,246,251); VAE: prior
+// variables (vae.py:233-238), encoder, decoder.
+static void build_layout(const GmvaeDims& d, int model, Layout& L) {
+  if (model == GMVAE_MODEL_GMVAE) {
+    add_net(L, L.ency, "encoder_y", d.D, d.hidden, d.n_hidden, d.K);
+    add_net(L, L.prior, "prior_gmm", d.K, nullptr, 0, 2 * d.L);
+    add_net(L, L.encg, "encoder_gmm", d.D + d.K, d.hidden, d.n_hidden, 2 * d.L);
+    add_net(L, L.dec, "decoder", d.L, d.hidden, d.n_hidden, d.D);
+  } else {
+    if (model == GMVAE_MODEL_VAE_GMP) {
+      add_entry(L, "loc", d.K, d.L, L.loc);
+      add_entry(L, "raw_scale_diag", d.K, d.L, L.rawscale);
+      add_entry(L, "mixture_logits", 1, d.K, L.mixlog);
+    }
+    add_net(L, L.enc, "encoder", d.D, d.hidden, d.n_hidden, 2 * d.L);
+    add_net(L, L.dec, "decoder", d.L, d.hidden, d.n_hidden, d.D);
+  }
+}
+
+// --------------------------------------------------------------- workspace
+struct WS {
+  float *eps, *u;
+  float* he[MAXH + 2];   // enc_y (GMVAE) / encoder (VAE) activations, he[i] = input of layer i (i>=1), [B, dim[i]]
+  float* hg[MAXH + 2];   // encoder_gmm activations [R, dim[i]]
+  float* hd[MAXH + 2];   // decoder activations [R, dim[i]]
+  float *gx, *logits, *y, *nent, *pp, *qp, *z, *logq, *logp, *logpx, *logw, *rw, *resp, *g, *part;
+  float *dbuf[2], *dz, *dqp, *dpp, *dy, *dlogits, *dqb, *slabs, *gmp_part;
+  int32_t* cl_pred;
+  uint64_t bytes;
+};
+constexpr int GMP_PARTS = 64;
+
+static int num_splits(long long R) {
+  long long ns = R / 256;
+  if (ns < 1) ns = 1;
+  if (ns > NS_MAX) ns = NS_MAX;
+  const char* e = getenv("GMVAE_NSPLIT");
+  if (e && atoi(e) >= 1 && atoi(e) <= NS_MAX) ns = atoi(e);
+  return (int)ns;
+}
+
+static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS& w) {
+  uint64_t off = 0;
+  auto take = [&](uint64_t nfloats) -> float* {
+    float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr;
+    off += (nfloats * 4 + 255) / 256 * 256;
+    return p;
+  };
+  const uint64_t B = d.B, R = (uint64_t)d.B * d.S, K = d.K, Lz = d.L, D = d.D;
+  int maxh = 1;
+  for (int i = 0; i < d.n_hidden; ++i) maxh = d.hidden[i] > maxh ? d.hidden[i] : maxh;
+  memset(&w, 0, sizeof(w));
+  w.eps = take(pad4(R * Lz));
+  w.u = take(pad4(R * K));
+  const NetL& e = (model == GMVAE_MODEL_GMVAE) ? L.ency : L.enc;
+  for (int i = 1; i < e.nl; ++i) w.he[i] = take(B * e.dim[i]);
+  if (model == GMVAE_MODEL_GMVAE) {
+    for (int i = 1; i < L.encg.nl; ++i) w.hg[i] = take(R * L.encg.dim[i]);
+    w.gx = take(B * L.encg.dim[1]);
+    w.logits = take(B * K);
+    w.y = take(R * K);
+    w.nent = take(B);
+    w.pp = take(R * 2 * Lz);
+    w.dpp = take(R * 2 * Lz);
+    w.dy = take(R * K);
+    w.dlogits = take(B * K);
+    w.qp = take(R * 2 * Lz);
+  } else {
+    w.qp = take(B * 2 * Lz);
+    w.dqb = take(B * 2 * Lz);
+    if (model == GMVAE_MODEL_VAE_GMP) {
+      w.resp = take(R * K);
+      w.gmp_part = take((uint64_t)GMP_PARTS * (2 * pad4(K * Lz) + pad4(K)));
+    }
+  }
+  for (int i = 1; i < L.dec.nl; ++i) w.hd[i] = take(R * L.dec.dim[i]);
+  w.z = take(R * Lz);
+  w.logq = take(R); w.logp = take(R); w.logpx = take(R); w.logw = take(R); w.rw = take(R);
+  w.g = take(R * D);
+  w.part = take(R * ((D + 31) / 32));
+  w.dbuf[0] = take(R * maxh);
+  w.dbuf[1] = take(R * maxh);
+  w.dz = take(R * Lz);
+  w.dqp = take(R * 2 * Lz);
+  w.slabs = take((uint64_t)num_splits(R) * L.P_pad);
+  w.cl_pred = reinterpret_cast<int32_t*>(take(B));
+  w.bytes = off;
+}
+
+// ----------------------------------------------------------- GEMM building
+static Operand opnd(const void* p, int ld, int n_mn, bool u8, bool kc, int div = 1, bool ones = false) {
+  Operand o;
+  o.ptr = p; o.ld = ld; o.n_mn = n_mn; o.row_div = div;
+  o.is_u8 = u8; o.k_contig = kc; o.ones_row = ones;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  o.vec_ok = (ld % 4 == 0) && (a % (u8 ? 4 : 16) == 0);
+  return o;
+}
+static Problem blank() {
+  Problem p;
+  memset(&p, 0, sizeof(p));
+  p.nseg = 1; p.splits = 1; p.add_div = 1; p.x_div = 1; p.epi = EPI_STORE;
+  p.seg[0].a.row_div = p.seg[0].b.row_div = p.seg[1].a.row_div = p.seg[1].b.row_div = 1;
+  return p;
+}
+// C[M,N] = act(A[M,K] W[K,N] + bias)
+static Problem p_nn(const void* A, bool u8, int lda, const float* W, int ldw, int M, int N, int K, float* C,
+                    int ldc, const float* bias, bool relu) {
+  Problem p = blank();
+  p.M = M; p.N = N;
+  p.seg[0].a = opnd(A, lda, M, u8, true);
+  p.seg[0].b = opnd(W, ldw, N, false, false);
+  p.seg[0].K = K;
+  p.C = C; p.ldc = ldc; p.bias = bias; p.relu = relu;
+  return p;
+}
+// dX[M,N] = dY[M,K] W[N,K]^T  (W row-major [N rows, ldw])
+static Problem p_nt(const float* dY, int ldy, const float* W, int ldw, int M, int N, int K, float* C, int ldc,
+                    const float* mask, int ld_mask) {
+  Problem p = blank();
+  p.M = M; p.N = N;
+  p.seg[0].a = opnd(dY, ldy, M, false, true);
+  p.seg[0].b = opnd(W, ldw, N, false, true);
+  p.seg[0].K = K;
+  p.C = C; p.ldc = ldc; p.mask = mask; p.ld_mask = ld_mask;
+  return p;
+}
+// dW[in,out] (+ db as an extra ones row) = Act[rows,in]^T dY[rows,out], split-K over rows into slabs
+static Problem p_tn(const void* Act, bool u8, int lda, int a_div, const float* dY, int ldy, int n_in, int n_out,
+                    int rows, float* dW, float* db, int ns, long long slab_stride, const float* kscale) {
+  Problem p = blank();
+  p.M = n_in + (db ? 1 : 0); p.N = n_out;
+  p.seg[0].a = opnd(Act, lda, n_in, u8, false, a_div, db != nullptr);
+  p.seg[0].b = opnd(dY, ldy, n_out, false, false);
+  p.seg[0].K = rows;
+  p.seg[0].kscale = kscale;
+  p.C = dW; p.ldc = n_out; p.bias_row_out = db;
+  p.splits = ns; p.split_stride = slab_stride;
+  return p;
+}
+
+struct Prof {
+  int n = 0;
+  hipEvent_t ev[MAX_LEVELS + 1];
+  char name[MAX_LEVELS][48];
+  double flops[MAX_LEVELS];
+  bool active = false;
+};
+
+struct Ctx {
+  hipStream_t st;
+  Prof* prof = nullptr;
+  int err = 0;
+  int force_cfg = -1;
+  void mark(const char* name, double flops) {
+    if (!prof || !prof->active || prof->n >= MAX_LEVELS) return;
+    snprintf(prof->name[prof->n], sizeof(prof->name[0]), "%s", name);
+    prof->flops[prof->n] = flops;
+    prof->n++;
+    hipEventRecord(prof->ev[prof->n], st);
+  }
+  void check() {
+    if (!err) {
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) err = (int)e;
+    }
+  }
+};
+
+struct Group {
+  Launch L;
+  Group() { L.nprob = 0; }
+  void add(const Problem& p) { if (L.nprob < MAXP) L.p[L.nprob++] = p; }
+};
+
+template <class C>
+static int tile_up(Launch& L) {
+  int t = 0;
+  for (int i = 0; i < L.nprob; ++i) {
+    Problem& p = L.p[i];
+    p.tiles_m = (p.M + C::BM - 1) / C::BM;
+    p.tiles_n = (p.N + C::BN - 1) / C::BN;
+    p.tile_begin = t;
+    p.nparts = p.tiles_n;
+    t += p.tiles_m * p.tiles_n * p.splits;
+  }
+  return t;
+}
+
+// returns the chosen tile configuration (0 small, 1 medium, 2 large)
+static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1) {
+  if (g.L.nprob == 0) return 0;
+  if (cfg < 0) cfg = cx.force_cfg;
+  if (cfg < 0) {
+    Launch t = g.L;
+    if (tile_up<CfgL>(t) >= 192) cfg = 2;
+    else if (tile_up<CfgM>(t) >= 160) cfg = 1;
+    else cfg = 0;
+  }
+  double fl = 0;
+  for (int i = 0; i < g.L.nprob; ++i)
+    for (int s = 0; s < g.L.p[i].nseg; ++s) fl += 2.0 * g.L.p[i].M * g.L.p[i].N * g.L.p[i].seg[s].K;
+  int tiles;
+  if (cfg == 2) {
+    tiles = tile_up<CfgL>(g.L);
+    hipLaunchKernelGGL(gemm_grouped<CfgL>, dim3(tiles), dim3(kThreads), 0, cx.st, g.L);
+  } else if (cfg == 1) {
+    tiles = tile_up<CfgM>(g.L);
+    hipLaunchKernelGGL(gemm_grouped<CfgM>, dim3(tiles), dim3(kThreads), 0, cx.st, g.L);
+  } else {
+    tiles = tile_up<CfgS>(g.L);
+    hipLaunchKernelGGL(gemm_grouped<CfgS>, dim3(tiles), dim3(kThreads), 0, cx.st, g.L);
+  }
+  cx.check();
+  cx.mark(name, fl);
+  return cfg;
+}
+static int cfg_bn(int cfg) { return cfg == 2 ? CfgL::BN : (cfg == 1 ? CfgM::BN : CfgS::BN); }
+
+static int grid_for(long long items, int per_block, int cap = 4096) {
+  long long g = (items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+// -------------------------------------------------------------- the step
+struct StepArgs {
+  const GmvaeDims* d;
+  int model;
+  const uint8_t* x;
+  const float *eps, *u, *params;
+  float* grads;        // [P_pad + TAIL] (backward) or nullptr
+  float* tail;         // forward-only tail destination
+  float *row_terms, *z_out, *y_out, *logits_out;
+  void* workspace;
+  uint64_t seed, step;
+  uint64_t* step_dev;
+  bool backward;
+};
+
+static void rowk(Ctx& cx, const char* name) {
+  cx.check();
+  cx.mark(name, 0);
+}
+
+static int run_step(Ctx& cx, const StepArgs& a) {
+  const GmvaeDims& d = *a.d;
+  const int model = a.model;
+  Layout L;
+  build_layout(d, model, L);
+  WS w;
+  carve(d, model, L, a.workspace, w);
+  const int B = d.B, S = d.S, R = B * S, K = d.K, Lz = d.L, D = d.D;
+  const float* P = a.params;
+  const bool gm = model == GMVAE_MODEL_GMVAE;
+  const float c = d.raw_sigma_bias, smin = d.sigma_min;
+  hipStream_t st = cx.st;
+
+  // ---- noise (fast mode): Philox in one launch for eps and u
+  const float* eps = a.eps;
+  const float* u = a.u;
+  if (!eps || (gm && !u)) {
+    float* ge = eps ? nullptr : w.eps;
+    float* gu = (gm && !u) ? w.u : nullptr;
+    const uint64_t ne = ge ? (uint64_t)R * Lz : 0, nu = gu ? (uint64_t)R * K : 0;
+    const uint64_t q = (ne + 3) / 4 + (nu + 3) / 4;
+    hipLaunchKernelGGL(noise_fill, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, ge, ne, gu, nu, a.seed,
+                       a.step, a.step_dev);
+    rowk(cx, "noise_fill");
+    if (ge) eps = ge;
+    if (gu) u = gu;
+  }
+
+  // ================================ forward ================================
+  const NetL& E = gm ? L.ency : L.enc;
+  {  // first layers over the uint8 batch: enc_y layer 0 and the x-part of enc_gmm layer 0
+    Group g;
+    float* out = (E.nl == 1) ? (gm ? w.logits : w.qp) : w.he[1];
+    g.add(p_nn(a.x, true, D, P + E.w[0], E.dim[1], B, E.dim[1], D, out, E.dim[1], P + E.b[0], E.nl > 1));
+    if (gm)
+      g.add(p_nn(a.x, true, D, P + L.encg.w[0], L.encg.dim[1], B, L.encg.dim[1], D, w.gx, L.encg.dim[1], nullptr,
+                 false));
+    launch_group(cx, g, "fwd_x_first_layers");
+  }
+  for (int i = 1; i < E.nl; ++i) {
+    Group g;
+    float* out = (i == E.nl - 1) ? (gm ? w.logits : w.qp) : w.he[i + 1];
+    g.add(p_nn(w.he[i], false, E.dim[i], P + E.w[i], E.dim[i + 1], B, E.dim[i + 1], E.dim[i], out, E.dim[i + 1],
+               P + E.b[i], i < E.nl - 1));
+    launch_group(cx, g, gm ? "fwd_enc_y" : "fwd_enc");
+  }
+  if (gm) {
+    hipLaunchKernelGGL(y_head_fwd, dim3(grid_for(R, 4)), dim3(256), 0, st, w.logits, u, w.y, w.nent, R, S, K,
+                       1.f / d.temperature);
+    rowk(cx, "y_head_fwd");
+    const NetL& G = L.encg;
+    {
+      Group g;
+      Problem p = p_nn(w.y, false, K, P + G.w[0] + (uint64_t)D * G.dim[1], G.dim[1], R, G.dim[1], K,
+                       (G.nl == 1) ? w.qp : w.hg[1], G.dim[1], P + G.b[0], G.nl > 1);
+      p.addsrc = w.gx; p.ld_add = G.dim[1]; p.add_div = S;
+      g.add(p);
+      g.add(p_nn(w.y, false, K, P + L.prior.w[0], 2 * Lz, R, 2 * Lz, K, w.pp, 2 * Lz, P + L.prior.b[0], false));
+      launch_group(cx, g, "fwd_y_layers");
+    }
+    for (int i = 1; i < G.nl; ++i) {
+      Group g;
+      g.add(p_nn(w.hg[i], false, G.dim[i], P + G.w[i], G.dim[i + 1], R, G.dim[i + 1], G.dim[i],
+                 (i == G.nl - 1) ? w.qp : w.hg[i + 1], G.dim[i + 1], P + G.b[i], i < G.nl - 1));
+      launch_group(cx, g, "fwd_enc_gmm");
+    }
+  }
+  const int prior = gm ? PRIOR_COND : (model == GMVAE_MODEL_VAE ? PRIOR_STD : PRIOR_GMP);
+  const int qp_div = gm ? 1 : S;
+  hipLaunchKernelGGL(z_head_fwd, dim3(grid_for(R, 4)), dim3(256), 0, st, w.qp, qp_div, w.pp, eps, w.z, w.logq,
+                     w.logp, R, Lz, prior, c, smin);
+  rowk(cx, "z_head_fwd");
+  if (prior == PRIOR_GMP) {
+    int Kp = 1;
+    while (Kp < K) Kp <<= 1;
+    const int nw = 4, rpw = 64 / Kp;
+    const size_t sh = (size_t)(2 * K * (Lz | 1) + 64 + nw * rpw * Lz) * sizeof(float);
+    hipLaunchKernelGGL(mixture_logprob_lse, dim3(grid_for(R, nw * rpw, 1024)), dim3(64 * nw), sh, st, w.z,
+                       P + L.loc, P + L.rawscale, P + L.mixlog, w.logp, w.resp, R, Lz, K, Kp);
+    rowk(cx, "mixture_logprob_lse");
+  }
+  int nparts = 1;
+  const NetL& Dn = L.dec;
+  for (int i = 0; i < Dn.nl; ++i) {
+    Group g;
+    const float* in = (i == 0) ? w.z : w.hd[i];
+    if (i < Dn.nl - 1) {
+      g.add(p_nn(in, false, Dn.dim[i], P + Dn.w[i], Dn.dim[i + 1], R, Dn.dim[i + 1], Dn.dim[i], w.hd[i + 1],
+                 Dn.dim[i + 1], P + Dn.b[i], true));
+      launch_group(cx, g, "fwd_dec");
+    } else {  // logits -> Bernoulli log-prob partials + (sigmoid(logit) - x)
+      Problem p = p_nn(in, false, Dn.dim[i], P + Dn.w[i], D, R, D, Dn.dim[i], a.backward ? w.g : nullptr, D,
+                       P + Dn.b[i], false);
+      p.epi = EPI_BERNOULLI;
+      p.addconst = d.gen_bias_init;
+      p.x = a.x; p.ldx = D; p.x_div = S; p.part = w.part;
+      g.add(p);
+      const int bn = cfg_bn(launch_group(cx, g, "fwd_dec_bernoulli"));
+      nparts = (D + bn - 1) / bn;
+    }
+  }
+  hipLaunchKernelGGL(row_terms, dim3(grid_for(R, 256, 1 << 22)), dim3(256), 0, st, w.part, nparts, w.logq, w.logp,
+                     gm ? w.nent : (const float*)nullptr, S, w.logpx, w.logw, a.row_terms, R);
+  rowk(cx, "row_terms");
+  float* tail = a.backward ? a.grads + L.P_pad : a.tail;
+  const float* rwS = (S > 1 && a.backward) ? w.rw : nullptr;
+  hipLaunchKernelGGL(loss_tail, dim3(1), dim3(1024), 0, st, w.logw, w.logpx, w.logq, w.logp,
+                     gm ? w.nent : (const float*)nullptr, (S > 1 && a.backward) ? w.rw : (float*)nullptr, tail, B, S,
+                     a.step_dev);
+  rowk(cx, "loss_tail");
+  if (a.z_out) hipMemcpyAsync(a.z_out, w.z, (size_t)R * Lz * 4, hipMemcpyDeviceToDevice, st);
+  if (a.y_out && gm) hipMemcpyAsync(a.y_out, w.y, (size_t)R * K * 4, hipMemcpyDeviceToDevice, st);
+  if (a.logits_out && gm) hipMemcpyAsync(a.logits_out, w.logits, (size_t)B * K * 4, hipMemcpyDeviceToDevice, st);
+  if (!a.backward) return cx.err;
+
+  // ================================ backward ===============================
+  const int NS = num_splits(R);
+  const long long PP = (long long)L.P_pad;
+  float* sl = w.slabs;
+  int pb = 0;
+  const float* dcur = w.g;
+  for (int i = Dn.nl - 1; i >= 0; --i) {   // decoder: dW_i (+db_i) and dX_i in one launch
+    Group g;
+    const bool top = (i == Dn.nl - 1);
+    const float* act = (i == 0) ? w.z : w.hd[i];
+    g.add(p_tn(act, false, Dn.dim[i], 1, dcur, Dn.dim[i + 1], Dn.dim[i], Dn.dim[i + 1], R, sl + Dn.w[i], sl + Dn.b[i],
+               NS, PP, top ? rwS : nullptr));
+    float* out = (i == 0) ? w.dz : w.dbuf[pb];
+    Problem p = p_nt(dcur, Dn.dim[i + 1], P + Dn.w[i], Dn.dim[i + 1], R, Dn.dim[i], Dn.dim[i + 1], out, Dn.dim[i],
+                     (i > 0) ? w.hd[i] : nullptr, Dn.dim[i]);
+    p.rowscale = top ? rwS : nullptr;
+    g.add(p);
+    launch_group(cx, g, top ? "bwd_dec_top" : "bwd_dec");
+    dcur = out;
+    pb ^= 1;
+  }
+  hipLaunchKernelGGL(z_head_bwd, dim3(grid_for(R, 4)), dim3(256), 0, st, w.dz, w.qp, qp_div, w.pp, eps, w.z, rwS,
+                     w.resp, P + L.loc, P + L.rawscale, w.dqp, w.dpp, R, Lz, K, prior, c, smin);
+  rowk(cx, "z_head_bwd");
+
+  if (gm) {
+    const NetL& G = L.encg;
+    bool prior_done = false;
+    auto prior_dw = [&]() {
+      return p_tn(w.y, false, K, 1, w.dpp, 2 * Lz, K, 2 * Lz, R, sl + L.prior.w[0], sl + L.prior.b[0], NS, PP, nullptr);
+    };
+    dcur = w.dqp;
+    for (int i = G.nl - 1; i >= 1; --i) {
+      Group g;
+      g.add(p_tn(w.hg[i], false, G.dim[i], 1, dcur, G.dim[i + 1], G.dim[i], G.dim[i + 1], R, sl + G.w[i], sl + G.b[i],
+                 NS, PP, nullptr));
+      float* out = w.dbuf[pb];
+      g.add(p_nt(dcur, G.dim[i + 1], P + G.w[i], G.dim[i + 1], R, G.dim[i], G.dim[i + 1], out, G.dim[i], w.hg[i],
+                 G.dim[i]));
+      if (!prior_done) { g.add(prior_dw()); prior_done = true; }
+      launch_group(cx, g, "bwd_enc_gmm");
+      dcur = out;
+      pb ^= 1;
+    }
+    {  // layer 0 of enc_gmm: input is concat(x, y) -- x rows need no gradient
+      Group g;
+      const float* Wy = P + G.w[0] + (uint64_t)D * G.dim[1];
+      g.add(p_tn(a.x, true, D, S, dcur, G.dim[1], D, G.dim[1], R, sl + G.w[0], sl + G.b[0], NS, PP, nullptr));
+      g.add(p_tn(w.y, false, K, 1, dcur, G.dim[1], K, G.dim[1], R, sl + G.w[0] + (uint64_t)D * G.dim[1], nullptr, NS,
+                 PP, nullptr));
+      Problem p = p_nt(dcur, G.dim[1], Wy, G.dim[1], R, K, G.dim[1], w.dy, K, nullptr, 0);
+      p.nseg = 2;                                   // dy = d_g0 Wg0[D:,:]^T + d_prior Wp^T
+      p.seg[1].a = opnd(w.dpp, 2 * Lz, R, false, true);
+      p.seg[1].b = opnd(P + L.prior.w[0], 2 * Lz, K, false, true);
+      p.seg[1].K = 2 * Lz;
+      p.seg[1].kscale = nullptr;
+      g.add(p);
+      if (!prior_done) { g.add(prior_dw()); prior_done = true; }
+      launch_group(cx, g, "bwd_enc_gmm_l0");
+    }
+    hipLaunchKernelGGL(y_head_bwd, dim3(grid_for(B, 4)), dim3(256), 0, st, w.logits, w.y, w.dy, w.nent, w.dlogits, B,
+                       S, K, 1.f / d.temperature);
+    rowk(cx, "y_head_bwd");
+    dcur = w.dlogits;
+  } else {
+    if (model == GMVAE_MODEL_VAE_GMP) {
+      hipLaunchKernelGGL(gmp_param_bwd, dim3(GMP_PARTS), dim3(256), 0, st, w.z, w.resp, rwS, P + L.loc,
+                         P + L.rawscale, P + L.mixlog, w.gmp_part, R, Lz, K, (int)pad4((uint64_t)K * Lz));
+      rowk(cx, "gmp_param_bwd");
+    }
+    if (S > 1) {
+      hipLaunchKernelGGL(sum_over_s, dim3(grid_for((long long)B * 2 * Lz, 256, 1 << 22)), dim3(256), 0, st, w.dqp,
+                         w.dqb, B, S, 2 * Lz);
+      rowk(cx, "sum_over_s");
+      dcur = w.dqb;
+    } else {
+      dcur = w.dqp;
+    }
+  }
+  for (int i = E.nl - 1; i >= 0; --i) {   // enc_y (GMVAE) / encoder (VAE): rows = B
+    Group g;
+    const void* act = (i == 0) ? (const void*)a.x : (const void*)w.he[i];
+    g.add(p_tn(act, i == 0, E.dim[i], 1, dcur, E.dim[i + 1], E.dim[i], E.dim[i + 1], B, sl + E.w[i], sl + E.b[i], NS,
+               PP, nullptr));
+    float* out = nullptr;
+    if (i > 0) {
+      out = w.dbuf[pb];
+      g.add(p_nt(dcur, E.dim[i + 1], P + E.w[i], E.dim[i + 1], B, E.dim[i], E.dim[i + 1], out, E.dim[i], w.he[i],
+                 E.dim[i]));
+    }
+    launch_group(cx, g, i == 0 ? "bwd_enc_l0" : "bwd_enc");
+    dcur = out;
+    pb ^= 1;
+  }
+  {
+    const bool gmp = model == GMVAE_MODEL_VAE_GMP;
+    const int KLp = (int)pad4((uint64_t)K * Lz);
+    hipLaunchKernelGGL(finalize_grads, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, sl, NS, PP, a.grads,
+                       gmp ? w.gmp_part : (const float*)nullptr, GMP_PARTS, gmp ? 2 * KLp + (int)pad4(K) : 0,
+                       (long long)L.loc);
+    rowk(cx, "finalize_grads");
+  }
+  return cx.err;
+}
+
+static int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// ================================ C ABI ====================================
+extern "C" {
+
+int gmvae_abi_version(void) { return GMVAE_ABI_VERSION; }
+
+int gmvae_param_count(const GmvaeDims* dims, int model, uint64_t* P_padded, uint64_t* P_real) {
+  if (int e = check_dims(dims, model)) return e;
+  Layout L;
+  build_layout(*dims, model, L);
+  if (P_padded) *P_padded = L.P_pad;
+  if (P_real) *P_real = L.P_real;
+  return 0;
+}
+
+int gmvae_param_layout(const GmvaeDims* dims, int model, GmvaeParamEntry* out, int max_entries, int* n_entries) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!n_entries) return GMVAE_E_NULL;
+  Layout L;
+  build_layout(*dims, model, L);
+  *n_entries = L.n;
+  if (out) {
+    if (max_entries < L.n) return GMVAE_E_SMALL;
+    memcpy(out, L.e, sizeof(GmvaeParamEntry) * L.n);
+  }
+  return 0;
+}
+
+int gmvae_workspace_bytes(const GmvaeDims* dims, int model, uint64_t* bytes) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!bytes) return GMVAE_E_NULL;
+  Layout L;
+  build_layout(*dims, model, L);
+  WS w;
+  carve(*dims, model, L, nullptr, w);
+  *bytes = w.bytes;
+  return 0;
+}
+
+int gmvae_step(const GmvaeDims* dims, int model, const uint8_t* x, const float* eps, const float* u,
+               const float* params, float* grads, void* workspace, uint64_t seed, uint64_t step, uint64_t* step_dev,
+               void* stream) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!x || !params || !grads || !workspace) return GMVAE_E_NULL;
+  if (!aligned16(params) || !aligned16(grads) || !aligned16(workspace) || (eps && !aligned16(eps)) ||
+      (u && !aligned16(u)))
+    return GMVAE_E_ALIGN;
+  Ctx cx;
+  cx.st = static_cast<hipStream_t>(stream);
+  const char* fc = getenv("GMVAE_FORCE_CFG");
+  if (fc) cx.force_cfg = atoi(fc);
+  StepArgs a = {dims, model, x, eps, u, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, seed, step,
+                step_dev, true};
+  return run_step(cx, a);
+}
+
+int gmvae_forward(const GmvaeDims* dims, int model, const uint8_t* x, const float* eps, const float* u,
+                  const float* params, float* tail, float* row_terms, float* z_out, float* y_out, float* logits_out,
+                  void* workspace, uint64_t seed, uint64_t step, void* stream) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!x || !params || !tail || !workspace) return GMVAE_E_NULL;
+  if (!aligned16(params) || !aligned16(workspace) || (eps && !aligned16(eps)) || (u && !aligned16(u)))
+    return GMVAE_E_ALIGN;
+  Ctx cx;
+  cx.st = static_cast<hipStream_t>(stream);
+  StepArgs a = {dims, model, x, eps, u, params, nullptr, tail, row_terms, z_out, y_out, logits_out, workspace, seed,
+                step, nullptr, false};
+  return run_step(cx, a);
+}
+
+int adam_tf_step(float* params, float* m, float* v, const float* grads, uint64_t P, float lr, float beta1,
+                 float beta2, float epsilon, uint64_t t, const uint64_t* t_dev, float grad_scale,
+                 const float* grad_scale_dev, void* stream) {
+  if (!params || !m || !v || !grads) return GMVAE_E_NULL;
+  if (P == 0) return GMVAE_E_DIMS;
+  if (!aligned16(params) || !aligned16(m) || !aligned16(v) || !aligned16(grads)) return GMVAE_E_ALIGN;
+  hipLaunchKernelGGL(adam_tf, dim3((unsigned)(((P + 3) / 4 + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), params, m, v, grads, (long long)P, lr, beta1, beta2, epsilon, t,
+                     t_dev, grad_scale, grad_scale_dev);
+  return (int)hipGetLastError();
+}
+
+int gmvae_noise_fill(float* eps, uint64_t n_eps, float* u, uint64_t n_u, uint64_t seed, uint64_t step,
+                     const uint64_t* step_dev, void* stream) {
+  if ((!eps && n_eps) || (!u && n_u)) return GMVAE_E_NULL;
+  const uint64_t q = (n_eps + 3) / 4 + (n_u + 3) / 4;
+  if (q == 0) return 0;
+  hipLaunchKernelGGL(noise_fill, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     eps, n_eps, u, n_u, seed, step, step_dev);
+  return (int)hipGetLastError();
+}
+
+int gmvae_mlp_forward(const GmvaeDims* dims, int model, int net, const void* in, int in_is_u8, const float* in2,
+                      int rows, const float* params, float* out, void* workspace, void* stream) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!in || !params || !out || !workspace) return GMVAE_E_NULL;
+  if (rows < 1) return GMVAE_E_DIMS;
+  GmvaeDims d = *dims;
+  d.B = rows;
+  d.S = 1;
+  Layout L;
+  build_layout(d, model, L);
+  WS w;
+  carve(d, model, L, workspace, w);
+  const NetL* N = nullptr;
+  const bool gm = model == GMVAE_MODEL_GMVAE;
+  switch (net) {
+    case GMVAE_NET_ENCODER_Y: N = gm ? &L.ency : nullptr; break;
+    case GMVAE_NET_PRIOR_GMM: N = gm ? &L.prior : nullptr; break;
+    case GMVAE_NET_ENCODER_GMM: N = gm ? &L.encg : nullptr; break;
+    case GMVAE_NET_DECODER: N = &L.dec; break;
+    case GMVAE_NET_ENCODER: N = gm ? nullptr : &L.enc; break;
+    default: return GMVAE_E_NET;
+  }
+  if (!N) return GMVAE_E_NET;
+  if (net == GMVAE_NET_ENCODER_GMM && !in2) return GMVAE_E_NULL;
+  Ctx cx;
+  cx.st = static_cast<hipStream_t>(stream);
+  float** hbuf = (net == GMVAE_NET_DECODER) ? w.hd : (net == GMVAE_NET_ENCODER_GMM ? w.hg : w.he);
+  const float* P = params;
+  for (int i = 0; i < N->nl; ++i) {
+    const bool last = i == N->nl - 1;
+    float* o = last ? out : hbuf[i + 1];
+    if (i == 0 && net == GMVAE_NET_ENCODER_GMM) {
+      const int D = d.D, K = d.K, H = N->dim[1];
+      Group g0;
+      g0.add(p_nn(in, in_is_u8 != 0, D, P + N->w[0], H, rows, H, D, w.gx, H, nullptr, false));
+      launch_group(cx, g0, "mlp_x");
+      Group g1;
+      Problem p = p_nn(in2, false, K, P + N->w[0] + (uint64_t)D * H, H, rows, H, K, o, H, P + N->b[0], !last);
+      p.addsrc = w.gx; p.ld_add = H; p.add_div = 1;
+      g1.add(p);
+      launch_group(cx, g1, "mlp_y");
+    } else {
+      Group g;
+      const void* a = (i == 0) ? in : (const void*)hbuf[i];
+      Problem p = p_nn(a, i == 0 && in_is_u8, N->dim[i], P + N->w[i], N->dim[i + 1], rows, N->dim[i + 1], N->dim[i],
+                       o, N->dim[i + 1], P + N->b[i], !last);
+      if (last && net == GMVAE_NET_DECODER) p.addconst = d.gen_bias_init;
+      g.add(p);
+      launch_group(cx, g, "mlp");
+    }
+  }
+  return cx.err;
+}
+
+int gmvae_cluster_acc(const float* logits, const int64_t* labels, int B, int K, int n_labels, int32_t* scratch,
+                      float* acc_out, void* stream) {
+  if (!logits || !labels || !scratch || !acc_out) return GMVAE_E_NULL;
+  if (B < 1 || K < 1 || K > 256 || n_labels < 1) return GMVAE_E_DIMS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int32_t* hist = scratch;
+  int32_t* pred = scratch + (size_t)K * n_labels;
+  hipError_t e = hipMemsetAsync(hist, 0, sizeof(int32_t) * K * n_labels, st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(cluster_hist, dim3((B + 255) / 256), dim3(256), 0, st, logits, labels, B, K, n_labels, hist, pred);
+  hipLaunchKernelGGL(cluster_match, dim3(1), dim3(1024), 0, st, hist, pred, labels, B, K, n_labels, acc_out);
+  return (int)hipGetLastError();
+}
+
+int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bias, float* C, int M, int N, int K,
+                    int trans, int relu, int cfg, int splitk, void* stream) {
+  if (!A || !W || !C) return GMVAE_E_NULL;
+  if (M < 1 || N < 1 || K < 1 || splitk < 1 || splitk > NS_MAX) return GMVAE_E_DIMS;
+  Ctx cx;
+  cx.st = static_cast<hipStream_t>(stream);
+  Group g;
+  if (trans == 0) {
+    g.add(p_nn(A, a_is_u8 != 0, K, W, N, M, N, K, C, N, bias, relu != 0));
+  } else if (trans == 1) {
+    g.add(p_nt(static_cast<const float*>(A), K, W, K, M, N, K, C, N, nullptr, 0));
+  } else {  // TN: A given as [K rows, M], W as dY [K rows, N]; output [splitk][M+1][N] when bias (any non-null) requested
+    Problem p = p_tn(A, a_is_u8 != 0, M, 1, W, N, M, N, K, C, bias ? C + (size_t)M * N : nullptr, splitk,
+                     (long long)(M + 1) * N, nullptr);
+    g.add(p);
+  }
+  launch_group(cx, g, "gemm_test", cfg);
+  return cx.err;
+}
+
+int gmvae_step_profile(const GmvaeDims* dims, int model, const uint8_t* x, const float* eps, const float* u,
+                       const float* params, float* grads, void* workspace, uint64_t seed, int iters, int max_levels,
+                       int* n_levels, char* names, float* usec, double* flops, void* stream) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!x || !params || !grads || !workspace || !n_levels || !names || !usec || !flops) return GMVAE_E_NULL;
+  if (iters < 1) return GMVAE_E_DIMS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Prof* pr = new Prof();
+  for (int i = 0; i <= MAX_LEVELS; ++i) hipEventCreate(&pr->ev[i]);
+  double acc[MAX_LEVELS] = {0};
+  int rc = 0;
+  for (int it = 0; it < iters && rc == 0; ++it) {
+    Ctx cx;
+    cx.st = st;
+    cx.prof = pr;
+    pr->n = 0;
+    pr->active = true;
+    hipEventRecord(pr->ev[0], st);
+    StepArgs a = {dims, model, x, eps, u, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, seed,
+                  (uint64_t)it, nullptr, true};
+    rc = run_step(cx, a);
+    hipStreamSynchronize(st);
+    for (int i = 0; i < pr->n; ++i) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, pr->ev[i], pr->ev[i + 1]);
+      acc[i] += ms * 1000.0;
+    }
+  }
+  const int n = pr->n < max_levels ? pr->n : max_levels;
+  *n_levels = n;
+  for (int i = 0; i < n; ++i) {
+    memcpy(names + (size_t)i * 48, pr->name[i], 48);
+    usec[i] = (float)(acc[i] / iters);
+    flops[i] = pr->flops[i];
+  }
+  for (int i = 0; i <= MAX_LEVELS; ++i) hipEventDestroy(pr->ev[i]);
+  delete pr;
+  return rc;
+}
+
+}  // extern "C"

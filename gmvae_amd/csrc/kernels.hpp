@@ -1,0 +1,538 @@
+// Row-local kernels of the ELBO step (everything that is not a GEMM).
+// Each kernel cites the reference arithmetic it replaces.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm.hpp"
+
+namespace gmvae {
+
+constexpr float kLog2Pi = 1.8378770664093453f;
+constexpr float kTiny = 1.17549435e-38f;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------- Philox
+// Philox4x32-10 (Salmon et al. 2011), counter = (index, stream, step), key = seed.
+// Stands in for tf.random_normal / tf.random_uniform inside the TFP samplers
+// (scripts/gmvae.py:240,248; scripts/vae.py:171) -- statistically, not bitwise.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ float u01(uint32_t b) { return (float)(b >> 8) * 5.9604644775390625e-8f; }  // [0,1)
+
+// eps ~ N(0,1) (Box-Muller), u ~ U[tiny,1).  One thread -> 4 values.
+__global__ void noise_fill(float* eps, uint64_t n_eps, float* u, uint64_t n_u, uint64_t seed, uint64_t step,
+                           const uint64_t* step_dev) {
+  if (step_dev) step = *step_dev;
+  const uint64_t q_eps = (n_eps + 3) / 4, q_u = (n_u + 3) / 4;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= q_eps + q_u) return;
+  const bool is_u = i >= q_eps;
+  const uint64_t q = is_u ? i - q_eps : i;
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32) | (is_u ? 0x80000000u : 0u), (uint32_t)step, (uint32_t)(step >> 32)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  float o[4];
+  if (is_u) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaxf(u01(c[j]), kTiny);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      const float r = sqrtf(-2.f * logf(1.f - u01(c[j])));       // 1-u in (0,1]
+      float sn, cs;
+      sincosf(6.283185307179586f * u01(c[j + 1]), &sn, &cs);
+      o[j] = r * cs;
+      o[j + 1] = r * sn;
+    }
+  }
+  float* dst = is_u ? u : eps;
+  const uint64_t n = is_u ? n_u : n_eps;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (q * 4 + j < n) dst[q * 4 + j] = o[j];
+}
+
+// ------------------------------------------------ q(y|x): Gumbel-softmax head
+// RelaxedOneHotCategorical.sample (scripts/base.py:206-209, gmvae.py:240):
+//   g = -log(-log u); y = softmax((logits + g)/T)
+// and utils.entropy(logits, softmax(logits)) (scripts/utils.py:165-170,
+// gmvae.py:262-263): nent_b = sum_k pi_k log pi_k.
+// One wave per row r; lanes stride over K (K <= 64 is a single pass).
+__global__ void y_head_fwd(const float* __restrict__ logits, const float* __restrict__ u, float* __restrict__ y,
+                           float* __restrict__ nent, int R, int S, int K, float invT) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < R; r += gridDim.x * wpb) {
+    const int b = r / S;
+    const float* lg = logits + (long long)b * K;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) {
+      const float g = -logf(-logf(u[(long long)r * K + k]));
+      mx = fmaxf(mx, (lg[k] + g) * invT);
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float g = -logf(-logf(u[(long long)r * K + k]));
+      se += expf((lg[k] + g) * invT - mx);
+    }
+    se = wave_sum(se);
+    const float lse = mx + logf(se);
+    for (int k = lane; k < K; k += 64) {
+      const float g = -logf(-logf(u[(long long)r * K + k]));
+      y[(long long)r * K + k] = expf((lg[k] + g) * invT - lse);
+    }
+    if (r == b * S) {       // once per x: entropy of q(y|x)
+      float m2 = -INFINITY;
+      for (int k = lane; k < K; k += 64) m2 = fmaxf(m2, lg[k]);
+      m2 = wave_max(m2);
+      float s2 = 0.f;
+      for (int k = lane; k < K; k += 64) s2 += expf(lg[k] - m2);
+      s2 = wave_sum(s2);
+      const float l2 = m2 + logf(s2);
+      float ne = 0.f;
+      for (int k = lane; k < K; k += 64) {
+        const float lp = lg[k] - l2;
+        ne += expf(lp) * lp;
+      }
+      ne = wave_sum(ne);
+      if (lane == 0) nent[b] = ne;
+    }
+  }
+}
+
+// Backward of the head above:
+//   da = y*(dy - sum_k y dy);  dlogits_b = sum_s da/T + pi*(log pi - sum pi log pi)
+// dy already carries the IWAE row weight; the entropy term has weight sum_s rw = 1.
+__global__ void y_head_bwd(const float* __restrict__ logits, const float* __restrict__ y,
+                           const float* __restrict__ dy, const float* __restrict__ nent,
+                           float* __restrict__ dlogits, int B, int S, int K, float invT) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int b = blockIdx.x * wpb + (threadIdx.x >> 6); b < B; b += gridDim.x * wpb) {
+    const float* lg = logits + (long long)b * K;
+    float m2 = -INFINITY;
+    for (int k = lane; k < K; k += 64) m2 = fmaxf(m2, lg[k]);
+    m2 = wave_max(m2);
+    float s2 = 0.f;
+    for (int k = lane; k < K; k += 64) s2 += expf(lg[k] - m2);
+    s2 = wave_sum(s2);
+    const float l2 = m2 + logf(s2);
+    const float ne = nent[b];
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      const int k = k0 + lane;
+      float acc = 0.f;
+      for (int s = 0; s < S; ++s) {
+        const long long r = (long long)b * S + s;
+        float dot = 0.f;
+        for (int kk = lane; kk < K; kk += 64) dot += y[r * K + kk] * dy[r * K + kk];
+        dot = wave_sum(dot);
+        if (k < K) acc += y[r * K + k] * (dy[r * K + k] - dot);
+      }
+      if (k < K) {
+        const float lp = lg[k] - l2;
+        dlogits[(long long)b * K + k] = acc * invT + expf(lp) * (lp - ne);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------ q(z|.) head, prior terms
+enum { PRIOR_STD = 0, PRIOR_GMP = 1, PRIOR_COND = 2 };
+
+// ConditionalNormal.condition (scripts/base.py:66-72): mu | raw split,
+// sigma = max(softplus(raw + c), sigma_min); MultivariateNormalDiag.sample
+// z = mu + sigma*eps (gmvae.py:248, vae.py:171) and .log_prob for q(z|.) and,
+// for PRIOR_COND, p(z|y) (gmvae.py:258); PRIOR_STD: N(0,I) (vae.py:247-250).
+// One wave per row; lanes stride over L.
+__global__ void z_head_fwd(const float* __restrict__ qp, int qp_div, const float* __restrict__ pp,
+                           const float* __restrict__ eps, float* __restrict__ z, float* __restrict__ logq,
+                           float* __restrict__ logp, int R, int L, int prior, float c, float smin) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < R; r += gridDim.x * wpb) {
+    const float* q = qp + (long long)(r / qp_div) * 2 * L;
+    float aq = 0.f, ap = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      const float mu = q[l];
+      const float sg = fmaxf(softplusf_(q[L + l] + c), smin);
+      const float zz = mu + sg * eps[(long long)r * L + l];
+      z[(long long)r * L + l] = zz;
+      const float e = (zz - mu) / sg;                       // from z, not eps (A7)
+      aq += -0.5f * e * e - 0.5f * kLog2Pi - logf(sg);
+      if (prior == PRIOR_COND) {
+        const float* p = pp + (long long)r * 2 * L;
+        const float sp = fmaxf(softplusf_(p[L + l] + c), smin);
+        const float t = (zz - p[l]) / sp;
+        ap += -0.5f * t * t - 0.5f * kLog2Pi - logf(sp);
+      } else if (prior == PRIOR_STD) {
+        ap += -0.5f * zz * zz - 0.5f * kLog2Pi;
+      }
+    }
+    aq = wave_sum(aq);
+    ap = wave_sum(ap);
+    if (lane == 0) {
+      logq[r] = aq;
+      if (prior != PRIOR_GMP) logp[r] = ap;
+    }
+  }
+}
+
+// MixtureSameFamily(Categorical(mixture_logits), MVNDiag(loc, softplus(raw_scale_diag))).log_prob
+// (scripts/vae.py:231-244, consumed at vae.py:181):
+//   log p(z) = logsumexp_k [ log_softmax(mixture_logits)_k + sum_l logN(z_l; loc_kl, s_kl) ]
+// The K x L component parameters are staged ONCE per workgroup in LDS as
+// (loc, 1/s) with an odd row stride; lanes are (row-in-wave, component k), each
+// lane walks l serially, and the K-way logsumexp is a wavefront-shuffle reduction.
+// Also writes the responsibilities r_k used by the backward pass.
+__global__ void mixture_logprob_lse(const float* __restrict__ z, const float* __restrict__ loc,
+                                    const float* __restrict__ raw_scale, const float* __restrict__ mixlog,
+                                    float* __restrict__ logp, float* __restrict__ resp, int R, int L, int K,
+                                    int Kp /* pow2 >= K, <= 64 */) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int LD = L | 1;
+  float* s_loc = sm;                    // [K][LD]
+  float* s_inv = s_loc + K * LD;        // [K][LD]  1/s
+  float* s_c = s_inv + K * LD;          // [Kp]     log w_k - sum_l log s_kl - L/2 log 2pi
+  float* s_z = s_c + 64;                // [waves][rows_per_wave][L]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  for (int i = tid; i < K * L; i += blockDim.x) {
+    const int k = i / L, l = i % L;
+    const float s = softplusf_(raw_scale[i]);
+    s_loc[k * LD + l] = loc[i];
+    s_inv[k * LD + l] = 1.f / s;
+  }
+  __syncthreads();
+  if (wave == 0) {                      // per-component constants + log_softmax of the mixture logits
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, mixlog[k]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int k = lane; k < K; k += 64) se += expf(mixlog[k] - mx);
+    se = wave_sum(se);
+    const float lse = mx + logf(se);
+    for (int k = lane; k < K; k += 64) {
+      float ls = 0.f;
+      for (int l = 0; l < L; ++l) ls += logf(s_inv[k * LD + l]);   // = -log s
+      s_c[k] = mixlog[k] - lse + ls - 0.5f * kLog2Pi * (float)L;
+    }
+  }
+  __syncthreads();
+  const int rpw = 64 / Kp;              // rows handled by one wave at a time
+  const int sub = lane / Kp, k = lane % Kp;
+  float* zw = s_z + wave * rpw * L;
+  for (int r0 = (blockIdx.x * nw + wave) * rpw; r0 < R; r0 += gridDim.x * nw * rpw) {
+    for (int i = lane; i < rpw * L; i += 64) {
+      const int rr = r0 + i / L;
+      zw[i] = rr < R ? z[(long long)rr * L + i % L] : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int r = r0 + sub;
+    float comp = -INFINITY;
+    if (k < K) {
+      float a = 0.f;
+      const float* zl = zw + sub * L;
+      for (int l = 0; l < L; ++l) {
+        const float t = (zl[l] - s_loc[k * LD + l]) * s_inv[k * LD + l];
+        a += t * t;
+      }
+      comp = s_c[k] - 0.5f * a;
+    }
+    float mx = comp;
+    for (int o = Kp >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float se = (k < K) ? expf(comp - mx) : 0.f;
+    for (int o = Kp >> 1; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    const float lse = mx + logf(se);
+    if (r < R) {
+      if (k < K) resp[(long long)r * K + k] = expf(comp - lse);
+      if (k == 0) logp[r] = lse;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Backward seeds at z, w = IWAE row weight (1 at S=1):
+//   dmu_q = dz_dec + w*prior_term ; dsig_q = dmu_q*eps - w/sig_q ;
+//   draw_q = dsig_q*sigmoid(raw_q + c)*[softplus > sigma_min]
+//   PRIOR_COND: dmu_p = -w*t/sig_p ; dsig_p = w*(1-t^2)/sig_p ; draw_p likewise
+//   prior_term: COND t/sig_p | STD z | GMP sum_k r_k (z-loc_k)/s_k^2
+__global__ void z_head_bwd(const float* __restrict__ dz, const float* __restrict__ qp, int qp_div,
+                           const float* __restrict__ pp, const float* __restrict__ eps,
+                           const float* __restrict__ z, const float* __restrict__ rw,
+                           const float* __restrict__ resp, const float* __restrict__ loc,
+                           const float* __restrict__ raw_scale, float* __restrict__ dqp,
+                           float* __restrict__ dpp, int R, int L, int K, int prior, float c, float smin) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < R; r += gridDim.x * wpb) {
+    const float w = rw ? rw[r] : 1.f;
+    const float* q = qp + (long long)(r / qp_div) * 2 * L;
+    for (int l = lane; l < L; l += 64) {
+      const float rawq = q[L + l] + c;
+      const float spq = softplusf_(rawq);
+      const float sg = fmaxf(spq, smin);
+      const float zz = z[(long long)r * L + l];
+      float pterm;
+      if (prior == PRIOR_COND) {
+        const float* p = pp + (long long)r * 2 * L;
+        const float rawp = p[L + l] + c;
+        const float spp = softplusf_(rawp);
+        const float sp = fmaxf(spp, smin);
+        const float t = (zz - p[l]) / sp;
+        pterm = t / sp;
+        dpp[(long long)r * 2 * L + l] = -w * pterm;
+        dpp[(long long)r * 2 * L + L + l] = (spp > smin) ? w * (1.f - t * t) / sp * sigmoidf_(rawp) : 0.f;
+      } else if (prior == PRIOR_STD) {
+        pterm = zz;
+      } else {
+        pterm = 0.f;
+        for (int k = 0; k < K; ++k) {
+          const float s = softplusf_(raw_scale[k * L + l]);
+          pterm += resp[(long long)r * K + k] * (zz - loc[k * L + l]) / (s * s);
+        }
+      }
+      const float dmu = dz[(long long)r * L + l] + w * pterm;
+      const float dsg = dmu * eps[(long long)r * L + l] - w / sg;
+      dqp[(long long)r * 2 * L + l] = dmu;
+      dqp[(long long)r * 2 * L + L + l] = (spq > smin) ? dsg * sigmoidf_(rawq) : 0.f;
+    }
+  }
+}
+
+// Gradients of the learned mixture prior (vae.py:233-244):
+//   dloc_kl = -sum_r w r_k (z-loc)/s^2 ; ds_kl = sum_r w r_k (1-t^2)/s ;
+//   dmix_k = -sum_r w (r_k - softmax(mixture_logits)_k)
+// Each workgroup reduces a strip of rows into one partial [2*K*L + K].
+__global__ void gmp_param_bwd(const float* __restrict__ z, const float* __restrict__ resp,
+                              const float* __restrict__ rw, const float* __restrict__ loc,
+                              const float* __restrict__ raw_scale, const float* __restrict__ mixlog,
+                              float* __restrict__ partial, int R, int L, int K, int KLp) {
+  // partial layout mirrors the padded flat layout: [loc KLp | raw_scale KLp | mixture_logits pad4(K)]
+  const int KL = K * L;
+  const int rows_per = (R + gridDim.x - 1) / gridDim.x;
+  const int rb = blockIdx.x * rows_per, re = min(R, rb + rows_per);
+  float* out = partial + (long long)blockIdx.x * (2 * KLp + (K + 3) / 4 * 4);
+  for (int i = threadIdx.x; i < KL; i += blockDim.x) {
+    const int k = i / L, l = i % L;
+    const float s = softplusf_(raw_scale[i]), lc = loc[i];
+    float a = 0.f, b = 0.f;
+    for (int r = rb; r < re; ++r) {
+      const float wr = (rw ? rw[r] : 1.f) * resp[(long long)r * K + k];
+      const float t = (z[(long long)r * L + l] - lc) / s;
+      a -= wr * t / s;
+      b += wr * (1.f - t * t) / s;
+    }
+    out[i] = a;
+    out[KLp + i] = b * sigmoidf_(raw_scale[i]);
+  }
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float mx = -INFINITY;
+    for (int j = 0; j < K; ++j) mx = fmaxf(mx, mixlog[j]);
+    float se = 0.f;
+    for (int j = 0; j < K; ++j) se += expf(mixlog[j] - mx);
+    const float wk = expf(mixlog[k] - mx) / se;
+    float a = 0.f;
+    for (int r = rb; r < re; ++r) a -= (rw ? rw[r] : 1.f) * (resp[(long long)r * K + k] - wk);
+    out[2 * KLp + k] = a;
+  }
+}
+
+// sum over the S samples of a row group: out[b,:] = sum_s in[b*S+s,:]
+__global__ void sum_over_s(const float* __restrict__ in, float* __restrict__ out, int B, int S, int N) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * N) return;
+  const int b = i / N, n = i % N;
+  float a = 0.f;
+  for (int s = 0; s < S; ++s) a += in[((long long)b * S + s) * N + n];
+  out[i] = a;
+}
+
+// ---------------------------------------------------------------- loss
+// log w_r = log p(x|z) + log p(z|.) - log q(z|.) - nent_b  (gmvae.py:254-267,
+// vae.py:177-185; A15 for S>1).  logpx = sum of the decoder epilogue partials.
+__global__ void row_terms(const float* __restrict__ part, int nparts, const float* __restrict__ logq,
+                          const float* __restrict__ logp, const float* __restrict__ nent, int S,
+                          float* __restrict__ logpx, float* __restrict__ logw, float* __restrict__ terms4, int R) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float a = 0.f;
+  for (int i = 0; i < nparts; ++i) a += part[(long long)r * nparts + i];
+  const float ne = nent ? nent[r / S] : 0.f;
+  const float lw = a + logp[r] - logq[r] - ne;
+  logpx[r] = a;
+  logw[r] = lw;
+  if (terms4) {
+    terms4[4 * r + 0] = a;
+    terms4[4 * r + 1] = logq[r];
+    terms4[4 * r + 2] = logp[r];
+    terms4[4 * r + 3] = lw;
+  }
+}
+
+// One workgroup: per-x IWAE bound logsumexp_s(log w) - log S, normalised row
+// weights rw = softmax_s(log w), and the tail sums
+// [sum_b loss_b, sum nll, sum kl, sum nent, B] (means over s inside a group).
+// Deterministic (fixed-order tree).  Also advances the device step counter.
+__global__ __launch_bounds__(1024) void loss_tail(const float* __restrict__ logw, const float* __restrict__ logpx,
+                                                  const float* __restrict__ logq, const float* __restrict__ logp,
+                                                  const float* __restrict__ nent, float* __restrict__ rw,
+                                                  float* __restrict__ tail, int B, int S, uint64_t* step_dev) {
+  __shared__ float red[4][1024];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const float invS = 1.f / (float)S;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const long long r0 = (long long)b * S;
+    float mx = -INFINITY;
+    for (int s = 0; s < S; ++s) mx = fmaxf(mx, logw[r0 + s]);
+    float se = 0.f;
+    for (int s = 0; s < S; ++s) se += expf(logw[r0 + s] - mx);
+    const float lse = mx + logf(se);
+    float nl = 0.f, kl = 0.f;
+    for (int s = 0; s < S; ++s) {
+      if (rw) rw[r0 + s] = expf(logw[r0 + s] - lse);
+      nl -= logpx[r0 + s];
+      kl += logq[r0 + s] - logp[r0 + s];
+    }
+    a0 -= (S == 1) ? logw[r0] : lse - logf((float)S);
+    a1 += nl * invS;
+    a2 += kl * invS;
+    a3 += nent ? nent[b] : 0.f;
+  }
+  red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2; red[3][threadIdx.x] = a3;
+  __syncthreads();
+  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int j = 0; j < 4; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    tail[0] = red[0][0]; tail[1] = red[1][0]; tail[2] = red[2][0]; tail[3] = red[3][0];
+    tail[4] = (float)B; tail[5] = 0.f; tail[6] = 0.f; tail[7] = 0.f;
+    if (step_dev) *step_dev += 1;
+  }
+}
+
+// ------------------------------------------------------- gradient assembly
+// grads[i] = sum over the split-K slabs (fixed order => bit-reproducible),
+// and the mixture-prior partials where present.
+__global__ void finalize_grads(const float* __restrict__ slabs, int nslab, long long P, float* __restrict__ grads,
+                               const float* __restrict__ gmp_part, int gmp_n, int gmp_len, long long gmp_off) {
+  const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= P) return;
+  float4 a = *reinterpret_cast<const float4*>(slabs + i4);
+  for (int s = 1; s < nslab; ++s) {
+    const float4 o = *reinterpret_cast<const float4*>(slabs + (long long)s * P + i4);
+    a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+  }
+  if (gmp_part && i4 >= gmp_off && i4 < gmp_off + gmp_len) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) {
+      const long long e = i4 + j - gmp_off;
+      if (e < gmp_len)
+        for (int g = 0; g < gmp_n; ++g) v[j] += gmp_part[(long long)g * gmp_len + e];
+    }
+    a = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  *reinterpret_cast<float4*>(grads + i4) = a;
+}
+
+// ---------------------------------------------------------------- Adam
+// TF1 AdamOptimizer / ApplyAdam (scripts/runners.py:181-183):
+//   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; theta -= lr_t*m/(sqrt(v)+eps)
+// One launch over the whole flat buffer (multi-tensor by construction).
+__global__ void adam_tf(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                        const float* __restrict__ g, long long P, float lr, float b1, float b2, float eps,
+                        uint64_t t, const uint64_t* t_dev, float gscale, const float* gscale_dev) {
+  if (t_dev) t = *t_dev;
+  if (gscale_dev) gscale = 1.f / *gscale_dev;
+  const float lr_t = lr * sqrtf(1.f - powf(b2, (float)t)) / (1.f - powf(b1, (float)t));
+  const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 3 < P) {
+    float4 pp = *reinterpret_cast<float4*>(p + i4), mm = *reinterpret_cast<float4*>(m + i4),
+           vv = *reinterpret_cast<float4*>(v + i4);
+    const float4 gg = *reinterpret_cast<const float4*>(g + i4);
+    float* pa = &pp.x; float* ma = &mm.x; float* va = &vv.x; const float* ga = &gg.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = ga[j] * gscale;
+      ma[j] = b1 * ma[j] + (1.f - b1) * gj;
+      va[j] = b2 * va[j] + (1.f - b2) * gj * gj;
+      pa[j] -= lr_t * ma[j] / (sqrtf(va[j]) + eps);
+    }
+    *reinterpret_cast<float4*>(p + i4) = pp;
+    *reinterpret_cast<float4*>(m + i4) = mm;
+    *reinterpret_cast<float4*>(v + i4) = vv;
+  } else {
+    for (long long i = i4; i < P; ++i) {
+      const float gj = g[i] * gscale;
+      m[i] = b1 * m[i] + (1.f - b1) * gj;
+      v[i] = b2 * v[i] + (1.f - b2) * gj * gj;
+      p[i] -= lr_t * m[i] / (sqrtf(v[i]) + eps);
+    }
+  }
+}
+
+// ------------------------------------------------------------ cluster_acc
+// utils.cluster_acc / mode_tensor (scripts/utils.py:156-191): argmax cluster,
+// per-cluster label histogram (LDS-free global atomics on a tiny [K,n_labels]
+// table), majority label (first maximum in first-occurrence order is not
+// recoverable from a histogram: ties resolve to the smallest label), match rate.
+__global__ void cluster_hist(const float* __restrict__ logits, const int64_t* __restrict__ labels, int B, int K,
+                             int NL, int32_t* __restrict__ hist, int32_t* __restrict__ pred) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int best = 0;
+  float bv = logits[(long long)b * K];
+  for (int k = 1; k < K; ++k) {
+    const float v = logits[(long long)b * K + k];
+    if (v > bv) { bv = v; best = k; }
+  }
+  pred[b] = best;
+  const int lab = (int)labels[b];
+  if (lab >= 0 && lab < NL) atomicAdd(&hist[best * NL + lab], 1);
+}
+__global__ void cluster_match(const int32_t* __restrict__ hist, const int32_t* __restrict__ pred,
+                              const int64_t* __restrict__ labels, int B, int K, int NL, float* __restrict__ acc) {
+  __shared__ int mode[256];
+  __shared__ int cnt[1024];
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    int best = 0, bc = 0;                 // empty cluster -> mode 0 (tf.cond branch, utils.py:183-185)
+    for (int l = 0; l < NL; ++l)
+      if (hist[k * NL + l] > bc) { bc = hist[k * NL + l]; best = l; }
+    mode[k] = best;
+  }
+  __syncthreads();
+  int c = 0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) c += (mode[pred[b]] == (int)labels[b]);
+  cnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) cnt[threadIdx.x] += cnt[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) acc[0] = (float)cnt[0] / (float)B;
+}
+
+}  // namespace gmvae

@@ -1,0 +1,180 @@
+/*
+ * gmvae_hip.h -- C ABI of libgmvae_hip.so: the MI355X (gfx950) implementation
+ * of the one hot path of mazrk7/gmvae: the VAE / VAE_GMP / GMVAE single-sample
+ * ELBO training step (+ the IWAE n_samples extension).
+ *
+ * The reference has NO FFI/plugin API (it is pure TF1 graph Python); the
+ * boundary it exposes is the Python object protocol of scripts/vae.py and
+ * scripts/gmvae.py.  gmvae_amd/{base,vae,gmvae}.py mirror that protocol and
+ * bind the entry points below with ctypes.  Each entry point cites the
+ * reference call site(s) whose arithmetic it replaces (paths relative to the
+ * upstream repo).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a positive hipError_t on a HIP
+ *     failure, or a negative GMVAE_E_* code on a bad argument; nothing throws;
+ *   - no allocation and no synchronisation inside: the caller owns every
+ *     buffer (device memory, 16-byte aligned) including the workspace, whose
+ *     size is queried with gmvae_workspace_bytes() and which must be zeroed
+ *     ONCE after allocation (padding words are never written again);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*), is
+ *     asynchronous and graph-capturable; no global state;
+ *   - all float tensors are fp32 row-major; x is uint8/bool {0,1} [B,D];
+ *   - sample-dependent tensors have R = B*S rows, row r = b*S + s.
+ */
+#ifndef GMVAE_HIP_H_
+#define GMVAE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMVAE_MAX_HIDDEN 8
+#define GMVAE_TAIL 8          /* floats appended to the gradient buffer */
+#define GMVAE_ABI_VERSION 1
+
+enum { GMVAE_MODEL_VAE = 0, GMVAE_MODEL_VAE_GMP = 1, GMVAE_MODEL_GMVAE = 2 };
+
+enum {
+  GMVAE_E_NULL = -1,      /* required pointer is NULL            */
+  GMVAE_E_DIMS = -2,      /* non-positive / unsupported sizes    */
+  GMVAE_E_MODEL = -3,     /* unknown model id                    */
+  GMVAE_E_ALIGN = -4,     /* pointer not 16-byte aligned         */
+  GMVAE_E_NET = -5,       /* unknown sub-network id              */
+  GMVAE_E_SMALL = -6      /* caller array too small              */
+};
+
+/* Sizes + the hyper-parameters scripts/runners.py:78-101 binds
+ * (sigma_min=0, raw_sigma_bias=0.5, temperature=1; gen_bias_init=0 from
+ * scripts/gmvae.py:285).  hidden[] = fcnet_hidden_sizes. */
+typedef struct GmvaeDims {
+  int32_t B;                          /* rows of x on this device            */
+  int32_t D;                          /* data_size                           */
+  int32_t L;                          /* latent_size                         */
+  int32_t K;                          /* mixture_components (1 for plain VAE)*/
+  int32_t S;                          /* IWAE samples; 1 == the reference    */
+  int32_t n_hidden;
+  int32_t hidden[GMVAE_MAX_HIDDEN];
+  float sigma_min;
+  float raw_sigma_bias;
+  float temperature;
+  float gen_bias_init;
+} GmvaeDims;
+
+/* One tensor of the flat parameter buffer.  Names are the reference's TF
+ * variable names (scripts/base.py:53,60 '<name>_fcnet/linear_<i>/{w,b}';
+ * scripts/vae.py:233-238 'loc','raw_scale_diag','mixture_logits'), in the
+ * reference's variable-creation order. */
+typedef struct GmvaeParamEntry {
+  char name[64];
+  int32_t rows;                       /* w: in  ; b: 1 ; loc: K              */
+  int32_t cols;                       /* w: out ; b: out                     */
+  uint64_t offset;                    /* in floats, multiple of 4            */
+} GmvaeParamEntry;
+
+/* sub-network ids for gmvae_mlp_forward */
+enum {
+  GMVAE_NET_ENCODER_Y = 0,            /* scripts/gmvae.py:340-345            */
+  GMVAE_NET_PRIOR_GMM = 1,            /* scripts/gmvae.py:321-327            */
+  GMVAE_NET_ENCODER_GMM = 2,          /* scripts/gmvae.py:347-353            */
+  GMVAE_NET_DECODER = 3,              /* scripts/gmvae.py:331-336, vae.py:254-259 */
+  GMVAE_NET_ENCODER = 4               /* scripts/vae.py:262-268              */
+};
+
+int gmvae_abi_version(void);
+
+/* Replaces variable creation in create_vae / create_gmvae
+ * (scripts/vae.py:191-271, scripts/gmvae.py:277-356): sizes of the flat
+ * buffer.  P_padded counts the 16-byte alignment padding, P_real does not
+ * (166,618 for GMVAE D=784 H=64 L=64 K=10). */
+int gmvae_param_count(const GmvaeDims* dims, int model, uint64_t* P_padded, uint64_t* P_real);
+int gmvae_param_layout(const GmvaeDims* dims, int model, GmvaeParamEntry* out, int max_entries, int* n_entries);
+
+int gmvae_workspace_bytes(const GmvaeDims* dims, int model, uint64_t* bytes);
+
+/* TrainableGMVAE.run_model (scripts/gmvae.py:223-274) /
+ * TrainableVAE.run_model (scripts/vae.py:153-188) PLUS the reverse-mode pass
+ * of opt.compute_gradients (scripts/runners.py:182).
+ *   x     uint8 [B,D]
+ *   eps   fp32 [B*S,L]  N(0,1) noise     (MultivariateNormalDiag.sample)
+ *   u     fp32 [B*S,K]  U[tiny,1) noise  (RelaxedOneHotCategorical.sample; GMVAE only)
+ *         eps/u NULL => generated in-kernel by Philox4x32-10(seed, step)
+ *   grads fp32 [P_padded + GMVAE_TAIL], OUT: SUMS over this device's rows of
+ *         d loss_b / d theta (NOT divided by B), then the tail
+ *         [0] sum_b loss_b  [1] sum nll  [2] sum kl  [3] sum nent  [4] B
+ *         (nll/kl are averaged over S inside a row group) -- one RCCL
+ *         all-reduce(SUM) of this buffer makes it global; adam_tf_step's
+ *         grad_scale = 1/tail[4] turns sums into the reference's batch means.
+ *   step_dev (may be NULL): device-resident step counter for hipGraph replay.
+ *         When given it overrides `step` for the Philox stream and is
+ *         incremented once per call (after the noise is drawn), so that
+ *         adam_tf_step(t_dev = step_dev) later on the stream sees t = step+1.
+ */
+int gmvae_step(const GmvaeDims* dims, int model, const uint8_t* x, const float* eps, const float* u,
+               const float* params, float* grads, void* workspace, uint64_t seed, uint64_t step,
+               uint64_t* step_dev, void* stream);
+
+/* Forward only (eval: scripts/runners.py:324-333).  tail: float[GMVAE_TAIL]
+ * as above.  row_terms (may be NULL): fp32 [B*S,4] = logpx, logq, logp, logw.
+ * z_out (may be NULL) [B*S,L]; y_out (may be NULL, GMVAE) [B*S,K];
+ * logits_out (may be NULL, GMVAE) [B,K] = q_y.distribution.logits. */
+int gmvae_forward(const GmvaeDims* dims, int model, const uint8_t* x, const float* eps, const float* u,
+                  const float* params, float* tail, float* row_terms, float* z_out, float* y_out,
+                  float* logits_out, void* workspace, uint64_t seed, uint64_t step, void* stream);
+
+/* tf.compat.v1.train.AdamOptimizer.apply_gradients (scripts/runners.py:181-183):
+ * epsilon is added to the UN-corrected sqrt(v).  t = 1-based step count.
+ * t_dev (may be NULL): device pointer overriding t (graph replay).
+ * g = grads[i] * grad_scale.  grad_scale_dev (may be NULL): device pointer to
+ * a count; when given, grad_scale = 1 / (*grad_scale_dev) overrides. */
+int adam_tf_step(float* params, float* m, float* v, const float* grads, uint64_t P, float lr, float beta1,
+                 float beta2, float epsilon, uint64_t t, const uint64_t* t_dev, float grad_scale,
+                 const float* grad_scale_dev, void* stream);
+
+/* One conditional network's MLP (scripts/base.py:66-67,133-135,196-198):
+ * out[rows, out_dim] = MLP(concat(in, in2)) (+ gen_bias_init for the decoder).
+ * `in` is uint8 when in_is_u8 else fp32.  in2 is y for ENCODER_GMM, else NULL.
+ * The distribution heads (softplus, sigmoid, softmax) are applied by the
+ * Python distribution objects on top of this. `B` in dims is ignored; rows is used. */
+int gmvae_mlp_forward(const GmvaeDims* dims, int model, int net, const void* in, int in_is_u8,
+                      const float* in2, int rows, const float* params, float* out, void* workspace,
+                      void* stream);
+
+/* Philox4x32-10 noise: eps ~ N(0,1) [n_eps], u ~ U[tiny,1) [n_u] (either may be NULL/0). */
+int gmvae_noise_fill(float* eps, uint64_t n_eps, float* u, uint64_t n_u, uint64_t seed, uint64_t step,
+                     const uint64_t* step_dev, void* stream);
+
+/* utils.cluster_acc (scripts/utils.py:173-191) on device.  scratch: int32
+ * [K*n_labels + B] (histogram, zeroed by the callee, then per-row argmax);
+ * acc_out float[1].  Mode ties resolve to the smallest label. */
+int gmvae_cluster_acc(const float* logits, const int64_t* labels, int B, int K, int n_labels,
+                      int32_t* scratch, float* acc_out, void* stream);
+
+/* ---- measurement / test hooks (not used by the reference-facing API) ---- */
+
+/* One GEMM through the same grouped fp32-MFMA kernel the step uses.
+ * cfg: tile configuration (0 small 32x32, 1 medium 64x64, 2 large 128x128, -1 auto).
+ * trans 0 (NN): C[M,N] = act(A[M,K] W[K,N] + bias)
+ * trans 1 (NT): C[M,N] = A[M,K] W[N,K]^T
+ * trans 2 (TN): C[s][M(+1),N] = A[K,M]^T W[K,N] split over K into `splitk` slabs
+ *               of (M+1)*N floats; bias != NULL requests the extra ones row
+ *               (column sums of W) at row M.
+ * a_is_u8: A holds uint8. */
+int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bias, float* C, int M, int N,
+                    int K, int trans, int relu, int cfg, int splitk, void* stream);
+
+/* Runs the full step `iters` times with hipEvents around EVERY launch (on
+ * `stream`) and returns, per launch ("level"), its name [48 chars each], mean
+ * microseconds and the algorithmic FLOPs (2*M*N*K summed over its GEMMs,
+ * 0 for row-local kernels).  Synchronises the stream: measurement only. */
+int gmvae_step_profile(const GmvaeDims* dims, int model, const uint8_t* x, const float* eps, const float* u,
+                       const float* params, float* grads, void* workspace, uint64_t seed, int iters,
+                       int max_levels, int* n_levels, char* names, float* usec, double* flops, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMVAE_HIP_H_ */

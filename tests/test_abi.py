@@ -1,0 +1,72 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol that
+include/gmvae_hip.h declares, and its host-only functions (layout, sizes,
+argument validation) agree with the oracle.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from gmvae_amd import build
+    build.build(verbose=False)
+    from gmvae_amd import _lib
+    return _lib
+
+
+def test_exports_every_declared_symbol(L):
+    hdr = open(os.path.join(ROOT, "include", "gmvae_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\bint\s+(\w+)\s*\(", hdr))
+    assert len(declared) >= 12
+    raw = C.CDLL(L.LIB_PATH)
+    for sym in declared:
+        assert hasattr(raw, sym), f"{sym} declared in include/gmvae_hip.h but not exported"
+    assert declared == set(L.EXPORTS)
+    assert L.lib.gmvae_abi_version() == 1
+
+
+@pytest.mark.parametrize("name,d", [
+    ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,))),
+    ("gmvae", O.Dims(D=3072, L=64, K=64, hidden=(512,), S=50)),
+    ("gmvae", O.Dims(D=100, L=5, K=7, hidden=(24, 24))),
+    ("gmvae", O.Dims(D=97, L=5, K=3, hidden=())),
+    ("vae", O.Dims(D=784, L=2, K=1, hidden=(64,))),
+    ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(64,))),
+])
+def test_layout_matches_oracle(L, name, d):
+    model = O.MODEL_NAMES[name]
+    cd = L.make_dims(16, d.D, d.L, d.K, d.hidden, S=d.S)
+    lay, P, real = O.param_layout(model, d)
+    assert L.param_count(cd, model) == (P, real)
+    got = L.param_layout(cd, model)
+    assert [g[0] for g in got] == [l[0] for l in lay]
+    assert [g[2] for g in got] == [l[2] for l in lay]
+    for (gn, (r, c), _), (_, shape, _) in zip(got, lay):
+        assert r * c == int(np.prod(shape))
+    assert L.workspace_bytes(cd, model) > 0
+
+
+def test_argument_validation(L):
+    cd = L.make_dims(16, 784, 64, 10, [64])
+    pp = C.c_uint64()
+    assert L.lib.gmvae_param_count(None, 2, C.byref(pp), None) == -1
+    assert L.lib.gmvae_param_count(C.byref(cd), 7, C.byref(pp), None) == -3
+    bad = L.make_dims(0, 784, 64, 10, [64])
+    assert L.lib.gmvae_param_count(C.byref(bad), 2, C.byref(pp), None) == -2
+    big_k = L.make_dims(16, 784, 64, 65, [64])
+    assert L.lib.gmvae_param_count(C.byref(big_k), 1, C.byref(pp), None) == -2     # GMP prior: K <= 64
+    assert L.lib.gmvae_step(C.byref(cd), 2, None, None, None, None, None, None, 0, 0, None, None) == -1
+    assert L.lib.adam_tf_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, None, 1.0, None, None) == -1
+    n = C.c_int()
+    arr = (L.GmvaeParamEntry * 2)()
+    assert L.lib.gmvae_param_layout(C.byref(cd), 2, arr, 2, C.byref(n)) == -6
+    with pytest.raises(ValueError):
+        L.make_dims(1, 1, 1, 1, [1] * 9)

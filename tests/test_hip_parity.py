@@ -1,0 +1,235 @@
+"""-m gpu: the HIP path, called through the C ABI, against the CPU oracle.
+
+Tolerances: ELBO (loss) <= 1e-4 relative (BASELINE.json north_star); per-term
+(nll / kl / nent) and per-tensor gradients are gated separately so cancellation
+inside the 1e-4 * |ELBO| budget cannot hide a bug."""
+import ctypes as C
+import glob
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hip_util
+    return hip_util
+
+
+def _L():
+    from gmvae_amd import _lib
+    return _lib
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K,u8", [(64, 64, 64, False), (100, 50, 70, False), (33, 10, 784, True),
+                                       (256, 128, 784, True), (130, 131, 33, False), (7, 3, 5, False)])
+def test_gemm_nn(H, cfg, M, N, K, u8):
+    L = _L()
+    rng = np.random.default_rng(M * 1000 + N)
+    A = (rng.random((M, K)) < 0.5).astype(np.uint8) if u8 else rng.normal(size=(M, K)).astype(np.float32)
+    W = rng.normal(size=(K, N)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    Ad, Wd, bd = H.dev(A), H.dev(W), H.dev(b)
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    L.check(L.lib.gmvae_gemm_test(L.ptr(Ad), int(u8), L.ptr(Wd), L.ptr(bd), L.ptr(Cd), M, N, K, 0, 1, cfg, 1,
+                                  L.current_stream()), "gemm_test")
+    ref = np.maximum(A.astype(np.float64) @ W.astype(np.float64) + b, 0)
+    np.testing.assert_allclose(Cd.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * math.sqrt(K))
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (100, 70, 50), (257, 10, 128), (31, 784, 64)])
+def test_gemm_nt(H, cfg, M, N, K):
+    L = _L()
+    rng = np.random.default_rng(M + N)
+    A = rng.normal(size=(M, K)).astype(np.float32)
+    W = rng.normal(size=(N, K)).astype(np.float32)
+    Ad, Wd = H.dev(A), H.dev(W)
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    L.check(L.lib.gmvae_gemm_test(L.ptr(Ad), 0, L.ptr(Wd), None, L.ptr(Cd), M, N, K, 1, 0, cfg, 1,
+                                  L.current_stream()), "gemm_test")
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    np.testing.assert_allclose(Cd.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * math.sqrt(K))
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K,u8,ns", [(64, 64, 256, False, 1), (784, 64, 300, True, 4), (10, 128, 1000, False, 3),
+                                          (65, 33, 70, False, 16)])
+def test_gemm_tn_splitk_bias_row(H, cfg, M, N, K, u8, ns):
+    L = _L()
+    rng = np.random.default_rng(K)
+    A = (rng.random((K, M)) < 0.5).astype(np.uint8) if u8 else rng.normal(size=(K, M)).astype(np.float32)
+    dY = rng.normal(size=(K, N)).astype(np.float32)
+    Ad, Yd = H.dev(A), H.dev(dY)
+    Cd = torch.full((ns, M + 1, N), float("nan"), device="cuda")
+    L.check(L.lib.gmvae_gemm_test(L.ptr(Ad), int(u8), L.ptr(Yd), L.ptr(Yd), L.ptr(Cd), M, N, K, 2, 0, cfg, ns,
+                                  L.current_stream()), "gemm_test")
+    got = Cd.cpu().numpy().astype(np.float64).sum(axis=0)
+    ref = np.concatenate([A.astype(np.float64).T @ dY, dY.astype(np.float64).sum(0, keepdims=True)], 0)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=3e-5 * math.sqrt(K))
+
+
+# ------------------------------------------------------------ full step
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(f)[:-4] for f in GOLDEN])
+def test_step_matches_golden(H, path):
+    z = np.load(path)
+    model = int(z["model"])
+    d = O.Dims(D=int(z["D"]), L=int(z["L"]), K=int(z["K"]), S=int(z["S"]), hidden=tuple(int(h) for h in z["hidden"]))
+    B = z["x"].shape[0]
+    u = z["u"] if "u" in z.files else None
+    gs, tail = H.hip_step(model, d, z["params"], z["x"], z["eps"], u)
+    assert abs(tail[0] / B - z["loss"]) <= 1e-4 * abs(z["loss"])
+    assert abs(tail[1] / B - z["nll"]) <= 1e-4 * abs(z["nll"])
+    assert abs(tail[2] / B - z["kl"]) <= 2e-3
+    assert abs(tail[3] / B - z["nent"]) <= 1e-4
+    lay, P, _ = O.param_layout(model, d)
+    for name, shape, off in lay:
+        n = int(np.prod(shape))
+        ref = z["grads"][off:off + n].astype(np.float64)
+        got = gs[off:off + n] / B
+        assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6), name
+
+
+STEP_CASES = [
+    ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,)), 256),
+    ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,)), 1024),
+    ("gmvae", O.Dims(D=784, L=8, K=10, hidden=(64,)), 16),                 # run_gmvae.py defaults
+    ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,)), 64),              # bin/run_train.sh
+    ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,)), 96),                # last partial batch of B=256
+    ("gmvae", O.Dims(D=784, L=16, K=10, hidden=(48, 32)), 50),
+    ("gmvae", O.Dims(D=300, L=16, K=64, hidden=(40,), S=5), 24),
+    ("gmvae", O.Dims(D=97, L=5, K=3, hidden=(), temperature=0.5), 9),
+    ("gmvae", O.Dims(D=64, L=8, K=4, hidden=(16,), sigma_min=0.9, raw_sigma_bias=0.25), 32),   # clamp active
+    ("vae", O.Dims(D=784, L=2, K=1, hidden=(64,)), 100),                   # BASELINE config 1
+    ("vae", O.Dims(D=784, L=8, K=1, hidden=(32,), S=4), 20),
+    ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(64,)), 256),             # BASELINE config 2
+    ("vae_gmp", O.Dims(D=200, L=24, K=64, hidden=(32,), S=3), 17),
+    ("vae_gmp", O.Dims(D=128, L=7, K=5, hidden=(20, 20), gen_bias_init=0.2), 33),
+]
+
+
+@pytest.mark.parametrize("name,d,B", STEP_CASES, ids=[f"{n}-D{d.D}-L{d.L}-K{d.K}-H{'x'.join(map(str, d.hidden))}-S{d.S}-B{B}"
+                                                       for n, d, B in STEP_CASES])
+def test_step_matches_oracle(H, name, d, B):
+    model = O.MODEL_NAMES[name]
+    rng = np.random.default_rng(B)
+    p = O.init_params(model, d, rng)
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    x, eps, u = O.make_inputs(d, B, model)
+    H.compare_step(model, d, p, x, eps, u)
+
+
+@pytest.mark.parametrize("D,K,expect", [(784, 10, 541.124804), (3072, 64, 2125.189256)])
+def test_kat_zero_weights_on_gpu(H, D, K, expect):
+    """all-zero parameters -> loss = D ln2 - ln K for any data/noise."""
+    d = O.Dims(D=D, L=64, K=K, hidden=(64,))
+    lay, P, _ = O.param_layout(O.MODEL_GMVAE, d)
+    x, eps, u = O.make_inputs(d, 32)
+    _, tail = H.hip_step(O.MODEL_GMVAE, d, np.zeros(P, np.float32), x, eps, u)
+    assert tail[0] / 32 == pytest.approx(expect, rel=2e-6)
+    assert abs(tail[2] / 32) < 1e-5
+    assert tail[3] / 32 == pytest.approx(-math.log(K), rel=1e-5)
+
+
+def test_forward_outputs(H):
+    d = O.Dims(D=784, L=16, K=10, hidden=(64,), S=2)
+    model = O.MODEL_GMVAE
+    p = O.init_params(model, d, np.random.default_rng(5))
+    x, eps, u = O.make_inputs(d, 40)
+    flat = O.pack(model, d, p, np.float32)
+    Cc = O.forward(model, d, O.unpack(model, d, flat.astype(np.float64)), x, eps, u)
+    tail, rows, z, y, lg = H.hip_forward(model, d, flat, x, eps, u)
+    np.testing.assert_allclose(z, Cc["z"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(y, Cc["y"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(lg, Cc["logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rows[:, 0], Cc["logpx"], rtol=1e-5)
+    np.testing.assert_allclose(rows[:, 3], Cc["logw"], rtol=1e-5)
+    assert tail[0] / 40 == pytest.approx(Cc["loss"], rel=1e-5)
+
+
+# ----------------------------------------------------------------- Adam
+def test_adam_tf_three_steps(H):
+    L = _L()
+    rng = np.random.default_rng(2)
+    P = 1003
+    th = rng.normal(size=P).astype(np.float32)
+    m = np.zeros(P, np.float32)
+    v = np.zeros(P, np.float32)
+    td, md, vd = H.dev(np.pad(th, (0, 1))), H.dev(np.pad(m, (0, 1))), H.dev(np.pad(v, (0, 1)))
+    for t in range(1, 4):
+        g = (rng.normal(size=P) * (1e-9 if t == 2 else 1.0)).astype(np.float32)
+        gd = H.dev(np.pad(g, (0, 1)) * 8.0)
+        L.check(L.lib.adam_tf_step(L.ptr(td), L.ptr(md), L.ptr(vd), L.ptr(gd), P, 1e-3, 0.9, 0.999, 1e-8, t, None,
+                                   1.0 / 8.0, None, L.current_stream()), "adam")
+        th, m, v = O.adam_tf_step(th.astype(np.float64), m.astype(np.float64), v.astype(np.float64),
+                                  g.astype(np.float64), t, dtype=np.float64)
+    np.testing.assert_allclose(td.cpu().numpy()[:P], th, rtol=2e-6, atol=2e-7)   # fp32 ulp at |theta|~1
+    np.testing.assert_allclose(vd.cpu().numpy()[:P], v, rtol=1e-5, atol=1e-30)
+
+
+def test_adam_device_counter_and_scale(H):
+    L = _L()
+    P = 64
+    td, md, vd = torch.ones(P, device="cuda"), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
+    gd = torch.full((P,), 6.0, device="cuda")
+    tdev = torch.tensor([3], dtype=torch.int64, device="cuda")
+    cnt = torch.tensor([4.0], device="cuda")
+    L.check(L.lib.adam_tf_step(L.ptr(td), L.ptr(md), L.ptr(vd), L.ptr(gd), P, 1e-3, 0.9, 0.999, 1e-8, 999, L.ptr(tdev),
+                               123.0, L.ptr(cnt), L.current_stream()), "adam")
+    th, _, _ = O.adam_tf_step(np.ones(P), np.zeros(P), np.zeros(P), np.full(P, 1.5), 3, dtype=np.float64)
+    np.testing.assert_allclose(td.cpu().numpy(), th, rtol=1e-6)
+
+
+# ---------------------------------------------------------------- noise
+def test_philox_noise_statistics_and_fast_mode(H):
+    L = _L()
+    n = 1 << 20
+    eps = torch.empty(n, device="cuda")
+    u = torch.empty(n, device="cuda")
+    L.check(L.lib.gmvae_noise_fill(L.ptr(eps), n, L.ptr(u), n, 7, 0, None, L.current_stream()), "noise")
+    e, uu = eps.cpu().numpy().astype(np.float64), u.cpu().numpy().astype(np.float64)
+    assert abs(e.mean()) < 5e-3 and abs(e.std() - 1) < 5e-3
+    assert abs((e ** 3).mean()) < 2e-2 and abs((e ** 4).mean() - 3) < 5e-2
+    assert uu.min() >= O.TINY_F32 and uu.max() < 1.0
+    assert abs(uu.mean() - 0.5) < 2e-3 and abs(uu.var() - 1 / 12) < 1e-3
+    eps2 = torch.empty(n, device="cuda")
+    L.check(L.lib.gmvae_noise_fill(L.ptr(eps2), n, None, 0, 7, 1, None, L.current_stream()), "noise")
+    assert abs(np.corrcoef(e, eps2.cpu().numpy())[0, 1]) < 5e-3        # a new step is a new stream
+    # fast mode of the step: eps/u = NULL -> loss within sampling distance of the parity-mode loss
+    d = O.Dims(D=784, L=64, K=10, hidden=(64,))
+    p = O.init_params(O.MODEL_GMVAE, d, np.random.default_rng(0))
+    x, eps_h, u_h = O.make_inputs(d, 1024)
+    flat = O.pack(O.MODEL_GMVAE, d, p, np.float32)
+    _, t_par = H.hip_step(O.MODEL_GMVAE, d, flat, x, eps_h, u_h)
+    _, t_fast = H.hip_step(O.MODEL_GMVAE, d, flat, x, None, None, seed=3, step=5)
+    assert abs(t_fast[0] - t_par[0]) / abs(t_par[0]) < 5e-3
+    _, t_fast2 = H.hip_step(O.MODEL_GMVAE, d, flat, x, None, None, seed=3, step=5)
+    assert t_fast2[0] == t_fast[0]                                         # same (seed, step) -> same bits
+
+
+def test_cluster_acc_kernel(H):
+    L = _L()
+    rng = np.random.default_rng(0)
+    B, K = 1000, 10
+    logits = rng.normal(size=(B, K)).astype(np.float32)
+    labels = rng.integers(0, 10, B)
+    ld, lab = H.dev(logits), H.dev(labels, torch.int64)
+    scratch = torch.zeros(K * 10 + B, dtype=torch.int32, device="cuda")
+    acc = torch.zeros(1, device="cuda")
+    L.check(L.lib.gmvae_cluster_acc(L.ptr(ld), L.ptr(lab), B, K, 10, L.ptr(scratch), L.ptr(acc), L.current_stream()),
+            "cluster_acc")
+    assert acc.item() == pytest.approx(O.cluster_acc(logits, labels, K), abs=2.0 / B)
