@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""ELBO-samples/sec of the GMVAE training step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = noise (Philox) + forward + backward + (RCCL all-reduce of the flat
+[P+8] gradient buffer when N>1) + TF-Adam, on a synthetic MNIST-shaped uint8
+batch already resident in HBM.  Workload = BASELINE.json configs[2]/[3]:
+GMVAE, D=784, K=10, latent 64, batch 1024 PER GPU (weak scaling: 8 GPUs = the
+B=8192 config), hidden = the reference default 64 (scripts/run_gmvae.py:19).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--model", default="gmvae", choices=["gmvae", "vae", "vae_gmp"])
+    ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch")
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=1)
+    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--components", type=int, default=10)
+    ap.add_argument("--data-dim", type=int, default=784)
+    ap.add_argument("--n-samples", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--levels", action="store_true", help="also print the per-launch table to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(model_id, d, B, flat, x, eps, u, budget_s):
+    """The oracle's fp32 restatement of the SAME step (fwd+bwd+TF-Adam) on the host cores."""
+    import oracle as O
+    res = {}
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
+    ncores = len(os.sched_getaffinity(0))
+    for label, nthreads in (("all", ncores), ("one", 1)):
+        import contextlib
+        ctx = threadpool_limits(limits=nthreads) if threadpool_limits else contextlib.nullcontext()
+        with ctx:
+            f, m, v = flat.copy(), np.zeros_like(flat), np.zeros_like(flat)
+            O.train_step(model_id, d, f, m, v, 1, x, eps, u, dtype=np.float32)      # warm
+            t0, n = time.perf_counter(), 0
+            while time.perf_counter() - t0 < budget_s / 2 and n < 200:
+                f, m, v, _, _ = O.train_step(model_id, d, f, m, v, n + 1, x, eps, u, dtype=np.float32)
+                n += 1
+            dt = time.perf_counter() - t0
+            res[label] = (B * d.S * n / dt, n, nthreads)
+    return res
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    n_gpus = world
+
+    import oracle as O
+    from gmvae_amd.engine import Engine
+
+    hidden = [a.hidden] * a.layers
+    d = O.Dims(D=a.data_dim, L=a.latent, K=a.components if a.model != "vae" else 1, hidden=tuple(hidden),
+               S=a.n_samples)
+    model_id = O.MODEL_NAMES[a.model]
+    B = a.batch
+    eng = Engine(a.model, d.D, d.L, d.K, hidden, n_samples=d.S, random_seed=0)     # same init on every rank
+    # synthetic MNIST-shaped batch: Bernoulli(0.87) uint8, per-rank shard of the global batch
+    x_np = (np.random.default_rng(1234 + rank).random((B, d.D)) < 0.87).astype(np.uint8)
+    x = torch.from_numpy(x_np).cuda()
+
+    # ---- parity in the same run: HIP vs the fp32 + fp64 CPU restatement on identical inputs
+    _, eps_np, u_np = O.make_inputs(d, B, model_id)
+    flat0 = eng.params.detach().cpu().numpy()
+    buf = eng.step(x, torch.from_numpy(eps_np), None if u_np is None else torch.from_numpy(u_np))
+    torch.cuda.synchronize()
+    tail = buf[eng.P:].cpu().numpy().astype(np.float64)
+    elbo_hip = -tail[0] / tail[4]
+    parity = {}
+    if rank == 0:
+        nb = min(B, 256)                    # the oracle finishes this in well under a second
+        C64 = O.forward(model_id, d, O.unpack(model_id, d, flat0.astype(np.float64)), x_np, eps_np, u_np, np.float64)
+        parity = {"elbo_hip": elbo_hip, "elbo_cpu_fp64": float(-C64["loss"]),
+                  "rel_err": float(abs(elbo_hip + C64["loss"]) / abs(C64["loss"]))}
+        del nb
+
+    # ---- the timed loop
+    use_graph = not a.no_graph
+    if use_graph:
+        try:
+            static_x, replay = eng.capture_train_step(B, lr=1e-3, all_reduce=world > 1)
+            static_x.copy_(x)
+            step_fn = replay
+        except Exception as e:                      # e.g. RCCL inside capture unsupported
+            if rank == 0:
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            use_graph = False
+    if not use_graph:
+        def step_fn():
+            eng.train_step(x, lr=1e-3, all_reduce=world > 1)
+
+    for _ in range(a.warmup):
+        step_fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step_fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_tail = eng.grads[eng.P:].cpu().numpy().astype(np.float64)
+    value = n_gpus * B * d.S * a.steps / dt
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: hipEvents around every launch of the step
+        levels = eng.profile_levels(x, iters=30)
+        gemms = [l for l in levels if l[2] > 0]
+        dom = max(gemms, key=lambda l: l[1])
+        step_flops = O.flops_per_step(model_id, d, B)
+        sum_us = sum(l[1] for l in levels)
+        roof = {"bound": "mfma", "kernel": f"gemm_grouped<{dom[0]}>", "achieved": dom[2] / dom[1] * 1e-6,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom[2] / dom[1] * 1e-6 / PEAK_F32_MFMA_TFLOPS,
+                "traffic": None, "usec_per_launch": dom[1], "flops_per_launch": dom[2],
+                "step_flops_alg": step_flops, "step_tflops_alg": step_flops / (dt / a.steps) * 1e-12,
+                "step_frac_of_mfma_peak": step_flops / (dt / a.steps) * 1e-12 / PEAK_F32_MFMA_TFLOPS,
+                "launches_per_step": len(levels) + 1, "sum_kernel_usec": sum_us}
+        if a.levels:
+            for nm, us, fl in levels:
+                print(f"  {nm:28s} {us:9.2f} us  {fl / max(us, 1e-9) * 1e-6:8.2f} TFLOP/s", file=sys.stderr)
+        cpu = None
+        if not a.no_cpu_baseline:
+            r = cpu_baseline(model_id, d, B, flat0, x_np, eps_np, u_np, a.cpu_seconds)
+            cpu = {"value": r["all"][0], "unit": "ELBO-samples/sec", "cores": r["all"][2], "kind": "port",
+                   "sample": f"{r['all'][1]} full steps (fwd+bwd+TF-Adam, fp32 NumPy/BLAS oracle) of the same "
+                             f"B={B} batch; 1-thread (reference's intra_op=inter_op=1): {r['one'][0]:.0f}/s over "
+                             f"{r['one'][1]} steps",
+                   "value_1thread": r["one"][0]}
+        out = {
+            "metric": "ELBO-samples/sec", "value": value, "unit": "samples/sec", "n_gpus": n_gpus, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.model} train step (noise+fwd+bwd+allreduce+TF-Adam), D={d.D} K={d.K} "
+                                   f"L={d.L} hidden={hidden} S={d.S}, batch {B}/GPU x {n_gpus} GPU "
+                                   f"(BASELINE configs[{2 if n_gpus == 1 else 3}])",
+                       "global_batch": B * n_gpus, "parallelism": f"dp{n_gpus}", "hipgraph": use_graph},
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "final_loss": final_tail[0] / max(final_tail[4], 1.0),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,10 +37,11 @@ class GmvaeError(RuntimeError):
 
 
 def _load():
+    import torch  # noqa: F401  -- loads PyTorch's HIP runtime first; libgmvae_hip.so binds to the same one
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. "
-            "Run `python -m gmvae_amd.build` (or __graft_entry__.build()). There is no CPU fallback.")
+            "Run `python build_hip.py` (or __graft_entry__.build()). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     vp, u64, i32, f32 = C.c_void_p, C.c_uint64, C.c_int, C.c_float
     dp = C.POINTER(GmvaeDims)
@@ -56,6 +57,7 @@ def _load():
         "gmvae_noise_fill": ([vp, u64, vp, u64, u64, u64, vp, vp], i32),
         "gmvae_cluster_acc": ([vp, vp, i32, i32, i32, vp, vp, vp], i32),
         "gmvae_gemm_test": ([vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+        "gmvae_bench_loop": ([dp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(f32), vp], i32),
         "gmvae_step_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),
     }
     for name, (args, res) in sigs.items():

@@ -1,0 +1,189 @@
+"""Conditional distributions: MLP -> distribution (mirror of scripts/base.py).
+
+Same class names, constructor arguments and methods as the reference
+(``ConditionalNormal`` scripts/base.py:15-83, ``ConditionalBernoulli``
+scripts/base.py:86-146, ``ConditionalCategorical`` scripts/base.py:149-209).
+The MLP runs in the HIP library (Engine.mlp -> gmvae_mlp_forward); the light
+distribution objects below play the role of the tfd.* objects the reference
+returns and are used only by the forward-only auxiliary methods.  The training
+loss does not go through them: it is the fused gmvae_step.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+
+TINY = 1.1754943508222875e-38
+
+
+def _check_relu(fn):
+    if fn is None or fn in (torch.relu, F.relu, "relu") or getattr(fn, "__name__", "") == "relu":
+        return
+    raise NotImplementedError("the HIP kernels fuse ReLU (the reference default, scripts/vae.py:196); "
+                              f"hidden_activation_fn={fn!r} is not supported")
+
+
+def _gen(seed, device):
+    if seed is None:
+        return None
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    return g
+
+
+# ----------------------------------------------------------- distributions
+class MultivariateNormalDiag:
+    """tfd.MultivariateNormalDiag(loc, scale_diag) subset: sample / log_prob / mean."""
+
+    def __init__(self, loc, scale_diag, name="MultivariateNormalDiag"):
+        self.loc, self.scale_diag, self.name = loc, scale_diag, name
+
+    def mean(self, name=None):
+        return self.loc
+
+    def sample(self, sample_shape=(), seed=None, name=None):
+        shape = (sample_shape,) if isinstance(sample_shape, int) else tuple(sample_shape)
+        full = shape + tuple(torch.broadcast_shapes(self.loc.shape, self.scale_diag.shape))
+        eps = torch.randn(full, device=self.loc.device, generator=_gen(seed, self.loc.device))
+        return self.loc + self.scale_diag * eps
+
+    def log_prob(self, z):
+        e = (z - self.loc) / self.scale_diag
+        return (-0.5 * e * e - 0.5 * math.log(2 * math.pi) - torch.log(self.scale_diag)).sum(-1)
+
+
+class IndependentBernoulli:
+    """tfd.Independent(tfd.Bernoulli(logits), 1) subset."""
+
+    def __init__(self, logits, name="Bernoulli"):
+        self.logits, self.name = logits, name
+
+    def mean(self, name=None):
+        return torch.sigmoid(self.logits)
+
+    def sample(self, seed=None):
+        p = torch.sigmoid(self.logits)
+        return torch.rand(p.shape, device=p.device, generator=_gen(seed, p.device)) < p
+
+    def log_prob(self, x):
+        x = x.to(self.logits.dtype)
+        return (x * self.logits - F.softplus(self.logits)).sum(-1)
+
+
+class _Categorical:
+    def __init__(self, logits):
+        self.logits = logits
+
+
+class RelaxedOneHotCategorical:
+    """tfd.RelaxedOneHotCategorical(temperature, logits) subset; ``.distribution.logits``
+    is what scripts/gmvae.py:263,271 reads."""
+
+    def __init__(self, temperature, logits, name="RelaxedOneHotCategorical"):
+        self.temperature, self.logits, self.name = temperature, logits, name
+        self.distribution = _Categorical(logits)
+
+    def sample(self, seed=None, uniform=None):
+        if uniform is None:
+            uniform = torch.rand(self.logits.shape, device=self.logits.device,
+                                 generator=_gen(seed, self.logits.device)).clamp_min(TINY)
+        g = -torch.log(-torch.log(uniform))
+        return torch.softmax((self.logits + g) / self.temperature, -1)
+
+
+class MixtureSameFamily:
+    """tfd.MixtureSameFamily(Categorical(logits), MVNDiag(loc[K,L], scale[K,L])) subset (scripts/vae.py:240-244)."""
+
+    def __init__(self, mixture_logits, loc, scale_diag, name="prior"):
+        self.mixture_logits, self.loc, self.scale_diag, self.name = mixture_logits, loc, scale_diag, name
+
+    def log_prob(self, z):
+        t = (z[..., None, :] - self.loc) / self.scale_diag
+        ln = (-0.5 * t * t - 0.5 * math.log(2 * math.pi) - torch.log(self.scale_diag)).sum(-1)
+        return torch.logsumexp(torch.log_softmax(self.mixture_logits, -1) + ln, -1)
+
+    def sample(self, sample_shape=(), seed=None, name=None):
+        n = sample_shape if isinstance(sample_shape, int) else int(torch.tensor(tuple(sample_shape)).prod())
+        g = _gen(seed, self.loc.device)
+        k = torch.multinomial(torch.softmax(self.mixture_logits, -1), n, replacement=True, generator=g)
+        eps = torch.randn((n, self.loc.shape[1]), device=self.loc.device, generator=g)
+        return self.loc[k] + self.scale_diag[k] * eps
+
+    def mean(self, name=None):
+        return (torch.softmax(self.mixture_logits, -1)[:, None] * self.loc).sum(0)
+
+
+# -------------------------------------------------- conditional networks
+class _Conditional:
+    def __init__(self, size, hidden_layer_sizes, hidden_activation_fn, name):
+        _check_relu(hidden_activation_fn)
+        self._name, self._size = name, size
+        self._hidden = None if hidden_layer_sizes is None else list(hidden_layer_sizes)
+        self._engine = None
+        self._net = None
+
+    def bind(self, engine, net_id):
+        """Attach to the flat parameter buffer (the factories do this; it stands in
+        for Sonnet's lazy variable creation, scripts/base.py:47-60)."""
+        self._engine, self._net = engine, net_id
+        return self
+
+    def _mlp(self, tensor_list):
+        if self._engine is None:
+            raise RuntimeError(f"{self._name}: not bound to an Engine; build models with create_vae/create_gmvae")
+        tensors = list(tensor_list)
+        if self._net == L.NET_ENCODER_GMM:
+            if len(tensors) != 2:
+                raise ValueError("encoder_gmm expects (x, y)")      # concat([x, y], 1), scripts/base.py:66
+            return self._engine.mlp(self._net, tensors[0], tensors[1])
+        if len(tensors) != 1:
+            raise ValueError(f"{self._name} expects one input tensor")
+        return self._engine.mlp(self._net, tensors[0])
+
+
+class ConditionalNormal(_Conditional):
+    def __init__(self, size, hidden_layer_sizes=None, initializers=None, sigma_min=0.0, raw_sigma_bias=0.25,
+                 hidden_activation_fn=torch.relu, name="cond_normal"):
+        super().__init__(size, hidden_layer_sizes, hidden_activation_fn, name)
+        self._sigma_min, self._raw_sigma_bias = sigma_min, raw_sigma_bias
+
+    def condition(self, tensor_list, **unused_kwargs):
+        outs = self._mlp(tensor_list)
+        mu, raw = outs[:, :self._size], outs[:, self._size:]            # tf.split(outs, 2, axis=1)
+        sigma = torch.clamp_min(F.softplus(raw + self._raw_sigma_bias), self._sigma_min)
+        return mu, sigma
+
+    def __call__(self, *args, **kwargs):
+        mu, sigma = self.condition(args, **kwargs)
+        return MultivariateNormalDiag(loc=mu, scale_diag=sigma, name=self._name)
+
+
+class ConditionalBernoulli(_Conditional):
+    def __init__(self, size, hidden_layer_sizes=None, initializers=None, bias_init=0.0,
+                 hidden_activation_fn=torch.relu, name="cond_bernoulli"):
+        super().__init__(size, hidden_layer_sizes, hidden_activation_fn, name)
+        self._bias_init = bias_init
+
+    def condition(self, tensor_list, **unused_kwargs):
+        return self._mlp(tensor_list)        # + bias_init is applied inside gmvae_mlp_forward (gen_bias_init)
+
+    def __call__(self, *args, **kwargs):
+        return IndependentBernoulli(self.condition(args, **kwargs), name=self._name)
+
+
+class ConditionalCategorical(_Conditional):
+    def __init__(self, size, hidden_layer_sizes=None, temperature=1.0, initializers=None,
+                 hidden_activation_fn=torch.relu, name="cond_categorical"):
+        super().__init__(size, hidden_layer_sizes, hidden_activation_fn, name)
+        self._temperature = temperature
+
+    def condition(self, tensor_list, **unused_kwargs):
+        return self._mlp(tensor_list)
+
+    def __call__(self, *args, **kwargs):
+        return RelaxedOneHotCategorical(self._temperature, logits=self.condition(args, **kwargs), name=self._name)

@@ -9,6 +9,13 @@
 // Replaces: snt.nets.MLP MatMul/BiasAdd/Relu nodes (scripts/base.py:47-60,
 // 67,135,198), their TF autodiff counterparts (scripts/runners.py:182) and the
 // Independent(Bernoulli).log_prob expansion (scripts/base.py:143-146).
+//
+// Code-generation rules followed here (cdna_hip_programming.md 5.4 rule 20,
+// 6 G5): every register array is indexed by compile-time constants only, no
+// out-of-line calls, kernel-argument structs never escape by reference, and
+// the staging loads are BRANCH-FREE: out-of-range coordinates are clamped to a
+// valid address and the value is replaced by 0 (or 1 for the bias "ones row")
+// with a select, so edge tiles and K tails run the same code as interior ones.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,7 +25,6 @@ namespace gmvae {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;   // 4 wavefronts of 64
-constexpr int kBK = 32;         // K-chunk staged through LDS
 constexpr int MAXP = 4;         // problems per launch
 
 enum { EPI_STORE = 0, EPI_BERNOULLI = 1 };
@@ -27,6 +33,9 @@ enum { EPI_STORE = 0, EPI_BERNOULLI = 1 };
 //   k_contig: element(mn,k) = ptr[(mn/row_div)*ld + k]      (row-major [mn][k])
 //   else    : element(mn,k) = ptr[(k /row_div)*ld + mn]     (row-major [k][mn])
 // ones_row: logical row mn == n_mn reads 1.0 (folds the bias gradient into dW).
+// vec_ok : 16-byte (fp32) / 4-byte (uint8) loads of 4 consecutive elements are
+//          legal: ld % 4 == 0 and the base is aligned (then every source row
+//          holds pad4(extent) elements along the contiguous dimension).
 struct Operand {
   const void* ptr;
   int ld;
@@ -69,22 +78,24 @@ struct Launch {
   Problem p[MAXP];
 };
 
-template <int BM_, int BN_, int WM_, int WN_, int WK_>
+// BK is sized so that every thread keeps 8 independent loads in flight per
+// staging round (the small configurations are latency-, not MFMA-bound).
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int WK_>
 struct Cfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, WK = WK_;
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_;
   static constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   static constexpr int LDA = BM + 1, LDB = BN + 1, LDC = BN + 4;
-  static constexpr int NSA = BM * kBK / 4 / kThreads, NSB = BN * kBK / 4 / kThreads;
-  static constexpr int OPS = 2 * (LDA + LDB) * kBK;                 // floats, double buffered
+  static constexpr int NSA = BM * BK / 4 / kThreads, NSB = BN * BK / 4 / kThreads;
+  static constexpr int OPS = 2 * (LDA + LDB) * BK;                  // floats, double buffered
   static constexpr int CST = WK * BM * LDC;                          // floats, C staging
   static constexpr int LDS_FLOATS = OPS > CST ? OPS : CST;
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
   static_assert(NSA >= 1 && NSB >= 1, "tile too small for 256 threads");
-  static_assert((kBK / WK) % 2 == 0, "k slice per wave must be even");
+  static_assert((BK / WK) % 2 == 0, "k slice per wave must be even");
 };
-typedef Cfg<32, 32, 1, 1, 4> CfgS;      // latency-bound: 4 waves split K inside the tile
-typedef Cfg<64, 64, 2, 2, 1> CfgM;
-typedef Cfg<128, 128, 2, 2, 1> CfgL;    // MFMA-bound: 64x64 per wave
+typedef Cfg<32, 32, 128, 1, 1, 4> CfgS;     // latency-bound: 4 waves split K inside the tile
+typedef Cfg<64, 64, 64, 2, 2, 1> CfgM;
+typedef Cfg<128, 128, 32, 2, 2, 1> CfgL;    // MFMA-bound: 64x64 per wave
 
 __device__ __forceinline__ float sigmoidf_(float v) {
   float e = __expf(-fabsf(v));
@@ -93,122 +104,145 @@ __device__ __forceinline__ float sigmoidf_(float v) {
 }
 __device__ __forceinline__ float softplusf_(float v) { return fmaxf(v, 0.f) + log1pf(__expf(-fabsf(v))); }
 
-// ---- global -> register slot loads -------------------------------------
+// ---- global -> register staging ------------------------------------------
 // A slot is 4 consecutive elements along the source's contiguous dimension.
-template <int BMN>
-__device__ __forceinline__ void slot_coords(const Operand& op, int s, int& mn, int& k) {
-  if (op.k_contig) {              // 8 slots per row: 8 full 128-byte lines per wave instruction
-    mn = s >> 3;
-    k = (s & 7) << 2;
-  } else {                        // lanes: 4 k-rows x 8 slots -> conflict-free LDS writes with odd LD
-    constexpr int QN = BMN / 4;
-    k = (s & 3) + 4 * (s / (4 * QN));
-    mn = ((s >> 2) % QN) << 2;
-  }
-}
-
-__device__ __forceinline__ float4 load_slot(const Operand& op, int mn, int k, int k_end, const float* kscale) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (op.k_contig) {
-    const long long base = (long long)(mn / op.row_div) * op.ld + k;
-    if (op.vec_ok && mn < op.n_mn && k + 3 < k_end) {
-      if (op.is_u8) {
-        uint32_t w = *reinterpret_cast<const uint32_t*>(static_cast<const unsigned char*>(op.ptr) + base);
-        v = make_float4((float)(w & 0xff), (float)((w >> 8) & 0xff), (float)((w >> 16) & 0xff), (float)(w >> 24));
-      } else {
-        v = *reinterpret_cast<const float4*>(static_cast<const float*>(op.ptr) + base);
-      }
-    } else {
-      float t[4];
+// Thread -> slot map (Q = slots per line of the contiguous dimension): every 32
+// consecutive slot ids cover 4 lines x 8 slots, so a half-wave touches 4 full
+// 128-byte lines in memory AND 32 distinct LDS banks when the [k][mn] image has
+// an odd leading dimension -- for k-contiguous and mn-contiguous sources alike.
+//
+// KIND bits: 1 = uint8 elements, 2 = mn-contiguous (else k-contiguous),
+//            4 = element-wise loads (source not 16-byte vectorisable).
+template <int KIND, int BMN, int BK, int NS>
+__device__ __forceinline__ void op_load(const void* __restrict__ base, const int ld, const int n_mn, const int ones,
+                                        const int row_div, const float* __restrict__ kscale, const int K,
+                                        const int mn0, const int k0, const int kend, const int tid, float4 (&r)[NS]) {
+  constexpr bool U8 = (KIND & 1) != 0, MC = (KIND & 2) != 0, SC = (KIND & 4) != 0;
+  const unsigned char* b8 = static_cast<const unsigned char*>(base);
+  const float* b32 = static_cast<const float*>(base);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        t[j] = 0.f;
-        if (k + j < k_end) {
-          if (mn < op.n_mn)
-            t[j] = op.is_u8 ? (float)static_cast<const unsigned char*>(op.ptr)[base + j]
-                            : static_cast<const float*>(op.ptr)[base + j];
-          else if (op.ones_row && mn == op.n_mn)
-            t[j] = 1.f;
-        }
-      }
-      v = make_float4(t[0], t[1], t[2], t[3]);
-    }
-    if (kscale) {
-      if (k + 0 < k_end) v.x *= kscale[k + 0];
-      if (k + 1 < k_end) v.y *= kscale[k + 1];
-      if (k + 2 < k_end) v.z *= kscale[k + 2];
-      if (k + 3 < k_end) v.w *= kscale[k + 3];
-    }
-  } else {
-    if (k < k_end) {
-      const long long base = (long long)(k / op.row_div) * op.ld + mn;
-      if (op.vec_ok && mn + 3 < op.n_mn) {
-        if (op.is_u8) {
-          uint32_t w = *reinterpret_cast<const uint32_t*>(static_cast<const unsigned char*>(op.ptr) + base);
-          v = make_float4((float)(w & 0xff), (float)((w >> 8) & 0xff), (float)((w >> 16) & 0xff), (float)(w >> 24));
+  for (int i = 0; i < NS; ++i) {
+    const int s = tid + i * kThreads;
+    float v[4];
+    if (!MC) {
+      constexpr int Q = BK / 4;
+      const int mn = mn0 + (s & 3) + 4 * (s / (4 * Q));
+      const int k = k0 + (((s >> 2) % Q) << 2);
+      const int mnc = min(mn, n_mn - 1);
+      const int row = (row_div == 1) ? mnc : mnc / row_div;
+      const uint32_t rb = (uint32_t)row * (uint32_t)ld;
+      if (!SC) {
+        const uint32_t e = rb + (uint32_t)min(k, ((K + 3) & ~3) - 4);
+        if (U8) {
+          const uint32_t w = *reinterpret_cast<const uint32_t*>(b8 + e);
+          v[0] = (float)(w & 0xff); v[1] = (float)((w >> 8) & 0xff); v[2] = (float)((w >> 16) & 0xff); v[3] = (float)(w >> 24);
         } else {
-          v = *reinterpret_cast<const float4*>(static_cast<const float*>(op.ptr) + base);
+          const float4 q = *reinterpret_cast<const float4*>(b32 + e);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
         }
       } else {
-        float t[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          t[j] = 0.f;
-          if (mn + j < op.n_mn)
-            t[j] = op.is_u8 ? (float)static_cast<const unsigned char*>(op.ptr)[base + j]
-                            : static_cast<const float*>(op.ptr)[base + j];
-          else if (op.ones_row && mn + j == op.n_mn)
-            t[j] = 1.f;
+          const uint32_t e = rb + (uint32_t)min(k + j, K - 1);
+          v[j] = U8 ? (float)b8[e] : b32[e];
         }
-        v = make_float4(t[0], t[1], t[2], t[3]);
       }
-      if (kscale) {
-        const float sc = kscale[k];
-        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = (k + j < kend) ? v[j] : 0.f;
+        if (kscale) x *= kscale[min(k + j, K - 1)];
+        v[j] = x;
+      }
+    } else {
+      constexpr int Q = BMN / 4;
+      const int k = k0 + (s & 3) + 4 * (s / (4 * Q));
+      const int mn = mn0 + (((s >> 2) % Q) << 2);
+      const int kc = min(k, K - 1);
+      const int row = (row_div == 1) ? kc : kc / row_div;
+      const uint32_t rb = (uint32_t)row * (uint32_t)ld;
+      if (!SC) {
+        const uint32_t e = rb + (uint32_t)min(mn, ((n_mn + 3) & ~3) - 4);
+        if (U8) {
+          const uint32_t w = *reinterpret_cast<const uint32_t*>(b8 + e);
+          v[0] = (float)(w & 0xff); v[1] = (float)((w >> 8) & 0xff); v[2] = (float)((w >> 16) & 0xff); v[3] = (float)(w >> 24);
+        } else {
+          const float4 q = *reinterpret_cast<const float4*>(b32 + e);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t e = rb + (uint32_t)min(mn + j, n_mn - 1);
+          v[j] = U8 ? (float)b8[e] : b32[e];
+        }
+      }
+      const bool kin = k < kend;
+      const float sc = kscale ? kscale[kc] : 1.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // rows mn > n_mn of a ones-row operand feed C rows that are never stored; for plain operands
+        // columns/rows beyond the extent likewise only reach unstored outputs -- but they must not be
+        // NaN-producing garbage for the Bernoulli row sums, which mask by column explicitly.
+        float x = (ones && mn + j == n_mn) ? 1.f : v[j];
+        v[j] = kin ? x * sc : 0.f;
       }
     }
+    r[i] = make_float4(v[0], v[1], v[2], v[3]);
   }
-  return v;
 }
 
 // LDS image of an operand tile is always [k][mn] with an odd leading dimension.
-template <int LD>
-__device__ __forceinline__ void store_slot(float* T, bool k_contig, int mn, int k, float4 v) {
-  if (k_contig) {
-    T[(k + 0) * LD + mn] = v.x;
-    T[(k + 1) * LD + mn] = v.y;
-    T[(k + 2) * LD + mn] = v.z;
-    T[(k + 3) * LD + mn] = v.w;
-  } else {
-    float* p = T + k * LD + mn;
-    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+template <int BMN, int BK, int LD, int NS>
+__device__ __forceinline__ void op_store(float* __restrict__ T, const bool mc, const int tid, const float4 (&r)[NS]) {
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int s = tid + i * kThreads;
+    if (!mc) {
+      constexpr int Q = BK / 4;
+      const int mn = (s & 3) + 4 * (s / (4 * Q)), k = ((s >> 2) % Q) << 2;
+      float* p = T + k * LD + mn;
+      p[0] = r[i].x; p[LD] = r[i].y; p[2 * LD] = r[i].z; p[3 * LD] = r[i].w;
+    } else {
+      constexpr int Q = BMN / 4;
+      const int k = (s & 3) + 4 * (s / (4 * Q)), mn = ((s >> 2) % Q) << 2;
+      float* p = T + k * LD + mn;
+      p[0] = r[i].x; p[1] = r[i].y; p[2] = r[i].z; p[3] = r[i].w;
+    }
   }
+}
+
+__device__ __forceinline__ int op_kind(const unsigned char is_u8, const unsigned char k_contig,
+                                       const unsigned char vec_ok) {
+  return (is_u8 ? 1 : 0) | (k_contig ? 0 : 2) | (vec_ok ? 0 : 4);
 }
 
 template <class C>
 __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
-  __shared__ float lds[C::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  constexpr int kBK = C::BK;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   int pi = 0;
-  for (int i = 1; i < L.nprob; ++i)
-    if ((int)blockIdx.x >= L.p[i].tile_begin) pi = i;
-  const Problem& P = L.p[pi];
+#pragma unroll
+  for (int i = 1; i < MAXP; ++i)
+    if (i < L.nprob && (int)blockIdx.x >= L.p[i].tile_begin) pi = i;
 
-  int t = blockIdx.x - P.tile_begin;
-  const int split = t % P.splits;
-  t /= P.splits;
-  const int tn = t % P.tiles_n;
-  const int tm = t / P.tiles_n;
+  int t = blockIdx.x - L.p[pi].tile_begin;
+  const int splits = L.p[pi].splits;
+  const int split = t % splits;
+  t /= splits;
+  const int tiles_n = L.p[pi].tiles_n;
+  const int tn = t % tiles_n;
+  const int tm = t / tiles_n;
   const int m0 = tm * C::BM, n0 = tn * C::BN;
 
-  // wave placement inside the tile
   const int wk = wave / (C::WM * C::WN);
   const int wmn = wave % (C::WM * C::WN);
   const int wm0 = (wmn / C::WN) * (C::TM * 32);
   const int wn0 = (wmn % C::WN) * (C::TN * 32);
+  const int khalf = lane >> 5, l31 = lane & 31;
 
   f32x16 acc[C::TM][C::TN];
 #pragma unroll
@@ -218,174 +252,203 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // chunk schedule over (segment, k-range of this split)
-  int kb[2], ke[2], nc[2] = {0, 0};
-  for (int s = 0; s < P.nseg; ++s) {
-    const int K = P.seg[s].K;
-    int kper = (K + P.splits - 1) / P.splits;
+  const int nseg = L.p[pi].nseg;
+#pragma unroll 1
+  for (int sgi = 0; sgi < nseg; ++sgi) {
+    // segment descriptor -> scalars (nothing below takes a reference into the kernel arguments)
+    const void* a_ptr = L.p[pi].seg[sgi].a.ptr;
+    const int a_ld = L.p[pi].seg[sgi].a.ld, a_n = L.p[pi].seg[sgi].a.n_mn, a_div = L.p[pi].seg[sgi].a.row_div;
+    const int a_ones = L.p[pi].seg[sgi].a.ones_row;
+    const bool a_mc = !L.p[pi].seg[sgi].a.k_contig;
+    const int akind = op_kind(L.p[pi].seg[sgi].a.is_u8, L.p[pi].seg[sgi].a.k_contig, L.p[pi].seg[sgi].a.vec_ok);
+    const void* b_ptr = L.p[pi].seg[sgi].b.ptr;
+    const int b_ld = L.p[pi].seg[sgi].b.ld, b_n = L.p[pi].seg[sgi].b.n_mn, b_div = L.p[pi].seg[sgi].b.row_div;
+    const bool b_mc = !L.p[pi].seg[sgi].b.k_contig;
+    const int bkind = op_kind(0, L.p[pi].seg[sgi].b.k_contig, L.p[pi].seg[sgi].b.vec_ok);
+    const float* kscale = L.p[pi].seg[sgi].kscale;
+    const int K = L.p[pi].seg[sgi].K;
+
+    int kper = (K + splits - 1) / splits;
     kper = (kper + kBK - 1) / kBK * kBK;
-    kb[s] = split * kper < K ? split * kper : K;
-    ke[s] = kb[s] + kper < K ? kb[s] + kper : K;
-    nc[s] = (ke[s] - kb[s] + kBK - 1) / kBK;
+    const int kb = split * kper < K ? split * kper : K;
+    const int ke = kb + kper < K ? kb + kper : K;
+    const int NC = (ke - kb + kBK - 1) / kBK;
+    if (NC == 0) continue;
+
+    float4 ra[C::NSA], rb[C::NSB];
+#define GMVAE_LOAD_A(KIND) \
+  op_load<KIND, C::BM, kBK, C::NSA>(a_ptr, a_ld, a_n, a_ones, a_div, nullptr, K, m0, k0_, ke, tid, ra)
+#define GMVAE_LOAD_B(KIND) \
+  op_load<KIND, C::BN, kBK, C::NSB>(b_ptr, b_ld, b_n, 0, b_div, kscale, K, n0, k0_, ke, tid, rb)
+#define GMVAE_GLOAD(c_)                                                     \
+  {                                                                         \
+    const int k0_ = kb + (c_) * kBK;                                        \
+    switch (akind) {                                                        \
+      case 0: GMVAE_LOAD_A(0); break;                                       \
+      case 1: GMVAE_LOAD_A(1); break;                                       \
+      case 2: GMVAE_LOAD_A(2); break;                                       \
+      case 3: GMVAE_LOAD_A(3); break;                                       \
+      case 4: GMVAE_LOAD_A(4); break;                                       \
+      case 5: GMVAE_LOAD_A(5); break;                                       \
+      case 6: GMVAE_LOAD_A(6); break;                                       \
+      default: GMVAE_LOAD_A(7); break;                                      \
+    }                                                                       \
+    switch (bkind) {                                                        \
+      case 0: GMVAE_LOAD_B(0); break;                                       \
+      case 2: GMVAE_LOAD_B(2); break;                                       \
+      case 4: GMVAE_LOAD_B(4); break;                                       \
+      default: GMVAE_LOAD_B(6); break;                                      \
+    }                                                                       \
   }
-  const int NC = nc[0] + (P.nseg > 1 ? nc[1] : 0);
-
-  float4 ra[C::NSA], rb[C::NSB];
-  bool a_kc = true, b_kc = false;
-
-  auto gload = [&](int c) {
-    const int s = (c < nc[0]) ? 0 : 1;
-    const Segment& sg = P.seg[s];
-    const int k0 = kb[s] + (s ? c - nc[0] : c) * kBK;
-    a_kc = sg.a.k_contig;
-    b_kc = sg.b.k_contig;
-#pragma unroll
-    for (int i = 0; i < C::NSA; ++i) {
-      int mn, k;
-      slot_coords<C::BM>(sg.a, tid + i * kThreads, mn, k);
-      ra[i] = load_slot(sg.a, m0 + mn, k0 + k, ke[s], nullptr);
-    }
-#pragma unroll
-    for (int i = 0; i < C::NSB; ++i) {
-      int mn, k;
-      slot_coords<C::BN>(sg.b, tid + i * kThreads, mn, k);
-      rb[i] = load_slot(sg.b, n0 + mn, k0 + k, ke[s], sg.kscale);
-    }
-  };
-  auto lstore = [&](int buf, int c) {
-    const int s = (c < nc[0]) ? 0 : 1;
-    const Segment& sg = P.seg[s];
-    float* As = lds + buf * (C::LDA + C::LDB) * kBK;
-    float* Bs = As + C::LDA * kBK;
-#pragma unroll
-    for (int i = 0; i < C::NSA; ++i) {
-      int mn, k;
-      slot_coords<C::BM>(sg.a, tid + i * kThreads, mn, k);
-      store_slot<C::LDA>(As, a_kc, mn, k, ra[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < C::NSB; ++i) {
-      int mn, k;
-      slot_coords<C::BN>(sg.b, tid + i * kThreads, mn, k);
-      store_slot<C::LDB>(Bs, b_kc, mn, k, rb[i]);
-    }
-  };
-
-  if (NC > 0) {
-    gload(0);
-    lstore(0, 0);
+#define GMVAE_LSTORE(buf_)                                                  \
+  {                                                                         \
+    float* As_ = lds + (buf_) * (C::LDA + C::LDB) * kBK;                    \
+    float* Bs_ = As_ + C::LDA * kBK;                                        \
+    op_store<C::BM, kBK, C::LDA, C::NSA>(As_, a_mc, tid, ra);               \
+    op_store<C::BN, kBK, C::LDB, C::NSB>(Bs_, b_mc, tid, rb);               \
   }
-  __syncthreads();
-  const int khalf = lane >> 5, l31 = lane & 31;
-  for (int c = 0; c < NC; ++c) {
-    if (c + 1 < NC) gload(c + 1);
-    const float* As = lds + (c & 1) * (C::LDA + C::LDB) * kBK;
-    const float* Bs = As + C::LDA * kBK;
-    constexpr int KW = kBK / C::WK;
-#pragma unroll
-    for (int kk = 0; kk < KW; kk += 2) {
-      const int krow = wk * KW + kk + khalf;
-      float a[C::TM], b[C::TN];
-#pragma unroll
-      for (int i = 0; i < C::TM; ++i) a[i] = As[krow * C::LDA + wm0 + i * 32 + l31];
-#pragma unroll
-      for (int j = 0; j < C::TN; ++j) b[j] = Bs[krow * C::LDB + wn0 + j * 32 + l31];
-#pragma unroll
-      for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (c + 1 < NC) lstore((c + 1) & 1, c + 1);
+
+    __syncthreads();          // LDS is free (first segment: trivially; second: previous loop finished)
+    GMVAE_GLOAD(0);
+    GMVAE_LSTORE(0);
     __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < NC; ++c) {
+      if (c + 1 < NC) GMVAE_GLOAD(c + 1);
+      const float* As = lds + (c & 1) * (C::LDA + C::LDB) * kBK;
+      const float* Bs = As + C::LDA * kBK;
+      constexpr int KW = kBK / C::WK;
+#pragma unroll
+      for (int kk = 0; kk < KW; kk += 2) {
+        const int krow = wk * KW + kk + khalf;
+        float a[C::TM], b[C::TN];
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) a[i] = As[krow * C::LDA + wm0 + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) b[j] = Bs[krow * C::LDB + wn0 + j * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < C::TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (c + 1 < NC) GMVAE_LSTORE((c + 1) & 1);
+      __syncthreads();
+    }
+#undef GMVAE_LOAD_A
+#undef GMVAE_LOAD_B
+#undef GMVAE_GLOAD
+#undef GMVAE_LSTORE
   }
 
   // ---- stage the accumulators to LDS in row-major [BM][LDC] (one image per k-wave)
-  float* Cs = lds + wk * C::BM * C::LDC;
+  __syncthreads();
+  {
+    float* Cs = lds + wk * C::BM * C::LDC;
 #pragma unroll
-  for (int i = 0; i < C::TM; ++i)
+    for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-    for (int j = 0; j < C::TN; ++j)
+      for (int j = 0; j < C::TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        Cs[row * C::LDC + wn0 + j * 32 + l31] = acc[i][j][r];
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+          Cs[row * C::LDC + wn0 + j * 32 + l31] = acc[i][j][r];
+        }
+  }
   __syncthreads();
 
   // ---- epilogue: each thread owns float4 groups of a row
+  const int M = L.p[pi].M, N = L.p[pi].N, ldc = L.p[pi].ldc, epi = L.p[pi].epi;
+  float* Cout = L.p[pi].C;
+  const float* bias = L.p[pi].bias;
+  const float addconst = L.p[pi].addconst;
   constexpr int GPR = C::BN / 4;                 // groups per row (8, 16 or 32 consecutive lanes)
   constexpr int PASSES = C::BM * GPR / kThreads;
-  const long long soff = (long long)split * P.split_stride;
+  if (epi == EPI_STORE) {
+    float* bias_row_out = L.p[pi].bias_row_out;
+    const float* addsrc = L.p[pi].addsrc;
+    const float* mask = L.p[pi].mask;
+    const float* rowscale = L.p[pi].rowscale;
+    const int relu = L.p[pi].relu, ld_add = L.p[pi].ld_add, add_div = L.p[pi].add_div, ld_mask = L.p[pi].ld_mask;
+    const long long soff = (long long)split * L.p[pi].split_stride;
 #pragma unroll 1
-  for (int ps = 0; ps < PASSES; ++ps) {
-    const int gidx = tid + ps * kThreads;
-    const int row = gidx / GPR, c4 = gidx % GPR;
-    float4 v4 = *reinterpret_cast<const float4*>(lds + row * C::LDC + 4 * c4);
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int gidx = tid + ps * kThreads;
+      const int row = gidx / GPR, c4 = gidx % GPR;
+      float4 v4 = *reinterpret_cast<const float4*>(lds + row * C::LDC + 4 * c4);
 #pragma unroll
-    for (int w = 1; w < C::WK; ++w) {
-      const float4 o = *reinterpret_cast<const float4*>(lds + (w * C::BM + row) * C::LDC + 4 * c4);
-      v4.x += o.x; v4.y += o.y; v4.z += o.z; v4.w += o.w;
-    }
-    float v[4] = {v4.x, v4.y, v4.z, v4.w};
-    const int m = m0 + row, nb = n0 + 4 * c4;
-    const bool mrow = m < P.M;
-
-    if (P.epi == EPI_STORE) {
-      if (mrow) {
-        float* dst;
-        if (P.bias_row_out && m == P.M - 1) dst = P.bias_row_out + soff + nb;
-        else dst = P.C + soff + (long long)m * P.ldc + nb;
-        const float rs = P.rowscale ? P.rowscale[m] : 1.f;
+      for (int w = 1; w < C::WK; ++w) {
+        const float4 o = *reinterpret_cast<const float4*>(lds + (w * C::BM + row) * C::LDC + 4 * c4);
+        v4.x += o.x; v4.y += o.y; v4.z += o.z; v4.w += o.w;
+      }
+      const int m = m0 + row, nb = n0 + 4 * c4;
+      if (m < M && nb < N) {
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        float* dst = (bias_row_out && m == M - 1) ? bias_row_out + soff + nb : Cout + soff + (long long)m * ldc + nb;
+        const float rs = rowscale ? rowscale[m] : 1.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int n = nb + j;
-          if (n < P.N) {
-            float x = v[j];
-            if (P.bias) x += P.bias[n];
-            if (P.addsrc) x += P.addsrc[(long long)(m / P.add_div) * P.ld_add + n];
-            x += P.addconst;
-            if (P.relu) x = fmaxf(x, 0.f);
-            if (P.mask) x = P.mask[(long long)m * P.ld_mask + n] > 0.f ? x : 0.f;
-            v[j] = x * rs;
-          }
+          const int n = min(nb + j, N - 1);
+          float x = v[j];
+          if (bias) x += bias[n];
+          if (addsrc) x += addsrc[(long long)(m / add_div) * ld_add + n];
+          x += addconst;
+          if (relu) x = fmaxf(x, 0.f);
+          if (mask) x = mask[(long long)m * ld_mask + n] > 0.f ? x : 0.f;
+          v[j] = x * rs;
         }
-        if (nb + 3 < P.N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        if (nb + 3 < N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
           *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (nb + j < P.N) dst[j] = v[j];
+          dst[0] = v[0];
+          if (nb + 1 < N) dst[1] = v[1];
+          if (nb + 2 < N) dst[2] = v[2];
+          if (nb + 3 < N) dst[3] = v[3];
         }
       }
-    } else {  // EPI_BERNOULLI: lambda -> (sigmoid(lambda) - x, sum_d x*lambda - softplus(lambda))
+    }
+  } else {  // EPI_BERNOULLI: lambda -> (sigmoid(lambda) - x, sum_d x*lambda - softplus(lambda))
+    const unsigned char* xp = L.p[pi].x;
+    float* part = L.p[pi].part;
+    const int ldx = L.p[pi].ldx, x_div = L.p[pi].x_div, nparts = L.p[pi].nparts;
+#pragma unroll 1
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int gidx = tid + ps * kThreads;
+      const int row = gidx / GPR, c4 = gidx % GPR;
+      float4 v4 = *reinterpret_cast<const float4*>(lds + row * C::LDC + 4 * c4);
+#pragma unroll
+      for (int w = 1; w < C::WK; ++w) {
+        const float4 o = *reinterpret_cast<const float4*>(lds + (w * C::BM + row) * C::LDC + 4 * c4);
+        v4.x += o.x; v4.y += o.y; v4.z += o.z; v4.w += o.w;
+      }
+      const int m = m0 + row, nb = n0 + 4 * c4;
       float rsum = 0.f;
-      if (mrow) {
-        const unsigned char* xr = P.x + (long long)(m / P.x_div) * P.ldx;
+      if (m < M && nb < N) {
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const unsigned char* xr = xp + (long long)(m / x_div) * ldx;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int n = nb + j;
-          if (n < P.N) {
-            const float lam = v[j] + P.bias[n] + P.addconst;
-            const float xv = (float)xr[n];
-            rsum += xv * lam - softplusf_(lam);
-            v[j] = sigmoidf_(lam) - xv;
-          }
+          const int n = min(nb + j, N - 1);
+          const float lam = v[j] + bias[n] + addconst;
+          const float xv = (float)xr[n];
+          rsum += (nb + j < N) ? xv * lam - softplusf_(lam) : 0.f;
+          v[j] = sigmoidf_(lam) - xv;
         }
-        if (P.C) {
-          float* dst = P.C + (long long)m * P.ldc + nb;
-          if (nb + 3 < P.N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        if (Cout) {
+          float* dst = Cout + (long long)m * ldc + nb;
+          if (nb + 3 < N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
             *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (nb + j < P.N) dst[j] = v[j];
+            dst[0] = v[0];
+            if (nb + 1 < N) dst[1] = v[1];
+            if (nb + 2 < N) dst[2] = v[2];
+            if (nb + 3 < N) dst[3] = v[3];
           }
         }
       }
 #pragma unroll
       for (int o = GPR / 2; o > 0; o >>= 1) rsum += __shfl_xor(rsum, o, 64);
-      if (mrow && c4 == 0) P.part[(long long)m * P.nparts + tn] = rsum;
+      if (m < M && c4 == 0) part[(long long)m * nparts + tn] = rsum;
     }
   }
 }

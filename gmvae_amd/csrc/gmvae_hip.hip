@@ -232,6 +232,7 @@ struct Ctx {
   Prof* prof = nullptr;
   int err = 0;
   int force_cfg = -1;
+  Ctx() { (void)hipGetLastError(); }   // drop any stale error another library left on this thread
   void mark(const char* name, double flops) {
     if (!prof || !prof->active || prof->n >= MAX_LEVELS) return;
     snprintf(prof->name[prof->n], sizeof(prof->name[0]), "%s", name);
@@ -623,6 +624,7 @@ int adam_tf_step(float* params, float* m, float* v, const float* grads, uint64_t
   if (!params || !m || !v || !grads) return GMVAE_E_NULL;
   if (P == 0) return GMVAE_E_DIMS;
   if (!aligned16(params) || !aligned16(m) || !aligned16(v) || !aligned16(grads)) return GMVAE_E_ALIGN;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(adam_tf, dim3((unsigned)(((P + 3) / 4 + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), params, m, v, grads, (long long)P, lr, beta1, beta2, epsilon, t,
                      t_dev, grad_scale, grad_scale_dev);
@@ -634,6 +636,7 @@ int gmvae_noise_fill(float* eps, uint64_t n_eps, float* u, uint64_t n_u, uint64_
   if ((!eps && n_eps) || (!u && n_u)) return GMVAE_E_NULL;
   const uint64_t q = (n_eps + 3) / 4 + (n_u + 3) / 4;
   if (q == 0) return 0;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(noise_fill, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      eps, n_eps, u, n_u, seed, step, step_dev);
   return (int)hipGetLastError();
@@ -700,6 +703,7 @@ int gmvae_cluster_acc(const float* logits, const int64_t* labels, int B, int K, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   int32_t* hist = scratch;
   int32_t* pred = scratch + (size_t)K * n_labels;
+  (void)hipGetLastError();
   hipError_t e = hipMemsetAsync(hist, 0, sizeof(int32_t) * K * n_labels, st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(cluster_hist, dim3((B + 255) / 256), dim3(256), 0, st, logits, labels, B, K, n_labels, hist, pred);
@@ -764,6 +768,66 @@ int gmvae_step_profile(const GmvaeDims* dims, int model, const uint8_t* x, const
   }
   for (int i = 0; i <= MAX_LEVELS; ++i) hipEventDestroy(pr->ev[i]);
   delete pr;
+  return rc;
+}
+
+/* measurement hook: `iters` full training steps (gmvae_step + adam_tf_step) issued from C on `stream`,
+ * timed with hipEvents.  mode 0: eager launches; mode 1: one hipGraph (captured once here) replayed. */
+int gmvae_bench_loop(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
+                     float* grads, void* workspace, uint64_t* step_dev, int iters, int mode, float* usec_per_step,
+                     void* stream) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!x || !params || !m || !v || !grads || !workspace || !step_dev || !usec_per_step) return GMVAE_E_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Layout L;
+  build_layout(*dims, model, L);
+  auto one = [&](hipStream_t s) -> int {
+    int rc = gmvae_step(dims, model, x, nullptr, nullptr, params, grads, workspace, 1234, 0, step_dev, s);
+    if (rc) return rc;
+    return adam_tf_step(params, m, v, grads, L.P_pad, 1e-3f, 0.9f, 0.999f, 1e-8f, 0, step_dev, 1.f,
+                        grads + L.P_pad + 4, s);
+  };
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  int rc = one(st);
+  hipStreamSynchronize(st);
+  if (rc) return rc;
+  if (mode == 0) {
+    hipEventRecord(e0, st);
+    for (int i = 0; i < iters && rc == 0; ++i) rc = one(st);
+    hipEventRecord(e1, st);
+  } else {
+    hipStream_t cs;
+    hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    rc = one(cs);
+    hipError_t he = hipStreamEndCapture(cs, &g);
+    if (rc == 0 && he != hipSuccess) rc = (int)he;
+    if (rc == 0) {
+      he = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+      if (he != hipSuccess) rc = (int)he;
+    }
+    if (rc == 0) {
+      hipGraphLaunch(ge, cs);
+      hipStreamSynchronize(cs);
+      hipEventRecord(e0, cs);
+      for (int i = 0; i < iters; ++i) hipGraphLaunch(ge, cs);
+      hipEventRecord(e1, cs);
+      hipStreamSynchronize(cs);
+      hipGraphExecDestroy(ge);
+      hipGraphDestroy(g);
+    }
+    hipStreamDestroy(cs);
+  }
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  *usec_per_step = ms * 1000.f / (float)iters;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
   return rc;
 }
 

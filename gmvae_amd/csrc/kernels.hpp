@@ -467,29 +467,33 @@ __global__ void adam_tf(float* __restrict__ p, float* __restrict__ m, float* __r
                         uint64_t t, const uint64_t* t_dev, float gscale, const float* gscale_dev) {
   if (t_dev) t = *t_dev;
   if (gscale_dev) gscale = 1.f / *gscale_dev;
-  const float lr_t = lr * sqrtf(1.f - powf(b2, (float)t)) / (1.f - powf(b1, (float)t));
+  // TF's ApplyAdam functor, in its own fp32 form (tensorflow/core/kernels/training_ops.cc):
+  //   alpha = lr*sqrt(1-b2^t)/(1-b1^t); m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); var -= m*alpha/(sqrt(v)+eps)
+  const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+  const float omb1 = 1.f - b1, omb2 = 1.f - b2;
   const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i4 + 3 < P) {
     float4 pp = *reinterpret_cast<float4*>(p + i4), mm = *reinterpret_cast<float4*>(m + i4),
            vv = *reinterpret_cast<float4*>(v + i4);
     const float4 gg = *reinterpret_cast<const float4*>(g + i4);
-    float* pa = &pp.x; float* ma = &mm.x; float* va = &vv.x; const float* ga = &gg.x;
+    float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+    const float ga[4] = {gg.x, gg.y, gg.z, gg.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gj = ga[j] * gscale;
-      ma[j] = b1 * ma[j] + (1.f - b1) * gj;
-      va[j] = b2 * va[j] + (1.f - b2) * gj * gj;
-      pa[j] -= lr_t * ma[j] / (sqrtf(va[j]) + eps);
+      ma[j] += (gj - ma[j]) * omb1;
+      va[j] += (gj * gj - va[j]) * omb2;
+      pa[j] -= ma[j] * lr_t / (sqrtf(va[j]) + eps);
     }
-    *reinterpret_cast<float4*>(p + i4) = pp;
-    *reinterpret_cast<float4*>(m + i4) = mm;
-    *reinterpret_cast<float4*>(v + i4) = vv;
+    *reinterpret_cast<float4*>(p + i4) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    *reinterpret_cast<float4*>(m + i4) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+    *reinterpret_cast<float4*>(v + i4) = make_float4(va[0], va[1], va[2], va[3]);
   } else {
     for (long long i = i4; i < P; ++i) {
       const float gj = g[i] * gscale;
-      m[i] = b1 * m[i] + (1.f - b1) * gj;
-      v[i] = b2 * v[i] + (1.f - b2) * gj * gj;
-      p[i] -= lr_t * m[i] / (sqrtf(v[i]) + eps);
+      m[i] += (gj - m[i]) * omb1;
+      v[i] += (gj * gj - v[i]) * omb2;
+      p[i] -= m[i] * lr_t / (sqrtf(v[i]) + eps);
     }
   }
 }

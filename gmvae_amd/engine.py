@@ -1,0 +1,284 @@
+"""Host-side owner of the flat parameter buffer and driver of the HIP step.
+
+Python / PyTorch here is plumbing only (device memory, streams, RCCL via
+torch.distributed, hipGraph capture through torch.cuda.graph).  All arithmetic
+of the hot path happens inside libgmvae_hip.so; there is no CPU fallback.
+
+Replaces, for one device: the TF graph that scripts/runners.py:162-185 builds
+(model -> loss -> AdamOptimizer.compute_gradients / apply_gradients) and the
+``sess.run([train_op, global_step])`` of scripts/runners.py:231-232.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+class _ElboFn(torch.autograd.Function):
+    """loss = mean_b loss_b with d loss / d params delivered by the fused HIP
+    forward+backward (the backward pass has already run when this returns)."""
+
+    @staticmethod
+    def forward(ctx, params, engine, x, eps, u):
+        buf = engine.step(x, eps, u)
+        P = engine.P
+        ctx.engine_buf = buf
+        ctx.P = P
+        return buf[P] / buf[P + 4]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        buf, P = ctx.engine_buf, ctx.P
+        return buf[:P] * (grad_out / buf[P + 4]), None, None, None, None
+
+
+class Engine:
+    def __init__(self, model: str, data_size: int, latent_size: int, mixture_components: int,
+                 hidden: Sequence[int], n_samples: int = 1, sigma_min: float = 0.0, raw_sigma_bias: float = 0.5,
+                 temperature: float = 1.0, gen_bias_init: float = 0.0, random_seed: Optional[int] = None):
+        self.device = L.require_gpu()
+        self.model_name = model
+        self.model = L.MODEL_IDS[model]
+        self.D, self.Lz, self.K, self.S = int(data_size), int(latent_size), int(mixture_components), int(n_samples)
+        self.hidden = [int(h) for h in hidden]
+        self.hp = dict(sigma_min=sigma_min, raw_sigma_bias=raw_sigma_bias, temperature=temperature,
+                       gen_bias_init=gen_bias_init)
+        d0 = self.dims(1)
+        self.P, self.P_real = L.param_count(d0, self.model)
+        self.layout = L.param_layout(d0, self.model)
+        self.random_seed = random_seed
+        self.noise_seed = int(random_seed) if random_seed is not None else int(torch.seed() & 0x7FFFFFFFFFFFFFFF)
+        self.params = torch.zeros(self.P, dtype=torch.float32, device=self.device, requires_grad=True)
+        self.grads = torch.zeros(self.P + L.TAIL, dtype=torch.float32, device=self.device)
+        self.m = torch.zeros(self.P, dtype=torch.float32, device=self.device)
+        self.v = torch.zeros(self.P, dtype=torch.float32, device=self.device)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)   # global_step (device resident)
+        self.global_step = 0
+        self._ws: Dict[tuple, tuple] = {}
+        self._graphs: Dict[tuple, tuple] = {}
+        self.init_parameters(random_seed)
+
+    # ------------------------------------------------------------ parameters
+    def dims(self, B: int, S: Optional[int] = None):
+        return L.make_dims(B, self.D, self.Lz, self.K, self.hidden, S=self.S if S is None else S, **self.hp)
+
+    def init_parameters(self, seed: Optional[int] = None):
+        """Xavier-uniform weights, zero biases (scripts/base.py:12); Glorot-uniform
+        prior variables (tf.get_variable default, scripts/vae.py:233-238)."""
+        gen = torch.Generator(device="cpu")
+        if seed is not None:
+            gen.manual_seed(int(seed))
+        else:
+            gen.seed()
+        flat = torch.zeros(self.P, dtype=torch.float32)
+        for name, (rows, cols), off in self.layout:
+            if name.endswith("/b"):
+                continue
+            fan_in, fan_out = (cols, cols) if name == "mixture_logits" else (rows, cols)
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            flat[off:off + rows * cols] = (torch.rand(rows * cols, generator=gen) * 2 - 1) * lim
+        with torch.no_grad():
+            self.params.copy_(flat.to(self.device))
+            self.m.zero_()
+            self.v.zero_()
+            self.step_dev.zero_()
+        self.global_step = 0
+
+    def views(self) -> Dict[str, torch.Tensor]:
+        """Named views of the flat buffer, keyed by the reference's TF variable names."""
+        out = {}
+        for name, (rows, cols), off in self.layout:
+            v = self.params.detach()[off:off + rows * cols]
+            if name.endswith("/b") or name == "mixture_logits":
+                out[name] = v
+            else:
+                out[name] = v.view(rows, cols)
+        return out
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        sd = {k: v.clone() for k, v in self.views().items()}
+        sd["global_step"] = torch.tensor(self.global_step)
+        sd["adam/m"], sd["adam/v"] = self.m.clone(), self.v.clone()
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        views = self.views()
+        with torch.no_grad():
+            for k, v in views.items():
+                v.copy_(sd[k].to(self.device).reshape(v.shape))
+            if "adam/m" in sd:
+                self.m.copy_(sd["adam/m"].to(self.device))
+                self.v.copy_(sd["adam/v"].to(self.device))
+            self.global_step = int(sd.get("global_step", 0))
+            self.step_dev.fill_(self.global_step)
+
+    # ------------------------------------------------------------- workspace
+    def _workspace(self, B: int, S: Optional[int] = None):
+        key = (B, self.S if S is None else S)
+        if key not in self._ws:
+            d = self.dims(B, S)
+            n = L.workspace_bytes(d, self.model)
+            self._ws[key] = (d, torch.zeros(n // 4 + 64, dtype=torch.float32, device=self.device))
+        return self._ws[key]
+
+    @staticmethod
+    def _as_u8(x: torch.Tensor) -> torch.Tensor:
+        if x.dtype == torch.bool:
+            x = x.view(torch.uint8) if x.is_contiguous() else x.to(torch.uint8)
+        elif x.dtype != torch.uint8:
+            x = x.to(torch.uint8)
+        return x.contiguous()
+
+    def _prep_x(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._as_u8(x.to(self.device))
+        x = x.reshape(x.shape[0], -1)           # utils.flatten_tensor (scripts/utils.py:140-141)
+        if x.shape[1] != self.D:
+            raise ValueError(f"expected [B,{self.D}] inputs, got {tuple(x.shape)}")
+        return x
+
+    def _prep_noise(self, t, rows, cols):
+        if t is None:
+            return None
+        t = t.to(self.device, torch.float32).contiguous()
+        if t.numel() != rows * cols:
+            raise ValueError(f"noise must have {rows}x{cols} elements")
+        return t
+
+    # ------------------------------------------------------------------ ops
+    def step(self, x, eps=None, u=None, use_step_dev: bool = False) -> torch.Tensor:
+        """Fused forward + backward.  Returns the [P + TAIL] buffer of gradient
+        SUMS and loss sums (see include/gmvae_hip.h).  eps/u None -> Philox."""
+        x = self._prep_x(x)
+        B = x.shape[0]
+        d, ws = self._workspace(B)
+        eps = self._prep_noise(eps, B * self.S, self.Lz)
+        u = self._prep_noise(u, B * self.S, self.K) if self.model == L.MODEL_GMVAE else None
+        rc = L.lib.gmvae_step(C.byref(d), self.model, L.ptr(x), L.ptr(eps), L.ptr(u), L.ptr(self.params),
+                              L.ptr(self.grads), L.ptr(ws), self.noise_seed, self.global_step,
+                              L.ptr(self.step_dev) if use_step_dev else None, L.current_stream())
+        L.check(rc, "gmvae_step")
+        self._keep = (x, eps, u)
+        return self.grads
+
+    def loss(self, x, eps=None, u=None) -> torch.Tensor:
+        """Differentiable scalar: loss.backward() fills params.grad."""
+        return _ElboFn.apply(self.params, self, x, eps, u)
+
+    def forward(self, x, eps=None, u=None, n_samples: Optional[int] = None):
+        """Forward only.  dict(tail[8], rows[R,4]=(logpx,logq,logp,logw), z, y, logits)."""
+        x = self._prep_x(x)
+        B = x.shape[0]
+        S = self.S if n_samples is None else int(n_samples)
+        d, ws = self._workspace(B, S)
+        R = B * S
+        eps = self._prep_noise(eps, R, self.Lz)
+        gm = self.model == L.MODEL_GMVAE
+        u = self._prep_noise(u, R, self.K) if gm else None
+        f32 = dict(dtype=torch.float32, device=self.device)
+        o = dict(tail=torch.empty(L.TAIL, **f32), rows=torch.empty(R, 4, **f32), z=torch.empty(R, self.Lz, **f32),
+                 y=torch.empty(R, self.K, **f32) if gm else None,
+                 logits=torch.empty(B, self.K, **f32) if gm else None)
+        rc = L.lib.gmvae_forward(C.byref(d), self.model, L.ptr(x), L.ptr(eps), L.ptr(u), L.ptr(self.params),
+                                 L.ptr(o["tail"]), L.ptr(o["rows"]), L.ptr(o["z"]), L.ptr(o["y"]), L.ptr(o["logits"]),
+                                 L.ptr(ws), self.noise_seed, self.global_step, L.current_stream())
+        L.check(rc, "gmvae_forward")
+        return o
+
+    def mlp(self, net: int, inp: torch.Tensor, in2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One conditional network's MLP on the device (snt.nets.MLP, scripts/base.py:47-60)."""
+        is_u8 = inp.dtype in (torch.uint8, torch.bool)
+        inp = self._as_u8(inp.to(self.device)) if is_u8 else inp.to(self.device, torch.float32).contiguous()
+        inp = inp.reshape(inp.shape[0], -1)
+        rows = inp.shape[0]
+        if in2 is not None:
+            in2 = in2.to(self.device, torch.float32).contiguous()
+        d, ws = self._workspace(rows, 1)
+        out_dim = {L.NET_ENCODER_Y: self.K, L.NET_PRIOR_GMM: 2 * self.Lz, L.NET_ENCODER_GMM: 2 * self.Lz,
+                   L.NET_DECODER: self.D, L.NET_ENCODER: 2 * self.Lz}[net]
+        out = torch.empty(rows, out_dim, dtype=torch.float32, device=self.device)
+        rc = L.lib.gmvae_mlp_forward(C.byref(d), self.model, net, L.ptr(inp), int(is_u8), L.ptr(in2), rows,
+                                     L.ptr(self.params), L.ptr(out), L.ptr(ws), L.current_stream())
+        L.check(rc, "gmvae_mlp_forward")
+        return out
+
+    def adam(self, lr: float = 1e-3, beta1=0.9, beta2=0.999, epsilon=1e-8, grads: Optional[torch.Tensor] = None,
+             use_step_dev: bool = False):
+        """TF-formula Adam over the flat buffer; gradient sums are scaled by
+        1/count read from the (possibly all-reduced) tail on the device."""
+        g = self.grads if grads is None else grads
+        if not use_step_dev:
+            self.global_step += 1
+        count = g[self.P + 4:self.P + 5]
+        rc = L.lib.adam_tf_step(L.ptr(self.params), L.ptr(self.m), L.ptr(self.v), L.ptr(g), self.P, lr, beta1, beta2,
+                                epsilon, self.global_step, L.ptr(self.step_dev) if use_step_dev else None, 1.0,
+                                L.ptr(count), L.current_stream())
+        L.check(rc, "adam_tf_step")
+
+    def train_step(self, x, eps=None, u=None, lr: float = 1e-3, all_reduce: bool = True) -> torch.Tensor:
+        """One full reference step: fwd + bwd (+ RCCL all-reduce) + Adam.
+        Returns the [TAIL] loss sums (device tensor; no host sync)."""
+        import torch.distributed as dist
+        self.step(x, eps, u)
+        if all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grads)         # ONE collective: grads + loss sums + count
+        self.adam(lr)
+        return self.grads[self.P:]
+
+    # -------------------------------------------------- hipGraph fast path
+    def capture_train_step(self, B: int, lr: float = 1e-3, all_reduce: bool = False):
+        """Captures noise + fwd + bwd (+ all-reduce) + Adam for batch size B into
+        one hipGraph (torch.cuda.graph).  Returns (static_x, replay)."""
+        import torch.distributed as dist
+        key = (B, lr, all_reduce)
+        if key in self._graphs:
+            return self._graphs[key]
+        static_x = torch.zeros(B, self.D, dtype=torch.uint8, device=self.device)
+        self._workspace(B)
+        self.step_dev.fill_(self.global_step)
+        do_ar = all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):           # warm-up outside capture (lazy module load, RCCL channels)
+            self.step(static_x, use_step_dev=True)
+            if do_ar:
+                dist.all_reduce(self.grads)
+            self.adam(lr, use_step_dev=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.step(static_x, use_step_dev=True)
+            if do_ar:
+                dist.all_reduce(self.grads)
+            self.adam(lr, use_step_dev=True)
+
+        def replay():
+            graph.replay()
+            self.global_step += 1
+
+        self.global_step += 1                    # the warm-up step advanced the device counter
+        self._graphs[key] = (static_x, replay)
+        return self._graphs[key]
+
+    def profile_levels(self, x, iters: int = 20):
+        """Per-launch timing of the step with hipEvents (gmvae_step_profile)."""
+        x = self._prep_x(x)
+        d, ws = self._workspace(x.shape[0])
+        n = C.c_int()
+        names = C.create_string_buffer(96 * 48)
+        usec = (C.c_float * 96)()
+        flops = (C.c_double * 96)()
+        rc = L.lib.gmvae_step_profile(C.byref(d), self.model, L.ptr(x), None, None, L.ptr(self.params),
+                                      L.ptr(self.grads), L.ptr(ws), self.noise_seed, iters, 96, C.byref(n), names,
+                                      usec, flops, L.current_stream())
+        L.check(rc, "gmvae_step_profile")
+        out = []
+        for i in range(n.value):
+            nm = names.raw[i * 48:(i + 1) * 48].split(b"\0")[0].decode()
+            out.append((nm, float(usec[i]), float(flops[i])))
+        return out

@@ -174,6 +174,13 @@ int gmvae_step_profile(const GmvaeDims* dims, int model, const uint8_t* x, const
                        const float* params, float* grads, void* workspace, uint64_t seed, int iters,
                        int max_levels, int* n_levels, char* names, float* usec, double* flops, void* stream);
 
+/* `iters` full training steps (gmvae_step in Philox mode + adam_tf_step) issued from C on `stream` and
+ * timed with hipEvents: mode 0 = eager launches, mode 1 = one hipGraph captured here and replayed.
+ * Synchronises: measurement only. */
+int gmvae_bench_loop(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
+                     float* grads, void* workspace, uint64_t* step_dev, int iters, int mode, float* usec_per_step,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

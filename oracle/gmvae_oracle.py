@@ -313,12 +313,17 @@ def loss_and_grads(model: int, d: Dims, p, x, eps, u=None, dtype=np.float64):
 # --------------------------------------------------------------------------
 def adam_tf_step(theta, m, v, grad, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, dtype=np.float32):
     """t is the 1-based step count AFTER increment.  eps is added to the
-    UN-corrected sqrt(v) (torch.optim.Adam differs)."""
+    UN-corrected sqrt(v) (torch.optim.Adam differs).  Written in the form of
+    TF's ApplyAdam functor (tensorflow/core/kernels/training_ops.cc):
+    m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); var -= m*alpha/(sqrt(v)+eps), with the
+    hyper-parameters held in `dtype` like TF holds them in T (so in fp32
+    1-b2 = 1 - 0.999f, not fp32(0.001))."""
     dt = dtype
-    lr_t = dt(lr) * np.sqrt(dt(1) - dt(b2) ** dt(t)) / (dt(1) - dt(b1) ** dt(t))
-    m = dt(b1) * m + dt(1 - b1) * grad
-    v = dt(b2) * v + dt(1 - b2) * grad * grad
-    theta = theta - lr_t * m / (np.sqrt(v) + dt(eps))
+    fb1, fb2 = dt(b1), dt(b2)
+    alpha = dt(float(lr) * math.sqrt(1.0 - float(fb2) ** t) / (1.0 - float(fb1) ** t))
+    m = m + (grad - m) * (dt(1) - fb1)
+    v = v + (grad * grad - v) * (dt(1) - fb2)
+    theta = theta - m * alpha / (np.sqrt(v) + dt(eps))
     return theta.astype(dt), m.astype(dt), v.astype(dt)
 
 

@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def L():
-    from gmvae_amd import build
-    build.build(verbose=False)
+    import build_hip
+    build_hip.build(verbose=False)
     from gmvae_amd import _lib
     return _lib
 

@@ -39,7 +39,7 @@ def test_gemm_nn(H, cfg, M, N, K, u8):
     W = rng.normal(size=(K, N)).astype(np.float32)
     b = rng.normal(size=N).astype(np.float32)
     Ad, Wd, bd = H.dev(A), H.dev(W), H.dev(b)
-    Cd = torch.full((M, N), float("nan"), device="cuda")
+    Cd = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
     L.check(L.lib.gmvae_gemm_test(L.ptr(Ad), int(u8), L.ptr(Wd), L.ptr(bd), L.ptr(Cd), M, N, K, 0, 1, cfg, 1,
                                   L.current_stream()), "gemm_test")
     ref = np.maximum(A.astype(np.float64) @ W.astype(np.float64) + b, 0)
@@ -54,7 +54,7 @@ def test_gemm_nt(H, cfg, M, N, K):
     A = rng.normal(size=(M, K)).astype(np.float32)
     W = rng.normal(size=(N, K)).astype(np.float32)
     Ad, Wd = H.dev(A), H.dev(W)
-    Cd = torch.full((M, N), float("nan"), device="cuda")
+    Cd = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
     L.check(L.lib.gmvae_gemm_test(L.ptr(Ad), 0, L.ptr(Wd), None, L.ptr(Cd), M, N, K, 1, 0, cfg, 1,
                                   L.current_stream()), "gemm_test")
     ref = A.astype(np.float64) @ W.astype(np.float64).T
@@ -70,7 +70,7 @@ def test_gemm_tn_splitk_bias_row(H, cfg, M, N, K, u8, ns):
     A = (rng.random((K, M)) < 0.5).astype(np.uint8) if u8 else rng.normal(size=(K, M)).astype(np.float32)
     dY = rng.normal(size=(K, N)).astype(np.float32)
     Ad, Yd = H.dev(A), H.dev(dY)
-    Cd = torch.full((ns, M + 1, N), float("nan"), device="cuda")
+    Cd = torch.full((ns, M + 1, N), float("nan"), dtype=torch.float32, device="cuda")
     L.check(L.lib.gmvae_gemm_test(L.ptr(Ad), int(u8), L.ptr(Yd), L.ptr(Yd), L.ptr(Cd), M, N, K, 2, 0, cfg, ns,
                                   L.current_stream()), "gemm_test")
     got = Cd.cpu().numpy().astype(np.float64).sum(axis=0)
@@ -163,31 +163,36 @@ def test_forward_outputs(H):
 
 # ----------------------------------------------------------------- Adam
 def test_adam_tf_three_steps(H):
+    """Against the oracle run in fp32 (TF's own arithmetic type) tightly, and in fp64 loosely."""
     L = _L()
     rng = np.random.default_rng(2)
     P = 1003
     th = rng.normal(size=P).astype(np.float32)
     m = np.zeros(P, np.float32)
     v = np.zeros(P, np.float32)
+    th64, m64, v64 = th.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
     td, md, vd = H.dev(np.pad(th, (0, 1))), H.dev(np.pad(m, (0, 1))), H.dev(np.pad(v, (0, 1)))
     for t in range(1, 4):
         g = (rng.normal(size=P) * (1e-9 if t == 2 else 1.0)).astype(np.float32)
         gd = H.dev(np.pad(g, (0, 1)) * 8.0)
         L.check(L.lib.adam_tf_step(L.ptr(td), L.ptr(md), L.ptr(vd), L.ptr(gd), P, 1e-3, 0.9, 0.999, 1e-8, t, None,
                                    1.0 / 8.0, None, L.current_stream()), "adam")
-        th, m, v = O.adam_tf_step(th.astype(np.float64), m.astype(np.float64), v.astype(np.float64),
-                                  g.astype(np.float64), t, dtype=np.float64)
-    np.testing.assert_allclose(td.cpu().numpy()[:P], th, rtol=2e-6, atol=2e-7)   # fp32 ulp at |theta|~1
-    np.testing.assert_allclose(vd.cpu().numpy()[:P], v, rtol=1e-5, atol=1e-30)
+        th, m, v = O.adam_tf_step(th, m, v, g, t, dtype=np.float32)
+        th64, m64, v64 = O.adam_tf_step(th64, m64, v64, g.astype(np.float64), t, dtype=np.float64)
+    np.testing.assert_allclose(td.cpu().numpy()[:P], th, rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(vd.cpu().numpy()[:P], v, rtol=2e-6, atol=1e-30)
+    np.testing.assert_allclose(md.cpu().numpy()[:P], m, rtol=2e-6, atol=5e-8)    # FMA contraction near m ~ 0
+    np.testing.assert_allclose(td.cpu().numpy()[:P], th64, rtol=1e-4, atol=1e-6)
 
 
 def test_adam_device_counter_and_scale(H):
     L = _L()
     P = 64
-    td, md, vd = torch.ones(P, device="cuda"), torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
-    gd = torch.full((P,), 6.0, device="cuda")
+    f32 = dict(dtype=torch.float32, device="cuda")
+    td, md, vd = torch.ones(P, **f32), torch.zeros(P, **f32), torch.zeros(P, **f32)
+    gd = torch.full((P,), 6.0, **f32)
     tdev = torch.tensor([3], dtype=torch.int64, device="cuda")
-    cnt = torch.tensor([4.0], device="cuda")
+    cnt = torch.tensor([4.0], dtype=torch.float32, device="cuda")
     L.check(L.lib.adam_tf_step(L.ptr(td), L.ptr(md), L.ptr(vd), L.ptr(gd), P, 1e-3, 0.9, 0.999, 1e-8, 999, L.ptr(tdev),
                                123.0, L.ptr(cnt), L.current_stream()), "adam")
     th, _, _ = O.adam_tf_step(np.ones(P), np.zeros(P), np.zeros(P), np.full(P, 1.5), 3, dtype=np.float64)
@@ -198,15 +203,15 @@ def test_adam_device_counter_and_scale(H):
 def test_philox_noise_statistics_and_fast_mode(H):
     L = _L()
     n = 1 << 20
-    eps = torch.empty(n, device="cuda")
-    u = torch.empty(n, device="cuda")
+    eps = torch.empty(n, dtype=torch.float32, device="cuda")
+    u = torch.empty(n, dtype=torch.float32, device="cuda")
     L.check(L.lib.gmvae_noise_fill(L.ptr(eps), n, L.ptr(u), n, 7, 0, None, L.current_stream()), "noise")
     e, uu = eps.cpu().numpy().astype(np.float64), u.cpu().numpy().astype(np.float64)
     assert abs(e.mean()) < 5e-3 and abs(e.std() - 1) < 5e-3
     assert abs((e ** 3).mean()) < 2e-2 and abs((e ** 4).mean() - 3) < 5e-2
     assert uu.min() >= O.TINY_F32 and uu.max() < 1.0
     assert abs(uu.mean() - 0.5) < 2e-3 and abs(uu.var() - 1 / 12) < 1e-3
-    eps2 = torch.empty(n, device="cuda")
+    eps2 = torch.empty(n, dtype=torch.float32, device="cuda")
     L.check(L.lib.gmvae_noise_fill(L.ptr(eps2), n, None, 0, 7, 1, None, L.current_stream()), "noise")
     assert abs(np.corrcoef(e, eps2.cpu().numpy())[0, 1]) < 5e-3        # a new step is a new stream
     # fast mode of the step: eps/u = NULL -> loss within sampling distance of the parity-mode loss
@@ -229,7 +234,7 @@ def test_cluster_acc_kernel(H):
     labels = rng.integers(0, 10, B)
     ld, lab = H.dev(logits), H.dev(labels, torch.int64)
     scratch = torch.zeros(K * 10 + B, dtype=torch.int32, device="cuda")
-    acc = torch.zeros(1, device="cuda")
+    acc = torch.zeros(1, dtype=torch.float32, device="cuda")
     L.check(L.lib.gmvae_cluster_acc(L.ptr(ld), L.ptr(lab), B, K, 10, L.ptr(scratch), L.ptr(acc), L.current_stream()),
             "cluster_acc")
     assert acc.item() == pytest.approx(O.cluster_acc(logits, labels, K), abs=2.0 / B)

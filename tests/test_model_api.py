@@ -1,0 +1,141 @@
+"""-m gpu: the reference-shaped Python surface (create_vae / create_gmvae / run_model /
+encoder* / decoder / prior*) on top of the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def test_gmvae_run_model_backward_and_adam_three_steps():
+    import gmvae_amd
+    d = O.Dims(D=784, L=16, K=10, hidden=(64,))
+    model = gmvae_amd.create_gmvae(784, 16, mixture_components=10, fcnet_hidden_sizes=[64], sigma_min=0.0,
+                                   raw_sigma_bias=0.5, random_seed=3)
+    e = model._engine
+    assert e.P_real == O.param_layout(O.MODEL_GMVAE, d)[2]
+    flat = _np(e.params).astype(np.float32)
+    m = np.zeros_like(flat)
+    v = np.zeros_like(flat)
+    for t in range(1, 4):
+        x, eps, u = O.make_inputs(d, 64, seed_x=t, seed_noise=10 + t)
+        xt = torch.from_numpy(x).cuda()
+        model.params.grad = None
+        loss = model.run_model(xt, xt, None, eps=torch.from_numpy(eps), u=torch.from_numpy(u))
+        loss.backward()
+        flat, m, v, C, g = O.train_step(O.MODEL_GMVAE, d, flat.astype(np.float64), m.astype(np.float64),
+                                        v.astype(np.float64), t, x, eps, u, dtype=np.float64)
+        assert loss.item() == pytest.approx(C["loss"], rel=1e-4)
+        np.testing.assert_allclose(_np(model.params.grad), g, atol=1e-4 * np.abs(g).max())
+        s = model.summaries
+        assert s["elbo"].item() == pytest.approx(-C["loss"], rel=1e-4)
+        assert s["nent"].item() == pytest.approx(C["nent"], abs=1e-4)
+        e.adam(1e-3)
+        assert e.global_step == t
+    # dead-ReLU / tiny-gradient coordinates make Adam's m/(sqrt(v)+eps) ill-conditioned: compare where |g| is sane
+    np.testing.assert_allclose(_np(e.params), flat, atol=2e-4)
+    assert np.abs(_np(e.params) - flat).mean() < 2e-6
+
+
+def test_vae_gmp_modules_and_aux_methods():
+    import gmvae_amd
+    model = gmvae_amd.create_vae(784, 8, mixture_components=5, fcnet_hidden_sizes=[32], sigma_min=0.0,
+                                 raw_sigma_bias=0.5, random_seed=1)
+    d = O.Dims(D=784, L=8, K=5, hidden=(32,))
+    p = O.unpack(O.MODEL_VAE_GMP, d, _np(model.params))
+    x, eps, _ = O.make_inputs(d, 12, O.MODEL_VAE_GMP)
+    xt = torch.from_numpy(x).cuda()
+    q = model.encoder(xt)
+    C = O.forward(O.MODEL_VAE_GMP, d, p, x, eps)
+    np.testing.assert_allclose(_np(q.mean()), C["mu_q"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(_np(q.scale_diag), C["sig_q"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(_np(model.transform(xt)), C["mu_q"], rtol=1e-4, atol=1e-5)
+    zt = torch.from_numpy(C["z"]).float().cuda()
+    np.testing.assert_allclose(_np(model.decoder(zt).log_prob(xt)), C["logpx"], rtol=1e-5)
+    np.testing.assert_allclose(_np(model.prior().log_prob(zt)), C["logp"], rtol=1e-4)
+    assert model.reconstruct_images(xt).shape == (12, 784)
+    assert model.generate_samples(7).shape == (7, 8)
+    assert model.generate_sample_images(num_samples=3).shape == (3, 784)
+    loss = model.run_model(xt, xt, eps=torch.from_numpy(eps))
+    assert loss.item() == pytest.approx(C["loss"], rel=1e-4)
+    assert model.mix_components == 5
+
+
+def test_gmvae_modules_match_oracle():
+    import gmvae_amd
+    model = gmvae_amd.create_gmvae(200, 6, mixture_components=4, fcnet_hidden_sizes=[24, 16], sigma_min=0.0,
+                                   raw_sigma_bias=0.5, temperature=0.8, random_seed=2)
+    d = O.Dims(D=200, L=6, K=4, hidden=(24, 16), temperature=0.8)
+    p = O.unpack(O.MODEL_GMVAE, d, _np(model.params))
+    x, eps, u = O.make_inputs(d, 10)
+    C = O.forward(O.MODEL_GMVAE, d, p, x, eps, u)
+    xt = torch.from_numpy(x).cuda()
+    q_y = model.encoder_y(xt)
+    np.testing.assert_allclose(_np(q_y.distribution.logits), C["logits"], rtol=1e-4, atol=1e-5)
+    y = q_y.sample(uniform=torch.from_numpy(u).cuda())
+    np.testing.assert_allclose(_np(y), C["y"], rtol=1e-4, atol=1e-6)
+    pz = model.prior_gmm(y)
+    np.testing.assert_allclose(_np(pz.loc), C["mu_p"], rtol=1e-4, atol=1e-5)
+    qz = model.encoder_gmm(xt, y)
+    np.testing.assert_allclose(_np(qz.scale_diag), C["sig_q"], rtol=1e-4, atol=1e-5)
+    assert model.generate_samples(3).shape == (12, 6)
+    assert model.generate_samples(2, clusters=[0, 3, 3]).shape == (6, 6)
+    assert model.transform(xt).shape == (10, 6)
+    labels = torch.randint(0, 10, (10,))
+    loss = model.run_model(xt, xt, labels, eps=torch.from_numpy(eps), u=torch.from_numpy(u))
+    assert loss.item() == pytest.approx(C["loss"], rel=1e-4)
+    acc = model.summaries["cluster_acc"].item()
+    assert acc == pytest.approx(O.cluster_acc(C["logits"], labels.numpy(), 4), abs=0.11)
+
+
+def test_state_dict_roundtrip_uses_tf_variable_names():
+    import gmvae_amd
+    m1 = gmvae_amd.create_gmvae(64, 4, mixture_components=3, fcnet_hidden_sizes=[8], random_seed=1)
+    sd = m1.state_dict()
+    assert "encoder_gmm_fcnet/linear_0/w" in sd and sd["encoder_gmm_fcnet/linear_0/w"].shape == (67, 8)
+    assert "prior_gmm_fcnet/linear_0/b" in sd and "global_step" in sd
+    m2 = gmvae_amd.create_gmvae(64, 4, mixture_components=3, fcnet_hidden_sizes=[8], random_seed=2)
+    assert not torch.equal(m1.params, m2.params)
+    m2.load_state_dict(sd)
+    assert torch.equal(m1.params.detach(), m2.params.detach())
+
+
+def test_graph_replay_matches_eager_steps():
+    import gmvae_amd
+    from gmvae_amd.engine import Engine
+    x, _, _ = O.make_inputs(O.Dims(D=784, L=16, K=10, hidden=(64,)), 128)
+    xt = torch.from_numpy(x).cuda()
+    outs = []
+    for graph in (False, True):
+        e = Engine("gmvae", 784, 16, 10, [64], random_seed=5)
+        if graph:
+            sx, replay = e.capture_train_step(128, lr=1e-3)
+            e.init_parameters(5)                      # undo the warm-up step
+            sx.copy_(xt)
+            for _ in range(3):
+                replay()
+        else:
+            for _ in range(3):
+                e.train_step(xt, lr=1e-3)
+        torch.cuda.synchronize()
+        outs.append((e.params.detach().clone(), e.global_step))
+    assert outs[0][1] == outs[1][1] == 3
+    assert torch.allclose(outs[0][0], outs[1][0], atol=1e-6)
+
+
+def test_missing_engine_and_bad_activation_fail_loudly():
+    import gmvae_amd
+    from gmvae_amd import base
+    with pytest.raises(NotImplementedError):
+        gmvae_amd.create_gmvae(64, 4, 3, hidden_activation_fn=torch.tanh)
+    m = gmvae_amd.TrainableGMVAE(3, None, None, None, None)
+    with pytest.raises(RuntimeError):
+        m.run_model(torch.zeros(1, 1), torch.zeros(1, 1), None)
+    with pytest.raises(RuntimeError):
+        base.ConditionalNormal(4, [8]).condition([torch.zeros(1, 4)])

@@ -8,7 +8,7 @@ import torch
 
 import oracle as O
 
-torch.set_default_dtype(torch.float64)
+F64 = torch.float64      # never change the global default dtype: other test modules share the process
 
 
 def zero_params(model, d):
@@ -86,7 +86,7 @@ def torch_loss(model, d, P, x, eps, u):
         return td.Independent(td.Normal(mu, sig), 1)
 
     eps_t = torch.as_tensor(eps, dtype=torch.float64)
-    nent = torch.zeros(B)
+    nent = torch.zeros(B, dtype=F64)
     if model == O.MODEL_GMVAE:
         logits = mlp("encoder_y", xf)
         g = -torch.log(-torch.log(torch.as_tensor(u, dtype=torch.float64)))
@@ -97,7 +97,7 @@ def torch_loss(model, d, P, x, eps, u):
     else:
         q_z = normal(mlp("encoder", xf).repeat_interleave(S, 0))
         if model == O.MODEL_VAE:
-            p_z = td.Independent(td.Normal(torch.zeros(d.L), torch.ones(d.L)), 1)
+            p_z = td.Independent(td.Normal(torch.zeros(d.L, dtype=F64), torch.ones(d.L, dtype=F64)), 1)
         else:
             p_z = td.MixtureSameFamily(
                 td.Categorical(logits=P["mixture_logits"]),
@@ -130,7 +130,7 @@ def test_oracle_matches_torch_autograd(name, d, B):
             p[k] = rng.normal(0, 0.1, p[k].shape)
     x, eps, u = O.make_inputs(d, B, model)
     C, g = O.loss_and_grads(model, d, p, x, eps, u)
-    P = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
+    P = {k: torch.tensor(v, dtype=F64, requires_grad=True) for k, v in p.items()}
     loss = torch_loss(model, d, P, x, eps, u)
     loss.backward()
     assert C["loss"] == pytest.approx(loss.item(), rel=1e-12)
@@ -177,11 +177,11 @@ def test_adam_tf_three_step_trajectory():
     for t in range(1, 4):
         g = rng.normal(size=50)
         th, m, v = O.adam_tf_step(th, m, v, g, t, dtype=np.float64)
-        m_ref = 0.9 * m_ref + 0.1 * g
-        v_ref = 0.999 * v_ref + 0.001 * g * g
+        m_ref = 0.9 * m_ref + (1 - 0.9) * g
+        v_ref = 0.999 * v_ref + (1 - 0.999) * g * g
         lr_t = 1e-3 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
         th_ref = th_ref - lr_t * m_ref / (np.sqrt(v_ref) + 1e-8)
-    np.testing.assert_allclose(th, th_ref, rtol=1e-14)
+    np.testing.assert_allclose(th, th_ref, rtol=1e-12)
 
 
 def test_cluster_acc():
