@@ -29,8 +29,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--model", default="gmvae", choices=["gmvae", "vae", "vae_gmp"])
     ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch")
     ap.add_argument("--hidden", type=int, default=64)
@@ -129,6 +129,14 @@ def main():
         def step_fn():
             eng.train_step(x, lr=1e-3, all_reduce=world > 1)
 
+    # The GPU drops its clocks while the host runs the fp64 parity check above; a step is ~100 us, so W
+    # warm-up steps alone can be shorter than the DVFS ramp (measured: 2x slower timed region).  Spin the
+    # same step untimed for a fixed wall time first, THEN do the W warm-up steps the contract asks for.
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.75:
+        for _ in range(50):
+            step_fn()
+        torch.cuda.synchronize()
     for _ in range(a.warmup):
         step_fn()
     torch.cuda.synchronize()

@@ -58,6 +58,9 @@ def _load():
         "gmvae_cluster_acc": ([vp, vp, i32, i32, i32, vp, vp, vp], i32),
         "gmvae_gemm_test": ([vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
         "gmvae_bench_loop": ([dp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(f32), vp], i32),
+        "gmvae_train_graph_create": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, C.POINTER(vp)], i32),
+        "gmvae_train_graph_launch": ([vp, vp], i32),
+        "gmvae_train_graph_destroy": ([vp], i32),
         "gmvae_step_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),
     }
     for name, (args, res) in sigs.items():

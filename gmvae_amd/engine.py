@@ -231,39 +231,50 @@ class Engine:
 
     # -------------------------------------------------- hipGraph fast path
     def capture_train_step(self, B: int, lr: float = 1e-3, all_reduce: bool = False):
-        """Captures noise + fwd + bwd (+ all-reduce) + Adam for batch size B into
-        one hipGraph (torch.cuda.graph).  Returns (static_x, replay)."""
+        """One hipGraph for noise + fwd + bwd + Adam at batch size B, captured and owned by the HIP
+        library (gmvae_train_graph_*).  Returns (static_x, replay).  With all_reduce (data parallel)
+        the step is two eager halves around ONE RCCL all-reduce instead: torch's RCCL stream handling
+        is not captured here."""
         import torch.distributed as dist
-        key = (B, lr, all_reduce)
-        if key in self._graphs:
-            return self._graphs[key]
-        static_x = torch.zeros(B, self.D, dtype=torch.uint8, device=self.device)
-        self._workspace(B)
-        self.step_dev.fill_(self.global_step)
         do_ar = all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):           # warm-up outside capture (lazy module load, RCCL channels)
-            self.step(static_x, use_step_dev=True)
-            if do_ar:
+        key = (B, lr, do_ar)
+        if key in self._graphs:
+            return self._graphs[key][:2]
+        static_x = torch.zeros(B, self.D, dtype=torch.uint8, device=self.device)
+        d, ws = self._workspace(B)
+        self.step_dev.fill_(self.global_step)
+        if do_ar:
+            def replay():
+                self.step(static_x, use_step_dev=True)
                 dist.all_reduce(self.grads)
-            self.adam(lr, use_step_dev=True)
-        torch.cuda.current_stream().wait_stream(side)
+                self.adam(lr, use_step_dev=True)
+                self.global_step += 1
+            self._graphs[key] = (static_x, replay, None)
+            return static_x, replay
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self.step(static_x, use_step_dev=True)
-            if do_ar:
-                dist.all_reduce(self.grads)
-            self.adam(lr, use_step_dev=True)
+        handle = C.c_void_p()
+        rc = L.lib.gmvae_train_graph_create(C.byref(d), self.model, L.ptr(static_x), L.ptr(self.params), L.ptr(self.m),
+                                            L.ptr(self.v), L.ptr(self.grads), L.ptr(ws), self.noise_seed,
+                                            L.ptr(self.step_dev), lr, 0.9, 0.999, 1e-8, C.byref(handle))
+        L.check(rc, "gmvae_train_graph_create")
+        launch = L.lib.gmvae_train_graph_launch
 
         def replay():
-            graph.replay()
+            rc = launch(handle, L.current_stream())
+            if rc:
+                L.check(rc, "gmvae_train_graph_launch")
             self.global_step += 1
 
-        self.global_step += 1                    # the warm-up step advanced the device counter
-        self._graphs[key] = (static_x, replay)
-        return self._graphs[key]
+        self._graphs[key] = (static_x, replay, handle)
+        return static_x, replay
+
+    def __del__(self):
+        try:
+            for _, _, handle in self._graphs.values():
+                if handle:
+                    L.lib.gmvae_train_graph_destroy(handle)
+        except Exception:
+            pass
 
     def profile_levels(self, x, iters: int = 20):
         """Per-launch timing of the step with hipEvents (gmvae_step_profile)."""

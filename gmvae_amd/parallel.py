@@ -1,0 +1,67 @@
+"""Data-parallel plumbing: one process per GPU, ONE all-reduce per step.
+
+The reference is single-device (scripts/runners.py:193 pins one GPU; SURVEY.md
+2.2).  The loss is a batch mean (scripts/gmvae.py:254,258,262), so gradients are
+sums over samples: rank r takes rows [r*B/G, (r+1)*B/G) of the global batch,
+computes gradient SUMS into the flat [P + TAIL] buffer (gmvae_step), a single
+all-reduce(SUM) -- RCCL over xGMI via torch.distributed backend "nccl" -- makes
+the buffer global (loss sums and the sample count ride in the tail), and every
+rank applies the identical TF-Adam update scaled by 1/count, so replicas stay
+bit-identical without ever broadcasting parameters again.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+TAIL = 8
+
+
+def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from torchrun's environment; initialises the process group when world > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local
+
+
+def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous row range of `rank`; the first n_rows % world ranks take one extra row
+    (the reference's last partial batch, scripts/runners.py:51, need not divide evenly)."""
+    base, rem = divmod(n_rows, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def all_reduce_flat(buf: torch.Tensor) -> torch.Tensor:
+    """The step's single collective: SUM of the flat [P + TAIL] buffer over all ranks, in place."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf
+
+
+def grad_scale(buf: torch.Tensor, P: int) -> torch.Tensor:
+    """1 / global sample count, read from the all-reduced tail (a tensor: no host sync)."""
+    return 1.0 / buf[P + 4]
+
+
+def assert_replicas_identical(params: torch.Tensor) -> bool:
+    """Debug check: max |params - params_rank0| == 0 on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return True
+    ref = params.detach().clone()
+    dist.broadcast(ref, src=0)
+    return bool((ref == params.detach()).all().item())

@@ -181,6 +181,17 @@ int gmvae_bench_loop(const GmvaeDims* dims, int model, const uint8_t* x, float* 
                      float* grads, void* workspace, uint64_t* step_dev, int iters, int mode, float* usec_per_step,
                      void* stream);
 
+/* One full training step -- Philox noise + gmvae_step + adam_tf_step(t = *step_dev, grad_scale =
+ * 1/count from the tail) -- captured ONCE into a hipGraph owned by the library, for replay with a single
+ * call per step (the sess.run([train_op, global_step]) of scripts/runners.py:231-232).  All pointers
+ * are baked into the graph: copy each new batch into `x` before launching.  Single-device step; the
+ * data-parallel step (with the RCCL all-reduce between the two halves) is driven from the host side. */
+int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m,
+                             float* v, float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr,
+                             float beta1, float beta2, float epsilon, void** graph_out);
+int gmvae_train_graph_launch(void* graph, void* stream);
+int gmvae_train_graph_destroy(void* graph);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,7 +116,6 @@ def test_graph_replay_matches_eager_steps():
         e = Engine("gmvae", 784, 16, 10, [64], random_seed=5)
         if graph:
             sx, replay = e.capture_train_step(128, lr=1e-3)
-            e.init_parameters(5)                      # undo the warm-up step
             sx.copy_(xt)
             for _ in range(3):
                 replay()

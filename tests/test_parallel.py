@@ -1,0 +1,110 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel plumbing: row sharding, the single flat
+all-reduce with the loss sums and count in the tail, and the replicated TF-Adam update.  The
+per-rank compute is the oracle (no GPU here); the -m gpu twin below runs the HIP step on one GPU
+split into two 'ranks' in-process."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle as O
+from gmvae_amd import parallel as par
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _local_buffer(model, d, flat, x, eps, u):
+    """What gmvae_step leaves in the flat buffer: gradient SUMS + [loss, nll, kl, nent, count] sums."""
+    B = x.shape[0]
+    C, g = O.loss_and_grads(model, d, O.unpack(model, d, flat), x, eps, u, np.float64)
+    P = flat.size
+    buf = np.zeros(P + par.TAIL)
+    buf[:P] = O.pack(model, d, g, np.float64) * B
+    buf[P:P + 5] = [C["loss"] * B, C["nll"] * B, C["kl"] * B, C["nent"] * B, B]
+    return buf
+
+
+def _worker(rank, world, port, Bg, steps, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = par.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    model, d = O.MODEL_GMVAE, O.Dims(D=40, L=4, K=3, hidden=(8,))
+    flat = O.pack(model, d, O.init_params(model, d, np.random.default_rng(0)), np.float64)
+    m, v = np.zeros_like(flat), np.zeros_like(flat)
+    P = flat.size
+    losses = []
+    for t in range(1, steps + 1):
+        x, eps, u = O.make_inputs(d, Bg, seed_x=t, seed_noise=100 + t)
+        a, b = par.shard_rows(Bg, rank, world)
+        buf = torch.from_numpy(_local_buffer(model, d, flat, x[a:b], eps[a:b], u[a:b]))
+        par.all_reduce_flat(buf)                       # the ONE collective of the step
+        scale = par.grad_scale(buf, P).item()
+        assert buf[P + 4].item() == Bg
+        flat, m, v = O.adam_tf_step(flat, m, v, buf[:P].numpy() * scale, t, dtype=np.float64)
+        losses.append(buf[P].item() * scale)
+    assert par.assert_replicas_identical(torch.from_numpy(flat))
+    out[rank] = (flat, losses)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("Bg", [16, 15])            # 15: uneven shards (8 + 7 rows)
+def test_two_rank_gloo_equals_single_process(Bg):
+    steps, world = 3, 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), Bg, steps, out), nprocs=world, join=True)
+    model, d = O.MODEL_GMVAE, O.Dims(D=40, L=4, K=3, hidden=(8,))
+    flat = O.pack(model, d, O.init_params(model, d, np.random.default_rng(0)), np.float64)
+    m, v = np.zeros_like(flat), np.zeros_like(flat)
+    ref_losses = []
+    for t in range(1, steps + 1):
+        x, eps, u = O.make_inputs(d, Bg, seed_x=t, seed_noise=100 + t)
+        flat, m, v, C, _ = O.train_step(model, d, flat, m, v, t, x, eps, u, dtype=np.float64)
+        ref_losses.append(C["loss"])
+    f0, l0 = out[0]
+    f1, l1 = out[1]
+    assert np.array_equal(f0, f1)                                   # replicas bit-identical
+    np.testing.assert_allclose(l0, ref_losses, rtol=1e-12)
+    # Adam divides by sqrt(v)+eps: reduction-order noise (1e-16) on near-dead coordinates is amplified
+    np.testing.assert_allclose(f0, flat, rtol=0, atol=1e-9)
+
+
+def test_shard_rows_cover_and_balance():
+    for n in (1, 7, 16, 1000, 1023):
+        for w in (1, 2, 3, 8):
+            spans = [par.shard_rows(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.gpu
+def test_hip_step_sharded_sum_equals_full_batch():
+    """1-GPU stand-in for the N-GPU equality: gradient SUMS of two row shards add up to the full-batch
+    buffer (what the all-reduce computes), to fp32 reduction-order tolerance."""
+    import hip_util as H
+    d = O.Dims(D=784, L=16, K=10, hidden=(64,))
+    model = O.MODEL_GMVAE
+    flat = O.pack(model, d, O.init_params(model, d, np.random.default_rng(1)), np.float32)
+    x, eps, u = O.make_inputs(d, 256)
+    full, tail = H.hip_step(model, d, flat, x, eps, u)
+    acc, tacc = 0.0, 0.0
+    for r in range(2):
+        a, b = par.shard_rows(256, r, 2)
+        g, t = H.hip_step(model, d, flat, x[a:b], eps[a:b], u[a:b])
+        acc, tacc = acc + g, tacc + t
+    assert tacc[4] == tail[4] == 256
+    assert abs(tacc[0] - tail[0]) <= 1e-5 * abs(tail[0])
+    assert np.abs(acc - full).max() <= 2e-5 * np.abs(full).max()
