@@ -9,8 +9,8 @@ import sys
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HERE = os.path.join(ROOT, "gmvae_amd")
 SRC = os.path.join(HERE, "csrc", "gmvae_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "gemm.hpp"), os.path.join(HERE, "csrc", "kernels.hpp"),
-        os.path.join(ROOT, "include", "gmvae_hip.h")]
+import glob
+DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(ROOT, "include", "gmvae_hip.h")]
 OUT = os.path.join(HERE, "lib", "libgmvae_hip.so")
 
 

@@ -61,6 +61,7 @@ def _load():
         "gmvae_train_graph_create": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, C.POINTER(vp)], i32),
         "gmvae_train_graph_launch": ([vp, vp], i32),
         "gmvae_train_graph_destroy": ([vp], i32),
+        "gmvae_workspace_offset": ([dp, i32, C.c_char_p, C.POINTER(u64)], i32),
         "gmvae_step_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),
     }
     for name, (args, res) in sigs.items():

@@ -25,7 +25,7 @@ namespace gmvae {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;   // 4 wavefronts of 64
-constexpr int MAXP = 4;         // problems per launch
+constexpr int MAXP = 8;         // problems per launch
 
 enum { EPI_STORE = 0, EPI_BERNOULLI = 1 };
 

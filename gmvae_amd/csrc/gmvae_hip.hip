@@ -15,6 +15,7 @@
 #include "../../include/gmvae_hip.h"
 #include "gemm.hpp"
 #include "kernels.hpp"
+#include "chain.hpp"
 
 using namespace gmvae;
 
@@ -104,11 +105,27 @@ struct WS {
   float* hg[MAXH + 2];   // encoder_gmm activations [R, dim[i]]
   float* hd[MAXH + 2];   // decoder activations [R, dim[i]]
   float *gx, *logits, *y, *nent, *pp, *qp, *z, *logq, *logp, *logpx, *logw, *rw, *resp, *g, *part;
-  float *dbuf[2], *dz, *dqp, *dpp, *dy, *dlogits, *dqb, *slabs, *gmp_part;
+  float *dbuf[3], *dz, *dqp, *dpp, *dy, *dlogits, *dqb, *slabs, *gmp_part;
+  float *s1, *s4;          // split-K slabs of the fused schedule: [NSF][B][2H], [NSF][B][H]
   int32_t* cl_pred;
   uint64_t bytes;
 };
 constexpr int GMP_PARTS = 64;
+
+// ---- fused schedule for the launch-bound default sizes (chain.hpp) ---------------------------
+static int fwd_splits(int D) {
+  int ns = (D + 127) / 128;
+  return ns < 1 ? 1 : (ns > NS_MAX ? NS_MAX : ns);
+}
+static bool fused_ok(const GmvaeDims& d, int model) {
+  const char* e = getenv("GMVAE_NO_FUSED");
+  if (e && atoi(e)) return false;
+  if (model != GMVAE_MODEL_GMVAE || d.n_hidden != 1 || d.S != 1) return false;
+  const int H = d.hidden[0];
+  if (H % 16 || H > 128 || d.L % 8 || d.L > 128 || d.K > 64) return false;
+  const int f = chain_fwd_lds_floats(H, d.L, d.K), b = chain_bwd_lds_floats(H, d.L, d.K);
+  return (size_t)(f > b ? f : b) * 4 <= 150 * 1024;
+}
 
 static int num_splits(long long R) {
   long long ns = R / 256;
@@ -160,6 +177,11 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
   w.part = take(R * ((D + 31) / 32));
   w.dbuf[0] = take(R * maxh);
   w.dbuf[1] = take(R * maxh);
+  w.dbuf[2] = take(R * maxh);
+  if (fused_ok(d, model)) {
+    w.s1 = take((uint64_t)fwd_splits(d.D) * B * 2 * d.hidden[0]);
+    w.s4 = take((uint64_t)fwd_splits(d.D) * B * d.hidden[0]);
+  }
   w.dz = take(R * Lz);
   w.dqp = take(R * 2 * Lz);
   w.slabs = take((uint64_t)num_splits(R) * L.P_pad);
@@ -325,6 +347,117 @@ static void rowk(Ctx& cx, const char* name) {
   cx.mark(name, 0);
 }
 
+// The fused schedule: 9 launches instead of 21 for GMVAE with one hidden layer at sizes whose
+// small-layer weights fit in LDS.  Every GEMM launch is a single staging round per workgroup
+// (split-K into slabs that the consumer reduces), so the chip is filled and no workgroup
+// waits on more than ~2 dependent memory round trips.
+static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, const float* eps, const float* u) {
+  const GmvaeDims& d = *a.d;
+  const int B = d.B, K = d.K, Lz = d.L, D = d.D, H = d.hidden[0];
+  const float* P = a.params;
+  hipStream_t st = cx.st;
+  const int NSF = fwd_splits(D);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const NetL &E = L.ency, &G = L.encg, &Dn = L.dec;
+  {  // P1: X * [Wy0 | Wg0x] as single-round split-K partials
+    Group g;
+    Problem p0 = p_nn(a.x, true, D, P + E.w[0], H, B, H, D, w.s1, 2 * H, nullptr, false);
+    p0.splits = NSF; p0.split_stride = (long long)B * 2 * H;
+    Problem p1 = p_nn(a.x, true, D, P + G.w[0], H, B, H, D, w.s1 + H, 2 * H, nullptr, false);
+    p1.splits = NSF; p1.split_stride = (long long)B * 2 * H;
+    g.add(p0);
+    g.add(p1);
+    launch_group(cx, g, "fwd_x_first_layers_splitk", 0);
+  }
+  {  // P2: the whole row-local forward chain
+    ChainFwdArgs c;
+    c.B = B; c.H = H; c.L = Lz; c.K = K; c.NS = NSF;
+    c.c = d.raw_sigma_bias; c.smin = d.sigma_min; c.invT = 1.f / d.temperature;
+    c.s1 = w.s1; c.by0 = P + E.b[0];
+    c.Wy1 = P + E.w[1]; c.by1 = P + E.b[1];
+    c.Wg0y = P + G.w[0] + (uint64_t)D * H; c.bg0 = P + G.b[0];
+    c.Wp = P + L.prior.w[0]; c.bp = P + L.prior.b[0];
+    c.Wg1 = P + G.w[1]; c.bg1 = P + G.b[1];
+    c.Wd0 = P + Dn.w[0]; c.bd0 = P + Dn.b[0];
+    c.eps = eps; c.u = u;
+    c.hy1 = w.he[1]; c.logits = w.logits; c.y = w.y; c.nent = w.nent; c.hg1 = w.hg[1]; c.pp = w.pp; c.qp = w.qp;
+    c.z = w.z; c.logq = w.logq; c.logp = w.logp; c.hd1 = w.hd[1];
+    const size_t sh = (size_t)chain_fwd_lds_floats(H, Lz, K) * sizeof(float);
+    hipLaunchKernelGGL(chain_fwd, dim3((B + kPanel - 1) / kPanel), dim3(kThreads), sh, st, c);
+    rowk(cx, "chain_fwd");
+  }
+  int nparts = 1;
+  {  // P3: decoder output layer + Bernoulli log-likelihood
+    Group g;
+    Problem p = p_nn(w.hd[1], false, H, P + Dn.w[1], D, B, D, H, a.backward ? w.g : nullptr, D, P + Dn.b[1], false);
+    p.epi = EPI_BERNOULLI;
+    p.addconst = d.gen_bias_init;
+    p.x = a.x; p.ldx = D; p.x_div = 1; p.part = w.part;
+    g.add(p);
+    const int bn = cfg_bn(launch_group(cx, g, "fwd_dec_bernoulli"));
+    nparts = (D + bn - 1) / bn;
+  }
+  float* tail = a.backward ? a.grads + L.P_pad : a.tail;
+  if (!a.backward) {
+    hipLaunchKernelGGL(row_terms, dim3(grid_for(B, 256, 1 << 22)), dim3(256), 0, st, w.part, nparts, w.logq, w.logp,
+                       w.nent, 1, w.logpx, w.logw, a.row_terms, B);
+    rowk(cx, "row_terms");
+    hipLaunchKernelGGL(loss_tail, dim3(1), dim3(1024), 0, st, w.logw, w.logpx, w.logq, w.logp, w.nent, (float*)nullptr,
+                       tail, B, 1, a.step_dev);
+    rowk(cx, "loss_tail");
+    return cx.err;
+  }
+  const int NS = num_splits(B);
+  const long long PP = (long long)L.P_pad;
+  float* sl = w.slabs;
+  {  // P4: top of the backward pass: dWd1 (+db) and the split-K partials of (sigmoid - x) * Wd1^T
+    Group g;
+    g.add(p_tn(w.hd[1], false, H, 1, w.g, D, H, D, B, sl + Dn.w[1], sl + Dn.b[1], NS, PP, nullptr));
+    Problem p = p_nt(w.g, D, P + Dn.w[1], D, B, H, D, w.s4, H, nullptr, 0);
+    p.splits = NSF; p.split_stride = (long long)B * H;
+    g.add(p);
+    launch_group(cx, g, "bwd_dec_top_splitk", 0);
+  }
+  {  // P5: the whole row-local backward chain
+    ChainBwdArgs c;
+    c.B = B; c.H = H; c.L = Lz; c.K = K; c.NS = NSF; c.nparts = nparts;
+    c.c = d.raw_sigma_bias; c.smin = d.sigma_min; c.invT = 1.f / d.temperature;
+    c.s4 = w.s4;
+    c.Wy1 = P + E.w[1]; c.Wg0y = P + G.w[0] + (uint64_t)D * H; c.Wp = P + L.prior.w[0]; c.Wg1 = P + G.w[1];
+    c.Wd0 = P + Dn.w[0];
+    c.hd1 = w.hd[1]; c.hg1 = w.hg[1]; c.hy1 = w.he[1]; c.qp = w.qp; c.pp = w.pp; c.z = w.z; c.eps = eps; c.y = w.y;
+    c.logits = w.logits; c.nent = w.nent; c.part = w.part; c.logq = w.logq; c.logp = w.logp;
+    c.dhd1 = w.dbuf[0]; c.dqp = w.dqp; c.dpp = w.dpp; c.dhg1 = w.dbuf[1]; c.dlogits = w.dlogits; c.dhy1 = w.dbuf[2];
+    c.logpx = w.logpx; c.logw = w.logw;
+    const size_t sh = (size_t)chain_bwd_lds_floats(H, Lz, K) * sizeof(float);
+    hipLaunchKernelGGL(chain_bwd, dim3((B + kPanel - 1) / kPanel), dim3(kThreads), sh, st, c);
+    rowk(cx, "chain_bwd");
+  }
+  {  // P6: every remaining weight gradient in one grouped launch
+    Group g;
+    g.add(p_tn(a.x, true, D, 1, w.dbuf[2], H, D, H, B, sl + E.w[0], sl + E.b[0], NS, PP, nullptr));            // dWy0
+    g.add(p_tn(a.x, true, D, 1, w.dbuf[1], H, D, H, B, sl + G.w[0], sl + G.b[0], NS, PP, nullptr));            // dWg0[x]
+    g.add(p_tn(w.y, false, K, 1, w.dbuf[1], H, K, H, B, sl + G.w[0] + (uint64_t)D * H, nullptr, NS, PP, nullptr));  // dWg0[y]
+    g.add(p_tn(w.he[1], false, H, 1, w.dlogits, K, H, K, B, sl + E.w[1], sl + E.b[1], NS, PP, nullptr));       // dWy1
+    g.add(p_tn(w.y, false, K, 1, w.dpp, 2 * Lz, K, 2 * Lz, B, sl + L.prior.w[0], sl + L.prior.b[0], NS, PP, nullptr));
+    g.add(p_tn(w.hg[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + G.w[1], sl + G.b[1], NS, PP, nullptr)); // dWg1
+    g.add(p_tn(w.z, false, Lz, 1, w.dbuf[0], H, Lz, H, B, sl + Dn.w[0], sl + Dn.b[0], NS, PP, nullptr));        // dWd0
+    launch_group(cx, g, "bwd_dw_all", 0);
+  }
+  hipLaunchKernelGGL(loss_tail, dim3(1), dim3(1024), 0, st, w.logw, w.logpx, w.logq, w.logp, w.nent, (float*)nullptr,
+                     tail, B, 1, a.step_dev);
+  rowk(cx, "loss_tail");
+  hipLaunchKernelGGL(finalize_grads, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, sl, NS, PP, a.grads,
+                     (const float*)nullptr, 0, 0, 0LL);
+  rowk(cx, "finalize_grads");
+  return cx.err;
+}
+
 static int run_step(Ctx& cx, const StepArgs& a) {
   const GmvaeDims& d = *a.d;
   const int model = a.model;
@@ -352,6 +485,8 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     if (ge) eps = ge;
     if (gu) u = gu;
   }
+
+  if (fused_ok(d, model) && !a.z_out && !a.y_out && !a.logits_out) return run_step_fused(cx, a, L, w, eps, u);
 
   // ================================ forward ================================
   const NetL& E = gm ? L.ency : L.enc;
@@ -886,6 +1021,30 @@ int gmvae_train_graph_destroy(void* graph) {
   hipGraphDestroy(tg->graph);
   delete tg;
   return 0;
+}
+
+/* debugging aid: byte offset of a named workspace buffer (tests compare intermediates with the oracle) */
+int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, uint64_t* byte_offset) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!name || !byte_offset) return GMVAE_E_NULL;
+  Layout L;
+  build_layout(*dims, model, L);
+  WS w;
+  char base[16];
+  carve(*dims, model, L, base, w);
+  struct { const char* n; float* p; } tab[] = {
+      {"hy1", w.he[1]}, {"hg1", w.hg[1]}, {"hd1", w.hd[1]}, {"gx", w.gx}, {"logits", w.logits}, {"y", w.y},
+      {"nent", w.nent}, {"pp", w.pp}, {"qp", w.qp}, {"z", w.z}, {"logq", w.logq}, {"logp", w.logp},
+      {"logpx", w.logpx}, {"logw", w.logw}, {"g", w.g}, {"dz", w.dz}, {"dqp", w.dqp}, {"dpp", w.dpp},
+      {"dy", w.dy}, {"dlogits", w.dlogits}, {"dbuf0", w.dbuf[0]}, {"dbuf1", w.dbuf[1]}, {"dbuf2", w.dbuf[2]},
+      {"slabs", w.slabs}, {"s1", w.s1}, {"s4", w.s4}, {"eps", w.eps}, {"u", w.u}};
+  for (auto& t : tab)
+    if (!strcmp(t.n, name)) {
+      if (!t.p) return GMVAE_E_NET;
+      *byte_offset = (uint64_t)(reinterpret_cast<char*>(t.p) - base);
+      return 0;
+    }
+  return GMVAE_E_NET;
 }
 
 }  // extern "C"

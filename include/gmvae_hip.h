@@ -192,6 +192,10 @@ int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x,
 int gmvae_train_graph_launch(void* graph, void* stream);
 int gmvae_train_graph_destroy(void* graph);
 
+/* Debugging aid: byte offset inside the workspace of a named intermediate ("hy1","hg1","hd1","y",
+ * "logits","qp","pp","z","g","dqp","dpp","dlogits","dbuf0".."dbuf2","s1","s4", ...). */
+int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, uint64_t* byte_offset);
+
 #ifdef __cplusplus
 }
 #endif
