@@ -1,0 +1,158 @@
+// Shared device helpers + the auxiliary work blocks that ride on a GEMM launch.
+//
+// A kernel boundary costs ~4.7 us of timeline on this stack even for a trivial kernel
+// (profiles/round1_bench_kernel_stats.csv), so small independent jobs are appended to the first
+// GEMM launch of the step as extra workgroups instead of being launched on their own:
+//   * the Philox noise fill (eps ~ N(0,1), u ~ U[tiny,1)),
+//   * the per-step preparation of the chain kernels' LDS weight images (padding / transposition
+//     done ONCE per step in global memory, so each of the 64 chain workgroups only issues a linear
+//     asynchronous LDS-DMA copy instead of ~10 serialized L2 round trips).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gmvae {
+
+constexpr int kThreads = 256;   // 4 wavefronts of 64
+constexpr float kTiny = 1.17549435e-38f;
+
+// ---------------------------------------------------------------- Philox
+// Philox4x32-10 (Salmon et al. 2011), counter = (index, stream, step), key = seed.
+// Stands in for tf.random_normal / tf.random_uniform inside the TFP samplers
+// (scripts/gmvae.py:240,248; scripts/vae.py:171) -- statistically, not bitwise.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ float u01(uint32_t b) { return (float)(b >> 8) * 5.9604644775390625e-8f; }  // [0,1)
+
+// thread `i` of the fill: 4 values of eps (Box-Muller) or of u
+__device__ __forceinline__ void noise_item(uint64_t i, float* eps, uint64_t n_eps, float* u, uint64_t n_u,
+                                           uint64_t seed, uint64_t step) {
+  const uint64_t q_eps = (n_eps + 3) / 4, q_u = (n_u + 3) / 4;
+  if (i >= q_eps + q_u) return;
+  const bool is_u = i >= q_eps;
+  const uint64_t q = is_u ? i - q_eps : i;
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32) | (is_u ? 0x80000000u : 0u), (uint32_t)step, (uint32_t)(step >> 32)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  float o[4];
+  if (is_u) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaxf(u01(c[j]), kTiny);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      const float r = sqrtf(-2.f * logf(1.f - u01(c[j])));       // 1-u in (0,1]
+      float sn, cs;
+      sincosf(6.283185307179586f * u01(c[j + 1]), &sn, &cs);
+      o[j] = r * cs;
+      o[j + 1] = r * sn;
+    }
+  }
+  float* dst = is_u ? u : eps;
+  const uint64_t n = is_u ? n_u : n_eps;
+  if (q * 4 + 3 < n) {
+    *reinterpret_cast<float4*>(dst + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q * 4 + j < n) dst[q * 4 + j] = o[j];
+  }
+}
+
+// ------------------------------------------------------- matrix copies
+// Cooperative copies of a row-major [rows][cols] matrix by one workgroup; dst is LDS or global.
+// Loads are issued in independent batches (4 x 16 B or 8 x 4 B per thread in flight) -- a naive
+// one-element-per-iteration loop serialises ~60 L2 round trips per thread.
+//   TRANS = false: dst[r*ld + c] = src[r][c]        TRANS = true: dst[c*ld + r] = src[r][c]
+template <bool TRANS>
+__device__ __forceinline__ void mat_fill(float* __restrict__ dst, const int ld, const float* __restrict__ src,
+                                         const int rows, const int cols, const int src_ld, const int tid) {
+  const bool vec = ((cols | src_ld) & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+  if (vec) {
+    const int q = cols >> 2, n4 = rows * q;
+    for (int base = tid; base < n4; base += kThreads * 4) {
+      float4 v[4];
+      int rr[4], cc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ic = min(base + j * kThreads, n4 - 1);
+        rr[j] = ic / q;
+        cc[j] = (ic - rr[j] * q) << 2;
+        v[j] = *reinterpret_cast<const float4*>(src + (long long)rr[j] * src_ld + cc[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (base + j * kThreads < n4) {
+          if (!TRANS) {
+            float* p = dst + rr[j] * ld + cc[j];
+            p[0] = v[j].x; p[1] = v[j].y; p[2] = v[j].z; p[3] = v[j].w;
+          } else {
+            float* p = dst + cc[j] * ld + rr[j];
+            p[0] = v[j].x; p[ld] = v[j].y; p[2 * ld] = v[j].z; p[3 * ld] = v[j].w;
+          }
+        }
+      }
+    }
+  } else {
+    const int n = rows * cols;
+    for (int base = tid; base < n; base += kThreads * 8) {
+      float v[8];
+      int rr[8], cc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ic = min(base + j * kThreads, n - 1);
+        rr[j] = ic / cols;
+        cc[j] = ic - rr[j] * cols;
+        v[j] = src[(long long)rr[j] * src_ld + cc[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (base + j * kThreads < n) dst[TRANS ? cc[j] * ld + rr[j] : rr[j] * ld + cc[j]] = v[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------ aux blocks
+constexpr int kMaxImgTasks = 16;
+struct ImgTask {
+  float* dst;
+  const float* src;
+  int ld, rows, cols, src_ld, trans;
+};
+struct Aux {
+  int nblocks;          // extra workgroups after the GEMM tiles (0: none)
+  int noise_blocks;     // the first noise_blocks of them run the Philox fill
+  int ntasks;           // then one workgroup per image task
+  float* eps;
+  float* u;
+  unsigned long long n_eps, n_u, seed, step;
+  unsigned long long* step_dev;   // [2]: [0] = completed steps, [1] = copy that the last kernel of the step reads
+  ImgTask task[kMaxImgTasks];
+};
+
+__device__ __forceinline__ void aux_block(const Aux& ax, const int b) {
+  if (b < ax.noise_blocks) {
+    const unsigned long long step = ax.step_dev ? ax.step_dev[0] : ax.step;
+    noise_item((uint64_t)b * kThreads + threadIdx.x, ax.eps, ax.n_eps, ax.u, ax.n_u, ax.seed, step);
+    if (b == 0 && threadIdx.x == 0 && ax.step_dev) ax.step_dev[1] = ax.step_dev[0];
+  } else {
+    const int t = b - ax.noise_blocks;
+    if (t < ax.ntasks) {
+      if (ax.task[t].trans) mat_fill<true>(ax.task[t].dst, ax.task[t].ld, ax.task[t].src, ax.task[t].rows, ax.task[t].cols, ax.task[t].src_ld, threadIdx.x);
+      else mat_fill<false>(ax.task[t].dst, ax.task[t].ld, ax.task[t].src, ax.task[t].rows, ax.task[t].cols, ax.task[t].src_ld, threadIdx.x);
+    }
+  }
+}
+
+}  // namespace gmvae

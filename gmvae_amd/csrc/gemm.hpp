@@ -20,11 +20,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "aux.hpp"
+
 namespace gmvae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kThreads = 256;   // 4 wavefronts of 64
 constexpr int MAXP = 8;         // problems per launch
 
 enum { EPI_STORE = 0, EPI_BERNOULLI = 1 };
@@ -75,7 +76,9 @@ struct Problem {
 
 struct Launch {
   int nprob;
+  int total_tiles;         // workgroups [total_tiles, total_tiles + aux.nblocks) run aux_block()
   Problem p[MAXP];
+  Aux aux;
 };
 
 // BK is sized so that every thread keeps 8 independent loads in flight per
@@ -223,6 +226,10 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((int)blockIdx.x >= L.total_tiles) {      // auxiliary work riding on this launch (aux.hpp)
+    aux_block(L.aux, (int)blockIdx.x - L.total_tiles);
+    return;
+  }
 
   int pi = 0;
 #pragma unroll

@@ -107,6 +107,8 @@ struct WS {
   float *gx, *logits, *y, *nent, *pp, *qp, *z, *logq, *logp, *logpx, *logw, *rw, *resp, *g, *part;
   float *dbuf[3], *dz, *dqp, *dpp, *dy, *dlogits, *dqb, *slabs, *gmp_part;
   float *s1, *s4;          // split-K slabs of the fused schedule: [NSF][B][2H], [NSF][B][H]
+  unsigned long long* stamps;   // diagnostic stamps of the chain kernels: [2][grid][16]
+  float *img_f, *img_b;         // per-step LDS weight images of chain_fwd / chain_bwd (prepared by aux blocks)
   int32_t* cl_pred;
   uint64_t bytes;
 };
@@ -122,9 +124,9 @@ static bool fused_ok(const GmvaeDims& d, int model) {
   if (e && atoi(e)) return false;
   if (model != GMVAE_MODEL_GMVAE || d.n_hidden != 1 || d.S != 1) return false;
   const int H = d.hidden[0];
-  if (H % 16 || H > 128 || d.L % 8 || d.L > 128 || d.K > 64) return false;
-  const int f = chain_fwd_lds_floats(H, d.L, d.K), b = chain_bwd_lds_floats(H, d.L, d.K);
-  return (size_t)(f > b ? f : b) * 4 <= 150 * 1024;
+  if (H % 16 || H > 64 || d.L % 8 || d.L > 128 || d.K > 64) return false;
+  const int f = fwd_lay(H, d.L, d.K).total, b = bwd_lay(H, d.L, d.K).total;
+  return (size_t)(f > b ? f : b) * 4 <= 156 * 1024;
 }
 
 static int num_splits(long long R) {
@@ -181,6 +183,9 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
   if (fused_ok(d, model)) {
     w.s1 = take((uint64_t)fwd_splits(d.D) * B * 2 * d.hidden[0]);
     w.s4 = take((uint64_t)fwd_splits(d.D) * B * d.hidden[0]);
+    w.stamps = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * 16 * 2));
+    w.img_f = take((uint64_t)fwd_lay(d.hidden[0], d.L, d.K).img);
+    w.img_b = take((uint64_t)bwd_lay(d.hidden[0], d.L, d.K).img);
   }
   w.dz = take(R * Lz);
   w.dqp = take(R * 2 * Lz);
@@ -272,7 +277,7 @@ struct Ctx {
 
 struct Group {
   Launch L;
-  Group() { L.nprob = 0; }
+  Group() { memset(&L, 0, sizeof(L)); }
   void add(const Problem& p) { if (L.nprob < MAXP) L.p[L.nprob++] = p; }
 };
 
@@ -305,14 +310,14 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1) {
     for (int s = 0; s < g.L.p[i].nseg; ++s) fl += 2.0 * g.L.p[i].M * g.L.p[i].N * g.L.p[i].seg[s].K;
   int tiles;
   if (cfg == 2) {
-    tiles = tile_up<CfgL>(g.L);
-    hipLaunchKernelGGL(gemm_grouped<CfgL>, dim3(tiles), dim3(kThreads), 0, cx.st, g.L);
+    tiles = g.L.total_tiles = tile_up<CfgL>(g.L);
+    hipLaunchKernelGGL(gemm_grouped<CfgL>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
   } else if (cfg == 1) {
-    tiles = tile_up<CfgM>(g.L);
-    hipLaunchKernelGGL(gemm_grouped<CfgM>, dim3(tiles), dim3(kThreads), 0, cx.st, g.L);
+    tiles = g.L.total_tiles = tile_up<CfgM>(g.L);
+    hipLaunchKernelGGL(gemm_grouped<CfgM>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
   } else {
-    tiles = tile_up<CfgS>(g.L);
-    hipLaunchKernelGGL(gemm_grouped<CfgS>, dim3(tiles), dim3(kThreads), 0, cx.st, g.L);
+    tiles = g.L.total_tiles = tile_up<CfgS>(g.L);
+    hipLaunchKernelGGL(gemm_grouped<CfgS>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
   }
   cx.check();
   cx.mark(name, fl);
@@ -340,6 +345,9 @@ struct StepArgs {
   uint64_t seed, step;
   uint64_t* step_dev;
   bool backward;
+  // when non-null the fused schedule ends with ONE kernel doing slab reduce + loss tail + TF-Adam
+  float *adam_p = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  float lr = 0.f, beta1 = 0.9f, beta2 = 0.999f, epsilon = 1e-8f;
 };
 
 static void rowk(Ctx& cx, const char* name) {
@@ -351,7 +359,8 @@ static void rowk(Ctx& cx, const char* name) {
 // small-layer weights fit in LDS.  Every GEMM launch is a single staging round per workgroup
 // (split-K into slabs that the consumer reduces), so the chip is filled and no workgroup
 // waits on more than ~2 dependent memory round trips.
-static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, const float* eps, const float* u) {
+static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, const float* eps, const float* u,
+                          float* gen_eps, uint64_t n_eps, float* gen_u, uint64_t n_u) {
   const GmvaeDims& d = *a.d;
   const int B = d.B, K = d.K, Lz = d.L, D = d.D, H = d.hidden[0];
   const float* P = a.params;
@@ -372,22 +381,53 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
     p1.splits = NSF; p1.split_stride = (long long)B * 2 * H;
     g.add(p0);
     g.add(p1);
-    launch_group(cx, g, "fwd_x_first_layers_splitk", 0);
+    // auxiliary workgroups on the same launch: Philox noise + this step's LDS weight images
+    Aux& ax = g.L.aux;
+    ax.eps = gen_eps; ax.u = gen_u; ax.n_eps = n_eps; ax.n_u = n_u; ax.seed = a.seed; ax.step = a.step;
+    ax.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
+    ax.noise_blocks = (int)(((n_eps + 3) / 4 + (n_u + 3) / 4 + kThreads - 1) / kThreads);
+    const FwdLay fl = fwd_lay(H, Lz, K);
+    const BwdLay bl = bwd_lay(H, Lz, K);
+    const float* Wy1 = P + E.w[1];
+    const float* Wg0y = P + G.w[0] + (uint64_t)D * H;
+    const float* Wp = P + L.prior.w[0];
+    const float* Wg1 = P + G.w[1];
+    const float* Wd0 = P + Dn.w[0];
+    int nt = 0;
+    auto task = [&](float* dst, int ld, const float* src, int rows, int cols, int src_ld, int trans) {
+      ImgTask& t = ax.task[nt++];
+      t.dst = dst; t.ld = ld; t.src = src; t.rows = rows; t.cols = cols; t.src_ld = src_ld; t.trans = trans;
+    };
+    task(w.img_f + fl.W_y1, fl.KP, Wy1, H, K, K, 0);
+    task(w.img_f + fl.W_g0y, H, Wg0y, K, H, H, 0);
+    task(w.img_f + fl.W_p, 2 * Lz, Wp, K, 2 * Lz, 2 * Lz, 0);
+    task(w.img_f + fl.W_g1, 2 * Lz, Wg1, H, 2 * Lz, 2 * Lz, 0);
+    task(w.img_f + fl.W_d0, H, Wd0, Lz, H, H, 0);
+    task(w.img_f + fl.b_y0, H, P + E.b[0], 1, H, H, 0);
+    task(w.img_f + fl.b_y1, K, P + E.b[1], 1, K, K, 0);
+    task(w.img_f + fl.b_g0, H, P + G.b[0], 1, H, H, 0);
+    task(w.img_f + fl.b_p, 2 * Lz, P + L.prior.b[0], 1, 2 * Lz, 2 * Lz, 0);
+    task(w.img_f + fl.b_g1, 2 * Lz, P + G.b[1], 1, 2 * Lz, 2 * Lz, 0);
+    task(w.img_f + fl.b_d0, H, P + Dn.b[0], 1, H, H, 0);
+    task(w.img_b + bl.W_d0T, bl.ldD, Wd0, Lz, H, H, 1);
+    task(w.img_b + bl.W_g1T, bl.ldG, Wg1, H, 2 * Lz, 2 * Lz, 1);
+    task(w.img_b + bl.W_cT, bl.ldC, Wg0y, K, H, H, 1);
+    task(w.img_b + bl.W_cT + H * bl.ldC, bl.ldC, Wp, K, 2 * Lz, 2 * Lz, 1);
+    task(w.img_b + bl.W_y1T, bl.ldY, Wy1, H, K, K, 1);
+    ax.ntasks = nt;
+    ax.nblocks = ax.noise_blocks + nt;
+    launch_group(cx, g, "fwd_x_first_layers_splitk+aux", 0);
   }
   {  // P2: the whole row-local forward chain
     ChainFwdArgs c;
     c.B = B; c.H = H; c.L = Lz; c.K = K; c.NS = NSF;
     c.c = d.raw_sigma_bias; c.smin = d.sigma_min; c.invT = 1.f / d.temperature;
-    c.s1 = w.s1; c.by0 = P + E.b[0];
-    c.Wy1 = P + E.w[1]; c.by1 = P + E.b[1];
-    c.Wg0y = P + G.w[0] + (uint64_t)D * H; c.bg0 = P + G.b[0];
-    c.Wp = P + L.prior.w[0]; c.bp = P + L.prior.b[0];
-    c.Wg1 = P + G.w[1]; c.bg1 = P + G.b[1];
-    c.Wd0 = P + Dn.w[0]; c.bd0 = P + Dn.b[0];
+    c.s1 = w.s1; c.img = w.img_f;
     c.eps = eps; c.u = u;
     c.hy1 = w.he[1]; c.logits = w.logits; c.y = w.y; c.nent = w.nent; c.hg1 = w.hg[1]; c.pp = w.pp; c.qp = w.qp;
     c.z = w.z; c.logq = w.logq; c.logp = w.logp; c.hd1 = w.hd[1];
-    const size_t sh = (size_t)chain_fwd_lds_floats(H, Lz, K) * sizeof(float);
+    c.dbg = getenv("GMVAE_STAMPS") ? w.stamps : nullptr;
+    const size_t sh = (size_t)fwd_lay(H, Lz, K).total * sizeof(float);
     hipLaunchKernelGGL(chain_fwd, dim3((B + kPanel - 1) / kPanel), dim3(kThreads), sh, st, c);
     rowk(cx, "chain_fwd");
   }
@@ -427,14 +467,13 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
     ChainBwdArgs c;
     c.B = B; c.H = H; c.L = Lz; c.K = K; c.NS = NSF; c.nparts = nparts;
     c.c = d.raw_sigma_bias; c.smin = d.sigma_min; c.invT = 1.f / d.temperature;
-    c.s4 = w.s4;
-    c.Wy1 = P + E.w[1]; c.Wg0y = P + G.w[0] + (uint64_t)D * H; c.Wp = P + L.prior.w[0]; c.Wg1 = P + G.w[1];
-    c.Wd0 = P + Dn.w[0];
+    c.s4 = w.s4; c.img = w.img_b;
     c.hd1 = w.hd[1]; c.hg1 = w.hg[1]; c.hy1 = w.he[1]; c.qp = w.qp; c.pp = w.pp; c.z = w.z; c.eps = eps; c.y = w.y;
     c.logits = w.logits; c.nent = w.nent; c.part = w.part; c.logq = w.logq; c.logp = w.logp;
     c.dhd1 = w.dbuf[0]; c.dqp = w.dqp; c.dpp = w.dpp; c.dhg1 = w.dbuf[1]; c.dlogits = w.dlogits; c.dhy1 = w.dbuf[2];
     c.logpx = w.logpx; c.logw = w.logw;
-    const size_t sh = (size_t)chain_bwd_lds_floats(H, Lz, K) * sizeof(float);
+    c.dbg = getenv("GMVAE_STAMPS") ? w.stamps + (size_t)((B + 15) / 16) * 16 : nullptr;
+    const size_t sh = (size_t)bwd_lay(H, Lz, K).total * sizeof(float);
     hipLaunchKernelGGL(chain_bwd, dim3((B + kPanel - 1) / kPanel), dim3(kThreads), sh, st, c);
     rowk(cx, "chain_bwd");
   }
@@ -448,6 +487,16 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
     g.add(p_tn(w.hg[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + G.w[1], sl + G.b[1], NS, PP, nullptr)); // dWg1
     g.add(p_tn(w.z, false, Lz, 1, w.dbuf[0], H, Lz, H, B, sl + Dn.w[0], sl + Dn.b[0], NS, PP, nullptr));        // dWd0
     launch_group(cx, g, "bwd_dw_all", 0);
+  }
+  if (a.adam_p && a.step_dev) {   // graph path: slab reduce + loss tail + Adam in one launch
+    FinalArgs fa;
+    fa.slabs = sl; fa.nslab = NS; fa.P = PP; fa.grads = a.grads; fa.p = a.adam_p; fa.m = a.adam_m; fa.v = a.adam_v;
+    fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = 1; fa.count = (float)B;
+    fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = w.nent;
+    fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
+    hipLaunchKernelGGL(finalize_adam, dim3((unsigned)((PP / 4 + 255) / 256) + 1), dim3(256), 0, st, fa);
+    rowk(cx, "finalize_adam");
+    return cx.err;
   }
   hipLaunchKernelGGL(loss_tail, dim3(1), dim3(1024), 0, st, w.logw, w.logpx, w.logq, w.logp, w.nent, (float*)nullptr,
                      tail, B, 1, a.step_dev);
@@ -471,22 +520,23 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   const float c = d.raw_sigma_bias, smin = d.sigma_min;
   hipStream_t st = cx.st;
 
-  // ---- noise (fast mode): Philox in one launch for eps and u
+  // ---- noise (fast mode): Philox for eps and u -- its own launch in the general schedule, auxiliary
+  // workgroups of the first GEMM launch in the fused one
   const float* eps = a.eps;
   const float* u = a.u;
-  if (!eps || (gm && !u)) {
-    float* ge = eps ? nullptr : w.eps;
-    float* gu = (gm && !u) ? w.u : nullptr;
-    const uint64_t ne = ge ? (uint64_t)R * Lz : 0, nu = gu ? (uint64_t)R * K : 0;
+  float* ge = eps ? nullptr : w.eps;
+  float* gu = (gm && !u) ? w.u : nullptr;
+  const uint64_t ne = ge ? (uint64_t)R * Lz : 0, nu = gu ? (uint64_t)R * K : 0;
+  if (ge) eps = ge;
+  if (gu) u = gu;
+  if (fused_ok(d, model) && !a.z_out && !a.y_out && !a.logits_out)
+    return run_step_fused(cx, a, L, w, eps, u, ge, ne, gu, nu);
+  if (ne + nu) {
     const uint64_t q = (ne + 3) / 4 + (nu + 3) / 4;
     hipLaunchKernelGGL(noise_fill, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, ge, ne, gu, nu, a.seed,
                        a.step, a.step_dev);
     rowk(cx, "noise_fill");
-    if (ge) eps = ge;
-    if (gu) u = gu;
   }
-
-  if (fused_ok(d, model) && !a.z_out && !a.y_out && !a.logits_out) return run_step_fused(cx, a, L, w, eps, u);
 
   // ================================ forward ================================
   const NetL& E = gm ? L.ency : L.enc;
@@ -739,6 +789,18 @@ int gmvae_step(const GmvaeDims* dims, int model, const uint8_t* x, const float* 
   return run_step(cx, a);
 }
 
+/* internal: gmvae_step with the end-of-step Adam fused in (single device; used by the train graph) */
+static int step_with_adam(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
+                          float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float b1,
+                          float b2, float eps_, hipStream_t st) {
+  Ctx cx;
+  cx.st = st;
+  StepArgs a = {dims, model, x, nullptr, nullptr, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
+                seed, 0, step_dev, true};
+  a.adam_p = params; a.adam_m = m; a.adam_v = v; a.lr = lr; a.beta1 = b1; a.beta2 = b2; a.epsilon = eps_;
+  return run_step(cx, a);
+}
+
 int gmvae_forward(const GmvaeDims* dims, int model, const uint8_t* x, const float* eps, const float* u,
                   const float* params, float* tail, float* row_terms, float* z_out, float* y_out, float* logits_out,
                   void* workspace, uint64_t seed, uint64_t step, void* stream) {
@@ -988,10 +1050,14 @@ int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x,
   he = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
   if (he != hipSuccess) rc = (int)he;
   if (rc == 0) {
-    rc = gmvae_step(dims, model, x, nullptr, nullptr, params, grads, workspace, seed, 0, step_dev, cs);
-    if (rc == 0)
-      rc = adam_tf_step(params, m, v, grads, L.P_pad, lr, beta1, beta2, epsilon, 0, step_dev, 1.f,
-                        grads + L.P_pad + 4, cs);
+    if (fused_ok(*dims, model)) {
+      rc = step_with_adam(dims, model, x, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, cs);
+    } else {
+      rc = gmvae_step(dims, model, x, nullptr, nullptr, params, grads, workspace, seed, 0, step_dev, cs);
+      if (rc == 0)
+        rc = adam_tf_step(params, m, v, grads, L.P_pad, lr, beta1, beta2, epsilon, 0, step_dev, 1.f,
+                          grads + L.P_pad + 4, cs);
+    }
     he = hipStreamEndCapture(cs, &tg->graph);
     if (rc == 0 && he != hipSuccess) rc = (int)he;
   }
@@ -1037,7 +1103,8 @@ int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, u
       {"nent", w.nent}, {"pp", w.pp}, {"qp", w.qp}, {"z", w.z}, {"logq", w.logq}, {"logp", w.logp},
       {"logpx", w.logpx}, {"logw", w.logw}, {"g", w.g}, {"dz", w.dz}, {"dqp", w.dqp}, {"dpp", w.dpp},
       {"dy", w.dy}, {"dlogits", w.dlogits}, {"dbuf0", w.dbuf[0]}, {"dbuf1", w.dbuf[1]}, {"dbuf2", w.dbuf[2]},
-      {"slabs", w.slabs}, {"s1", w.s1}, {"s4", w.s4}, {"eps", w.eps}, {"u", w.u}};
+      {"slabs", w.slabs}, {"s1", w.s1}, {"s4", w.s4}, {"eps", w.eps}, {"u", w.u},
+      {"stamps", reinterpret_cast<float*>(w.stamps)}};
   for (auto& t : tab)
     if (!strcmp(t.n, name)) {
       if (!t.p) return GMVAE_E_NET;

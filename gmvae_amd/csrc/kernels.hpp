@@ -9,7 +9,6 @@
 namespace gmvae {
 
 constexpr float kLog2Pi = 1.8378770664093453f;
-constexpr float kTiny = 1.17549435e-38f;
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -22,56 +21,11 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// ---------------------------------------------------------------- Philox
-// Philox4x32-10 (Salmon et al. 2011), counter = (index, stream, step), key = seed.
-// Stands in for tf.random_normal / tf.random_uniform inside the TFP samplers
-// (scripts/gmvae.py:240,248; scripts/vae.py:171) -- statistically, not bitwise.
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-}
-__device__ __forceinline__ float u01(uint32_t b) { return (float)(b >> 8) * 5.9604644775390625e-8f; }  // [0,1)
-
-// eps ~ N(0,1) (Box-Muller), u ~ U[tiny,1).  One thread -> 4 values.
+// eps ~ N(0,1) (Box-Muller), u ~ U[tiny,1).  One thread -> 4 values (aux.hpp: noise_item).
 __global__ void noise_fill(float* eps, uint64_t n_eps, float* u, uint64_t n_u, uint64_t seed, uint64_t step,
                            const uint64_t* step_dev) {
   if (step_dev) step = *step_dev;
-  const uint64_t q_eps = (n_eps + 3) / 4, q_u = (n_u + 3) / 4;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= q_eps + q_u) return;
-  const bool is_u = i >= q_eps;
-  const uint64_t q = is_u ? i - q_eps : i;
-  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32) | (is_u ? 0x80000000u : 0u), (uint32_t)step, (uint32_t)(step >> 32)};
-  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-  float o[4];
-  if (is_u) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = fmaxf(u01(c[j]), kTiny);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; j += 2) {
-      const float r = sqrtf(-2.f * logf(1.f - u01(c[j])));       // 1-u in (0,1]
-      float sn, cs;
-      sincosf(6.283185307179586f * u01(c[j + 1]), &sn, &cs);
-      o[j] = r * cs;
-      o[j + 1] = r * sn;
-    }
-  }
-  float* dst = is_u ? u : eps;
-  const uint64_t n = is_u ? n_u : n_eps;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (q * 4 + j < n) dst[q * 4 + j] = o[j];
+  noise_item((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, eps, n_eps, u, n_u, seed, step);
 }
 
 // ------------------------------------------------ q(y|x): Gumbel-softmax head
@@ -496,6 +450,74 @@ __global__ void adam_tf(float* __restrict__ p, float* __restrict__ m, float* __r
       p[i] -= m[i] * lr_t / (sqrtf(v[i]) + eps);
     }
   }
+}
+
+// ----------------------------------------------- fused end-of-step kernel
+// One launch for the three tail kernels of the step (each costs ~4.7 us of timeline on its own):
+//   blocks [0, nb)  : gradient = fixed-order sum of the split-K slabs (-> grads), then TF-Adam on it
+//   block  nb       : loss tail sums (loss_tail) and the device step counter.
+// Counter protocol (no intra-kernel race): every block reads t-1 from step_dev[1] (copied from
+// step_dev[0] by the FIRST launch of the step, aux.hpp); only the tail block writes step_dev[0].
+struct FinalArgs {
+  const float* slabs; int nslab; long long P;
+  float *grads, *p, *m, *v;
+  float lr, b1, b2, eps;
+  int do_adam; float count;            // count = number of rows on this device (single-device scale)
+  const float *logw, *logpx, *logq, *logp, *nent;
+  float* tail; int B;
+  unsigned long long* step_dev;
+};
+__global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
+  const int nb = gridDim.x - 1;
+  if ((int)blockIdx.x == nb) {
+    __shared__ float red[4][256];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int b = threadIdx.x; b < a.B; b += 256) {
+      a0 -= a.logw[b];
+      a1 -= a.logpx[b];
+      a2 += a.logq[b] - a.logp[b];
+      a3 += a.nent ? a.nent[b] : 0.f;
+    }
+    red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2; red[3][threadIdx.x] = a3;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o)
+        for (int j = 0; j < 4; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      a.tail[0] = red[0][0]; a.tail[1] = red[1][0]; a.tail[2] = red[2][0]; a.tail[3] = red[3][0];
+      a.tail[4] = (float)a.B; a.tail[5] = 0.f; a.tail[6] = 0.f; a.tail[7] = 0.f;
+      if (a.step_dev) a.step_dev[0] = a.step_dev[1] + 1;
+    }
+    return;
+  }
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= a.P) return;
+  float4 g = *reinterpret_cast<const float4*>(a.slabs + i4);
+  for (int s = 1; s < a.nslab; ++s) {
+    const float4 o = *reinterpret_cast<const float4*>(a.slabs + (long long)s * a.P + i4);
+    g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w;
+  }
+  *reinterpret_cast<float4*>(a.grads + i4) = g;
+  if (!a.do_adam) return;
+  const unsigned long long t = (a.step_dev ? a.step_dev[1] : 0ull) + 1ull;
+  const float lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, (double)t)) / (1.0 - pow((double)a.b1, (double)t)));
+  const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, gs = 1.f / a.count;
+  float4 pp = *reinterpret_cast<float4*>(a.p + i4), mm = *reinterpret_cast<float4*>(a.m + i4),
+         vv = *reinterpret_cast<float4*>(a.v + i4);
+  float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+  const float ga[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float gj = ga[j] * gs;
+    ma[j] += (gj - ma[j]) * omb1;
+    va[j] += (gj * gj - va[j]) * omb2;
+    pa[j] -= ma[j] * lr_t / (sqrtf(va[j]) + a.eps);
+  }
+  *reinterpret_cast<float4*>(a.p + i4) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+  *reinterpret_cast<float4*>(a.m + i4) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+  *reinterpret_cast<float4*>(a.v + i4) = make_float4(va[0], va[1], va[2], va[3]);
 }
 
 // ------------------------------------------------------------ cluster_acc

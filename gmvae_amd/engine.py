@@ -57,7 +57,7 @@ class Engine:
         self.grads = torch.zeros(self.P + L.TAIL, dtype=torch.float32, device=self.device)
         self.m = torch.zeros(self.P, dtype=torch.float32, device=self.device)
         self.v = torch.zeros(self.P, dtype=torch.float32, device=self.device)
-        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)   # global_step (device resident)
+        self.step_dev = torch.zeros(2, dtype=torch.int64, device=self.device)   # global_step (device resident) + scratch copy
         self.global_step = 0
         self._ws: Dict[tuple, tuple] = {}
         self._graphs: Dict[tuple, tuple] = {}

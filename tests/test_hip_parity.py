@@ -191,7 +191,7 @@ def test_adam_device_counter_and_scale(H):
     f32 = dict(dtype=torch.float32, device="cuda")
     td, md, vd = torch.ones(P, **f32), torch.zeros(P, **f32), torch.zeros(P, **f32)
     gd = torch.full((P,), 6.0, **f32)
-    tdev = torch.tensor([3], dtype=torch.int64, device="cuda")
+    tdev = torch.tensor([3, 0], dtype=torch.int64, device="cuda")
     cnt = torch.tensor([4.0], dtype=torch.float32, device="cuda")
     L.check(L.lib.adam_tf_step(L.ptr(td), L.ptr(md), L.ptr(vd), L.ptr(gd), P, 1e-3, 0.9, 0.999, 1e-8, 999, L.ptr(tdev),
                                123.0, L.ptr(cnt), L.current_stream()), "adam")
