@@ -124,7 +124,7 @@ __device__ __forceinline__ void mat_fill(float* __restrict__ dst, const int ld, 
 }
 
 // ------------------------------------------------------------ aux blocks
-constexpr int kMaxImgTasks = 16;
+constexpr int kMaxImgTasks = 32;
 struct ImgTask {
   float* dst;
   const float* src;

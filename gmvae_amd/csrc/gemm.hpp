@@ -76,27 +76,30 @@ struct Problem {
 
 struct Launch {
   int nprob;
-  int total_tiles;         // workgroups [total_tiles, total_tiles + aux.nblocks) run aux_block()
+  int total_tiles;         // the FIRST aux.nblocks workgroups run aux_block() (they start at once), the GEMM tiles follow
   Problem p[MAXP];
   Aux aux;
 };
 
 // BK is sized so that every thread keeps 8 independent loads in flight per
 // staging round (the small configurations are latency-, not MFMA-bound).
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int WK_>
+// NBUF = 1 (single staging buffer, one extra barrier per round) halves the LDS footprint: the small
+// configuration mostly runs single-round split-K problems, where residency (4 instead of 2
+// workgroups per CU) matters and double buffering buys nothing.
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int NBUF_ = 2>
 struct Cfg {
-  static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_;
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_, NBUF = NBUF_;
   static constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   static constexpr int LDA = BM + 1, LDB = BN + 1, LDC = BN + 4;
   static constexpr int NSA = BM * BK / 4 / kThreads, NSB = BN * BK / 4 / kThreads;
-  static constexpr int OPS = 2 * (LDA + LDB) * BK;                  // floats, double buffered
+  static constexpr int OPS = NBUF * (LDA + LDB) * BK;               // floats, NBUF staging buffers
   static constexpr int CST = WK * BM * LDC;                          // floats, C staging
   static constexpr int LDS_FLOATS = OPS > CST ? OPS : CST;
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
   static_assert(NSA >= 1 && NSB >= 1, "tile too small for 256 threads");
   static_assert((BK / WK) % 2 == 0, "k slice per wave must be even");
 };
-typedef Cfg<32, 32, 128, 1, 1, 4> CfgS;     // latency-bound: 4 waves split K inside the tile
+typedef Cfg<32, 32, 128, 1, 1, 4, 1> CfgS;  // latency-bound: 4 waves split K inside the tile, single buffer
 typedef Cfg<64, 64, 64, 2, 2, 1> CfgM;
 typedef Cfg<128, 128, 32, 2, 2, 1> CfgL;    // MFMA-bound: 64x64 per wave
 
@@ -226,17 +229,18 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if ((int)blockIdx.x >= L.total_tiles) {      // auxiliary work riding on this launch (aux.hpp)
-    aux_block(L.aux, (int)blockIdx.x - L.total_tiles);
+  if ((int)blockIdx.x < L.aux.nblocks) {       // auxiliary work riding on this launch (aux.hpp)
+    aux_block(L.aux, (int)blockIdx.x);
     return;
   }
+  const int bid = (int)blockIdx.x - L.aux.nblocks;
 
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < MAXP; ++i)
-    if (i < L.nprob && (int)blockIdx.x >= L.p[i].tile_begin) pi = i;
+    if (i < L.nprob && bid >= L.p[i].tile_begin) pi = i;
 
-  int t = blockIdx.x - L.p[pi].tile_begin;
+  int t = bid - L.p[pi].tile_begin;
   const int splits = L.p[pi].splits;
   const int split = t % splits;
   t /= splits;
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
 #pragma unroll 1
     for (int c = 0; c < NC; ++c) {
       if (c + 1 < NC) GMVAE_GLOAD(c + 1);
-      const float* As = lds + (c & 1) * (C::LDA + C::LDB) * kBK;
+      const float* As = lds + (C::NBUF == 2 ? (c & 1) : 0) * (C::LDA + C::LDB) * kBK;
       const float* Bs = As + C::LDA * kBK;
       constexpr int KW = kBK / C::WK;
 #pragma unroll
@@ -339,7 +343,8 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
           for (int j = 0; j < C::TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
-      if (c + 1 < NC) GMVAE_LSTORE((c + 1) & 1);
+      if (C::NBUF == 1 && c + 1 < NC) __syncthreads();     // everyone is done reading the only buffer
+      if (c + 1 < NC) GMVAE_LSTORE(C::NBUF == 2 ? ((c + 1) & 1) : 0);
       __syncthreads();
     }
 #undef GMVAE_LOAD_A

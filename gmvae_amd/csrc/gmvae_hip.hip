@@ -16,6 +16,7 @@
 #include "gemm.hpp"
 #include "kernels.hpp"
 #include "chain.hpp"
+#include "mega.hpp"
 
 using namespace gmvae;
 
@@ -109,6 +110,7 @@ struct WS {
   float *s1, *s4;          // split-K slabs of the fused schedule: [NSF][B][2H], [NSF][B][H]
   unsigned long long* stamps;   // diagnostic stamps of the chain kernels: [2][grid][16]
   float *img_f, *img_b;         // per-step LDS weight images of chain_fwd / chain_bwd (prepared by aux blocks)
+  float *img_m, *dimg;          // mega kernel: small-weight image (odd leading dimensions) + decoder chunk images
   int32_t* cl_pred;
   uint64_t bytes;
 };
@@ -118,6 +120,14 @@ constexpr int GMP_PARTS = 64;
 static int fwd_splits(int D) {
   int ns = (D + 127) / 128;
   return ns < 1 ? 1 : (ns > NS_MAX ? NS_MAX : ns);
+}
+static bool fused_ok(const GmvaeDims& d, int model);
+// the single-launch per-row kernel (mega.hpp): needs the fused schedule, 16-byte aligned x rows and its LDS budget
+static bool mega_ok(const GmvaeDims& d, int model) {
+  const char* e = getenv("GMVAE_NO_MEGA");
+  if (e && atoi(e)) return false;
+  if (!fused_ok(d, model) || d.D % 16) return false;
+  return (size_t)mega_lay(d.hidden[0], d.L, d.K, d.D).total * 4 <= 160 * 1024;
 }
 static bool fused_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_FUSED");
@@ -186,6 +196,11 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     w.stamps = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * 16 * 2));
     w.img_f = take((uint64_t)fwd_lay(d.hidden[0], d.L, d.K).img);
     w.img_b = take((uint64_t)bwd_lay(d.hidden[0], d.L, d.K).img);
+    if (mega_ok(d, model)) {
+      const MegaLay ml = mega_lay(d.hidden[0], d.L, d.K, d.D);
+      w.img_m = take((uint64_t)ml.img);
+      w.dimg = take((uint64_t)ml.nch * ml.chunk);
+    }
   }
   w.dz = take(R * Lz);
   w.dqp = take(R * 2 * Lz);
@@ -355,6 +370,30 @@ static void rowk(Ctx& cx, const char* name) {
   cx.mark(name, 0);
 }
 
+// end of the fused schedule: slab reduce + loss tail (+ TF-Adam in the graph path)
+static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, float* tail, int NS, int B) {
+  hipStream_t st = cx.st;
+  const long long PP = (long long)L.P_pad;
+  float* sl = w.slabs;
+  if (a.adam_p && a.step_dev) {   // graph path: slab reduce + loss tail + Adam in one launch
+    FinalArgs fa;
+    fa.slabs = sl; fa.nslab = NS; fa.P = PP; fa.grads = a.grads; fa.p = a.adam_p; fa.m = a.adam_m; fa.v = a.adam_v;
+    fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = 1; fa.count = (float)B;
+    fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = w.nent;
+    fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
+    hipLaunchKernelGGL(finalize_adam, dim3((unsigned)((PP / 4 + 255) / 256) + 1), dim3(256), 0, st, fa);
+    rowk(cx, "finalize_adam");
+    return cx.err;
+  }
+  hipLaunchKernelGGL(loss_tail, dim3(1), dim3(1024), 0, st, w.logw, w.logpx, w.logq, w.logp, w.nent, (float*)nullptr,
+                     tail, B, 1, a.step_dev);
+  rowk(cx, "loss_tail");
+  hipLaunchKernelGGL(finalize_grads, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, sl, NS, PP, a.grads,
+                     (const float*)nullptr, 0, 0, 0LL);
+  rowk(cx, "finalize_grads");
+  return cx.err;
+}
+
 // The fused schedule: 9 launches instead of 21 for GMVAE with one hidden layer at sizes whose
 // small-layer weights fit in LDS.  Every GEMM launch is a single staging round per workgroup
 // (split-K into slabs that the consumer reduces), so the chip is filled and no workgroup
@@ -398,25 +437,85 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
       ImgTask& t = ax.task[nt++];
       t.dst = dst; t.ld = ld; t.src = src; t.rows = rows; t.cols = cols; t.src_ld = src_ld; t.trans = trans;
     };
-    task(w.img_f + fl.W_y1, fl.KP, Wy1, H, K, K, 0);
-    task(w.img_f + fl.W_g0y, H, Wg0y, K, H, H, 0);
-    task(w.img_f + fl.W_p, 2 * Lz, Wp, K, 2 * Lz, 2 * Lz, 0);
-    task(w.img_f + fl.W_g1, 2 * Lz, Wg1, H, 2 * Lz, 2 * Lz, 0);
-    task(w.img_f + fl.W_d0, H, Wd0, Lz, H, H, 0);
-    task(w.img_f + fl.b_y0, H, P + E.b[0], 1, H, H, 0);
-    task(w.img_f + fl.b_y1, K, P + E.b[1], 1, K, K, 0);
-    task(w.img_f + fl.b_g0, H, P + G.b[0], 1, H, H, 0);
-    task(w.img_f + fl.b_p, 2 * Lz, P + L.prior.b[0], 1, 2 * Lz, 2 * Lz, 0);
-    task(w.img_f + fl.b_g1, 2 * Lz, P + G.b[1], 1, 2 * Lz, 2 * Lz, 0);
-    task(w.img_f + fl.b_d0, H, P + Dn.b[0], 1, H, H, 0);
-    task(w.img_b + bl.W_d0T, bl.ldD, Wd0, Lz, H, H, 1);
-    task(w.img_b + bl.W_g1T, bl.ldG, Wg1, H, 2 * Lz, 2 * Lz, 1);
-    task(w.img_b + bl.W_cT, bl.ldC, Wg0y, K, H, H, 1);
-    task(w.img_b + bl.W_cT + H * bl.ldC, bl.ldC, Wp, K, 2 * Lz, 2 * Lz, 1);
-    task(w.img_b + bl.W_y1T, bl.ldY, Wy1, H, K, K, 1);
+    const bool mega = a.backward && mega_ok(d, a.model);
+    if (!mega) {
+      task(w.img_f + fl.W_y1, fl.KP, Wy1, H, K, K, 0);
+      task(w.img_f + fl.W_g0y, H, Wg0y, K, H, H, 0);
+      task(w.img_f + fl.W_p, 2 * Lz, Wp, K, 2 * Lz, 2 * Lz, 0);
+      task(w.img_f + fl.W_g1, 2 * Lz, Wg1, H, 2 * Lz, 2 * Lz, 0);
+      task(w.img_f + fl.W_d0, H, Wd0, Lz, H, H, 0);
+      task(w.img_f + fl.b_y0, H, P + E.b[0], 1, H, H, 0);
+      task(w.img_f + fl.b_y1, K, P + E.b[1], 1, K, K, 0);
+      task(w.img_f + fl.b_g0, H, P + G.b[0], 1, H, H, 0);
+      task(w.img_f + fl.b_p, 2 * Lz, P + L.prior.b[0], 1, 2 * Lz, 2 * Lz, 0);
+      task(w.img_f + fl.b_g1, 2 * Lz, P + G.b[1], 1, 2 * Lz, 2 * Lz, 0);
+      task(w.img_f + fl.b_d0, H, P + Dn.b[0], 1, H, H, 0);
+      if (a.backward) {
+        task(w.img_b + bl.W_d0T, bl.ldD, Wd0, Lz, H, H, 1);
+        task(w.img_b + bl.W_g1T, bl.ldG, Wg1, H, 2 * Lz, 2 * Lz, 1);
+        task(w.img_b + bl.W_cT, bl.ldC, Wg0y, K, H, H, 1);
+        task(w.img_b + bl.W_cT + H * bl.ldC, bl.ldC, Wp, K, 2 * Lz, 2 * Lz, 1);
+        task(w.img_b + bl.W_y1T, bl.ldY, Wy1, H, K, K, 1);
+      }
+    } else {
+      const MegaLay ml = mega_lay(H, Lz, K, D);
+      task(w.img_m + ml.W_y1, ml.ldY1, Wy1, H, K, K, 0);
+      task(w.img_m + ml.W_g0y, ml.ldG0, Wg0y, K, H, H, 0);
+      task(w.img_m + ml.W_p, ml.ldP, Wp, K, 2 * Lz, 2 * Lz, 0);
+      task(w.img_m + ml.W_g1, ml.ldG1, Wg1, H, 2 * Lz, 2 * Lz, 0);
+      task(w.img_m + ml.W_d0, ml.ldD0, Wd0, Lz, H, H, 0);
+      task(w.img_m + ml.b_y0, H, P + E.b[0], 1, H, H, 0);
+      task(w.img_m + ml.b_y1, K, P + E.b[1], 1, K, K, 0);
+      task(w.img_m + ml.b_g0, H, P + G.b[0], 1, H, H, 0);
+      task(w.img_m + ml.b_p, 2 * Lz, P + L.prior.b[0], 1, 2 * Lz, 2 * Lz, 0);
+      task(w.img_m + ml.b_g1, 2 * Lz, P + G.b[1], 1, 2 * Lz, 2 * Lz, 0);
+      task(w.img_m + ml.b_d0, H, P + Dn.b[0], 1, H, H, 0);
+      for (int c = 0; c < ml.nch; ++c) {             // decoder chunk images: [H rows of Wd1 | bias row]
+        const int nc = (D - c * kCW) < kCW ? (D - c * kCW) : kCW;
+        task(w.dimg + (uint64_t)c * ml.chunk, ml.ldc, P + Dn.w[1] + c * kCW, H, nc, D, 0);
+        task(w.dimg + (uint64_t)c * ml.chunk + H * ml.ldc, nc, P + Dn.b[1] + c * kCW, 1, nc, nc, 0);
+      }
+    }
     ax.ntasks = nt;
     ax.nblocks = ax.noise_blocks + nt;
     launch_group(cx, g, "fwd_x_first_layers_splitk+aux", 0);
+  }
+  const int NS = num_splits(B);
+  const long long PP = (long long)L.P_pad;
+  float* sl = w.slabs;
+  float* tail = a.backward ? a.grads + L.P_pad : a.tail;
+  if (a.backward && mega_ok(d, a.model)) {
+    {  // the whole per-row forward + backward in one launch
+      const MegaLay ml = mega_lay(H, Lz, K, D);
+      MegaArgs c;
+      c.B = B; c.H = H; c.L = Lz; c.K = K; c.D = D; c.NS = NSF;
+      c.c = d.raw_sigma_bias; c.smin = d.sigma_min; c.invT = 1.f / d.temperature; c.gen_bias = d.gen_bias_init;
+      c.s1 = w.s1; c.img = w.img_m; c.dimg = w.dimg; c.x = a.x; c.eps = eps; c.u = u;
+      c.hy1 = w.he[1]; c.y = w.y; c.hg1 = w.hg[1]; c.z = w.z; c.hd1 = w.hd[1]; c.g = w.g;
+      c.dhd1 = w.dbuf[0]; c.dqp = w.dqp; c.dpp = w.dpp; c.dhg1 = w.dbuf[1]; c.dlogits = w.dlogits; c.dhy1 = w.dbuf[2];
+      c.nent = w.nent; c.logq = w.logq; c.logp = w.logp; c.logpx = w.logpx; c.logw = w.logw;
+      c.dbg = getenv("GMVAE_STAMPS") ? w.stamps : nullptr;
+      static bool mattr = false;
+      if (!mattr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(mega_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        mattr = true;
+      }
+      hipLaunchKernelGGL(mega_fwd_bwd, dim3((B + kPanel - 1) / kPanel), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
+      rowk(cx, "mega_fwd_bwd");
+    }
+    {  // every weight gradient in one grouped launch
+      Group g;
+      g.add(p_tn(a.x, true, D, 1, w.dbuf[2], H, D, H, B, sl + E.w[0], sl + E.b[0], NS, PP, nullptr));            // dWy0
+      g.add(p_tn(a.x, true, D, 1, w.dbuf[1], H, D, H, B, sl + G.w[0], sl + G.b[0], NS, PP, nullptr));            // dWg0[x]
+      g.add(p_tn(w.hd[1], false, H, 1, w.g, D, H, D, B, sl + Dn.w[1], sl + Dn.b[1], NS, PP, nullptr));           // dWd1
+      g.add(p_tn(w.y, false, K, 1, w.dbuf[1], H, K, H, B, sl + G.w[0] + (uint64_t)D * H, nullptr, NS, PP, nullptr));
+      g.add(p_tn(w.he[1], false, H, 1, w.dlogits, K, H, K, B, sl + E.w[1], sl + E.b[1], NS, PP, nullptr));       // dWy1
+      g.add(p_tn(w.y, false, K, 1, w.dpp, 2 * Lz, K, 2 * Lz, B, sl + L.prior.w[0], sl + L.prior.b[0], NS, PP, nullptr));
+      g.add(p_tn(w.hg[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + G.w[1], sl + G.b[1], NS, PP, nullptr)); // dWg1
+      g.add(p_tn(w.z, false, Lz, 1, w.dbuf[0], H, Lz, H, B, sl + Dn.w[0], sl + Dn.b[0], NS, PP, nullptr));        // dWd0
+      launch_group(cx, g, "bwd_dw_all", 0);
+    }
+    return finish_fused(cx, a, L, w, tail, NS, B);
   }
   {  // P2: the whole row-local forward chain
     ChainFwdArgs c;
@@ -442,7 +541,6 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
     const int bn = cfg_bn(launch_group(cx, g, "fwd_dec_bernoulli"));
     nparts = (D + bn - 1) / bn;
   }
-  float* tail = a.backward ? a.grads + L.P_pad : a.tail;
   if (!a.backward) {
     hipLaunchKernelGGL(row_terms, dim3(grid_for(B, 256, 1 << 22)), dim3(256), 0, st, w.part, nparts, w.logq, w.logp,
                        w.nent, 1, w.logpx, w.logw, a.row_terms, B);
@@ -452,9 +550,6 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
     rowk(cx, "loss_tail");
     return cx.err;
   }
-  const int NS = num_splits(B);
-  const long long PP = (long long)L.P_pad;
-  float* sl = w.slabs;
   {  // P4: top of the backward pass: dWd1 (+db) and the split-K partials of (sigmoid - x) * Wd1^T
     Group g;
     g.add(p_tn(w.hd[1], false, H, 1, w.g, D, H, D, B, sl + Dn.w[1], sl + Dn.b[1], NS, PP, nullptr));
@@ -488,23 +583,7 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
     g.add(p_tn(w.z, false, Lz, 1, w.dbuf[0], H, Lz, H, B, sl + Dn.w[0], sl + Dn.b[0], NS, PP, nullptr));        // dWd0
     launch_group(cx, g, "bwd_dw_all", 0);
   }
-  if (a.adam_p && a.step_dev) {   // graph path: slab reduce + loss tail + Adam in one launch
-    FinalArgs fa;
-    fa.slabs = sl; fa.nslab = NS; fa.P = PP; fa.grads = a.grads; fa.p = a.adam_p; fa.m = a.adam_m; fa.v = a.adam_v;
-    fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = 1; fa.count = (float)B;
-    fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = w.nent;
-    fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
-    hipLaunchKernelGGL(finalize_adam, dim3((unsigned)((PP / 4 + 255) / 256) + 1), dim3(256), 0, st, fa);
-    rowk(cx, "finalize_adam");
-    return cx.err;
-  }
-  hipLaunchKernelGGL(loss_tail, dim3(1), dim3(1024), 0, st, w.logw, w.logpx, w.logq, w.logp, w.nent, (float*)nullptr,
-                     tail, B, 1, a.step_dev);
-  rowk(cx, "loss_tail");
-  hipLaunchKernelGGL(finalize_grads, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, sl, NS, PP, a.grads,
-                     (const float*)nullptr, 0, 0, 0LL);
-  rowk(cx, "finalize_grads");
-  return cx.err;
+  return finish_fused(cx, a, L, w, tail, NS, B);
 }
 
 static int run_step(Ctx& cx, const StepArgs& a) {

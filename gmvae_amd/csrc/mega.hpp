@@ -1,0 +1,534 @@
+// mega_fwd_bwd: the whole per-row part of the GMVAE training step in ONE launch.
+//
+// A workgroup owns 16 batch rows and runs, without leaving the CU:
+//   F  the forward chain of chain.hpp (slab reduce -> logits -> Gumbel-softmax -> heads -> z -> decoder hidden),
+//   D  the decoder output layer streamed in 128-column chunks through an LDS ring filled by LDS-DMA:
+//      lambda = hd1*Wd1 + b (scripts/base.py:133-135), Bernoulli log-likelihood (base.py:143-146,
+//      gmvae.py:254), g = sigmoid(lambda) - x, and IN THE SAME PASS the data gradient
+//      dhd1 += g_chunk * Wd1_chunk^T (both products read the same chunk image),
+//   B  the backward chain of chain.hpp on the accumulated dhd1.
+// Only the batch-reduced weight gradients (one grouped TN launch) and the optimiser remain outside.
+//
+// ONE weight image serves both directions: every matrix is stored row-major with an ODD leading
+// dimension, so the forward operand B(k,n) = W[k*ld + n] and the transposed backward operand
+// B(k,n) = W[n*ld + k] are both bank-conflict-free fragment reads.
+#pragma once
+#include "chain.hpp"
+
+namespace gmvae {
+
+constexpr int kCW = 128;       // decoder columns per streamed chunk
+constexpr int kMW = 8;         // wavefronts per workgroup (2 per SIMD: the partner hides LDS/DMA/VALU latency)
+constexpr int kMT = kMW * 64;
+
+struct MegaLay {
+  int KP, K2, L2, LP;
+  int ldY1, ldG0, ldP, ldG1, ldD0, ldc;
+  int W_y1, W_g0y, W_p, W_g1, W_d0, b_y0, b_y1, b_g0, b_p, b_g1, b_d0, img;   // small-weight image [0, img)
+  int chunk, nch;                    // floats per decoder chunk image ([H+1][ldc], row H = bias slice), chunks
+  int ring, xring;                   // LDS: ring of 2 chunk images (aliases the small-weight image), 2 x-chunks
+  int A_hy, A_y, A_hg, A_z, A_hd, A_g;          // forward / decoder operand images ([k][17])
+  int A_dhd, A_dqp, A_cat, A_dl;                // backward operand images (overlay the same region)
+  int P_lg, P_qp, P_pp, P_eps, P_z, P_hd, P_hg, P_hy, P_y, P_gx, P_u, P_dz, P_dy, nll, red, total;
+};
+__host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D) {
+  MegaLay m;
+  m.KP = (K + 15) & ~15; m.K2 = (K + 3) & ~3; m.L2 = 2 * L; m.LP = (L + 15) & ~15;
+  m.ldY1 = m.KP + 1; m.ldG0 = H + 1; m.ldP = m.L2 + 1; m.ldG1 = m.L2 + 1; m.ldD0 = H + 1; m.ldc = kCW + 1;
+  int o = 0;
+  auto take = [&](int n) { const int r = o; o += GMVAE_P4(n); return r; };
+  m.W_y1 = take(H * m.ldY1);       // [H][KP+1]
+  m.W_g0y = take(m.K2 * m.ldG0);   // [K2][H+1]
+  m.W_p = take(m.K2 * m.ldP);      // [K2][L2+1]
+  m.W_g1 = take(H * m.ldG1);       // [H][L2+1]
+  m.W_d0 = take(L * m.ldD0);       // [L][H+1]
+  m.b_y0 = take(H); m.b_y1 = take(m.KP); m.b_g0 = take(H); m.b_p = take(m.L2); m.b_g1 = take(m.L2); m.b_d0 = take(H);
+  m.img = GMVAE_P256(o);
+  m.chunk = GMVAE_P256((H + 1) * m.ldc);
+  m.nch = (D + kCW - 1) / kCW;
+  m.ring = 0;
+  o = (m.img > 2 * m.chunk) ? m.img : 2 * m.chunk;
+  m.xring = take(2 * kPanel * kCW / 4);          // 2 x [16][128] bytes
+  const int abase = o;
+  m.A_hy = take(H * kLDA); m.A_y = take(m.K2 * kLDA); m.A_hg = take(H * kLDA); m.A_z = take(L * kLDA);
+  m.A_hd = take(H * kLDA); m.A_g = take(kCW * kLDA);
+  const int aend_f = o;
+  o = abase;
+  m.A_dhd = take(H * kLDA); m.A_dqp = take(m.L2 * kLDA); m.A_cat = take((H + m.L2) * kLDA); m.A_dl = take(m.K2 * kLDA);
+  o = o > aend_f ? o : aend_f;
+  m.P_lg = take(kPanel * m.KP); m.P_qp = take(kPanel * m.L2); m.P_pp = take(kPanel * m.L2); m.P_eps = take(kPanel * L);
+  m.P_z = take(kPanel * L); m.P_hd = take(kPanel * H); m.P_hg = take(kPanel * H); m.P_hy = take(kPanel * H);
+  m.P_y = take(kPanel * K);
+  const int pb = o;
+  m.P_gx = take(kPanel * H); m.P_u = take(kPanel * K);
+  const int pe_f = o;
+  o = pb;
+  m.P_dz = take(kPanel * m.LP); m.P_dy = take(kPanel * m.KP);
+  o = o > pe_f ? o : pe_f;
+  m.nll = take(4 * kPanel);
+  m.red = take(kMW * 256);
+  m.total = o;
+  return m;
+}
+
+// partial sums of one 16x16 tile over k-steps [s0, s1) -> acc (operand reads 8 steps ahead of the MFMA chain;
+// a 16-deep batch and a blocked k-assignment were both measured SLOWER: tools/stamps.py)
+__device__ __forceinline__ f32x4 tile_ksteps(const float* __restrict__ A, const float* __restrict__ Bw, const int sk,
+                                             const int sn, const int tile, const int s0, const int s1, const int smax,
+                                             const int lane, f32x4 acc) {
+  const int ln = lane & 15, lk = lane >> 4;
+  for (int sb = s0; sb < s1; sb += 8) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = min(sb + j, smax - 1) * 4;
+      av[j] = A[(kk + lk) * kLDA + ln];
+      bv[j] = Bw[(kk + lk) * sk + (tile * 16 + ln) * sn];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (sb + j < s1) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// 16x16 tiles of A[K][17] x B with B(k,n) = Bw[k*sk + n*sn]; tile t = wave, wave + kMW, ...
+template <class Epi>
+__device__ __forceinline__ void panel_gemm_s(const float* __restrict__ A, const float* __restrict__ Bw, const int sk,
+                                             const int sn, const int K4, const int ntiles, const int wave,
+                                             const int lane, Epi epi) {
+  const int ln = lane & 15, lk = lane >> 4;
+  for (int t = wave; t < ntiles; t += kMW) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = tile_ksteps(A, Bw, sk, sn, t, 0, K4 / 4, K4 / 4, lane, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) epi(lk * 4 + r, t * 16 + ln, acc[r]);
+  }
+}
+
+template <class Epi>
+__device__ __forceinline__ void ksplit_finish(const f32x4 acc, const int tile, float* __restrict__ red, const int wave,
+                                              const int lane, Epi epi) {
+  const int ln = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave * 256 + (lk * 4 + r) * 16 + ln] = acc[r];
+  __syncthreads();
+  const int tid = wave * 64 + lane;
+  if (tid < 256) {
+    float v = red[tid];
+#pragma unroll
+    for (int w = 1; w < kMW; ++w) v += red[w * 256 + tid];
+    epi(tid >> 4, tile * 16 + (tid & 15), v);
+  }
+}
+
+// asynchronous linear copy by the kMW waves of the mega workgroup
+__device__ __forceinline__ void dma_copy_m(float* __restrict__ lds_dst, const float* __restrict__ g, const int nfloats,
+                                           const int wave, const int lane) {
+  for (int c = wave * 256; c < nfloats; c += kMW * 256) {
+    const int idx = c + lane * 4;
+    if (idx < nfloats) __builtin_amdgcn_global_load_lds(g + idx, lds_dst + c, 16, 0, 0);
+  }
+}
+
+struct MegaArgs {
+  int B, H, L, K, D, NS;
+  float c, smin, invT, gen_bias;
+  const float* s1;            // [NS][B][2H] split-K partials of X*[Wy0 | Wg0x]
+  const float* img;           // small-weight image (mega_lay [0, img))
+  const float* dimg;          // decoder chunk images [nch][chunk]
+  const unsigned char* x;     // [B][D]
+  const float *eps, *u;
+  float *hy1, *y, *hg1, *z, *hd1, *g;                           // saved for the weight gradients
+  float *dhd1, *dqp, *dpp, *dhg1, *dlogits, *dhy1;              // pre-activation gradients
+  float *nent, *logq, *logp, *logpx, *logw;                     // per-row loss terms
+  unsigned long long* dbg;
+};
+
+__global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = a.H, L = a.L, K = a.K, B = a.B, D = a.D;
+  const MegaLay f = mega_lay(H, L, K, D);
+  const int KP = f.KP, K2 = f.K2, L2 = f.L2, LP = f.LP;
+  float *W_y1 = sm + f.W_y1, *W_g0y = sm + f.W_g0y, *W_p = sm + f.W_p, *W_g1 = sm + f.W_g1, *W_d0 = sm + f.W_d0;
+  float *b_y0 = sm + f.b_y0, *b_y1 = sm + f.b_y1, *b_g0 = sm + f.b_g0, *b_p = sm + f.b_p, *b_g1 = sm + f.b_g1, *b_d0 = sm + f.b_d0;
+  float *A_hy = sm + f.A_hy, *A_y = sm + f.A_y, *A_hg = sm + f.A_hg, *A_z = sm + f.A_z, *A_hd = sm + f.A_hd, *A_g = sm + f.A_g;
+  float *A_dhd = sm + f.A_dhd, *A_dqp = sm + f.A_dqp, *A_cat = sm + f.A_cat, *A_dl = sm + f.A_dl;
+  float *P_lg = sm + f.P_lg, *P_qp = sm + f.P_qp, *P_pp = sm + f.P_pp, *P_eps = sm + f.P_eps, *P_z = sm + f.P_z;
+  float *P_hd = sm + f.P_hd, *P_hg = sm + f.P_hg, *P_hy = sm + f.P_hy, *P_y = sm + f.P_y;
+  float *P_gx = sm + f.P_gx, *P_u = sm + f.P_u, *P_dz = sm + f.P_dz, *P_dy = sm + f.P_dy;
+  float *nllp = sm + f.nll, *red = sm + f.red;
+  float* nllp2 = sm + f.P_gx;                  // [kMW][16] Bernoulli row sums per wave (P_gx is dead after the forward chain)
+  unsigned char* xring = reinterpret_cast<unsigned char*>(sm + f.xring);
+  float* A_dhg = A_cat;
+  float* A_dpp = A_cat + H * kLDA;
+
+  const int r0 = blockIdx.x * kPanel;
+  const int nrow = min(kPanel, B - r0);
+  const int ln = lane & 15, lk = lane >> 4;
+  GMVAE_STAMP(0);
+  // ======================================================================= F: forward chain
+  dma_copy_m(sm, a.img, f.img, wave, lane);
+  dma_copy_m(P_eps, a.eps + (long long)r0 * L, nrow * L, wave, lane);
+  dma_copy_m(P_u, a.u + (long long)r0 * K, (nrow * K) & ~3, wave, lane);
+  {
+    const int H2 = 2 * H;
+    const long long sstride = (long long)B * H2;
+    const int nitem = kPanel * H2 / 4;             // <= 512 for H <= 64: one item per thread
+    const int i = min(tid, nitem - 1);
+    const int row = (i * 4) / H2, col = (i * 4) % H2;
+    const float4 v = slab_sum4(a.s1 + (long long)min(r0 + row, B - 1) * H2 + col, sstride, a.NS);
+    for (int e = ((nrow * K) & ~3) + tid; e < nrow * K; e += kMT) P_u[e] = a.u[(long long)r0 * K + e];
+    dma_wait();
+    __syncthreads();
+    if (tid < nitem) {
+      float vv[4] = {v.x, v.y, v.z, v.w};
+      if (col < H) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vv[j] = fmaxf(vv[j] + b_y0[col + j], 0.f);
+          A_hy[(col + j) * kLDA + row] = vv[j];
+        }
+        *reinterpret_cast<float4*>(P_hy + row * H + col) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (row < nrow) *reinterpret_cast<float4*>(a.hy1 + (long long)(r0 + row) * H + col) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      } else {
+        *reinterpret_cast<float4*>(P_gx + row * H + (col - H)) = v;
+      }
+    }
+  }
+  __syncthreads();
+  GMVAE_STAMP(1);
+  // logits
+  for (int t = 0; t < KP / 16; ++t) {
+    const int steps = H / 4, per = (steps + kMW - 1) / kMW;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = tile_ksteps(A_hy, W_y1, f.ldY1, 1, t, min(steps, wave * per), min(steps, wave * per + per), steps, lane, acc);
+    ksplit_finish(acc, t, red, wave, lane, [&](int row, int col, float v) { P_lg[row * KP + col] = v + b_y1[col]; });
+    __syncthreads();
+  }
+  // Gumbel-softmax + entropy (16 lanes per row: the first 4 waves)
+  if (tid < 256) {
+    const int row = tid >> 4, sub = tid & 15;
+    const bool ok = row < nrow;
+    float lgv[4], av[4];
+    float mx = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = sub + 16 * j;
+      lgv[j] = -INFINITY; av[j] = -INFINITY;
+      if (k < K) {
+        lgv[j] = P_lg[row * KP + k];
+        const float uu = ok ? P_u[row * K + k] : 0.5f;
+        av[j] = (lgv[j] - flog(-flog(uu))) * a.invT;
+        mx = fmaxf(mx, av[j]);
+        m2 = fmaxf(m2, lgv[j]);
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); m2 = fmaxf(m2, __shfl_xor(m2, o, 64)); }
+    float se = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (sub + 16 * j < K) { se += fexp(av[j] - mx); s2 += fexp(lgv[j] - m2); }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    const float lse = mx + flog(se), l2 = m2 + flog(s2);
+    float ne = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = sub + 16 * j;
+      if (k < K2) {
+        float yv = 0.f;
+        if (k < K) {
+          yv = fexp(av[j] - lse);
+          const float lp = lgv[j] - l2;
+          ne += fexp(lp) * lp;
+          P_y[row * K + k] = yv;
+          if (ok) a.y[(long long)(r0 + row) * K + k] = yv;
+        }
+        A_y[k * kLDA + row] = yv;
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ne += __shfl_xor(ne, o, 64);
+    if (sub == 0) { nllp[3 * kPanel + row] = ne; if (ok) a.nent[r0 + row] = ne; }     // nllp[48..63]: nent per row
+  }
+  __syncthreads();
+  GMVAE_STAMP(2);
+  // hg1 and prior head
+  panel_gemm_s(A_y, W_g0y, f.ldG0, 1, K2, H / 16, wave, lane, [&](int row, int col, float v) {
+    const float h = fmaxf(v + P_gx[row * H + col] + b_g0[col], 0.f);
+    A_hg[col * kLDA + row] = h;
+    P_hg[row * H + col] = h;
+    if (row < nrow) a.hg1[(long long)(r0 + row) * H + col] = h;
+  });
+  panel_gemm_s(A_y, W_p, f.ldP, 1, K2, L2 / 16, wave, lane,
+               [&](int row, int col, float v) { P_pp[row * L2 + col] = v + b_p[col]; });
+  __syncthreads();
+  // q head
+  panel_gemm_s(A_hg, W_g1, f.ldG1, 1, H, L2 / 16, wave, lane,
+               [&](int row, int col, float v) { P_qp[row * L2 + col] = v + b_g1[col]; });
+  __syncthreads();
+  GMVAE_STAMP(3);
+  // z, log q, log p
+  float my_logq = 0.f, my_logp = 0.f;          // valid in the first 256 threads (16 lanes per row)
+  if (tid < 256) {
+    const int row = tid >> 4, sub = tid & 15;
+    const bool ok = row < nrow;
+    float aq = 0.f, ap = 0.f;
+    for (int l = sub; l < L; l += 16) {
+      const float mu = P_qp[row * L2 + l];
+      const float sg = fmaxf(fsoftplus(P_qp[row * L2 + L + l] + a.c), a.smin);
+      const float ee = ok ? P_eps[row * L + l] : 0.f;
+      const float zz = mu + sg * ee;
+      A_z[l * kLDA + row] = zz;
+      P_z[row * L + l] = zz;
+      if (ok) a.z[(long long)(r0 + row) * L + l] = zz;
+      const float e = (zz - mu) / sg;
+      aq += -0.5f * e * e - 0.5f * kLog2Pi - flog(sg);
+      const float sp = fmaxf(fsoftplus(P_pp[row * L2 + L + l] + a.c), a.smin);
+      const float t = (zz - P_pp[row * L2 + l]) / sp;
+      ap += -0.5f * t * t - 0.5f * kLog2Pi - flog(sp);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { aq += __shfl_xor(aq, o, 64); ap += __shfl_xor(ap, o, 64); }
+    my_logq = aq; my_logp = ap;
+    if (sub == 0 && ok) { a.logq[r0 + row] = aq; a.logp[r0 + row] = ap; }
+  }
+  __syncthreads();
+  // decoder hidden
+  panel_gemm_s(A_z, W_d0, f.ldD0, 1, L, H / 16, wave, lane, [&](int row, int col, float v) {
+    const float h = fmaxf(v + b_d0[col], 0.f);
+    A_hd[col * kLDA + row] = h;
+    P_hd[row * H + col] = h;
+    if (row < nrow) a.hd1[(long long)(r0 + row) * H + col] = h;
+  });
+  __syncthreads();                 // the small-weight image is dead from here until phase B
+  GMVAE_STAMP(4);
+
+  // ======================================================================= D: decoder output, streamed
+  const int nch = f.nch, ldc = f.ldc;
+  auto issue_chunk = [&](int c) {
+    dma_copy_m(sm + f.ring + (c & 1) * f.chunk, a.dimg + (long long)c * f.chunk, f.chunk, wave, lane);
+    // x chunk: [16 rows][128 bytes]; lane -> (row, 16-byte piece); columns beyond D are masked off
+    if (tid < kPanel * (kCW / 16)) {
+      const int row = tid >> 3, piece = tid & 7;
+      const int col = c * kCW + piece * 16;
+      if (col < D && row < nrow)
+        __builtin_amdgcn_global_load_lds(a.x + (long long)(r0 + row) * D + col,
+                                         reinterpret_cast<float*>(xring + (c & 1) * kPanel * kCW + (tid >> 6) * 1024), 16, 0, 0);
+    }
+  };
+  f32x4 dacc = {0.f, 0.f, 0.f, 0.f};           // partial 16x16 tile of dhd1: tile = wave & 3, column half = wave >> 2
+  const int dtile = wave & 3, dhalf = wave >> 2;
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};          // Bernoulli terms of rows lk*4 + r, this lane's columns
+  issue_chunk(0);
+  unsigned long long tseg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = a.dbg ? __builtin_amdgcn_s_memtime() : 0;   // diagnostic only
+#define GMVAE_SEG(i) if (a.dbg) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tseg[i] += tn_ - tprev; tprev = tn_; }
+  for (int c = 0; c < nch; ++c) {
+    dma_wait();
+    __syncthreads();                            // chunk c landed; A_g and buffer (c+1)&1 are free
+    GMVAE_SEG(0);
+    if (c + 1 < nch) issue_chunk(c + 1);
+    GMVAE_SEG(4);
+    const float* Wc = sm + f.ring + (c & 1) * f.chunk;
+    const unsigned char* xc = xring + (c & 1) * kPanel * kCW;
+    const int c0 = c * kCW;
+    // lambda tiles (2 per wave) + Bernoulli epilogue.  One wave per SIMD: nothing hides latency, so the
+    // operand-independent LDS reads (bias, x bytes) are issued before the MFMA chain, the element math is
+    // branch-free with ONE exp, ONE rcp and ONE log per element, and g leaves through the A_g image as
+    // 16-byte row-major stores after the barrier (cdna_hip_programming.md T21).
+    for (int t = wave; t < kCW / 16; t += kMW) {
+      const int cl = t * 16 + ln, col = c0 + cl;
+      const float bias = Wc[H * ldc + cl] + a.gen_bias;
+      float xv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xv[r] = (float)xc[(lk * 4 + r) * kCW + cl];
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = tile_ksteps(A_hd, Wc, ldc, 1, t, 0, H / 4, H / 4, lane, acc);
+      if (a.dbg) { asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); }
+      GMVAE_SEG(5);
+      const bool cok = col < D;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = lk * 4 + r;
+        const bool ok = cok && row < nrow;
+        const float lam = acc[r] + bias;
+        const float e = __expf(-fabsf(lam));
+        const float rcp = __builtin_amdgcn_rcpf(1.f + e);          // 1/(1+e): sigmoid(|lam|)
+        const float sp = fmaxf(lam, 0.f) - __logf(rcp);             // softplus = max(lam,0) + log(1+e)
+        const float sg = lam >= 0.f ? rcp : e * rcp;
+        const float x_ = ok ? xv[r] : 0.f;
+        rs[r] += ok ? x_ * lam - sp : 0.f;
+        A_g[cl * kLDA + row] = ok ? sg - x_ : 0.f;
+      }
+    }
+    GMVAE_SEG(1);
+    __syncthreads();
+    GMVAE_SEG(2);
+    // g chunk -> HBM as 16-byte row-major stores (for the dWd1 GEMM): thread -> (row, 4 columns), 2 per thread
+    {
+      const int row = tid >> 5, c4 = (tid & 31) << 2;     // 512 float4 per chunk: one per thread
+      if (row < nrow && c0 + c4 < D) {
+        const float4 gv = make_float4(A_g[(c4 + 0) * kLDA + row], A_g[(c4 + 1) * kLDA + row], A_g[(c4 + 2) * kLDA + row],
+                                      A_g[(c4 + 3) * kLDA + row]);
+        *reinterpret_cast<float4*>(a.g + (long long)(r0 + row) * D + c0 + c4) = gv;
+      }
+    }
+    // dhd1 += g_chunk * Wd1_chunk^T   (B(k = column, n = h) = Wc[h*ldc + column]); each tile's K split over 2 waves
+    if (dtile * 16 < H)
+      dacc = tile_ksteps(A_g, Wc, 1, ldc, dtile, dhalf * (kCW / 8), (dhalf + 1) * (kCW / 8), kCW / 4, lane, dacc);
+    GMVAE_SEG(3);
+  }
+  if (a.dbg && threadIdx.x == 0)
+    for (int i = 0; i < 8; ++i) a.dbg[(size_t)blockIdx.x * 16 + 8 + i] = tseg[i];
+  GMVAE_STAMP(5);
+  // per-row log p(x|z): reduce over the 16 column lanes, then over the 4 waves
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) rs[r] += __shfl_xor(rs[r], o, 64);
+  }
+  __syncthreads();                               // every wave is done with the ring and A_g
+  // ======================================================================= B: backward chain
+  dma_copy_m(sm, a.img, f.img, wave, lane);      // the ring overwrote the small-weight image
+  if (ln == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nllp2[wave * kPanel + lk * 4 + r] = rs[r];
+  }
+  if (dhalf == 1) {                              // upper column halves hand their partial tiles over
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[dtile * 256 + (lk * 4 + r) * 16 + ln] = dacc[r];
+  }
+  dma_wait();
+  __syncthreads();
+  if (dhalf == 0) {                              // masked top gradient -> A_dhd (+ saved for dWd0)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = lk * 4 + r, col = dtile * 16 + ln;
+      if (col < H) {
+        const float dv = dacc[r] + red[dtile * 256 + (lk * 4 + r) * 16 + ln];
+        const float d = (row < nrow && P_hd[row * H + col] > 0.f) ? dv : 0.f;
+        A_dhd[col * kLDA + row] = d;              // overlays A_hy.. (dead)
+        if (row < nrow) a.dhd1[(long long)(r0 + row) * H + col] = d;
+      }
+    }
+  }
+  if (tid < 256) {
+    const int row = tid >> 4, sub = tid & 15;
+    if (sub == 0 && row < nrow) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < kMW; ++w) s_ += nllp2[w * kPanel + row];
+      a.logpx[r0 + row] = s_;
+      a.logw[r0 + row] = s_ + my_logp - my_logq - nllp[3 * kPanel + row];
+    }
+  }
+  __syncthreads();
+  GMVAE_STAMP(6);
+  // dz_dec = dhd1 * Wd0^T
+  panel_gemm_s(A_dhd, W_d0, 1, f.ldD0, H, LP / 16, wave, lane, [&](int row, int col, float v) { P_dz[row * LP + col] = v; });
+  __syncthreads();
+  if (tid < 256) {
+    const int row = tid >> 4, sub = tid & 15;
+    const bool ok = row < nrow;
+    for (int l = sub; l < L; l += 16) {
+      float dmu = 0.f, draw = 0.f, dmup = 0.f, drawp = 0.f;
+      if (ok) {
+        const float rawq = P_qp[row * L2 + L + l] + a.c;
+        const float spq = fsoftplus(rawq);
+        const float sg = fmaxf(spq, a.smin);
+        const float zz = P_z[row * L + l];
+        const float rawp = P_pp[row * L2 + L + l] + a.c;
+        const float spp = fsoftplus(rawp);
+        const float sp = fmaxf(spp, a.smin);
+        const float t = (zz - P_pp[row * L2 + l]) / sp;
+        const float pterm = t / sp;
+        dmu = P_dz[row * LP + l] + pterm;
+        const float dsg = dmu * P_eps[row * L + l] - 1.f / sg;
+        draw = (spq > a.smin) ? dsg * sigmoidf_(rawq) : 0.f;
+        dmup = -pterm;
+        drawp = (spp > a.smin) ? (1.f - t * t) / sp * sigmoidf_(rawp) : 0.f;
+        float* dq = a.dqp + (long long)(r0 + row) * L2;
+        float* dp = a.dpp + (long long)(r0 + row) * L2;
+        dq[l] = dmu; dq[L + l] = draw; dp[l] = dmup; dp[L + l] = drawp;
+      }
+      A_dqp[l * kLDA + row] = dmu;
+      A_dqp[(L + l) * kLDA + row] = draw;
+      A_dpp[l * kLDA + row] = dmup;
+      A_dpp[(L + l) * kLDA + row] = drawp;
+    }
+  }
+  __syncthreads();
+  // dhg1 = (dqp * Wg1^T) * [hg1 > 0]
+  panel_gemm_s(A_dqp, W_g1, 1, f.ldG1, L2, H / 16, wave, lane, [&](int row, int col, float v) {
+    const float d = (row < nrow && P_hg[row * H + col] > 0.f) ? v : 0.f;
+    A_dhg[col * kLDA + row] = d;
+    if (row < nrow) a.dhg1[(long long)(r0 + row) * H + col] = d;
+  });
+  __syncthreads();
+  // dy = dhg1 * Wg0[D:,:]^T + dpp * Wp^T : K = H then K = 2L, split over the 4 waves
+  for (int t = 0; t < KP / 16; ++t) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    {
+      const int steps = H / 4, per = (steps + kMW - 1) / kMW;
+      acc = tile_ksteps(A_dhg, W_g0y, 1, f.ldG0, t, min(steps, wave * per), min(steps, wave * per + per), steps, lane, acc);
+    }
+    {
+      const int steps = L2 / 4, per = (steps + kMW - 1) / kMW;
+      acc = tile_ksteps(A_dpp, W_p, 1, f.ldP, t, min(steps, wave * per), min(steps, wave * per + per), steps, lane, acc);
+    }
+    ksplit_finish(acc, t, red, wave, lane, [&](int row, int col, float v) { P_dy[row * KP + col] = v; });
+    __syncthreads();
+  }
+  // softmax backward + entropy gradient
+  if (tid < 256) {
+    const int row = tid >> 4, sub = tid & 15;
+    const bool ok = row < nrow;
+    float lgv[4], yv[4];
+    float m2 = -INFINITY, dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = sub + 16 * j;
+      lgv[j] = -INFINITY; yv[j] = 0.f;
+      if (k < K && ok) {
+        lgv[j] = P_lg[row * KP + k];
+        yv[j] = P_y[row * K + k];
+        m2 = fmaxf(m2, lgv[j]);
+        dot += yv[j] * P_dy[row * KP + k];
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { m2 = fmaxf(m2, __shfl_xor(m2, o, 64)); dot += __shfl_xor(dot, o, 64); }
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (sub + 16 * j < K && ok) s2 += fexp(lgv[j] - m2);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    const float l2 = m2 + flog(s2);
+    const float ne = nllp[3 * kPanel + row];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = sub + 16 * j;
+      if (k < K2) {
+        float dl = 0.f;
+        if (k < K && ok) {
+          const float lp = lgv[j] - l2;
+          dl = yv[j] * (P_dy[row * KP + k] - dot) * a.invT + fexp(lp) * (lp - ne);
+          a.dlogits[(long long)(r0 + row) * K + k] = dl;
+        }
+        A_dl[k * kLDA + row] = dl;
+      }
+    }
+  }
+  __syncthreads();
+  // dhy1 = (dlogits * Wy1^T) * [hy1 > 0]
+  panel_gemm_s(A_dl, W_y1, 1, f.ldY1, K2, H / 16, wave, lane, [&](int row, int col, float v) {
+    if (row < nrow) a.dhy1[(long long)(r0 + row) * H + col] = P_hy[row * H + col] > 0.f ? v : 0.f;
+  });
+  GMVAE_STAMP(7);
+}
+
+}  // namespace gmvae

@@ -12,8 +12,11 @@ torch.cuda.synchronize()
 d, ws = e._workspace(B)
 off = C.c_uint64(); L.check(L.lib.gmvae_workspace_offset(C.byref(d), e.model, b"stamps", C.byref(off)), "off")
 raw = ws.view(torch.int64)[off.value // 8: off.value // 8 + 2 * 64 * 16].cpu().numpy().reshape(2, 64, 16)
-for k, name in enumerate(["chain_fwd", "chain_bwd"]):
+names = ["mega (F0 | logits+gumbel | heads | z+hd | decoder | B0 | bwd chain)", "chain_bwd"] if not os.environ.get("GMVAE_NO_MEGA") else ["chain_fwd", "chain_bwd"]
+for k, name in enumerate(names):
     st = raw[k][:, :8].astype(np.float64)
-    dur = np.diff(st, axis=1)          # s_memtime ticks (shader clock on gfx950: 100 MHz? report raw)
-    print(name, "median per-stage ticks:", np.round(np.median(dur, axis=0)).astype(int), "total", int(np.median(st[:, 7] - st[:, 0])))
-    print("   start skew across WGs (ticks):", int(st[:, 0].max() - st[:, 0].min()), " end skew:", int(st[:, 7].max() - st[:, 7].min()))
+    if st.max() == 0: continue
+    dur = np.diff(st, axis=1)
+    if k == 0 and raw[0][:, 8:12].max() > 0:
+        print("  decoder loop segments (sum over chunks) [wait+sync | lambda+epilogue | sync | dhd product]:", np.round(np.median(raw[0][:, 8:12], axis=0)).astype(int), " | issue_dma, mfma_tile, (epilogue = seg1):", np.round(np.median(raw[0][:, 12:14], axis=0)).astype(int))
+    print(name, "median per-stage cycles:", np.round(np.median(dur, axis=0)).astype(int), "total", int(np.median(st[:, 7] - st[:, 0])))
