@@ -116,6 +116,12 @@ def main():
 
     # ---- the timed loop
     use_graph = not a.no_graph
+    if world > 1:
+        try:
+            eng.enable_rccl()           # RCCL communicator inside libgmvae_hip.so: step + all-reduce + Adam in one graph
+        except Exception as e:
+            if rank == 0:
+                print(f"[bench] in-library RCCL unavailable ({type(e).__name__}: {e}); torch.distributed all-reduce", file=sys.stderr)
     if use_graph:
         try:
             static_x, replay = eng.capture_train_step(B, lr=1e-3, all_reduce=world > 1)
@@ -156,16 +162,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     final_tail = eng.grads[eng.P:].cpu().numpy().astype(np.float64)
+    replicas_identical = None
+    if world > 1:                                   # every rank must hold bit-identical parameters
+        cs = eng.params.detach().double().sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool((lo == hi).item())
     value = n_gpus * B * d.S * a.steps / dt
 
     if rank == 0:
         # ---- roofline of the dominant kernel: hipEvents around every launch of the step
         levels = eng.profile_levels(x, iters=30)
-        gemms = [l for l in levels if l[2] > 0]
+        gemms = [l for l in levels if l[2] > 0]          # launches that do MFMA work (grouped GEMMs, mega kernel)
         dom = max(gemms, key=lambda l: l[1])
         step_flops = O.flops_per_step(model_id, d, B)
         sum_us = sum(l[1] for l in levels)
-        roof = {"bound": "mfma", "kernel": f"gemm_grouped<{dom[0]}>", "achieved": dom[2] / dom[1] * 1e-6,
+        roof = {"bound": "mfma", "kernel": dom[0] if dom[0].startswith("mega") else f"gemm_grouped<{dom[0]}>", "achieved": dom[2] / dom[1] * 1e-6,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom[2] / dom[1] * 1e-6 / PEAK_F32_MFMA_TFLOPS,
                 "traffic": None, "usec_per_launch": dom[1], "flops_per_launch": dom[2],
                 "step_flops_alg": step_flops, "step_tflops_alg": step_flops / (dt / a.steps) * 1e-12,
@@ -189,7 +202,8 @@ def main():
             "config": {"workload": f"{a.model} train step (noise+fwd+bwd+allreduce+TF-Adam), D={d.D} K={d.K} "
                                    f"L={d.L} hidden={hidden} S={d.S}, batch {B}/GPU x {n_gpus} GPU "
                                    f"(BASELINE configs[{2 if n_gpus == 1 else 3}])",
-                       "global_batch": B * n_gpus, "parallelism": f"dp{n_gpus}", "hipgraph": use_graph},
+                       "global_batch": B * n_gpus, "parallelism": f"dp{n_gpus}", "hipgraph": use_graph,
+                       "all_reduce": getattr(eng, "dp_mode", None), "replicas_identical": replicas_identical},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "final_loss": final_tail[0] / max(final_tail[4], 1.0),
         }

@@ -61,6 +61,11 @@ def _load():
         "gmvae_train_graph_create": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, C.POINTER(vp)], i32),
         "gmvae_train_graph_launch": ([vp, vp], i32),
         "gmvae_train_graph_destroy": ([vp], i32),
+        "gmvae_comm_unique_id": ([C.c_char_p, vp], i32),
+        "gmvae_comm_init": ([C.c_char_p, vp, i32, i32, C.POINTER(vp)], i32),
+        "gmvae_comm_destroy": ([vp], i32),
+        "gmvae_dp_step": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, vp, vp], i32),
+        "gmvae_dp_graph_create": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, vp, C.POINTER(vp)], i32),
         "gmvae_workspace_offset": ([dp, i32, C.c_char_p, C.POINTER(u64)], i32),
         "gmvae_step_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),
     }
@@ -126,6 +131,13 @@ def require_gpu():
     if not torch.cuda.is_available():
         raise GmvaeError("no HIP device visible: gmvae_amd has no CPU fallback")
     return torch.device("cuda", torch.cuda.current_device())
+
+
+def rccl_path():
+    """The librccl.so PyTorch itself loaded (one RCCL per process)."""
+    import torch
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p.encode() if os.path.exists(p) else b"librccl.so"
 
 
 def current_stream():

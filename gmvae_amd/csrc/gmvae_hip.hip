@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -501,7 +502,12 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
         mattr = true;
       }
       hipLaunchKernelGGL(mega_fwd_bwd, dim3((B + kPanel - 1) / kPanel), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
-      rowk(cx, "mega_fwd_bwd");
+      cx.check();
+      // algorithmic MFMA FLOPs of the launch: forward chain + decoder layer (lambda and its data gradient) + backward chain
+      const double macs = (double)H * K + (double)K * H + (double)K * 2 * Lz + (double)H * 2 * Lz + (double)Lz * H   // forward
+                          + 2.0 * H * D                                                                              // decoder fwd + dX
+                          + (double)H * Lz + 2.0 * Lz * H + (double)(H + 2 * Lz) * K + (double)K * H;               // backward
+      cx.mark("mega_fwd_bwd", 2.0 * B * macs);
     }
     {  // every weight gradient in one grouped launch
       Group g;
@@ -1191,6 +1197,110 @@ int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, u
       return 0;
     }
   return GMVAE_E_NET;
+}
+
+/* ---- data parallel: RCCL is bound at run time (dlopen of the copy the host process already uses), so the
+ * library itself has no link-time dependency on it.  One all-reduce(SUM) of the flat [P + TAIL] buffer per
+ * step, on the caller's stream, between the gradient half and the optimiser half of the step. ---------- */
+struct RcclApi {
+  void* h = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, ...) = nullptr;   // (ncclComm_t*, int nranks, ncclUniqueId by value, int rank)
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+};
+static RcclApi g_rccl;
+struct UniqueId128 { char b[128]; };
+
+static int rccl_load(const char* path) {
+  if (g_rccl.h) return 0;
+  void* h = dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return GMVAE_E_NULL;
+  g_rccl.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<int (*)(void**, int, ...)>(dlsym(h, "ncclCommInitRank"));
+  g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
+  g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) return GMVAE_E_NULL;
+  g_rccl.h = h;
+  return 0;
+}
+
+int gmvae_comm_unique_id(const char* rccl_path, char* out128) {
+  if (!out128) return GMVAE_E_NULL;
+  if (int e = rccl_load(rccl_path)) return e;
+  return g_rccl.GetUniqueId(out128) ? 1000 : 0;
+}
+
+int gmvae_comm_init(const char* rccl_path, const char* id128, int rank, int world, void** comm) {
+  if (!id128 || !comm) return GMVAE_E_NULL;
+  if (world < 1 || rank < 0 || rank >= world) return GMVAE_E_DIMS;
+  if (int e = rccl_load(rccl_path)) return e;
+  UniqueId128 id;
+  memcpy(id.b, id128, 128);
+  typedef int (*InitFn)(void**, int, UniqueId128, int);
+  const int rc = reinterpret_cast<InitFn>(g_rccl.CommInitRank)(comm, world, id, rank);
+  return rc ? 1000 + rc : 0;
+}
+
+int gmvae_comm_destroy(void* comm) {
+  if (!comm || !g_rccl.h) return GMVAE_E_NULL;
+  return g_rccl.CommDestroy(comm) ? 1000 : 0;
+}
+
+/* one data-parallel training step on `stream`: gradient sums -> ONE RCCL all-reduce -> TF-Adam scaled by 1/count */
+int gmvae_dp_step(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
+                  float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1,
+                  float beta2, float epsilon, void* comm, void* stream) {
+  if (!comm || !g_rccl.h || !step_dev) return GMVAE_E_NULL;
+  int rc = gmvae_step(dims, model, x, nullptr, nullptr, params, grads, workspace, seed, 0, step_dev, stream);
+  if (rc) return rc;
+  Layout L;
+  build_layout(*dims, model, L);
+  const int nrc = g_rccl.AllReduce(grads, grads, (size_t)L.P_pad + GMVAE_TAIL, /*ncclFloat*/ 7, /*ncclSum*/ 0, comm,
+                                   static_cast<hipStream_t>(stream));
+  if (nrc) return 1000 + nrc;
+  return adam_tf_step(params, m, v, grads, L.P_pad, lr, beta1, beta2, epsilon, 0, step_dev, 1.f, grads + L.P_pad + 4,
+                      stream);
+}
+
+/* the same step captured once into a hipGraph (RCCL kernels included); replay with gmvae_train_graph_launch */
+int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
+                          float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1,
+                          float beta2, float epsilon, void* comm, void** graph_out) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!graph_out || !comm) return GMVAE_E_NULL;
+  hipStream_t cs;
+  hipError_t he = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+  if (he != hipSuccess) return (int)he;
+  // warm-up outside capture: RCCL sets up its channels on first use of a communicator.  The gradient buffer is
+  // scratch at this point (gmvae_step overwrites it), so reducing it changes no training state.
+  Layout L;
+  build_layout(*dims, model, L);
+  int rc = g_rccl.AllReduce(grads, grads, (size_t)L.P_pad + GMVAE_TAIL, 7, 0, comm, cs) ? 1000 : 0;
+  hipStreamSynchronize(cs);
+  GmvaeTrainGraph* tg = new GmvaeTrainGraph();
+  if (rc == 0) {
+    he = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (he != hipSuccess) rc = (int)he;
+  }
+  if (rc == 0) {
+    rc = gmvae_dp_step(dims, model, x, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, comm, cs);
+    he = hipStreamEndCapture(cs, &tg->graph);
+    if (rc == 0 && he != hipSuccess) rc = (int)he;
+  }
+  if (rc == 0) {
+    he = hipGraphInstantiate(&tg->exec, tg->graph, nullptr, nullptr, 0);
+    if (he != hipSuccess) rc = (int)he;
+  }
+  hipStreamDestroy(cs);
+  if (rc != 0) {
+    if (tg->graph) hipGraphDestroy(tg->graph);
+    delete tg;
+    (void)hipGetLastError();
+    return rc;
+  }
+  *graph_out = tg;
+  return 0;
 }
 
 }  // extern "C"

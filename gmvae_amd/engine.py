@@ -229,6 +229,42 @@ class Engine:
         self.adam(lr)
         return self.grads[self.P:]
 
+    # -------------------------------------------------- data parallel over RCCL inside the C library
+    def enable_rccl(self):
+        """Creates this rank's RCCL communicator inside libgmvae_hip.so (the 128-byte unique id travels over
+        torch.distributed).  Afterwards train_step / capture_train_step(all_reduce=True) enqueue
+        gradients -> ONE all-reduce -> Adam from a single C call (or one hipGraph)."""
+        import torch.distributed as dist
+        if getattr(self, "_comm", None):
+            return self._comm
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            L.check(L.lib.gmvae_comm_unique_id(L.rccl_path(), buf), "gmvae_comm_unique_id")
+        if world > 1:
+            t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            t = t.to(self.device) if dist.get_backend() == "nccl" else t
+            dist.broadcast(t, src=0)
+            buf = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+        comm = C.c_void_p()
+        torch.cuda.synchronize()
+        L.check(L.lib.gmvae_comm_init(L.rccl_path(), buf, rank, world, C.byref(comm)), "gmvae_comm_init")
+        self._comm = comm
+        return comm
+
+    def dp_step(self, x, lr: float = 1e-3):
+        """gmvae_dp_step: one C call enqueues step + RCCL all-reduce + Adam on the current stream."""
+        x = self._prep_x(x)
+        d, ws = self._workspace(x.shape[0])
+        self._keep = (x, None, None)
+        rc = L.lib.gmvae_dp_step(C.byref(d), self.model, L.ptr(x), L.ptr(self.params), L.ptr(self.m), L.ptr(self.v),
+                                 L.ptr(self.grads), L.ptr(ws), self.noise_seed, L.ptr(self.step_dev), lr, 0.9, 0.999,
+                                 1e-8, self._comm, L.current_stream())
+        L.check(rc, "gmvae_dp_step")
+        self.global_step += 1
+        return self.grads[self.P:]
+
     # -------------------------------------------------- hipGraph fast path
     def capture_train_step(self, B: int, lr: float = 1e-3, all_reduce: bool = False):
         """One hipGraph for noise + fwd + bwd + Adam at batch size B, captured and owned by the HIP
@@ -236,14 +272,40 @@ class Engine:
         the step is two eager halves around ONE RCCL all-reduce instead: torch's RCCL stream handling
         is not captured here."""
         import torch.distributed as dist
-        do_ar = all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        do_ar = all_reduce and ((dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+                                or getattr(self, "_comm", None) is not None)
         key = (B, lr, do_ar)
         if key in self._graphs:
             return self._graphs[key][:2]
         static_x = torch.zeros(B, self.D, dtype=torch.uint8, device=self.device)
         d, ws = self._workspace(B)
         self.step_dev.fill_(self.global_step)
+        if do_ar and getattr(self, "_comm", None):
+            torch.cuda.synchronize()
+            handle = C.c_void_p()
+            rc = L.lib.gmvae_dp_graph_create(C.byref(d), self.model, L.ptr(static_x), L.ptr(self.params), L.ptr(self.m),
+                                             L.ptr(self.v), L.ptr(self.grads), L.ptr(ws), self.noise_seed,
+                                             L.ptr(self.step_dev), lr, 0.9, 0.999, 1e-8, self._comm, C.byref(handle))
+            if rc == 0:
+                launch = L.lib.gmvae_train_graph_launch
+                self.dp_mode = "rccl-in-hipgraph"
+
+                def replay():
+                    rc2 = launch(handle, L.current_stream())
+                    if rc2:
+                        L.check(rc2, "gmvae_train_graph_launch")
+                    self.global_step += 1
+                self._graphs[key] = (static_x, replay, handle)
+                return static_x, replay
+            self.step_dev.fill_(self.global_step)   # capture refused: eager C-side step instead
+            self.dp_mode = "rccl-eager-c"
+
+            def replay():
+                self.dp_step(static_x, lr)
+            self._graphs[key] = (static_x, replay, None)
+            return static_x, replay
         if do_ar:
+            self.dp_mode = "torch.distributed"
             def replay():
                 self.step(static_x, use_step_dev=True)
                 dist.all_reduce(self.grads)

@@ -192,6 +192,23 @@ int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x,
 int gmvae_train_graph_launch(void* graph, void* stream);
 int gmvae_train_graph_destroy(void* graph);
 
+/* ---- data parallel over RCCL (no reference counterpart: the reference is single-device, scripts/runners.py:193).
+ * RCCL is bound with dlopen(rccl_path or "librccl.so") at first use.  Rank 0 calls gmvae_comm_unique_id and
+ * distributes the 128 bytes by any means (torch.distributed broadcast in gmvae_amd); every rank then calls
+ * gmvae_comm_init.  gmvae_dp_step = gmvae_step (Philox mode) -> ONE all-reduce(SUM) of grads[P_padded + TAIL]
+ * -> adam_tf_step with grad_scale = 1/tail[4], all enqueued on `stream`.  gmvae_dp_graph_create warms RCCL up
+ * with one all-reduce of the (scratch) gradient buffer and changes no training state.
+ * Return codes >= 1000 are 1000 + ncclResult_t. */
+int gmvae_comm_unique_id(const char* rccl_path, char* out128);
+int gmvae_comm_init(const char* rccl_path, const char* id128, int rank, int world, void** comm);
+int gmvae_comm_destroy(void* comm);
+int gmvae_dp_step(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
+                  float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1,
+                  float beta2, float epsilon, void* comm, void* stream);
+int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
+                          float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1,
+                          float beta2, float epsilon, void* comm, void** graph_out);
+
 /* Debugging aid: byte offset inside the workspace of a named intermediate ("hy1","hg1","hd1","y",
  * "logits","qp","pp","z","g","dqp","dpp","dlogits","dbuf0".."dbuf2","s1","s4", ...). */
 int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, uint64_t* byte_offset);

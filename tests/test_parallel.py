@@ -108,3 +108,27 @@ def test_hip_step_sharded_sum_equals_full_batch():
     assert tacc[4] == tail[4] == 256
     assert abs(tacc[0] - tail[0]) <= 1e-5 * abs(tail[0])
     assert np.abs(acc - full).max() <= 2e-5 * np.abs(full).max()
+
+
+@pytest.mark.gpu
+def test_rccl_in_library_world1_matches_plain_step():
+    """The C-side RCCL path (communicator of one rank on this GPU): gmvae_dp_step and the captured DP graph
+    give the same trajectory as step + Adam without any collective."""
+    from gmvae_amd.engine import Engine
+    x, _, _ = O.make_inputs(O.Dims(D=784, L=16, K=10, hidden=(64,)), 128)
+    xt = torch.from_numpy(x).cuda()
+    ref = Engine("gmvae", 784, 16, 10, [64], random_seed=5)
+    for _ in range(4):
+        ref.train_step(xt, lr=1e-3)
+    e = Engine("gmvae", 784, 16, 10, [64], random_seed=5)
+    e.enable_rccl()
+    e.dp_step(xt, 1e-3)
+    e.dp_step(xt, 1e-3)
+    sx, replay = e.capture_train_step(128, lr=1e-3, all_reduce=True)
+    sx.copy_(xt)
+    replay()
+    replay()
+    torch.cuda.synchronize()
+    assert e.global_step == ref.global_step == 4
+    assert torch.allclose(e.params.detach(), ref.params.detach(), atol=1e-6)
+    assert int(e.step_dev[0].item()) == 4
