@@ -190,11 +190,12 @@ def main():
         cpu = None
         if not a.no_cpu_baseline:
             r = cpu_baseline(model_id, d, B, flat0, x_np, eps_np, u_np, a.cpu_seconds)
-            cpu = {"value": r["all"][0], "unit": "ELBO-samples/sec", "cores": r["all"][2], "kind": "port",
-                   "sample": f"{r['all'][1]} full steps (fwd+bwd+TF-Adam, fp32 NumPy/BLAS oracle) of the same "
-                             f"B={B} batch; 1-thread (reference's intra_op=inter_op=1): {r['one'][0]:.0f}/s over "
-                             f"{r['one'][1]} steps",
-                   "value_1thread": r["one"][0]}
+            best = "one" if r["one"][0] >= r["all"][0] else "all"      # the faster CPU variant is the baseline
+            cpu = {"value": r[best][0], "unit": "ELBO-samples/sec", "cores": r[best][2], "kind": "port",
+                   "sample": f"{r[best][1]} full steps (fwd+bwd+TF-Adam, fp32 NumPy/BLAS oracle) of the same "
+                             f"B={B} batch on {r[best][2]} thread(s); all {r['all'][2]} cores: {r['all'][0]:.0f}/s, "
+                             f"1 thread (the reference pins intra_op=inter_op=1): {r['one'][0]:.0f}/s",
+                   "value_all_cores": r["all"][0], "value_1thread": r["one"][0]}
         out = {
             "metric": "ELBO-samples/sec", "value": value, "unit": "samples/sec", "n_gpus": n_gpus, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",

@@ -133,6 +133,26 @@ def test_step_matches_oracle(H, name, d, B):
     H.compare_step(model, d, p, x, eps, u)
 
 
+@pytest.mark.parametrize("env", [{}, {"GMVAE_NO_MEGA": "1"}, {"GMVAE_NO_FUSED": "1"}],
+                         ids=["mega", "chain-kernels", "general-schedule"])
+@pytest.mark.parametrize("B,L", [(1024, 64), (40, 16), (7, 8)])
+def test_all_three_schedules_match_oracle(H, env, B, L, monkeypatch):
+    """The same eligible configuration through (a) the single-launch mega kernel, (b) the chain kernels,
+    (c) the general one-launch-per-level schedule: each must meet the oracle tolerance on its own."""
+    for k in ("GMVAE_NO_MEGA", "GMVAE_NO_FUSED"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    d = O.Dims(D=784, L=L, K=10, hidden=(64,))
+    rng = np.random.default_rng(B + L)
+    p = O.init_params(O.MODEL_GMVAE, d, rng)
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    x, eps, u = O.make_inputs(d, B)
+    H.compare_step(O.MODEL_GMVAE, d, p, x, eps, u)
+
+
 @pytest.mark.parametrize("D,K,expect", [(784, 10, 541.124804), (3072, 64, 2125.189256)])
 def test_kat_zero_weights_on_gpu(H, D, K, expect):
     """all-zero parameters -> loss = D ln2 - ln K for any data/noise."""
