@@ -184,6 +184,17 @@ def main():
                 "step_flops_alg": step_flops, "step_tflops_alg": step_flops / (dt / a.steps) * 1e-12,
                 "step_frac_of_mfma_peak": step_flops / (dt / a.steps) * 1e-12 / PEAK_F32_MFMA_TFLOPS,
                 "launches_per_step": len(levels) + 1, "sum_kernel_usec": sum_us}
+        # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE;
+        # rocprofv3 --pmc cannot run inside this process): profiles/round1_traffic.json, same workload only
+        try:
+            if (a.model, B, a.hidden, a.layers, a.latent, a.components, a.data_dim, a.n_samples) == ("gmvae", 1024, 64, 1, 64, 10, 784, 1):
+                tj = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))
+                key = [k for k in tj if k.startswith("gmvae::mega_fwd_bwd")] if dom[0].startswith("mega") else []
+                if key:
+                    roof["traffic"] = tj[key[0]]["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/round1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except Exception:
+            pass
         if a.levels:
             for nm, us, fl in levels:
                 print(f"  {nm:28s} {us:9.2f} us  {fl / max(us, 1e-9) * 1e-6:8.2f} TFLOP/s", file=sys.stderr)

@@ -197,6 +197,36 @@ __device__ __forceinline__ void op_load(const void* __restrict__ base, const int
   }
 }
 
+// Lean variant for the common case -- tile completely inside the operand, chunk completely inside
+// [kb, ke), 16-byte loads legal, no row broadcast / ones row / k scale: no clamps, no selects, shift-only
+// slot arithmetic.  (SQ counters showed the grouped launches VALU-issue-bound on the predicated loader:
+// ~580 VALU instructions per wave around 16 MFMAs, profiles/round1_pmc_sq_per_kernel.txt.)
+template <int KIND, int BMN, int BK, int NS>
+__device__ __forceinline__ void op_load_fast(const void* __restrict__ base, const int ld, const int mn0, const int k0,
+                                             const int tid, float4 (&r)[NS]) {
+  constexpr bool U8 = (KIND & 1) != 0, MC = (KIND & 2) != 0;
+  const unsigned char* b8 = static_cast<const unsigned char*>(base);
+  const float* b32 = static_cast<const float*>(base);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int s = tid + i * kThreads;
+    uint32_t e;
+    if (!MC) {
+      constexpr int Q = BK / 4;
+      e = (uint32_t)(mn0 + (s & 3) + 4 * (s / (4 * Q))) * (uint32_t)ld + (uint32_t)(k0 + (((s >> 2) % Q) << 2));
+    } else {
+      constexpr int Q = BMN / 4;
+      e = (uint32_t)(k0 + (s & 3) + 4 * (s / (4 * Q))) * (uint32_t)ld + (uint32_t)(mn0 + (((s >> 2) % Q) << 2));
+    }
+    if (U8) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(b8 + e);
+      r[i] = make_float4((float)(w & 0xff), (float)((w >> 8) & 0xff), (float)((w >> 16) & 0xff), (float)(w >> 24));
+    } else {
+      r[i] = *reinterpret_cast<const float4*>(b32 + e);
+    }
+  }
+}
+
 // LDS image of an operand tile is always [k][mn] with an odd leading dimension.
 template <int BMN, int BK, int LD, int NS>
 __device__ __forceinline__ void op_store(float* __restrict__ T, const bool mc, const int tid, const float4 (&r)[NS]) {
@@ -286,7 +316,13 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
     const int NC = (ke - kb + kBK - 1) / kBK;
     if (NC == 0) continue;
 
+    // wave-uniform eligibility of the lean loader for this tile
+    const bool a_fast = akind < 4 && a_div == 1 && !a_ones && m0 + C::BM <= a_n;
+    const bool b_fast = bkind < 4 && b_div == 1 && kscale == nullptr && n0 + C::BN <= b_n;
+
     float4 ra[C::NSA], rb[C::NSB];
+#define GMVAE_FAST_A(KIND) op_load_fast<KIND, C::BM, kBK, C::NSA>(a_ptr, a_ld, m0, k0_, tid, ra)
+#define GMVAE_FAST_B(KIND) op_load_fast<KIND, C::BN, kBK, C::NSB>(b_ptr, b_ld, n0, k0_, tid, rb)
 #define GMVAE_LOAD_A(KIND) \
   op_load<KIND, C::BM, kBK, C::NSA>(a_ptr, a_ld, a_n, a_ones, a_div, nullptr, K, m0, k0_, ke, tid, ra)
 #define GMVAE_LOAD_B(KIND) \
@@ -294,6 +330,15 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
 #define GMVAE_GLOAD(c_)                                                     \
   {                                                                         \
     const int k0_ = kb + (c_) * kBK;                                        \
+    const bool full_ = k0_ + kBK <= ke;                                     \
+    if (a_fast && full_) {                                                  \
+      switch (akind) {                                                      \
+        case 0: GMVAE_FAST_A(0); break;                                     \
+        case 1: GMVAE_FAST_A(1); break;                                     \
+        case 2: GMVAE_FAST_A(2); break;                                     \
+        default: GMVAE_FAST_A(3); break;                                    \
+      }                                                                     \
+    } else                                                                  \
     switch (akind) {                                                        \
       case 0: GMVAE_LOAD_A(0); break;                                       \
       case 1: GMVAE_LOAD_A(1); break;                                       \
@@ -304,6 +349,9 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
       case 6: GMVAE_LOAD_A(6); break;                                       \
       default: GMVAE_LOAD_A(7); break;                                      \
     }                                                                       \
+    if (b_fast && full_) {                                                  \
+      if (bkind == 0) GMVAE_FAST_B(0); else GMVAE_FAST_B(2);                \
+    } else                                                                  \
     switch (bkind) {                                                        \
       case 0: GMVAE_LOAD_B(0); break;                                       \
       case 2: GMVAE_LOAD_B(2); break;                                       \
@@ -348,6 +396,8 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
       __syncthreads();
     }
 #undef GMVAE_LOAD_A
+#undef GMVAE_FAST_A
+#undef GMVAE_FAST_B
 #undef GMVAE_LOAD_B
 #undef GMVAE_GLOAD
 #undef GMVAE_LSTORE
