@@ -138,9 +138,15 @@ def main():
     # The GPU drops its clocks while the host runs the fp64 parity check above; a step is ~100 us, so W
     # warm-up steps alone can be shorter than the DVFS ramp (measured: 2x slower timed region).  Spin the
     # same step untimed for a fixed wall time first, THEN do the W warm-up steps the contract asks for.
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.75:
-        for _ in range(50):
+    if world == 1:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.75:
+            for _ in range(50):
+                step_fn()
+            torch.cuda.synchronize()
+    else:
+        # every rank must issue the SAME number of steps (each contains a collective): fixed count, not wall time
+        for _ in range(4000):
             step_fn()
         torch.cuda.synchronize()
     for _ in range(a.warmup):
