@@ -118,9 +118,25 @@ struct WS {
 constexpr int GMP_PARTS = 64;
 
 // ---- fused schedule for the launch-bound default sizes (chain.hpp) ---------------------------
+// measured (tools/sweep.sh, B=1024 D=784 H=64): 4 forward splits of 256 and 8 batch splits with 64x64 tiles
+// for the weight-gradient launch are the fastest combination (82 us/step vs 88 with 7 / 4 splits, 32x32 tiles)
+static int dw_splits(long long B) {
+  long long ns = B / 128;
+  if (ns < 1) ns = 1;
+  if (ns > NS_MAX) ns = NS_MAX;
+  const char* e = getenv("GMVAE_NSPLIT");
+  if (e && atoi(e) >= 1 && atoi(e) <= NS_MAX) ns = atoi(e);
+  return (int)ns;
+}
 static int fwd_splits(int D) {
-  int ns = (D + 127) / 128;
+  int ns = (D + 255) / 256;
+  const char* e = getenv("GMVAE_FWD_SPLITS");      // tuning hook (tools/sweep.sh)
+  if (e && atoi(e) >= 1) ns = atoi(e);
   return ns < 1 ? 1 : (ns > NS_MAX ? NS_MAX : ns);
+}
+static int env_cfg(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
 }
 static bool fused_ok(const GmvaeDims& d, int model);
 // the single-launch per-row kernel (mega.hpp): needs the fused schedule, 16-byte aligned x rows and its LDS budget
@@ -205,7 +221,11 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
   }
   w.dz = take(R * Lz);
   w.dqp = take(R * 2 * Lz);
-  w.slabs = take((uint64_t)num_splits(R) * L.P_pad);
+  {
+    int ns = num_splits(R);
+    if (fused_ok(d, model) && dw_splits(d.B) > ns) ns = dw_splits(d.B);
+    w.slabs = take((uint64_t)ns * L.P_pad);
+  }
   w.cl_pred = reinterpret_cast<int32_t*>(take(B));
   w.bytes = off;
 }
@@ -479,9 +499,9 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
     }
     ax.ntasks = nt;
     ax.nblocks = ax.noise_blocks + nt;
-    launch_group(cx, g, "fwd_x_first_layers_splitk+aux", 0);
+    launch_group(cx, g, "fwd_x_first_layers_splitk+aux", env_cfg("GMVAE_P1_CFG", 0));
   }
-  const int NS = num_splits(B);
+  const int NS = dw_splits(B);
   const long long PP = (long long)L.P_pad;
   float* sl = w.slabs;
   float* tail = a.backward ? a.grads + L.P_pad : a.tail;
@@ -519,7 +539,7 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
       g.add(p_tn(w.y, false, K, 1, w.dpp, 2 * Lz, K, 2 * Lz, B, sl + L.prior.w[0], sl + L.prior.b[0], NS, PP, nullptr));
       g.add(p_tn(w.hg[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + G.w[1], sl + G.b[1], NS, PP, nullptr)); // dWg1
       g.add(p_tn(w.z, false, Lz, 1, w.dbuf[0], H, Lz, H, B, sl + Dn.w[0], sl + Dn.b[0], NS, PP, nullptr));        // dWd0
-      launch_group(cx, g, "bwd_dw_all", 0);
+      launch_group(cx, g, "bwd_dw_all", env_cfg("GMVAE_DW_CFG", B >= 512 ? 1 : 0));
     }
     return finish_fused(cx, a, L, w, tail, NS, B);
   }
