@@ -401,13 +401,16 @@ __global__ void finalize_grads(const float* __restrict__ slabs, int nslab, long 
     a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
   }
   if (gmp_part && i4 >= gmp_off && i4 < gmp_off + gmp_len) {
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < 4; ++j) {
-      const long long e = i4 + j - gmp_off;
-      if (e < gmp_len)
-        for (int g = 0; g < gmp_n; ++g) v[j] += gmp_part[(long long)g * gmp_len + e];
+    // mixture-prior gradients: sum the per-workgroup partials (rows of gmp_len floats, 16-byte aligned);
+    // independent 16-byte loads, 8 in flight
+    const float* p0 = gmp_part + (i4 - gmp_off);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int g = 0; g < gmp_n; ++g) {
+      const float4 o = *reinterpret_cast<const float4*>(p0 + (long long)g * gmp_len);
+      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
     }
-    a = make_float4(v[0], v[1], v[2], v[3]);
+    a = acc;
   }
   *reinterpret_cast<float4*>(grads + i4) = a;
 }
