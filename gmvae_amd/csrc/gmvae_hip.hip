@@ -26,6 +26,7 @@ namespace {
 constexpr int MAXH = GMVAE_MAX_HIDDEN;
 constexpr int NS_MAX = 16;
 constexpr int MAX_LEVELS = 96;
+constexpr int GMP_PARTS = 64;
 
 // ------------------------------------------------------------------ layout
 struct NetL {
@@ -115,7 +116,6 @@ struct WS {
   int32_t* cl_pred;
   uint64_t bytes;
 };
-constexpr int GMP_PARTS = 64;
 
 // ---- fused schedule for the launch-bound default sizes (chain.hpp) ---------------------------
 // measured (tools/sweep.sh, B=1024 D=784 H=64): 4 forward splits of 256 and 8 batch splits with 64x64 tiles
@@ -139,12 +139,18 @@ static int env_cfg(const char* name, int dflt) {
   return (e && e[0]) ? atoi(e) : dflt;
 }
 static bool fused_ok(const GmvaeDims& d, int model);
-// the single-launch per-row kernel (mega.hpp): needs the fused schedule, 16-byte aligned x rows and its LDS budget
+// the single-launch per-row kernel (mega.hpp), all three models: one hidden layer <= 64, S = 1, 16-byte aligned
+// x rows, its LDS budget, and (VAE_GMP) one prior-gradient partial per workgroup
 static bool mega_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_MEGA");
   if (e && atoi(e)) return false;
-  if (!fused_ok(d, model) || d.D % 16) return false;
-  return (size_t)mega_lay(d.hidden[0], d.L, d.K, d.D).total * 4 <= 160 * 1024;
+  const char* e2 = getenv("GMVAE_NO_FUSED");
+  if (e2 && atoi(e2)) return false;
+  if (d.n_hidden != 1 || d.S != 1 || d.D % 16) return false;
+  const int H = d.hidden[0];
+  if (H % 16 || H > 64 || d.L % 8 || d.L > 128 || d.K > 64) return false;
+  if (model == GMVAE_MODEL_VAE_GMP && (d.B + kPanel - 1) / kPanel > GMP_PARTS) return false;
+  return (size_t)mega_lay(H, d.L, d.K, d.D, model).total * 4 <= 160 * 1024;
 }
 static bool fused_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_FUSED");
@@ -213,17 +219,19 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     w.stamps = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * 16 * 2));
     w.img_f = take((uint64_t)fwd_lay(d.hidden[0], d.L, d.K).img);
     w.img_b = take((uint64_t)bwd_lay(d.hidden[0], d.L, d.K).img);
-    if (mega_ok(d, model)) {
-      const MegaLay ml = mega_lay(d.hidden[0], d.L, d.K, d.D);
-      w.img_m = take((uint64_t)ml.img);
-      w.dimg = take((uint64_t)ml.nch * ml.chunk);
-    }
+  }
+  if (mega_ok(d, model)) {
+    const MegaLay ml = mega_lay(d.hidden[0], d.L, d.K, d.D, model);
+    w.img_m = take((uint64_t)ml.img);
+    w.dimg = take((uint64_t)ml.nch * ml.chunk);
+    if (!w.s1) w.s1 = take((uint64_t)fwd_splits(d.D) * B * 2 * d.hidden[0]);
+    if (!w.stamps) w.stamps = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * 16 * 2));
   }
   w.dz = take(R * Lz);
   w.dqp = take(R * 2 * Lz);
   {
     int ns = num_splits(R);
-    if (fused_ok(d, model) && dw_splits(d.B) > ns) ns = dw_splits(d.B);
+    if ((fused_ok(d, model) || mega_ok(d, model)) && dw_splits(d.B) > ns) ns = dw_splits(d.B);
     w.slabs = take((uint64_t)ns * L.P_pad);
   }
   w.cl_pred = reinterpret_cast<int32_t*>(take(B));
@@ -391,28 +399,150 @@ static void rowk(Ctx& cx, const char* name) {
   cx.mark(name, 0);
 }
 
-// end of the fused schedule: slab reduce + loss tail (+ TF-Adam in the graph path)
+// end of the fused schedules: slab reduce + loss tail (+ TF-Adam in the graph path)
 static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, float* tail, int NS, int B) {
   hipStream_t st = cx.st;
+  const GmvaeDims& d = *a.d;
   const long long PP = (long long)L.P_pad;
   float* sl = w.slabs;
-  if (a.adam_p && a.step_dev) {   // graph path: slab reduce + loss tail + Adam in one launch
+  const bool gmp = a.model == GMVAE_MODEL_VAE_GMP;
+  const float* nent = a.model == GMVAE_MODEL_GMVAE ? w.nent : nullptr;
+  if (a.adam_p && a.step_dev && !gmp) {   // graph path: slab reduce + loss tail + Adam in one launch
     FinalArgs fa;
     fa.slabs = sl; fa.nslab = NS; fa.P = PP; fa.grads = a.grads; fa.p = a.adam_p; fa.m = a.adam_m; fa.v = a.adam_v;
     fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = 1; fa.count = (float)B;
-    fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = w.nent;
+    fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = nent;
     fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
     hipLaunchKernelGGL(finalize_adam, dim3((unsigned)((PP / 4 + 255) / 256) + 1), dim3(256), 0, st, fa);
     rowk(cx, "finalize_adam");
     return cx.err;
   }
-  hipLaunchKernelGGL(loss_tail, dim3(1), dim3(1024), 0, st, w.logw, w.logpx, w.logq, w.logp, w.nent, (float*)nullptr,
-                     tail, B, 1, a.step_dev);
+  hipLaunchKernelGGL(loss_tail, dim3(1), dim3(1024), 0, st, w.logw, w.logpx, w.logq, w.logp, nent, (float*)nullptr, tail,
+                     B, 1, a.step_dev);
   rowk(cx, "loss_tail");
+  const int KLp = (int)pad4((uint64_t)d.K * d.L);
   hipLaunchKernelGGL(finalize_grads, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, sl, NS, PP, a.grads,
-                     (const float*)nullptr, 0, 0, 0LL);
+                     gmp ? w.gmp_part : (const float*)nullptr, (B + kPanel - 1) / kPanel,
+                     gmp ? 2 * KLp + (int)pad4(d.K) : 0, (long long)L.loc);
   rowk(cx, "finalize_grads");
+  if (a.adam_p && a.step_dev) {           // VAE_GMP in the graph path: its prior partials need finalize_grads first
+    hipLaunchKernelGGL(adam_tf, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, a.adam_p, a.adam_m, a.adam_v,
+                       a.grads, PP, a.lr, a.beta1, a.beta2, a.epsilon, (uint64_t)0, a.step_dev, 1.f / (float)B,
+                       (const float*)nullptr);
+    rowk(cx, "adam_tf");
+  }
   return cx.err;
+}
+
+// ---- the mega schedule (all three models): first-layer split-K GEMM (+ aux) -> mega_fwd_bwd -> all dW -> finish
+static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, const float* eps, const float* u,
+                         float* gen_eps, uint64_t n_eps, float* gen_u, uint64_t n_u) {
+  const GmvaeDims& d = *a.d;
+  const int model = a.model;
+  const bool gm = model == GMVAE_MODEL_GMVAE, gmp = model == GMVAE_MODEL_VAE_GMP;
+  const int B = d.B, K = d.K, Lz = d.L, D = d.D, H = d.hidden[0];
+  const float* P = a.params;
+  hipStream_t st = cx.st;
+  const int NSF = fwd_splits(D), NS = dw_splits(B);
+  const long long PP = (long long)L.P_pad;
+  float* sl = w.slabs;
+  float* tail = a.grads + L.P_pad;
+  const NetL &E = gm ? L.ency : L.enc, &G = L.encg, &Dn = L.dec;
+  const MegaLay ml = mega_lay(H, Lz, K, D, model);
+  const int H2 = gm ? 2 * H : H;
+  {  // P1: first layer(s) over the uint8 batch as single-round split-K partials + auxiliary workgroups
+    Group g;
+    Problem p0 = p_nn(a.x, true, D, P + E.w[0], H, B, H, D, w.s1, H2, nullptr, false);
+    p0.splits = NSF; p0.split_stride = (long long)B * H2;
+    g.add(p0);
+    if (gm) {
+      Problem p1 = p_nn(a.x, true, D, P + G.w[0], H, B, H, D, w.s1 + H, H2, nullptr, false);
+      p1.splits = NSF; p1.split_stride = (long long)B * H2;
+      g.add(p1);
+    }
+    Aux& ax = g.L.aux;
+    ax.eps = gen_eps; ax.u = gen_u; ax.n_eps = n_eps; ax.n_u = n_u; ax.seed = a.seed; ax.step = a.step;
+    ax.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
+    ax.noise_blocks = (int)(((n_eps + 3) / 4 + (n_u + 3) / 4 + kThreads - 1) / kThreads);
+    int nt = 0;
+    auto task = [&](float* dst, int ld, const float* src, int rows, int cols, int src_ld) {
+      ImgTask& t = ax.task[nt++];
+      t.dst = dst; t.ld = ld; t.src = src; t.rows = rows; t.cols = cols; t.src_ld = src_ld; t.trans = 0;
+    };
+    float* im = w.img_m;
+    if (gm) {
+      task(im + ml.W_y1, ml.ldY1, P + E.w[1], H, K, K);
+      task(im + ml.W_g0y, ml.ldG0, P + G.w[0] + (uint64_t)D * H, K, H, H);
+      task(im + ml.W_p, ml.ldP, P + L.prior.w[0], K, 2 * Lz, 2 * Lz);
+      task(im + ml.W_g1, ml.ldG1, P + G.w[1], H, 2 * Lz, 2 * Lz);
+      task(im + ml.b_y1, K, P + E.b[1], 1, K, K);
+      task(im + ml.b_g0, H, P + G.b[0], 1, H, H);
+      task(im + ml.b_p, 2 * Lz, P + L.prior.b[0], 1, 2 * Lz, 2 * Lz);
+      task(im + ml.b_g1, 2 * Lz, P + G.b[1], 1, 2 * Lz, 2 * Lz);
+    } else {                       // the encoder's second layer takes the q-head slot
+      task(im + ml.W_g1, ml.ldG1, P + E.w[1], H, 2 * Lz, 2 * Lz);
+      task(im + ml.b_g1, 2 * Lz, P + E.b[1], 1, 2 * Lz, 2 * Lz);
+      if (gmp) {
+        task(im + ml.M_loc, ml.ldM, P + L.loc, K, Lz, Lz);
+        task(im + ml.M_raw, ml.ldM, P + L.rawscale, K, Lz, Lz);
+        task(im + ml.M_mix, K, P + L.mixlog, 1, K, K);
+      }
+    }
+    task(im + ml.b_y0, H, P + E.b[0], 1, H, H);
+    task(im + ml.W_d0, ml.ldD0, P + Dn.w[0], Lz, H, H);
+    task(im + ml.b_d0, H, P + Dn.b[0], 1, H, H);
+    for (int c = 0; c < ml.nch; ++c) {             // decoder chunk images: [H rows of Wd1 | bias row]
+      const int nc = (D - c * kCW) < kCW ? (D - c * kCW) : kCW;
+      task(w.dimg + (uint64_t)c * ml.chunk, ml.ldc, P + Dn.w[1] + c * kCW, H, nc, D);
+      task(w.dimg + (uint64_t)c * ml.chunk + H * ml.ldc, nc, P + Dn.b[1] + c * kCW, 1, nc, nc);
+    }
+    ax.ntasks = nt;
+    ax.nblocks = ax.noise_blocks + nt;
+    launch_group(cx, g, "fwd_x_first_layers_splitk+aux", env_cfg("GMVAE_P1_CFG", 0));
+  }
+  {  // the whole per-row forward + backward in one launch
+    MegaArgs c;
+    memset(&c, 0, sizeof(c));
+    c.model = model;
+    c.B = B; c.H = H; c.L = Lz; c.K = K; c.D = D; c.NS = NSF;
+    c.c = d.raw_sigma_bias; c.smin = d.sigma_min; c.invT = 1.f / d.temperature; c.gen_bias = d.gen_bias_init;
+    c.s1 = w.s1; c.img = w.img_m; c.dimg = w.dimg; c.x = a.x; c.eps = eps; c.u = u;
+    c.hy1 = w.he[1]; c.y = w.y; c.hg1 = w.hg[1]; c.z = w.z; c.hd1 = w.hd[1]; c.g = w.g;
+    c.dhd1 = w.dbuf[0]; c.dqp = w.dqp; c.dpp = w.dpp; c.dhg1 = w.dbuf[1]; c.dlogits = w.dlogits; c.dhy1 = w.dbuf[2];
+    c.nent = w.nent; c.logq = w.logq; c.logp = w.logp; c.logpx = w.logpx; c.logw = w.logw;
+    c.gmp_part = w.gmp_part;
+    c.dbg = getenv("GMVAE_STAMPS") ? w.stamps : nullptr;
+    static bool mattr = false;
+    if (!mattr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(mega_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      mattr = true;
+    }
+    hipLaunchKernelGGL(mega_fwd_bwd, dim3((B + kPanel - 1) / kPanel), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
+    cx.check();
+    // algorithmic MFMA FLOPs of the launch: forward chain + decoder layer (lambda and its data gradient) + backward chain
+    double macs = (double)H * 2 * Lz + (double)Lz * H + 2.0 * H * D + (double)H * Lz + 2.0 * Lz * H;
+    if (gm) macs += (double)H * K + (double)K * H + (double)K * 2 * Lz + (double)(H + 2 * Lz) * K + (double)K * H;
+    cx.mark("mega_fwd_bwd", 2.0 * B * macs);
+  }
+  {  // every weight gradient in one grouped launch
+    Group g;
+    if (gm) {
+      g.add(p_tn(a.x, true, D, 1, w.dbuf[2], H, D, H, B, sl + E.w[0], sl + E.b[0], NS, PP, nullptr));            // dWy0
+      g.add(p_tn(a.x, true, D, 1, w.dbuf[1], H, D, H, B, sl + G.w[0], sl + G.b[0], NS, PP, nullptr));            // dWg0[x]
+      g.add(p_tn(w.hd[1], false, H, 1, w.g, D, H, D, B, sl + Dn.w[1], sl + Dn.b[1], NS, PP, nullptr));           // dWd1
+      g.add(p_tn(w.y, false, K, 1, w.dbuf[1], H, K, H, B, sl + G.w[0] + (uint64_t)D * H, nullptr, NS, PP, nullptr));
+      g.add(p_tn(w.he[1], false, H, 1, w.dlogits, K, H, K, B, sl + E.w[1], sl + E.b[1], NS, PP, nullptr));       // dWy1
+      g.add(p_tn(w.y, false, K, 1, w.dpp, 2 * Lz, K, 2 * Lz, B, sl + L.prior.w[0], sl + L.prior.b[0], NS, PP, nullptr));
+      g.add(p_tn(w.hg[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + G.w[1], sl + G.b[1], NS, PP, nullptr)); // dWg1
+    } else {
+      g.add(p_tn(a.x, true, D, 1, w.dbuf[1], H, D, H, B, sl + E.w[0], sl + E.b[0], NS, PP, nullptr));            // dWe0
+      g.add(p_tn(w.hd[1], false, H, 1, w.g, D, H, D, B, sl + Dn.w[1], sl + Dn.b[1], NS, PP, nullptr));           // dWd1
+      g.add(p_tn(w.he[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + E.w[1], sl + E.b[1], NS, PP, nullptr)); // dWe1
+    }
+    g.add(p_tn(w.z, false, Lz, 1, w.dbuf[0], H, Lz, H, B, sl + Dn.w[0], sl + Dn.b[0], NS, PP, nullptr));          // dWd0
+    launch_group(cx, g, "bwd_dw_all", env_cfg("GMVAE_DW_CFG", B >= 512 ? 1 : 0));
+  }
+  return finish_fused(cx, a, L, w, tail, NS, B);
 }
 
 // The fused schedule: 9 launches instead of 21 for GMVAE with one hidden layer at sizes whose
@@ -458,8 +588,7 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
       ImgTask& t = ax.task[nt++];
       t.dst = dst; t.ld = ld; t.src = src; t.rows = rows; t.cols = cols; t.src_ld = src_ld; t.trans = trans;
     };
-    const bool mega = a.backward && mega_ok(d, a.model);
-    if (!mega) {
+    {
       task(w.img_f + fl.W_y1, fl.KP, Wy1, H, K, K, 0);
       task(w.img_f + fl.W_g0y, H, Wg0y, K, H, H, 0);
       task(w.img_f + fl.W_p, 2 * Lz, Wp, K, 2 * Lz, 2 * Lz, 0);
@@ -478,24 +607,6 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
         task(w.img_b + bl.W_cT + H * bl.ldC, bl.ldC, Wp, K, 2 * Lz, 2 * Lz, 1);
         task(w.img_b + bl.W_y1T, bl.ldY, Wy1, H, K, K, 1);
       }
-    } else {
-      const MegaLay ml = mega_lay(H, Lz, K, D);
-      task(w.img_m + ml.W_y1, ml.ldY1, Wy1, H, K, K, 0);
-      task(w.img_m + ml.W_g0y, ml.ldG0, Wg0y, K, H, H, 0);
-      task(w.img_m + ml.W_p, ml.ldP, Wp, K, 2 * Lz, 2 * Lz, 0);
-      task(w.img_m + ml.W_g1, ml.ldG1, Wg1, H, 2 * Lz, 2 * Lz, 0);
-      task(w.img_m + ml.W_d0, ml.ldD0, Wd0, Lz, H, H, 0);
-      task(w.img_m + ml.b_y0, H, P + E.b[0], 1, H, H, 0);
-      task(w.img_m + ml.b_y1, K, P + E.b[1], 1, K, K, 0);
-      task(w.img_m + ml.b_g0, H, P + G.b[0], 1, H, H, 0);
-      task(w.img_m + ml.b_p, 2 * Lz, P + L.prior.b[0], 1, 2 * Lz, 2 * Lz, 0);
-      task(w.img_m + ml.b_g1, 2 * Lz, P + G.b[1], 1, 2 * Lz, 2 * Lz, 0);
-      task(w.img_m + ml.b_d0, H, P + Dn.b[0], 1, H, H, 0);
-      for (int c = 0; c < ml.nch; ++c) {             // decoder chunk images: [H rows of Wd1 | bias row]
-        const int nc = (D - c * kCW) < kCW ? (D - c * kCW) : kCW;
-        task(w.dimg + (uint64_t)c * ml.chunk, ml.ldc, P + Dn.w[1] + c * kCW, H, nc, D, 0);
-        task(w.dimg + (uint64_t)c * ml.chunk + H * ml.ldc, nc, P + Dn.b[1] + c * kCW, 1, nc, nc, 0);
-      }
     }
     ax.ntasks = nt;
     ax.nblocks = ax.noise_blocks + nt;
@@ -505,44 +616,6 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
   const long long PP = (long long)L.P_pad;
   float* sl = w.slabs;
   float* tail = a.backward ? a.grads + L.P_pad : a.tail;
-  if (a.backward && mega_ok(d, a.model)) {
-    {  // the whole per-row forward + backward in one launch
-      const MegaLay ml = mega_lay(H, Lz, K, D);
-      MegaArgs c;
-      c.B = B; c.H = H; c.L = Lz; c.K = K; c.D = D; c.NS = NSF;
-      c.c = d.raw_sigma_bias; c.smin = d.sigma_min; c.invT = 1.f / d.temperature; c.gen_bias = d.gen_bias_init;
-      c.s1 = w.s1; c.img = w.img_m; c.dimg = w.dimg; c.x = a.x; c.eps = eps; c.u = u;
-      c.hy1 = w.he[1]; c.y = w.y; c.hg1 = w.hg[1]; c.z = w.z; c.hd1 = w.hd[1]; c.g = w.g;
-      c.dhd1 = w.dbuf[0]; c.dqp = w.dqp; c.dpp = w.dpp; c.dhg1 = w.dbuf[1]; c.dlogits = w.dlogits; c.dhy1 = w.dbuf[2];
-      c.nent = w.nent; c.logq = w.logq; c.logp = w.logp; c.logpx = w.logpx; c.logw = w.logw;
-      c.dbg = getenv("GMVAE_STAMPS") ? w.stamps : nullptr;
-      static bool mattr = false;
-      if (!mattr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(mega_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        mattr = true;
-      }
-      hipLaunchKernelGGL(mega_fwd_bwd, dim3((B + kPanel - 1) / kPanel), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
-      cx.check();
-      // algorithmic MFMA FLOPs of the launch: forward chain + decoder layer (lambda and its data gradient) + backward chain
-      const double macs = (double)H * K + (double)K * H + (double)K * 2 * Lz + (double)H * 2 * Lz + (double)Lz * H   // forward
-                          + 2.0 * H * D                                                                              // decoder fwd + dX
-                          + (double)H * Lz + 2.0 * Lz * H + (double)(H + 2 * Lz) * K + (double)K * H;               // backward
-      cx.mark("mega_fwd_bwd", 2.0 * B * macs);
-    }
-    {  // every weight gradient in one grouped launch
-      Group g;
-      g.add(p_tn(a.x, true, D, 1, w.dbuf[2], H, D, H, B, sl + E.w[0], sl + E.b[0], NS, PP, nullptr));            // dWy0
-      g.add(p_tn(a.x, true, D, 1, w.dbuf[1], H, D, H, B, sl + G.w[0], sl + G.b[0], NS, PP, nullptr));            // dWg0[x]
-      g.add(p_tn(w.hd[1], false, H, 1, w.g, D, H, D, B, sl + Dn.w[1], sl + Dn.b[1], NS, PP, nullptr));           // dWd1
-      g.add(p_tn(w.y, false, K, 1, w.dbuf[1], H, K, H, B, sl + G.w[0] + (uint64_t)D * H, nullptr, NS, PP, nullptr));
-      g.add(p_tn(w.he[1], false, H, 1, w.dlogits, K, H, K, B, sl + E.w[1], sl + E.b[1], NS, PP, nullptr));       // dWy1
-      g.add(p_tn(w.y, false, K, 1, w.dpp, 2 * Lz, K, 2 * Lz, B, sl + L.prior.w[0], sl + L.prior.b[0], NS, PP, nullptr));
-      g.add(p_tn(w.hg[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + G.w[1], sl + G.b[1], NS, PP, nullptr)); // dWg1
-      g.add(p_tn(w.z, false, Lz, 1, w.dbuf[0], H, Lz, H, B, sl + Dn.w[0], sl + Dn.b[0], NS, PP, nullptr));        // dWd0
-      launch_group(cx, g, "bwd_dw_all", env_cfg("GMVAE_DW_CFG", B >= 512 ? 1 : 0));
-    }
-    return finish_fused(cx, a, L, w, tail, NS, B);
-  }
   {  // P2: the whole row-local forward chain
     ChainFwdArgs c;
     c.B = B; c.H = H; c.L = Lz; c.K = K; c.NS = NSF;
@@ -634,6 +707,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   const uint64_t ne = ge ? (uint64_t)R * Lz : 0, nu = gu ? (uint64_t)R * K : 0;
   if (ge) eps = ge;
   if (gu) u = gu;
+  if (a.backward && mega_ok(d, model)) return run_step_mega(cx, a, L, w, eps, u, ge, ne, gu, nu);
   if (fused_ok(d, model) && !a.z_out && !a.y_out && !a.logits_out)
     return run_step_fused(cx, a, L, w, eps, u, ge, ne, gu, nu);
   if (ne + nu) {
@@ -1155,7 +1229,7 @@ int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x,
   he = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
   if (he != hipSuccess) rc = (int)he;
   if (rc == 0) {
-    if (fused_ok(*dims, model)) {
+    if (fused_ok(*dims, model) || mega_ok(*dims, model)) {
       rc = step_with_adam(dims, model, x, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, cs);
     } else {
       rc = gmvae_step(dims, model, x, nullptr, nullptr, params, grads, workspace, seed, 0, step_dev, cs);

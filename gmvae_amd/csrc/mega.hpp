@@ -30,8 +30,11 @@ struct MegaLay {
   int A_hy, A_y, A_hg, A_z, A_hd, A_g;          // forward / decoder operand images ([k][17])
   int A_dhd, A_dqp, A_cat, A_dl;                // backward operand images (overlay the same region)
   int P_lg, P_qp, P_pp, P_eps, P_z, P_hd, P_hg, P_hy, P_y, P_gx, P_u, P_dz, P_dy, nll, red, total;
+  int ldM, M_loc, M_raw, M_mix;      // VAE_GMP: prior variables in the image ([K][L+1], [K][L+1], [KP])
+  int M_inv, M_c, M_w, P_r;          // VAE_GMP: 1/s [K][L+1], per-component constants [KP], softmax weights [KP], resp [16][KP]
 };
-__host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D) {
+// model: 0 VAE (std-normal prior), 1 VAE_GMP (learned mixture prior), 2 GMVAE
+__host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D, int model = 2) {
   MegaLay m;
   m.KP = (K + 15) & ~15; m.K2 = (K + 3) & ~3; m.L2 = 2 * L; m.LP = (L + 15) & ~15;
   m.ldY1 = m.KP + 1; m.ldG0 = H + 1; m.ldP = m.L2 + 1; m.ldG1 = m.L2 + 1; m.ldD0 = H + 1; m.ldc = kCW + 1;
@@ -43,6 +46,9 @@ __host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D) {
   m.W_g1 = take(H * m.ldG1);       // [H][L2+1]
   m.W_d0 = take(L * m.ldD0);       // [L][H+1]
   m.b_y0 = take(H); m.b_y1 = take(m.KP); m.b_g0 = take(H); m.b_p = take(m.L2); m.b_g1 = take(m.L2); m.b_d0 = take(H);
+  m.ldM = L + 1;
+  m.M_loc = m.M_raw = m.M_mix = m.M_inv = m.M_c = m.M_w = m.P_r = 0;
+  if (model == 1) { m.M_loc = take(K * m.ldM); m.M_raw = take(K * m.ldM); m.M_mix = take(m.KP); }
   m.img = GMVAE_P256(o);
   m.chunk = GMVAE_P256((H + 1) * m.ldc);
   m.nch = (D + kCW - 1) / kCW;
@@ -67,6 +73,7 @@ __host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D) {
   o = o > pe_f ? o : pe_f;
   m.nll = take(4 * kPanel);
   m.red = take(kMW * 256);
+  if (model == 1) { m.M_inv = take(K * m.ldM); m.M_c = take(m.KP); m.M_w = take(m.KP); m.P_r = take(kPanel * m.KP); }
   m.total = o;
   return m;
 }
@@ -132,6 +139,7 @@ __device__ __forceinline__ void dma_copy_m(float* __restrict__ lds_dst, const fl
 }
 
 struct MegaArgs {
+  int model;                  // 0 VAE, 1 VAE_GMP, 2 GMVAE
   int B, H, L, K, D, NS;
   float c, smin, invT, gen_bias;
   const float* s1;            // [NS][B][2H] split-K partials of X*[Wy0 | Wg0x]
@@ -142,6 +150,7 @@ struct MegaArgs {
   float *hy1, *y, *hg1, *z, *hd1, *g;                           // saved for the weight gradients
   float *dhd1, *dqp, *dpp, *dhg1, *dlogits, *dhy1;              // pre-activation gradients
   float *nent, *logq, *logp, *logpx, *logw;                     // per-row loss terms
+  float* gmp_part;            // VAE_GMP: per-workgroup partial gradients of (loc, raw_scale_diag, mixture_logits)
   unsigned long long* dbg;
 };
 
@@ -149,7 +158,9 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = a.H, L = a.L, K = a.K, B = a.B, D = a.D;
-  const MegaLay f = mega_lay(H, L, K, D);
+  const int model = a.model;
+  const bool gm = model == 2, gmp = model == 1;
+  const MegaLay f = mega_lay(H, L, K, D, model);
   const int KP = f.KP, K2 = f.K2, L2 = f.L2, LP = f.LP;
   float *W_y1 = sm + f.W_y1, *W_g0y = sm + f.W_g0y, *W_p = sm + f.W_p, *W_g1 = sm + f.W_g1, *W_d0 = sm + f.W_d0;
   float *b_y0 = sm + f.b_y0, *b_y1 = sm + f.b_y1, *b_g0 = sm + f.b_g0, *b_p = sm + f.b_p, *b_g1 = sm + f.b_g1, *b_d0 = sm + f.b_d0;
@@ -163,6 +174,12 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   unsigned char* xring = reinterpret_cast<unsigned char*>(sm + f.xring);
   float* A_dhg = A_cat;
   float* A_dpp = A_cat + H * kLDA;
+  // the hidden activations feeding the q head: encoder_gmm's (GMVAE) or the encoder's own first layer (VAE)
+  float* A_hq = gm ? A_hg : A_hy;
+  float* P_hq = gm ? P_hg : P_hy;
+  float *M_loc = sm + f.M_loc, *M_raw = sm + f.M_raw, *M_mix = sm + f.M_mix, *M_inv = sm + f.M_inv, *M_c = sm + f.M_c,
+        *M_w = sm + f.M_w, *P_r = sm + f.P_r;
+  const int ldM = f.ldM;
 
   const int r0 = blockIdx.x * kPanel;
   const int nrow = min(kPanel, B - r0);
@@ -171,15 +188,16 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   // ======================================================================= F: forward chain
   dma_copy_m(sm, a.img, f.img, wave, lane);
   dma_copy_m(P_eps, a.eps + (long long)r0 * L, nrow * L, wave, lane);
-  dma_copy_m(P_u, a.u + (long long)r0 * K, (nrow * K) & ~3, wave, lane);
+  if (gm) dma_copy_m(P_u, a.u + (long long)r0 * K, (nrow * K) & ~3, wave, lane);
   {
-    const int H2 = 2 * H;
+    const int H2 = gm ? 2 * H : H;
     const long long sstride = (long long)B * H2;
     const int nitem = kPanel * H2 / 4;             // <= 512 for H <= 64: one item per thread
     const int i = min(tid, nitem - 1);
     const int row = (i * 4) / H2, col = (i * 4) % H2;
     const float4 v = slab_sum4(a.s1 + (long long)min(r0 + row, B - 1) * H2 + col, sstride, a.NS);
-    for (int e = ((nrow * K) & ~3) + tid; e < nrow * K; e += kMT) P_u[e] = a.u[(long long)r0 * K + e];
+    if (gm)
+      for (int e = ((nrow * K) & ~3) + tid; e < nrow * K; e += kMT) P_u[e] = a.u[(long long)r0 * K + e];
     dma_wait();
     __syncthreads();
     if (tid < nitem) {
@@ -197,8 +215,31 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       }
     }
   }
+  if (gmp) {                      // mixture constants: 1/s, log-softmax weights, per-component constant
+    for (int i = tid; i < K * L; i += kMT) {
+      const int k = i / L, l = i - k * L;
+      M_inv[k * ldM + l] = 1.f / fsoftplus(M_raw[k * ldM + l]);
+    }
+  }
   __syncthreads();
+  if (gmp && tid < 64) {
+    float mx = -INFINITY;
+    for (int k = tid; k < K; k += 64) mx = fmaxf(mx, M_mix[k]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int k = tid; k < K; k += 64) se += fexp(M_mix[k] - mx);
+    se = wave_sum(se);
+    const float lse = mx + flog(se);
+    for (int k = tid; k < K; k += 64) {
+      float ls = 0.f;
+      for (int l = 0; l < L; ++l) ls += flog(M_inv[k * ldM + l]);          // = -sum log s
+      const float lw = M_mix[k] - lse;
+      M_w[k] = fexp(lw);
+      M_c[k] = lw + ls - 0.5f * kLog2Pi * (float)L;
+    }
+  }
   GMVAE_STAMP(1);
+  if (gm) {
   // logits
   for (int t = 0; t < KP / 16; ++t) {
     const int steps = H / 4, per = (steps + kMW - 1) / kMW;
@@ -266,8 +307,9 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   panel_gemm_s(A_y, W_p, f.ldP, 1, K2, L2 / 16, wave, lane,
                [&](int row, int col, float v) { P_pp[row * L2 + col] = v + b_p[col]; });
   __syncthreads();
+  }  // gm
   // q head
-  panel_gemm_s(A_hg, W_g1, f.ldG1, 1, H, L2 / 16, wave, lane,
+  panel_gemm_s(A_hq, W_g1, f.ldG1, 1, H, L2 / 16, wave, lane,
                [&](int row, int col, float v) { P_qp[row * L2 + col] = v + b_g1[col]; });
   __syncthreads();
   GMVAE_STAMP(3);
@@ -287,16 +329,61 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       if (ok) a.z[(long long)(r0 + row) * L + l] = zz;
       const float e = (zz - mu) / sg;
       aq += -0.5f * e * e - 0.5f * kLog2Pi - flog(sg);
-      const float sp = fmaxf(fsoftplus(P_pp[row * L2 + L + l] + a.c), a.smin);
-      const float t = (zz - P_pp[row * L2 + l]) / sp;
-      ap += -0.5f * t * t - 0.5f * kLog2Pi - flog(sp);
+      if (gm) {                                             // p(z|y): gmvae.py:258
+        const float sp = fmaxf(fsoftplus(P_pp[row * L2 + L + l] + a.c), a.smin);
+        const float t = (zz - P_pp[row * L2 + l]) / sp;
+        ap += -0.5f * t * t - 0.5f * kLog2Pi - flog(sp);
+      } else {                                              // N(0, I): vae.py:247-250 (VAE_GMP: mixture stage below)
+        ap += -0.5f * zz * zz - 0.5f * kLog2Pi;
+      }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) { aq += __shfl_xor(aq, o, 64); ap += __shfl_xor(ap, o, 64); }
     my_logq = aq; my_logp = ap;
-    if (sub == 0 && ok) { a.logq[r0 + row] = aq; a.logp[r0 + row] = ap; }
+    if (sub == 0) {
+      nllp[row] = aq;
+      if (!gmp) nllp[kPanel + row] = ap;
+      if (ok) { a.logq[r0 + row] = aq; if (!gmp) a.logp[r0 + row] = ap; }
+    }
   }
   __syncthreads();
+  if (gmp) {
+    // MixtureSameFamily.log_prob (vae.py:240-244,181): 32 lanes per row, lane = component (+32), each lane
+    // walks l over the LDS-resident (loc, 1/s) image; K-way logsumexp by wavefront shuffles; responsibilities kept.
+    const int row = tid >> 5, sub = tid & 31;
+    float comp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = sub + 32 * j;
+      comp[j] = -INFINITY;
+      if (k < K) {
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) {
+          const float t = (P_z[row * L + l] - M_loc[k * ldM + l]) * M_inv[k * ldM + l];
+          acc += t * t;
+        }
+        comp[j] = M_c[k] - 0.5f * acc;
+      }
+    }
+    float mx = fmaxf(comp[0], comp[1]);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (sub + 32 * j < K) se += fexp(comp[j] - mx);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    const float lse = mx + flog(se);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (sub + 32 * j < K) P_r[row * KP + sub + 32 * j] = fexp(comp[j] - lse);
+    if (sub == 0) {
+      nllp[kPanel + row] = lse;
+      if (row < nrow) a.logp[r0 + row] = lse;
+    }
+    __syncthreads();
+  }
   // decoder hidden
   panel_gemm_s(A_z, W_d0, f.ldD0, 1, L, H / 16, wave, lane, [&](int row, int col, float v) {
     const float h = fmaxf(v + b_d0[col], 0.f);
@@ -422,7 +509,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
 #pragma unroll
       for (int w = 0; w < kMW; ++w) s_ += nllp2[w * kPanel + row];
       a.logpx[r0 + row] = s_;
-      a.logw[r0 + row] = s_ + my_logp - my_logq - nllp[3 * kPanel + row];
+      a.logw[r0 + row] = s_ + nllp[kPanel + row] - nllp[row] - (gm ? nllp[3 * kPanel + row] : 0.f);
     }
   }
   __syncthreads();
@@ -440,33 +527,71 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
         const float spq = fsoftplus(rawq);
         const float sg = fmaxf(spq, a.smin);
         const float zz = P_z[row * L + l];
-        const float rawp = P_pp[row * L2 + L + l] + a.c;
-        const float spp = fsoftplus(rawp);
-        const float sp = fmaxf(spp, a.smin);
-        const float t = (zz - P_pp[row * L2 + l]) / sp;
-        const float pterm = t / sp;
+        float pterm;                                   // d(-log p)/dz
+        if (gm) {
+          const float rawp = P_pp[row * L2 + L + l] + a.c;
+          const float spp = fsoftplus(rawp);
+          const float sp = fmaxf(spp, a.smin);
+          const float t = (zz - P_pp[row * L2 + l]) / sp;
+          pterm = t / sp;
+          dmup = -pterm;
+          drawp = (spp > a.smin) ? (1.f - t * t) / sp * sigmoidf_(rawp) : 0.f;
+          float* dp = a.dpp + (long long)(r0 + row) * L2;
+          dp[l] = dmup; dp[L + l] = drawp;
+        } else if (gmp) {                              // sum_k r_k (z - loc_k) / s_k^2
+          pterm = 0.f;
+          for (int k = 0; k < K; ++k) {
+            const float iv = M_inv[k * ldM + l];
+            pterm += P_r[row * KP + k] * (zz - M_loc[k * ldM + l]) * iv * iv;
+          }
+        } else {
+          pterm = zz;
+        }
         dmu = P_dz[row * LP + l] + pterm;
         const float dsg = dmu * P_eps[row * L + l] - 1.f / sg;
         draw = (spq > a.smin) ? dsg * sigmoidf_(rawq) : 0.f;
-        dmup = -pterm;
-        drawp = (spp > a.smin) ? (1.f - t * t) / sp * sigmoidf_(rawp) : 0.f;
         float* dq = a.dqp + (long long)(r0 + row) * L2;
-        float* dp = a.dpp + (long long)(r0 + row) * L2;
-        dq[l] = dmu; dq[L + l] = draw; dp[l] = dmup; dp[L + l] = drawp;
+        dq[l] = dmu; dq[L + l] = draw;
       }
       A_dqp[l * kLDA + row] = dmu;
       A_dqp[(L + l) * kLDA + row] = draw;
-      A_dpp[l * kLDA + row] = dmup;
-      A_dpp[(L + l) * kLDA + row] = drawp;
+      if (gm) {
+        A_dpp[l * kLDA + row] = dmup;
+        A_dpp[(L + l) * kLDA + row] = drawp;
+      }
     }
   }
   __syncthreads();
-  // dhg1 = (dqp * Wg1^T) * [hg1 > 0]
+  // dh = (dqp * W^T) * [h > 0]: encoder_gmm's hidden layer (GMVAE) or the encoder's (VAE)
   panel_gemm_s(A_dqp, W_g1, 1, f.ldG1, L2, H / 16, wave, lane, [&](int row, int col, float v) {
-    const float d = (row < nrow && P_hg[row * H + col] > 0.f) ? v : 0.f;
+    const float d = (row < nrow && P_hq[row * H + col] > 0.f) ? v : 0.f;
     A_dhg[col * kLDA + row] = d;
     if (row < nrow) a.dhg1[(long long)(r0 + row) * H + col] = d;
   });
+  if (gmp) {
+    // gradients of the learned mixture prior over this panel's rows (A12): one partial per workgroup
+    const int KL = K * L, KLp = (KL + 3) & ~3;
+    float* out = a.gmp_part + (long long)blockIdx.x * (2 * KLp + ((K + 3) & ~3));
+    for (int i = tid; i < KL; i += kMT) {
+      const int k = i / L, l = i - k * L;
+      const float iv = M_inv[k * ldM + l], lc = M_loc[k * ldM + l];
+      float ga = 0.f, gb = 0.f;
+      for (int row = 0; row < nrow; ++row) {
+        const float wr = P_r[row * KP + k];
+        const float t = (P_z[row * L + l] - lc) * iv;
+        ga -= wr * t * iv;
+        gb += wr * (1.f - t * t) * iv;
+      }
+      out[i] = ga;
+      out[KLp + i] = gb * sigmoidf_(M_raw[k * ldM + l]);
+    }
+    for (int k = tid; k < K; k += kMT) {
+      float ga = 0.f;
+      for (int row = 0; row < nrow; ++row) ga -= P_r[row * KP + k] - M_w[k];
+      out[2 * KLp + k] = ga;
+    }
+  }
+  if (!gm) { GMVAE_STAMP(7); return; }
   __syncthreads();
   // dy = dhg1 * Wg0[D:,:]^T + dpp * Wp^T : K = H then K = 2L, split over the 4 waves
   for (int t = 0; t < KP / 16; ++t) {

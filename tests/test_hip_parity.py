@@ -117,6 +117,12 @@ STEP_CASES = [
     ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(64,)), 256),             # BASELINE config 2
     ("vae_gmp", O.Dims(D=200, L=24, K=64, hidden=(32,), S=3), 17),
     ("vae_gmp", O.Dims(D=128, L=7, K=5, hidden=(20, 20), gen_bias_init=0.2), 33),
+    # single-launch (mega) schedule of the VAE family: std-normal prior, learned mixture prior (K > 32: two
+    # components per lane), ragged last panel, sigma clamp and decoder bias offset
+    ("vae", O.Dims(D=784, L=64, K=1, hidden=(64,)), 1024),
+    ("vae", O.Dims(D=784, L=16, K=1, hidden=(32,), sigma_min=0.8, gen_bias_init=-0.3), 37),
+    ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(64,)), 1000),
+    ("vae_gmp", O.Dims(D=208, L=24, K=40, hidden=(48,)), 50),
 ]
 
 
