@@ -138,10 +138,12 @@ struct Aux {
   float* u;
   unsigned long long n_eps, n_u, seed, step;
   unsigned long long* step_dev;   // [2]: [0] = completed steps, [1] = copy that the last kernel of the step reads
+  unsigned* epoch_word;           // bumped once per step: tag of the in-launch hand-offs of mega_fwd_bwd
   ImgTask task[kMaxImgTasks];
 };
 
 __device__ __forceinline__ void aux_block(const Aux& ax, const int b) {
+  if (b == 0 && threadIdx.x == 0 && ax.epoch_word) *ax.epoch_word += 1u;
   if (b < ax.noise_blocks) {
     const unsigned long long step = ax.step_dev ? ax.step_dev[0] : ax.step;
     noise_item((uint64_t)b * kThreads + threadIdx.x, ax.eps, ax.n_eps, ax.u, ax.n_u, ax.seed, step);

@@ -27,6 +27,17 @@ constexpr int MAXH = GMVAE_MAX_HIDDEN;
 constexpr int NS_MAX = 16;
 constexpr int MAX_LEVELS = 96;
 constexpr int GMP_PARTS = 64;
+constexpr int kMegaQMax = 4;
+
+// Workgroups that share one 16-row panel of mega_fwd_bwd (they split its decoder chunks): as many as keep the
+// whole grid co-resident on the chip's 256 CUs (one 150 KB-LDS workgroup per CU).
+static int mega_q(int B) {
+  const int panels = (B + 15) / 16;
+  int q = panels * 4 <= 256 ? 4 : panels * 2 <= 256 ? 2 : 1;
+  const char* e = getenv("GMVAE_MEGA_Q");
+  if (e && atoi(e) >= 1 && atoi(e) <= kMegaQMax) q = atoi(e);
+  return q;
+}
 
 // ------------------------------------------------------------------ layout
 struct NetL {
@@ -111,6 +122,8 @@ struct WS {
   float *dbuf[3], *dz, *dqp, *dpp, *dy, *dlogits, *dqb, *slabs, *gmp_part;
   float *s1, *s4;          // split-K slabs of the fused schedule: [NSF][B][2H], [NSF][B][H]
   unsigned long long* stamps;   // diagnostic stamps of the chain kernels: [2][grid][16]
+  unsigned long long* xchg;     // mega_fwd_bwd's in-launch hand-off granules: [panels][Q-1][16*H + 16]
+  unsigned* sync;               // [0] = per-step epoch of the hand-off, [1] = hand-off timeout flag
   float *img_f, *img_b;         // per-step LDS weight images of chain_fwd / chain_bwd (prepared by aux blocks)
   float *img_m, *dimg;          // mega kernel: small-weight image (odd leading dimensions) + decoder chunk images
   int32_t* cl_pred;
@@ -225,7 +238,10 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     w.img_m = take((uint64_t)ml.img);
     w.dimg = take((uint64_t)ml.nch * ml.chunk);
     if (!w.s1) w.s1 = take((uint64_t)fwd_splits(d.D) * B * 2 * d.hidden[0]);
-    if (!w.stamps) w.stamps = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * 16 * 2));
+    w.stamps = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * kMegaQMax * 16 * 2));   // one slot per workgroup
+    w.xchg = reinterpret_cast<unsigned long long*>(
+        take(2ull * ((B + 15) / 16) * (kMegaQMax - 1) * (kPanel * d.hidden[0] + kPanel)));
+    w.sync = reinterpret_cast<unsigned*>(take(64));
   }
   w.dz = take(R * Lz);
   w.dqp = take(R * 2 * Lz);
@@ -463,6 +479,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     Aux& ax = g.L.aux;
     ax.eps = gen_eps; ax.u = gen_u; ax.n_eps = n_eps; ax.n_u = n_u; ax.seed = a.seed; ax.step = a.step;
     ax.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
+    ax.epoch_word = w.sync;
     ax.noise_blocks = (int)(((n_eps + 3) / 4 + (n_u + 3) / 4 + kThreads - 1) / kThreads);
     int nt = 0;
     auto task = [&](float* dst, int ld, const float* src, int rows, int cols, int src_ld) {
@@ -511,13 +528,14 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     c.dhd1 = w.dbuf[0]; c.dqp = w.dqp; c.dpp = w.dpp; c.dhg1 = w.dbuf[1]; c.dlogits = w.dlogits; c.dhy1 = w.dbuf[2];
     c.nent = w.nent; c.logq = w.logq; c.logp = w.logp; c.logpx = w.logpx; c.logw = w.logw;
     c.gmp_part = w.gmp_part;
+    c.Q = mega_q(B); c.xchg = w.xchg; c.epoch_word = w.sync; c.err_word = w.sync + 1;
     c.dbg = getenv("GMVAE_STAMPS") ? w.stamps : nullptr;
     static bool mattr = false;
     if (!mattr) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(mega_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       mattr = true;
     }
-    hipLaunchKernelGGL(mega_fwd_bwd, dim3((B + kPanel - 1) / kPanel), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
+    hipLaunchKernelGGL(mega_fwd_bwd, dim3((B + kPanel - 1) / kPanel * c.Q), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
     cx.check();
     // algorithmic MFMA FLOPs of the launch: forward chain + decoder layer (lambda and its data gradient) + backward chain
     double macs = (double)H * 2 * Lz + (double)Lz * H + 2.0 * H * D + (double)H * Lz + 2.0 * Lz * H;

@@ -151,6 +151,13 @@ struct MegaArgs {
   float *dhd1, *dqp, *dpp, *dhg1, *dlogits, *dhy1;              // pre-activation gradients
   float *nent, *logq, *logp, *logpx, *logw;                     // per-row loss terms
   float* gmp_part;            // VAE_GMP: per-workgroup partial gradients of (loc, raw_scale_diag, mixture_logits)
+  // Decoder chunks of one panel are spread over Q workgroups (all run the cheap forward chain); quarters
+  // 1..Q-1 hand their partial dhd1 tile and Bernoulli row sums to quarter 0 through 8-byte {epoch, value}
+  // granules (cdna_hip_programming.md G16 recipe R2: the data is its own flag, no fences).
+  int Q;
+  unsigned long long* xchg;   // [panels][Q-1][16*H + 16] granules
+  const unsigned* epoch_word; // tag of this step (bumped by the first launch of the step)
+  unsigned* err_word;         // set to 1 if a bounded spin gives up (results are then invalid)
   unsigned long long* dbg;
 };
 
@@ -181,7 +188,13 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
         *M_w = sm + f.M_w, *P_r = sm + f.P_r;
   const int ldM = f.ldM;
 
-  const int r0 = blockIdx.x * kPanel;
+  // producers (quarters 1..Q-1) take the LOWER block ids: a consumer can then never keep its producers off the chip
+  const int nP = (B + kPanel - 1) / kPanel, Q = a.Q;
+  const int bid = blockIdx.x;
+  const int q = bid < nP * (Q - 1) ? 1 + bid / nP : 0;
+  const int pnl = bid < nP * (Q - 1) ? bid % nP : bid - nP * (Q - 1);
+  const bool lead = q == 0;                    // quarter 0 owns the panel: saves activations, runs phase B
+  const int r0 = pnl * kPanel;
   const int nrow = min(kPanel, B - r0);
   const int ln = lane & 15, lk = lane >> 4;
   GMVAE_STAMP(0);
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
           A_hy[(col + j) * kLDA + row] = vv[j];
         }
         *reinterpret_cast<float4*>(P_hy + row * H + col) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        if (row < nrow) *reinterpret_cast<float4*>(a.hy1 + (long long)(r0 + row) * H + col) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (lead && row < nrow) *reinterpret_cast<float4*>(a.hy1 + (long long)(r0 + row) * H + col) = make_float4(vv[0], vv[1], vv[2], vv[3]);
       } else {
         *reinterpret_cast<float4*>(P_gx + row * H + (col - H)) = v;
       }
@@ -286,14 +299,14 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
           const float lp = lgv[j] - l2;
           ne += fexp(lp) * lp;
           P_y[row * K + k] = yv;
-          if (ok) a.y[(long long)(r0 + row) * K + k] = yv;
+          if (ok && lead) a.y[(long long)(r0 + row) * K + k] = yv;
         }
         A_y[k * kLDA + row] = yv;
       }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) ne += __shfl_xor(ne, o, 64);
-    if (sub == 0) { nllp[3 * kPanel + row] = ne; if (ok) a.nent[r0 + row] = ne; }     // nllp[48..63]: nent per row
+    if (sub == 0) { nllp[3 * kPanel + row] = ne; if (ok && lead) a.nent[r0 + row] = ne; }     // nllp[48..63]: nent per row
   }
   __syncthreads();
   GMVAE_STAMP(2);
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     const float h = fmaxf(v + P_gx[row * H + col] + b_g0[col], 0.f);
     A_hg[col * kLDA + row] = h;
     P_hg[row * H + col] = h;
-    if (row < nrow) a.hg1[(long long)(r0 + row) * H + col] = h;
+    if (lead && row < nrow) a.hg1[(long long)(r0 + row) * H + col] = h;
   });
   panel_gemm_s(A_y, W_p, f.ldP, 1, K2, L2 / 16, wave, lane,
                [&](int row, int col, float v) { P_pp[row * L2 + col] = v + b_p[col]; });
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       const float zz = mu + sg * ee;
       A_z[l * kLDA + row] = zz;
       P_z[row * L + l] = zz;
-      if (ok) a.z[(long long)(r0 + row) * L + l] = zz;
+      if (ok && lead) a.z[(long long)(r0 + row) * L + l] = zz;
       const float e = (zz - mu) / sg;
       aq += -0.5f * e * e - 0.5f * kLog2Pi - flog(sg);
       if (gm) {                                             // p(z|y): gmvae.py:258
@@ -343,7 +356,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     if (sub == 0) {
       nllp[row] = aq;
       if (!gmp) nllp[kPanel + row] = ap;
-      if (ok) { a.logq[r0 + row] = aq; if (!gmp) a.logp[r0 + row] = ap; }
+      if (ok && lead) { a.logq[r0 + row] = aq; if (!gmp) a.logp[r0 + row] = ap; }
     }
   }
   __syncthreads();
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       if (sub + 32 * j < K) P_r[row * KP + sub + 32 * j] = fexp(comp[j] - lse);
     if (sub == 0) {
       nllp[kPanel + row] = lse;
-      if (row < nrow) a.logp[r0 + row] = lse;
+      if (lead && row < nrow) a.logp[r0 + row] = lse;
     }
     __syncthreads();
   }
@@ -389,39 +402,42 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     const float h = fmaxf(v + b_d0[col], 0.f);
     A_hd[col * kLDA + row] = h;
     P_hd[row * H + col] = h;
-    if (row < nrow) a.hd1[(long long)(r0 + row) * H + col] = h;
+    if (lead && row < nrow) a.hd1[(long long)(r0 + row) * H + col] = h;
   });
   __syncthreads();                 // the small-weight image is dead from here until phase B
   GMVAE_STAMP(4);
 
   // ======================================================================= D: decoder output, streamed
   const int nch = f.nch, ldc = f.ldc;
-  auto issue_chunk = [&](int c) {
-    dma_copy_m(sm + f.ring + (c & 1) * f.chunk, a.dimg + (long long)c * f.chunk, f.chunk, wave, lane);
+  auto issue_chunk = [&](int i) {             // i = local index; chunk c = q + i * Q
+    const int c = q + i * Q;
+    dma_copy_m(sm + f.ring + (i & 1) * f.chunk, a.dimg + (long long)c * f.chunk, f.chunk, wave, lane);
     // x chunk: [16 rows][128 bytes]; lane -> (row, 16-byte piece); columns beyond D are masked off
     if (tid < kPanel * (kCW / 16)) {
       const int row = tid >> 3, piece = tid & 7;
       const int col = c * kCW + piece * 16;
       if (col < D && row < nrow)
         __builtin_amdgcn_global_load_lds(a.x + (long long)(r0 + row) * D + col,
-                                         reinterpret_cast<float*>(xring + (c & 1) * kPanel * kCW + (tid >> 6) * 1024), 16, 0, 0);
+                                         reinterpret_cast<float*>(xring + (i & 1) * kPanel * kCW + (tid >> 6) * 1024), 16, 0, 0);
     }
   };
   f32x4 dacc = {0.f, 0.f, 0.f, 0.f};           // partial 16x16 tile of dhd1: tile = wave & 3, column half = wave >> 2
   const int dtile = wave & 3, dhalf = wave >> 2;
   float rs[4] = {0.f, 0.f, 0.f, 0.f};          // Bernoulli terms of rows lk*4 + r, this lane's columns
-  issue_chunk(0);
+  // this workgroup's chunks: q, q + Q, q + 2Q, ...  (ring buffer parity follows the LOCAL index)
+  const int nloc = (nch - q + Q - 1) / Q;
+  if (nloc > 0) issue_chunk(0);
   unsigned long long tseg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = a.dbg ? __builtin_amdgcn_s_memtime() : 0;   // diagnostic only
 #define GMVAE_SEG(i) if (a.dbg) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tseg[i] += tn_ - tprev; tprev = tn_; }
-  for (int c = 0; c < nch; ++c) {
+  for (int i = 0; i < nloc; ++i) {
     dma_wait();
-    __syncthreads();                            // chunk c landed; A_g and buffer (c+1)&1 are free
+    __syncthreads();                            // chunk i landed; A_g and buffer (i+1)&1 are free
     GMVAE_SEG(0);
-    if (c + 1 < nch) issue_chunk(c + 1);
+    if (i + 1 < nloc) issue_chunk(i + 1);
     GMVAE_SEG(4);
-    const float* Wc = sm + f.ring + (c & 1) * f.chunk;
-    const unsigned char* xc = xring + (c & 1) * kPanel * kCW;
-    const int c0 = c * kCW;
+    const float* Wc = sm + f.ring + (i & 1) * f.chunk;
+    const unsigned char* xc = xring + (i & 1) * kPanel * kCW;
+    const int c0 = (q + i * Q) * kCW;
     // lambda tiles (2 per wave) + Bernoulli epilogue.  One wave per SIMD: nothing hides latency, so the
     // operand-independent LDS reads (bias, x bytes) are issued before the MFMA chain, the element math is
     // branch-free with ONE exp, ONE rcp and ONE log per element, and g leaves through the A_g image as
@@ -478,6 +494,41 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     for (int o = 8; o > 0; o >>= 1) rs[r] += __shfl_xor(rs[r], o, 64);
   }
   __syncthreads();                               // every wave is done with the ring and A_g
+  const unsigned epoch = Q > 1 ? *a.epoch_word : 0u;
+  const int ngr = kPanel * H + kPanel;           // granules one producer publishes: dhd1 tile partials + row sums
+  if (!lead) {
+    // ------------------------------------------------------------- producer: publish the partials and leave
+    if (ln == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nllp2[wave * kPanel + lk * 4 + r] = rs[r];
+    }
+    if (dhalf == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[dtile * 256 + (lk * 4 + r) * 16 + ln] = dacc[r];
+    }
+    __syncthreads();
+    unsigned long long* xo = a.xchg + ((long long)pnl * (Q - 1) + (q - 1)) * ngr;
+    if (dhalf == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = lk * 4 + r, col = dtile * 16 + ln;
+        if (col < H) {
+          const float dv = dacc[r] + red[dtile * 256 + (lk * 4 + r) * 16 + ln];
+          __hip_atomic_store(xo + row * H + col, ((unsigned long long)epoch << 32) | __float_as_uint(dv), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (tid >= 256 && tid < 256 + kPanel) {
+      const int row = tid - 256;
+      float s_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < kMW; ++w) s_ += nllp2[w * kPanel + row];
+      __hip_atomic_store(xo + kPanel * H + row, ((unsigned long long)epoch << 32) | __float_as_uint(s_), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   // ======================================================================= B: backward chain
   dma_copy_m(sm, a.img, f.img, wave, lane);      // the ring overwrote the small-weight image
   if (ln == 0) {
@@ -488,6 +539,42 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[dtile * 256 + (lk * 4 + r) * 16 + ln] = dacc[r];
   }
+  // the other quarters' partials: sweep the granules until every tag carries this step's epoch (bounded)
+  float xd[4] = {0.f, 0.f, 0.f, 0.f}, xn = 0.f;
+  if (Q > 1) {
+    const unsigned long long* xi = a.xchg + (long long)pnl * (Q - 1) * ngr;
+    const bool wd = dhalf == 0 && dtile * 16 + ln < H;      // this lane waits for dhd1 granules
+    const bool wn = tid >= 256 && tid < 256 + kPanel;       // ... for a row-sum granule
+    for (int pq = 0; pq < Q - 1; ++pq) {
+      const unsigned long long* xp = xi + (long long)pq * ngr;
+      unsigned long long v[5] = {0, 0, 0, 0, 0};
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+        if (wd) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = __hip_atomic_load(xp + (lk * 4 + r) * H + dtile * 16 + ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (unsigned)(v[r] >> 32) == epoch;
+          }
+        }
+        if (wn) {
+          v[4] = __hip_atomic_load(xp + kPanel * H + (tid - 256), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (unsigned)(v[4] >> 32) == epoch;
+        }
+        if (__all(ok)) break;
+        if (++spins > (1u << 22)) {                          // ~seconds: the producer never ran; flag and go on
+          if (lane == 0) atomicExch(a.err_word, 1u);
+          v[0] = v[1] = v[2] = v[3] = v[4] = 0x7fc00000ull;  // NaN: the step's loss and gradients say so loudly
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xd[r] += __uint_as_float((unsigned)v[r]);
+      xn += __uint_as_float((unsigned)v[4]);
+    }
+  }
   dma_wait();
   __syncthreads();
   if (dhalf == 0) {                              // masked top gradient -> A_dhd (+ saved for dWd0)
@@ -495,17 +582,17 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     for (int r = 0; r < 4; ++r) {
       const int row = lk * 4 + r, col = dtile * 16 + ln;
       if (col < H) {
-        const float dv = dacc[r] + red[dtile * 256 + (lk * 4 + r) * 16 + ln];
+        const float dv = dacc[r] + red[dtile * 256 + (lk * 4 + r) * 16 + ln] + xd[r];
         const float d = (row < nrow && P_hd[row * H + col] > 0.f) ? dv : 0.f;
         A_dhd[col * kLDA + row] = d;              // overlays A_hy.. (dead)
         if (row < nrow) a.dhd1[(long long)(r0 + row) * H + col] = d;
       }
     }
   }
-  if (tid < 256) {
-    const int row = tid >> 4, sub = tid & 15;
-    if (sub == 0 && row < nrow) {
-      float s_ = 0.f;
+  if (tid >= 256 && tid < 256 + kPanel) {
+    const int row = tid - 256;
+    if (row < nrow) {
+      float s_ = xn;
 #pragma unroll
       for (int w = 0; w < kMW; ++w) s_ += nllp2[w * kPanel + row];
       a.logpx[r0 + row] = s_;
@@ -571,7 +658,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   if (gmp) {
     // gradients of the learned mixture prior over this panel's rows (A12): one partial per workgroup
     const int KL = K * L, KLp = (KL + 3) & ~3;
-    float* out = a.gmp_part + (long long)blockIdx.x * (2 * KLp + ((K + 3) & ~3));
+    float* out = a.gmp_part + (long long)pnl * (2 * KLp + ((K + 3) & ~3));
     for (int i = tid; i < KL; i += kMT) {
       const int k = i / L, l = i - k * L;
       const float iv = M_inv[k * ldM + l], lc = M_loc[k * ldM + l];
