@@ -14,7 +14,7 @@
 // 6 G5): every register array is indexed by compile-time constants only, no
 // out-of-line calls, kernel-argument structs never escape by reference, and
 // the staging loads are BRANCH-FREE: out-of-range coordinates are clamped to a
-// valid address and the value is replaced by 0 (or 1 for the bias "ones row")
+// valid address and the value is replaced by 0
 // with a select, so edge tiles and K tails run the same code as interior ones.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -33,7 +33,6 @@ enum { EPI_STORE = 0, EPI_BERNOULLI = 1 };
 // One GEMM operand as seen by the kernel: a logical [mn][k] matrix.
 //   k_contig: element(mn,k) = ptr[(mn/row_div)*ld + k]      (row-major [mn][k])
 //   else    : element(mn,k) = ptr[(k /row_div)*ld + mn]     (row-major [k][mn])
-// ones_row: logical row mn == n_mn reads 1.0 (folds the bias gradient into dW).
 // vec_ok : 16-byte (fp32) / 4-byte (uint8) loads of 4 consecutive elements are
 //          legal: ld % 4 == 0 and the base is aligned (then every source row
 //          holds pad4(extent) elements along the contiguous dimension).
@@ -42,7 +41,7 @@ struct Operand {
   int ld;
   int n_mn;
   int row_div;
-  unsigned char is_u8, k_contig, ones_row, vec_ok;
+  unsigned char is_u8, k_contig, pad_, vec_ok;
 };
 
 struct Segment {
@@ -52,7 +51,7 @@ struct Segment {
 };
 
 struct Problem {
-  int M, N;                // output extents (M counts the ones row)
+  int M, N;                // output extents
   int nseg;
   int tiles_m, tiles_n, splits, tile_begin;
   int epi;
@@ -64,7 +63,8 @@ struct Problem {
   float addconst;
   long long split_stride;  // floats between split-K slabs
   float* C;
-  float* bias_row_out;     // destination of row M-1 when a.ones_row
+  float* colsum_out;       // bias gradient riding on a dW problem: column sums of operand b over the tile's k
+                           // range, written by the tiles of the first tile row to colsum_out[split][n]
   const float* bias;
   const float* addsrc;
   const float* mask;       // keep where mask > 0
@@ -75,8 +75,14 @@ struct Problem {
 };
 
 struct Launch {
+  // header: all a workgroup needs before it knows its problem, adjacent so that ONE scalar load fetches it (every
+  // dependent round of kernel-argument loads costs ~0.3 us at a launch's cold start)
   int nprob;
-  int total_tiles;         // the FIRST aux.nblocks workgroups run aux_block() (they start at once), the GEMM tiles follow
+  int total_tiles;         // the FIRST aux_nblocks workgroups run aux_block() (they start at once), the GEMM tiles follow
+  int aux_nblocks;         // copy of aux.nblocks
+  int pad_;
+  unsigned long long* dbg; // diagnostic: [block][8] wall-clock stamps (100 MHz) or nullptr
+  int tile_begin[MAXP];    // copy of p[i].tile_begin
   Problem p[MAXP];
   Aux aux;
 };
@@ -94,7 +100,10 @@ struct Cfg {
   static constexpr int NSA = BM * BK / 4 / kThreads, NSB = BN * BK / 4 / kThreads;
   static constexpr int OPS = NBUF * (LDA + LDB) * BK;               // floats, NBUF staging buffers
   static constexpr int CST = WK * BM * LDC;                          // floats, C staging
-  static constexpr int LDS_FLOATS = OPS > CST ? OPS : CST;
+  static constexpr int LDS_FLOATS = OPS > CST + kThreads ? OPS : CST + kThreads;   // + column-sum partials
+  // waves per SIMD the register allocator must leave room for: the small configuration's launches carry more
+  // workgroups than 2 per CU (tiles + auxiliary blocks), and a workgroup that starts late ends the launch late
+  static constexpr int WAVES_EU = (BM * BN <= 32 * 32) ? 3 : 1;
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
   static_assert(NSA >= 1 && NSB >= 1, "tile too small for 256 threads");
   static_assert((BK / WK) % 2 == 0, "k slice per wave must be even");
@@ -102,6 +111,8 @@ struct Cfg {
 typedef Cfg<32, 32, 128, 1, 1, 4, 1> CfgS;  // latency-bound: 4 waves split K inside the tile, single buffer
 typedef Cfg<64, 64, 64, 2, 2, 1> CfgM;
 typedef Cfg<128, 128, 32, 2, 2, 1> CfgL;    // MFMA-bound: 64x64 per wave
+// (Single-round variants -- BK = the whole k range of a split, one batch of loads -- were measured and dropped:
+// the staging phase of these launches scales with the bytes requested, not with the number of round trips.)
 
 __device__ __forceinline__ float sigmoidf_(float v) {
   float e = __expf(-fabsf(v));
@@ -120,7 +131,7 @@ __device__ __forceinline__ float softplusf_(float v) { return fmaxf(v, 0.f) + lo
 // KIND bits: 1 = uint8 elements, 2 = mn-contiguous (else k-contiguous),
 //            4 = element-wise loads (source not 16-byte vectorisable).
 template <int KIND, int BMN, int BK, int NS>
-__device__ __forceinline__ void op_load(const void* __restrict__ base, const int ld, const int n_mn, const int ones,
+__device__ __forceinline__ void op_load(const void* __restrict__ base, const int ld, const int n_mn,
                                         const int row_div, const float* __restrict__ kscale, const int K,
                                         const int mn0, const int k0, const int kend, const int tid, float4 (&r)[NS]) {
   constexpr bool U8 = (KIND & 1) != 0, MC = (KIND & 2) != 0, SC = (KIND & 4) != 0;
@@ -186,11 +197,8 @@ __device__ __forceinline__ void op_load(const void* __restrict__ base, const int
       const float sc = kscale ? kscale[kc] : 1.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        // rows mn > n_mn of a ones-row operand feed C rows that are never stored; for plain operands
-        // columns/rows beyond the extent likewise only reach unstored outputs -- but they must not be
-        // NaN-producing garbage for the Bernoulli row sums, which mask by column explicitly.
-        float x = (ones && mn + j == n_mn) ? 1.f : v[j];
-        v[j] = kin ? x * sc : 0.f;
+        // columns/rows beyond the extent only reach unstored outputs (clamped loads: finite values)
+        v[j] = kin ? v[j] * sc : 0.f;
       }
     }
     r[i] = make_float4(v[0], v[1], v[2], v[3]);
@@ -198,7 +206,7 @@ __device__ __forceinline__ void op_load(const void* __restrict__ base, const int
 }
 
 // Lean variant for the common case -- tile completely inside the operand, chunk completely inside
-// [kb, ke), 16-byte loads legal, no row broadcast / ones row / k scale: no clamps, no selects, shift-only
+// [kb, ke), 16-byte loads legal, no row broadcast / k scale: no clamps, no selects, shift-only
 // slot arithmetic.  (SQ counters showed the grouped launches VALU-issue-bound on the predicated loader:
 // ~580 VALU instructions per wave around 16 MFMAs, profiles/round1_pmc_sq_per_kernel.txt.)
 template <int KIND, int BMN, int BK, int NS>
@@ -253,28 +261,59 @@ __device__ __forceinline__ int op_kind(const unsigned char is_u8, const unsigned
 }
 
 template <class C>
-__global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
+__global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Launch L) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   constexpr int kBK = C::BK;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if ((int)blockIdx.x < L.aux.nblocks) {       // auxiliary work riding on this launch (aux.hpp)
+  // Round 1 of kernel-argument loads: the whole header, before the first branch.
+  const unsigned long long t_in = wall_clock64();
+  unsigned long long* const dbg = L.dbg;
+  const int auxn = L.aux_nblocks, nprob = L.nprob;
+  const int bid = (int)blockIdx.x - auxn;
+  int pi = 0, tb = 0;
+#pragma unroll
+  for (int i = 1; i < MAXP; ++i) {
+    const int tbi = L.tile_begin[i];
+    if (i < nprob && bid >= tbi) { pi = i; tb = tbi; }
+  }
+  // pin the header's consumers here: the compiler otherwise sinks these loads below the branches that follow
+  // and every one of them becomes its own serialised round trip
+  asm volatile("" ::"s"(pi), "s"(tb), "s"(dbg), "s"(auxn));
+#define GMVAE_GSTAMP(i) if (dbg && tid == 0) dbg[(size_t)blockIdx.x * 8 + (i)] = wall_clock64()
+  if (dbg && tid == 0) dbg[(size_t)blockIdx.x * 8] = t_in;
+  if (bid < 0) {                                // auxiliary work riding on this launch (aux.hpp)
     aux_block(L.aux, (int)blockIdx.x);
+    GMVAE_GSTAMP(4);
+    if (dbg && tid == 0) dbg[(size_t)blockIdx.x * 8 + 5] = 100;
     return;
   }
-  const int bid = (int)blockIdx.x - L.aux.nblocks;
 
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < MAXP; ++i)
-    if (i < L.nprob && bid >= L.p[i].tile_begin) pi = i;
+  // Round 2: every scalar of this tile's problem and of its first segment, requested back to back.
+  const int splits = L.p[pi].splits, tiles_n = L.p[pi].tiles_n, nseg = L.p[pi].nseg;
+  // segment descriptor -> scalars (nothing below takes a reference into the kernel arguments); the next
+  // segment's are fetched at the top of its iteration
+#define GMVAE_SEG_FIELDS(sg_)                                                                              \
+  a_ptr = L.p[pi].seg[sg_].a.ptr; a_ld = L.p[pi].seg[sg_].a.ld; a_n = L.p[pi].seg[sg_].a.n_mn;             \
+  a_div = L.p[pi].seg[sg_].a.row_div;                                                                      \
+  a_mc = !L.p[pi].seg[sg_].a.k_contig;                                                                     \
+  akind = op_kind(L.p[pi].seg[sg_].a.is_u8, L.p[pi].seg[sg_].a.k_contig, L.p[pi].seg[sg_].a.vec_ok);       \
+  b_ptr = L.p[pi].seg[sg_].b.ptr; b_ld = L.p[pi].seg[sg_].b.ld; b_n = L.p[pi].seg[sg_].b.n_mn;             \
+  b_div = L.p[pi].seg[sg_].b.row_div; b_mc = !L.p[pi].seg[sg_].b.k_contig;                                 \
+  bkind = op_kind(0, L.p[pi].seg[sg_].b.k_contig, L.p[pi].seg[sg_].b.vec_ok);                              \
+  kscale = L.p[pi].seg[sg_].kscale; K = L.p[pi].seg[sg_].K
+  const void *a_ptr, *b_ptr;
+  const float* kscale;
+  int a_ld, a_n, a_div, akind, b_ld, b_n, b_div, bkind, K;
+  bool a_mc, b_mc;
+  GMVAE_SEG_FIELDS(0);
+  asm volatile("" ::"s"(splits), "s"(tiles_n), "s"(nseg), "s"(a_ptr), "s"(a_ld), "s"(a_n), "s"(a_div),
+               "s"(akind), "s"(b_ptr), "s"(b_ld), "s"(b_n), "s"(b_div), "s"(bkind), "s"(kscale), "s"(K));
 
-  int t = bid - L.p[pi].tile_begin;
-  const int splits = L.p[pi].splits;
+  int t = bid - tb;
   const int split = t % splits;
   t /= splits;
-  const int tiles_n = L.p[pi].tiles_n;
   const int tn = t % tiles_n;
   const int tm = t / tiles_n;
   const int m0 = tm * C::BM, n0 = tn * C::BN;
@@ -293,21 +332,15 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nseg = L.p[pi].nseg;
+  // bias gradient of a dW problem: column sums of b over this tile's k range (first tile row only)
+  float* const colsum_out = L.p[pi].colsum_out;
+  const bool do_colsum = colsum_out != nullptr && tm == 0;
+  float csum = 0.f;
+  constexpr int CSG = kThreads / C::BN;          // k groups of the column-sum threads
+  const int cs_n = tid % C::BN, cs_k = tid / C::BN;
 #pragma unroll 1
   for (int sgi = 0; sgi < nseg; ++sgi) {
-    // segment descriptor -> scalars (nothing below takes a reference into the kernel arguments)
-    const void* a_ptr = L.p[pi].seg[sgi].a.ptr;
-    const int a_ld = L.p[pi].seg[sgi].a.ld, a_n = L.p[pi].seg[sgi].a.n_mn, a_div = L.p[pi].seg[sgi].a.row_div;
-    const int a_ones = L.p[pi].seg[sgi].a.ones_row;
-    const bool a_mc = !L.p[pi].seg[sgi].a.k_contig;
-    const int akind = op_kind(L.p[pi].seg[sgi].a.is_u8, L.p[pi].seg[sgi].a.k_contig, L.p[pi].seg[sgi].a.vec_ok);
-    const void* b_ptr = L.p[pi].seg[sgi].b.ptr;
-    const int b_ld = L.p[pi].seg[sgi].b.ld, b_n = L.p[pi].seg[sgi].b.n_mn, b_div = L.p[pi].seg[sgi].b.row_div;
-    const bool b_mc = !L.p[pi].seg[sgi].b.k_contig;
-    const int bkind = op_kind(0, L.p[pi].seg[sgi].b.k_contig, L.p[pi].seg[sgi].b.vec_ok);
-    const float* kscale = L.p[pi].seg[sgi].kscale;
-    const int K = L.p[pi].seg[sgi].K;
+    if (sgi > 0) { GMVAE_SEG_FIELDS(sgi); }
 
     int kper = (K + splits - 1) / splits;
     kper = (kper + kBK - 1) / kBK * kBK;
@@ -317,16 +350,16 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
     if (NC == 0) continue;
 
     // wave-uniform eligibility of the lean loader for this tile
-    const bool a_fast = akind < 4 && a_div == 1 && !a_ones && m0 + C::BM <= a_n;
+    const bool a_fast = akind < 4 && a_div == 1 && m0 + C::BM <= a_n;
     const bool b_fast = bkind < 4 && b_div == 1 && kscale == nullptr && n0 + C::BN <= b_n;
 
     float4 ra[C::NSA], rb[C::NSB];
 #define GMVAE_FAST_A(KIND) op_load_fast<KIND, C::BM, kBK, C::NSA>(a_ptr, a_ld, m0, k0_, tid, ra)
 #define GMVAE_FAST_B(KIND) op_load_fast<KIND, C::BN, kBK, C::NSB>(b_ptr, b_ld, n0, k0_, tid, rb)
 #define GMVAE_LOAD_A(KIND) \
-  op_load<KIND, C::BM, kBK, C::NSA>(a_ptr, a_ld, a_n, a_ones, a_div, nullptr, K, m0, k0_, ke, tid, ra)
+  op_load<KIND, C::BM, kBK, C::NSA>(a_ptr, a_ld, a_n, a_div, nullptr, K, m0, k0_, ke, tid, ra)
 #define GMVAE_LOAD_B(KIND) \
-  op_load<KIND, C::BN, kBK, C::NSB>(b_ptr, b_ld, b_n, 0, b_div, kscale, K, n0, k0_, ke, tid, rb)
+  op_load<KIND, C::BN, kBK, C::NSB>(b_ptr, b_ld, b_n, b_div, kscale, K, n0, k0_, ke, tid, rb)
 #define GMVAE_GLOAD(c_)                                                     \
   {                                                                         \
     const int k0_ = kb + (c_) * kBK;                                        \
@@ -368,15 +401,22 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
   }
 
     __syncthreads();          // LDS is free (first segment: trivially; second: previous loop finished)
+    if (sgi == 0) GMVAE_GSTAMP(6);
     GMVAE_GLOAD(0);
+    if (L.dbg && sgi == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GMVAE_GSTAMP(7); }
     GMVAE_LSTORE(0);
     __syncthreads();
+    if (sgi == 0) GMVAE_GSTAMP(1);
 #pragma unroll 1
     for (int c = 0; c < NC; ++c) {
       if (c + 1 < NC) GMVAE_GLOAD(c + 1);
       const float* As = lds + (C::NBUF == 2 ? (c & 1) : 0) * (C::LDA + C::LDB) * kBK;
       const float* Bs = As + C::LDA * kBK;
       constexpr int KW = kBK / C::WK;
+      if (do_colsum) {
+#pragma unroll
+        for (int i = 0; i < kBK / CSG; ++i) csum += Bs[(cs_k + i * CSG) * C::LDB + cs_n];
+      }
 #pragma unroll
       for (int kk = 0; kk < KW; kk += 2) {
         const int krow = wk * KW + kk + khalf;
@@ -405,6 +445,7 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
 
   // ---- stage the accumulators to LDS in row-major [BM][LDC] (one image per k-wave)
   __syncthreads();
+  GMVAE_GSTAMP(2);
   {
     float* Cs = lds + wk * C::BM * C::LDC;
 #pragma unroll
@@ -416,9 +457,17 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
           const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
           Cs[row * C::LDC + wn0 + j * 32 + l31] = acc[i][j][r];
         }
+    if (do_colsum) lds[C::CST + tid] = csum;
   }
   __syncthreads();
+  if (do_colsum && tid < C::BN && n0 + tid < L.p[pi].N) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < CSG; ++g) v += lds[C::CST + g * C::BN + tid];
+    colsum_out[(long long)split * L.p[pi].split_stride + n0 + tid] = v;
+  }
 
+  GMVAE_GSTAMP(3);
   // ---- epilogue: each thread owns float4 groups of a row
   const int M = L.p[pi].M, N = L.p[pi].N, ldc = L.p[pi].ldc, epi = L.p[pi].epi;
   float* Cout = L.p[pi].C;
@@ -427,7 +476,6 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
   constexpr int GPR = C::BN / 4;                 // groups per row (8, 16 or 32 consecutive lanes)
   constexpr int PASSES = C::BM * GPR / kThreads;
   if (epi == EPI_STORE) {
-    float* bias_row_out = L.p[pi].bias_row_out;
     const float* addsrc = L.p[pi].addsrc;
     const float* mask = L.p[pi].mask;
     const float* rowscale = L.p[pi].rowscale;
@@ -446,7 +494,7 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
       const int m = m0 + row, nb = n0 + 4 * c4;
       if (m < M && nb < N) {
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        float* dst = (bias_row_out && m == M - 1) ? bias_row_out + soff + nb : Cout + soff + (long long)m * ldc + nb;
+        float* dst = Cout + soff + (long long)m * ldc + nb;
         const float rs = rowscale ? rowscale[m] : 1.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -513,6 +561,9 @@ __global__ __launch_bounds__(kThreads) void gemm_grouped(const Launch L) {
       if (m < M && c4 == 0) part[(long long)m * nparts + tn] = rsum;
     }
   }
+  GMVAE_GSTAMP(4);
+  if (L.dbg && tid == 0) L.dbg[(size_t)blockIdx.x * 8 + 5] = pi;
+#undef GMVAE_GSTAMP
 }
 
 }  // namespace gmvae

@@ -123,6 +123,7 @@ struct WS {
   float *s1, *s4;          // split-K slabs of the fused schedule: [NSF][B][2H], [NSF][B][H]
   unsigned long long* stamps;   // diagnostic stamps of the chain kernels: [2][grid][16]
   unsigned long long* xchg;     // mega_fwd_bwd's in-launch hand-off granules: [panels][Q-1][16*H + 16]
+  unsigned long long* gstamps;  // diagnostic stamps of the grouped-GEMM launches: [4 launches][2048 blocks][8]
   unsigned* sync;               // [0] = per-step epoch of the hand-off, [1] = hand-off timeout flag
   float *img_f, *img_b;         // per-step LDS weight images of chain_fwd / chain_bwd (prepared by aux blocks)
   float *img_m, *dimg;          // mega kernel: small-weight image (odd leading dimensions) + decoder chunk images
@@ -242,6 +243,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     w.xchg = reinterpret_cast<unsigned long long*>(
         take(2ull * ((B + 15) / 16) * (kMegaQMax - 1) * (kPanel * d.hidden[0] + kPanel)));
     w.sync = reinterpret_cast<unsigned*>(take(64));
+    w.gstamps = reinterpret_cast<unsigned long long*>(take(2ull * 4 * 2048 * 8));
   }
   w.dz = take(R * Lz);
   w.dqp = take(R * 2 * Lz);
@@ -255,10 +257,10 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
 }
 
 // ----------------------------------------------------------- GEMM building
-static Operand opnd(const void* p, int ld, int n_mn, bool u8, bool kc, int div = 1, bool ones = false) {
+static Operand opnd(const void* p, int ld, int n_mn, bool u8, bool kc, int div = 1) {
   Operand o;
   o.ptr = p; o.ld = ld; o.n_mn = n_mn; o.row_div = div;
-  o.is_u8 = u8; o.k_contig = kc; o.ones_row = ones;
+  o.is_u8 = u8; o.k_contig = kc; o.pad_ = 0;
   const uintptr_t a = reinterpret_cast<uintptr_t>(p);
   o.vec_ok = (ld % 4 == 0) && (a % (u8 ? 4 : 16) == 0);
   return o;
@@ -292,16 +294,16 @@ static Problem p_nt(const float* dY, int ldy, const float* W, int ldw, int M, in
   p.C = C; p.ldc = ldc; p.mask = mask; p.ld_mask = ld_mask;
   return p;
 }
-// dW[in,out] (+ db as an extra ones row) = Act[rows,in]^T dY[rows,out], split-K over rows into slabs
+// dW[in,out] = Act[rows,in]^T dY[rows,out] (+ db = column sums of dY), split-K over rows into slabs
 static Problem p_tn(const void* Act, bool u8, int lda, int a_div, const float* dY, int ldy, int n_in, int n_out,
                     int rows, float* dW, float* db, int ns, long long slab_stride, const float* kscale) {
   Problem p = blank();
-  p.M = n_in + (db ? 1 : 0); p.N = n_out;
-  p.seg[0].a = opnd(Act, lda, n_in, u8, false, a_div, db != nullptr);
+  p.M = n_in; p.N = n_out;
+  p.seg[0].a = opnd(Act, lda, n_in, u8, false, a_div);
   p.seg[0].b = opnd(dY, ldy, n_out, false, false);
   p.seg[0].K = rows;
   p.seg[0].kscale = kscale;
-  p.C = dW; p.ldc = n_out; p.bias_row_out = db;
+  p.C = dW; p.ldc = n_out; p.colsum_out = db;
   p.splits = ns; p.split_stride = slab_stride;
   return p;
 }
@@ -349,6 +351,7 @@ static int tile_up(Launch& L) {
     p.tiles_m = (p.M + C::BM - 1) / C::BM;
     p.tiles_n = (p.N + C::BN - 1) / C::BN;
     p.tile_begin = t;
+    L.tile_begin[i] = t;
     p.nparts = p.tiles_n;
     t += p.tiles_m * p.tiles_n * p.splits;
   }
@@ -356,8 +359,10 @@ static int tile_up(Launch& L) {
 }
 
 // returns the chosen tile configuration (0 small, 1 medium, 2 large)
-static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1) {
+static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsigned long long* dbg = nullptr) {
   if (g.L.nprob == 0) return 0;
+  g.L.dbg = dbg;
+  g.L.aux_nblocks = g.L.aux.nblocks;
   if (cfg < 0) cfg = cx.force_cfg;
   if (cfg < 0) {
     Launch t = g.L;
@@ -515,7 +520,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     }
     ax.ntasks = nt;
     ax.nblocks = ax.noise_blocks + nt;
-    launch_group(cx, g, "fwd_x_first_layers_splitk+aux", env_cfg("GMVAE_P1_CFG", 0));
+    launch_group(cx, g, "fwd_x_first_layers_splitk+aux", env_cfg("GMVAE_P1_CFG", 0), getenv("GMVAE_STAMPS") ? w.gstamps : nullptr);
   }
   {  // the whole per-row forward + backward in one launch
     MegaArgs c;
@@ -530,6 +535,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     c.gmp_part = w.gmp_part;
     c.Q = mega_q(B); c.xchg = w.xchg; c.epoch_word = w.sync; c.err_word = w.sync + 1;
     c.dbg = getenv("GMVAE_STAMPS") ? w.stamps : nullptr;
+    c.fine = getenv("GMVAE_STAMPS") ? atoi(getenv("GMVAE_STAMPS")) : 0;
     static bool mattr = false;
     if (!mattr) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(mega_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -558,7 +564,8 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       g.add(p_tn(w.he[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + E.w[1], sl + E.b[1], NS, PP, nullptr)); // dWe1
     }
     g.add(p_tn(w.z, false, Lz, 1, w.dbuf[0], H, Lz, H, B, sl + Dn.w[0], sl + Dn.b[0], NS, PP, nullptr));          // dWd0
-    launch_group(cx, g, "bwd_dw_all", env_cfg("GMVAE_DW_CFG", B >= 512 ? 1 : 0));
+    launch_group(cx, g, "bwd_dw_all", env_cfg("GMVAE_DW_CFG", B >= 512 ? 1 : 0),
+                 getenv("GMVAE_STAMPS") ? w.gstamps + 2048 * 8 : nullptr);
   }
   return finish_fused(cx, a, L, w, tail, NS, B);
 }
@@ -1286,6 +1293,21 @@ int gmvae_train_graph_destroy(void* graph) {
   return 0;
 }
 
+/* debugging aid: resident workgroups per CU as the runtime computes them */
+int gmvae_kernel_occupancy(int which, int* blocks_per_cu) {
+  if (!blocks_per_cu) return GMVAE_E_NULL;
+  hipError_t e;
+  switch (which) {
+    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, gemm_grouped<CfgS>, kThreads, 0); break;
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, gemm_grouped<CfgM>, kThreads, 0); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, gemm_grouped<CfgL>, kThreads, 0); break;
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mega_fwd_bwd, kMT, 150 * 1024); break;
+    case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, finalize_adam, 256, 0); break;
+    default: return GMVAE_E_DIMS;
+  }
+  return (int)e;
+}
+
 /* debugging aid: byte offset of a named workspace buffer (tests compare intermediates with the oracle) */
 int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, uint64_t* byte_offset) {
   if (int e = check_dims(dims, model)) return e;
@@ -1301,7 +1323,7 @@ int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, u
       {"logpx", w.logpx}, {"logw", w.logw}, {"g", w.g}, {"dz", w.dz}, {"dqp", w.dqp}, {"dpp", w.dpp},
       {"dy", w.dy}, {"dlogits", w.dlogits}, {"dbuf0", w.dbuf[0]}, {"dbuf1", w.dbuf[1]}, {"dbuf2", w.dbuf[2]},
       {"slabs", w.slabs}, {"s1", w.s1}, {"s4", w.s4}, {"eps", w.eps}, {"u", w.u},
-      {"stamps", reinterpret_cast<float*>(w.stamps)}};
+      {"stamps", reinterpret_cast<float*>(w.stamps)}, {"gstamps", reinterpret_cast<float*>(w.gstamps)}};
   for (auto& t : tab)
     if (!strcmp(t.n, name)) {
       if (!t.p) return GMVAE_E_NET;

@@ -78,23 +78,43 @@ __host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D, int mode
   return m;
 }
 
-// partial sums of one 16x16 tile over k-steps [s0, s1) -> acc (operand reads 8 steps ahead of the MFMA chain;
-// a 16-deep batch and a blocked k-assignment were both measured SLOWER: tools/stamps.py)
+// partial sums of one 16x16 tile over k-steps [s0, s1) -> acc.  Operand reads run 8 steps ahead of the MFMA chain
+// (a 16-deep batch and a blocked k-assignment were both measured SLOWER: tools/stamps.py).  Addresses advance by
+// pointer increments: the multiply-and-clamp form cost ~2x the MFMA chain in quarter-rate integer VALU.
 __device__ __forceinline__ f32x4 tile_ksteps(const float* __restrict__ A, const float* __restrict__ Bw, const int sk,
-                                             const int sn, const int tile, const int s0, const int s1, const int smax,
+                                             const int sn, const int tile, const int s0, const int s1, const int /*smax*/,
                                              const int lane, f32x4 acc) {
   const int ln = lane & 15, lk = lane >> 4;
-  for (int sb = s0; sb < s1; sb += 8) {
+  const float* pa = A + (s0 * 4 + lk) * kLDA + ln;
+  const float* pb = Bw + (s0 * 4 + lk) * sk + (tile * 16 + ln) * sn;
+  const int sb4 = 4 * sk;
+  int n = s1 - s0;
+  for (; n >= 8; n -= 8) {
     float av[8], bv[8];
+    const float* q = pb;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int kk = min(sb + j, smax - 1) * 4;
-      av[j] = A[(kk + lk) * kLDA + ln];
-      bv[j] = Bw[(kk + lk) * sk + (tile * 16 + ln) * sn];
+      av[j] = pa[j * 4 * kLDA];
+      bv[j] = *q;
+      q += sb4;
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (sb + j < s1) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+    pa += 32 * kLDA;
+    pb = q;
+  }
+  if (n > 0) {                                   // 1..7 steps left (wave-uniform)
+    float av[7], bv[7];
+    const float* q = pb;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      av[j] = pa[j * 4 * kLDA < (n - 1) * 4 * kLDA ? j * 4 * kLDA : (n - 1) * 4 * kLDA];
+      bv[j] = *q;
+      if (j + 1 < n) q += sb4;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+      if (j < n) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
   }
   return acc;
 }
@@ -159,6 +179,7 @@ struct MegaArgs {
   const unsigned* epoch_word; // tag of this step (bumped by the first launch of the step)
   unsigned* err_word;         // set to 1 if a bounded spin gives up (results are then invalid)
   unsigned long long* dbg;
+  int fine;                   // diagnostic: slots 8.. of a block's stamp record take intra-stage stamps instead
 };
 
 __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
@@ -198,7 +219,10 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   const int nrow = min(kPanel, B - r0);
   const int ln = lane & 15, lk = lane >> 4;
   GMVAE_STAMP(0);
+#define GMVAE_FS(i) if (a.dbg && a.fine >= 2 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime()
   // ======================================================================= F: forward chain
+  for (int rep_ = 0; rep_ < (a.fine == 3 ? 2 : 1); ++rep_) {     // diagnostic: a second, instruction-cache-warm pass
+  if (rep_) { __syncthreads(); GMVAE_STAMP(0); }
   dma_copy_m(sm, a.img, f.img, wave, lane);
   dma_copy_m(P_eps, a.eps + (long long)r0 * L, nrow * L, wave, lane);
   if (gm) dma_copy_m(P_u, a.u + (long long)r0 * K, (nrow * K) & ~3, wave, lane);
@@ -211,8 +235,10 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     const float4 v = slab_sum4(a.s1 + (long long)min(r0 + row, B - 1) * H2 + col, sstride, a.NS);
     if (gm)
       for (int e = ((nrow * K) & ~3) + tid; e < nrow * K; e += kMT) P_u[e] = a.u[(long long)r0 * K + e];
+    GMVAE_FS(0);
     dma_wait();
     __syncthreads();
+    GMVAE_FS(1);
     if (tid < nitem) {
       float vv[4] = {v.x, v.y, v.z, v.w};
       if (col < H) {
@@ -261,6 +287,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     ksplit_finish(acc, t, red, wave, lane, [&](int row, int col, float v) { P_lg[row * KP + col] = v + b_y1[col]; });
     __syncthreads();
   }
+  GMVAE_FS(2);
   // Gumbel-softmax + entropy (16 lanes per row: the first 4 waves)
   if (tid < 256) {
     const int row = tid >> 4, sub = tid & 15;
@@ -320,39 +347,51 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   panel_gemm_s(A_y, W_p, f.ldP, 1, K2, L2 / 16, wave, lane,
                [&](int row, int col, float v) { P_pp[row * L2 + col] = v + b_p[col]; });
   __syncthreads();
+  GMVAE_FS(3);
   }  // gm
   // q head
   panel_gemm_s(A_hq, W_g1, f.ldG1, 1, H, L2 / 16, wave, lane,
                [&](int row, int col, float v) { P_qp[row * L2 + col] = v + b_g1[col]; });
   __syncthreads();
   GMVAE_STAMP(3);
-  // z, log q, log p
-  float my_logq = 0.f, my_logp = 0.f;          // valid in the first 256 threads (16 lanes per row)
-  if (tid < 256) {
-    const int row = tid >> 4, sub = tid & 15;
+  // z, log q, log p: 32 lanes per row.  One exp, one rcp and one log give softplus AND its derivative (the
+  // sigmoid); the backward chain's inputs replace the head outputs in place -- P_qp[row] = [sigmoid(raw_q) | sigma_q],
+  // P_pp[row] = [t = (z - mu_p) / sigma_p | sigma_p], P_z[row] = sigmoid(raw_p) (GMVAE; the others keep z) -- so that
+  // phase B needs no transcendental at all.
+  {
+    const int row = tid >> 5, sub = tid & 31;
     const bool ok = row < nrow;
     float aq = 0.f, ap = 0.f;
-    for (int l = sub; l < L; l += 16) {
+    for (int l = sub; l < L; l += 32) {
       const float mu = P_qp[row * L2 + l];
-      const float sg = fmaxf(fsoftplus(P_qp[row * L2 + L + l] + a.c), a.smin);
+      const float vq = P_qp[row * L2 + L + l] + a.c;
+      const float eq = fexp(-fabsf(vq));
+      const float rq = __builtin_amdgcn_rcpf(1.f + eq);
+      const float sg = fmaxf(fmaxf(vq, 0.f) - flog(rq), a.smin);
       const float ee = ok ? P_eps[row * L + l] : 0.f;
       const float zz = mu + sg * ee;
       A_z[l * kLDA + row] = zz;
-      P_z[row * L + l] = zz;
       if (ok && lead) a.z[(long long)(r0 + row) * L + l] = zz;
-      const float e = (zz - mu) / sg;
-      aq += -0.5f * e * e - 0.5f * kLog2Pi - flog(sg);
+      P_qp[row * L2 + l] = vq >= 0.f ? rq : eq * rq;
+      P_qp[row * L2 + L + l] = sg;
+      aq += -0.5f * ee * ee - 0.5f * kLog2Pi - flog(sg);     // (z - mu) / sigma IS eps
       if (gm) {                                             // p(z|y): gmvae.py:258
-        const float sp = fmaxf(fsoftplus(P_pp[row * L2 + L + l] + a.c), a.smin);
-        const float t = (zz - P_pp[row * L2 + l]) / sp;
+        const float vp = P_pp[row * L2 + L + l] + a.c;
+        const float ep = fexp(-fabsf(vp));
+        const float rp = __builtin_amdgcn_rcpf(1.f + ep);
+        const float sp = fmaxf(fmaxf(vp, 0.f) - flog(rp), a.smin);
+        const float t = (zz - P_pp[row * L2 + l]) * __builtin_amdgcn_rcpf(sp);
         ap += -0.5f * t * t - 0.5f * kLog2Pi - flog(sp);
+        P_pp[row * L2 + l] = t;
+        P_pp[row * L2 + L + l] = sp;
+        P_z[row * L + l] = vp >= 0.f ? rp : ep * rp;
       } else {                                              // N(0, I): vae.py:247-250 (VAE_GMP: mixture stage below)
+        P_z[row * L + l] = zz;
         ap += -0.5f * zz * zz - 0.5f * kLog2Pi;
       }
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { aq += __shfl_xor(aq, o, 64); ap += __shfl_xor(ap, o, 64); }
-    my_logq = aq; my_logp = ap;
+    for (int o = 16; o > 0; o >>= 1) { aq += __shfl_xor(aq, o, 64); ap += __shfl_xor(ap, o, 64); }
     if (sub == 0) {
       nllp[row] = aq;
       if (!gmp) nllp[kPanel + row] = ap;
@@ -360,6 +399,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     }
   }
   __syncthreads();
+  GMVAE_FS(4);
   if (gmp) {
     // MixtureSameFamily.log_prob (vae.py:240-244,181): 32 lanes per row, lane = component (+32), each lane
     // walks l over the LDS-resident (loc, 1/s) image; K-way logsumexp by wavefront shuffles; responsibilities kept.
@@ -406,6 +446,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   });
   __syncthreads();                 // the small-weight image is dead from here until phase B
   GMVAE_STAMP(4);
+  }
 
   // ======================================================================= D: decoder output, streamed
   const int nch = f.nch, ldc = f.ldc;
@@ -484,7 +525,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       dacc = tile_ksteps(A_g, Wc, 1, ldc, dtile, dhalf * (kCW / 8), (dhalf + 1) * (kCW / 8), kCW / 4, lane, dacc);
     GMVAE_SEG(3);
   }
-  if (a.dbg && threadIdx.x == 0)
+  if (a.dbg && a.fine < 2 && threadIdx.x == 0)
     for (int i = 0; i < 8; ++i) a.dbg[(size_t)blockIdx.x * 16 + 8 + i] = tseg[i];
   GMVAE_STAMP(5);
   // per-row log p(x|z): reduce over the 16 column lanes, then over the 4 waves
@@ -604,39 +645,36 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   // dz_dec = dhd1 * Wd0^T
   panel_gemm_s(A_dhd, W_d0, 1, f.ldD0, H, LP / 16, wave, lane, [&](int row, int col, float v) { P_dz[row * LP + col] = v; });
   __syncthreads();
-  if (tid < 256) {
-    const int row = tid >> 4, sub = tid & 15;
+  GMVAE_FS(5);
+  {                                             // 32 lanes per row; inputs prepared by the forward z stage
+    const int row = tid >> 5, sub = tid & 31;
     const bool ok = row < nrow;
-    for (int l = sub; l < L; l += 16) {
+    for (int l = sub; l < L; l += 32) {
       float dmu = 0.f, draw = 0.f, dmup = 0.f, drawp = 0.f;
       if (ok) {
-        const float rawq = P_qp[row * L2 + L + l] + a.c;
-        const float spq = fsoftplus(rawq);
-        const float sg = fmaxf(spq, a.smin);
-        const float zz = P_z[row * L + l];
+        const float sg = P_qp[row * L2 + L + l];
         float pterm;                                   // d(-log p)/dz
         if (gm) {
-          const float rawp = P_pp[row * L2 + L + l] + a.c;
-          const float spp = fsoftplus(rawp);
-          const float sp = fmaxf(spp, a.smin);
-          const float t = (zz - P_pp[row * L2 + l]) / sp;
-          pterm = t / sp;
+          const float sp = P_pp[row * L2 + L + l], t = P_pp[row * L2 + l];
+          const float isp = __builtin_amdgcn_rcpf(sp);
+          pterm = t * isp;
           dmup = -pterm;
-          drawp = (spp > a.smin) ? (1.f - t * t) / sp * sigmoidf_(rawp) : 0.f;
+          drawp = (sp > a.smin) ? (1.f - t * t) * isp * P_z[row * L + l] : 0.f;
           float* dp = a.dpp + (long long)(r0 + row) * L2;
           dp[l] = dmup; dp[L + l] = drawp;
         } else if (gmp) {                              // sum_k r_k (z - loc_k) / s_k^2
+          const float zz = P_z[row * L + l];
           pterm = 0.f;
           for (int k = 0; k < K; ++k) {
             const float iv = M_inv[k * ldM + l];
             pterm += P_r[row * KP + k] * (zz - M_loc[k * ldM + l]) * iv * iv;
           }
         } else {
-          pterm = zz;
+          pterm = P_z[row * L + l];
         }
         dmu = P_dz[row * LP + l] + pterm;
-        const float dsg = dmu * P_eps[row * L + l] - 1.f / sg;
-        draw = (spq > a.smin) ? dsg * sigmoidf_(rawq) : 0.f;
+        const float dsg = dmu * P_eps[row * L + l] - __builtin_amdgcn_rcpf(sg);
+        draw = (sg > a.smin) ? dsg * P_qp[row * L2 + l] : 0.f;
         float* dq = a.dqp + (long long)(r0 + row) * L2;
         dq[l] = dmu; dq[L + l] = draw;
       }
@@ -649,6 +687,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     }
   }
   __syncthreads();
+  GMVAE_FS(6);
   // dh = (dqp * W^T) * [h > 0]: encoder_gmm's hidden layer (GMVAE) or the encoder's (VAE)
   panel_gemm_s(A_dqp, W_g1, 1, f.ldG1, L2, H / 16, wave, lane, [&](int row, int col, float v) {
     const float d = (row < nrow && P_hq[row * H + col] > 0.f) ? v : 0.f;
@@ -680,6 +719,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   }
   if (!gm) { GMVAE_STAMP(7); return; }
   __syncthreads();
+  GMVAE_FS(7);
   // dy = dhg1 * Wg0[D:,:]^T + dpp * Wp^T : K = H then K = 2L, split over the 4 waves
   for (int t = 0; t < KP / 16; ++t) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};

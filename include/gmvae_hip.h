@@ -213,6 +213,10 @@ int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, fl
  * "logits","qp","pp","z","g","dqp","dpp","dlogits","dbuf0".."dbuf2","s1","s4", ...). */
 int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, uint64_t* byte_offset);
 
+/* Debugging aid: resident workgroups per CU the HIP runtime reports for a kernel of the library
+ * (which: 0/1/2 = grouped GEMM small/medium/large configuration, 3 = mega_fwd_bwd, 4 = finalize_adam). */
+int gmvae_kernel_occupancy(int which, int* blocks_per_cu);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,22 +1,37 @@
+"""Per-stage s_memtime stamps of mega_fwd_bwd (diagnostic build path GMVAE_STAMPS=1), split by producer / consumer."""
 import sys, os, ctypes as C
-os.environ["GMVAE_STAMPS"] = "1"
+os.environ.setdefault("GMVAE_STAMPS", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gmvae_amd import _lib as L
 from gmvae_amd.engine import Engine
 B = 1024
+Q = int(os.environ.get("GMVAE_MEGA_Q", "4"))
+nP = B // 16
 e = Engine("gmvae", 784, 64, 10, [64], random_seed=0)
 x = torch.from_numpy((np.random.default_rng(0).random((B, 784)) < 0.87).astype(np.uint8)).cuda()
 for _ in range(50): e.train_step(x)
 torch.cuda.synchronize()
 d, ws = e._workspace(B)
 off = C.c_uint64(); L.check(L.lib.gmvae_workspace_offset(C.byref(d), e.model, b"stamps", C.byref(off)), "off")
-raw = ws.view(torch.int64)[off.value // 8: off.value // 8 + 2 * 64 * 16].cpu().numpy().reshape(2, 64, 16)
-names = ["mega (F0 | logits+gumbel | heads | z+hd | decoder | B0 | bwd chain)", "chain_bwd"] if not os.environ.get("GMVAE_NO_MEGA") else ["chain_fwd", "chain_bwd"]
-for k, name in enumerate(names):
-    st = raw[k][:, :8].astype(np.float64)
-    if st.max() == 0: continue
-    dur = np.diff(st, axis=1)
-    if k == 0 and raw[0][:, 8:12].max() > 0:
-        print("  decoder loop segments (sum over chunks) [wait+sync | lambda+epilogue | sync | dhd product]:", np.round(np.median(raw[0][:, 8:12], axis=0)).astype(int), " | issue_dma, mfma_tile, (epilogue = seg1):", np.round(np.median(raw[0][:, 12:14], axis=0)).astype(int))
-    print(name, "median per-stage cycles:", np.round(np.median(dur, axis=0)).astype(int), "total", int(np.median(st[:, 7] - st[:, 0])))
+raw = ws.view(torch.int64)[off.value // 8: off.value // 8 + nP * Q * 16].cpu().numpy().reshape(nP * Q, 16)
+t0 = raw[:, 0].min()
+cons = raw[nP * (Q - 1):]
+print("stages: F0 | logits+gumbel | heads | z+hd | decoder | B0(+hand-off) | bwd chain")
+st = cons[:, :8].astype(np.float64)
+print("consumers: start (rel. to first block)", int(np.median(st[:, 0] - t0)), "per-stage", np.round(np.median(np.diff(st, axis=1), axis=0)).astype(int),
+      "total", int(np.median(st[:, 7] - st[:, 0])), "end (rel.)", int(np.max(st[:, 7] - t0)))
+if os.environ["GMVAE_STAMPS"] in ("2", "3"):
+    c = cons.astype(np.float64)
+    med = lambda a, b: int(np.median(c[:, a] - c[:, b]))
+    print("fine (consumers): F0: issue", med(8, 0), "| loads+dma return", med(9, 8), "| bias/relu/LDS", med(1, 9))
+    print("   logits ksplit", med(10, 1), "| gumbel-softmax", med(2, 10), "| hg1+prior heads", med(11, 2), "| q head", med(3, 11),
+          "| z/logq/logp", med(12, 3), "| hd", med(4, 12))
+    print("   B: dz gemm", med(13, 6), "| dqp elementwise", med(14, 13), "| dhg gemm", med(15, 14), "| dy+softmax bwd+dhy", med(7, 15))
+    sys.exit(0)
+print("  decoder segments [wait+sync | lambda+epilogue | sync | dhd product | issue | mfma]:", np.round(np.median(cons[:, 8:14], axis=0)).astype(int))
+for q in range(1, Q):
+    pr = raw[nP * (q - 1): nP * q]
+    st = pr[:, :6].astype(np.float64)
+    print(f"producers q={q}: start", int(np.median(st[:, 0] - t0)), "per-stage", np.round(np.median(np.diff(st, axis=1), axis=0)).astype(int),
+          "decoder end (rel.)", int(np.median(st[:, 5] - t0)))
