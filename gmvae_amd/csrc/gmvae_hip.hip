@@ -533,15 +533,21 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     c.dhd1 = w.dbuf[0]; c.dqp = w.dqp; c.dpp = w.dpp; c.dhg1 = w.dbuf[1]; c.dlogits = w.dlogits; c.dhy1 = w.dbuf[2];
     c.nent = w.nent; c.logq = w.logq; c.logp = w.logp; c.logpx = w.logpx; c.logw = w.logw;
     c.gmp_part = w.gmp_part;
+    c.lay = ml;
     c.Q = mega_q(B); c.xchg = w.xchg; c.epoch_word = w.sync; c.err_word = w.sync + 1;
     c.dbg = getenv("GMVAE_STAMPS") ? w.stamps : nullptr;
     c.fine = getenv("GMVAE_STAMPS") ? atoi(getenv("GMVAE_STAMPS")) : 0;
+    // the reference's default sizes (run_gmvae.py: latent 64, hidden 64, K 10; MNIST D 784) run a specialised instance
+    typedef void (*MegaFn)(const MegaArgs);
+    const bool spec = H == 64 && Lz == 64 && K == 10 && D == 784 && gm && !getenv("GMVAE_MEGA_GENERIC");
+    const MegaFn fn = spec ? mega_fwd_bwd<64, 64, 10, 784, 2> : mega_fwd_bwd<0, 0, 0, 0, -1>;
     static bool mattr = false;
     if (!mattr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(mega_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(mega_fwd_bwd<64, 64, 10, 784, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(mega_fwd_bwd<0, 0, 0, 0, -1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       mattr = true;
     }
-    hipLaunchKernelGGL(mega_fwd_bwd, dim3((B + kPanel - 1) / kPanel * c.Q), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
+    hipLaunchKernelGGL(fn, dim3((B + kPanel - 1) / kPanel * c.Q), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
     cx.check();
     // algorithmic MFMA FLOPs of the launch: forward chain + decoder layer (lambda and its data gradient) + backward chain
     double macs = (double)H * 2 * Lz + (double)Lz * H + 2.0 * H * D + (double)H * Lz + 2.0 * Lz * H;
@@ -1301,7 +1307,7 @@ int gmvae_kernel_occupancy(int which, int* blocks_per_cu) {
     case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, gemm_grouped<CfgS>, kThreads, 0); break;
     case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, gemm_grouped<CfgM>, kThreads, 0); break;
     case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, gemm_grouped<CfgL>, kThreads, 0); break;
-    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mega_fwd_bwd, kMT, 150 * 1024); break;
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mega_fwd_bwd<0, 0, 0, 0, -1>, kMT, 150 * 1024); break;
     case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, finalize_adam, 256, 0); break;
     default: return GMVAE_E_DIMS;
   }

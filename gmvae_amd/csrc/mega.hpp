@@ -25,6 +25,7 @@ struct MegaLay {
   int KP, K2, L2, LP;
   int ldY1, ldG0, ldP, ldG1, ldD0, ldc;
   int W_y1, W_g0y, W_p, W_g1, W_d0, b_y0, b_y1, b_g0, b_p, b_g1, b_d0, img;   // small-weight image [0, img)
+  int img_early;                     // [0, img_early): what the first stages need; the rest lands while they run
   int chunk, nch;                    // floats per decoder chunk image ([H+1][ldc], row H = bias slice), chunks
   int ring, xring;                   // LDS: ring of 2 chunk images (aliases the small-weight image), 2 x-chunks
   int A_hy, A_y, A_hg, A_z, A_hd, A_g;          // forward / decoder operand images ([k][17])
@@ -40,15 +41,16 @@ __host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D, int mode
   m.ldY1 = m.KP + 1; m.ldG0 = H + 1; m.ldP = m.L2 + 1; m.ldG1 = m.L2 + 1; m.ldD0 = H + 1; m.ldc = kCW + 1;
   int o = 0;
   auto take = [&](int n) { const int r = o; o += GMVAE_P4(n); return r; };
+  m.b_y0 = take(H); m.b_y1 = take(m.KP); m.b_g0 = take(H); m.b_p = take(m.L2); m.b_g1 = take(m.L2); m.b_d0 = take(H);
   m.W_y1 = take(H * m.ldY1);       // [H][KP+1]
   m.W_g0y = take(m.K2 * m.ldG0);   // [K2][H+1]
   m.W_p = take(m.K2 * m.ldP);      // [K2][L2+1]
-  m.W_g1 = take(H * m.ldG1);       // [H][L2+1]
-  m.W_d0 = take(L * m.ldD0);       // [L][H+1]
-  m.b_y0 = take(H); m.b_y1 = take(m.KP); m.b_g0 = take(H); m.b_p = take(m.L2); m.b_g1 = take(m.L2); m.b_d0 = take(H);
   m.ldM = L + 1;
   m.M_loc = m.M_raw = m.M_mix = m.M_inv = m.M_c = m.M_w = m.P_r = 0;
   if (model == 1) { m.M_loc = take(K * m.ldM); m.M_raw = take(K * m.ldM); m.M_mix = take(m.KP); }
+  m.img_early = o = GMVAE_P256(o);
+  m.W_g1 = take(H * m.ldG1);       // [H][L2+1]
+  m.W_d0 = take(L * m.ldD0);       // [L][H+1]
   m.img = GMVAE_P256(o);
   m.chunk = GMVAE_P256((H + 1) * m.ldc);
   m.nch = (D + kCW - 1) / kCW;
@@ -77,6 +79,24 @@ __host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D, int mode
   m.total = o;
   return m;
 }
+
+// All-reduce over the 16 lanes of a DPP row by rotations (row_ror 8, 4, 2, 1): 4 VALU instructions instead of
+// 4 dependent trips through the LDS crossbar (ds_bpermute, what __shfl_xor compiles to).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(const float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0x128>(v)); v = fmaxf(v, dpp_mov<0x124>(v)); v = fmaxf(v, dpp_mov<0x122>(v)); v = fmaxf(v, dpp_mov<0x121>(v));
+  return v;
+}
+__device__ __forceinline__ float row32_sum(float v) { v = row16_sum(v); return v + __shfl_xor(v, 16, 64); }
+__device__ __forceinline__ float row32_max(float v) { v = row16_max(v); return fmaxf(v, __shfl_xor(v, 16, 64)); }
 
 // partial sums of one 16x16 tile over k-steps [s0, s1) -> acc.  Operand reads run 8 steps ahead of the MFMA chain
 // (a 16-deep batch and a blocked k-assignment were both measured SLOWER: tools/stamps.py).  Addresses advance by
@@ -161,6 +181,7 @@ __device__ __forceinline__ void dma_copy_m(float* __restrict__ lds_dst, const fl
 struct MegaArgs {
   int model;                  // 0 VAE, 1 VAE_GMP, 2 GMVAE
   int B, H, L, K, D, NS;
+  int Q;                      // workgroups per panel (see xchg below)
   float c, smin, invT, gen_bias;
   const float* s1;            // [NS][B][2H] split-K partials of X*[Wy0 | Wg0x]
   const float* img;           // small-weight image (mega_lay [0, img))
@@ -174,21 +195,43 @@ struct MegaArgs {
   // Decoder chunks of one panel are spread over Q workgroups (all run the cheap forward chain); quarters
   // 1..Q-1 hand their partial dhd1 tile and Bernoulli row sums to quarter 0 through 8-byte {epoch, value}
   // granules (cdna_hip_programming.md G16 recipe R2: the data is its own flag, no fences).
-  int Q;
   unsigned long long* xchg;   // [panels][Q-1][16*H + 16] granules
   const unsigned* epoch_word; // tag of this step (bumped by the first launch of the step)
   unsigned* err_word;         // set to 1 if a bounded spin gives up (results are then invalid)
   unsigned long long* dbg;
   int fine;                   // diagnostic: slots 8.. of a block's stamp record take intra-stage stamps instead
+  MegaLay lay;                // mega_lay(H, L, K, D, model), computed once on the host
 };
 
+// HT, LT, KT, DT, MODEL: compile-time sizes of a specialised instance (0 / -1 = read them from the arguments).
+// With runtime sizes the launch spends ~1100 instructions on pointer and index set-up before its first DMA and
+// keeps ~100 scalars live (spilled to VGPR lanes); with the sizes folded in, the layout is a table of constants.
+template <int HT, int LT, int KT, int DT, int MODEL>
 __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = a.H, L = a.L, K = a.K, B = a.B, D = a.D;
-  const int model = a.model;
+  const int H = HT ? HT : a.H, L = LT ? LT : a.L, K = KT ? KT : a.K, D = DT ? DT : a.D, B = a.B;
+  const int model = MODEL >= 0 ? MODEL : a.model;
   const bool gm = model == 2, gmp = model == 1;
-  const MegaLay f = mega_lay(H, L, K, D, model);
+  // producers (quarters 1..Q-1) take the LOWER block ids: a consumer can then never keep its producers off the chip
+  const int nP = (B + kPanel - 1) / kPanel, Q = a.Q;
+  const int bid = blockIdx.x;
+  const int q = bid < nP * (Q - 1) ? 1 + bid / nP : 0;
+  const int pnl = bid < nP * (Q - 1) ? bid % nP : bid - nP * (Q - 1);
+  const int r0 = pnl * kPanel;
+  // The split-K partials of the first layer are the longest (coldest) wait of the launch: their loads go out
+  // before anything else (the scheduling barrier keeps the ~1000 instructions of pointer set-up below them).
+  const int H2f = gm ? 2 * H : H;
+  const int nitem = kPanel * H2f / 4;             // <= 512 for H <= 64: one item per thread
+  const int fi = min(tid, nitem - 1);
+  const int frow = (fi * 4) / H2f, fcol = (fi * 4) % H2f;
+  const float* const sp = a.s1 + (long long)min(r0 + frow, B - 1) * H2f + fcol;
+  const long long sstride = (long long)B * H2f;
+  float4 so[4];                                   // raw: summed after the DMA issue
+#pragma unroll
+  for (int j = 0; j < 4; ++j) so[j] = *reinterpret_cast<const float4*>(sp + (long long)min(j, a.NS - 1) * sstride);
+  __builtin_amdgcn_sched_barrier(0);
+  const MegaLay f = HT ? mega_lay(H, L, K, D, model) : a.lay;
   const int KP = f.KP, K2 = f.K2, L2 = f.L2, LP = f.LP;
   float *W_y1 = sm + f.W_y1, *W_g0y = sm + f.W_g0y, *W_p = sm + f.W_p, *W_g1 = sm + f.W_g1, *W_d0 = sm + f.W_d0;
   float *b_y0 = sm + f.b_y0, *b_y1 = sm + f.b_y1, *b_g0 = sm + f.b_g0, *b_p = sm + f.b_p, *b_g1 = sm + f.b_g1, *b_d0 = sm + f.b_d0;
@@ -209,13 +252,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
         *M_w = sm + f.M_w, *P_r = sm + f.P_r;
   const int ldM = f.ldM;
 
-  // producers (quarters 1..Q-1) take the LOWER block ids: a consumer can then never keep its producers off the chip
-  const int nP = (B + kPanel - 1) / kPanel, Q = a.Q;
-  const int bid = blockIdx.x;
-  const int q = bid < nP * (Q - 1) ? 1 + bid / nP : 0;
-  const int pnl = bid < nP * (Q - 1) ? bid % nP : bid - nP * (Q - 1);
   const bool lead = q == 0;                    // quarter 0 owns the panel: saves activations, runs phase B
-  const int r0 = pnl * kPanel;
   const int nrow = min(kPanel, B - r0);
   const int ln = lane & 15, lk = lane >> 4;
   GMVAE_STAMP(0);
@@ -223,22 +260,28 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   // ======================================================================= F: forward chain
   for (int rep_ = 0; rep_ < (a.fine == 3 ? 2 : 1); ++rep_) {     // diagnostic: a second, instruction-cache-warm pass
   if (rep_) { __syncthreads(); GMVAE_STAMP(0); }
-  dma_copy_m(sm, a.img, f.img, wave, lane);
+  dma_copy_m(sm, a.img, f.img_early, wave, lane);
   dma_copy_m(P_eps, a.eps + (long long)r0 * L, nrow * L, wave, lane);
   if (gm) dma_copy_m(P_u, a.u + (long long)r0 * K, (nrow * K) & ~3, wave, lane);
   {
-    const int H2 = gm ? 2 * H : H;
-    const long long sstride = (long long)B * H2;
-    const int nitem = kPanel * H2 / 4;             // <= 512 for H <= 64: one item per thread
-    const int i = min(tid, nitem - 1);
-    const int row = (i * 4) / H2, col = (i * 4) % H2;
-    const float4 v = slab_sum4(a.s1 + (long long)min(r0 + row, B - 1) * H2 + col, sstride, a.NS);
+    const int row = frow, col = fcol;
     if (gm)
       for (int e = ((nrow * K) & ~3) + tid; e < nrow * K; e += kMT) P_u[e] = a.u[(long long)r0 * K + e];
     GMVAE_FS(0);
     dma_wait();
     __syncthreads();
     GMVAE_FS(1);
+    dma_copy_m(sm + f.img_early, a.img + f.img_early, f.img - f.img_early, wave, lane);   // q head / decoder hidden weights
+    float4 v = so[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      const float w = j < a.NS ? 1.f : 0.f;
+      v.x += w * so[j].x; v.y += w * so[j].y; v.z += w * so[j].z; v.w += w * so[j].w;
+    }
+    if (a.NS > 4) {
+      const float4 t = slab_sum4(sp + 4 * sstride, sstride, a.NS - 4);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
     if (tid < nitem) {
       float vv[4] = {v.x, v.y, v.z, v.w};
       if (col < H) {
@@ -306,14 +349,12 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
         m2 = fmaxf(m2, lgv[j]);
       }
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); m2 = fmaxf(m2, __shfl_xor(m2, o, 64)); }
+    mx = row16_max(mx); m2 = row16_max(m2);
     float se = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (sub + 16 * j < K) { se += fexp(av[j] - mx); s2 += fexp(lgv[j] - m2); }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    se = row16_sum(se); s2 = row16_sum(s2);
     const float lse = mx + flog(se), l2 = m2 + flog(s2);
     float ne = 0.f;
 #pragma unroll
@@ -331,8 +372,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
         A_y[k * kLDA + row] = yv;
       }
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) ne += __shfl_xor(ne, o, 64);
+    ne = row16_sum(ne);
     if (sub == 0) { nllp[3 * kPanel + row] = ne; if (ok && lead) a.nent[r0 + row] = ne; }     // nllp[48..63]: nent per row
   }
   __syncthreads();
@@ -346,9 +386,10 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   });
   panel_gemm_s(A_y, W_p, f.ldP, 1, K2, L2 / 16, wave, lane,
                [&](int row, int col, float v) { P_pp[row * L2 + col] = v + b_p[col]; });
+  }  // gm
+  dma_wait();                      // the late part of the weight image
   __syncthreads();
   GMVAE_FS(3);
-  }  // gm
   // q head
   panel_gemm_s(A_hq, W_g1, f.ldG1, 1, H, L2 / 16, wave, lane,
                [&](int row, int col, float v) { P_qp[row * L2 + col] = v + b_g1[col]; });
@@ -390,8 +431,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
         ap += -0.5f * zz * zz - 0.5f * kLog2Pi;
       }
     }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) { aq += __shfl_xor(aq, o, 64); ap += __shfl_xor(ap, o, 64); }
+    aq = row32_sum(aq); ap = row32_sum(ap);
     if (sub == 0) {
       nllp[row] = aq;
       if (!gmp) nllp[kPanel + row] = ap;
@@ -419,14 +459,12 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       }
     }
     float mx = fmaxf(comp[0], comp[1]);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = row32_max(mx);
     float se = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       if (sub + 32 * j < K) se += fexp(comp[j] - mx);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    se = row32_sum(se);
     const float lse = mx + flog(se);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -531,8 +569,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   // per-row log p(x|z): reduce over the 16 column lanes, then over the 4 waves
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) rs[r] += __shfl_xor(rs[r], o, 64);
+    rs[r] = row16_sum(rs[r]);
   }
   __syncthreads();                               // every wave is done with the ring and A_g
   const unsigned epoch = Q > 1 ? *a.epoch_word : 0u;
@@ -751,14 +788,12 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
         dot += yv[j] * P_dy[row * KP + k];
       }
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { m2 = fmaxf(m2, __shfl_xor(m2, o, 64)); dot += __shfl_xor(dot, o, 64); }
+    m2 = row16_max(m2); dot = row16_sum(dot);
     float s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (sub + 16 * j < K && ok) s2 += fexp(lgv[j] - m2);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    s2 = row16_sum(s2);
     const float l2 = m2 + flog(s2);
     const float ne = nllp[3 * kPanel + row];
 #pragma unroll
