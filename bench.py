@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--data-dim", type=int, default=784)
     ap.add_argument("--n-samples", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--graph-steps", type=int, default=16, help="consecutive steps captured in one hipGraph launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--levels", action="store_true", help="also print the per-launch table to stderr")
@@ -122,18 +123,35 @@ def main():
         except Exception as e:
             if rank == 0:
                 print(f"[bench] in-library RCCL unavailable ({type(e).__name__}: {e}); torch.distributed all-reduce", file=sys.stderr)
+    # One graph launch runs G consecutive steps, each on its own resident batch (the next G batches of an input
+    # pipeline): the GPU idles ~6 us between two graph launches, nothing between the kernels inside one.
+    G = max(1, a.graph_steps)
+    multi_fn = None
     if use_graph:
         try:
             static_x, replay = eng.capture_train_step(B, lr=1e-3, all_reduce=world > 1)
             static_x.copy_(x)
             step_fn = replay
+            if G > 1:
+                xs, multi_fn = eng.capture_train_step(B, lr=1e-3, all_reduce=world > 1, n_steps=G)
+                rng = np.random.default_rng(4321 + rank)
+                xs.copy_(torch.from_numpy((rng.random((G, B, d.D)) < 0.87).astype(np.uint8)))
         except Exception as e:                      # e.g. RCCL inside capture unsupported
             if rank == 0:
                 print(f"[bench] graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
             use_graph = False
+            multi_fn = None
     if not use_graph:
         def step_fn():
             eng.train_step(x, lr=1e-3, all_reduce=world > 1)
+
+    def run_steps(k):                               # exactly k training steps
+        if multi_fn is not None:
+            for _ in range(k // G):
+                multi_fn()
+            k = k % G
+        for _ in range(k):
+            step_fn()
 
     # The GPU drops its clocks while the host runs the fp64 parity check above; a step is ~100 us, so W
     # warm-up steps alone can be shorter than the DVFS ramp (measured: 2x slower timed region).  Spin the
@@ -141,23 +159,19 @@ def main():
     if world == 1:
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < 0.75:
-            for _ in range(50):
-                step_fn()
+            run_steps(64)
             torch.cuda.synchronize()
     else:
         # every rank must issue the SAME number of steps (each contains a collective): fixed count, not wall time
-        for _ in range(4000):
-            step_fn()
+        run_steps(4000)
         torch.cuda.synchronize()
-    for _ in range(a.warmup):
-        step_fn()
+    run_steps(a.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step_fn()
+    run_steps(a.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -1245,11 +1245,13 @@ struct GmvaeTrainGraph {
   hipGraphExec_t exec = nullptr;
 };
 
-int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m,
+int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, int n_steps, float* params, float* m,
                              float* v, float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr,
                              float beta1, float beta2, float epsilon, void** graph_out) {
   if (int e = check_dims(dims, model)) return e;
   if (!x || !params || !m || !v || !grads || !workspace || !step_dev || !graph_out) return GMVAE_E_NULL;
+  if (n_steps < 1 || n_steps > 1024) return GMVAE_E_DIMS;
+  const size_t xstride = (size_t)dims->B * dims->D;
   Layout L;
   build_layout(*dims, model, L);
   hipStream_t cs;
@@ -1260,13 +1262,16 @@ int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x,
   he = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
   if (he != hipSuccess) rc = (int)he;
   if (rc == 0) {
-    if (fused_ok(*dims, model) || mega_ok(*dims, model)) {
-      rc = step_with_adam(dims, model, x, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, cs);
-    } else {
-      rc = gmvae_step(dims, model, x, nullptr, nullptr, params, grads, workspace, seed, 0, step_dev, cs);
-      if (rc == 0)
-        rc = adam_tf_step(params, m, v, grads, L.P_pad, lr, beta1, beta2, epsilon, 0, step_dev, 1.f,
-                          grads + L.P_pad + 4, cs);
+    for (int s = 0; s < n_steps && rc == 0; ++s) {
+      const uint8_t* xs = x + s * xstride;
+      if (fused_ok(*dims, model) || mega_ok(*dims, model)) {
+        rc = step_with_adam(dims, model, xs, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, cs);
+      } else {
+        rc = gmvae_step(dims, model, xs, nullptr, nullptr, params, grads, workspace, seed, 0, step_dev, cs);
+        if (rc == 0)
+          rc = adam_tf_step(params, m, v, grads, L.P_pad, lr, beta1, beta2, epsilon, 0, step_dev, 1.f,
+                            grads + L.P_pad + 4, cs);
+      }
     }
     he = hipStreamEndCapture(cs, &tg->graph);
     if (rc == 0 && he != hipSuccess) rc = (int)he;
@@ -1404,11 +1409,12 @@ int gmvae_dp_step(const GmvaeDims* dims, int model, const uint8_t* x, float* par
 }
 
 /* the same step captured once into a hipGraph (RCCL kernels included); replay with gmvae_train_graph_launch */
-int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
+int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, int n_steps, float* params, float* m, float* v,
                           float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1,
                           float beta2, float epsilon, void* comm, void** graph_out) {
   if (int e = check_dims(dims, model)) return e;
   if (!graph_out || !comm) return GMVAE_E_NULL;
+  if (n_steps < 1 || n_steps > 1024) return GMVAE_E_DIMS;
   hipStream_t cs;
   hipError_t he = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
   if (he != hipSuccess) return (int)he;
@@ -1424,7 +1430,9 @@ int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, fl
     if (he != hipSuccess) rc = (int)he;
   }
   if (rc == 0) {
-    rc = gmvae_dp_step(dims, model, x, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, comm, cs);
+    for (int s = 0; s < n_steps && rc == 0; ++s)
+      rc = gmvae_dp_step(dims, model, x + (size_t)s * dims->B * dims->D, params, m, v, grads, workspace, seed, step_dev, lr,
+                         beta1, beta2, epsilon, comm, cs);
     he = hipStreamEndCapture(cs, &tg->graph);
     if (rc == 0 && he != hipSuccess) rc = (int)he;
   }

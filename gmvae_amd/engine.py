@@ -266,24 +266,30 @@ class Engine:
         return self.grads[self.P:]
 
     # -------------------------------------------------- hipGraph fast path
-    def capture_train_step(self, B: int, lr: float = 1e-3, all_reduce: bool = False):
+    def capture_train_step(self, B: int, lr: float = 1e-3, all_reduce: bool = False, n_steps: int = 1):
         """One hipGraph for noise + fwd + bwd + Adam at batch size B, captured and owned by the HIP
-        library (gmvae_train_graph_*).  Returns (static_x, replay).  With all_reduce (data parallel)
-        the step is two eager halves around ONE RCCL all-reduce instead: torch's RCCL stream handling
-        is not captured here."""
+        library (gmvae_train_graph_*).  Returns (static_x, replay).  With n_steps > 1 the graph holds
+        that many consecutive steps and static_x is [n_steps, B, D] (the next n_steps batches): one
+        launch per n_steps steps hides the idle time between graph launches.  With all_reduce (data
+        parallel) the RCCL all-reduce is captured too when the library owns the communicator
+        (enable_rccl); otherwise the step is two eager halves around torch.distributed.all_reduce."""
         import torch.distributed as dist
         do_ar = all_reduce and ((dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
                                 or getattr(self, "_comm", None) is not None)
-        key = (B, lr, do_ar)
+        n_steps = int(n_steps)
+        key = (B, lr, do_ar, n_steps)
         if key in self._graphs:
             return self._graphs[key][:2]
-        static_x = torch.zeros(B, self.D, dtype=torch.uint8, device=self.device)
+        if n_steps == 1:
+            static_x = torch.zeros(B, self.D, dtype=torch.uint8, device=self.device)
+        else:
+            static_x = torch.zeros(n_steps, B, self.D, dtype=torch.uint8, device=self.device)
         d, ws = self._workspace(B)
         self.step_dev.fill_(self.global_step)
         if do_ar and getattr(self, "_comm", None):
             torch.cuda.synchronize()
             handle = C.c_void_p()
-            rc = L.lib.gmvae_dp_graph_create(C.byref(d), self.model, L.ptr(static_x), L.ptr(self.params), L.ptr(self.m),
+            rc = L.lib.gmvae_dp_graph_create(C.byref(d), self.model, L.ptr(static_x), n_steps, L.ptr(self.params), L.ptr(self.m),
                                              L.ptr(self.v), L.ptr(self.grads), L.ptr(ws), self.noise_seed,
                                              L.ptr(self.step_dev), lr, 0.9, 0.999, 1e-8, self._comm, C.byref(handle))
             if rc == 0:
@@ -294,28 +300,33 @@ class Engine:
                     rc2 = launch(handle, L.current_stream())
                     if rc2:
                         L.check(rc2, "gmvae_train_graph_launch")
-                    self.global_step += 1
+                    self.global_step += n_steps
                 self._graphs[key] = (static_x, replay, handle)
                 return static_x, replay
             self.step_dev.fill_(self.global_step)   # capture refused: eager C-side step instead
             self.dp_mode = "rccl-eager-c"
+            batches = [static_x] if n_steps == 1 else list(static_x.unbind(0))
 
             def replay():
-                self.dp_step(static_x, lr)
+                for xb in batches:
+                    self.dp_step(xb, lr)
             self._graphs[key] = (static_x, replay, None)
             return static_x, replay
         if do_ar:
             self.dp_mode = "torch.distributed"
+            batches = [static_x] if n_steps == 1 else list(static_x.unbind(0))
+
             def replay():
-                self.step(static_x, use_step_dev=True)
-                dist.all_reduce(self.grads)
-                self.adam(lr, use_step_dev=True)
-                self.global_step += 1
+                for xb in batches:
+                    self.step(xb, use_step_dev=True)
+                    dist.all_reduce(self.grads)
+                    self.adam(lr, use_step_dev=True)
+                    self.global_step += 1
             self._graphs[key] = (static_x, replay, None)
             return static_x, replay
         torch.cuda.synchronize()
         handle = C.c_void_p()
-        rc = L.lib.gmvae_train_graph_create(C.byref(d), self.model, L.ptr(static_x), L.ptr(self.params), L.ptr(self.m),
+        rc = L.lib.gmvae_train_graph_create(C.byref(d), self.model, L.ptr(static_x), n_steps, L.ptr(self.params), L.ptr(self.m),
                                             L.ptr(self.v), L.ptr(self.grads), L.ptr(ws), self.noise_seed,
                                             L.ptr(self.step_dev), lr, 0.9, 0.999, 1e-8, C.byref(handle))
         L.check(rc, "gmvae_train_graph_create")
@@ -325,7 +336,7 @@ class Engine:
             rc = launch(handle, L.current_stream())
             if rc:
                 L.check(rc, "gmvae_train_graph_launch")
-            self.global_step += 1
+            self.global_step += n_steps
 
         self._graphs[key] = (static_x, replay, handle)
         return static_x, replay

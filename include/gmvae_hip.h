@@ -184,9 +184,12 @@ int gmvae_bench_loop(const GmvaeDims* dims, int model, const uint8_t* x, float* 
 /* One full training step -- Philox noise + gmvae_step + adam_tf_step(t = *step_dev, grad_scale =
  * 1/count from the tail) -- captured ONCE into a hipGraph owned by the library, for replay with a single
  * call per step (the sess.run([train_op, global_step]) of scripts/runners.py:231-232).  All pointers
- * are baked into the graph: copy each new batch into `x` before launching.  Single-device step; the
- * data-parallel step (with the RCCL all-reduce between the two halves) is driven from the host side. */
-int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m,
+ * are baked into the graph: copy each new batch into `x` before launching.
+ * n_steps >= 1 consecutive steps go into the one graph; `x` then holds n_steps batches back to back
+ * ([n_steps][B][D]: the next n_steps batches of the input pipeline).  One launch per n_steps steps amortises
+ * the ~6 us the GPU idles between two graph launches (measured, profiles/): the kernels inside a graph run
+ * back to back. */
+int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, int n_steps, float* params, float* m,
                              float* v, float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr,
                              float beta1, float beta2, float epsilon, void** graph_out);
 int gmvae_train_graph_launch(void* graph, void* stream);
@@ -205,7 +208,7 @@ int gmvae_comm_destroy(void* comm);
 int gmvae_dp_step(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
                   float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1,
                   float beta2, float epsilon, void* comm, void* stream);
-int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
+int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, int n_steps, float* params, float* m, float* v,
                           float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1,
                           float beta2, float epsilon, void* comm, void** graph_out);
 

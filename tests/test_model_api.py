@@ -128,6 +128,33 @@ def test_graph_replay_matches_eager_steps():
     assert torch.allclose(outs[0][0], outs[1][0], atol=1e-6)
 
 
+def test_multi_step_graph_matches_eager_steps_on_the_same_batches():
+    """n_steps batches in ONE graph launch == the same batches stepped one by one (bit-identical: same kernels,
+    same Philox (seed, step) stream, same order)."""
+    from gmvae_amd.engine import Engine
+    n, B = 4, 1024
+    rng = np.random.default_rng(3)
+    xs = torch.from_numpy((rng.random((n, B, 784)) < 0.87).astype(np.uint8)).cuda()
+    outs = []
+    for multi in (False, True):
+        e = Engine("gmvae", 784, 64, 10, [64], random_seed=5)
+        if multi:
+            sx, replay = e.capture_train_step(B, lr=1e-3, n_steps=n)
+            assert tuple(sx.shape) == (n, B, 784)
+            sx.copy_(xs)
+            replay()
+            replay()
+        else:
+            for r in range(2):
+                for i in range(n):
+                    e.train_step(xs[i], lr=1e-3)
+        torch.cuda.synchronize()
+        outs.append((e.params.detach().clone(), e.global_step, e.grads[e.P:].clone()))
+    assert outs[0][1] == outs[1][1] == 2 * n
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][2], outs[1][2])
+
+
 def test_missing_engine_and_bad_activation_fail_loudly():
     import gmvae_amd
     from gmvae_amd import base
