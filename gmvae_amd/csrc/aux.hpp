@@ -36,6 +36,29 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 }
 __device__ __forceinline__ float u01(uint32_t b) { return (float)(b >> 8) * 5.9604644775390625e-8f; }  // [0,1)
 
+// 4 consecutive values of the eps stream (Box-Muller normals) or of the u stream (uniforms in [kTiny, 1)):
+// quad q of the flat array, keyed by (seed, step) -- every consumer of the noise calls this one function
+__device__ __forceinline__ void noise_vals(const uint64_t q, const bool is_u, const uint64_t seed, const uint64_t step,
+                                           float (&o)[4]) {
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32) | (is_u ? 0x80000000u : 0u), (uint32_t)step, (uint32_t)(step >> 32)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  if (is_u) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaxf(u01(c[j]), kTiny);
+  } else {
+#pragma unroll
+    // Box-Muller on the hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, and v_sin/v_cos_f32, whose
+    // argument is in TURNS -- the uniform goes in as it is.  (The libm forms cost ~10x the instructions, which
+    // matters where mega_fwd_bwd draws its panel's noise itself.)
+    for (int j = 0; j < 4; j += 2) {
+      const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(1.f - u01(c[j])));   // 1-u in (0,1]
+      const float t = u01(c[j + 1]);
+      o[j] = r * __builtin_amdgcn_cosf(t);
+      o[j + 1] = r * __builtin_amdgcn_sinf(t);
+    }
+  }
+}
+
 // thread `i` of the fill: 4 values of eps (Box-Muller) or of u
 __device__ __forceinline__ void noise_item(uint64_t i, float* eps, uint64_t n_eps, float* u, uint64_t n_u,
                                            uint64_t seed, uint64_t step) {
@@ -43,22 +66,8 @@ __device__ __forceinline__ void noise_item(uint64_t i, float* eps, uint64_t n_ep
   if (i >= q_eps + q_u) return;
   const bool is_u = i >= q_eps;
   const uint64_t q = is_u ? i - q_eps : i;
-  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32) | (is_u ? 0x80000000u : 0u), (uint32_t)step, (uint32_t)(step >> 32)};
-  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   float o[4];
-  if (is_u) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = fmaxf(u01(c[j]), kTiny);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; j += 2) {
-      const float r = sqrtf(-2.f * logf(1.f - u01(c[j])));       // 1-u in (0,1]
-      float sn, cs;
-      sincosf(6.283185307179586f * u01(c[j + 1]), &sn, &cs);
-      o[j] = r * cs;
-      o[j + 1] = r * sn;
-    }
-  }
+  noise_vals(q, is_u, seed, step, o);
   float* dst = is_u ? u : eps;
   const uint64_t n = is_u ? n_u : n_eps;
   if (q * 4 + 3 < n) {

@@ -170,24 +170,6 @@ __device__ __forceinline__ void panel_gemm_ksplit(const float* __restrict__ A, c
   epi(tid >> 4, tile * 16 + (tid & 15), v);
 }
 
-// sum of NS split-K slabs at one float4 location
-// (loads go out four at a time, clamped to the last slab and predicated at the add: a runtime-count loop of
-// load-then-add serialises one cold memory round trip per slab)
-__device__ __forceinline__ float4 slab_sum4(const float* __restrict__ p, const long long sstride, const int NS) {
-  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s0 = 0; s0 < NS; s0 += 4) {
-    float4 o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = *reinterpret_cast<const float4*>(p + (long long)min(s0 + j, NS - 1) * sstride);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float w = s0 + j < NS ? 1.f : 0.f;
-      r.x += w * o[j].x; r.y += w * o[j].y; r.z += w * o[j].z; r.w += w * o[j].w;
-    }
-  }
-  return r;
-}
-
 struct ChainFwdArgs {
   int B, H, L, K, NS;
   float c, smin, invT;

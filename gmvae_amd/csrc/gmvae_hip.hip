@@ -123,6 +123,7 @@ struct WS {
   float *s1, *s4;          // split-K slabs of the fused schedule: [NSF][B][2H], [NSF][B][H]
   unsigned long long* stamps;   // diagnostic stamps of the chain kernels: [2][grid][16]
   unsigned long long* xchg;     // mega_fwd_bwd's in-launch hand-off granules: [panels][Q-1][16*H + 16]
+  unsigned long long* xfl;      // mega_fwd_bwd's first-layer exchange granules: [panels][4][16 * H2]
   unsigned long long* gstamps;  // diagnostic stamps of the grouped-GEMM launches: [4 launches][2048 blocks][8]
   unsigned* sync;               // [0] = per-step epoch of the hand-off, [1] = hand-off timeout flag
   float *img_f, *img_b;         // per-step LDS weight images of chain_fwd / chain_bwd (prepared by aux blocks)
@@ -243,6 +244,8 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     w.xchg = reinterpret_cast<unsigned long long*>(
         take(2ull * ((B + 15) / 16) * (kMegaQMax - 1) * (kPanel * d.hidden[0] + kPanel)));
     w.sync = reinterpret_cast<unsigned*>(take(64));
+    if (ml.fl_ok)
+      w.xfl = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * 4 * kPanel * 2 * d.hidden[0]));
     w.gstamps = reinterpret_cast<unsigned long long*>(take(2ull * 4 * 2048 * 8));
   }
   w.dz = take(R * Lz);
@@ -413,11 +416,79 @@ struct StepArgs {
   // when non-null the fused schedule ends with ONE kernel doing slab reduce + loss tail + TF-Adam
   float *adam_p = nullptr, *adam_m = nullptr, *adam_v = nullptr;
   float lr = 0.f, beta1 = 0.9f, beta2 = 0.999f, epsilon = 1e-8f;
+  // the previous step of the same graph ran finalize_adam with the image scatter on this workspace and nothing
+  // touched the parameters since: the step may skip its first launch (mega_fwd_bwd runs the first layer itself)
+  bool imgs_ready = false;
 };
 
 static void rowk(Ctx& cx, const char* name) {
   cx.check();
   cx.mark(name, 0);
+}
+
+// Where every parameter that mega_fwd_bwd reads from an LDS image lives: as copy tasks (for the auxiliary
+// workgroups of the first launch) and as a parameter-index map (for finalize_adam's scatter of the updated values).
+struct ImgPlan {
+  ImgTask task[kMaxImgTasks];
+  int nt = 0;
+  ImgMap map[kMaxImgMap];
+  int nmap = 0, lo = 0, hi = 0;
+  bool map_ok = true;
+};
+static void plan_images(const GmvaeDims& d, int model, const Layout& L, const WS& w, const MegaLay& ml, const float* P,
+                        ImgPlan& pl) {
+  const bool gm = model == GMVAE_MODEL_GMVAE, gmp = model == GMVAE_MODEL_VAE_GMP;
+  const int K = d.K, Lz = d.L, D = d.D, H = d.hidden[0];
+  const NetL &E = gm ? L.ency : L.enc, &G = L.encg, &Dn = L.dec;
+  float* im = w.img_m;
+  auto add_map = [&](long long begin, long long n, int cols, int kind, int base, int ld, int which) {
+    if (pl.nmap >= kMaxImgMap || (unsigned long long)n * (unsigned long long)cols >= (1ull << 32)) { pl.map_ok = false; return; }
+    ImgMap& m = pl.map[pl.nmap++];
+    m.begin = (int)begin; m.end = (int)(begin + n); m.cols = cols; m.kind = kind; m.base = base; m.ld = ld;
+    m.cw = kCW; m.chunk = ml.chunk; m.magic = (unsigned)((1ull << 32) / (unsigned)cols) + 1u; m.which = which;
+  };
+  auto task = [&](float* dst, int ld, const float* src, int rows, int cols) {      // dense source rows
+    ImgTask& t = pl.task[pl.nt++];
+    t.dst = dst; t.ld = ld; t.src = src; t.rows = rows; t.cols = cols; t.src_ld = cols; t.trans = 0;
+    add_map(src - P, (long long)rows * cols, cols, 0, (int)(dst - im), ld, 0);
+  };
+  if (gm) {
+    task(im + ml.W_y1, ml.ldY1, P + E.w[1], H, K);
+    task(im + ml.W_g0y, ml.ldG0, P + G.w[0] + (uint64_t)D * H, K, H);
+    task(im + ml.W_p, ml.ldP, P + L.prior.w[0], K, 2 * Lz);
+    task(im + ml.W_g1, ml.ldG1, P + G.w[1], H, 2 * Lz);
+    task(im + ml.b_y1, K, P + E.b[1], 1, K);
+    task(im + ml.b_g0, H, P + G.b[0], 1, H);
+    task(im + ml.b_p, 2 * Lz, P + L.prior.b[0], 1, 2 * Lz);
+    task(im + ml.b_g1, 2 * Lz, P + G.b[1], 1, 2 * Lz);
+  } else {                       // the encoder's second layer takes the q-head slot
+    task(im + ml.W_g1, ml.ldG1, P + E.w[1], H, 2 * Lz);
+    task(im + ml.b_g1, 2 * Lz, P + E.b[1], 1, 2 * Lz);
+    if (gmp) {
+      task(im + ml.M_loc, ml.ldM, P + L.loc, K, Lz);
+      task(im + ml.M_raw, ml.ldM, P + L.rawscale, K, Lz);
+      task(im + ml.M_mix, K, P + L.mixlog, 1, K);
+    }
+  }
+  task(im + ml.b_y0, H, P + E.b[0], 1, H);
+  task(im + ml.W_d0, ml.ldD0, P + Dn.w[0], Lz, H);
+  task(im + ml.b_d0, H, P + Dn.b[0], 1, H);
+  for (int c = 0; c < ml.nch; ++c) {             // decoder chunk images: [H rows of Wd1 | bias row]
+    const int nc = (D - c * kCW) < kCW ? (D - c * kCW) : kCW;
+    ImgTask& t0 = pl.task[pl.nt++];
+    t0.dst = w.dimg + (uint64_t)c * ml.chunk; t0.ld = ml.ldc; t0.src = P + Dn.w[1] + c * kCW; t0.rows = H; t0.cols = nc;
+    t0.src_ld = D; t0.trans = 0;
+    ImgTask& t1 = pl.task[pl.nt++];
+    t1.dst = w.dimg + (uint64_t)c * ml.chunk + H * ml.ldc; t1.ld = nc; t1.src = P + Dn.b[1] + c * kCW; t1.rows = 1;
+    t1.cols = nc; t1.src_ld = nc; t1.trans = 0;
+  }
+  add_map(Dn.w[1], (long long)H * D, D, 1, 0, ml.ldc, 1);
+  add_map(Dn.b[1], D, D, 1, H * ml.ldc, ml.ldc, 1);
+  pl.lo = 1 << 30; pl.hi = 0;
+  for (int i = 0; i < pl.nmap; ++i) {
+    pl.lo = pl.map[i].begin < pl.lo ? pl.map[i].begin : pl.lo;
+    pl.hi = pl.map[i].end > pl.hi ? pl.map[i].end : pl.hi;
+  }
 }
 
 // end of the fused schedules: slab reduce + loss tail (+ TF-Adam in the graph path)
@@ -434,6 +505,17 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
     fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = 1; fa.count = (float)B;
     fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = nent;
     fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
+    fa.nmap = 0; fa.map_lo = fa.map_hi = 0; fa.img0 = fa.img1 = nullptr; fa.epoch_word = nullptr;
+    if (mega_ok(d, a.model) && a.adam_p == a.params) {      // the next step's weight images ride on the update
+      const MegaLay ml = mega_lay(d.hidden[0], d.L, d.K, d.D, a.model);
+      ImgPlan pl;
+      plan_images(d, a.model, L, w, ml, a.params, pl);
+      fa.epoch_word = w.sync;
+      if (pl.map_ok && ml.fl_ok) {
+        fa.nmap = pl.nmap; fa.map_lo = pl.lo; fa.map_hi = pl.hi; fa.img0 = w.img_m; fa.img1 = w.dimg;
+        for (int i = 0; i < pl.nmap; ++i) { fa.map[i] = pl.map[i]; fa.mbegin[i] = pl.map[i].begin; fa.mend[i] = pl.map[i].end; }
+      }
+    }
     hipLaunchKernelGGL(finalize_adam, dim3((unsigned)((PP / 4 + 255) / 256) + 1), dim3(256), 0, st, fa);
     rowk(cx, "finalize_adam");
     return cx.err;
@@ -471,7 +553,19 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
   const NetL &E = gm ? L.ency : L.enc, &G = L.encg, &Dn = L.dec;
   const MegaLay ml = mega_lay(H, Lz, K, D, model);
   const int H2 = gm ? 2 * H : H;
-  {  // P1: first layer(s) over the uint8 batch as single-round split-K partials + auxiliary workgroups
+  // The first launch (first layer as split-K partials + noise + weight images) is skipped when the previous step
+  // of the same graph left the images behind (finalize_adam) and the launch below can run the first layer itself:
+  // a panel's 4 workgroups must all be resident for their exchange, i.e. one workgroup per CU.
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  const int Qm = mega_q(B);
+  const bool fl = a.imgs_ready && ml.fl_ok && Qm == 4 && (B + kPanel - 1) / kPanel * 4 <= n_cu && a.adam_p == a.params &&
+                  a.step_dev && gen_eps && w.xfl && !getenv("GMVAE_NO_FL");
+  if (!fl) {  // P1: first layer(s) over the uint8 batch as single-round split-K partials + auxiliary workgroups
     Group g;
     Problem p0 = p_nn(a.x, true, D, P + E.w[0], H, B, H, D, w.s1, H2, nullptr, false);
     p0.splits = NSF; p0.split_stride = (long long)B * H2;
@@ -486,38 +580,10 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     ax.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
     ax.epoch_word = w.sync;
     ax.noise_blocks = (int)(((n_eps + 3) / 4 + (n_u + 3) / 4 + kThreads - 1) / kThreads);
-    int nt = 0;
-    auto task = [&](float* dst, int ld, const float* src, int rows, int cols, int src_ld) {
-      ImgTask& t = ax.task[nt++];
-      t.dst = dst; t.ld = ld; t.src = src; t.rows = rows; t.cols = cols; t.src_ld = src_ld; t.trans = 0;
-    };
-    float* im = w.img_m;
-    if (gm) {
-      task(im + ml.W_y1, ml.ldY1, P + E.w[1], H, K, K);
-      task(im + ml.W_g0y, ml.ldG0, P + G.w[0] + (uint64_t)D * H, K, H, H);
-      task(im + ml.W_p, ml.ldP, P + L.prior.w[0], K, 2 * Lz, 2 * Lz);
-      task(im + ml.W_g1, ml.ldG1, P + G.w[1], H, 2 * Lz, 2 * Lz);
-      task(im + ml.b_y1, K, P + E.b[1], 1, K, K);
-      task(im + ml.b_g0, H, P + G.b[0], 1, H, H);
-      task(im + ml.b_p, 2 * Lz, P + L.prior.b[0], 1, 2 * Lz, 2 * Lz);
-      task(im + ml.b_g1, 2 * Lz, P + G.b[1], 1, 2 * Lz, 2 * Lz);
-    } else {                       // the encoder's second layer takes the q-head slot
-      task(im + ml.W_g1, ml.ldG1, P + E.w[1], H, 2 * Lz, 2 * Lz);
-      task(im + ml.b_g1, 2 * Lz, P + E.b[1], 1, 2 * Lz, 2 * Lz);
-      if (gmp) {
-        task(im + ml.M_loc, ml.ldM, P + L.loc, K, Lz, Lz);
-        task(im + ml.M_raw, ml.ldM, P + L.rawscale, K, Lz, Lz);
-        task(im + ml.M_mix, K, P + L.mixlog, 1, K, K);
-      }
-    }
-    task(im + ml.b_y0, H, P + E.b[0], 1, H, H);
-    task(im + ml.W_d0, ml.ldD0, P + Dn.w[0], Lz, H, H);
-    task(im + ml.b_d0, H, P + Dn.b[0], 1, H, H);
-    for (int c = 0; c < ml.nch; ++c) {             // decoder chunk images: [H rows of Wd1 | bias row]
-      const int nc = (D - c * kCW) < kCW ? (D - c * kCW) : kCW;
-      task(w.dimg + (uint64_t)c * ml.chunk, ml.ldc, P + Dn.w[1] + c * kCW, H, nc, D);
-      task(w.dimg + (uint64_t)c * ml.chunk + H * ml.ldc, nc, P + Dn.b[1] + c * kCW, 1, nc, nc);
-    }
+    ImgPlan pl;
+    plan_images(d, model, L, w, ml, P, pl);
+    const int nt = pl.nt;
+    for (int i = 0; i < nt; ++i) ax.task[i] = pl.task[i];
     ax.ntasks = nt;
     ax.nblocks = ax.noise_blocks + nt;
     launch_group(cx, g, "fwd_x_first_layers_splitk+aux", env_cfg("GMVAE_P1_CFG", 0), getenv("GMVAE_STAMPS") ? w.gstamps : nullptr);
@@ -534,7 +600,10 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     c.nent = w.nent; c.logq = w.logq; c.logp = w.logp; c.logpx = w.logpx; c.logw = w.logw;
     c.gmp_part = w.gmp_part;
     c.lay = ml;
-    c.Q = mega_q(B); c.xchg = w.xchg; c.epoch_word = w.sync; c.err_word = w.sync + 1;
+    c.fl = fl ? 1 : 0;
+    c.w0a = P + E.w[0]; c.w0b = gm ? P + G.w[0] : nullptr; c.xfl = w.xfl; c.seed = a.seed;
+    c.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
+    c.Q = Qm; c.xchg = w.xchg; c.epoch_word = w.sync; c.err_word = w.sync + 1;
     c.dbg = getenv("GMVAE_STAMPS") ? w.stamps : nullptr;
     c.fine = getenv("GMVAE_STAMPS") ? atoi(getenv("GMVAE_STAMPS")) : 0;
     // the reference's default sizes (run_gmvae.py: latent 64, hidden 64, K 10; MNIST D 784) run a specialised instance
@@ -1002,12 +1071,13 @@ int gmvae_step(const GmvaeDims* dims, int model, const uint8_t* x, const float* 
 /* internal: gmvae_step with the end-of-step Adam fused in (single device; used by the train graph) */
 static int step_with_adam(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
                           float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float b1,
-                          float b2, float eps_, hipStream_t st) {
+                          float b2, float eps_, hipStream_t st, bool imgs_ready = false) {
   Ctx cx;
   cx.st = st;
   StepArgs a = {dims, model, x, nullptr, nullptr, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
                 seed, 0, step_dev, true};
   a.adam_p = params; a.adam_m = m; a.adam_v = v; a.lr = lr; a.beta1 = b1; a.beta2 = b2; a.epsilon = eps_;
+  a.imgs_ready = imgs_ready;
   return run_step(cx, a);
 }
 
@@ -1265,7 +1335,8 @@ int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x,
     for (int s = 0; s < n_steps && rc == 0; ++s) {
       const uint8_t* xs = x + s * xstride;
       if (fused_ok(*dims, model) || mega_ok(*dims, model)) {
-        rc = step_with_adam(dims, model, xs, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, cs);
+        // every step after the first finds its weight images written by the step before it (same graph, nothing in between)
+        rc = step_with_adam(dims, model, xs, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, cs, s > 0);
       } else {
         rc = gmvae_step(dims, model, xs, nullptr, nullptr, params, grads, workspace, seed, 0, step_dev, cs);
         if (rc == 0)

@@ -461,6 +461,35 @@ __global__ void adam_tf(float* __restrict__ p, float* __restrict__ m, float* __r
 //   block  nb       : loss tail sums (loss_tail) and the device step counter.
 // Counter protocol (no intra-kernel race): every block reads t-1 from step_dev[1] (copied from
 // step_dev[0] by the FIRST launch of the step, aux.hpp); only the tail block writes step_dev[0].
+// sum of NS split-K slabs at one float4 location
+// (loads go out four at a time, clamped to the last slab and predicated at the add: a runtime-count loop of
+// load-then-add serialises one cold memory round trip per slab)
+__device__ __forceinline__ float4 slab_sum4(const float* __restrict__ p, const long long sstride, const int NS) {
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s0 = 0; s0 < NS; s0 += 4) {
+    float4 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = *reinterpret_cast<const float4*>(p + (long long)min(s0 + j, NS - 1) * sstride);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float w = s0 + j < NS ? 1.f : 0.f;
+      r.x += w * o[j].x; r.y += w * o[j].y; r.z += w * o[j].z; r.w += w * o[j].w;
+    }
+  }
+  return r;
+}
+
+// One tensor (or row range of one) that also lives in an LDS-image of the next step's mega_fwd_bwd: flat parameter
+// indices [begin, end), `cols` per source row.  kind 0: img[base + r * ld + c]; kind 1 (decoder output layer, stored
+// as column chunks of `cw`): img[base + (c / cw) * chunk + r * ld + c % cw].
+struct ImgMap {
+  int begin, end, cols, kind;
+  int base, ld, cw, chunk;
+  unsigned magic;             // floor(2^32 / cols) + 1: row = (off * magic) >> 32 (checked on the host for the range)
+  int which;                  // 0: small-weight image, 1: decoder chunk images
+};
+constexpr int kMaxImgMap = 20;
+
 struct FinalArgs {
   const float* slabs; int nslab; long long P;
   float *grads, *p, *m, *v;
@@ -469,6 +498,13 @@ struct FinalArgs {
   const float *logw, *logpx, *logq, *logp, *nent;
   float* tail; int B;
   unsigned long long* step_dev;
+  // the updated parameters are also scattered into the next step's weight images (then that step needs no
+  // image-building launch); nmap = 0: off
+  int nmap, map_lo, map_hi;
+  float *img0, *img1;
+  unsigned* epoch_word;       // bumped for the next step's in-launch hand-offs
+  int mbegin[kMaxImgMap], mend[kMaxImgMap];   // the ranges again, adjacent: one round of scalar loads finds the entry
+  ImgMap map[kMaxImgMap];
 };
 __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
   const int nb = gridDim.x - 1;
@@ -492,16 +528,29 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
       a.tail[0] = red[0][0]; a.tail[1] = red[1][0]; a.tail[2] = red[2][0]; a.tail[3] = red[3][0];
       a.tail[4] = (float)a.B; a.tail[5] = 0.f; a.tail[6] = 0.f; a.tail[7] = 0.f;
       if (a.step_dev) a.step_dev[0] = a.step_dev[1] + 1;
+      if (a.epoch_word) *a.epoch_word += 1u;
     }
     return;
   }
   const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i4 >= a.P) return;
-  float4 g = *reinterpret_cast<const float4*>(a.slabs + i4);
-  for (int s = 1; s < a.nslab; ++s) {
-    const float4 o = *reinterpret_cast<const float4*>(a.slabs + (long long)s * a.P + i4);
-    g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w;
+  // Image scatter, part 1 (before the slab loads, so that its scalar loads ride under them).  A block covers 1024
+  // consecutive parameters: nearly always inside ONE map entry, so the entries are found with block-uniform tests
+  // and their fields stay scalar (a per-lane entry index would turn every field read into a waterfall).
+  const int blo = (int)blockIdx.x * 1024, bhi = blo + 1024;
+  unsigned hit = 0;                                           // entries this block overlaps
+  if (a.nmap > 0 && bhi > a.map_lo && blo < a.map_hi) {
+#pragma unroll
+    for (int k = 0; k < kMaxImgMap; ++k)
+      if (k < a.nmap && bhi > a.mbegin[k] && blo < a.mend[k]) hit |= 1u << k;
   }
+  const int k0 = hit ? __builtin_ctz(hit) : 0;
+  int e_begin = a.map[k0].begin, e_end = a.map[k0].end, e_cols = a.map[k0].cols, e_kind = a.map[k0].kind,
+      e_base = a.map[k0].base, e_ld = a.map[k0].ld, e_chunk = a.map[k0].chunk, e_which = a.map[k0].which;
+  unsigned e_magic = a.map[k0].magic;
+  asm volatile("" ::"s"(hit), "s"(e_begin), "s"(e_end), "s"(e_cols), "s"(e_kind), "s"(e_base), "s"(e_ld), "s"(e_chunk),
+               "s"(e_which), "s"(e_magic));
+  if (i4 >= a.P) return;
+  const float4 g = slab_sum4(a.slabs + i4, a.P, a.nslab);
   *reinterpret_cast<float4*>(a.grads + i4) = g;
   if (!a.do_adam) return;
   const unsigned long long t = (a.step_dev ? a.step_dev[1] : 0ull) + 1ull;
@@ -521,7 +570,34 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
   *reinterpret_cast<float4*>(a.p + i4) = make_float4(pa[0], pa[1], pa[2], pa[3]);
   *reinterpret_cast<float4*>(a.m + i4) = make_float4(ma[0], ma[1], ma[2], ma[3]);
   *reinterpret_cast<float4*>(a.v + i4) = make_float4(va[0], va[1], va[2], va[3]);
+  // Image scatter, part 2: the updated values go to their image positions.
+  while (hit) {
+    hit &= hit - 1;
+    if (i4 >= e_begin && i4 < e_end) {
+      float* const img = e_which ? a.img1 : a.img0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = (int)i4 + j;
+        if (idx < e_end) {
+          const unsigned off = (unsigned)(idx - e_begin);
+          const int r = (int)(((unsigned long long)off * e_magic) >> 32);
+          const int c = (int)off - r * e_cols;
+          const int dst = e_kind ? e_base + (c >> 7) * e_chunk + r * e_ld + (c & 127) : e_base + r * e_ld + c;   // kCW = 128
+          img[dst] = pa[j];
+        }
+      }
+    }
+    if (hit) {                                                // a block on a tensor boundary: next entry
+      const int k = __builtin_ctz(hit);
+      e_begin = a.map[k].begin; e_end = a.map[k].end; e_cols = a.map[k].cols; e_kind = a.map[k].kind;
+      e_base = a.map[k].base; e_ld = a.map[k].ld; e_chunk = a.map[k].chunk; e_which = a.map[k].which;
+      e_magic = a.map[k].magic;
+    }
+  }
 }
+
+// auxiliary work without a GEMM: the image tasks of the first step of a train graph
+__global__ __launch_bounds__(kThreads) void aux_only(const Aux ax) { aux_block(ax, (int)blockIdx.x); }
 
 // ------------------------------------------------------------ cluster_acc
 // utils.cluster_acc / mode_tensor (scripts/utils.py:156-191): argmax cluster,

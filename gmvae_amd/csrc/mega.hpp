@@ -17,7 +17,7 @@
 
 namespace gmvae {
 
-constexpr int kCW = 128;       // decoder columns per streamed chunk
+constexpr int kCW = 128;       // decoder columns per streamed chunk (finalize_adam's image scatter shifts by 7)
 constexpr int kMW = 8;         // wavefronts per workgroup (2 per SIMD: the partner hides LDS/DMA/VALU latency)
 constexpr int kMT = kMW * 64;
 
@@ -26,6 +26,7 @@ struct MegaLay {
   int ldY1, ldG0, ldP, ldG1, ldD0, ldc;
   int W_y1, W_g0y, W_p, W_g1, W_d0, b_y0, b_y1, b_g0, b_p, b_g1, b_d0, img;   // small-weight image [0, img)
   int img_early;                     // [0, img_early): what the first stages need; the rest lands while they run
+  int fl_kq, fl_ld, fl_W, fl_A, fl_ok;   // in-launch first layer: k rows per quarter, staging [kq][fl_ld] + x image [kq][17]
   int chunk, nch;                    // floats per decoder chunk image ([H+1][ldc], row H = bias slice), chunks
   int ring, xring;                   // LDS: ring of 2 chunk images (aliases the small-weight image), 2 x-chunks
   int A_hy, A_y, A_hg, A_z, A_hd, A_g;          // forward / decoder operand images ([k][17])
@@ -77,6 +78,19 @@ __host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D, int mode
   m.red = take(kMW * 256);
   if (model == 1) { m.M_inv = take(K * m.ldM); m.M_c = take(m.KP); m.M_w = take(m.KP); m.P_r = take(kPanel * m.KP); }
   m.total = o;
+  // first layer inside the launch: each of the 4 workgroups of a panel takes a quarter of the D input columns.
+  // Its weight rows are staged as they lie in memory ([kq][H] per tensor: linear 1 KB DMA bursts; the 2-way bank
+  // conflict of the MFMA operand reads costs far less than padded per-row DMAs did).  The staging overlays
+  // everything below the row-sum / reduction scratch (nothing else is live yet).
+  {
+    const int nw = model == 2 ? 2 : 1;
+    m.fl_kq = (((D + 3) / 4) + 3) & ~3;
+    m.fl_ld = H;
+    m.fl_W = 0;
+    m.fl_A = GMVAE_P256(nw * m.fl_kq * H);
+    m.fl_ok = (m.fl_A + m.fl_kq * kLDA <= m.nll) && model != 1 && D % 16 == 0 && nw * H <= 128 && H % 16 == 0 && L % 4 == 0 &&
+              H == 64 && (m.fl_kq * H) % 256 == 0 && kPanel * m.fl_kq / 4 <= 2 * kMT && 4 * L + (model == 2 ? 4 * K : 0) <= kMT;
+  }
   return m;
 }
 
@@ -178,6 +192,22 @@ __device__ __forceinline__ void dma_copy_m(float* __restrict__ lds_dst, const fl
   }
 }
 
+// First-layer weight staging: [rows][64-float row pieces] copied in 1 KB bursts (4 rows of 64 floats), burst order
+// rotated by `rot` (the workgroups of an XCD would otherwise walk the same L2 lines in lockstep), and the two
+// 16-column halves of every 32 columns swapped in odd rows: the MFMA operand read of a half-wave (k rows lk = 0,1
+// or 2,3, 16 columns each) then covers 32 distinct banks although the row stride is a multiple of 32 floats.
+__device__ __forceinline__ void dma_stage_w(float* __restrict__ lds_dst, const float* __restrict__ g, const int nfloats,
+                                            const int rot, const int wave, const int lane) {
+  const int nb = nfloats >> 8;                     // bursts (nfloats is a multiple of 256 here)
+  const int row = lane >> 4, piece = lane & 15;    // H = 64: 16 pieces of 16 bytes per row, 4 rows per burst
+  const int src = row * 64 + ((piece ^ ((row & 1) << 2)) << 2);
+  for (int b = wave; b < nb; b += kMW) {
+    int bb = b + rot;
+    bb = bb >= nb ? bb - nb : bb;
+    __builtin_amdgcn_global_load_lds(g + (bb << 8) + src, lds_dst + (bb << 8), 16, 0, 0);
+  }
+}
+
 struct MegaArgs {
   int model;                  // 0 VAE, 1 VAE_GMP, 2 GMVAE
   int B, H, L, K, D, NS;
@@ -201,6 +231,15 @@ struct MegaArgs {
   unsigned long long* dbg;
   int fine;                   // diagnostic: slots 8.. of a block's stamp record take intra-stage stamps instead
   MegaLay lay;                // mega_lay(H, L, K, D, model), computed once on the host
+  // fl = 1: the launch also runs the first layer (no separate split-K GEMM launch, no noise / image launch):
+  // the panel's 4 workgroups each reduce a quarter of the D input columns and exchange their [16][H2] partials
+  // through tagged granules (all four then hold identical sums), draw their own Philox noise, and read weight
+  // images the previous step's finalize_adam wrote.
+  int fl;
+  const float *w0a, *w0b;     // first-layer weights [D][H]: encoder(_y) and, GMVAE, encoder_gmm's x rows
+  unsigned long long* xfl;    // [panels][4][16 * H2] granules
+  unsigned long long seed;
+  unsigned long long* step_dev;
 };
 
 // HT, LT, KT, DT, MODEL: compile-time sizes of a specialised instance (0 / -1 = read them from the arguments).
@@ -228,8 +267,10 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   const float* const sp = a.s1 + (long long)min(r0 + frow, B - 1) * H2f + fcol;
   const long long sstride = (long long)B * H2f;
   float4 so[4];                                   // raw: summed after the DMA issue
+  if (!a.fl) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) so[j] = *reinterpret_cast<const float4*>(sp + (long long)min(j, a.NS - 1) * sstride);
+    for (int j = 0; j < 4; ++j) so[j] = *reinterpret_cast<const float4*>(sp + (long long)min(j, a.NS - 1) * sstride);
+  }
   __builtin_amdgcn_sched_barrier(0);
   const MegaLay f = HT ? mega_lay(H, L, K, D, model) : a.lay;
   const int KP = f.KP, K2 = f.K2, L2 = f.L2, LP = f.LP;
@@ -256,15 +297,135 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   const int nrow = min(kPanel, B - r0);
   const int ln = lane & 15, lk = lane >> 4;
   GMVAE_STAMP(0);
-#define GMVAE_FS(i) if (a.dbg && a.fine >= 2 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime()
+#define GMVAE_FL(i) if (a.dbg && a.fine == 4 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime()
+#define GMVAE_FS(i) if (a.dbg && a.fine >= 2 && a.fine != 4 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime()
   // ======================================================================= F: forward chain
   for (int rep_ = 0; rep_ < (a.fine == 3 ? 2 : 1); ++rep_) {     // diagnostic: a second, instruction-cache-warm pass
   if (rep_) { __syncthreads(); GMVAE_STAMP(0); }
+  float4 v;
+  if (a.fl) {
+    // ---------------------------------------------------------------- FL: first layer over this quarter's columns
+    const int KQ = f.fl_kq, kq4 = KQ / 4;
+    float* const Wst = sm + f.fl_W;
+    float* const A_x = sm + f.fl_A;
+    const int k0 = q * KQ;
+    const int kn = max(0, min(KQ, D - k0));        // rows of this quarter that exist (the last quarter may be short)
+    const int rot = ((pnl >> 3) * 6) % max(1, (kn * H) >> 8);
+    dma_stage_w(Wst, a.w0a + (long long)k0 * H, kn * H, rot, wave, lane);
+    if (gm) dma_stage_w(Wst + KQ * H, a.w0b + (long long)k0 * H, kn * H, rot, wave, lane);
+    GMVAE_FL(0);
+    unsigned xw[2];                                // this thread's x bytes: (row, 4 consecutive columns), <= 2 items
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = tid + it * kMT;
+      const int row = i / kq4, k4 = (i - row * kq4) * 4;
+      xw[it] = 0;
+      if (i < kPanel * kq4 && row < nrow && k4 < kn)
+        xw[it] = *reinterpret_cast<const unsigned*>(a.x + (long long)(r0 + row) * D + k0 + k4);
+    }
+    const unsigned epoch_fl = *a.epoch_word;
+    GMVAE_FL(1);
+    // this panel's rows of the Philox streams (the values gmvae_noise_fill produces for the same seed and step),
+    // drawn while the loads above are in flight and parked in registers until the staging area is dead
+    const unsigned long long step = a.step_dev[0];
+    const int qe = kPanel * L / 4, qu = gm ? kPanel * K / 4 : 0;
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < qe + qu) {
+      const bool is_u = tid >= qe;
+      const int li = is_u ? tid - qe : tid;
+      noise_vals((unsigned long long)(is_u ? (long long)r0 * K / 4 : (long long)r0 * L / 4) + li, is_u, a.seed, step, nz);
+    }
+    GMVAE_FL(2);
+    if (kn < KQ) {                                 // zero the staging rows past D (their x columns are zero: no NaN * 0)
+      for (int i = kn * H + tid; i < KQ * H; i += kMT) { Wst[i] = 0.f; if (gm) Wst[KQ * H + i] = 0.f; }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = tid + it * kMT;
+      if (i < kPanel * kq4) {
+        const int row = i / kq4, k4 = (i - row * kq4) * 4;
+        const unsigned w = xw[it];
+        A_x[(k4 + 0) * kLDA + row] = (float)(w & 0xff);
+        A_x[(k4 + 1) * kLDA + row] = (float)((w >> 8) & 0xff);
+        A_x[(k4 + 2) * kLDA + row] = (float)((w >> 16) & 0xff);
+        A_x[(k4 + 3) * kLDA + row] = (float)(w >> 24);
+      }
+    }
+    GMVAE_FS(0);
+    GMVAE_FL(3);
+    dma_wait();
+    __syncthreads();
+    GMVAE_FL(4);
+    const int ntile = H2f / 16, tpw = H / 16;      // tiles; tiles per weight tensor
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (wave < ntile) {
+      const int tl = wave < tpw ? wave : wave - tpw;
+      const int swz = ((tl * 16 + ln) ^ ((lk & 1) << 4)) - (tl * 16 + ln);      // this lane's k rows are all odd or all even
+      acc = tile_ksteps(A_x, (wave < tpw ? Wst : Wst + KQ * H) + swz, H, 1, tl, 0, kq4, kq4, lane, acc);
+    }
+    GMVAE_FL(5);
+    const int ngr = kPanel * H2f;
+    if (wave < ntile) {
+      unsigned long long* xo = a.xfl + ((long long)pnl * 4 + q) * ngr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        __hip_atomic_store(xo + (lk * 4 + r) * H2f + wave * 16 + ln, ((unsigned long long)epoch_fl << 32) | __float_as_uint(acc[r]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                               // the staging area is dead: the weight image may land on it
+    GMVAE_FS(1);
+    GMVAE_FL(6);
+    dma_copy_m(sm, a.img, f.img_early, wave, lane);
+    if (tid < qe + qu) {
+      const bool is_u = tid >= qe;
+      *reinterpret_cast<float4*>((is_u ? P_u : P_eps) + (is_u ? tid - qe : tid) * 4) = make_float4(nz[0], nz[1], nz[2], nz[3]);
+    }
+    if (bid == gridDim.x - 1 && tid == 0) a.step_dev[1] = step;       // the copy finalize_adam reads
+    // the other quarters' partials: all 12 granules of a lane are requested together and re-read until every tag
+    // carries this step's epoch; summed in quarter order (every workgroup of the panel gets the same bits)
+    if (wave < ntile) {
+      const unsigned long long* xp = a.xfl + (long long)pnl * 4 * ngr;
+      unsigned long long gv[4][4];
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            gv[pq][r] = __hip_atomic_load(xp + (long long)pq * ngr + (lk * 4 + r) * H2f + wave * 16 + ln, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (unsigned)(gv[pq][r] >> 32) == epoch_fl;
+          }
+        }
+        if (__all(ok)) break;
+        if (++spins > (1u << 22)) {
+          if (lane == 0) atomicExch(a.err_word, 1u);
+#pragma unroll
+          for (int pq = 0; pq < 4; ++pq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gv[pq][r] = 0x7fc00000ull;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) t += __uint_as_float((unsigned)gv[pq][r]);
+        red[(lk * 4 + r) * H2f + wave * 16 + ln] = t;
+      }
+    }
+    GMVAE_FL(7);
+    dma_wait();
+    __syncthreads();
+    dma_copy_m(sm + f.img_early, a.img + f.img_early, f.img - f.img_early, wave, lane);   // q head / decoder hidden weights
+    v = *reinterpret_cast<const float4*>(red + frow * H2f + fcol);
+  } else {
   dma_copy_m(sm, a.img, f.img_early, wave, lane);
   dma_copy_m(P_eps, a.eps + (long long)r0 * L, nrow * L, wave, lane);
   if (gm) dma_copy_m(P_u, a.u + (long long)r0 * K, (nrow * K) & ~3, wave, lane);
-  {
-    const int row = frow, col = fcol;
     if (gm)
       for (int e = ((nrow * K) & ~3) + tid; e < nrow * K; e += kMT) P_u[e] = a.u[(long long)r0 * K + e];
     GMVAE_FS(0);
@@ -272,7 +433,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     __syncthreads();
     GMVAE_FS(1);
     dma_copy_m(sm + f.img_early, a.img + f.img_early, f.img - f.img_early, wave, lane);   // q head / decoder hidden weights
-    float4 v = so[0];
+    v = so[0];
 #pragma unroll
     for (int j = 1; j < 4; ++j) {
       const float w = j < a.NS ? 1.f : 0.f;
@@ -282,6 +443,9 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       const float4 t = slab_sum4(sp + 4 * sstride, sstride, a.NS - 4);
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
+  }
+  {
+    const int row = frow, col = fcol;
     if (tid < nitem) {
       float vv[4] = {v.x, v.y, v.z, v.w};
       if (col < H) {

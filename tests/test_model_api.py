@@ -128,10 +128,15 @@ def test_graph_replay_matches_eager_steps():
     assert torch.allclose(outs[0][0], outs[1][0], atol=1e-6)
 
 
-def test_multi_step_graph_matches_eager_steps_on_the_same_batches():
-    """n_steps batches in ONE graph launch == the same batches stepped one by one (bit-identical: same kernels,
-    same Philox (seed, step) stream, same order)."""
+@pytest.mark.parametrize("in_launch_first_layer", [False, True])
+def test_multi_step_graph_matches_eager_steps_on_the_same_batches(in_launch_first_layer, monkeypatch):
+    """n_steps batches in ONE graph launch == the same batches stepped one by one: same Philox (seed, step) stream,
+    same order.  With the separate first-layer launch in every step (GMVAE_NO_FL) the kernels are the same and the
+    result is bit-identical; by default steps 2..n run the first layer inside mega_fwd_bwd, on weight images the
+    previous finalize_adam scattered and with noise drawn in the kernel -- same values, another summation order."""
     from gmvae_amd.engine import Engine
+    if not in_launch_first_layer:
+        monkeypatch.setenv("GMVAE_NO_FL", "1")
     n, B = 4, 1024
     rng = np.random.default_rng(3)
     xs = torch.from_numpy((rng.random((n, B, 784)) < 0.87).astype(np.uint8)).cuda()
@@ -151,8 +156,14 @@ def test_multi_step_graph_matches_eager_steps_on_the_same_batches():
         torch.cuda.synchronize()
         outs.append((e.params.detach().clone(), e.global_step, e.grads[e.P:].clone()))
     assert outs[0][1] == outs[1][1] == 2 * n
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert torch.equal(outs[0][2], outs[1][2])
+    if not in_launch_first_layer:
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert torch.equal(outs[0][2], outs[1][2])
+    else:
+        assert torch.isfinite(outs[1][0]).all()
+        # 8 Adam steps of lr 1e-3 move a weight by <= 8e-3; the two paths may differ by rounding in the gradients only
+        assert (outs[0][0] - outs[1][0]).abs().max().item() < 2e-5
+        assert abs(outs[0][2][0].item() - outs[1][2][0].item()) < 1e-4 * abs(outs[0][2][0].item())
 
 
 def test_missing_engine_and_bad_activation_fail_loudly():

@@ -10,9 +10,10 @@ Q = int(os.environ.get("GMVAE_MEGA_Q", "4"))
 nP = B // 16
 e = Engine("gmvae", 784, 64, 10, [64], random_seed=0)
 x = torch.from_numpy((np.random.default_rng(0).random((B, 784)) < 0.87).astype(np.uint8)).cuda()
-sx, replay = e.capture_train_step(B, 1e-3)          # the hipGraph the bench replays
-sx.copy_(x)
-for _ in range(3000): replay()                      # long enough for the clocks to ramp
+G = int(os.environ.get("GRAPH_STEPS", "16"))
+sx, replay = e.capture_train_step(B, 1e-3, n_steps=G)          # the hipGraph the bench replays
+sx.copy_(x if G == 1 else x.unsqueeze(0).expand(G, -1, -1))
+for _ in range(3000 // G): replay()                      # long enough for the clocks to ramp
 torch.cuda.synchronize()
 d, ws = e._workspace(B)
 off = C.c_uint64(); L.check(L.lib.gmvae_workspace_offset(C.byref(d), e.model, b"stamps", C.byref(off)), "off")
@@ -23,10 +24,19 @@ print("stages: F0 | logits+gumbel | heads | z+hd | decoder | B0(+hand-off) | bwd
 st = cons[:, :8].astype(np.float64)
 print("consumers: start (rel. to first block)", int(np.median(st[:, 0] - t0)), "per-stage", np.round(np.median(np.diff(st, axis=1), axis=0)).astype(int),
       "total", int(np.median(st[:, 7] - st[:, 0])), "end (rel.)", int(np.max(st[:, 7] - t0)))
+if os.environ["GMVAE_STAMPS"] == "4":
+    c = cons.astype(np.float64)
+    names = ["W dma issued", "x loads issued", "noise drawn", "x image stored", "dma landed + sync", "MFMA", "publish + sync", "image dma + poll done", "F0 end"]
+    ts = [8, 9, 10, 11, 12, 13, 14, 15, 1]
+    prev = 0
+    for nm, t in zip(names, ts):
+        print(f"  {nm:24s} +{int(np.median(c[:, t] - c[:, prev])):6d}")
+        prev = t
+    sys.exit(0)
 if os.environ["GMVAE_STAMPS"] in ("2", "3"):
     c = cons.astype(np.float64)
     med = lambda a, b: int(np.median(c[:, a] - c[:, b]))
-    print("fine (consumers): F0: issue", med(8, 0), "| loads+dma return", med(9, 8), "| bias/relu/LDS", med(1, 9))
+    print("fine (consumers): F0/FL: issue (FL: +stage loads)", med(8, 0), "| loads+dma return (FL: wait+MFMA+publish)", med(9, 8), "| bias/relu/LDS (FL: noise+exchange+F0)", med(1, 9))
     print("   logits ksplit", med(10, 1), "| gumbel-softmax", med(2, 10), "| hg1+prior heads", med(11, 2), "| q head", med(3, 11),
           "| z/logq/logp", med(12, 3), "| hd", med(4, 12))
     print("   B: dz gemm", med(13, 6), "| dqp elementwise", med(14, 13), "| dhg gemm", med(15, 14), "| dy+softmax bwd+dhy", med(7, 15))
