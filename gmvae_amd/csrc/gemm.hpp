@@ -63,6 +63,7 @@ struct Problem {
   float addconst;
   long long split_stride;  // floats between split-K slabs
   float* C;
+  int xbf16;               // dW of a uint8 activation (A = x^T, k-major rows of bytes; B = dY fp32 rows): bf16 MFMA path
   float* colsum_out;       // bias gradient riding on a dW problem: column sums of operand b over the tile's k
                            // range, written by the tiles of the first tile row to colsum_out[split][n]
   const float* bias;
@@ -100,7 +101,7 @@ struct Cfg {
   static constexpr int NSA = BM * BK / 4 / kThreads, NSB = BN * BK / 4 / kThreads;
   static constexpr int OPS = NBUF * (LDA + LDB) * BK;               // floats, NBUF staging buffers
   static constexpr int CST = WK * BM * LDC;                          // floats, C staging
-  static constexpr int LDS_FLOATS = OPS > CST + kThreads ? OPS : CST + kThreads;   // + column-sum partials
+  static constexpr int LDS_FLOATS = OPS > CST + 4 * kThreads ? OPS : CST + 4 * kThreads;   // + column-sum partials
   // waves per SIMD the register allocator must leave room for: the small configuration's launches carry more
   // workgroups than 2 per CU (tiles + auxiliary blocks), and a workgroup that starts late ends the launch late
   static constexpr int WAVES_EU = (BM * BN <= 32 * 32) ? 3 : 1;
@@ -260,6 +261,26 @@ __device__ __forceinline__ int op_kind(const unsigned char is_u8, const unsigned
   return (is_u8 ? 1 : 0) | (k_contig ? 0 : 2) | (vec_ok ? 0 : 4);
 }
 
+// ---- uint8 x fp32 products on the bf16 matrix cores --------------------------------------------------------------
+// dW = X^T dY with X uint8 (exact in bf16: 8 significant bits) and dY fp32 written as hi + mid + lo, three bf16
+// pieces that reproduce its 24-bit significand exactly (truncation splits; the residuals are exact in fp32).  Every
+// product is then exact and the fp32 accumulation is the only rounding, as on the fp32 MFMA path -- at 3 MFMAs of
+// K = 16 per 16 k instead of 8 of K = 2 (v_mfma_f32_32x32x16_bf16 runs 16x the fp32 rate).  Both operands are
+// k-major in memory (rows = batch index), so their LDS images stay [k][column] (coalesced 8-byte writes) and the
+// fragments come through ds_read_b64_tr_b16, gfx950's transposing LDS read.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+constexpr int kXLD = 96;     // 16-bit elements per image row: 192 B = 48 banks, so the 4 rows of a transposed read tile the 64 banks
+
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned short* p) {     // rows +0..3 and +4..7 of this lane's 8 k
+  typedef __attribute__((address_space(3))) s16x4_t* lp;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p + 4 * kXLD));
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
 template <class C>
 __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Launch L) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
@@ -338,8 +359,84 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
   float csum = 0.f;
   constexpr int CSG = kThreads / C::BN;          // k groups of the column-sum threads
   const int cs_n = tid % C::BN, cs_k = tid / C::BN;
+  bool did_bf16 = false;
+  float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (C::BM == 64 && C::BN == 64 && C::BK == 64) {
+    if (L.p[pi].xbf16) {
+      did_bf16 = true;
+      unsigned short* const Xs = reinterpret_cast<unsigned short*>(lds);          // [64 k][kXLD]
+      unsigned short* const Ds = Xs + 64 * kXLD;                                  // [3][64 k][kXLD]: hi, mid, lo
+      const unsigned char* const xa = static_cast<const unsigned char*>(a_ptr);
+      const float* const db = static_cast<const float*>(b_ptr);
+      int kper = (K + splits - 1) / splits;
+      kper = (kper + 63) / 64 * 64;
+      const int kb = split * kper < K ? split * kper : K;
+      const int ke = kb + kper < K ? kb + kper : K;
+      const int NC = (ke - kb + 63) / 64;
+      const int kr = tid >> 4, c4 = (tid & 15) << 2;          // this thread's (k row, 4 columns); 4 slots 16 rows apart
+      const bool m_ok = m0 + c4 < a_n, n_ok = n0 + c4 < b_n;  // extents are multiples of 4 (vec_ok)
+      unsigned xr[4];
+      float4 dr[4];
+      auto gload = [&](const int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = kb + c * 64 + kr + 16 * i;
+          const bool kv = k < ke;
+          const int kc = kv ? k : K - 1;
+          xr[i] = (kv && m_ok) ? *reinterpret_cast<const unsigned*>(xa + (long long)kc * a_ld + m0 + c4) : 0u;
+          dr[i] = (kv && n_ok) ? *reinterpret_cast<const float4*>(db + (long long)kc * b_ld + n0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      };
+      auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = kr + 16 * i;
+          const unsigned w = xr[i];
+          const unsigned b0 = __float_as_uint((float)(w & 0xff)) >> 16, b1 = __float_as_uint((float)((w >> 8) & 0xff)) >> 16,
+                         b2 = __float_as_uint((float)((w >> 16) & 0xff)) >> 16, b3 = __float_as_uint((float)(w >> 24)) >> 16;
+          *reinterpret_cast<uint2*>(Xs + row * kXLD + c4) = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+          const float v[4] = {dr[i].x, dr[i].y, dr[i].z, dr[i].w};
+          unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned hb = __float_as_uint(v[j]) & 0xffff0000u;
+            const float r1 = v[j] - __uint_as_float(hb);
+            const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(mb);
+            hi[j] = hb >> 16; mi[j] = mb >> 16; lo[j] = __float_as_uint(r2) >> 16;
+          }
+          *reinterpret_cast<uint2*>(Ds + (0 * 64 + row) * kXLD + c4) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+          *reinterpret_cast<uint2*>(Ds + (1 * 64 + row) * kXLD + c4) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+          *reinterpret_cast<uint2*>(Ds + (2 * 64 + row) * kXLD + c4) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+          cs4.x += v[0]; cs4.y += v[1]; cs4.z += v[2]; cs4.w += v[3];
+        }
+      };
+      // transposed-read addressing (cdna_hip_programming.md T10): lane 4q+p of a 16-lane group names row q, columns 4p..
+      const int g16 = lane >> 4, i16 = lane & 15;
+      const int fro = (8 * (g16 >> 1) + (i16 >> 2)) * kXLD + 16 * (g16 & 1) + 4 * (i16 & 3);
+      if (NC > 0) gload(0);
+      __syncthreads();
 #pragma unroll 1
-  for (int sgi = 0; sgi < nseg; ++sgi) {
+      for (int c = 0; c < NC; ++c) {
+        lstore();
+        __syncthreads();
+        if (c + 1 < NC) gload(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8_t af = tr_frag(Xs + ks * 16 * kXLD + wm0 + fro);
+          const bf16x8_t b2 = tr_frag(Ds + (2 * 64 + ks * 16) * kXLD + wn0 + fro);
+          const bf16x8_t b1 = tr_frag(Ds + (1 * 64 + ks * 16) * kXLD + wn0 + fro);
+          const bf16x8_t b0 = tr_frag(Ds + (0 * 64 + ks * 16) * kXLD + wn0 + fro);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2, acc[0][0], 0, 0, 0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[0][0], 0, 0, 0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[0][0], 0, 0, 0);
+        }
+        __syncthreads();
+      }
+    }
+  }
+#pragma unroll 1
+  for (int sgi = 0; sgi < (did_bf16 ? 0 : nseg); ++sgi) {
     if (sgi > 0) { GMVAE_SEG_FIELDS(sgi); }
 
     int kper = (K + splits - 1) / splits;
@@ -457,13 +554,21 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
           const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
           Cs[row * C::LDC + wn0 + j * 32 + l31] = acc[i][j][r];
         }
-    if (do_colsum) lds[C::CST + tid] = csum;
+    if (do_colsum) {
+      if (did_bf16) *reinterpret_cast<float4*>(lds + C::CST + 4 * tid) = cs4;     // (k rows tid>>4 + 16i, columns 4(tid&15)..)
+      else lds[C::CST + tid] = csum;
+    }
   }
   __syncthreads();
   if (do_colsum && tid < C::BN && n0 + tid < L.p[pi].N) {
     float v = 0.f;
+    if (did_bf16) {
 #pragma unroll
-    for (int g = 0; g < CSG; ++g) v += lds[C::CST + g * C::BN + tid];
+      for (int g = 0; g < 16; ++g) v += lds[C::CST + 4 * ((tid >> 2) + 16 * g) + (tid & 3)];
+    } else {
+#pragma unroll
+      for (int g = 0; g < CSG; ++g) v += lds[C::CST + g * C::BN + tid];
+    }
     colsum_out[(long long)split * L.p[pi].split_stride + n0 + tid] = v;
   }
 

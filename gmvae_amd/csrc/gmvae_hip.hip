@@ -308,6 +308,9 @@ static Problem p_tn(const void* Act, bool u8, int lda, int a_div, const float* d
   p.seg[0].kscale = kscale;
   p.C = dW; p.ldc = n_out; p.colsum_out = db;
   p.splits = ns; p.split_stride = slab_stride;
+  // uint8 activations with plain 4-aligned extents take the bf16 matrix-core path of the medium tile configuration
+  p.xbf16 = (u8 && a_div == 1 && !kscale && p.seg[0].a.vec_ok && p.seg[0].b.vec_ok && n_in % 4 == 0 && n_out % 4 == 0 &&
+             !getenv("GMVAE_NO_XBF16")) ? 1 : 0;
   return p;
 }
 
