@@ -193,7 +193,12 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel: hipEvents around every launch of the step
-        levels = eng.profile_levels(x, iters=30)
+        # (the steady-state training step of the train graph when a single device runs it; the eager forward+backward
+        #  step otherwise: the data-parallel step has an RCCL launch between its halves)
+        try:
+            levels = eng.profile_train_levels(x, lr=1e-3, iters=30) if world == 1 else eng.profile_levels(x, iters=30)
+        except Exception:
+            levels = eng.profile_levels(x, iters=30)
         gemms = [l for l in levels if l[2] > 0]          # launches that do MFMA work (grouped GEMMs, mega kernel)
         dom = max(gemms, key=lambda l: l[1])
         step_flops = O.flops_per_step(model_id, d, B)
@@ -203,7 +208,8 @@ def main():
                 "traffic": None, "usec_per_launch": dom[1], "flops_per_launch": dom[2],
                 "step_flops_alg": step_flops, "step_tflops_alg": step_flops / (dt / a.steps) * 1e-12,
                 "step_frac_of_mfma_peak": step_flops / (dt / a.steps) * 1e-12 / PEAK_F32_MFMA_TFLOPS,
-                "launches_per_step": len(levels) + 1, "sum_kernel_usec": sum_us}
+                "launches_per_step": len(levels), "sum_kernel_usec": sum_us,
+                "levels": [[nm, round(us, 2)] for nm, us, _ in levels]}
         # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE;
         # rocprofv3 --pmc cannot run inside this process): profiles/round1_traffic.json, same workload only
         try:

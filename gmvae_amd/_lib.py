@@ -68,6 +68,7 @@ def _load():
         "gmvae_dp_graph_create": ([dp, i32, vp, i32, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, vp, C.POINTER(vp)], i32),
         "gmvae_workspace_offset": ([dp, i32, C.c_char_p, C.POINTER(u64)], i32),
         "gmvae_kernel_occupancy": ([i32, C.POINTER(i32)], i32),
+        "gmvae_train_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),
         "gmvae_step_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),
     }
     for name, (args, res) in sigs.items():

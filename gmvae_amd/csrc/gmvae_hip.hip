@@ -623,6 +623,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     cx.check();
     // algorithmic MFMA FLOPs of the launch: forward chain + decoder layer (lambda and its data gradient) + backward chain
     double macs = (double)H * 2 * Lz + (double)Lz * H + 2.0 * H * D + (double)H * Lz + 2.0 * Lz * H;
+    if (fl) macs += (double)D * H2;                    // the first layer rides in the launch
     if (gm) macs += (double)H * K + (double)K * H + (double)K * 2 * Lz + (double)(H + 2 * Lz) * K + (double)K * H;
     cx.mark("mega_fwd_bwd", 2.0 * B * macs);
   }
@@ -1234,6 +1235,49 @@ int gmvae_step_profile(const GmvaeDims* dims, int model, const uint8_t* x, const
     rc = run_step(cx, a);
     hipStreamSynchronize(st);
     for (int i = 0; i < pr->n; ++i) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, pr->ev[i], pr->ev[i + 1]);
+      acc[i] += ms * 1000.0;
+    }
+  }
+  const int n = pr->n < max_levels ? pr->n : max_levels;
+  *n_levels = n;
+  for (int i = 0; i < n; ++i) {
+    memcpy(names + (size_t)i * 48, pr->name[i], 48);
+    usec[i] = (float)(acc[i] / iters);
+    flops[i] = pr->flops[i];
+  }
+  for (int i = 0; i <= MAX_LEVELS; ++i) hipEventDestroy(pr->ev[i]);
+  delete pr;
+  return rc;
+}
+
+int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
+                        float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, int iters,
+                        int max_levels, int* n_levels, char* names, float* usec, double* flops, void* stream) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!x || !params || !m || !v || !grads || !workspace || !step_dev || !n_levels || !names || !usec || !flops)
+    return GMVAE_E_NULL;
+  if (iters < 1) return GMVAE_E_DIMS;
+  if (!(fused_ok(*dims, model) || mega_ok(*dims, model))) return GMVAE_E_DIMS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Prof* pr = new Prof();
+  for (int i = 0; i <= MAX_LEVELS; ++i) hipEventCreate(&pr->ev[i]);
+  double acc[MAX_LEVELS] = {0};
+  int rc = 0;
+  for (int it = 0; it <= iters && rc == 0; ++it) {      // it = 0: untimed, leaves the weight images behind
+    Ctx cx;
+    cx.st = st;
+    cx.prof = pr;
+    pr->n = 0;
+    pr->active = it > 0;
+    if (it > 0) hipEventRecord(pr->ev[0], st);
+    StepArgs a = {dims, model, x, nullptr, nullptr, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
+                  seed, 0, step_dev, true};
+    a.adam_p = params; a.adam_m = m; a.adam_v = v; a.lr = lr; a.imgs_ready = it > 0;
+    rc = run_step(cx, a);
+    hipStreamSynchronize(st);
+    for (int i = 0; it > 0 && i < pr->n; ++i) {
       float ms = 0.f;
       hipEventElapsedTime(&ms, pr->ev[i], pr->ev[i + 1]);
       acc[i] += ms * 1000.0;

@@ -349,6 +349,27 @@ class Engine:
         except Exception:
             pass
 
+    def profile_train_levels(self, x, lr: float = 1e-3, iters: int = 20):
+        """Per-launch timing of the steady-state training step of a train graph (gmvae_train_profile).
+        Advances the optimizer by iters + 1 steps."""
+        x = self._prep_x(x)
+        d, ws = self._workspace(x.shape[0])
+        self.step_dev.fill_(self.global_step)
+        n = C.c_int()
+        names = C.create_string_buffer(96 * 48)
+        usec = (C.c_float * 96)()
+        flops = (C.c_double * 96)()
+        rc = L.lib.gmvae_train_profile(C.byref(d), self.model, L.ptr(x), L.ptr(self.params), L.ptr(self.m), L.ptr(self.v),
+                                       L.ptr(self.grads), L.ptr(ws), self.noise_seed, L.ptr(self.step_dev), lr, iters, 96,
+                                       C.byref(n), names, usec, flops, L.current_stream())
+        L.check(rc, "gmvae_train_profile")
+        self.global_step += iters + 1
+        out = []
+        for i in range(n.value):
+            nm = names.raw[i * 48:(i + 1) * 48].split(b"\0")[0].decode()
+            out.append((nm, float(usec[i]), float(flops[i])))
+        return out
+
     def profile_levels(self, x, iters: int = 20):
         """Per-launch timing of the step with hipEvents (gmvae_step_profile)."""
         x = self._prep_x(x)

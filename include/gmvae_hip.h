@@ -169,7 +169,13 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
 /* Runs the full step `iters` times with hipEvents around EVERY launch (on
  * `stream`) and returns, per launch ("level"), its name [48 chars each], mean
  * microseconds and the algorithmic FLOPs (2*M*N*K summed over its GEMMs,
- * 0 for row-local kernels).  Synchronises the stream: measurement only. */
+ * 0 for row-local kernels).  Synchronises the stream: measurement only.
+ * gmvae_train_profile does the same for the steady-state TRAINING step of a train graph (Philox noise, TF-Adam
+ * fused into the last launch, first layer inside mega_fwd_bwd where that schedule applies): one untimed step
+ * first, then `iters` timed ones; it advances params / m / v / *step_dev like `iters + 1` real steps. */
+int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
+                        float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, int iters,
+                        int max_levels, int* n_levels, char* names, float* usec, double* flops, void* stream);
 int gmvae_step_profile(const GmvaeDims* dims, int model, const uint8_t* x, const float* eps, const float* u,
                        const float* params, float* grads, void* workspace, uint64_t seed, int iters,
                        int max_levels, int* n_levels, char* names, float* usec, double* flops, void* stream);
