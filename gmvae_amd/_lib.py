@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgmvae_hip.so")
+# GMVAE_HIP_LIB: another build of the same ABI (A/B measurements of two kernels on one GPU box)
+LIB_PATH = os.environ.get("GMVAE_HIP_LIB") or os.path.join(HERE, "lib", "libgmvae_hip.so")
 
 MAX_HIDDEN = 8
 TAIL = 8

@@ -612,11 +612,13 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     // the reference's default sizes (run_gmvae.py: latent 64, hidden 64, K 10; MNIST D 784) run a specialised instance
     typedef void (*MegaFn)(const MegaArgs);
     const bool spec = H == 64 && Lz == 64 && K == 10 && D == 784 && gm && !getenv("GMVAE_MEGA_GENERIC");
-    const MegaFn fn = spec ? mega_fwd_bwd<64, 64, 10, 784, 2> : mega_fwd_bwd<0, 0, 0, 0, -1>;
+    const MegaFn fns[4] = {mega_fwd_bwd<0, 0, 0, 0, -1, 0>, mega_fwd_bwd<0, 0, 0, 0, -1, 1>, mega_fwd_bwd<64, 64, 10, 784, 2, 0>,
+                           mega_fwd_bwd<64, 64, 10, 784, 2, 1>};
+    const MegaFn fn = fns[(spec ? 2 : 0) + (fl ? 1 : 0)];
     static bool mattr = false;
     if (!mattr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(mega_fwd_bwd<64, 64, 10, 784, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(mega_fwd_bwd<0, 0, 0, 0, -1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      for (int i = 0; i < 4; ++i)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       mattr = true;
     }
     hipLaunchKernelGGL(fn, dim3((B + kPanel - 1) / kPanel * c.Q), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
@@ -1430,7 +1432,7 @@ int gmvae_kernel_occupancy(int which, int* blocks_per_cu) {
     case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, gemm_grouped<CfgS>, kThreads, 0); break;
     case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, gemm_grouped<CfgM>, kThreads, 0); break;
     case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, gemm_grouped<CfgL>, kThreads, 0); break;
-    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mega_fwd_bwd<0, 0, 0, 0, -1>, kMT, 150 * 1024); break;
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mega_fwd_bwd<0, 0, 0, 0, -1, 0>, kMT, 150 * 1024); break;
     case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, finalize_adam, 256, 0); break;
     default: return GMVAE_E_DIMS;
   }

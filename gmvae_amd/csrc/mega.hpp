@@ -18,6 +18,7 @@
 namespace gmvae {
 
 constexpr int kCW = 128;       // decoder columns per streamed chunk (finalize_adam's image scatter shifts by 7)
+constexpr int kFlLda = 226;    // row stride of the in-launch first layer's x image: = 2 (mod 32), >= D/4 rounded up to 4
 constexpr int kMW = 8;         // wavefronts per workgroup (2 per SIMD: the partner hides LDS/DMA/VALU latency)
 constexpr int kMT = kMW * 64;
 
@@ -88,7 +89,7 @@ __host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D, int mode
     m.fl_ld = H;
     m.fl_W = 0;
     m.fl_A = GMVAE_P256(nw * m.fl_kq * H);
-    m.fl_ok = (m.fl_A + m.fl_kq * kLDA <= m.nll) && model != 1 && D % 16 == 0 && nw * H <= 128 && H % 16 == 0 && L % 4 == 0 &&
+    m.fl_ok = (m.fl_A + kPanel * kFlLda <= m.nll) && m.fl_kq <= kFlLda && model != 1 && D % 16 == 0 && nw * H <= 128 && H % 16 == 0 && L % 4 == 0 &&
               H == 64 && (m.fl_kq * H) % 256 == 0 && kPanel * m.fl_kq / 4 <= 2 * kMT && 4 * L + (model == 2 ? 4 * K : 0) <= kMT;
   }
   return m;
@@ -115,11 +116,13 @@ __device__ __forceinline__ float row32_max(float v) { v = row16_max(v); return f
 // partial sums of one 16x16 tile over k-steps [s0, s1) -> acc.  Operand reads run 8 steps ahead of the MFMA chain
 // (a 16-deep batch and a blocked k-assignment were both measured SLOWER: tools/stamps.py).  Addresses advance by
 // pointer increments: the multiply-and-clamp form cost ~2x the MFMA chain in quarter-rate integer VALU.
+// A(row, k) = A[k * ASK + row * ASM]: the [k][17] activation images (ASK = 17, ASM = 1) or a row-major image (ASK = 1).
+template <int ASK = kLDA, int ASM = 1>
 __device__ __forceinline__ f32x4 tile_ksteps(const float* __restrict__ A, const float* __restrict__ Bw, const int sk,
                                              const int sn, const int tile, const int s0, const int s1, const int /*smax*/,
                                              const int lane, f32x4 acc) {
   const int ln = lane & 15, lk = lane >> 4;
-  const float* pa = A + (s0 * 4 + lk) * kLDA + ln;
+  const float* pa = A + (s0 * 4 + lk) * ASK + ln * ASM;
   const float* pb = Bw + (s0 * 4 + lk) * sk + (tile * 16 + ln) * sn;
   const int sb4 = 4 * sk;
   int n = s1 - s0;
@@ -128,13 +131,13 @@ __device__ __forceinline__ f32x4 tile_ksteps(const float* __restrict__ A, const 
     const float* q = pb;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      av[j] = pa[j * 4 * kLDA];
+      av[j] = pa[j * 4 * ASK];
       bv[j] = *q;
       q += sb4;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
-    pa += 32 * kLDA;
+    pa += 32 * ASK;
     pb = q;
   }
   if (n > 0) {                                   // 1..7 steps left (wave-uniform)
@@ -142,7 +145,7 @@ __device__ __forceinline__ f32x4 tile_ksteps(const float* __restrict__ A, const 
     const float* q = pb;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-      av[j] = pa[j * 4 * kLDA < (n - 1) * 4 * kLDA ? j * 4 * kLDA : (n - 1) * 4 * kLDA];
+      av[j] = pa[j * 4 * ASK < (n - 1) * 4 * ASK ? j * 4 * ASK : (n - 1) * 4 * ASK];
       bv[j] = *q;
       if (j + 1 < n) q += sb4;
     }
@@ -245,7 +248,9 @@ struct MegaArgs {
 // HT, LT, KT, DT, MODEL: compile-time sizes of a specialised instance (0 / -1 = read them from the arguments).
 // With runtime sizes the launch spends ~1100 instructions on pointer and index set-up before its first DMA and
 // keeps ~100 scalars live (spilled to VGPR lanes); with the sizes folded in, the layout is a table of constants.
-template <int HT, int LT, int KT, int DT, int MODEL>
+// FLT = 1: the instance that runs the first layer itself (MegaArgs::fl); a compile-time switch, because the two
+// forms of the first stage together push the kernel over its 256 registers.
+template <int HT, int LT, int KT, int DT, int MODEL, int FLT>
 __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   const float* const sp = a.s1 + (long long)min(r0 + frow, B - 1) * H2f + fcol;
   const long long sstride = (long long)B * H2f;
   float4 so[4];                                   // raw: summed after the DMA issue
-  if (!a.fl) {
+  if (!FLT) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) so[j] = *reinterpret_cast<const float4*>(sp + (long long)min(j, a.NS - 1) * sstride);
   }
@@ -302,8 +307,8 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   // ======================================================================= F: forward chain
   for (int rep_ = 0; rep_ < (a.fine == 3 ? 2 : 1); ++rep_) {     // diagnostic: a second, instruction-cache-warm pass
   if (rep_) { __syncthreads(); GMVAE_STAMP(0); }
-  float4 v;
-  if (a.fl) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (FLT) {
     // ---------------------------------------------------------------- FL: first layer over this quarter's columns
     const int KQ = f.fl_kq, kq4 = KQ / 4;
     float* const Wst = sm + f.fl_W;
@@ -344,11 +349,10 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       const int i = tid + it * kMT;
       if (i < kPanel * kq4) {
         const int row = i / kq4, k4 = (i - row * kq4) * 4;
-        const unsigned w = xw[it];
-        A_x[(k4 + 0) * kLDA + row] = (float)(w & 0xff);
-        A_x[(k4 + 1) * kLDA + row] = (float)((w >> 8) & 0xff);
-        A_x[(k4 + 2) * kLDA + row] = (float)((w >> 16) & 0xff);
-        A_x[(k4 + 3) * kLDA + row] = (float)(w >> 24);
+        const unsigned w = xw[it];                 // row-major [16][kFlLda]: consecutive lanes, consecutive 16 bytes
+        float2* const dst = reinterpret_cast<float2*>(A_x + row * kFlLda + k4);
+        dst[0] = make_float2((float)(w & 0xff), (float)((w >> 8) & 0xff));
+        dst[1] = make_float2((float)((w >> 16) & 0xff), (float)(w >> 24));
       }
     }
     GMVAE_FS(0);
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     if (wave < ntile) {
       const int tl = wave < tpw ? wave : wave - tpw;
       const int swz = ((tl * 16 + ln) ^ ((lk & 1) << 4)) - (tl * 16 + ln);      // this lane's k rows are all odd or all even
-      acc = tile_ksteps(A_x, (wave < tpw ? Wst : Wst + KQ * H) + swz, H, 1, tl, 0, kq4, kq4, lane, acc);
+      acc = tile_ksteps<1, kFlLda>(A_x, (wave < tpw ? Wst : Wst + KQ * H) + swz, H, 1, tl, 0, kq4, kq4, lane, acc);
     }
     GMVAE_FL(5);
     const int ngr = kPanel * H2f;
@@ -383,6 +387,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     if (bid == gridDim.x - 1 && tid == 0) a.step_dev[1] = step;       // the copy finalize_adam reads
     // the other quarters' partials: all 12 granules of a lane are requested together and re-read until every tag
     // carries this step's epoch; summed in quarter order (every workgroup of the panel gets the same bits)
+    float flt[4] = {0.f, 0.f, 0.f, 0.f};
     if (wave < ntile) {
       const unsigned long long* xp = a.xfl + (long long)pnl * 4 * ngr;
       unsigned long long gv[4][4];
@@ -414,14 +419,27 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
         float t = 0.f;
 #pragma unroll
         for (int pq = 0; pq < 4; ++pq) t += __uint_as_float((unsigned)gv[pq][r]);
-        red[(lk * 4 + r) * H2f + wave * 16 + ln] = t;
+        flt[r] = t;
       }
     }
     GMVAE_FL(7);
-    dma_wait();
+    dma_wait();                                    // the biases (early image part) have landed
     __syncthreads();
     dma_copy_m(sm + f.img_early, a.img + f.img_early, f.img - f.img_early, wave, lane);   // q head / decoder hidden weights
-    v = *reinterpret_cast<const float4*>(red + frow * H2f + fcol);
+    if (wave < ntile) {                            // bias + ReLU straight from the accumulator layout
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = lk * 4 + r, col = wave * 16 + ln;
+        if (col < H) {
+          const float h = fmaxf(flt[r] + b_y0[col], 0.f);
+          A_hy[col * kLDA + row] = h;
+          P_hy[row * H + col] = h;
+          if (lead && row < nrow) a.hy1[(long long)(r0 + row) * H + col] = h;
+        } else {
+          P_gx[row * H + (col - H)] = flt[r];
+        }
+      }
+    }
   } else {
   dma_copy_m(sm, a.img, f.img_early, wave, lane);
   dma_copy_m(P_eps, a.eps + (long long)r0 * L, nrow * L, wave, lane);
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
   }
-  {
+  if (!FLT) {
     const int row = frow, col = fcol;
     if (tid < nitem) {
       float vv[4] = {v.x, v.y, v.z, v.w};
@@ -713,7 +731,8 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     GMVAE_SEG(1);
     __syncthreads();
     GMVAE_SEG(2);
-    // g chunk -> HBM as 16-byte row-major stores (for the dWd1 GEMM): thread -> (row, 4 columns), 2 per thread
+    // g chunk -> HBM as 16-byte row-major stores (for the dWd1 GEMM): thread -> (row, 4 columns).  (A conflict-free
+    // read mapping with four 4-byte stores per thread was measured SLOWER: every later vmcnt(0) drains 4x the stores.)
     {
       const int row = tid >> 5, c4 = (tid & 31) << 2;     // 512 float4 per chunk: one per thread
       if (row < nrow && c0 + c4 < D) {
