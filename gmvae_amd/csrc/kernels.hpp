@@ -550,14 +550,30 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
   asm volatile("" ::"s"(hit), "s"(e_begin), "s"(e_end), "s"(e_cols), "s"(e_kind), "s"(e_base), "s"(e_ld), "s"(e_chunk),
                "s"(e_which), "s"(e_magic));
   if (i4 >= a.P) return;
-  const float4 g = slab_sum4(a.slabs + i4, a.P, a.nslab);
+  // every load of the block goes out before the first wait: parameters and moments, then up to 8 slabs at once
+  // (the launch is one wave of blocks: its length is its chain of dependent memory round trips)
+  float4 pp = make_float4(0.f, 0.f, 0.f, 0.f), mm = pp, vv = pp;
+  if (a.do_adam) {
+    pp = *reinterpret_cast<const float4*>(a.p + i4);
+    mm = *reinterpret_cast<const float4*>(a.m + i4);
+    vv = *reinterpret_cast<const float4*>(a.v + i4);
+  }
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s0 = 0; s0 < a.nslab; s0 += 8) {
+    float4 o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = *reinterpret_cast<const float4*>(a.slabs + (long long)min(s0 + j, a.nslab - 1) * a.P + i4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float w = s0 + j < a.nslab ? 1.f : 0.f;
+      g.x += w * o[j].x; g.y += w * o[j].y; g.z += w * o[j].z; g.w += w * o[j].w;
+    }
+  }
   *reinterpret_cast<float4*>(a.grads + i4) = g;
   if (!a.do_adam) return;
   const unsigned long long t = (a.step_dev ? a.step_dev[1] : 0ull) + 1ull;
   const float lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, (double)t)) / (1.0 - pow((double)a.b1, (double)t)));
   const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, gs = 1.f / a.count;
-  float4 pp = *reinterpret_cast<float4*>(a.p + i4), mm = *reinterpret_cast<float4*>(a.m + i4),
-         vv = *reinterpret_cast<float4*>(a.v + i4);
   float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
   const float ga[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
