@@ -615,6 +615,9 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     const MegaFn fns[4] = {mega_fwd_bwd<0, 0, 0, 0, -1, 0>, mega_fwd_bwd<0, 0, 0, 0, -1, 1>, mega_fwd_bwd<64, 64, 10, 784, 2, 0>,
                            mega_fwd_bwd<64, 64, 10, 784, 2, 1>};
     const MegaFn fn = fns[(spec ? 2 : 0) + (fl ? 1 : 0)];
+    if (getenv("GMVAE_TRACE"))
+      fprintf(stderr, "[gmvae] mega_fwd_bwd: model %d B %d first_layer_inside %d workgroups_per_panel %d specialised %d\n", model, B,
+              (int)fl, Qm, (int)spec);
     static bool mattr = false;
     if (!mattr) {
       for (int i = 0; i < 4; ++i)
@@ -1454,7 +1457,8 @@ int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, u
       {"logpx", w.logpx}, {"logw", w.logw}, {"g", w.g}, {"dz", w.dz}, {"dqp", w.dqp}, {"dpp", w.dpp},
       {"dy", w.dy}, {"dlogits", w.dlogits}, {"dbuf0", w.dbuf[0]}, {"dbuf1", w.dbuf[1]}, {"dbuf2", w.dbuf[2]},
       {"slabs", w.slabs}, {"s1", w.s1}, {"s4", w.s4}, {"eps", w.eps}, {"u", w.u},
-      {"stamps", reinterpret_cast<float*>(w.stamps)}, {"gstamps", reinterpret_cast<float*>(w.gstamps)}};
+      {"stamps", reinterpret_cast<float*>(w.stamps)}, {"gstamps", reinterpret_cast<float*>(w.gstamps)},
+      {"sync", reinterpret_cast<float*>(w.sync)}};
   for (auto& t : tab)
     if (!strcmp(t.n, name)) {
       if (!t.p) return GMVAE_E_NET;

@@ -341,6 +341,17 @@ class Engine:
         self._graphs[key] = (static_x, replay, handle)
         return static_x, replay
 
+    def handoff_timeouts(self) -> int:
+        """Number of workspaces whose in-launch hand-off (mega_fwd_bwd's tagged-granule exchange between the
+        workgroups of a panel) ever gave up waiting.  Such a step also poisons its loss and gradients with NaN;
+        this is the explicit flag.  0 on a healthy device."""
+        bad = 0
+        for (d, ws) in self._ws.values():
+            off = C.c_uint64()
+            if L.lib.gmvae_workspace_offset(C.byref(d), self.model, b"sync", C.byref(off)) == 0:
+                bad += int(ws.view(torch.int32)[off.value // 4 + 1].item() != 0)
+        return bad
+
     def __del__(self):
         try:
             for _, _, handle in self._graphs.values():

@@ -166,6 +166,35 @@ def test_multi_step_graph_matches_eager_steps_on_the_same_batches(in_launch_firs
         assert abs(outs[0][2][0].item() - outs[1][2][0].item()) < 1e-4 * abs(outs[0][2][0].item())
 
 
+@pytest.mark.parametrize("model,L_,K_,B", [("vae", 8, 1, 256), ("gmvae", 16, 10, 100), ("gmvae", 64, 10, 1000)])
+def test_in_launch_first_layer_other_models_and_sizes(model, L_, K_, B):
+    """Steps 2..n of a train graph run the first layer inside mega_fwd_bwd also for the VAE (one first-layer tensor,
+    4 column tiles), for sizes other than the specialised instance's and for a ragged last panel (B = 100, 1000);
+    they must track eager steps on the same batches and leave the hand-off error word clear."""
+    from gmvae_amd.engine import Engine
+    n = 3
+    rng = np.random.default_rng(11)
+    xs = torch.from_numpy((rng.random((n, B, 784)) < 0.87).astype(np.uint8)).cuda()
+    outs = []
+    for multi in (False, True):
+        e = Engine(model, 784, L_, K_, [64], random_seed=2)
+        if multi:
+            sx, replay = e.capture_train_step(B, lr=1e-3, n_steps=n)
+            sx.copy_(xs)
+            replay()
+            replay()
+            assert e.handoff_timeouts() == 0
+        else:
+            for r in range(2):
+                for i in range(n):
+                    e.train_step(xs[i], lr=1e-3)
+        torch.cuda.synchronize()
+        outs.append((e.params.detach().clone(), e.grads[e.P:].clone()))
+    assert torch.isfinite(outs[1][0]).all()
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 2e-5
+    assert abs(outs[0][1][0].item() - outs[1][1][0].item()) < 1e-4 * abs(outs[0][1][0].item())
+
+
 def test_missing_engine_and_bad_activation_fail_loudly():
     import gmvae_amd
     from gmvae_amd import base
