@@ -101,16 +101,20 @@ struct Cfg {
   static constexpr int NSA = BM * BK / 4 / kThreads, NSB = BN * BK / 4 / kThreads;
   static constexpr int OPS = NBUF * (LDA + LDB) * BK;               // floats, NBUF staging buffers
   static constexpr int CST = WK * BM * LDC;                          // floats, C staging
-  static constexpr int LDS_FLOATS = OPS > CST + 4 * kThreads ? OPS : CST + 4 * kThreads;   // + column-sum partials
+  static constexpr int XBF = (BM == 64 && BN == 64 && BK == 64) ? 4 * 64 * 96 / 2 : 0;     // the bf16 path's 4 images [64][96] x 2 B
+  static constexpr int LDS0 = OPS > CST + 4 * kThreads ? OPS : CST + 4 * kThreads;          // + column-sum partials
+  static constexpr int LDS_FLOATS = LDS0 > XBF ? LDS0 : XBF;
   // waves per SIMD the register allocator must leave room for: the small configuration's launches carry more
   // workgroups than 2 per CU (tiles + auxiliary blocks), and a workgroup that starts late ends the launch late
-  static constexpr int WAVES_EU = (BM * BN <= 32 * 32) ? 3 : 1;
+  static constexpr int WAVES_EU = (BM * BN <= 32 * 32 || (NBUF == 1 && BM * BN <= 64 * 64)) ? 3 : 1;
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
   static_assert(NSA >= 1 && NSB >= 1, "tile too small for 256 threads");
   static_assert((BK / WK) % 2 == 0, "k slice per wave must be even");
 };
 typedef Cfg<32, 32, 128, 1, 1, 4, 1> CfgS;  // latency-bound: 4 waves split K inside the tile, single buffer
 typedef Cfg<64, 64, 64, 2, 2, 1> CfgM;
+typedef Cfg<64, 64, 64, 2, 2, 1, 1> CfgM1;  // single staging buffer (48 KB with the bf16 images): 3 workgroups per CU, for
+                                            // launches whose tiles are one or two rounds long
 typedef Cfg<128, 128, 32, 2, 2, 1> CfgL;    // MFMA-bound: 64x64 per wave
 // (Single-round variants -- BK = the whole k range of a split, one batch of loads -- were measured and dropped:
 // the staging phase of these launches scales with the bytes requested, not with the number of round trips.)
@@ -586,6 +590,25 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
     const float* rowscale = L.p[pi].rowscale;
     const int relu = L.p[pi].relu, ld_add = L.p[pi].ld_add, add_div = L.p[pi].add_div, ld_mask = L.p[pi].ld_mask;
     const long long soff = (long long)split * L.p[pi].split_stride;
+    // plain slab / matrix store of an interior tile (every weight-gradient tile but the edge ones): no per-element
+    // options, all passes unrolled, 16-byte stores
+    const bool plain = !bias && !addsrc && !mask && !rowscale && !relu && addconst == 0.f && m0 + C::BM <= M &&
+                       n0 + C::BN <= N && (ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(Cout + soff) & 15) == 0);
+    if (plain) {
+      float* const dst0 = Cout + soff + (long long)m0 * ldc + n0;
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int gidx = tid + ps * kThreads;
+        const int row = gidx / GPR, c4 = gidx % GPR;
+        float4 v4 = *reinterpret_cast<const float4*>(lds + row * C::LDC + 4 * c4);
+#pragma unroll
+        for (int w = 1; w < C::WK; ++w) {
+          const float4 o = *reinterpret_cast<const float4*>(lds + (w * C::BM + row) * C::LDC + 4 * c4);
+          v4.x += o.x; v4.y += o.y; v4.z += o.z; v4.w += o.w;
+        }
+        *reinterpret_cast<float4*>(dst0 + (long long)row * ldc + 4 * c4) = v4;
+      }
+    } else
 #pragma unroll 1
     for (int ps = 0; ps < PASSES; ++ps) {
       const int gidx = tid + ps * kThreads;

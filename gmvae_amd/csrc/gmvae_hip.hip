@@ -205,12 +205,12 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     for (int i = 1; i < L.encg.nl; ++i) w.hg[i] = take(R * L.encg.dim[i]);
     w.gx = take(B * L.encg.dim[1]);
     w.logits = take(B * K);
-    w.y = take(R * K);
+    w.y = take(R * pad4(K));                 // the mega schedule stores rows of pad4(K): 16-byte loads in the dW launch
     w.nent = take(B);
     w.pp = take(R * 2 * Lz);
     w.dpp = take(R * 2 * Lz);
     w.dy = take(R * K);
-    w.dlogits = take(B * K);
+    w.dlogits = take(B * pad4(K));
     w.qp = take(R * 2 * Lz);
   } else {
     w.qp = take(B * 2 * Lz);
@@ -253,6 +253,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
   {
     int ns = num_splits(R);
     if ((fused_ok(d, model) || mega_ok(d, model)) && dw_splits(d.B) > ns) ns = dw_splits(d.B);
+    if (mega_ok(d, model) && 2 * dw_splits(d.B) <= NS_MAX && 2 * dw_splits(d.B) > ns) ns = 2 * dw_splits(d.B);
     w.slabs = take((uint64_t)ns * L.P_pad);
   }
   w.cl_pred = reinterpret_cast<int32_t*>(take(B));
@@ -383,6 +384,9 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
   if (cfg == 2) {
     tiles = g.L.total_tiles = tile_up<CfgL>(g.L);
     hipLaunchKernelGGL(gemm_grouped<CfgL>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
+  } else if (cfg == 3) {
+    tiles = g.L.total_tiles = tile_up<CfgM1>(g.L);
+    hipLaunchKernelGGL(gemm_grouped<CfgM1>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
   } else if (cfg == 1) {
     tiles = g.L.total_tiles = tile_up<CfgM>(g.L);
     hipLaunchKernelGGL(gemm_grouped<CfgM>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
@@ -394,7 +398,7 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
   cx.mark(name, fl);
   return cfg;
 }
-static int cfg_bn(int cfg) { return cfg == 2 ? CfgL::BN : (cfg == 1 ? CfgM::BN : CfgS::BN); }
+static int cfg_bn(int cfg) { return cfg == 2 ? CfgL::BN : ((cfg == 1 || cfg == 3) ? CfgM::BN : CfgS::BN); }
 
 static int grid_for(long long items, int per_block, int cap = 4096) {
   long long g = (items + per_block - 1) / per_block;
@@ -495,7 +499,11 @@ static void plan_images(const GmvaeDims& d, int model, const Layout& L, const WS
 }
 
 // end of the fused schedules: slab reduce + loss tail (+ TF-Adam in the graph path)
-static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, float* tail, int NS, int B) {
+static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, float* tail, int NS, int B,
+                        const SlabX* sxp = nullptr) {
+  SlabX sx;
+  memset(&sx, 0, sizeof(sx));
+  if (sxp) sx = *sxp;
   hipStream_t st = cx.st;
   const GmvaeDims& d = *a.d;
   const long long PP = (long long)L.P_pad;
@@ -509,6 +517,7 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
     fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = nent;
     fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
     fa.nmap = 0; fa.map_lo = fa.map_hi = 0; fa.img0 = fa.img1 = nullptr; fa.epoch_word = nullptr;
+    fa.sx = sx;
     if (mega_ok(d, a.model) && a.adam_p == a.params) {      // the next step's weight images ride on the update
       const MegaLay ml = mega_lay(d.hidden[0], d.L, d.K, d.D, a.model);
       ImgPlan pl;
@@ -529,7 +538,7 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
   const int KLp = (int)pad4((uint64_t)d.K * d.L);
   hipLaunchKernelGGL(finalize_grads, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, sl, NS, PP, a.grads,
                      gmp ? w.gmp_part : (const float*)nullptr, (B + kPanel - 1) / kPanel,
-                     gmp ? 2 * KLp + (int)pad4(d.K) : 0, (long long)L.loc);
+                     gmp ? 2 * KLp + (int)pad4(d.K) : 0, (long long)L.loc, sx);
   rowk(cx, "finalize_grads");
   if (a.adam_p && a.step_dev) {           // VAE_GMP in the graph path: its prior partials need finalize_grads first
     hipLaunchKernelGGL(adam_tf, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, a.adam_p, a.adam_m, a.adam_v,
@@ -632,26 +641,39 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     if (gm) macs += (double)H * K + (double)K * H + (double)K * 2 * Lz + (double)(H + 2 * Lz) * K + (double)K * H;
     cx.mark("mega_fwd_bwd", 2.0 * B * macs);
   }
-  {  // every weight gradient in one grouped launch
+  // Every weight gradient in one grouped launch.  The uint8-activation problems (bf16 matrix cores) take NS splits
+  // of two 64-row staging rounds; the fp32 problems take 2 NS splits of ONE round each: their workgroups, the
+  // launch's critical path, are latency chains, and the single-buffered tile configuration leaves room for all
+  // of them on the chip at once (3 per CU).
+  const int NS2 = (2 * NS <= NS_MAX && B / (2 * NS) >= 64 && !getenv("GMVAE_DW_UNIFORM")) ? 2 * NS : NS;
+  SlabX sx;
+  memset(&sx, 0, sizeof(sx));
+  {
     Group g;
+    auto xrange = [&](uint64_t b, uint64_t n) { sx.b[sx.n] = (int)b; sx.e[sx.n] = (int)(b + pad4(n)); sx.n++; };
+    sx.ns = NS;
     if (gm) {
       g.add(p_tn(a.x, true, D, 1, w.dbuf[2], H, D, H, B, sl + E.w[0], sl + E.b[0], NS, PP, nullptr));            // dWy0
       g.add(p_tn(a.x, true, D, 1, w.dbuf[1], H, D, H, B, sl + G.w[0], sl + G.b[0], NS, PP, nullptr));            // dWg0[x]
-      g.add(p_tn(w.hd[1], false, H, 1, w.g, D, H, D, B, sl + Dn.w[1], sl + Dn.b[1], NS, PP, nullptr));           // dWd1
-      g.add(p_tn(w.y, false, K, 1, w.dbuf[1], H, K, H, B, sl + G.w[0] + (uint64_t)D * H, nullptr, NS, PP, nullptr));
-      g.add(p_tn(w.he[1], false, H, 1, w.dlogits, K, H, K, B, sl + E.w[1], sl + E.b[1], NS, PP, nullptr));       // dWy1
-      g.add(p_tn(w.y, false, K, 1, w.dpp, 2 * Lz, K, 2 * Lz, B, sl + L.prior.w[0], sl + L.prior.b[0], NS, PP, nullptr));
-      g.add(p_tn(w.hg[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + G.w[1], sl + G.b[1], NS, PP, nullptr)); // dWg1
+      xrange(E.w[0], (uint64_t)D * H); xrange(E.b[0], H); xrange(G.w[0], (uint64_t)D * H); xrange(G.b[0], H);
+      g.add(p_tn(w.hd[1], false, H, 1, w.g, D, H, D, B, sl + Dn.w[1], sl + Dn.b[1], NS2, PP, nullptr));          // dWd1
+      const int K4 = (int)pad4(K);       // row stride of y and dlogits as mega_fwd_bwd stores them
+      g.add(p_tn(w.y, false, K4, 1, w.dbuf[1], H, K, H, B, sl + G.w[0] + (uint64_t)D * H, nullptr, NS2, PP, nullptr));
+      g.add(p_tn(w.he[1], false, H, 1, w.dlogits, K4, H, K, B, sl + E.w[1], sl + E.b[1], NS2, PP, nullptr));     // dWy1
+      g.add(p_tn(w.y, false, K4, 1, w.dpp, 2 * Lz, K, 2 * Lz, B, sl + L.prior.w[0], sl + L.prior.b[0], NS2, PP, nullptr));
+      g.add(p_tn(w.hg[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + G.w[1], sl + G.b[1], NS2, PP, nullptr)); // dWg1
     } else {
       g.add(p_tn(a.x, true, D, 1, w.dbuf[1], H, D, H, B, sl + E.w[0], sl + E.b[0], NS, PP, nullptr));            // dWe0
-      g.add(p_tn(w.hd[1], false, H, 1, w.g, D, H, D, B, sl + Dn.w[1], sl + Dn.b[1], NS, PP, nullptr));           // dWd1
-      g.add(p_tn(w.he[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + E.w[1], sl + E.b[1], NS, PP, nullptr)); // dWe1
+      xrange(E.w[0], (uint64_t)D * H); xrange(E.b[0], H);
+      g.add(p_tn(w.hd[1], false, H, 1, w.g, D, H, D, B, sl + Dn.w[1], sl + Dn.b[1], NS2, PP, nullptr));          // dWd1
+      g.add(p_tn(w.he[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + E.w[1], sl + E.b[1], NS2, PP, nullptr)); // dWe1
     }
-    g.add(p_tn(w.z, false, Lz, 1, w.dbuf[0], H, Lz, H, B, sl + Dn.w[0], sl + Dn.b[0], NS, PP, nullptr));          // dWd0
-    launch_group(cx, g, "bwd_dw_all", env_cfg("GMVAE_DW_CFG", B >= 512 ? 1 : 0),
+    g.add(p_tn(w.z, false, Lz, 1, w.dbuf[0], H, Lz, H, B, sl + Dn.w[0], sl + Dn.b[0], NS2, PP, nullptr));         // dWd0
+    if (NS2 == NS) sx.n = 0;
+    launch_group(cx, g, "bwd_dw_all", env_cfg("GMVAE_DW_CFG", B >= 512 ? (NS2 != NS ? 3 : 1) : 0),
                  getenv("GMVAE_STAMPS") ? w.gstamps + 2048 * 8 : nullptr);
   }
-  return finish_fused(cx, a, L, w, tail, NS, B);
+  return finish_fused(cx, a, L, w, tail, NS2, B, &sx);
 }
 
 // The fused schedule: 9 launches instead of 21 for GMVAE with one hidden layer at sizes whose
@@ -1012,7 +1034,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     const int KLp = (int)pad4((uint64_t)K * Lz);
     hipLaunchKernelGGL(finalize_grads, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, sl, NS, PP, a.grads,
                        gmp ? w.gmp_part : (const float*)nullptr, GMP_PARTS, gmp ? 2 * KLp + (int)pad4(K) : 0,
-                       (long long)L.loc);
+                       (long long)L.loc, SlabX{});
     rowk(cx, "finalize_grads");
   }
   return cx.err;

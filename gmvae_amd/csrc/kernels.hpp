@@ -389,17 +389,46 @@ __global__ __launch_bounds__(1024) void loss_tail(const float* __restrict__ logw
 }
 
 // ------------------------------------------------------- gradient assembly
+// sum of NS split-K slabs at one float4 location
+// (loads go out four at a time, clamped to the last slab and predicated at the add: a runtime-count loop of
+// load-then-add serialises one cold memory round trip per slab)
+__device__ __forceinline__ float4 slab_sum4(const float* __restrict__ p, const long long sstride, const int NS) {
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s0 = 0; s0 < NS; s0 += 4) {
+    float4 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = *reinterpret_cast<const float4*>(p + (long long)min(s0 + j, NS - 1) * sstride);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float w = s0 + j < NS ? 1.f : 0.f;
+      r.x += w * o[j].x; r.y += w * o[j].y; r.z += w * o[j].z; r.w += w * o[j].w;
+    }
+  }
+  return r;
+}
+
+// Parameter ranges whose weight gradients were split over fewer slabs than the rest (the uint8-activation
+// problems of the fused dW launch run on the bf16 matrix cores and take half the splits of the fp32 ones).
+struct SlabX {
+  int n, ns;                  // ranges in use; slabs of those ranges
+  int b[4], e[4];             // [begin, end) flat parameter indices, multiples of 4
+};
+__device__ __forceinline__ int slab_count(const SlabX& sx, const long long i4, const int dflt) {
+  int ns = dflt;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < sx.n && i4 >= sx.b[k] && i4 < sx.e[k]) ns = sx.ns;
+  return ns;
+}
+
 // grads[i] = sum over the split-K slabs (fixed order => bit-reproducible),
 // and the mixture-prior partials where present.
 __global__ void finalize_grads(const float* __restrict__ slabs, int nslab, long long P, float* __restrict__ grads,
-                               const float* __restrict__ gmp_part, int gmp_n, int gmp_len, long long gmp_off) {
+                               const float* __restrict__ gmp_part, int gmp_n, int gmp_len, long long gmp_off,
+                               const SlabX sx) {
   const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i4 >= P) return;
-  float4 a = *reinterpret_cast<const float4*>(slabs + i4);
-  for (int s = 1; s < nslab; ++s) {
-    const float4 o = *reinterpret_cast<const float4*>(slabs + (long long)s * P + i4);
-    a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
-  }
+  float4 a = slab_sum4(slabs + i4, P, slab_count(sx, i4, nslab));
   if (gmp_part && i4 >= gmp_off && i4 < gmp_off + gmp_len) {
     // mixture-prior gradients: sum the per-workgroup partials (rows of gmp_len floats, 16-byte aligned);
     // independent 16-byte loads, 8 in flight
@@ -461,24 +490,6 @@ __global__ void adam_tf(float* __restrict__ p, float* __restrict__ m, float* __r
 //   block  nb       : loss tail sums (loss_tail) and the device step counter.
 // Counter protocol (no intra-kernel race): every block reads t-1 from step_dev[1] (copied from
 // step_dev[0] by the FIRST launch of the step, aux.hpp); only the tail block writes step_dev[0].
-// sum of NS split-K slabs at one float4 location
-// (loads go out four at a time, clamped to the last slab and predicated at the add: a runtime-count loop of
-// load-then-add serialises one cold memory round trip per slab)
-__device__ __forceinline__ float4 slab_sum4(const float* __restrict__ p, const long long sstride, const int NS) {
-  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s0 = 0; s0 < NS; s0 += 4) {
-    float4 o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = *reinterpret_cast<const float4*>(p + (long long)min(s0 + j, NS - 1) * sstride);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float w = s0 + j < NS ? 1.f : 0.f;
-      r.x += w * o[j].x; r.y += w * o[j].y; r.z += w * o[j].z; r.w += w * o[j].w;
-    }
-  }
-  return r;
-}
-
 // One tensor (or row range of one) that also lives in an LDS-image of the next step's mega_fwd_bwd: flat parameter
 // indices [begin, end), `cols` per source row.  kind 0: img[base + r * ld + c]; kind 1 (decoder output layer, stored
 // as column chunks of `cw`): img[base + (c / cw) * chunk + r * ld + c % cw].
@@ -503,6 +514,7 @@ struct FinalArgs {
   int nmap, map_lo, map_hi;
   float *img0, *img1;
   unsigned* epoch_word;       // bumped for the next step's in-launch hand-offs
+  SlabX sx;
   int mbegin[kMaxImgMap], mend[kMaxImgMap];   // the ranges again, adjacent: one round of scalar loads finds the entry
   ImgMap map[kMaxImgMap];
 };
@@ -559,13 +571,14 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
     vv = *reinterpret_cast<const float4*>(a.v + i4);
   }
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s0 = 0; s0 < a.nslab; s0 += 8) {
+  const int nsl = slab_count(a.sx, i4, a.nslab);
+  for (int s0 = 0; s0 < nsl; s0 += 8) {
     float4 o[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = *reinterpret_cast<const float4*>(a.slabs + (long long)min(s0 + j, a.nslab - 1) * a.P + i4);
+    for (int j = 0; j < 8; ++j) o[j] = *reinterpret_cast<const float4*>(a.slabs + (long long)min(s0 + j, nsl - 1) * a.P + i4);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float w = s0 + j < a.nslab ? 1.f : 0.f;
+      const float w = s0 + j < nsl ? 1.f : 0.f;
       g.x += w * o[j].x; g.y += w * o[j].y; g.z += w * o[j].z; g.w += w * o[j].w;
     }
   }

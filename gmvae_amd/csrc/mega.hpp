@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
           const float lp = lgv[j] - l2;
           ne += fexp(lp) * lp;
           P_y[row * K + k] = yv;
-          if (ok && lead) a.y[(long long)(r0 + row) * K + k] = yv;
+          if (ok && lead) a.y[(long long)(r0 + row) * K2 + k] = yv;        // rows of pad4(K) floats
         }
         A_y[k * kLDA + row] = yv;
       }
@@ -987,7 +987,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
         if (k < K && ok) {
           const float lp = lgv[j] - l2;
           dl = yv[j] * (P_dy[row * KP + k] - dot) * a.invT + fexp(lp) * (lp - ne);
-          a.dlogits[(long long)(r0 + row) * K + k] = dl;
+          a.dlogits[(long long)(r0 + row) * K2 + k] = dl;
         }
         A_dl[k * kLDA + row] = dl;
       }
