@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--data-dim", type=int, default=784)
     ap.add_argument("--n-samples", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
-    ap.add_argument("--graph-steps", type=int, default=16, help="consecutive steps captured in one hipGraph launch")
+    ap.add_argument("--graph-steps", type=int, default=40, help="consecutive steps captured in one hipGraph launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--levels", action="store_true", help="also print the per-launch table to stderr")
