@@ -690,11 +690,14 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   if (nloc > 0) issue_chunk(0);
   unsigned long long tseg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = a.dbg ? __builtin_amdgcn_s_memtime() : 0;   // diagnostic only
 #define GMVAE_SEG(i) if (a.dbg) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tseg[i] += tn_ - tprev; tprev = tn_; }
+  // the backward chain's weight image was overwritten by the ring: its first part returns during the last chunk
+  const int pre_img = (lead && nloc > 0 && ((nloc - 1) & 1)) ? min(f.img, f.chunk) : 0;
   for (int i = 0; i < nloc; ++i) {
     dma_wait();
     __syncthreads();                            // chunk i landed; A_g and buffer (i+1)&1 are free
     GMVAE_SEG(0);
     if (i + 1 < nloc) issue_chunk(i + 1);
+    else if (lead && (i & 1)) dma_copy_m(sm, a.img, pre_img, wave, lane);   // last chunk sits in buffer 1: buffer 0 is free
     GMVAE_SEG(4);
     const float* Wc = sm + f.ring + (i & 1) * f.chunk;
     const unsigned char* xc = xring + (i & 1) * kPanel * kCW;
@@ -791,7 +794,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     return;
   }
   // ======================================================================= B: backward chain
-  dma_copy_m(sm, a.img, f.img, wave, lane);      // the ring overwrote the small-weight image
+  dma_copy_m(sm + pre_img, a.img + pre_img, f.img - pre_img, wave, lane);      // the rest of the small-weight image
   if (ln == 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) nllp2[wave * kPanel + lk * 4 + r] = rs[r];
