@@ -305,8 +305,6 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
 #define GMVAE_FL(i) if (a.dbg && a.fine == 4 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime()
 #define GMVAE_FS(i) if (a.dbg && a.fine >= 2 && a.fine != 4 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime()
   // ======================================================================= F: forward chain
-  for (int rep_ = 0; rep_ < (a.fine == 3 ? 2 : 1); ++rep_) {     // diagnostic: a second, instruction-cache-warm pass
-  if (rep_) { __syncthreads(); GMVAE_STAMP(0); }
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (FLT) {
     // ---------------------------------------------------------------- FL: first layer over this quarter's columns
@@ -315,11 +313,75 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     float* const A_x = sm + f.fl_A;
     const int k0 = q * KQ;
     const int kn = max(0, min(KQ, D - k0));        // rows of this quarter that exist (the last quarter may be short)
+    const unsigned epoch_fl = *a.epoch_word;
+    const unsigned long long step = a.step_dev[0];
+    const int qe = kPanel * L / 4, qu = gm ? kPanel * K / 4 : 0;
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ntile = H2f / 16, tpw = H / 16;      // tiles; tiles per weight tensor
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    unsigned xw[2];                                // this thread's x bytes: (row, 4 consecutive columns), <= 2 items
+    auto x_store = [&]() {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int i = tid + it * kMT;
+        if (i < kPanel * kq4) {
+          const int row = i / kq4, k4 = (i - row * kq4) * 4;
+          const unsigned w = xw[it];               // row-major [16][kFlLda]: consecutive lanes, consecutive 16 bytes
+          float2* const dst = reinterpret_cast<float2*>(A_x + row * kFlLda + k4);
+          dst[0] = make_float2((float)(w & 0xff), (float)((w >> 8) & 0xff));
+          dst[1] = make_float2((float)((w >> 16) & 0xff), (float)(w >> 24));
+        }
+      }
+    };
+    auto noise_draw = [&]() {
+      // this panel's rows of the Philox streams (the values gmvae_noise_fill produces for the same seed and step),
+      // drawn while the loads are in flight and parked in registers until the staging area is dead
+      if (tid < qe + qu) {
+        const bool is_u = tid >= qe;
+        const int li = is_u ? tid - qe : tid;
+        noise_vals((unsigned long long)(is_u ? (long long)r0 * K / 4 : (long long)r0 * L / 4) + li, is_u, a.seed, step, nz);
+      }
+    };
+    if constexpr (HT == 64 && DT == 784 && MODEL == 2) {
+      // Specialised sizes: 49 bursts of 4 rows per tensor, staged as 2 sub-chunks (24 and 25 bursts per tensor);
+      // every wave issues exactly 6 + 7 bursts (straight-line code, so the vmcnt below is a constant) and the MFMAs
+      // of the first half run while the second is still landing.  (4 sub-chunks spilled registers and lost 3 us.)
+      const int row_ = lane >> 4, piece = lane & 15;
+      const int src = row_ * 64 + ((piece ^ ((row_ & 1) << 2)) << 2);
+      auto burst = [&](const int first, const int b, const int per) {      // b-th burst of a sub-chunk, `per` per tensor
+        const int t = b / per, idx = first + b % per;
+        __builtin_amdgcn_global_load_lds((t ? a.w0b : a.w0a) + (long long)k0 * H + (idx << 8) + src, Wst + t * KQ * H + (idx << 8), 16,
+                                         0, 0);
+      };
+#pragma unroll
+      for (int j = 0; j < 6; ++j) burst(0, wave + 8 * j, 24);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {             // always two loads per thread (clamped): uniform vmcnt accounting
+        const int i = min(tid + it * kMT, kPanel * kq4 - 1);
+        const int row = i / kq4, k4 = (i - row * kq4) * 4;
+        const unsigned wv = *reinterpret_cast<const unsigned*>(a.x + (long long)min(r0 + row, B - 1) * D + k0 + k4);
+        xw[it] = row < nrow ? wv : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < 7; ++j) burst(24, min(wave + 8 * j, 49), 25);    // 50 bursts: waves 2..7 repeat the last one
+      noise_draw();
+      // (no diagnostic stamp in here: a stamp is a global store, younger than the bursts, and would be counted)
+      asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                      // the first half and the x bytes are in
+      x_store();
+      __syncthreads();
+      const int tl = wave & 3;
+      const int swz = ((tl * 16 + ln) ^ ((lk & 1) << 4)) - (tl * 16 + ln);  // this lane's k rows are all odd or all even
+      const float* const Wt = (wave < 4 ? Wst : Wst + KQ * H) + swz;
+      acc = tile_ksteps<1, kFlLda>(A_x, Wt, H, 1, tl, 0, 24, 24, lane, acc);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      GMVAE_FL(4);
+      acc = tile_ksteps<1, kFlLda>(A_x, Wt, H, 1, tl, 24, 49, 49, lane, acc);
+    } else {
     const int rot = ((pnl >> 3) * 6) % max(1, (kn * H) >> 8);
     dma_stage_w(Wst, a.w0a + (long long)k0 * H, kn * H, rot, wave, lane);
     if (gm) dma_stage_w(Wst + KQ * H, a.w0b + (long long)k0 * H, kn * H, rot, wave, lane);
     GMVAE_FL(0);
-    unsigned xw[2];                                // this thread's x bytes: (row, 4 consecutive columns), <= 2 items
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int i = tid + it * kMT;
@@ -328,44 +390,23 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       if (i < kPanel * kq4 && row < nrow && k4 < kn)
         xw[it] = *reinterpret_cast<const unsigned*>(a.x + (long long)(r0 + row) * D + k0 + k4);
     }
-    const unsigned epoch_fl = *a.epoch_word;
     GMVAE_FL(1);
-    // this panel's rows of the Philox streams (the values gmvae_noise_fill produces for the same seed and step),
-    // drawn while the loads above are in flight and parked in registers until the staging area is dead
-    const unsigned long long step = a.step_dev[0];
-    const int qe = kPanel * L / 4, qu = gm ? kPanel * K / 4 : 0;
-    float nz[4] = {0.f, 0.f, 0.f, 0.f};
-    if (tid < qe + qu) {
-      const bool is_u = tid >= qe;
-      const int li = is_u ? tid - qe : tid;
-      noise_vals((unsigned long long)(is_u ? (long long)r0 * K / 4 : (long long)r0 * L / 4) + li, is_u, a.seed, step, nz);
-    }
+    noise_draw();
     GMVAE_FL(2);
     if (kn < KQ) {                                 // zero the staging rows past D (their x columns are zero: no NaN * 0)
       for (int i = kn * H + tid; i < KQ * H; i += kMT) { Wst[i] = 0.f; if (gm) Wst[KQ * H + i] = 0.f; }
     }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int i = tid + it * kMT;
-      if (i < kPanel * kq4) {
-        const int row = i / kq4, k4 = (i - row * kq4) * 4;
-        const unsigned w = xw[it];                 // row-major [16][kFlLda]: consecutive lanes, consecutive 16 bytes
-        float2* const dst = reinterpret_cast<float2*>(A_x + row * kFlLda + k4);
-        dst[0] = make_float2((float)(w & 0xff), (float)((w >> 8) & 0xff));
-        dst[1] = make_float2((float)((w >> 16) & 0xff), (float)(w >> 24));
-      }
-    }
+    x_store();
     GMVAE_FS(0);
     GMVAE_FL(3);
     dma_wait();
     __syncthreads();
     GMVAE_FL(4);
-    const int ntile = H2f / 16, tpw = H / 16;      // tiles; tiles per weight tensor
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (wave < ntile) {
       const int tl = wave < tpw ? wave : wave - tpw;
       const int swz = ((tl * 16 + ln) ^ ((lk & 1) << 4)) - (tl * 16 + ln);      // this lane's k rows are all odd or all even
       acc = tile_ksteps<1, kFlLda>(A_x, (wave < tpw ? Wst : Wst + KQ * H) + swz, H, 1, tl, 0, kq4, kq4, lane, acc);
+    }
     }
     GMVAE_FL(5);
     const int ngr = kPanel * H2f;
@@ -385,41 +426,42 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       *reinterpret_cast<float4*>((is_u ? P_u : P_eps) + (is_u ? tid - qe : tid) * 4) = make_float4(nz[0], nz[1], nz[2], nz[3]);
     }
     if (bid == gridDim.x - 1 && tid == 0) a.step_dev[1] = step;       // the copy finalize_adam reads
-    // the other quarters' partials: all 12 granules of a lane are requested together and re-read until every tag
-    // carries this step's epoch; summed in quarter order (every workgroup of the panel gets the same bits)
+    // the quarters' partials (this workgroup's own included), two quarters per sweep: 8 granules of a lane are
+    // requested together and re-read until every tag carries this step's epoch; summed in quarter order, so every
+    // workgroup of the panel gets the same bits
     float flt[4] = {0.f, 0.f, 0.f, 0.f};
     if (wave < ntile) {
-      const unsigned long long* xp = a.xfl + (long long)pnl * 4 * ngr;
-      unsigned long long gv[4][4];
-      unsigned spins = 0;
-      for (;;) {
-        bool ok = true;
+      const unsigned long long* xp = a.xfl + (long long)pnl * 4 * ngr + (lk * 4) * H2f + wave * 16 + ln;
 #pragma unroll
-        for (int pq = 0; pq < 4; ++pq) {
+      for (int half = 0; half < 2; ++half) {
+        unsigned long long gv[2][4];
+        unsigned spins = 0;
+        for (;;) {
+          bool ok = true;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            gv[pq][r] = __hip_atomic_load(xp + (long long)pq * ngr + (lk * 4 + r) * H2f + wave * 16 + ln, __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT);
-            ok = ok && (unsigned)(gv[pq][r] >> 32) == epoch_fl;
+          for (int pq = 0; pq < 2; ++pq) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              gv[pq][r] = __hip_atomic_load(xp + (long long)(2 * half + pq) * ngr + r * H2f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok = ok && (unsigned)(gv[pq][r] >> 32) == epoch_fl;
+            }
           }
+          if (__all(ok)) break;
+          if (++spins > (1u << 22)) {
+            if (lane == 0) atomicExch(a.err_word, 1u);
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) gv[pq][r] = 0x7fc00000ull;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
         }
-        if (__all(ok)) break;
-        if (++spins > (1u << 22)) {
-          if (lane == 0) atomicExch(a.err_word, 1u);
 #pragma unroll
-          for (int pq = 0; pq < 4; ++pq)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gv[pq][r] = 0x7fc00000ull;
-          break;
+        for (int r = 0; r < 4; ++r) {
+          flt[r] += __uint_as_float((unsigned)gv[0][r]);
+          flt[r] += __uint_as_float((unsigned)gv[1][r]);
         }
-        __builtin_amdgcn_s_sleep(2);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = 0.f;
-#pragma unroll
-        for (int pq = 0; pq < 4; ++pq) t += __uint_as_float((unsigned)gv[pq][r]);
-        flt[r] = t;
       }
     }
     GMVAE_FL(7);
@@ -479,6 +521,10 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       }
     }
   }
+  {                               // (closes at the end of the kernel) laundered thread index, see phase B
+  int tidf_ = threadIdx.x;
+  asm volatile("" : "+v"(tidf_));
+  const int tid = tidf_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 15, lk = lane >> 4;
   if (gmp) {                      // mixture constants: 1/s, log-softmax weights, per-component constant
     for (int i = tid; i < K * L; i += kMT) {
       const int k = i / L, l = i - k * L;
@@ -666,9 +712,12 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   });
   __syncthreads();                 // the small-weight image is dead from here until phase B
   GMVAE_STAMP(4);
-  }
 
   // ======================================================================= D: decoder output, streamed
+  {                                              // (closes at the end of the kernel)
+  int tidd_ = threadIdx.x;                       // laundered thread index (see phase B)
+  asm volatile("" : "+v"(tidd_));
+  const int tid = tidd_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 15, lk = lane >> 4;
   const int nch = f.nch, ldc = f.ldc;
   auto issue_chunk = [&](int i) {             // i = local index; chunk c = q + i * Q
     const int c = q + i * Q;
@@ -794,6 +843,13 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     return;
   }
   // ======================================================================= B: backward chain
+  // The thread index is "laundered" at the phase boundary: index arithmetic of this phase can then not be merged
+  // with (and hoisted to) the kernel's start, where it used to stay live across every other phase and spill.
+  {
+  int tidb_ = threadIdx.x;
+  asm volatile("" : "+v"(tidb_));
+  const int tid = tidb_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 15, lk = lane >> 4;
+  const int dtile = wave & 3, dhalf = wave >> 2;
   dma_copy_m(sm + pre_img, a.img + pre_img, f.img - pre_img, wave, lane);      // the rest of the small-weight image
   if (ln == 0) {
 #pragma unroll
@@ -1002,6 +1058,9 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     if (row < nrow) a.dhy1[(long long)(r0 + row) * H + col] = P_hy[row * H + col] > 0.f ? v : 0.f;
   });
   GMVAE_STAMP(7);
+  }
+  }
+  }
 }
 
 }  // namespace gmvae
