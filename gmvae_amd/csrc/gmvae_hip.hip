@@ -510,15 +510,16 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
   float* sl = w.slabs;
   const bool gmp = a.model == GMVAE_MODEL_VAE_GMP;
   const float* nent = a.model == GMVAE_MODEL_GMVAE ? w.nent : nullptr;
-  if (a.adam_p && a.step_dev && !gmp) {   // graph path: slab reduce + loss tail + Adam in one launch
+  if (!gmp && (!a.adam_p || a.step_dev)) {   // slab reduce + loss tail (+ TF-Adam in the train-graph path) in one launch
     FinalArgs fa;
+    memset(&fa, 0, sizeof(fa));
     fa.slabs = sl; fa.nslab = NS; fa.P = PP; fa.grads = a.grads; fa.p = a.adam_p; fa.m = a.adam_m; fa.v = a.adam_v;
-    fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = 1; fa.count = (float)B;
+    fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = a.adam_p ? 1 : 0; fa.count = (float)B;
     fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = nent;
     fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
     fa.nmap = 0; fa.map_lo = fa.map_hi = 0; fa.img0 = fa.img1 = nullptr; fa.epoch_word = nullptr;
     fa.sx = sx;
-    if (mega_ok(d, a.model) && a.adam_p == a.params) {      // the next step's weight images ride on the update
+    if (mega_ok(d, a.model) && a.adam_p && a.adam_p == a.params) {      // the next step's weight images ride on the update
       const MegaLay ml = mega_lay(d.hidden[0], d.L, d.K, d.D, a.model);
       ImgPlan pl;
       plan_images(d, a.model, L, w, ml, a.params, pl);
@@ -529,7 +530,7 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
       }
     }
     hipLaunchKernelGGL(finalize_adam, dim3((unsigned)((PP / 4 + 255) / 256) + 1), dim3(256), 0, st, fa);
-    rowk(cx, "finalize_adam");
+    rowk(cx, a.adam_p ? "finalize_adam" : "finalize_grads+loss_tail");
     return cx.err;
   }
   hipLaunchKernelGGL(loss_tail, dim3(1), dim3(1024), 0, st, w.logw, w.logpx, w.logq, w.logp, nent, (float*)nullptr, tail,
