@@ -159,7 +159,7 @@ def main():
     if world == 1:
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < 0.75:
-            run_steps(64)
+            run_steps(2 * G)
             torch.cuda.synchronize()
     else:
         # every rank must issue the SAME number of steps (each contains a collective): fixed count, not wall time
@@ -209,13 +209,16 @@ def main():
                 "step_flops_alg": step_flops, "step_tflops_alg": step_flops / (dt / a.steps) * 1e-12,
                 "step_frac_of_mfma_peak": step_flops / (dt / a.steps) * 1e-12 / PEAK_F32_MFMA_TFLOPS,
                 "launches_per_step": len(levels), "sum_kernel_usec": sum_us,
+                "timing": "in-kernel wall-clock stamps (s_memrealtime): last workgroup end - first workgroup start, "
+                          "steady-state step replayed inside a hipGraph" if world == 1 else "hipEvents around eager launches",
                 "levels": [[nm, round(us, 2)] for nm, us, _ in levels]}
         # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE;
         # rocprofv3 --pmc cannot run inside this process): profiles/round1_traffic.json, same workload only
         try:
             if (a.model, B, a.hidden, a.layers, a.latent, a.components, a.data_dim, a.n_samples) == ("gmvae", 1024, 64, 1, 64, 10, 784, 1):
                 tj = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))
-                key = [k for k in tj if k.startswith("gmvae::mega_fwd_bwd")] if dom[0].startswith("mega") else []
+                # the instance that runs the first layer itself (template argument FLT = 1): the steady-state launch
+                key = [k for k in tj if "mega_fwd_bwd<64, 64, 10, 784, 2, 1>" in k] if dom[0].startswith("mega") else []
                 if key:
                     roof["traffic"] = tj[key[0]]["hbm_bytes_per_launch"]
                     roof["traffic_source"] = "profiles/round1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"

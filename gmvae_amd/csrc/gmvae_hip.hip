@@ -124,6 +124,7 @@ struct WS {
   unsigned long long* stamps;   // diagnostic stamps of the chain kernels: [2][grid][16]
   unsigned long long* xchg;     // mega_fwd_bwd's in-launch hand-off granules: [panels][Q-1][16*H + 16]
   unsigned long long* xfl;      // mega_fwd_bwd's first-layer exchange granules: [panels][4][16 * H2]
+  unsigned long long* spans;    // measurement: [2 kernels][2048 blocks][2] wall-clock stamps (mega_fwd_bwd, finalize_adam)
   unsigned long long* gstamps;  // diagnostic stamps of the grouped-GEMM launches: [4 launches][2048 blocks][8]
   unsigned* sync;               // [0] = per-step epoch of the hand-off, [1] = hand-off timeout flag
   float *img_f, *img_b;         // per-step LDS weight images of chain_fwd / chain_bwd (prepared by aux blocks)
@@ -247,6 +248,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     if (ml.fl_ok)
       w.xfl = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * 4 * kPanel * 2 * d.hidden[0]));
     w.gstamps = reinterpret_cast<unsigned long long*>(take(2ull * 4 * 2048 * 8));
+    w.spans = reinterpret_cast<unsigned long long*>(take(2ull * 2 * 2048 * 2));
   }
   w.dz = take(R * Lz);
   w.dqp = take(R * 2 * Lz);
@@ -321,6 +323,7 @@ struct Prof {
   char name[MAX_LEVELS][48];
   double flops[MAX_LEVELS];
   bool active = false;
+  bool events = true;      // false: only names and FLOPs are collected (the launches time themselves)
 };
 
 struct Ctx {
@@ -334,7 +337,7 @@ struct Ctx {
     snprintf(prof->name[prof->n], sizeof(prof->name[0]), "%s", name);
     prof->flops[prof->n] = flops;
     prof->n++;
-    hipEventRecord(prof->ev[prof->n], st);
+    if (prof->events) hipEventRecord(prof->ev[prof->n], st);
   }
   void check() {
     if (!err) {
@@ -426,6 +429,7 @@ struct StepArgs {
   // the previous step of the same graph ran finalize_adam with the image scatter on this workspace and nothing
   // touched the parameters since: the step may skip its first launch (mega_fwd_bwd runs the first layer itself)
   bool imgs_ready = false;
+  bool want_spans = false;     // measurement: every launch of the step records per-workgroup wall-clock stamps
 };
 
 static void rowk(Ctx& cx, const char* name) {
@@ -519,6 +523,7 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
     fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
     fa.nmap = 0; fa.map_lo = fa.map_hi = 0; fa.img0 = fa.img1 = nullptr; fa.epoch_word = nullptr;
     fa.sx = sx;
+    fa.span = (a.want_spans && w.spans) ? w.spans + 2048 * 2 : nullptr;
     if (mega_ok(d, a.model) && a.adam_p && a.adam_p == a.params) {      // the next step's weight images ride on the update
       const MegaLay ml = mega_lay(d.hidden[0], d.L, d.K, d.D, a.model);
       ImgPlan pl;
@@ -618,6 +623,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     c.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
     c.Q = Qm; c.xchg = w.xchg; c.epoch_word = w.sync; c.err_word = w.sync + 1;
     c.dbg = getenv("GMVAE_STAMPS") ? w.stamps : nullptr;
+    c.span = a.want_spans ? w.spans : nullptr;
     c.fine = getenv("GMVAE_STAMPS") ? atoi(getenv("GMVAE_STAMPS")) : 0;
     // the reference's default sizes (run_gmvae.py: latent 64, hidden 64, K 10; MNIST D 784) run a specialised instance
     typedef void (*MegaFn)(const MegaArgs);
@@ -672,7 +678,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     g.add(p_tn(w.z, false, Lz, 1, w.dbuf[0], H, Lz, H, B, sl + Dn.w[0], sl + Dn.b[0], NS2, PP, nullptr));         // dWd0
     if (NS2 == NS) sx.n = 0;
     launch_group(cx, g, "bwd_dw_all", env_cfg("GMVAE_DW_CFG", B >= 512 ? (NS2 != NS ? 3 : 1) : 0),
-                 getenv("GMVAE_STAMPS") ? w.gstamps + 2048 * 8 : nullptr);
+                 (getenv("GMVAE_STAMPS") || a.want_spans) ? w.gstamps + 2048 * 8 : nullptr);
   }
   return finish_fused(cx, a, L, w, tail, NS2, B, &sx);
 }
@@ -1293,24 +1299,78 @@ int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, floa
   for (int i = 0; i <= MAX_LEVELS; ++i) hipEventCreate(&pr->ev[i]);
   double acc[MAX_LEVELS] = {0};
   int rc = 0;
-  for (int it = 0; it <= iters && rc == 0; ++it) {      // it = 0: untimed, leaves the weight images behind
-    Ctx cx;
-    cx.st = st;
-    cx.prof = pr;
-    pr->n = 0;
-    pr->active = it > 0;
-    if (it > 0) hipEventRecord(pr->ev[0], st);
-    StepArgs a = {dims, model, x, nullptr, nullptr, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
-                  seed, 0, step_dev, true};
-    a.adam_p = params; a.adam_m = m; a.adam_v = v; a.lr = lr; a.imgs_ready = it > 0;
-    rc = run_step(cx, a);
+  // Two steps in ONE captured graph: an untimed one that leaves the weight images behind, then the steady-state
+  // step, whose launches record per-workgroup wall-clock stamps (s_memrealtime, 100 MHz, one clock for the whole
+  // device): a launch's duration is last end - first start over its workgroups.  Replayed `iters` times, so the
+  // kernels run back to back as in the train graph.  (hipEventRecord nodes inside a captured graph return no
+  // elapsed time on this stack, and eager launches with events in between add ~10 us of idle per launch.)
+  if (!mega_ok(*dims, model)) { delete pr; return GMVAE_E_DIMS; }
+  pr->events = false;
+  Layout L;
+  build_layout(*dims, model, L);
+  WS w;
+  carve(*dims, model, L, workspace, w);
+  hipStream_t cs = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  auto two_steps = [&](hipStream_t s) {
+    for (int it = 0; it < 2 && rc == 0; ++it) {
+      Ctx cx;
+      cx.st = s;
+      cx.prof = pr;
+      pr->n = 0;
+      pr->active = it > 0;
+      StepArgs a = {dims, model, x, nullptr, nullptr, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
+                    seed, 0, step_dev, true};
+      a.adam_p = params; a.adam_m = m; a.adam_v = v; a.lr = lr; a.imgs_ready = it > 0; a.want_spans = it > 0;
+      rc = run_step(cx, a);
+    }
+  };
+  bool graphed = false;
+  if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess) {
+    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      two_steps(cs);
+      const hipError_t he = hipStreamEndCapture(cs, &graph);
+      if (rc == 0 && he == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) graphed = true;
+    }
+    (void)hipGetLastError();
+  }
+  if (!graphed) rc = 0;
+  const size_t nsp = 2 * 2048 * 2, ngs = 2048 * 8;
+  unsigned long long* hsp = new unsigned long long[nsp + ngs];
+  for (int it = 0; it < iters && rc == 0; ++it) {
+    hipMemsetAsync(w.spans, 0, nsp * 8, st);
+    hipMemsetAsync(w.gstamps + 2048 * 8, 0, ngs * 8, st);
+    if (graphed) {
+      if (hipGraphLaunch(exec, st) != hipSuccess) { rc = (int)hipGetLastError(); break; }
+    } else {
+      two_steps(st);
+    }
     hipStreamSynchronize(st);
-    for (int i = 0; it > 0 && i < pr->n; ++i) {
-      float ms = 0.f;
-      hipEventElapsedTime(&ms, pr->ev[i], pr->ev[i + 1]);
-      acc[i] += ms * 1000.0;
+    hipMemcpy(hsp, w.spans, nsp * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(hsp + nsp, w.gstamps + 2048 * 8, ngs * 8, hipMemcpyDeviceToHost);
+    auto span_of = [&](const unsigned long long* p, int stride, int e_off) {
+      unsigned long long lo = ~0ull, hi = 0;
+      for (int b = 0; b < 2048; ++b) {
+        const unsigned long long s0 = p[(size_t)b * stride], s1 = p[(size_t)b * stride + e_off];
+        if (!s0 || !s1) continue;
+        lo = s0 < lo ? s0 : lo;
+        hi = s1 > hi ? s1 : hi;
+      }
+      return hi > lo ? (double)(hi - lo) * 0.01 : 0.0;          // 100 MHz ticks -> microseconds
+    };
+    for (int i = 0; i < pr->n; ++i) {
+      double us = 0.0;
+      if (!strncmp(pr->name[i], "mega_fwd_bwd", 12)) us = span_of(hsp, 2, 1);
+      else if (!strncmp(pr->name[i], "bwd_dw_all", 10)) us = span_of(hsp + nsp, 8, 4);
+      else if (!strncmp(pr->name[i], "finalize_adam", 13)) us = span_of(hsp + 2048 * 2, 2, 1);
+      acc[i] += us;
     }
   }
+  delete[] hsp;
+  if (exec) hipGraphExecDestroy(exec);
+  if (graph) hipGraphDestroy(graph);
+  if (cs) hipStreamDestroy(cs);
   const int n = pr->n < max_levels ? pr->n : max_levels;
   *n_levels = n;
   for (int i = 0; i < n; ++i) {

@@ -514,11 +514,14 @@ struct FinalArgs {
   int nmap, map_lo, map_hi;
   float *img0, *img1;
   unsigned* epoch_word;       // bumped for the next step's in-launch hand-offs
+  unsigned long long* span;   // measurement: [block][2] wall-clock (100 MHz) at a block's first and last instruction
   SlabX sx;
   int mbegin[kMaxImgMap], mend[kMaxImgMap];   // the ranges again, adjacent: one round of scalar loads finds the entry
   ImgMap map[kMaxImgMap];
 };
 __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
+#define GMVAE_FIN_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
+  if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x] = wall_clock64();
   const int nb = gridDim.x - 1;
   if ((int)blockIdx.x == nb) {
     __shared__ float red[4][256];
@@ -542,6 +545,7 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
       if (a.step_dev) a.step_dev[0] = a.step_dev[1] + 1;
       if (a.epoch_word) *a.epoch_word += 1u;
     }
+    GMVAE_FIN_END();
     return;
   }
   const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
   unsigned e_magic = a.map[k0].magic;
   asm volatile("" ::"s"(hit), "s"(e_begin), "s"(e_end), "s"(e_cols), "s"(e_kind), "s"(e_base), "s"(e_ld), "s"(e_chunk),
                "s"(e_which), "s"(e_magic));
-  if (i4 >= a.P) return;
+  if (i4 >= a.P) { GMVAE_FIN_END(); return; }
   // every load of the block goes out before the first wait: parameters and moments, then up to 8 slabs at once
   // (the launch is one wave of blocks: its length is its chain of dependent memory round trips)
   float4 pp = make_float4(0.f, 0.f, 0.f, 0.f), mm = pp, vv = pp;
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
     }
   }
   *reinterpret_cast<float4*>(a.grads + i4) = g;
-  if (!a.do_adam) return;
+  if (!a.do_adam) { GMVAE_FIN_END(); return; }
   const unsigned long long t = (a.step_dev ? a.step_dev[1] : 0ull) + 1ull;
   const float lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, (double)t)) / (1.0 - pow((double)a.b1, (double)t)));
   const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, gs = 1.f / a.count;
@@ -623,6 +627,8 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
       e_magic = a.map[k].magic;
     }
   }
+  GMVAE_FIN_END();
+#undef GMVAE_FIN_END
 }
 
 // auxiliary work without a GEMM: the image tasks of the first step of a train graph

@@ -232,6 +232,7 @@ struct MegaArgs {
   const unsigned* epoch_word; // tag of this step (bumped by the first launch of the step)
   unsigned* err_word;         // set to 1 if a bounded spin gives up (results are then invalid)
   unsigned long long* dbg;
+  unsigned long long* span;   // measurement: [block][2] wall-clock (100 MHz) at a workgroup's first and last instruction
   int fine;                   // diagnostic: slots 8.. of a block's stamp record take intra-stage stamps instead
   MegaLay lay;                // mega_lay(H, L, K, D, model), computed once on the host
   // fl = 1: the launch also runs the first layer (no separate split-K GEMM launch, no noise / image launch):
@@ -263,6 +264,8 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   const int q = bid < nP * (Q - 1) ? 1 + bid / nP : 0;
   const int pnl = bid < nP * (Q - 1) ? bid % nP : bid - nP * (Q - 1);
   const int r0 = pnl * kPanel;
+  if (a.span && tid == 0) a.span[2 * bid] = wall_clock64();
+#define GMVAE_SPAN_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
   // The split-K partials of the first layer are the longest (coldest) wait of the launch: their loads go out
   // before anything else (the scheduling barrier keeps the ~1000 instructions of pointer set-up below them).
   const int H2f = gm ? 2 * H : H;
@@ -840,6 +843,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       __hip_atomic_store(xo + kPanel * H + row, ((unsigned long long)epoch << 32) | __float_as_uint(s_), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     }
+    GMVAE_SPAN_END();
     return;
   }
   // ======================================================================= B: backward chain
@@ -996,7 +1000,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       out[2 * KLp + k] = ga;
     }
   }
-  if (!gm) { GMVAE_STAMP(7); return; }
+  if (!gm) { GMVAE_STAMP(7); GMVAE_SPAN_END(); return; }
   __syncthreads();
   GMVAE_FS(7);
   // dy = dhg1 * Wg0[D:,:]^T + dpp * Wp^T : K = H then K = 2L, split over the 4 waves
@@ -1058,6 +1062,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     if (row < nrow) a.dhy1[(long long)(r0 + row) * H + col] = P_hy[row * H + col] > 0.f ? v : 0.f;
   });
   GMVAE_STAMP(7);
+  GMVAE_SPAN_END();
   }
   }
   }

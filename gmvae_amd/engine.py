@@ -362,7 +362,7 @@ class Engine:
 
     def profile_train_levels(self, x, lr: float = 1e-3, iters: int = 20):
         """Per-launch timing of the steady-state training step of a train graph (gmvae_train_profile).
-        Advances the optimizer by iters + 1 steps."""
+        Advances the optimizer by 2 * iters steps (each repetition is an untimed step + the timed one)."""
         x = self._prep_x(x)
         d, ws = self._workspace(x.shape[0])
         self.step_dev.fill_(self.global_step)
@@ -374,7 +374,7 @@ class Engine:
                                        L.ptr(self.grads), L.ptr(ws), self.noise_seed, L.ptr(self.step_dev), lr, iters, 96,
                                        C.byref(n), names, usec, flops, L.current_stream())
         L.check(rc, "gmvae_train_profile")
-        self.global_step += iters + 1
+        self.global_step += 2 * iters
         out = []
         for i in range(n.value):
             nm = names.raw[i * 48:(i + 1) * 48].split(b"\0")[0].decode()

@@ -171,8 +171,9 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
  * microseconds and the algorithmic FLOPs (2*M*N*K summed over its GEMMs,
  * 0 for row-local kernels).  Synchronises the stream: measurement only.
  * gmvae_train_profile does the same for the steady-state TRAINING step of a train graph (Philox noise, TF-Adam
- * fused into the last launch, first layer inside mega_fwd_bwd where that schedule applies): one untimed step
- * first, then `iters` timed ones; it advances params / m / v / *step_dev like `iters + 1` real steps. */
+ * fused into the last launch, first layer inside mega_fwd_bwd where that schedule applies): a two-step graph (an
+ * untimed step, then the timed one with an event-record node between its launches) replayed `iters` times, so the
+ * kernels run back to back as in a train graph; it advances params / m / v / *step_dev like 2 * iters real steps. */
 int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
                         float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, int iters,
                         int max_levels, int* n_levels, char* names, float* usec, double* flops, void* stream);
