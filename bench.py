@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--data-dim", type=int, default=784)
     ap.add_argument("--n-samples", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="start every step from raw uint8 pixels resident in HBM: the reference's dynamic binarisation "
+                         "(gmvae_binarize) runs inside the train graph (single GPU)")
     ap.add_argument("--graph-steps", type=int, default=40, help="consecutive steps captured in one hipGraph launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -132,7 +135,12 @@ def main():
             static_x, replay = eng.capture_train_step(B, lr=1e-3, all_reduce=world > 1)
             static_x.copy_(x)
             step_fn = replay
-            if G > 1:
+            if a.pipeline and world == 1:
+                from gmvae_amd.data import DeviceDataset
+                ds = DeviceDataset(np.random.default_rng(99).integers(0, 256, (60000, d.D), dtype=np.uint8), shuffle=True, seed=1)
+                multi_fn = eng.capture_train_pipeline(ds, B, lr=1e-3, n_steps=G)
+                step_fn = eng.capture_train_pipeline(ds, B, lr=1e-3, n_steps=1)
+            elif G > 1:
                 xs, multi_fn = eng.capture_train_step(B, lr=1e-3, all_reduce=world > 1, n_steps=G)
                 rng = np.random.default_rng(4321 + rank)
                 xs.copy_(torch.from_numpy((rng.random((G, B, d.D)) < 0.87).astype(np.uint8)))
@@ -243,7 +251,7 @@ def main():
             "config": {"workload": f"{a.model} train step (noise+fwd+bwd+allreduce+TF-Adam), D={d.D} K={d.K} "
                                    f"L={d.L} hidden={hidden} S={d.S}, batch {B}/GPU x {n_gpus} GPU "
                                    f"(BASELINE configs[{2 if n_gpus == 1 else 3}])",
-                       "global_batch": B * n_gpus, "parallelism": f"dp{n_gpus}", "hipgraph": use_graph,
+                       "global_batch": B * n_gpus, "parallelism": f"dp{n_gpus}", "hipgraph": use_graph, "input_pipeline_on_device": bool(a.pipeline and world == 1),
                        "all_reduce": getattr(eng, "dp_mode", None), "replicas_identical": replicas_identical},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "final_loss": final_tail[0] / max(final_tail[4], 1.0),

@@ -60,6 +60,7 @@ def _load():
         "gmvae_gemm_test": ([vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
         "gmvae_bench_loop": ([dp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(f32), vp], i32),
         "gmvae_train_graph_create": ([dp, i32, vp, i32, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, C.POINTER(vp)], i32),
+        "gmvae_train_graph_create_pipeline": ([dp, i32, vp, u64, vp, vp, i32, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, C.POINTER(vp)], i32),
         "gmvae_train_graph_launch": ([vp, vp], i32),
         "gmvae_train_graph_destroy": ([vp], i32),
         "gmvae_comm_unique_id": ([C.c_char_p, vp], i32),
@@ -68,6 +69,7 @@ def _load():
         "gmvae_dp_step": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, vp, vp], i32),
         "gmvae_dp_graph_create": ([dp, i32, vp, i32, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, vp, C.POINTER(vp)], i32),
         "gmvae_workspace_offset": ([dp, i32, C.c_char_p, C.POINTER(u64)], i32),
+        "gmvae_binarize": ([vp, u64, vp, u64, i32, i32, u64, u64, vp, vp, vp], i32),
         "gmvae_kernel_occupancy": ([i32, C.POINTER(i32)], i32),
         "gmvae_train_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),
         "gmvae_step_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),

@@ -1157,6 +1157,18 @@ int gmvae_noise_fill(float* eps, uint64_t n_eps, float* u, uint64_t n_u, uint64_
   return (int)hipGetLastError();
 }
 
+int gmvae_binarize(const uint8_t* pixels, uint64_t n_rows, const int32_t* idx, uint64_t row0, int B, int D,
+                   uint64_t seed, uint64_t step, const uint64_t* step_dev, uint8_t* x_out, void* stream) {
+  if (!pixels || !x_out) return GMVAE_E_NULL;
+  if (B < 1 || D < 4 || (D & 3) || n_rows < 1 || (!idx && row0 + (uint64_t)B > n_rows)) return GMVAE_E_DIMS;
+  if ((reinterpret_cast<uintptr_t>(pixels) & 3) || (reinterpret_cast<uintptr_t>(x_out) & 3)) return GMVAE_E_ALIGN;
+  (void)hipGetLastError();
+  const uint64_t q = (uint64_t)B * (D >> 2);
+  hipLaunchKernelGGL(binarize_rows, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), pixels,
+                     idx, row0, n_rows, B, D, seed, step, step_dev, x_out);
+  return (int)hipGetLastError();
+}
+
 int gmvae_mlp_forward(const GmvaeDims* dims, int model, int net, const void* in, int in_is_u8, const float* in2,
                       int rows, const float* params, float* out, void* workspace, void* stream) {
   if (int e = check_dims(dims, model)) return e;
@@ -1450,12 +1462,14 @@ struct GmvaeTrainGraph {
   hipGraphExec_t exec = nullptr;
 };
 
-int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, int n_steps, float* params, float* m,
-                             float* v, float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr,
-                             float beta1, float beta2, float epsilon, void** graph_out) {
+static int train_graph_create(const GmvaeDims* dims, int model, const uint8_t* pixels, uint64_t n_rows, const int32_t* idx,
+                              uint8_t* x, int n_steps, float* params, float* m, float* v, float* grads, void* workspace,
+                              uint64_t seed, uint64_t* step_dev, float lr, float beta1, float beta2, float epsilon,
+                              void** graph_out) {
   if (int e = check_dims(dims, model)) return e;
   if (!x || !params || !m || !v || !grads || !workspace || !step_dev || !graph_out) return GMVAE_E_NULL;
   if (n_steps < 1 || n_steps > 1024) return GMVAE_E_DIMS;
+  if (pixels && (!idx || n_rows < 1 || (dims->D & 3))) return GMVAE_E_DIMS;
   const size_t xstride = (size_t)dims->B * dims->D;
   Layout L;
   build_layout(*dims, model, L);
@@ -1468,7 +1482,11 @@ int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x,
   if (he != hipSuccess) rc = (int)he;
   if (rc == 0) {
     for (int s = 0; s < n_steps && rc == 0; ++s) {
-      const uint8_t* xs = x + s * xstride;
+      uint8_t* xs = x + s * xstride;
+      if (pixels)   // the input pipeline's step: this batch's rows, binarised with the step's own uniforms
+        rc = gmvae_binarize(pixels, n_rows, idx + (size_t)s * dims->B, 0, dims->B, dims->D, seed ^ 0x62696e6172697a65ull, 0, step_dev,
+                            xs, cs);
+      if (rc) break;
       if (fused_ok(*dims, model) || mega_ok(*dims, model)) {
         // every step after the first finds its weight images written by the step before it (same graph, nothing in between)
         rc = step_with_adam(dims, model, xs, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, cs, s > 0);
@@ -1494,6 +1512,22 @@ int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x,
   }
   *graph_out = tg;
   return 0;
+}
+
+int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, int n_steps, float* params, float* m,
+                             float* v, float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr,
+                             float beta1, float beta2, float epsilon, void** graph_out) {
+  return train_graph_create(dims, model, nullptr, 0, nullptr, const_cast<uint8_t*>(x), n_steps, params, m, v, grads, workspace,
+                            seed, step_dev, lr, beta1, beta2, epsilon, graph_out);
+}
+
+int gmvae_train_graph_create_pipeline(const GmvaeDims* dims, int model, const uint8_t* pixels, uint64_t n_rows,
+                                      const int32_t* idx, uint8_t* x_scratch, int n_steps, float* params, float* m, float* v,
+                                      float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr,
+                                      float beta1, float beta2, float epsilon, void** graph_out) {
+  if (!pixels || !idx) return GMVAE_E_NULL;
+  return train_graph_create(dims, model, pixels, n_rows, idx, x_scratch, n_steps, params, m, v, grads, workspace, seed, step_dev,
+                            lr, beta1, beta2, epsilon, graph_out);
 }
 
 int gmvae_train_graph_launch(void* graph, void* stream) {

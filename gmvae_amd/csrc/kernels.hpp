@@ -28,6 +28,33 @@ __global__ void noise_fill(float* eps, uint64_t n_eps, float* u, uint64_t n_u, u
   noise_item((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, eps, n_eps, u, n_u, seed, step);
 }
 
+// Dynamic binarisation of the input pipeline (scripts/runners.py:48-51 `_preprocess`):
+//   image = cast(pixel, float32) / 255.;  x = image < uniform(shape)        (so P[x = 1] = 1 - pixel/255)
+// drawn anew for every step (tf.data re-runs the map on every pass).  One thread -> 4 consecutive pixels of one
+// output row: one 4-byte load, one Philox4x32-10 call (counter = output quad index, stream tag 0x40000000, key =
+// seed, (step)), one 4-byte store.  HBM-bound byte work: D + D bytes per row.
+__global__ void binarize_rows(const unsigned char* __restrict__ pixels, const int32_t* __restrict__ idx, uint64_t row0,
+                              uint64_t n_rows_src, int B, int D, uint64_t seed, uint64_t step,
+                              const uint64_t* step_dev, unsigned char* __restrict__ x) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // quad of the output [B][D]
+  const int qpr = D >> 2;
+  if (q >= (uint64_t)B * qpr) return;
+  if (step_dev) step = *step_dev;
+  const int b = (int)(q / qpr), d4 = (int)(q - (uint64_t)b * qpr) << 2;
+  uint64_t r = idx ? (uint64_t)idx[b] : row0 + b;
+  r = r < n_rows_src ? r : n_rows_src - 1;
+  const uint32_t w = *reinterpret_cast<const uint32_t*>(pixels + r * D + d4);
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32) | 0x40000000u, (uint32_t)step, (uint32_t)(step >> 32)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  uint32_t o = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float img = (float)((w >> (8 * j)) & 0xff) / 255.f;               // IEEE division, as TF's RealDiv
+    o |= (img < u01(c[j]) ? 1u : 0u) << (8 * j);
+  }
+  *reinterpret_cast<uint32_t*>(x + (uint64_t)b * D + d4) = o;
+}
+
 // ------------------------------------------------ q(y|x): Gumbel-softmax head
 // RelaxedOneHotCategorical.sample (scripts/base.py:206-209, gmvae.py:240):
 //   g = -log(-log u); y = softmax((logits + g)/T)

@@ -341,6 +341,43 @@ class Engine:
         self._graphs[key] = (static_x, replay, handle)
         return static_x, replay
 
+    BINARIZE_SEED_XOR = 0x62696E6172697A65      # the pipeline graph keys its binarisation uniforms by noise_seed ^ this
+
+    def capture_train_pipeline(self, dataset, B: int, lr: float = 1e-3, n_steps: int = 16):
+        """A train graph that starts from the RAW pixels (gmvae_train_graph_create_pipeline): each of its n_steps
+        steps first binarises its own batch on the device (scripts/runners.py:48-51), rows taken from `dataset`
+        (gmvae_amd.data.DeviceDataset: resident uint8 pixels + an epoch permutation on the device).  Returns
+        replay(): refills the row indices (device-to-device) and launches the graph; nothing crosses PCIe."""
+        n_steps = int(n_steps)
+        key = ("pipeline", id(dataset), B, lr, n_steps)
+        if key in self._graphs:
+            return self._graphs[key][1]
+        if dataset.D != self.D:
+            raise ValueError("dataset rows must have D pixels")
+        d, ws = self._workspace(B)
+        idx = torch.zeros(n_steps, B, dtype=torch.int32, device=self.device)
+        xs = torch.zeros(n_steps, B, self.D, dtype=torch.uint8, device=self.device)
+        self.step_dev.fill_(self.global_step)
+        torch.cuda.synchronize()
+        handle = C.c_void_p()
+        rc = L.lib.gmvae_train_graph_create_pipeline(C.byref(d), self.model, L.ptr(dataset.pixels), dataset.N, L.ptr(idx),
+                                                     L.ptr(xs), n_steps, L.ptr(self.params), L.ptr(self.m), L.ptr(self.v),
+                                                     L.ptr(self.grads), L.ptr(ws), self.noise_seed, L.ptr(self.step_dev), lr,
+                                                     0.9, 0.999, 1e-8, C.byref(handle))
+        L.check(rc, "gmvae_train_graph_create_pipeline")
+        launch = L.lib.gmvae_train_graph_launch
+
+        def replay():
+            idx.copy_(dataset.next_rows(n_steps * B).view(n_steps, B))
+            rc2 = launch(handle, L.current_stream())
+            if rc2:
+                L.check(rc2, "gmvae_train_graph_launch")
+            self.global_step += n_steps
+
+        replay.rows, replay.batches = idx, xs          # the buffers of the last launch (tests, summaries)
+        self._graphs[key] = (xs, replay, handle)
+        return replay
+
     def handoff_timeouts(self) -> int:
         """Number of workspaces whose in-launch hand-off (mega_fwd_bwd's tagged-granule exchange between the
         workgroups of a panel) ever gave up waiting.  Such a step also poisons its loss and gradients with NaN;

@@ -143,6 +143,15 @@ int gmvae_mlp_forward(const GmvaeDims* dims, int model, int net, const void* in,
                       const float* in2, int rows, const float* params, float* out, void* workspace,
                       void* stream);
 
+/* Dynamic binarisation of the reference's input pipeline on the device (scripts/runners.py:48-51 `_preprocess`:
+ * image = pixel / 255.; x = image < uniform -- note P[x = 1] = 1 - pixel/255 -- re-drawn on every pass).
+ * pixels: uint8 [n_rows][D] resident in HBM (MNIST: 60000 x 784 = 47 MB); idx: int32 [B] source rows of this batch
+ * (an epoch permutation kept on the device) or NULL for rows row0 .. row0+B-1; x_out: uint8 [B][D] of 0/1, the
+ * layout gmvae_step takes.  The uniforms are Philox4x32-10 keyed by (seed, step or *step_dev) and the element's
+ * position in x_out, so a step is reproducible.  D % 4 == 0; pixels and x_out 4-byte aligned. */
+int gmvae_binarize(const uint8_t* pixels, uint64_t n_rows, const int32_t* idx, uint64_t row0, int B, int D,
+                   uint64_t seed, uint64_t step, const uint64_t* step_dev, uint8_t* x_out, void* stream);
+
 /* Philox4x32-10 noise: eps ~ N(0,1) [n_eps], u ~ U[tiny,1) [n_u] (either may be NULL/0). */
 int gmvae_noise_fill(float* eps, uint64_t n_eps, float* u, uint64_t n_u, uint64_t seed, uint64_t step,
                      const uint64_t* step_dev, void* stream);
@@ -199,6 +208,14 @@ int gmvae_bench_loop(const GmvaeDims* dims, int model, const uint8_t* x, float* 
 int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, int n_steps, float* params, float* m,
                              float* v, float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr,
                              float beta1, float beta2, float epsilon, void** graph_out);
+/* The same graph with the input pipeline inside: before each of its n_steps steps, gmvae_binarize draws that
+ * step's batch from the resident uint8 `pixels` [n_rows][D] -- rows idx[s][0..B) of the int32 device buffer
+ * idx [n_steps][B], which the caller refills (an epoch permutation) before every launch -- into x_scratch
+ * [n_steps][B][D], with uniforms keyed by the device step counter: a new draw every step, nothing crosses PCIe. */
+int gmvae_train_graph_create_pipeline(const GmvaeDims* dims, int model, const uint8_t* pixels, uint64_t n_rows,
+                                      const int32_t* idx, uint8_t* x_scratch, int n_steps, float* params, float* m, float* v,
+                                      float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr,
+                                      float beta1, float beta2, float epsilon, void** graph_out);
 int gmvae_train_graph_launch(void* graph, void* stream);
 int gmvae_train_graph_destroy(void* graph);
 

@@ -30,6 +30,7 @@ __all__ = [
     "param_specs", "param_layout", "init_params", "pack", "unpack",
     "softplus", "sigmoid", "forward", "loss_and_grads", "adam_tf_step",
     "train_step", "make_inputs", "flops_per_step", "cluster_acc", "TINY_F32",
+    "philox4x32_10", "binarize", "cluster_acc_from_hist",
 ]
 
 
@@ -361,6 +362,47 @@ def flops_per_step(model: int, d: Dims, B: int) -> float:
         fwd = mac(d.D, 2 * d.L) + S * mac(d.L, d.D)
         dx = fwd - d.D * h0
     return 2.0 * B * (2 * fwd + dx)
+
+
+def philox4x32_10(c: np.ndarray, k0: int, k1: int) -> np.ndarray:
+    """Philox4x32-10 (Salmon et al., SC'11) on an array of counters c[..., 4] (uint32) with key (k0, k1):
+    the generator of the HIP path's noise streams (gmvae_amd/csrc/aux.hpp), restated with NumPy integers."""
+    c = [c[..., i].astype(np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(k0 & 0xFFFFFFFF), np.uint64(k1 & 0xFFFFFFFF)
+    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[1] ^ k0) & MASK
+        n1 = p1 & MASK
+        n2 = ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & MASK
+        n3 = p0 & MASK
+        c = [n0, n1, n2, n3]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & MASK
+        k1 = (k1 + np.uint64(0xBB67AE85)) & MASK
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def binarize(pixels: np.ndarray, rows: np.ndarray, seed: int, step: int) -> np.ndarray:
+    """scripts/runners.py:48-51 `_preprocess` for one batch: image = float32(pixel) / 255; x = image < uniform.
+    The uniforms are the HIP path's: Philox4x32-10, counter = (output quad index, 0x40000000, step), key = seed,
+    u = (bits >> 8) * 2^-24.  pixels uint8 [N, D], rows int [B] -> uint8 [B, D] of 0/1 (bit-exact contract)."""
+    B, D = len(rows), pixels.shape[1]
+    q = np.arange(B * D // 4, dtype=np.uint64)
+    c = np.stack([q & np.uint64(0xFFFFFFFF), (q >> np.uint64(32)) | np.uint64(0x40000000),
+                  np.full_like(q, step & 0xFFFFFFFF), np.full_like(q, (step >> 32) & 0xFFFFFFFF)], axis=-1).astype(np.uint32)
+    r = philox4x32_10(c, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = ((r >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).reshape(B, D)
+    img = pixels[np.asarray(rows)].astype(np.float32) / np.float32(255.0)
+    return (img < u).astype(np.uint8)
+
+
+def cluster_acc_from_hist(hist: np.ndarray) -> float:
+    """utils.cluster_acc (scripts/utils.py:173-191) from the [K, n_labels] cluster x label histogram alone: every
+    sample of a cluster whose label is the cluster's majority label is a match, so matches = sum_k max_l hist[k, l].
+    This is the form that data-parallel ranks can combine (sum the histograms, then reduce)."""
+    hist = np.asarray(hist, dtype=np.int64)
+    n = hist.sum()
+    return float(hist.max(axis=1).sum()) / float(n) if n else 0.0
 
 
 def cluster_acc(logits: np.ndarray, labels: np.ndarray, K: int) -> float:

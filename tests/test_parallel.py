@@ -80,6 +80,34 @@ def test_two_rank_gloo_equals_single_process(Bg):
     np.testing.assert_allclose(f0, flat, rtol=0, atol=1e-9)
 
 
+def _hist_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    par.init_from_env("gloo")
+    from gmvae_amd.utils import cluster_acc_from_hist
+    rng = np.random.default_rng(5)
+    logits, labels = rng.normal(size=(300, 10)), rng.integers(0, 10, 300)
+    a, b = par.shard_rows(300, rank, world)
+    hist = torch.zeros(10, 10, dtype=torch.int64)                      # what cluster_hist leaves on each rank
+    hist.index_put_((torch.from_numpy(logits[a:b].argmax(1)), torch.from_numpy(labels[a:b])), torch.ones(b - a, dtype=torch.int64),
+                    accumulate=True)
+    dist.all_reduce(hist)                                              # the collective of utils.cluster_acc(all_reduce=True)
+    out[rank] = float(cluster_acc_from_hist(hist))
+    dist.destroy_process_group()
+
+
+def test_two_rank_cluster_acc_is_the_global_batch_accuracy():
+    """the data-parallel definition of cluster_acc -- sum the [K, n_labels] histograms over the
+    ranks, then take each cluster's majority -- equals scripts/utils.py:173-191 on the unsharded batch."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_hist_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    rng = np.random.default_rng(5)
+    logits, labels = rng.normal(size=(300, 10)), rng.integers(0, 10, 300)
+    want = O.cluster_acc(logits, labels, 10)
+    assert abs(out[0] - want) < 1e-6 and out[0] == out[1]
+
+
 def test_shard_rows_cover_and_balance():
     for n in (1, 7, 16, 1000, 1023):
         for w in (1, 2, 3, 8):
