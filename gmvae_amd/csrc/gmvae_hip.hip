@@ -653,15 +653,18 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
   // launch's critical path, are latency chains, and the single-buffered tile configuration leaves room for all
   // of them on the chip at once (3 per CU).
   const int NS2 = (2 * NS <= NS_MAX && B / (2 * NS) >= 64 && !getenv("GMVAE_DW_UNIFORM")) ? 2 * NS : NS;
+  int NSX = NS;                  // splits of the uint8-activation problems
+  if (getenv("GMVAE_DW_XSPLITS") && atoi(getenv("GMVAE_DW_XSPLITS")) >= 1 && atoi(getenv("GMVAE_DW_XSPLITS")) <= NS2)
+    NSX = atoi(getenv("GMVAE_DW_XSPLITS"));
   SlabX sx;
   memset(&sx, 0, sizeof(sx));
   {
     Group g;
     auto xrange = [&](uint64_t b, uint64_t n) { sx.b[sx.n] = (int)b; sx.e[sx.n] = (int)(b + pad4(n)); sx.n++; };
-    sx.ns = NS;
+    sx.ns = NSX;
     if (gm) {
-      g.add(p_tn(a.x, true, D, 1, w.dbuf[2], H, D, H, B, sl + E.w[0], sl + E.b[0], NS, PP, nullptr));            // dWy0
-      g.add(p_tn(a.x, true, D, 1, w.dbuf[1], H, D, H, B, sl + G.w[0], sl + G.b[0], NS, PP, nullptr));            // dWg0[x]
+      g.add(p_tn(a.x, true, D, 1, w.dbuf[2], H, D, H, B, sl + E.w[0], sl + E.b[0], NSX, PP, nullptr));           // dWy0
+      g.add(p_tn(a.x, true, D, 1, w.dbuf[1], H, D, H, B, sl + G.w[0], sl + G.b[0], NSX, PP, nullptr));           // dWg0[x]
       xrange(E.w[0], (uint64_t)D * H); xrange(E.b[0], H); xrange(G.w[0], (uint64_t)D * H); xrange(G.b[0], H);
       g.add(p_tn(w.hd[1], false, H, 1, w.g, D, H, D, B, sl + Dn.w[1], sl + Dn.b[1], NS2, PP, nullptr));          // dWd1
       const int K4 = (int)pad4(K);       // row stride of y and dlogits as mega_fwd_bwd stores them
@@ -670,13 +673,13 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       g.add(p_tn(w.y, false, K4, 1, w.dpp, 2 * Lz, K, 2 * Lz, B, sl + L.prior.w[0], sl + L.prior.b[0], NS2, PP, nullptr));
       g.add(p_tn(w.hg[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + G.w[1], sl + G.b[1], NS2, PP, nullptr)); // dWg1
     } else {
-      g.add(p_tn(a.x, true, D, 1, w.dbuf[1], H, D, H, B, sl + E.w[0], sl + E.b[0], NS, PP, nullptr));            // dWe0
+      g.add(p_tn(a.x, true, D, 1, w.dbuf[1], H, D, H, B, sl + E.w[0], sl + E.b[0], NSX, PP, nullptr));           // dWe0
       xrange(E.w[0], (uint64_t)D * H); xrange(E.b[0], H);
       g.add(p_tn(w.hd[1], false, H, 1, w.g, D, H, D, B, sl + Dn.w[1], sl + Dn.b[1], NS2, PP, nullptr));          // dWd1
       g.add(p_tn(w.he[1], false, H, 1, w.dqp, 2 * Lz, H, 2 * Lz, B, sl + E.w[1], sl + E.b[1], NS2, PP, nullptr)); // dWe1
     }
     g.add(p_tn(w.z, false, Lz, 1, w.dbuf[0], H, Lz, H, B, sl + Dn.w[0], sl + Dn.b[0], NS2, PP, nullptr));         // dWd0
-    if (NS2 == NS) sx.n = 0;
+    if (NS2 == NSX) sx.n = 0;
     launch_group(cx, g, "bwd_dw_all", env_cfg("GMVAE_DW_CFG", B >= 512 ? (NS2 != NS ? 3 : 1) : 0),
                  (getenv("GMVAE_STAMPS") || a.want_spans) ? w.gstamps + 2048 * 8 : nullptr);
   }
