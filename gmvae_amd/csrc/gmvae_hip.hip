@@ -514,7 +514,7 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
   float* sl = w.slabs;
   const bool gmp = a.model == GMVAE_MODEL_VAE_GMP;
   const float* nent = a.model == GMVAE_MODEL_GMVAE ? w.nent : nullptr;
-  if (!gmp && (!a.adam_p || a.step_dev)) {   // slab reduce + loss tail (+ TF-Adam in the train-graph path) in one launch
+  if ((!gmp || mega_ok(d, a.model)) && (!a.adam_p || a.step_dev)) {   // slab reduce + loss tail (+ TF-Adam) in one launch
     FinalArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.slabs = sl; fa.nslab = NS; fa.P = PP; fa.grads = a.grads; fa.p = a.adam_p; fa.m = a.adam_m; fa.v = a.adam_v;
@@ -523,6 +523,10 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
     fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
     fa.nmap = 0; fa.map_lo = fa.map_hi = 0; fa.img0 = fa.img1 = nullptr; fa.epoch_word = nullptr;
     fa.sx = sx;
+    if (gmp) {                               // (mega schedule only: one partial per panel)
+      const int KLp = (int)pad4((uint64_t)d.K * d.L);
+      fa.gmp_part = w.gmp_part; fa.gmp_n = (B + kPanel - 1) / kPanel; fa.gmp_len = 2 * KLp + (int)pad4(d.K); fa.gmp_off = (long long)L.loc;
+    }
     fa.span = (a.want_spans && w.spans) ? w.spans + 2048 * 2 : nullptr;
     if (mega_ok(d, a.model) && a.adam_p && a.adam_p == a.params) {      // the next step's weight images ride on the update
       const MegaLay ml = mega_lay(d.hidden[0], d.L, d.K, d.D, a.model);
@@ -627,16 +631,17 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     c.fine = getenv("GMVAE_STAMPS") ? atoi(getenv("GMVAE_STAMPS")) : 0;
     // the reference's default sizes (run_gmvae.py: latent 64, hidden 64, K 10; MNIST D 784) run a specialised instance
     typedef void (*MegaFn)(const MegaArgs);
-    const bool spec = H == 64 && Lz == 64 && K == 10 && D == 784 && gm && !getenv("GMVAE_MEGA_GENERIC");
-    const MegaFn fns[4] = {mega_fwd_bwd<0, 0, 0, 0, -1, 0>, mega_fwd_bwd<0, 0, 0, 0, -1, 1>, mega_fwd_bwd<64, 64, 10, 784, 2, 0>,
-                           mega_fwd_bwd<64, 64, 10, 784, 2, 1>};
-    const MegaFn fn = fns[(spec ? 2 : 0) + (fl ? 1 : 0)];
+    const bool spec = H == 64 && Lz == 64 && K == 10 && D == 784 && (gm || gmp) && !getenv("GMVAE_MEGA_GENERIC");
+    const MegaFn fns[6] = {mega_fwd_bwd<0, 0, 0, 0, -1, 0>,      mega_fwd_bwd<0, 0, 0, 0, -1, 1>,
+                           mega_fwd_bwd<64, 64, 10, 784, 2, 0>, mega_fwd_bwd<64, 64, 10, 784, 2, 1>,
+                           mega_fwd_bwd<64, 64, 10, 784, 1, 0>, mega_fwd_bwd<64, 64, 10, 784, 1, 1>};
+    const MegaFn fn = fns[(spec ? (gm ? 2 : 4) : 0) + (fl ? 1 : 0)];
     if (getenv("GMVAE_TRACE"))
       fprintf(stderr, "[gmvae] mega_fwd_bwd: model %d B %d first_layer_inside %d workgroups_per_panel %d specialised %d\n", model, B,
               (int)fl, Qm, (int)spec);
     static bool mattr = false;
     if (!mattr) {
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 6; ++i)
         hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       mattr = true;
     }

@@ -542,6 +542,8 @@ struct FinalArgs {
   float *img0, *img1;
   unsigned* epoch_word;       // bumped for the next step's in-launch hand-offs
   unsigned long long* span;   // measurement: [block][2] wall-clock (100 MHz) at a block's first and last instruction
+  // VAE_GMP: the prior variables' gradients are per-workgroup partials of mega_fwd_bwd, not split-K slabs
+  const float* gmp_part; int gmp_n, gmp_len; long long gmp_off;
   SlabX sx;
   int mbegin[kMaxImgMap], mend[kMaxImgMap];   // the ranges again, adjacent: one round of scalar loads finds the entry
   ImgMap map[kMaxImgMap];
@@ -612,6 +614,16 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
       const float w = s0 + j < nsl ? 1.f : 0.f;
       g.x += w * o[j].x; g.y += w * o[j].y; g.z += w * o[j].z; g.w += w * o[j].w;
     }
+  }
+  if (a.gmp_part && i4 >= a.gmp_off && i4 < a.gmp_off + a.gmp_len) {
+    const float* p0 = a.gmp_part + (i4 - a.gmp_off);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int k = 0; k < a.gmp_n; ++k) {
+      const float4 o = *reinterpret_cast<const float4*>(p0 + (long long)k * a.gmp_len);
+      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    g = acc;
   }
   *reinterpret_cast<float4*>(a.grads + i4) = g;
   if (!a.do_adam) { GMVAE_FIN_END(); return; }
