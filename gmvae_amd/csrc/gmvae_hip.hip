@@ -125,7 +125,7 @@ struct WS {
   unsigned long long* xchg;     // mega_fwd_bwd's in-launch hand-off granules: [panels][Q-1][16*H + 16]
   unsigned long long* xfl;      // mega_fwd_bwd's first-layer exchange granules: [panels][4][16 * H2]
   unsigned long long* spans;    // measurement: [2 kernels][2048 blocks][2] wall-clock stamps (mega_fwd_bwd, finalize_adam)
-  unsigned long long* gstamps;  // diagnostic stamps of the grouped-GEMM launches: [4 launches][2048 blocks][8]
+  unsigned long long* gstamps;  // diagnostic stamps of the grouped-GEMM launches: [4 slots][2048 blocks][8]
   unsigned* sync;               // [0] = per-step epoch of the hand-off, [1] = hand-off timeout flag
   float *img_f, *img_b;         // per-step LDS weight images of chain_fwd / chain_bwd (prepared by aux blocks)
   float *img_m, *dimg;          // mega kernel: small-weight image (odd leading dimensions) + decoder chunk images
@@ -134,8 +134,9 @@ struct WS {
 };
 
 // ---- fused schedule for the launch-bound default sizes (chain.hpp) ---------------------------
-// measured (tools/sweep.sh, B=1024 D=784 H=64): 4 forward splits of 256 and 8 batch splits with 64x64 tiles
-// for the weight-gradient launch are the fastest combination (82 us/step vs 88 with 7 / 4 splits, 32x32 tiles)
+// measured (tools/sweep.sh, B=1024 D=784 H=64): 4 forward splits of 256 and 8 batch splits with 64x64 tiles for the
+// weight-gradient launch are the fastest combination (re-checked after every change of the launch: 4, 6, 12 and 16
+// splits all measured slower; the fp32 problems of the mega schedule take twice this, see run_step_mega)
 static int dw_splits(long long B) {
   long long ns = B / 128;
   if (ns < 1) ns = 1;

@@ -169,8 +169,8 @@ int gmvae_cluster_acc(const float* logits, const int64_t* labels, int B, int K, 
  * trans 0 (NN): C[M,N] = act(A[M,K] W[K,N] + bias)
  * trans 1 (NT): C[M,N] = A[M,K] W[N,K]^T
  * trans 2 (TN): C[s][M(+1),N] = A[K,M]^T W[K,N] split over K into `splitk` slabs
- *               of (M+1)*N floats; bias != NULL requests the extra ones row
- *               (column sums of W) at row M.
+ *               of (M+1)*N floats; bias != NULL requests the bias gradient
+ *               (column sums of W over the slab's K range) at row M.
  * a_is_u8: A holds uint8. */
 int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bias, float* C, int M, int N,
                     int K, int trans, int relu, int cfg, int splitk, void* stream);
