@@ -431,6 +431,7 @@ struct StepArgs {
   // touched the parameters since: the step may skip its first launch (mega_fwd_bwd runs the first layer itself)
   bool imgs_ready = false;
   bool want_spans = false;     // measurement: every launch of the step records per-workgroup wall-clock stamps
+  bool dp_images = false;      // data-parallel graph: the Adam launch after the all-reduce scatters the weight images
 };
 
 static void rowk(Ctx& cx, const char* name) {
@@ -586,8 +587,8 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
   }
   const int Qm = mega_q(B);
-  const bool fl = a.imgs_ready && ml.fl_ok && Qm == 4 && (B + kPanel - 1) / kPanel * 4 <= n_cu && a.adam_p == a.params &&
-                  a.step_dev && gen_eps && w.xfl && !getenv("GMVAE_NO_FL");
+  const bool fl = a.imgs_ready && ml.fl_ok && Qm == 4 && (B + kPanel - 1) / kPanel * 4 <= n_cu &&
+                  (a.adam_p == a.params || a.dp_images) && a.step_dev && gen_eps && w.xfl && !getenv("GMVAE_NO_FL");
   if (!fl) {  // P1: first layer(s) over the uint8 batch as single-round split-K partials + auxiliary workgroups
     Group g;
     Problem p0 = p_nn(a.x, true, D, P + E.w[0], H, B, H, D, w.s1, H2, nullptr, false);
@@ -1642,20 +1643,55 @@ int gmvae_comm_destroy(void* comm) {
   return g_rccl.CommDestroy(comm) ? 1000 : 0;
 }
 
-/* one data-parallel training step on `stream`: gradient sums -> ONE RCCL all-reduce -> TF-Adam scaled by 1/count */
+/* one data-parallel training step on `stream`: gradient sums -> ONE RCCL all-reduce -> TF-Adam scaled by 1/count.
+ * in_graph: the Adam launch also scatters the next step's weight images (kernels.hpp adam_tf_img); imgs_ready: the
+ * previous step of the same graph did so, and this step may run its first layer inside mega_fwd_bwd. */
+static int dp_step_impl(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v, float* grads,
+                        void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1, float beta2,
+                        float epsilon, void* comm, hipStream_t st, bool in_graph, bool imgs_ready) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!x || !params || !m || !v || !grads || !workspace || !comm || !g_rccl.h || !step_dev) return GMVAE_E_NULL;
+  if (!aligned16(params) || !aligned16(grads) || !aligned16(workspace)) return GMVAE_E_ALIGN;
+  Layout L;
+  build_layout(*dims, model, L);
+  WS w;
+  carve(*dims, model, L, workspace, w);
+  const bool mega = mega_ok(*dims, model) && model != GMVAE_MODEL_VAE_GMP;
+  ImgPlan pl;
+  MegaLay ml;
+  bool scatter = false;
+  if (in_graph && mega) {
+    ml = mega_lay(dims->hidden[0], dims->L, dims->K, dims->D, model);
+    plan_images(*dims, model, L, w, ml, params, pl);
+    scatter = pl.map_ok && ml.fl_ok && !getenv("GMVAE_NO_FL");
+  }
+  Ctx cx;
+  cx.st = st;
+  StepArgs a = {dims, model, x, nullptr, nullptr, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
+                seed, 0, step_dev, true};
+  a.dp_images = scatter;
+  a.imgs_ready = scatter && imgs_ready;
+  int rc = run_step(cx, a);
+  if (rc) return rc;
+  const int nrc = g_rccl.AllReduce(grads, grads, (size_t)L.P_pad + GMVAE_TAIL, /*ncclFloat*/ 7, /*ncclSum*/ 0, comm, st);
+  if (nrc) return 1000 + nrc;
+  if (!scatter)
+    return adam_tf_step(params, m, v, grads, L.P_pad, lr, beta1, beta2, epsilon, 0, step_dev, 1.f, grads + L.P_pad + 4, st);
+  ImgScatter sc;
+  memset(&sc, 0, sizeof(sc));
+  sc.nmap = pl.nmap; sc.lo = pl.lo; sc.hi = pl.hi; sc.img0 = w.img_m; sc.img1 = w.dimg; sc.epoch_word = w.sync;
+  for (int i = 0; i < pl.nmap; ++i) { sc.map[i] = pl.map[i]; sc.mbegin[i] = pl.map[i].begin; sc.mend[i] = pl.map[i].end; }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(adam_tf_img, dim3((unsigned)((L.P_pad / 4 + 255) / 256)), dim3(256), 0, st, params, m, v, grads,
+                     (long long)L.P_pad, lr, beta1, beta2, epsilon, step_dev, grads + L.P_pad + 4, sc);
+  return (int)hipGetLastError();
+}
+
 int gmvae_dp_step(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
                   float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1,
                   float beta2, float epsilon, void* comm, void* stream) {
-  if (!comm || !g_rccl.h || !step_dev) return GMVAE_E_NULL;
-  int rc = gmvae_step(dims, model, x, nullptr, nullptr, params, grads, workspace, seed, 0, step_dev, stream);
-  if (rc) return rc;
-  Layout L;
-  build_layout(*dims, model, L);
-  const int nrc = g_rccl.AllReduce(grads, grads, (size_t)L.P_pad + GMVAE_TAIL, /*ncclFloat*/ 7, /*ncclSum*/ 0, comm,
-                                   static_cast<hipStream_t>(stream));
-  if (nrc) return 1000 + nrc;
-  return adam_tf_step(params, m, v, grads, L.P_pad, lr, beta1, beta2, epsilon, 0, step_dev, 1.f, grads + L.P_pad + 4,
-                      stream);
+  return dp_step_impl(dims, model, x, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, comm,
+                      static_cast<hipStream_t>(stream), false, false);
 }
 
 /* the same step captured once into a hipGraph (RCCL kernels included); replay with gmvae_train_graph_launch */
@@ -1681,8 +1717,8 @@ int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, in
   }
   if (rc == 0) {
     for (int s = 0; s < n_steps && rc == 0; ++s)
-      rc = gmvae_dp_step(dims, model, x + (size_t)s * dims->B * dims->D, params, m, v, grads, workspace, seed, step_dev, lr,
-                         beta1, beta2, epsilon, comm, cs);
+      rc = dp_step_impl(dims, model, x + (size_t)s * dims->B * dims->D, params, m, v, grads, workspace, seed, step_dev, lr,
+                        beta1, beta2, epsilon, comm, cs, true, s > 0);
     he = hipStreamEndCapture(cs, &tg->graph);
     if (rc == 0 && he != hipSuccess) rc = (int)he;
   }

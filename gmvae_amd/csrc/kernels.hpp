@@ -670,6 +670,67 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
 #undef GMVAE_FIN_END
 }
 
+// TF-Adam after the data-parallel all-reduce, with finalize_adam's image scatter: the updated parameters also go to
+// their positions in the next step's weight images (so that step can run its first layer inside mega_fwd_bwd).
+struct ImgScatter {
+  int nmap, lo, hi;
+  float *img0, *img1;
+  unsigned* epoch_word;
+  int mbegin[kMaxImgMap], mend[kMaxImgMap];
+  ImgMap map[kMaxImgMap];
+};
+__global__ __launch_bounds__(256) void adam_tf_img(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ g, long long P, float lr, float b1, float b2,
+                                                   float eps, const uint64_t* t_dev, const float* gscale_dev,
+                                                   const ImgScatter sc) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && sc.epoch_word) *sc.epoch_word += 1u;
+  const unsigned long long t = *t_dev;
+  const float gscale = 1.f / *gscale_dev;
+  const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+  const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= P) return;                                        // P is the padded parameter count: a multiple of 4
+  float4 pp = *reinterpret_cast<float4*>(p + i4), mm = *reinterpret_cast<float4*>(m + i4), vv = *reinterpret_cast<float4*>(v + i4);
+  const float4 gg = *reinterpret_cast<const float4*>(g + i4);
+  float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+  const float ga[4] = {gg.x, gg.y, gg.z, gg.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float gj = ga[j] * gscale;
+    ma[j] += (gj - ma[j]) * omb1;
+    va[j] += (gj * gj - va[j]) * omb2;
+    pa[j] -= ma[j] * lr_t / (sqrtf(va[j]) + eps);
+  }
+  *reinterpret_cast<float4*>(p + i4) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+  *reinterpret_cast<float4*>(m + i4) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+  *reinterpret_cast<float4*>(v + i4) = make_float4(va[0], va[1], va[2], va[3]);
+  const int blo = (int)blockIdx.x * 1024, bhi = blo + 1024;
+  if (sc.nmap <= 0 || bhi <= sc.lo || blo >= sc.hi) return;
+  unsigned hit = 0;                                           // entries this block overlaps (block-uniform)
+#pragma unroll
+  for (int k = 0; k < kMaxImgMap; ++k)
+    if (k < sc.nmap && bhi > sc.mbegin[k] && blo < sc.mend[k]) hit |= 1u << k;
+  while (hit) {
+    const int k = __builtin_ctz(hit);
+    hit &= hit - 1;
+    const int begin = sc.map[k].begin, end = sc.map[k].end, cols = sc.map[k].cols, kind = sc.map[k].kind;
+    const int base = sc.map[k].base, ld = sc.map[k].ld, chunk = sc.map[k].chunk;
+    const unsigned magic = sc.map[k].magic;
+    float* const img = sc.map[k].which ? sc.img1 : sc.img0;
+    if (i4 < begin || i4 >= end) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = (int)i4 + j;
+      if (idx < end) {
+        const unsigned off = (unsigned)(idx - begin);
+        const int r = (int)(((unsigned long long)off * magic) >> 32);
+        const int c = (int)off - r * cols;
+        img[kind ? base + (c >> 7) * chunk + r * ld + (c & 127) : base + r * ld + c] = pa[j];   // kCW = 128
+      }
+    }
+  }
+}
+
 // auxiliary work without a GEMM: the image tasks of the first step of a train graph
 __global__ __launch_bounds__(kThreads) void aux_only(const Aux ax) { aux_block(ax, (int)blockIdx.x); }
 

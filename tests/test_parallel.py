@@ -160,3 +160,30 @@ def test_rccl_in_library_world1_matches_plain_step():
     assert e.global_step == ref.global_step == 4
     assert torch.allclose(e.params.detach(), ref.params.detach(), atol=1e-6)
     assert int(e.step_dev[0].item()) == 4
+
+
+@pytest.mark.gpu
+def test_rccl_multi_step_graph_world1_tracks_eager_steps():
+    """The data-parallel train graph with several steps per launch: from its second step on the first layer runs inside
+    mega_fwd_bwd on weight images that the Adam launch AFTER the all-reduce scattered (adam_tf_img).  With a
+    one-rank communicator the all-reduce is the identity, so the trajectory must track plain eager steps."""
+    from gmvae_amd.engine import Engine
+    rng = np.random.default_rng(12)
+    n, B = 3, 1024
+    xs = torch.from_numpy((rng.random((n, B, 784)) < 0.87).astype(np.uint8)).cuda()
+    ref = Engine("gmvae", 784, 64, 10, [64], random_seed=6)
+    for r in range(2):
+        for i in range(n):
+            ref.train_step(xs[i], lr=1e-3)
+    e = Engine("gmvae", 784, 64, 10, [64], random_seed=6)
+    e.enable_rccl()
+    sx, replay = e.capture_train_step(B, lr=1e-3, all_reduce=True, n_steps=n)
+    assert e.dp_mode == "rccl-in-hipgraph" and tuple(sx.shape) == (n, B, 784)
+    sx.copy_(xs)
+    replay()
+    replay()
+    torch.cuda.synchronize()
+    assert e.global_step == ref.global_step == 2 * n and int(e.step_dev[0].item()) == 2 * n
+    assert e.handoff_timeouts() == 0 and torch.isfinite(e.params).all()
+    assert (e.params - ref.params).abs().max().item() < 2e-5
+    assert abs(e.grads[e.P].item() - ref.grads[ref.P].item()) < 1e-4 * abs(ref.grads[ref.P].item())
