@@ -132,6 +132,32 @@ __device__ __forceinline__ void mat_fill(float* __restrict__ dst, const int ld, 
   }
 }
 
+// Dynamic binarisation of the input pipeline (scripts/runners.py:48-51 `_preprocess`), one quad (4 consecutive pixels
+// of one output row): image = cast(pixel, float32) / 255.; x = image < uniform(shape)  (so P[x = 1] = 1 - pixel/255).
+// One 4-byte load, one Philox4x32-10 call (counter = output quad index, stream tag 0x40000000, key = seed, step), one
+// 4-byte store.
+__device__ __forceinline__ void binarize_quad(const uint64_t q, const unsigned char* __restrict__ pixels,
+                                              const int32_t* __restrict__ idx, const uint64_t row0, const uint64_t n_rows_src,
+                                              const int B, const int D, const uint64_t seed, const uint64_t step,
+                                              unsigned char* __restrict__ x) {
+  const int qpr = D >> 2;
+  if (q >= (uint64_t)B * qpr) return;
+  const int b = (int)(q / qpr), d4 = (int)(q - (uint64_t)b * qpr) << 2;
+  uint64_t r = idx ? (uint64_t)idx[b] : row0 + b;
+  r = r < n_rows_src ? r : n_rows_src - 1;
+  const uint32_t w = *reinterpret_cast<const uint32_t*>(pixels + r * D + d4);
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32) | 0x40000000u, (uint32_t)step, (uint32_t)(step >> 32)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  uint32_t o = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float img = (float)((w >> (8 * j)) & 0xff) / 255.f;               // IEEE division, as TF's RealDiv
+    o |= (img < u01(c[j]) ? 1u : 0u) << (8 * j);
+  }
+  *reinterpret_cast<uint32_t*>(x + (uint64_t)b * D + d4) = o;
+}
+constexpr int kBinQuadsPerThread = 4;      // as extra workgroups of finalize_adam: 1024 quads (4 KB of pixels) each
+
 // ------------------------------------------------------------ aux blocks
 constexpr int kMaxImgTasks = 32;
 struct ImgTask {

@@ -432,6 +432,12 @@ struct StepArgs {
   bool imgs_ready = false;
   bool want_spans = false;     // measurement: every launch of the step records per-workgroup wall-clock stamps
   bool dp_images = false;      // data-parallel graph: the Adam launch after the all-reduce scatters the weight images
+  // input pipeline inside the train graph: the NEXT step's batch is binarised by auxiliary workgroups of this step's
+  // weight-gradient launch (mega schedule)
+  const uint8_t* next_pix = nullptr;
+  const int32_t* next_idx = nullptr;
+  uint8_t* next_x = nullptr;
+  uint64_t next_rows_src = 0, bin_seed = 0;
 };
 
 static void rowk(Ctx& cx, const char* name) {
@@ -540,7 +546,13 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
         for (int i = 0; i < pl.nmap; ++i) { fa.map[i] = pl.map[i]; fa.mbegin[i] = pl.map[i].begin; fa.mend[i] = pl.map[i].end; }
       }
     }
-    hipLaunchKernelGGL(finalize_adam, dim3((unsigned)((PP / 4 + 255) / 256) + 1), dim3(256), 0, st, fa);
+    if (a.next_x && a.next_pix && a.next_idx && a.step_dev && a.adam_p) {
+      fa.bin_pix = a.next_pix; fa.bin_idx = a.next_idx; fa.bin_x = a.next_x; fa.bin_rows_src = a.next_rows_src;
+      fa.bin_B = B; fa.bin_D = d.D; fa.bin_seed = a.bin_seed;
+      const uint64_t quads = (uint64_t)B * (d.D >> 2);
+      fa.bin_blocks = (int)((quads + (uint64_t)kBinQuadsPerThread * 256 - 1) / ((uint64_t)kBinQuadsPerThread * 256));
+    }
+    hipLaunchKernelGGL(finalize_adam, dim3((unsigned)((PP / 4 + 255) / 256) + 1 + fa.bin_blocks), dim3(256), 0, st, fa);
     rowk(cx, a.adam_p ? "finalize_adam" : "finalize_grads+loss_tail");
     return cx.err;
   }
@@ -1119,13 +1131,16 @@ int gmvae_step(const GmvaeDims* dims, int model, const uint8_t* x, const float* 
 /* internal: gmvae_step with the end-of-step Adam fused in (single device; used by the train graph) */
 static int step_with_adam(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
                           float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float b1,
-                          float b2, float eps_, hipStream_t st, bool imgs_ready = false) {
+                          float b2, float eps_, hipStream_t st, bool imgs_ready = false, const uint8_t* next_pix = nullptr,
+                          const int32_t* next_idx = nullptr, uint8_t* next_x = nullptr, uint64_t next_rows_src = 0,
+                          uint64_t bin_seed = 0) {
   Ctx cx;
   cx.st = st;
   StepArgs a = {dims, model, x, nullptr, nullptr, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
                 seed, 0, step_dev, true};
   a.adam_p = params; a.adam_m = m; a.adam_v = v; a.lr = lr; a.beta1 = b1; a.beta2 = b2; a.epsilon = eps_;
   a.imgs_ready = imgs_ready;
+  a.next_pix = next_pix; a.next_idx = next_idx; a.next_x = next_x; a.next_rows_src = next_rows_src; a.bin_seed = bin_seed;
   return run_step(cx, a);
 }
 
@@ -1493,13 +1508,20 @@ static int train_graph_create(const GmvaeDims* dims, int model, const uint8_t* p
   if (rc == 0) {
     for (int s = 0; s < n_steps && rc == 0; ++s) {
       uint8_t* xs = x + s * xstride;
-      if (pixels)   // the input pipeline's step: this batch's rows, binarised with the step's own uniforms
-        rc = gmvae_binarize(pixels, n_rows, idx + (size_t)s * dims->B, 0, dims->B, dims->D, seed ^ 0x62696e6172697a65ull, 0, step_dev,
-                            xs, cs);
+      // The input pipeline's step: this batch's rows, binarised with the step's own uniforms.  In the mega schedule
+      // only the first batch of a launch is a launch of its own; batch s + 1 is drawn by extra workgroups of step s's
+      // finalize_adam launch (same values: the uniforms are keyed by the consuming step's index).
+      const uint64_t bseed = seed ^ 0x62696e6172697a65ull;
+      const bool ride = pixels && mega_ok(*dims, model) && !getenv("GMVAE_NO_BIN_RIDE");
+      if (pixels && (!ride || s == 0))
+        rc = gmvae_binarize(pixels, n_rows, idx + (size_t)s * dims->B, 0, dims->B, dims->D, bseed, 0, step_dev, xs, cs);
       if (rc) break;
       if (fused_ok(*dims, model) || mega_ok(*dims, model)) {
         // every step after the first finds its weight images written by the step before it (same graph, nothing in between)
-        rc = step_with_adam(dims, model, xs, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, cs, s > 0);
+        const bool nxt = ride && s + 1 < n_steps;
+        rc = step_with_adam(dims, model, xs, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, cs, s > 0,
+                            nxt ? pixels : nullptr, nxt ? idx + (size_t)(s + 1) * dims->B : nullptr, nxt ? xs + xstride : nullptr,
+                            n_rows, bseed);
       } else {
         rc = gmvae_step(dims, model, xs, nullptr, nullptr, params, grads, workspace, seed, 0, step_dev, cs);
         if (rc == 0)

@@ -28,31 +28,13 @@ __global__ void noise_fill(float* eps, uint64_t n_eps, float* u, uint64_t n_u, u
   noise_item((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, eps, n_eps, u, n_u, seed, step);
 }
 
-// Dynamic binarisation of the input pipeline (scripts/runners.py:48-51 `_preprocess`):
-//   image = cast(pixel, float32) / 255.;  x = image < uniform(shape)        (so P[x = 1] = 1 - pixel/255)
-// drawn anew for every step (tf.data re-runs the map on every pass).  One thread -> 4 consecutive pixels of one
-// output row: one 4-byte load, one Philox4x32-10 call (counter = output quad index, stream tag 0x40000000, key =
-// seed, (step)), one 4-byte store.  HBM-bound byte work: D + D bytes per row.
+// Dynamic binarisation of the input pipeline as its own launch (aux.hpp: binarize_quad): HBM-bound byte work,
+// D + D bytes per row, one thread per 4 pixels.
 __global__ void binarize_rows(const unsigned char* __restrict__ pixels, const int32_t* __restrict__ idx, uint64_t row0,
                               uint64_t n_rows_src, int B, int D, uint64_t seed, uint64_t step,
                               const uint64_t* step_dev, unsigned char* __restrict__ x) {
-  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // quad of the output [B][D]
-  const int qpr = D >> 2;
-  if (q >= (uint64_t)B * qpr) return;
   if (step_dev) step = *step_dev;
-  const int b = (int)(q / qpr), d4 = (int)(q - (uint64_t)b * qpr) << 2;
-  uint64_t r = idx ? (uint64_t)idx[b] : row0 + b;
-  r = r < n_rows_src ? r : n_rows_src - 1;
-  const uint32_t w = *reinterpret_cast<const uint32_t*>(pixels + r * D + d4);
-  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32) | 0x40000000u, (uint32_t)step, (uint32_t)(step >> 32)};
-  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-  uint32_t o = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float img = (float)((w >> (8 * j)) & 0xff) / 255.f;               // IEEE division, as TF's RealDiv
-    o |= (img < u01(c[j]) ? 1u : 0u) << (8 * j);
-  }
-  *reinterpret_cast<uint32_t*>(x + (uint64_t)b * D + d4) = o;
+  binarize_quad((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, pixels, idx, row0, n_rows_src, B, D, seed, step, x);
 }
 
 // ------------------------------------------------ q(y|x): Gumbel-softmax head
@@ -544,6 +526,13 @@ struct FinalArgs {
   unsigned long long* span;   // measurement: [block][2] wall-clock (100 MHz) at a block's first and last instruction
   // VAE_GMP: the prior variables' gradients are per-workgroup partials of mega_fwd_bwd, not split-K slabs
   const float* gmp_part; int gmp_n, gmp_len; long long gmp_off;
+  // input pipeline inside the train graph: bin_blocks extra workgroups (after the tail block) binarise the NEXT step's
+  // batch -- this launch is a latency chain on 2/3 of the CUs, the Philox work hides in it
+  int bin_blocks, bin_B, bin_D;
+  const unsigned char* bin_pix;
+  const int32_t* bin_idx;
+  unsigned char* bin_x;
+  unsigned long long bin_rows_src, bin_seed;
   SlabX sx;
   int mbegin[kMaxImgMap], mend[kMaxImgMap];   // the ranges again, adjacent: one round of scalar loads finds the entry
   ImgMap map[kMaxImgMap];
@@ -551,7 +540,16 @@ struct FinalArgs {
 __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
 #define GMVAE_FIN_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
   if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x] = wall_clock64();
-  const int nb = gridDim.x - 1;
+  const int nb = gridDim.x - 1 - a.bin_blocks;
+  if ((int)blockIdx.x > nb) {                    // the next step's batch: its uniforms are keyed by that step's index
+    const unsigned long long step = a.step_dev[1] + 1ull;
+    const uint64_t q0 = ((uint64_t)((int)blockIdx.x - nb - 1) * kBinQuadsPerThread) * 256 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < kBinQuadsPerThread; ++j)
+      binarize_quad(q0 + (uint64_t)j * 256, a.bin_pix, a.bin_idx, 0, a.bin_rows_src, a.bin_B, a.bin_D, a.bin_seed, step, a.bin_x);
+    GMVAE_FIN_END();
+    return;
+  }
   if ((int)blockIdx.x == nb) {
     __shared__ float red[4][256];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
