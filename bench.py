@@ -50,9 +50,11 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(model_id, d, B, flat, x, eps, u, budget_s):
-    """The oracle's fp32 restatement of the SAME step (fwd+bwd+TF-Adam) on the host cores."""
+def cpu_baseline(model, dims, B, flat, x, eps, u, budget_s):
+    """CPU leg, part 2: the oracle's fp32 restatement of the SAME step (fwd+bwd+TF-Adam) timed on the host cores."""
     import oracle as O
+    d = O.Dims(**dims)
+    model_id = O.MODEL_NAMES[model]
     res = {}
     try:
         from threadpoolctl import threadpool_limits
@@ -74,6 +76,30 @@ def cpu_baseline(model_id, d, B, flat, x, eps, u, budget_s):
     return res
 
 
+def flops_per_step(model: str, D: int, L: int, K: int, hidden, S: int, B: int) -> float:
+    """SURVEY.md A.1 FLOP rule: 2*(fwd + dW + dX MACs) per sample, the x-input dX excluded (it is never computed)."""
+    def mac(n_in, n_out):
+        dims = [n_in] + list(hidden) + [n_out]
+        return sum(p * q for p, q in zip(dims[:-1], dims[1:]))
+    h0 = hidden[0]
+    if model == "gmvae":
+        fwd = mac(D, K) + S * (K * 2 * L + mac(D + K, 2 * L) + mac(L, D))
+        dx = fwd - D * h0 * (1 + S)
+    else:
+        fwd = mac(D, 2 * L) + S * mac(L, D)
+        dx = fwd - D * h0
+    return 2.0 * B * (2 * fwd + dx)
+
+
+def cpu_parity(model: str, dims: dict, flat0, x_np, eps_np, u_np):
+    """CPU leg, part 1 (the checker): ELBO of the fp64 oracle on the inputs the HIP step just ran on."""
+    import oracle as O
+    d = O.Dims(**dims)
+    mid = O.MODEL_NAMES[model]
+    C64 = O.forward(mid, d, O.unpack(mid, d, flat0.astype(np.float64)), x_np, eps_np, u_np, np.float64)
+    return float(-C64["loss"])
+
+
 def main():
     a = parse()
     import torch
@@ -90,21 +116,25 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     n_gpus = world
 
-    import oracle as O
+    from types import SimpleNamespace
     from gmvae_amd.engine import Engine
 
     hidden = [a.hidden] * a.layers
-    d = O.Dims(D=a.data_dim, L=a.latent, K=a.components if a.model != "vae" else 1, hidden=tuple(hidden),
-               S=a.n_samples)
-    model_id = O.MODEL_NAMES[a.model]
+    dims = dict(D=a.data_dim, L=a.latent, K=a.components if a.model != "vae" else 1, hidden=tuple(hidden), S=a.n_samples)
+    d = SimpleNamespace(**dims)
     B = a.batch
     eng = Engine(a.model, d.D, d.L, d.K, hidden, n_samples=d.S, random_seed=0)     # same init on every rank
     # synthetic MNIST-shaped batch: Bernoulli(0.87) uint8, per-rank shard of the global batch
     x_np = (np.random.default_rng(1234 + rank).random((B, d.D)) < 0.87).astype(np.uint8)
     x = torch.from_numpy(x_np).cuda()
 
-    # ---- parity in the same run: HIP vs the fp32 + fp64 CPU restatement on identical inputs
-    _, eps_np, u_np = O.make_inputs(d, B, model_id)
+    # ---- parity in the same run: HIP vs the fp64 CPU restatement on identical (x, eps, u, parameters)
+    rn = np.random.default_rng(42)
+    tiny = float(np.finfo(np.float32).tiny)
+    eps_np = rn.standard_normal((B * d.S, d.L)).astype(np.float32)
+    u_np = np.clip(rn.uniform(tiny, 1.0, (B * d.S, d.K)).astype(np.float32), tiny, np.nextafter(np.float32(1), np.float32(0)))
+    if a.model != "gmvae":
+        u_np = None
     flat0 = eng.params.detach().cpu().numpy()
     buf = eng.step(x, torch.from_numpy(eps_np), None if u_np is None else torch.from_numpy(u_np))
     torch.cuda.synchronize()
@@ -112,11 +142,8 @@ def main():
     elbo_hip = -tail[0] / tail[4]
     parity = {}
     if rank == 0:
-        nb = min(B, 256)                    # the oracle finishes this in well under a second
-        C64 = O.forward(model_id, d, O.unpack(model_id, d, flat0.astype(np.float64)), x_np, eps_np, u_np, np.float64)
-        parity = {"elbo_hip": elbo_hip, "elbo_cpu_fp64": float(-C64["loss"]),
-                  "rel_err": float(abs(elbo_hip + C64["loss"]) / abs(C64["loss"]))}
-        del nb
+        elbo_cpu = cpu_parity(a.model, dims, flat0, x_np, eps_np, u_np)
+        parity = {"elbo_hip": elbo_hip, "elbo_cpu_fp64": elbo_cpu, "rel_err": float(abs(elbo_hip - elbo_cpu) / abs(elbo_cpu))}
 
     # ---- the timed loop
     use_graph = not a.no_graph
@@ -209,7 +236,7 @@ def main():
             levels = eng.profile_levels(x, iters=30)
         gemms = [l for l in levels if l[2] > 0]          # launches that do MFMA work (grouped GEMMs, mega kernel)
         dom = max(gemms, key=lambda l: l[1])
-        step_flops = O.flops_per_step(model_id, d, B)
+        step_flops = flops_per_step(a.model, d.D, d.L, d.K, hidden, d.S, B)
         sum_us = sum(l[1] for l in levels)
         roof = {"bound": "mfma", "kernel": dom[0] if dom[0].startswith("mega") else f"gemm_grouped<{dom[0]}>", "achieved": dom[2] / dom[1] * 1e-6,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom[2] / dom[1] * 1e-6 / PEAK_F32_MFMA_TFLOPS,
@@ -237,7 +264,7 @@ def main():
                 print(f"  {nm:28s} {us:9.2f} us  {fl / max(us, 1e-9) * 1e-6:8.2f} TFLOP/s", file=sys.stderr)
         cpu = None
         if not a.no_cpu_baseline:
-            r = cpu_baseline(model_id, d, B, flat0, x_np, eps_np, u_np, a.cpu_seconds)
+            r = cpu_baseline(a.model, dims, B, flat0, x_np, eps_np, u_np, a.cpu_seconds)
             best = "one" if r["one"][0] >= r["all"][0] else "all"      # the faster CPU variant is the baseline
             cpu = {"value": r[best][0], "unit": "ELBO-samples/sec", "cores": r[best][2], "kind": "port",
                    "sample": f"{r[best][1]} full steps (fwd+bwd+TF-Adam, fp32 NumPy/BLAS oracle) of the same "
