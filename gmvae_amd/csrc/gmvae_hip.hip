@@ -165,7 +165,7 @@ static bool mega_ok(const GmvaeDims& d, int model) {
   if (e2 && atoi(e2)) return false;
   if (d.n_hidden != 1 || d.S != 1 || d.D % 16) return false;
   const int H = d.hidden[0];
-  if (H % 16 || H > 64 || d.L % 8 || d.L > 128 || d.K > 64) return false;
+  if (H % 16 || H > 64 || d.L % 2 || d.L > 128 || d.K > 64) return false;      // L even: k-steps of 4 over [mu | raw]
   if (model == GMVAE_MODEL_VAE_GMP && (d.B + kPanel - 1) / kPanel > GMP_PARTS) return false;
   return (size_t)mega_lay(H, d.L, d.K, d.D, model).total * 4 <= 160 * 1024;
 }

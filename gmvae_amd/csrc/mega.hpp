@@ -52,7 +52,7 @@ __host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D, int mode
   if (model == 1) { m.M_loc = take(K * m.ldM); m.M_raw = take(K * m.ldM); m.M_mix = take(m.KP); }
   m.img_early = o = GMVAE_P256(o);
   m.W_g1 = take(H * m.ldG1);       // [H][L2+1]
-  m.W_d0 = take(L * m.ldD0);       // [L][H+1]
+  m.W_d0 = take(GMVAE_P4(L) * m.ldD0);   // [L][H+1] (+ zero rows up to a multiple of 4: the k-steps of z * Wd0)
   m.img = GMVAE_P256(o);
   m.chunk = GMVAE_P256((H + 1) * m.ldc);
   m.nch = (D + kCW - 1) / kCW;
@@ -60,7 +60,7 @@ __host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D, int mode
   o = (m.img > 2 * m.chunk) ? m.img : 2 * m.chunk;
   m.xring = take(2 * kPanel * kCW / 4);          // 2 x [16][128] bytes
   const int abase = o;
-  m.A_hy = take(H * kLDA); m.A_y = take(m.K2 * kLDA); m.A_hg = take(H * kLDA); m.A_z = take(L * kLDA);
+  m.A_hy = take(H * kLDA); m.A_y = take(m.K2 * kLDA); m.A_hg = take(H * kLDA); m.A_z = take(GMVAE_P4(L) * kLDA);
   m.A_hd = take(H * kLDA); m.A_g = take(kCW * kLDA);
   const int aend_f = o;
   o = abase;
@@ -487,7 +487,8 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     }
   } else {
   dma_copy_m(sm, a.img, f.img_early, wave, lane);
-  dma_copy_m(P_eps, a.eps + (long long)r0 * L, nrow * L, wave, lane);
+  dma_copy_m(P_eps, a.eps + (long long)r0 * L, (nrow * L) & ~3, wave, lane);
+  for (int e = ((nrow * L) & ~3) + tid; e < nrow * L; e += kMT) P_eps[e] = a.eps[(long long)r0 * L + e];   // ragged tail
   if (gm) dma_copy_m(P_u, a.u + (long long)r0 * K, (nrow * K) & ~3, wave, lane);
     if (gm)
       for (int e = ((nrow * K) & ~3) + tid; e < nrow * K; e += kMT) P_u[e] = a.u[(long long)r0 * K + e];
@@ -615,15 +616,15 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     P_hg[row * H + col] = h;
     if (lead && row < nrow) a.hg1[(long long)(r0 + row) * H + col] = h;
   });
-  panel_gemm_s(A_y, W_p, f.ldP, 1, K2, L2 / 16, wave, lane,
-               [&](int row, int col, float v) { P_pp[row * L2 + col] = v + b_p[col]; });
+  panel_gemm_s(A_y, W_p, f.ldP, 1, K2, (L2 + 15) / 16, wave, lane,
+               [&](int row, int col, float v) { if (col < L2) P_pp[row * L2 + col] = v + b_p[col]; });
   }  // gm
   dma_wait();                      // the late part of the weight image
   __syncthreads();
   GMVAE_FS(3);
   // q head
-  panel_gemm_s(A_hq, W_g1, f.ldG1, 1, H, L2 / 16, wave, lane,
-               [&](int row, int col, float v) { P_qp[row * L2 + col] = v + b_g1[col]; });
+  panel_gemm_s(A_hq, W_g1, f.ldG1, 1, H, (L2 + 15) / 16, wave, lane,
+               [&](int row, int col, float v) { if (col < L2) P_qp[row * L2 + col] = v + b_g1[col]; });
   __syncthreads();
   GMVAE_STAMP(3);
   // z, log q, log p: 32 lanes per row.  One exp, one rcp and one log give softplus AND its derivative (the
@@ -634,6 +635,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     const int row = tid >> 5, sub = tid & 31;
     const bool ok = row < nrow;
     float aq = 0.f, ap = 0.f;
+    if (sub >= L && sub < GMVAE_P4(L)) A_z[sub * kLDA + row] = 0.f;      // k rows that pad L to a multiple of 4
     for (int l = sub; l < L; l += 32) {
       const float mu = P_qp[row * L2 + l];
       const float vq = P_qp[row * L2 + L + l] + a.c;
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     __syncthreads();
   }
   // decoder hidden
-  panel_gemm_s(A_z, W_d0, f.ldD0, 1, L, H / 16, wave, lane, [&](int row, int col, float v) {
+  panel_gemm_s(A_z, W_d0, f.ldD0, 1, GMVAE_P4(L), H / 16, wave, lane, [&](int row, int col, float v) {
     const float h = fmaxf(v + b_d0[col], 0.f);
     A_hd[col * kLDA + row] = h;
     P_hd[row * H + col] = h;

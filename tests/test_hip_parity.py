@@ -123,6 +123,10 @@ STEP_CASES = [
     ("vae", O.Dims(D=784, L=16, K=1, hidden=(32,), sigma_min=0.8, gen_bias_init=-0.3), 37),
     ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(64,)), 1000),
     ("vae_gmp", O.Dims(D=208, L=24, K=40, hidden=(48,)), 50),
+    # latent sizes that are even but no multiple of 8 (padded head tiles, zero k rows in z * Wd0, ragged eps rows)
+    ("gmvae", O.Dims(D=784, L=6, K=10, hidden=(64,)), 41),
+    ("vae_gmp", O.Dims(D=400, L=10, K=7, hidden=(32,)), 23),
+    ("vae", O.Dims(D=784, L=2, K=1, hidden=(64,)), 1024),
 ]
 
 
