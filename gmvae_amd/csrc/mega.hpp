@@ -89,7 +89,7 @@ __host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D, int mode
     m.fl_ld = H;
     m.fl_W = 0;
     m.fl_A = GMVAE_P256(nw * m.fl_kq * H);
-    m.fl_ok = (m.fl_A + kPanel * kFlLda <= m.nll) && m.fl_kq <= kFlLda && D % 16 == 0 && nw * H <= 128 && H % 16 == 0 && L % 4 == 0 &&
+    m.fl_ok = (m.fl_A + kPanel * kFlLda <= m.nll) && m.fl_kq <= kFlLda && D % 16 == 0 && nw * H <= 128 && H % 16 == 0 && L % 2 == 0 &&
               H == 64 && (m.fl_kq * H) % 256 == 0 && kPanel * m.fl_kq / 4 <= 2 * kMT && 4 * L + (model == 2 ? 4 * K : 0) <= kMT;
   }
   return m;

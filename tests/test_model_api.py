@@ -167,7 +167,7 @@ def test_multi_step_graph_matches_eager_steps_on_the_same_batches(in_launch_firs
 
 
 @pytest.mark.parametrize("model,L_,K_,B", [("vae", 8, 1, 256), ("gmvae", 16, 10, 100), ("gmvae", 64, 10, 1000),
-                                          ("vae_gmp", 64, 10, 256)])
+                                          ("vae_gmp", 64, 10, 256), ("vae", 2, 1, 100)])
 def test_in_launch_first_layer_other_models_and_sizes(model, L_, K_, B):
     """Steps 2..n of a train graph run the first layer inside mega_fwd_bwd also for the VAE (one first-layer tensor,
     4 column tiles), for sizes other than the specialised instance's and for a ragged last panel (B = 100, 1000);
