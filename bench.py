@@ -200,6 +200,24 @@ def main():
         # every rank must issue the SAME number of steps (each contains a collective): fixed count, not wall time
         run_steps(4000)
         torch.cuda.synchronize()
+    # Safety net for unattended runs: the 3-launch schedule's workgroups wait for each other inside mega_fwd_bwd and
+    # need the whole chip.  If a wait ever timed out during the pre-warm (something else held CUs), every rank
+    # switches to the schedule without mutual waits and re-captures -- slower, never stalling.
+    bad = torch.tensor([eng.handoff_timeouts()], dtype=torch.int32, device="cuda")
+    if world > 1:
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+    safe_schedule = bool(bad.item())
+    if safe_schedule and use_graph:
+        os.environ["GMVAE_NO_FL"] = "1"
+        eng.drop_graphs()
+        static_x, step_fn = eng.capture_train_step(B, lr=1e-3, all_reduce=world > 1)
+        static_x.copy_(x)
+        multi_fn = None
+        if G > 1:
+            xs, multi_fn = eng.capture_train_step(B, lr=1e-3, all_reduce=world > 1, n_steps=G)
+            xs.copy_(torch.from_numpy((np.random.default_rng(4321 + rank).random((G, B, d.D)) < 0.87).astype(np.uint8)))
+        run_steps(2 * G)
+        torch.cuda.synchronize()
     run_steps(a.warmup)
     torch.cuda.synchronize()
     if world > 1:
@@ -278,7 +296,7 @@ def main():
             "config": {"workload": f"{a.model} train step (noise+fwd+bwd+allreduce+TF-Adam), D={d.D} K={d.K} "
                                    f"L={d.L} hidden={hidden} S={d.S}, batch {B}/GPU x {n_gpus} GPU "
                                    f"(BASELINE configs[{2 if n_gpus == 1 else 3}])",
-                       "global_batch": B * n_gpus, "parallelism": f"dp{n_gpus}", "hipgraph": use_graph, "input_pipeline_on_device": bool(a.pipeline and world == 1),
+                       "global_batch": B * n_gpus, "parallelism": f"dp{n_gpus}", "hipgraph": use_graph, "input_pipeline_on_device": bool(a.pipeline and world == 1), "safe_schedule": safe_schedule,
                        "all_reduce": getattr(eng, "dp_mode", None), "replicas_identical": replicas_identical},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "final_loss": final_tail[0] / max(final_tail[4], 1.0),

@@ -265,6 +265,9 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   const int pnl = bid < nP * (Q - 1) ? bid % nP : bid - nP * (Q - 1);
   const int r0 = pnl * kPanel;
   if (a.span && tid == 0) a.span[2 * bid] = wall_clock64();
+  // Bounded spins: ~2^19 polls (a few 100 ms) before a hand-off gives up, sets the error word and poisons the step
+  // with NaN; once the word is set every later wait of this workspace gives up at once (fail fast, no stalls).
+  const unsigned spin_limit = (Q > 1 && *a.err_word) ? 0u : (1u << 19);
 #define GMVAE_SPAN_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
   // The split-K partials of the first layer are the longest (coldest) wait of the launch: their loads go out
   // before anything else (the scheduling barrier keeps the ~1000 instructions of pointer set-up below them).
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
             }
           }
           if (__all(ok)) break;
-          if (++spins > (1u << 22)) {
+          if (++spins > spin_limit) {
             if (lane == 0) atomicExch(a.err_word, 1u);
 #pragma unroll
             for (int pq = 0; pq < 2; ++pq)
@@ -889,7 +892,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
           ok = ok && (unsigned)(v[4] >> 32) == epoch;
         }
         if (__all(ok)) break;
-        if (++spins > (1u << 22)) {                          // ~seconds: the producer never ran; flag and go on
+        if (++spins > spin_limit) {                          // the producer never ran; flag and go on
           if (lane == 0) atomicExch(a.err_word, 1u);
           v[0] = v[1] = v[2] = v[3] = v[4] = 0x7fc00000ull;  // NaN: the step's loss and gradients say so loudly
           break;

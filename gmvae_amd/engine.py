@@ -389,6 +389,19 @@ class Engine:
                 bad += int(ws.view(torch.int32)[off.value // 4 + 1].item() != 0)
         return bad
 
+    def drop_graphs(self, clear_handoff_errors: bool = True):
+        """Destroy every captured train graph (they are re-captured on the next capture_* call, under whatever
+        GMVAE_* schedule switches are set by then) and, optionally, clear the workspaces' hand-off error words."""
+        for _, _, handle in self._graphs.values():
+            if handle:
+                L.lib.gmvae_train_graph_destroy(handle)
+        self._graphs.clear()
+        if clear_handoff_errors:
+            for (d, ws) in self._ws.values():
+                off = C.c_uint64()
+                if L.lib.gmvae_workspace_offset(C.byref(d), self.model, b"sync", C.byref(off)) == 0:
+                    ws.view(torch.int32)[off.value // 4 + 1] = 0
+
     def __del__(self):
         try:
             for _, _, handle in self._graphs.values():

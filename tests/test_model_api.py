@@ -196,6 +196,45 @@ def test_in_launch_first_layer_other_models_and_sizes(model, L_, K_, B):
     assert abs(outs[0][1][0].item() - outs[1][1][0].item()) < 1e-4 * abs(outs[0][1][0].item())
 
 
+def test_handoff_error_word_fails_fast_and_recovers(monkeypatch):
+    """A set hand-off error word (what a timed-out wait leaves behind) makes every later wait give up at its first
+    failed poll (the step is then correct or NaN-poisoned, never stalled, never stale: granules are only accepted
+    with this step's tag); the word stays set until drop_graphs() clears it, after which the schedule without mutual
+    waits (GMVAE_NO_FL) runs clean."""
+    import ctypes as C
+    import time
+    from gmvae_amd import _lib as L
+    from gmvae_amd.engine import Engine
+    B, n = 1024, 3
+    rng = np.random.default_rng(1)
+    xs = torch.from_numpy((rng.random((n, B, 784)) < 0.87).astype(np.uint8)).cuda()
+    e = Engine("gmvae", 784, 64, 10, [64], random_seed=1)
+    sx, replay = e.capture_train_step(B, lr=1e-3, n_steps=n)
+    sx.copy_(xs)
+    replay()
+    torch.cuda.synchronize()
+    assert e.handoff_timeouts() == 0 and np.isfinite(e.grads[e.P].item())
+    good = e.params.clone()
+    d, ws = e._workspace(B)
+    off = C.c_uint64()
+    L.check(L.lib.gmvae_workspace_offset(C.byref(d), e.model, b"sync", C.byref(off)), "off")
+    ws.view(torch.int32)[off.value // 4 + 1] = 1                     # as if a wait had timed out
+    t0 = time.perf_counter()
+    replay()
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 1.0                            # no stall
+    assert e.handoff_timeouts() == 1
+    monkeypatch.setenv("GMVAE_NO_FL", "1")
+    e.drop_graphs()
+    e.params.copy_(good)
+    e.m.zero_(); e.v.zero_()
+    sx, replay = e.capture_train_step(B, lr=1e-3, n_steps=n)
+    sx.copy_(xs)
+    replay()
+    torch.cuda.synchronize()
+    assert e.handoff_timeouts() == 0 and np.isfinite(e.grads[e.P].item()) and torch.isfinite(e.params).all()
+
+
 def test_missing_engine_and_bad_activation_fail_loudly():
     import gmvae_amd
     from gmvae_amd import base
