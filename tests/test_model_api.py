@@ -214,7 +214,7 @@ def test_handoff_error_word_fails_fast_and_recovers(monkeypatch):
     replay()
     torch.cuda.synchronize()
     assert e.handoff_timeouts() == 0 and np.isfinite(e.grads[e.P].item())
-    good = e.params.clone()
+    good = e.params.detach().clone()
     d, ws = e._workspace(B)
     off = C.c_uint64()
     L.check(L.lib.gmvae_workspace_offset(C.byref(d), e.model, b"sync", C.byref(off)), "off")
@@ -226,8 +226,10 @@ def test_handoff_error_word_fails_fast_and_recovers(monkeypatch):
     assert e.handoff_timeouts() == 1
     monkeypatch.setenv("GMVAE_NO_FL", "1")
     e.drop_graphs()
-    e.params.copy_(good)
-    e.m.zero_(); e.v.zero_()
+    with torch.no_grad():
+        e.params.copy_(good)
+        e.m.zero_()
+        e.v.zero_()
     sx, replay = e.capture_train_step(B, lr=1e-3, n_steps=n)
     sx.copy_(xs)
     replay()
