@@ -155,7 +155,8 @@ def main():
                 print(f"[bench] in-library RCCL unavailable ({type(e).__name__}: {e}); torch.distributed all-reduce", file=sys.stderr)
     # One graph launch runs G consecutive steps, each on its own resident batch (the next G batches of an input
     # pipeline): the GPU idles ~6 us between two graph launches, nothing between the kernels inside one.
-    G = max(1, a.graph_steps)
+    # (the largest divisor of K up to --graph-steps, so that the timed K steps are whole launches of one graph)
+    G = max(g for g in range(1, max(1, min(a.graph_steps, a.steps)) + 1) if a.steps % g == 0)
     multi_fn = None
     if use_graph:
         try:
