@@ -157,6 +157,8 @@ def main():
     # pipeline): the GPU idles ~6 us between two graph launches, nothing between the kernels inside one.
     # (the largest divisor of K up to --graph-steps, so that the timed K steps are whole launches of one graph)
     G = max(g for g in range(1, max(1, min(a.graph_steps, a.steps)) + 1) if a.steps % g == 0)
+    if G < 8 <= a.steps:                 # no useful divisor: whole launches of --graph-steps + single steps for the rest
+        G = min(a.graph_steps, a.steps)
     multi_fn = None
     if use_graph:
         try:
