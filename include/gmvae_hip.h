@@ -16,7 +16,12 @@
  *   - no allocation and no synchronisation inside: the caller owns every
  *     buffer (device memory, 16-byte aligned) including the workspace, whose
  *     size is queried with gmvae_workspace_bytes() and which must be zeroed
- *     ONCE after allocation (padding words are never written again);
+ *     ONCE after allocation and then used with ONE set of dims (padding words
+ *     are never written again; it also holds the epoch counter and the error
+ *     word of the in-launch hand-offs of the fused schedule: a hand-off that
+ *     times out -- the schedule needs the whole device to itself -- poisons
+ *     that step's loss and gradients with NaN and sets the error word, after
+ *     which waits no longer block; re-zero the workspace to clear it);
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*), is
  *     asynchronous and graph-capturable; no global state;
  *   - all float tensors are fp32 row-major; x is uint8/bool {0,1} [B,D];
