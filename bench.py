@@ -26,6 +26,44 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PEAK_HBM_GBS = 8000.0
 
 
+# Named workloads (per-GPU shapes).  configs0..2 = BASELINE.json configs[0..2]; configs4_shard = the per-GPU shard of
+# configs[4] (B = 4096 / 8); run_train = the reference's bin/run_train.sh sizes.  Multi-GPU runs of configs2 ARE configs[3].
+CONFIGS = {
+    "configs0": dict(model="vae", batch=100, latent=2, components=1, hidden=64, layers=1, data_dim=784, n_samples=1),
+    "configs1": dict(model="vae_gmp", batch=256, latent=64, components=10, hidden=64, layers=1, data_dim=784, n_samples=1),
+    "configs2": dict(model="gmvae", batch=1024, latent=64, components=10, hidden=64, layers=1, data_dim=784, n_samples=1),
+    "configs4_shard": dict(model="gmvae", batch=512, latent=64, components=64, hidden=512, layers=1, data_dim=3072, n_samples=50),
+    "run_train": dict(model="gmvae", batch=64, latent=128, components=10, hidden=512, layers=1, data_dim=784, n_samples=1),
+}
+
+
+def workload_name(a, n_gpus):
+    key = dict(model=a.model, batch=a.batch, latent=a.latent, components=a.components if a.model != "vae" else 1,
+               hidden=a.hidden, layers=a.layers, data_dim=a.data_dim, n_samples=a.n_samples)
+    for name, c in CONFIGS.items():
+        if c == key:
+            if name == "configs2":
+                return "BASELINE configs[2]" if n_gpus == 1 else f"BASELINE configs[3] shape: 1024 rows per GPU x {n_gpus}"
+            return {"configs0": "BASELINE configs[0]", "configs1": "BASELINE configs[1]",
+                    "configs4_shard": "per-GPU shard of BASELINE configs[4]", "run_train": "bin/run_train.sh sizes"}[name]
+    return "custom sizes"
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves, BEFORE anything
+    touches the GPU (one process per GPU over RCCL, the same command line the driver uses), and exit with their code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -47,7 +85,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--levels", action="store_true", help="also print the per-launch table to stderr")
-    return ap.parse_args()
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="a named workload (BASELINE.json configs / SURVEY.md 8(d)); the default line is configs2")
+    a = ap.parse_args()
+    if a.config:
+        for k, v in CONFIGS[a.config].items():
+            setattr(a, k, v)
+    return a
 
 
 def cpu_baseline(model, dims, B, flat, x, eps, u, budget_s):
@@ -102,12 +146,16 @@ def cpu_parity(model: str, dims: dict, flat0, x_np, eps_np, u_np):
 
 def main():
     a = parse()
-    import torch
-    import torch.distributed as dist
-
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
@@ -123,7 +171,11 @@ def main():
     dims = dict(D=a.data_dim, L=a.latent, K=a.components if a.model != "vae" else 1, hidden=tuple(hidden), S=a.n_samples)
     d = SimpleNamespace(**dims)
     B = a.batch
-    eng = Engine(a.model, d.D, d.L, d.K, hidden, n_samples=d.S, random_seed=0)     # same init on every rank
+    # random_seed=None is the reference's default (scripts/run_gmvae.py:30): every process seeds itself from entropy, so the
+    # replicas START different; sync_replicas() makes rank 0's parameters, moments, step and noise seed everyone's.  The
+    # noise itself differs per rank by construction: the Philox counter holds the GLOBAL row (rank * B + b).
+    eng = Engine(a.model, d.D, d.L, d.K, hidden, n_samples=d.S, random_seed=0 if world == 1 else None)
+    eng.sync_replicas()
     # synthetic MNIST-shaped batch: Bernoulli(0.87) uint8, per-rank shard of the global batch
     x_np = (np.random.default_rng(1234 + rank).random((B, d.D)) < 0.87).astype(np.uint8)
     x = torch.from_numpy(x_np).cuda()
@@ -213,6 +265,8 @@ def main():
     if safe_schedule and use_graph:
         os.environ["GMVAE_NO_FL"] = "1"
         eng.drop_graphs()
+        eng.init_parameters(0)                       # poisoned steps were skipped by the optimizer, but start clean anyway
+        eng.sync_replicas()
         static_x, step_fn = eng.capture_train_step(B, lr=1e-3, all_reduce=world > 1)
         static_x.copy_(x)
         multi_fn = None
@@ -238,6 +292,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     final_tail = eng.grads[eng.P:].cpu().numpy().astype(np.float64)
+    # ---- the same loop once more with HIP events around every graph launch (median, events on the compute
+    # stream).  `value` above stays the whole-region host clock the contract prescribes; this is the per-launch view.
+    unit = G if multi_fn is not None else 1
+    launch_fn = multi_fn if multi_fn is not None else step_fn
+    n_ev = int(max(8, min(200, a.steps // unit)))
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    for e0, e1 in evs:
+        e0.record()
+        launch_fn()
+        e1.record()
+    torch.cuda.synchronize()
+    ev_ms = sorted(e0.elapsed_time(e1) / unit for e0, e1 in evs)
+    ms_median_events = ev_ms[len(ev_ms) // 2]
+    if world > 1:
+        dist.barrier()
     replicas_identical = None
     if world > 1:                                   # every rank must hold bit-identical parameters
         cs = eng.params.detach().double().sum().reshape(1)
@@ -294,11 +363,12 @@ def main():
                    "value_all_cores": r["all"][0], "value_1thread": r["one"][0]}
         out = {
             "metric": "ELBO-samples/sec", "value": value, "unit": "samples/sec", "n_gpus": n_gpus, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "ms_per_step_median_hip_events": ms_median_events,
+            "steps_per_graph_launch": unit, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.model} train step (noise+fwd+bwd+allreduce+TF-Adam), D={d.D} K={d.K} "
                                    f"L={d.L} hidden={hidden} S={d.S}, batch {B}/GPU x {n_gpus} GPU "
-                                   f"(BASELINE configs[{2 if n_gpus == 1 else 3}])",
+                                   f"({workload_name(a, n_gpus)})",
                        "global_batch": B * n_gpus, "parallelism": f"dp{n_gpus}", "hipgraph": use_graph, "input_pipeline_on_device": bool(a.pipeline and world == 1), "safe_schedule": safe_schedule,
                        "all_reduce": getattr(eng, "dp_mode", None), "replicas_identical": replicas_identical},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,

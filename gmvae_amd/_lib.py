@@ -26,7 +26,7 @@ class GmvaeDims(C.Structure):
     _fields_ = [("B", C.c_int32), ("D", C.c_int32), ("L", C.c_int32), ("K", C.c_int32), ("S", C.c_int32),
                 ("n_hidden", C.c_int32), ("hidden", C.c_int32 * MAX_HIDDEN),
                 ("sigma_min", C.c_float), ("raw_sigma_bias", C.c_float), ("temperature", C.c_float),
-                ("gen_bias_init", C.c_float)]
+                ("gen_bias_init", C.c_float), ("row0", C.c_uint64)]
 
 
 class GmvaeParamEntry(C.Structure):
@@ -53,23 +53,23 @@ def _load():
         "gmvae_workspace_bytes": ([dp, i32, C.POINTER(u64)], i32),
         "gmvae_step": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, u64, vp, vp], i32),
         "gmvae_forward": ([dp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, u64, vp], i32),
-        "adam_tf_step": ([vp, vp, vp, vp, u64, f32, f32, f32, f32, u64, vp, f32, vp, vp], i32),
+        "adam_tf_step": ([vp, vp, vp, vp, u64, f32, f32, f32, f32, u64, vp, f32, vp, vp, vp], i32),
         "gmvae_mlp_forward": ([dp, i32, i32, vp, i32, vp, i32, vp, vp, vp, vp], i32),
-        "gmvae_noise_fill": ([vp, u64, vp, u64, u64, u64, vp, vp], i32),
+        "gmvae_noise_fill": ([vp, vp, u64, i32, i32, u64, u64, u64, vp, vp], i32),
         "gmvae_cluster_acc": ([vp, vp, i32, i32, i32, vp, vp, vp], i32),
         "gmvae_gemm_test": ([vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
         "gmvae_bench_loop": ([dp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(f32), vp], i32),
-        "gmvae_train_graph_create": ([dp, i32, vp, i32, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, C.POINTER(vp)], i32),
-        "gmvae_train_graph_create_pipeline": ([dp, i32, vp, u64, vp, vp, i32, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, C.POINTER(vp)], i32),
+        "gmvae_train_graph_create": ([dp, i32, vp, i32, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, vp, C.POINTER(vp)], i32),
+        "gmvae_train_graph_create_pipeline": ([dp, i32, vp, u64, vp, vp, i32, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, vp, C.POINTER(vp)], i32),
         "gmvae_train_graph_launch": ([vp, vp], i32),
         "gmvae_train_graph_destroy": ([vp], i32),
         "gmvae_comm_unique_id": ([C.c_char_p, vp], i32),
         "gmvae_comm_init": ([C.c_char_p, vp, i32, i32, C.POINTER(vp)], i32),
         "gmvae_comm_destroy": ([vp], i32),
         "gmvae_dp_step": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, vp, vp], i32),
-        "gmvae_dp_graph_create": ([dp, i32, vp, i32, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, vp, C.POINTER(vp)], i32),
+        "gmvae_dp_graph_create": ([dp, i32, vp, i32, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, vp, vp, C.POINTER(vp)], i32),
         "gmvae_workspace_offset": ([dp, i32, C.c_char_p, C.POINTER(u64)], i32),
-        "gmvae_binarize": ([vp, u64, vp, u64, i32, i32, u64, u64, vp, vp, vp], i32),
+        "gmvae_binarize": ([vp, u64, vp, u64, i32, i32, u64, u64, vp, vp, u64, vp], i32),
         "gmvae_kernel_occupancy": ([i32, C.POINTER(i32)], i32),
         "gmvae_train_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),
         "gmvae_step_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),
@@ -92,7 +92,7 @@ def check(rc: int, what: str):
     raise GmvaeError(f"{what}: hipError_t {rc}")
 
 
-def make_dims(B, D, L, K, hidden, S=1, sigma_min=0.0, raw_sigma_bias=0.5, temperature=1.0, gen_bias_init=0.0):
+def make_dims(B, D, L, K, hidden, S=1, sigma_min=0.0, raw_sigma_bias=0.5, temperature=1.0, gen_bias_init=0.0, row0=0):
     hidden = list(hidden)
     if len(hidden) > MAX_HIDDEN:
         raise ValueError(f"at most {MAX_HIDDEN} hidden layers")
@@ -102,6 +102,7 @@ def make_dims(B, D, L, K, hidden, S=1, sigma_min=0.0, raw_sigma_bias=0.5, temper
         d.hidden[i] = int(h)
     d.sigma_min, d.raw_sigma_bias = float(sigma_min), float(raw_sigma_bias)
     d.temperature, d.gen_bias_init = float(temperature), float(gen_bias_init)
+    d.row0 = int(row0)          # data parallel: global index of this device's first batch row (Philox counters only)
     return d
 
 

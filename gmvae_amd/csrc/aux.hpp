@@ -36,11 +36,14 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 }
 __device__ __forceinline__ float u01(uint32_t b) { return (float)(b >> 8) * 5.9604644775390625e-8f; }  // [0,1)
 
-// 4 consecutive values of the eps stream (Box-Muller normals) or of the u stream (uniforms in [kTiny, 1)):
-// quad q of the flat array, keyed by (seed, step) -- every consumer of the noise calls this one function
-__device__ __forceinline__ void noise_vals(const uint64_t q, const bool is_u, const uint64_t seed, const uint64_t step,
-                                           float (&o)[4]) {
-  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32) | (is_u ? 0x80000000u : 0u), (uint32_t)step, (uint32_t)(step >> 32)};
+// 4 consecutive values of ONE ROW of the eps stream (Box-Muller normals) or of the u stream (uniforms in [kTiny, 1)):
+// quad `quad` of GLOBAL row `row`, keyed by (seed, step) -- every consumer of the noise calls this one function.
+// The counter holds the global row index (GmvaeDims::row0 + local row), never a position in a device's buffer, so a
+// batch sharded over G devices draws exactly the rows the single-device step on the whole batch would draw.
+__device__ __forceinline__ void noise_vals(const uint64_t row, const uint32_t quad, const bool is_u, const uint64_t seed,
+                                           const uint64_t step, float (&o)[4]) {
+  uint32_t c[4] = {(uint32_t)row, (quad & 0x00ffffffu) | (((uint32_t)(row >> 32) & 0x3fu) << 24) | (is_u ? 0x80000000u : 0u),
+                   (uint32_t)step, (uint32_t)(step >> 32)};
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   if (is_u) {
 #pragma unroll
@@ -59,24 +62,31 @@ __device__ __forceinline__ void noise_vals(const uint64_t q, const bool is_u, co
   }
 }
 
-// thread `i` of the fill: 4 values of eps (Box-Muller) or of u
-__device__ __forceinline__ void noise_item(uint64_t i, float* eps, uint64_t n_eps, float* u, uint64_t n_u,
+// thread `i` of the fill of eps [rows][L] and u [rows][K] (either pointer may be null): one quad of one row
+__device__ __forceinline__ void noise_item(uint64_t i, float* eps, float* u, uint64_t rows, int L, int K, uint64_t row_base,
                                            uint64_t seed, uint64_t step) {
-  const uint64_t q_eps = (n_eps + 3) / 4, q_u = (n_u + 3) / 4;
-  if (i >= q_eps + q_u) return;
-  const bool is_u = i >= q_eps;
-  const uint64_t q = is_u ? i - q_eps : i;
+  const uint32_t qe = eps ? (uint32_t)(L + 3) / 4 : 0u, qu = u ? (uint32_t)(K + 3) / 4 : 0u;
+  const uint64_t n_e = rows * qe;
+  if (i >= n_e + rows * qu) return;
+  const bool is_u = i >= n_e;
+  if (is_u) i -= n_e;
+  const uint32_t qpr = is_u ? qu : qe;
+  const uint64_t row = i / qpr;
+  const uint32_t quad = (uint32_t)(i - row * qpr);
   float o[4];
-  noise_vals(q, is_u, seed, step, o);
-  float* dst = is_u ? u : eps;
-  const uint64_t n = is_u ? n_u : n_eps;
-  if (q * 4 + 3 < n) {
-    *reinterpret_cast<float4*>(dst + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  noise_vals(row_base + row, quad, is_u, seed, step, o);
+  const int n = is_u ? K : L;
+  float* dst = (is_u ? u : eps) + row * (uint64_t)n + quad * 4;
+  if ((n & 3) == 0) {
+    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (q * 4 + j < n) dst[q * 4 + j] = o[j];
+      if ((int)quad * 4 + j < n) dst[j] = o[j];
   }
+}
+__host__ __device__ inline uint64_t noise_items(bool has_eps, bool has_u, uint64_t rows, int L, int K) {
+  return rows * ((has_eps ? (uint64_t)(L + 3) / 4 : 0) + (has_u ? (uint64_t)(K + 3) / 4 : 0));
 }
 
 // ------------------------------------------------------- matrix copies
@@ -139,14 +149,15 @@ __device__ __forceinline__ void mat_fill(float* __restrict__ dst, const int ld, 
 __device__ __forceinline__ void binarize_quad(const uint64_t q, const unsigned char* __restrict__ pixels,
                                               const int32_t* __restrict__ idx, const uint64_t row0, const uint64_t n_rows_src,
                                               const int B, const int D, const uint64_t seed, const uint64_t step,
-                                              unsigned char* __restrict__ x) {
+                                              unsigned char* __restrict__ x, const uint64_t out_row0 = 0) {
   const int qpr = D >> 2;
   if (q >= (uint64_t)B * qpr) return;
   const int b = (int)(q / qpr), d4 = (int)(q - (uint64_t)b * qpr) << 2;
   uint64_t r = idx ? (uint64_t)idx[b] : row0 + b;
   r = r < n_rows_src ? r : n_rows_src - 1;
   const uint32_t w = *reinterpret_cast<const uint32_t*>(pixels + r * D + d4);
-  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32) | 0x40000000u, (uint32_t)step, (uint32_t)(step >> 32)};
+  const uint64_t qg = q + out_row0 * (uint64_t)qpr;          // position in the GLOBAL batch (data parallel: out_row0 = rank * B)
+  uint32_t c[4] = {(uint32_t)qg, (uint32_t)(qg >> 32) | 0x40000000u, (uint32_t)step, (uint32_t)(step >> 32)};
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   uint32_t o = 0;
 #pragma unroll
@@ -171,7 +182,8 @@ struct Aux {
   int ntasks;           // then one workgroup per image task
   float* eps;
   float* u;
-  unsigned long long n_eps, n_u, seed, step;
+  unsigned long long n_rows, row_base, seed, step;   // eps [n_rows][nL], u [n_rows][nK]; row_base: global index of row 0
+  int nL, nK;
   unsigned long long* step_dev;   // [2]: [0] = completed steps, [1] = copy that the last kernel of the step reads
   unsigned* epoch_word;           // bumped once per step: tag of the in-launch hand-offs of mega_fwd_bwd
   ImgTask task[kMaxImgTasks];
@@ -181,7 +193,7 @@ __device__ __forceinline__ void aux_block(const Aux& ax, const int b) {
   if (b == 0 && threadIdx.x == 0 && ax.epoch_word) *ax.epoch_word += 1u;
   if (b < ax.noise_blocks) {
     const unsigned long long step = ax.step_dev ? ax.step_dev[0] : ax.step;
-    noise_item((uint64_t)b * kThreads + threadIdx.x, ax.eps, ax.n_eps, ax.u, ax.n_u, ax.seed, step);
+    noise_item((uint64_t)b * kThreads + threadIdx.x, ax.eps, ax.u, ax.n_rows, ax.nL, ax.nK, ax.row_base, ax.seed, step);
     if (b == 0 && threadIdx.x == 0 && ax.step_dev) ax.step_dev[1] = ax.step_dev[0];
   } else {
     const int t = b - ax.noise_blocks;

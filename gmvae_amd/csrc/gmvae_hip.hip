@@ -434,6 +434,7 @@ struct StepArgs {
   bool dp_images = false;      // data-parallel graph: the Adam launch after the all-reduce scatters the weight images
   // input pipeline inside the train graph: the NEXT step's batch is binarised by auxiliary workgroups of this step's
   // weight-gradient launch (mega schedule)
+  float* tail_log = nullptr;   // train graph: this step's slot of the per-step tail log (may be null)
   const uint8_t* next_pix = nullptr;
   const int32_t* next_idx = nullptr;
   uint8_t* next_x = nullptr;
@@ -528,8 +529,9 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
     fa.slabs = sl; fa.nslab = NS; fa.P = PP; fa.grads = a.grads; fa.p = a.adam_p; fa.m = a.adam_m; fa.v = a.adam_v;
     fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = a.adam_p ? 1 : 0; fa.count = (float)B;
     fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = nent;
-    fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
+    fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev); fa.tail_log = a.tail_log;
     fa.nmap = 0; fa.map_lo = fa.map_hi = 0; fa.img0 = fa.img1 = nullptr; fa.epoch_word = nullptr;
+    fa.err_word = (mega_ok(d, a.model) && w.sync) ? w.sync + 1 : nullptr;
     fa.sx = sx;
     if (gmp) {                               // (mega schedule only: one partial per panel)
       const int KLp = (int)pad4((uint64_t)d.K * d.L);
@@ -548,7 +550,7 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
     }
     if (a.next_x && a.next_pix && a.next_idx && a.step_dev && a.adam_p) {
       fa.bin_pix = a.next_pix; fa.bin_idx = a.next_idx; fa.bin_x = a.next_x; fa.bin_rows_src = a.next_rows_src;
-      fa.bin_B = B; fa.bin_D = d.D; fa.bin_seed = a.bin_seed;
+      fa.bin_B = B; fa.bin_D = d.D; fa.bin_seed = a.bin_seed; fa.bin_row0 = d.row0;
       const uint64_t quads = (uint64_t)B * (d.D >> 2);
       fa.bin_blocks = (int)((quads + (uint64_t)kBinQuadsPerThread * 256 - 1) / ((uint64_t)kBinQuadsPerThread * 256));
     }
@@ -567,15 +569,16 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
   if (a.adam_p && a.step_dev) {           // VAE_GMP in the graph path: its prior partials need finalize_grads first
     hipLaunchKernelGGL(adam_tf, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, a.adam_p, a.adam_m, a.adam_v,
                        a.grads, PP, a.lr, a.beta1, a.beta2, a.epsilon, (uint64_t)0, a.step_dev, 1.f / (float)B,
-                       (const float*)nullptr);
+                       (const float*)nullptr, (const float*)tail);
     rowk(cx, "adam_tf");
   }
+  if (a.tail_log) hipMemcpyAsync(a.tail_log, tail, GMVAE_TAIL * sizeof(float), hipMemcpyDeviceToDevice, st);
   return cx.err;
 }
 
 // ---- the mega schedule (all three models): first-layer split-K GEMM (+ aux) -> mega_fwd_bwd -> all dW -> finish
 static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, const float* eps, const float* u,
-                         float* gen_eps, uint64_t n_eps, float* gen_u, uint64_t n_u) {
+                         float* gen_eps, float* gen_u) {
   const GmvaeDims& d = *a.d;
   const int model = a.model;
   const bool gm = model == GMVAE_MODEL_GMVAE, gmp = model == GMVAE_MODEL_VAE_GMP;
@@ -612,10 +615,11 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       g.add(p1);
     }
     Aux& ax = g.L.aux;
-    ax.eps = gen_eps; ax.u = gen_u; ax.n_eps = n_eps; ax.n_u = n_u; ax.seed = a.seed; ax.step = a.step;
+    ax.eps = gen_eps; ax.u = gen_u; ax.n_rows = (unsigned long long)B * d.S; ax.nL = Lz; ax.nK = K; ax.row_base = d.row0 * d.S;
+    ax.seed = a.seed; ax.step = a.step;
     ax.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
     ax.epoch_word = w.sync;
-    ax.noise_blocks = (int)(((n_eps + 3) / 4 + (n_u + 3) / 4 + kThreads - 1) / kThreads);
+    ax.noise_blocks = (int)((noise_items(gen_eps, gen_u, ax.n_rows, Lz, K) + kThreads - 1) / kThreads);
     ImgPlan pl;
     plan_images(d, model, L, w, ml, P, pl);
     const int nt = pl.nt;
@@ -637,7 +641,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     c.gmp_part = w.gmp_part;
     c.lay = ml;
     c.fl = fl ? 1 : 0;
-    c.w0a = P + E.w[0]; c.w0b = gm ? P + G.w[0] : nullptr; c.xfl = w.xfl; c.seed = a.seed;
+    c.w0a = P + E.w[0]; c.w0b = gm ? P + G.w[0] : nullptr; c.xfl = w.xfl; c.seed = a.seed; c.row0 = d.row0;
     c.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
     c.Q = Qm; c.xchg = w.xchg; c.epoch_word = w.sync; c.err_word = w.sync + 1;
     c.dbg = getenv("GMVAE_STAMPS") ? w.stamps : nullptr;
@@ -710,7 +714,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
 // (split-K into slabs that the consumer reduces), so the chip is filled and no workgroup
 // waits on more than ~2 dependent memory round trips.
 static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, const float* eps, const float* u,
-                          float* gen_eps, uint64_t n_eps, float* gen_u, uint64_t n_u) {
+                          float* gen_eps, float* gen_u) {
   const GmvaeDims& d = *a.d;
   const int B = d.B, K = d.K, Lz = d.L, D = d.D, H = d.hidden[0];
   const float* P = a.params;
@@ -733,9 +737,10 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
     g.add(p1);
     // auxiliary workgroups on the same launch: Philox noise + this step's LDS weight images
     Aux& ax = g.L.aux;
-    ax.eps = gen_eps; ax.u = gen_u; ax.n_eps = n_eps; ax.n_u = n_u; ax.seed = a.seed; ax.step = a.step;
+    ax.eps = gen_eps; ax.u = gen_u; ax.n_rows = (unsigned long long)B * d.S; ax.nL = Lz; ax.nK = K; ax.row_base = d.row0 * d.S;
+    ax.seed = a.seed; ax.step = a.step;
     ax.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
-    ax.noise_blocks = (int)(((n_eps + 3) / 4 + (n_u + 3) / 4 + kThreads - 1) / kThreads);
+    ax.noise_blocks = (int)((noise_items(gen_eps, gen_u, ax.n_rows, Lz, K) + kThreads - 1) / kThreads);
     const FwdLay fl = fwd_lay(H, Lz, K);
     const BwdLay bl = bwd_lay(H, Lz, K);
     const float* Wy1 = P + E.w[1];
@@ -864,16 +869,15 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   const float* u = a.u;
   float* ge = eps ? nullptr : w.eps;
   float* gu = (gm && !u) ? w.u : nullptr;
-  const uint64_t ne = ge ? (uint64_t)R * Lz : 0, nu = gu ? (uint64_t)R * K : 0;
   if (ge) eps = ge;
   if (gu) u = gu;
-  if (a.backward && mega_ok(d, model)) return run_step_mega(cx, a, L, w, eps, u, ge, ne, gu, nu);
+  if (a.backward && mega_ok(d, model)) return run_step_mega(cx, a, L, w, eps, u, ge, gu);
   if (fused_ok(d, model) && !a.z_out && !a.y_out && !a.logits_out)
-    return run_step_fused(cx, a, L, w, eps, u, ge, ne, gu, nu);
-  if (ne + nu) {
-    const uint64_t q = (ne + 3) / 4 + (nu + 3) / 4;
-    hipLaunchKernelGGL(noise_fill, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, ge, ne, gu, nu, a.seed,
-                       a.step, a.step_dev);
+    return run_step_fused(cx, a, L, w, eps, u, ge, gu);
+  if (ge || gu) {
+    const uint64_t q = noise_items(ge, gu, (uint64_t)R, Lz, K);
+    hipLaunchKernelGGL(noise_fill, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, ge, gu, (uint64_t)R, Lz, K,
+                       (uint64_t)d.row0 * S, a.seed, a.step, a.step_dev);
     rowk(cx, "noise_fill");
   }
 
@@ -1133,7 +1137,7 @@ static int step_with_adam(const GmvaeDims* dims, int model, const uint8_t* x, fl
                           float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float b1,
                           float b2, float eps_, hipStream_t st, bool imgs_ready = false, const uint8_t* next_pix = nullptr,
                           const int32_t* next_idx = nullptr, uint8_t* next_x = nullptr, uint64_t next_rows_src = 0,
-                          uint64_t bin_seed = 0) {
+                          uint64_t bin_seed = 0, float* tail_log = nullptr) {
   Ctx cx;
   cx.st = st;
   StepArgs a = {dims, model, x, nullptr, nullptr, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
@@ -1141,6 +1145,7 @@ static int step_with_adam(const GmvaeDims* dims, int model, const uint8_t* x, fl
   a.adam_p = params; a.adam_m = m; a.adam_v = v; a.lr = lr; a.beta1 = b1; a.beta2 = b2; a.epsilon = eps_;
   a.imgs_ready = imgs_ready;
   a.next_pix = next_pix; a.next_idx = next_idx; a.next_x = next_x; a.next_rows_src = next_rows_src; a.bin_seed = bin_seed;
+  a.tail_log = tail_log;
   return run_step(cx, a);
 }
 
@@ -1160,37 +1165,39 @@ int gmvae_forward(const GmvaeDims* dims, int model, const uint8_t* x, const floa
 
 int adam_tf_step(float* params, float* m, float* v, const float* grads, uint64_t P, float lr, float beta1,
                  float beta2, float epsilon, uint64_t t, const uint64_t* t_dev, float grad_scale,
-                 const float* grad_scale_dev, void* stream) {
+                 const float* grad_scale_dev, const float* loss_sum_dev, void* stream) {
   if (!params || !m || !v || !grads) return GMVAE_E_NULL;
   if (P == 0) return GMVAE_E_DIMS;
   if (!aligned16(params) || !aligned16(m) || !aligned16(v) || !aligned16(grads)) return GMVAE_E_ALIGN;
   (void)hipGetLastError();
   hipLaunchKernelGGL(adam_tf, dim3((unsigned)(((P + 3) / 4 + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), params, m, v, grads, (long long)P, lr, beta1, beta2, epsilon, t,
-                     t_dev, grad_scale, grad_scale_dev);
+                     t_dev, grad_scale, grad_scale_dev, loss_sum_dev);
   return (int)hipGetLastError();
 }
 
-int gmvae_noise_fill(float* eps, uint64_t n_eps, float* u, uint64_t n_u, uint64_t seed, uint64_t step,
+int gmvae_noise_fill(float* eps, float* u, uint64_t rows, int L, int K, uint64_t row_base, uint64_t seed, uint64_t step,
                      const uint64_t* step_dev, void* stream) {
-  if ((!eps && n_eps) || (!u && n_u)) return GMVAE_E_NULL;
-  const uint64_t q = (n_eps + 3) / 4 + (n_u + 3) / 4;
+  if ((eps && L < 1) || (u && K < 1)) return GMVAE_E_DIMS;
+  if ((eps && !aligned16(eps)) || (u && !aligned16(u))) return GMVAE_E_ALIGN;
+  const uint64_t q = noise_items(eps, u, rows, L, K);
   if (q == 0) return 0;
   (void)hipGetLastError();
   hipLaunchKernelGGL(noise_fill, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     eps, n_eps, u, n_u, seed, step, step_dev);
+                     eps, u, rows, L, K, row_base, seed, step, step_dev);
   return (int)hipGetLastError();
 }
 
 int gmvae_binarize(const uint8_t* pixels, uint64_t n_rows, const int32_t* idx, uint64_t row0, int B, int D,
-                   uint64_t seed, uint64_t step, const uint64_t* step_dev, uint8_t* x_out, void* stream) {
+                   uint64_t seed, uint64_t step, const uint64_t* step_dev, uint8_t* x_out, uint64_t out_row0,
+                   void* stream) {
   if (!pixels || !x_out) return GMVAE_E_NULL;
   if (B < 1 || D < 4 || (D & 3) || n_rows < 1 || (!idx && row0 + (uint64_t)B > n_rows)) return GMVAE_E_DIMS;
   if ((reinterpret_cast<uintptr_t>(pixels) & 3) || (reinterpret_cast<uintptr_t>(x_out) & 3)) return GMVAE_E_ALIGN;
   (void)hipGetLastError();
   const uint64_t q = (uint64_t)B * (D >> 2);
   hipLaunchKernelGGL(binarize_rows, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), pixels,
-                     idx, row0, n_rows, B, D, seed, step, step_dev, x_out);
+                     idx, row0, n_rows, B, D, seed, step, step_dev, x_out, out_row0);
   return (int)hipGetLastError();
 }
 
@@ -1434,7 +1441,7 @@ int gmvae_bench_loop(const GmvaeDims* dims, int model, const uint8_t* x, float* 
     int rc = gmvae_step(dims, model, x, nullptr, nullptr, params, grads, workspace, 1234, 0, step_dev, s);
     if (rc) return rc;
     return adam_tf_step(params, m, v, grads, L.P_pad, 1e-3f, 0.9f, 0.999f, 1e-8f, 0, step_dev, 1.f,
-                        grads + L.P_pad + 4, s);
+                        grads + L.P_pad + 4, grads + L.P_pad, s);
   };
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
@@ -1490,7 +1497,7 @@ struct GmvaeTrainGraph {
 static int train_graph_create(const GmvaeDims* dims, int model, const uint8_t* pixels, uint64_t n_rows, const int32_t* idx,
                               uint8_t* x, int n_steps, float* params, float* m, float* v, float* grads, void* workspace,
                               uint64_t seed, uint64_t* step_dev, float lr, float beta1, float beta2, float epsilon,
-                              void** graph_out) {
+                              float* tail_log, void** graph_out) {
   if (int e = check_dims(dims, model)) return e;
   if (!x || !params || !m || !v || !grads || !workspace || !step_dev || !graph_out) return GMVAE_E_NULL;
   if (n_steps < 1 || n_steps > 1024) return GMVAE_E_DIMS;
@@ -1514,19 +1521,22 @@ static int train_graph_create(const GmvaeDims* dims, int model, const uint8_t* p
       const uint64_t bseed = seed ^ 0x62696e6172697a65ull;
       const bool ride = pixels && mega_ok(*dims, model) && !getenv("GMVAE_NO_BIN_RIDE");
       if (pixels && (!ride || s == 0))
-        rc = gmvae_binarize(pixels, n_rows, idx + (size_t)s * dims->B, 0, dims->B, dims->D, bseed, 0, step_dev, xs, cs);
+        rc = gmvae_binarize(pixels, n_rows, idx + (size_t)s * dims->B, 0, dims->B, dims->D, bseed, 0, step_dev, xs,
+                            dims->row0, cs);
       if (rc) break;
       if (fused_ok(*dims, model) || mega_ok(*dims, model)) {
         // every step after the first finds its weight images written by the step before it (same graph, nothing in between)
         const bool nxt = ride && s + 1 < n_steps;
         rc = step_with_adam(dims, model, xs, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, cs, s > 0,
                             nxt ? pixels : nullptr, nxt ? idx + (size_t)(s + 1) * dims->B : nullptr, nxt ? xs + xstride : nullptr,
-                            n_rows, bseed);
+                            n_rows, bseed, tail_log ? tail_log + (size_t)s * GMVAE_TAIL : nullptr);
       } else {
         rc = gmvae_step(dims, model, xs, nullptr, nullptr, params, grads, workspace, seed, 0, step_dev, cs);
         if (rc == 0)
           rc = adam_tf_step(params, m, v, grads, L.P_pad, lr, beta1, beta2, epsilon, 0, step_dev, 1.f,
-                            grads + L.P_pad + 4, cs);
+                            grads + L.P_pad + 4, grads + L.P_pad, cs);
+        if (rc == 0 && tail_log)
+          hipMemcpyAsync(tail_log + (size_t)s * GMVAE_TAIL, grads + L.P_pad, GMVAE_TAIL * sizeof(float), hipMemcpyDeviceToDevice, cs);
       }
     }
     he = hipStreamEndCapture(cs, &tg->graph);
@@ -1548,18 +1558,18 @@ static int train_graph_create(const GmvaeDims* dims, int model, const uint8_t* p
 
 int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, int n_steps, float* params, float* m,
                              float* v, float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr,
-                             float beta1, float beta2, float epsilon, void** graph_out) {
+                             float beta1, float beta2, float epsilon, float* tail_log, void** graph_out) {
   return train_graph_create(dims, model, nullptr, 0, nullptr, const_cast<uint8_t*>(x), n_steps, params, m, v, grads, workspace,
-                            seed, step_dev, lr, beta1, beta2, epsilon, graph_out);
+                            seed, step_dev, lr, beta1, beta2, epsilon, tail_log, graph_out);
 }
 
 int gmvae_train_graph_create_pipeline(const GmvaeDims* dims, int model, const uint8_t* pixels, uint64_t n_rows,
                                       const int32_t* idx, uint8_t* x_scratch, int n_steps, float* params, float* m, float* v,
                                       float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr,
-                                      float beta1, float beta2, float epsilon, void** graph_out) {
+                                      float beta1, float beta2, float epsilon, float* tail_log, void** graph_out) {
   if (!pixels || !idx) return GMVAE_E_NULL;
   return train_graph_create(dims, model, pixels, n_rows, idx, x_scratch, n_steps, params, m, v, grads, workspace, seed, step_dev,
-                            lr, beta1, beta2, epsilon, graph_out);
+                            lr, beta1, beta2, epsilon, tail_log, graph_out);
 }
 
 int gmvae_train_graph_launch(void* graph, void* stream) {
@@ -1670,7 +1680,7 @@ int gmvae_comm_destroy(void* comm) {
  * previous step of the same graph did so, and this step may run its first layer inside mega_fwd_bwd. */
 static int dp_step_impl(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v, float* grads,
                         void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1, float beta2,
-                        float epsilon, void* comm, hipStream_t st, bool in_graph, bool imgs_ready) {
+                        float epsilon, void* comm, hipStream_t st, bool in_graph, bool imgs_ready, float* tail_log = nullptr) {
   if (int e = check_dims(dims, model)) return e;
   if (!x || !params || !m || !v || !grads || !workspace || !comm || !g_rccl.h || !step_dev) return GMVAE_E_NULL;
   if (!aligned16(params) || !aligned16(grads) || !aligned16(workspace)) return GMVAE_E_ALIGN;
@@ -1697,15 +1707,18 @@ static int dp_step_impl(const GmvaeDims* dims, int model, const uint8_t* x, floa
   if (rc) return rc;
   const int nrc = g_rccl.AllReduce(grads, grads, (size_t)L.P_pad + GMVAE_TAIL, /*ncclFloat*/ 7, /*ncclSum*/ 0, comm, st);
   if (nrc) return 1000 + nrc;
-  if (!scatter)
-    return adam_tf_step(params, m, v, grads, L.P_pad, lr, beta1, beta2, epsilon, 0, step_dev, 1.f, grads + L.P_pad + 4, st);
+  if (!scatter) {
+    if (tail_log) hipMemcpyAsync(tail_log, grads + L.P_pad, GMVAE_TAIL * sizeof(float), hipMemcpyDeviceToDevice, st);
+    return adam_tf_step(params, m, v, grads, L.P_pad, lr, beta1, beta2, epsilon, 0, step_dev, 1.f, grads + L.P_pad + 4,
+                        grads + L.P_pad, st);
+  }
   ImgScatter sc;
   memset(&sc, 0, sizeof(sc));
   sc.nmap = pl.nmap; sc.lo = pl.lo; sc.hi = pl.hi; sc.img0 = w.img_m; sc.img1 = w.dimg; sc.epoch_word = w.sync;
   for (int i = 0; i < pl.nmap; ++i) { sc.map[i] = pl.map[i]; sc.mbegin[i] = pl.map[i].begin; sc.mend[i] = pl.map[i].end; }
   (void)hipGetLastError();
   hipLaunchKernelGGL(adam_tf_img, dim3((unsigned)((L.P_pad / 4 + 255) / 256)), dim3(256), 0, st, params, m, v, grads,
-                     (long long)L.P_pad, lr, beta1, beta2, epsilon, step_dev, grads + L.P_pad + 4, sc);
+                     (long long)L.P_pad, lr, beta1, beta2, epsilon, step_dev, grads + L.P_pad + 4, grads + L.P_pad, tail_log, sc);
   return (int)hipGetLastError();
 }
 
@@ -1719,7 +1732,7 @@ int gmvae_dp_step(const GmvaeDims* dims, int model, const uint8_t* x, float* par
 /* the same step captured once into a hipGraph (RCCL kernels included); replay with gmvae_train_graph_launch */
 int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, int n_steps, float* params, float* m, float* v,
                           float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1,
-                          float beta2, float epsilon, void* comm, void** graph_out) {
+                          float beta2, float epsilon, void* comm, float* tail_log, void** graph_out) {
   if (int e = check_dims(dims, model)) return e;
   if (!graph_out || !comm) return GMVAE_E_NULL;
   if (n_steps < 1 || n_steps > 1024) return GMVAE_E_DIMS;
@@ -1740,7 +1753,7 @@ int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, in
   if (rc == 0) {
     for (int s = 0; s < n_steps && rc == 0; ++s)
       rc = dp_step_impl(dims, model, x + (size_t)s * dims->B * dims->D, params, m, v, grads, workspace, seed, step_dev, lr,
-                        beta1, beta2, epsilon, comm, cs, true, s > 0);
+                        beta1, beta2, epsilon, comm, cs, true, s > 0, tail_log ? tail_log + (size_t)s * GMVAE_TAIL : nullptr);
     he = hipStreamEndCapture(cs, &tg->graph);
     if (rc == 0 && he != hipSuccess) rc = (int)he;
   }

@@ -22,19 +22,19 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // eps ~ N(0,1) (Box-Muller), u ~ U[tiny,1).  One thread -> 4 values (aux.hpp: noise_item).
-__global__ void noise_fill(float* eps, uint64_t n_eps, float* u, uint64_t n_u, uint64_t seed, uint64_t step,
+__global__ void noise_fill(float* eps, float* u, uint64_t rows, int L, int K, uint64_t row_base, uint64_t seed, uint64_t step,
                            const uint64_t* step_dev) {
   if (step_dev) step = *step_dev;
-  noise_item((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, eps, n_eps, u, n_u, seed, step);
+  noise_item((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, eps, u, rows, L, K, row_base, seed, step);
 }
 
 // Dynamic binarisation of the input pipeline as its own launch (aux.hpp: binarize_quad): HBM-bound byte work,
 // D + D bytes per row, one thread per 4 pixels.
 __global__ void binarize_rows(const unsigned char* __restrict__ pixels, const int32_t* __restrict__ idx, uint64_t row0,
                               uint64_t n_rows_src, int B, int D, uint64_t seed, uint64_t step,
-                              const uint64_t* step_dev, unsigned char* __restrict__ x) {
+                              const uint64_t* step_dev, unsigned char* __restrict__ x, uint64_t out_row0) {
   if (step_dev) step = *step_dev;
-  binarize_quad((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, pixels, idx, row0, n_rows_src, B, D, seed, step, x);
+  binarize_quad((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, pixels, idx, row0, n_rows_src, B, D, seed, step, x, out_row0);
 }
 
 // ------------------------------------------------ q(y|x): Gumbel-softmax head
@@ -459,7 +459,10 @@ __global__ void finalize_grads(const float* __restrict__ slabs, int nslab, long 
 // One launch over the whole flat buffer (multi-tensor by construction).
 __global__ void adam_tf(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                         const float* __restrict__ g, long long P, float lr, float b1, float b2, float eps,
-                        uint64_t t, const uint64_t* t_dev, float gscale, const float* gscale_dev) {
+                        uint64_t t, const uint64_t* t_dev, float gscale, const float* gscale_dev,
+                        const float* loss_sum_dev) {
+  // a poisoned step (hand-off timeout: NaN loss sum, here or on any rank of the all-reduce) must not reach the state
+  if (loss_sum_dev && !__builtin_isfinite(*loss_sum_dev)) return;
   if (t_dev) t = *t_dev;
   if (gscale_dev) gscale = 1.f / *gscale_dev;
   // TF's ApplyAdam functor, in its own fp32 form (tensorflow/core/kernels/training_ops.cc):
@@ -517,12 +520,14 @@ struct FinalArgs {
   int do_adam; float count;            // count = number of rows on this device (single-device scale)
   const float *logw, *logpx, *logq, *logp, *nent;
   float* tail; int B;
+  float* tail_log;            // (may be null) a second copy of the tail: slot of this step in a train graph's per-step log
   unsigned long long* step_dev;
   // the updated parameters are also scattered into the next step's weight images (then that step needs no
   // image-building launch); nmap = 0: off
   int nmap, map_lo, map_hi;
   float *img0, *img1;
   unsigned* epoch_word;       // bumped for the next step's in-launch hand-offs
+  const unsigned* err_word;   // hand-off timeout flag of this workspace: when set the step is poisoned and NOT applied
   unsigned long long* span;   // measurement: [block][2] wall-clock (100 MHz) at a block's first and last instruction
   // VAE_GMP: the prior variables' gradients are per-workgroup partials of mega_fwd_bwd, not split-K slabs
   const float* gmp_part; int gmp_n, gmp_len; long long gmp_off;
@@ -532,7 +537,7 @@ struct FinalArgs {
   const unsigned char* bin_pix;
   const int32_t* bin_idx;
   unsigned char* bin_x;
-  unsigned long long bin_rows_src, bin_seed;
+  unsigned long long bin_rows_src, bin_seed, bin_row0;   // bin_row0: global index of the batch's first row (Philox counter)
   SlabX sx;
   int mbegin[kMaxImgMap], mend[kMaxImgMap];   // the ranges again, adjacent: one round of scalar loads finds the entry
   ImgMap map[kMaxImgMap];
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
     const uint64_t q0 = ((uint64_t)((int)blockIdx.x - nb - 1) * kBinQuadsPerThread) * 256 + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < kBinQuadsPerThread; ++j)
-      binarize_quad(q0 + (uint64_t)j * 256, a.bin_pix, a.bin_idx, 0, a.bin_rows_src, a.bin_B, a.bin_D, a.bin_seed, step, a.bin_x);
+      binarize_quad(q0 + (uint64_t)j * 256, a.bin_pix, a.bin_idx, 0, a.bin_rows_src, a.bin_B, a.bin_D, a.bin_seed, step, a.bin_x, a.bin_row0);
     GMVAE_FIN_END();
     return;
   }
@@ -569,6 +574,10 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
     if (threadIdx.x == 0) {
       a.tail[0] = red[0][0]; a.tail[1] = red[1][0]; a.tail[2] = red[2][0]; a.tail[3] = red[3][0];
       a.tail[4] = (float)a.B; a.tail[5] = 0.f; a.tail[6] = 0.f; a.tail[7] = 0.f;
+      if (a.tail_log) {
+        a.tail_log[0] = red[0][0]; a.tail_log[1] = red[1][0]; a.tail_log[2] = red[2][0]; a.tail_log[3] = red[3][0];
+        a.tail_log[4] = (float)a.B; a.tail_log[5] = 0.f; a.tail_log[6] = 0.f; a.tail_log[7] = 0.f;
+      }
       if (a.step_dev) a.step_dev[0] = a.step_dev[1] + 1;
       if (a.epoch_word) *a.epoch_word += 1u;
     }
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
     g = acc;
   }
   *reinterpret_cast<float4*>(a.grads + i4) = g;
-  if (!a.do_adam) { GMVAE_FIN_END(); return; }
+  if (!a.do_adam || (a.err_word && *a.err_word)) { GMVAE_FIN_END(); return; }
   const unsigned long long t = (a.step_dev ? a.step_dev[1] : 0ull) + 1ull;
   const float lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, (double)t)) / (1.0 - pow((double)a.b1, (double)t)));
   const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, gs = 1.f / a.count;
@@ -680,8 +689,10 @@ struct ImgScatter {
 __global__ __launch_bounds__(256) void adam_tf_img(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ g, long long P, float lr, float b1, float b2,
                                                    float eps, const uint64_t* t_dev, const float* gscale_dev,
-                                                   const ImgScatter sc) {
+                                                   const float* loss_sum_dev, float* tail_log, const ImgScatter sc) {
   if (blockIdx.x == 0 && threadIdx.x == 0 && sc.epoch_word) *sc.epoch_word += 1u;
+  if (blockIdx.x == 0 && threadIdx.x < 8 && tail_log && loss_sum_dev) tail_log[threadIdx.x] = loss_sum_dev[threadIdx.x];   // the all-reduced tail
+  if (loss_sum_dev && !__builtin_isfinite(*loss_sum_dev)) return;   // poisoned step: keep params, m, v and the images
   const unsigned long long t = *t_dev;
   const float gscale = 1.f / *gscale_dev;
   const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));

@@ -90,7 +90,7 @@ __host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D, int mode
     m.fl_W = 0;
     m.fl_A = GMVAE_P256(nw * m.fl_kq * H);
     m.fl_ok = (m.fl_A + kPanel * kFlLda <= m.nll) && m.fl_kq <= kFlLda && D % 16 == 0 && nw * H <= 128 && H % 16 == 0 && L % 2 == 0 &&
-              H == 64 && (m.fl_kq * H) % 256 == 0 && kPanel * m.fl_kq / 4 <= 2 * kMT && 4 * L + (model == 2 ? 4 * K : 0) <= kMT;
+              H == 64 && (m.fl_kq * H) % 256 == 0 && kPanel * m.fl_kq / 4 <= 2 * kMT && L % 4 == 0 && 4 * L + (model == 2 ? 4 * ((K + 3) & ~3) : 0) <= kMT;
   }
   return m;
 }
@@ -243,6 +243,7 @@ struct MegaArgs {
   const float *w0a, *w0b;     // first-layer weights [D][H]: encoder(_y) and, GMVAE, encoder_gmm's x rows
   unsigned long long* xfl;    // [panels][4][16 * H2] granules
   unsigned long long seed;
+  unsigned long long row0;    // global index of this device's first batch row (GmvaeDims::row0): Philox counter only
   unsigned long long* step_dev;
 };
 
@@ -321,7 +322,9 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     const int kn = max(0, min(KQ, D - k0));        // rows of this quarter that exist (the last quarter may be short)
     const unsigned epoch_fl = *a.epoch_word;
     const unsigned long long step = a.step_dev[0];
-    const int qe = kPanel * L / 4, qu = gm ? kPanel * K / 4 : 0;
+    // noise items of this panel: one quad of one row each (L % 4 == 0 here; K is padded to quads per row)
+    const int qer = L / 4, qur = gm ? (K + 3) / 4 : 0;
+    const int qe = kPanel * qer, qu = kPanel * qur;
     float nz[4] = {0.f, 0.f, 0.f, 0.f};
     const int ntile = H2f / 16, tpw = H / 16;      // tiles; tiles per weight tensor
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -340,12 +343,14 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       }
     };
     auto noise_draw = [&]() {
-      // this panel's rows of the Philox streams (the values gmvae_noise_fill produces for the same seed and step),
-      // drawn while the loads are in flight and parked in registers until the staging area is dead
+      // this panel's rows of the Philox streams (the values gmvae_noise_fill produces for the same seed, step and
+      // global row), drawn while the loads are in flight and parked in registers until the staging area is dead
       if (tid < qe + qu) {
         const bool is_u = tid >= qe;
         const int li = is_u ? tid - qe : tid;
-        noise_vals((unsigned long long)(is_u ? (long long)r0 * K / 4 : (long long)r0 * L / 4) + li, is_u, a.seed, step, nz);
+        const int qpr = max(is_u ? qur : qer, 1);
+        const int row = li / qpr, quad = li - row * qpr;
+        noise_vals(a.row0 + (unsigned long long)(r0 + row), (unsigned)quad, is_u, a.seed, step, nz);
       }
     };
     if constexpr (HT == 64 && DT == 784 && MODEL == 2) {
@@ -427,9 +432,13 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     GMVAE_FS(1);
     GMVAE_FL(6);
     dma_copy_m(sm, a.img, f.img_early, wave, lane);
-    if (tid < qe + qu) {
-      const bool is_u = tid >= qe;
-      *reinterpret_cast<float4*>((is_u ? P_u : P_eps) + (is_u ? tid - qe : tid) * 4) = make_float4(nz[0], nz[1], nz[2], nz[3]);
+    if (tid < qe) {
+      *reinterpret_cast<float4*>(P_eps + tid * 4) = make_float4(nz[0], nz[1], nz[2], nz[3]);
+    } else if (tid < qe + qu) {
+      const int li = tid - qe, row = li / max(qur, 1), k0u = (li - row * qur) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (k0u + j < K) P_u[row * K + k0u + j] = nz[j];
     }
     if (bid == gridDim.x - 1 && tid == 0) a.step_dev[1] = step;       // the copy finalize_adam reads
     // the quarters' partials (this workgroup's own included), two quarters per sweep: 8 granules of a lane are

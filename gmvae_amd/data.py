@@ -18,9 +18,10 @@ from . import _lib as L
 
 
 def binarize(pixels: torch.Tensor, rows: Optional[torch.Tensor] = None, row0: int = 0, batch: Optional[int] = None,
-             seed: int = 0, step: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             seed: int = 0, step: int = 0, out: Optional[torch.Tensor] = None, out_row0: int = 0) -> torch.Tensor:
     """x[b, :] = (pixels[rows[b], :] / 255 < U) as uint8 0/1 (runners.py:48-51).  `rows`: int32 device tensor of
-    source rows, or None for rows row0 .. row0+batch-1.  The uniforms are Philox4x32-10 keyed by (seed, step)."""
+    source rows, or None for rows row0 .. row0+batch-1.  The uniforms are Philox4x32-10 keyed by (seed, step) and the
+    element's position in the global batch (out_row0 = this shard's first row: rank * B under data parallelism)."""
     dev = L.require_gpu()
     if pixels.dtype != torch.uint8 or pixels.dim() != 2 or not pixels.is_cuda or not pixels.is_contiguous():
         raise ValueError("pixels must be a contiguous uint8 [N, D] tensor on the GPU")
@@ -33,7 +34,8 @@ def binarize(pixels: torch.Tensor, rows: Optional[torch.Tensor] = None, row0: in
     if out is None:
         out = torch.empty(B, D, dtype=torch.uint8, device=dev)
     L.check(L.lib.gmvae_binarize(L.ptr(pixels), N, L.ptr(rows) if rows is not None else None, int(row0), B, D,
-                                 int(seed), int(step), None, L.ptr(out), L.current_stream()), "gmvae_binarize")
+                                 int(seed), int(step), None, L.ptr(out), int(out_row0), L.current_stream()),
+            "gmvae_binarize")
     return out
 
 

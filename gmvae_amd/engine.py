@@ -42,6 +42,11 @@ class Engine:
                  hidden: Sequence[int], n_samples: int = 1, sigma_min: float = 0.0, raw_sigma_bias: float = 0.5,
                  temperature: float = 1.0, gen_bias_init: float = 0.0, random_seed: Optional[int] = None):
         self.device = L.require_gpu()
+        # data parallel: this process's shard index.  Row b of a local batch of B rows is global row rank*B + b for the
+        # Philox counters (GmvaeDims.row0), so G ranks draw the noise of ONE step on the global batch of G*B rows.
+        import torch.distributed as dist
+        self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.model_name = model
         self.model = L.MODEL_IDS[model]
         self.D, self.Lz, self.K, self.S = int(data_size), int(latent_size), int(mixture_components), int(n_samples)
@@ -59,13 +64,29 @@ class Engine:
         self.v = torch.zeros(self.P, dtype=torch.float32, device=self.device)
         self.step_dev = torch.zeros(2, dtype=torch.int64, device=self.device)   # global_step (device resident) + scratch copy
         self.global_step = 0
-        self._ws: Dict[tuple, tuple] = {}
+        self._ws: Dict[tuple, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
+        self._graph_gen = 0                     # bumped by drop_graphs: replay closures of dropped graphs raise
         self.init_parameters(random_seed)
 
     # ------------------------------------------------------------ parameters
-    def dims(self, B: int, S: Optional[int] = None):
-        return L.make_dims(B, self.D, self.Lz, self.K, self.hidden, S=self.S if S is None else S, **self.hp)
+    def dims(self, B: int, S: Optional[int] = None, row0: Optional[int] = None):
+        """GmvaeDims for a local batch of B rows; row0 = global index of its first row (default rank * B)."""
+        return L.make_dims(B, self.D, self.Lz, self.K, self.hidden, S=self.S if S is None else S,
+                           row0=self.rank * B if row0 is None else int(row0), **self.hp)
+
+    def sync_replicas(self, src: int = 0):
+        """Data parallel: every rank takes rank `src`'s parameters, Adam moments, step counter and noise seed (the
+        reference's default random_seed=None seeds each process from entropy, scripts/run_gmvae.py:30).  Afterwards
+        replicas stay bit-identical: every rank applies the same all-reduced gradient."""
+        import torch.distributed as dist
+        from . import parallel
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        self.noise_seed, self.global_step = parallel.broadcast_state((self.params, self.m, self.v),
+                                                                     (self.noise_seed, self.global_step), src)
+        self.step_dev.fill_(self.global_step)
+        self.drop_graphs()                       # captured graphs baked the old seed
 
     def init_parameters(self, seed: Optional[int] = None):
         """Xavier-uniform weights, zero biases (scripts/base.py:12); Glorot-uniform
@@ -100,10 +121,27 @@ class Engine:
                 out[name] = v.view(rows, cols)
         return out
 
+    def _slot_views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        out = {}
+        for name, (rows, cols), off in self.layout:
+            v = flat[off:off + rows * cols]
+            out[name] = v if (name.endswith("/b") or name == "mixture_logits") else v.view(rows, cols)
+        return out
+
     def state_dict(self) -> Dict[str, torch.Tensor]:
+        """Keys = the reference's TF checkpoint variable names: every model variable, its two Adam
+        slots `<var>/Adam` (m) and `<var>/Adam_1` (v) as tf.train.AdamOptimizer names them (scripts/runners.py:181),
+        the optimizer's `beta1_power` / `beta2_power` accumulators (= beta^(global_step+1) in TF 1.13: the value the
+        NEXT apply uses) and `global_step`.  `noise_seed` (not a TF variable) keeps the Philox stream across a restart."""
         sd = {k: v.clone() for k, v in self.views().items()}
+        for k, v in self._slot_views(self.m).items():
+            sd[k + "/Adam"] = v.clone()
+        for k, v in self._slot_views(self.v).items():
+            sd[k + "/Adam_1"] = v.clone()
         sd["global_step"] = torch.tensor(self.global_step)
-        sd["adam/m"], sd["adam/v"] = self.m.clone(), self.v.clone()
+        sd["beta1_power"] = torch.tensor(0.9 ** (self.global_step + 1), dtype=torch.float32)
+        sd["beta2_power"] = torch.tensor(0.999 ** (self.global_step + 1), dtype=torch.float32)
+        sd["noise_seed"] = torch.tensor(self.noise_seed, dtype=torch.int64)
         return sd
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -111,20 +149,28 @@ class Engine:
         with torch.no_grad():
             for k, v in views.items():
                 v.copy_(sd[k].to(self.device).reshape(v.shape))
-            if "adam/m" in sd:
+            if "adam/m" in sd:                    # round-1 checkpoints: two flat blobs
                 self.m.copy_(sd["adam/m"].to(self.device))
                 self.v.copy_(sd["adam/v"].to(self.device))
+            else:
+                for slot, flat in (("/Adam", self.m), ("/Adam_1", self.v)):
+                    for k, v in self._slot_views(flat).items():
+                        if k + slot in sd:
+                            v.copy_(sd[k + slot].to(self.device).reshape(v.shape))
             self.global_step = int(sd.get("global_step", 0))
+            if "noise_seed" in sd:
+                self.noise_seed = int(sd["noise_seed"])
             self.step_dev.fill_(self.global_step)
+        self.drop_graphs()                        # graphs bake the noise seed
 
     # ------------------------------------------------------------- workspace
-    def _workspace(self, B: int, S: Optional[int] = None):
+    def _workspace(self, B: int, S: Optional[int] = None, row0: Optional[int] = None):
         key = (B, self.S if S is None else S)
+        d = self.dims(B, S, row0)
         if key not in self._ws:
-            d = self.dims(B, S)
             n = L.workspace_bytes(d, self.model)
-            self._ws[key] = (d, torch.zeros(n // 4 + 64, dtype=torch.float32, device=self.device))
-        return self._ws[key]
+            self._ws[key] = torch.zeros(n // 4 + 64, dtype=torch.float32, device=self.device)
+        return d, self._ws[key]
 
     @staticmethod
     def _as_u8(x: torch.Tensor) -> torch.Tensor:
@@ -150,12 +196,13 @@ class Engine:
         return t
 
     # ------------------------------------------------------------------ ops
-    def step(self, x, eps=None, u=None, use_step_dev: bool = False) -> torch.Tensor:
+    def step(self, x, eps=None, u=None, use_step_dev: bool = False, row0: Optional[int] = None) -> torch.Tensor:
         """Fused forward + backward.  Returns the [P + TAIL] buffer of gradient
-        SUMS and loss sums (see include/gmvae_hip.h).  eps/u None -> Philox."""
+        SUMS and loss sums (see include/gmvae_hip.h).  eps/u None -> Philox, keyed by
+        (noise_seed, global_step, global row = row0 + b; row0 defaults to rank * B)."""
         x = self._prep_x(x)
         B = x.shape[0]
-        d, ws = self._workspace(B)
+        d, ws = self._workspace(B, row0=row0)
         eps = self._prep_noise(eps, B * self.S, self.Lz)
         u = self._prep_noise(u, B * self.S, self.K) if self.model == L.MODEL_GMVAE else None
         rc = L.lib.gmvae_step(C.byref(d), self.model, L.ptr(x), L.ptr(eps), L.ptr(u), L.ptr(self.params),
@@ -214,42 +261,64 @@ class Engine:
         if not use_step_dev:
             self.global_step += 1
         count = g[self.P + 4:self.P + 5]
+        loss_sum = g[self.P:self.P + 1]          # non-finite (poisoned step, on any rank) -> the update is skipped
         rc = L.lib.adam_tf_step(L.ptr(self.params), L.ptr(self.m), L.ptr(self.v), L.ptr(g), self.P, lr, beta1, beta2,
                                 epsilon, self.global_step, L.ptr(self.step_dev) if use_step_dev else None, 1.0,
-                                L.ptr(count), L.current_stream())
+                                L.ptr(count), L.ptr(loss_sum), L.current_stream())
         L.check(rc, "adam_tf_step")
+        if not use_step_dev:
+            self.step_dev.fill_(self.global_step)   # one source of truth: graphs replayed later start from here
 
-    def train_step(self, x, eps=None, u=None, lr: float = 1e-3, all_reduce: bool = True) -> torch.Tensor:
+    def train_step(self, x, eps=None, u=None, lr: float = 1e-3, all_reduce: bool = True,
+                   row0: Optional[int] = None) -> torch.Tensor:
         """One full reference step: fwd + bwd (+ RCCL all-reduce) + Adam.
         Returns the [TAIL] loss sums (device tensor; no host sync)."""
         import torch.distributed as dist
-        self.step(x, eps, u)
+        self.step(x, eps, u, row0=row0)
         if all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.grads)         # ONE collective: grads + loss sums + count
         self.adam(lr)
         return self.grads[self.P:]
 
     # -------------------------------------------------- data parallel over RCCL inside the C library
+    def _agree(self, ok: bool) -> bool:
+        """True only if `ok` on EVERY rank (one all-reduce(MIN)): ranks must never split over a fallback decision,
+        or they would issue mismatched collectives and hang."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        t = t.to(self.device) if dist.get_backend() == "nccl" else t
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
     def enable_rccl(self):
         """Creates this rank's RCCL communicator inside libgmvae_hip.so (the 128-byte unique id travels over
         torch.distributed).  Afterwards train_step / capture_train_step(all_reduce=True) enqueue
-        gradients -> ONE all-reduce -> Adam from a single C call (or one hipGraph)."""
+        gradients -> ONE all-reduce -> Adam from a single C call (or one hipGraph).  Every rank takes every
+        collective of this function whatever happens locally; a failure on any rank raises on ALL ranks."""
         import torch.distributed as dist
         if getattr(self, "_comm", None):
             return self._comm
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
         buf = C.create_string_buffer(128)
+        ok, why = True, ""
         if rank == 0:
-            L.check(L.lib.gmvae_comm_unique_id(L.rccl_path(), buf), "gmvae_comm_unique_id")
+            rc = L.lib.gmvae_comm_unique_id(L.rccl_path(), buf)
+            ok, why = rc == 0, f"gmvae_comm_unique_id rc={rc}"
         if world > 1:
             t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
             t = t.to(self.device) if dist.get_backend() == "nccl" else t
             dist.broadcast(t, src=0)
             buf = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+        if not self._agree(ok):
+            raise L.GmvaeError(f"in-library RCCL unavailable on some rank ({why or 'another rank failed'})")
         comm = C.c_void_p()
         torch.cuda.synchronize()
-        L.check(L.lib.gmvae_comm_init(L.rccl_path(), buf, rank, world, C.byref(comm)), "gmvae_comm_init")
+        rc = L.lib.gmvae_comm_init(L.rccl_path(), buf, rank, world, C.byref(comm))
+        if not self._agree(rc == 0):
+            raise L.GmvaeError(f"gmvae_comm_init failed on some rank (this rank rc={rc})")
         self._comm = comm
         return comm
 
@@ -279,6 +348,7 @@ class Engine:
         n_steps = int(n_steps)
         key = (B, lr, do_ar, n_steps)
         if key in self._graphs:
+            self.step_dev.fill_(self.global_step)   # eager steps may have run since the capture
             return self._graphs[key][:2]
         if n_steps == 1:
             static_x = torch.zeros(B, self.D, dtype=torch.uint8, device=self.device)
@@ -286,30 +356,40 @@ class Engine:
             static_x = torch.zeros(n_steps, B, self.D, dtype=torch.uint8, device=self.device)
         d, ws = self._workspace(B)
         self.step_dev.fill_(self.global_step)
+        # per-step tails of one launch (loss sums + count; all-reduced under data parallelism): replay.tail_log
+        tail_log = torch.zeros(n_steps, L.TAIL, dtype=torch.float32, device=self.device)
         if do_ar and getattr(self, "_comm", None):
             torch.cuda.synchronize()
             handle = C.c_void_p()
             rc = L.lib.gmvae_dp_graph_create(C.byref(d), self.model, L.ptr(static_x), n_steps, L.ptr(self.params), L.ptr(self.m),
                                              L.ptr(self.v), L.ptr(self.grads), L.ptr(ws), self.noise_seed,
-                                             L.ptr(self.step_dev), lr, 0.9, 0.999, 1e-8, self._comm, C.byref(handle))
-            if rc == 0:
+                                             L.ptr(self.step_dev), lr, 0.9, 0.999, 1e-8, self._comm, L.ptr(tail_log),
+                                             C.byref(handle))
+            if self._agree(rc == 0):                # all ranks jointly: the graph, or (below) the eager C-side step
                 launch = L.lib.gmvae_train_graph_launch
                 self.dp_mode = "rccl-in-hipgraph"
+                gen = self._graph_gen
 
                 def replay():
+                    self._check_alive(gen)
                     rc2 = launch(handle, L.current_stream())
                     if rc2:
                         L.check(rc2, "gmvae_train_graph_launch")
                     self.global_step += n_steps
+                replay.tail_log = tail_log
                 self._graphs[key] = (static_x, replay, handle)
                 return static_x, replay
-            self.step_dev.fill_(self.global_step)   # capture refused: eager C-side step instead
+            if rc == 0:
+                L.lib.gmvae_train_graph_destroy(handle)
+            self.step_dev.fill_(self.global_step)   # capture refused somewhere: eager C-side step instead
             self.dp_mode = "rccl-eager-c"
             batches = [static_x] if n_steps == 1 else list(static_x.unbind(0))
 
             def replay():
-                for xb in batches:
+                for i, xb in enumerate(batches):
                     self.dp_step(xb, lr)
+                    tail_log[i].copy_(self.grads[self.P:])
+            replay.tail_log = tail_log
             self._graphs[key] = (static_x, replay, None)
             return static_x, replay
         if do_ar:
@@ -317,27 +397,32 @@ class Engine:
             batches = [static_x] if n_steps == 1 else list(static_x.unbind(0))
 
             def replay():
-                for xb in batches:
+                for i, xb in enumerate(batches):
                     self.step(xb, use_step_dev=True)
                     dist.all_reduce(self.grads)
                     self.adam(lr, use_step_dev=True)
                     self.global_step += 1
+                    tail_log[i].copy_(self.grads[self.P:])
+            replay.tail_log = tail_log
             self._graphs[key] = (static_x, replay, None)
             return static_x, replay
         torch.cuda.synchronize()
         handle = C.c_void_p()
         rc = L.lib.gmvae_train_graph_create(C.byref(d), self.model, L.ptr(static_x), n_steps, L.ptr(self.params), L.ptr(self.m),
                                             L.ptr(self.v), L.ptr(self.grads), L.ptr(ws), self.noise_seed,
-                                            L.ptr(self.step_dev), lr, 0.9, 0.999, 1e-8, C.byref(handle))
+                                            L.ptr(self.step_dev), lr, 0.9, 0.999, 1e-8, L.ptr(tail_log), C.byref(handle))
         L.check(rc, "gmvae_train_graph_create")
         launch = L.lib.gmvae_train_graph_launch
+        gen = self._graph_gen
 
         def replay():
+            self._check_alive(gen)
             rc = launch(handle, L.current_stream())
             if rc:
                 L.check(rc, "gmvae_train_graph_launch")
             self.global_step += n_steps
 
+        replay.tail_log = tail_log
         self._graphs[key] = (static_x, replay, handle)
         return static_x, replay
 
@@ -351,62 +436,81 @@ class Engine:
         n_steps = int(n_steps)
         key = ("pipeline", id(dataset), B, lr, n_steps)
         if key in self._graphs:
+            self.step_dev.fill_(self.global_step)
             return self._graphs[key][1]
         if dataset.D != self.D:
             raise ValueError("dataset rows must have D pixels")
         d, ws = self._workspace(B)
         idx = torch.zeros(n_steps, B, dtype=torch.int32, device=self.device)
         xs = torch.zeros(n_steps, B, self.D, dtype=torch.uint8, device=self.device)
+        tail_log = torch.zeros(n_steps, L.TAIL, dtype=torch.float32, device=self.device)
         self.step_dev.fill_(self.global_step)
         torch.cuda.synchronize()
         handle = C.c_void_p()
         rc = L.lib.gmvae_train_graph_create_pipeline(C.byref(d), self.model, L.ptr(dataset.pixels), dataset.N, L.ptr(idx),
                                                      L.ptr(xs), n_steps, L.ptr(self.params), L.ptr(self.m), L.ptr(self.v),
                                                      L.ptr(self.grads), L.ptr(ws), self.noise_seed, L.ptr(self.step_dev), lr,
-                                                     0.9, 0.999, 1e-8, C.byref(handle))
+                                                     0.9, 0.999, 1e-8, L.ptr(tail_log), C.byref(handle))
         L.check(rc, "gmvae_train_graph_create_pipeline")
         launch = L.lib.gmvae_train_graph_launch
+        gen = self._graph_gen
 
         def replay():
+            self._check_alive(gen)
             idx.copy_(dataset.next_rows(n_steps * B).view(n_steps, B))
             rc2 = launch(handle, L.current_stream())
             if rc2:
                 L.check(rc2, "gmvae_train_graph_launch")
             self.global_step += n_steps
 
-        replay.rows, replay.batches = idx, xs          # the buffers of the last launch (tests, summaries)
+        replay.rows, replay.batches, replay.tail_log = idx, xs, tail_log   # the buffers of the last launch (tests, summaries)
         self._graphs[key] = (xs, replay, handle)
         return replay
 
+    def _check_alive(self, gen: int):
+        if gen != self._graph_gen:
+            raise L.GmvaeError("this replay closure belongs to a train graph that drop_graphs() destroyed; capture again")
+
+    def _sync_word(self, key, ws):
+        off = C.c_uint64()
+        d = self.dims(key[0], key[1])
+        if L.lib.gmvae_workspace_offset(C.byref(d), self.model, b"sync", C.byref(off)) != 0:
+            return None
+        return ws.view(torch.int32)[off.value // 4 + 1:off.value // 4 + 2]
+
     def handoff_timeouts(self) -> int:
         """Number of workspaces whose in-launch hand-off (mega_fwd_bwd's tagged-granule exchange between the
-        workgroups of a panel) ever gave up waiting.  Such a step also poisons its loss and gradients with NaN;
-        this is the explicit flag.  0 on a healthy device."""
+        workgroups of a panel) ever gave up waiting.  Such a step poisons its loss and gradients with NaN and the
+        optimizer skips it (params, m, v untouched); this is the explicit flag.  0 on a healthy device."""
         bad = 0
-        for (d, ws) in self._ws.values():
-            off = C.c_uint64()
-            if L.lib.gmvae_workspace_offset(C.byref(d), self.model, b"sync", C.byref(off)) == 0:
-                bad += int(ws.view(torch.int32)[off.value // 4 + 1].item() != 0)
+        for key, ws in self._ws.items():
+            w = self._sync_word(key, ws)
+            if w is not None:
+                bad += int(w.item() != 0)
         return bad
 
     def drop_graphs(self, clear_handoff_errors: bool = True):
         """Destroy every captured train graph (they are re-captured on the next capture_* call, under whatever
-        GMVAE_* schedule switches are set by then) and, optionally, clear the workspaces' hand-off error words."""
+        GMVAE_* schedule switches are set by then; replay closures handed out before raise from now on) and,
+        optionally, clear the workspaces' hand-off error words."""
         for _, _, handle in self._graphs.values():
             if handle:
                 L.lib.gmvae_train_graph_destroy(handle)
         self._graphs.clear()
+        self._graph_gen += 1
         if clear_handoff_errors:
-            for (d, ws) in self._ws.values():
-                off = C.c_uint64()
-                if L.lib.gmvae_workspace_offset(C.byref(d), self.model, b"sync", C.byref(off)) == 0:
-                    ws.view(torch.int32)[off.value // 4 + 1] = 0
+            for key, ws in self._ws.items():
+                w = self._sync_word(key, ws)
+                if w is not None:
+                    w.zero_()
 
     def __del__(self):
         try:
             for _, _, handle in self._graphs.values():
                 if handle:
                     L.lib.gmvae_train_graph_destroy(handle)
+            self._graphs.clear()
+            self._graph_gen += 1
         except Exception:
             pass
 

@@ -58,6 +58,31 @@ def grad_scale(buf: torch.Tensor, P: int) -> torch.Tensor:
     return 1.0 / buf[P + 4]
 
 
+def broadcast_state(tensors, ints=(), src: int = 0):
+    """Start-of-training replica sync (and after a checkpoint restore on rank 0 only): every rank takes rank `src`'s
+    tensors (parameters, Adam moments ...) IN PLACE and returns rank `src`'s integers (global step, noise seed ...).
+    The reference's default `--random_seed=None` (scripts/run_gmvae.py:30) seeds each process from entropy, so without
+    this the ranks would apply identical all-reduced gradients to different parameters.  Works with device tensors
+    over RCCL (backend "nccl") and with CPU or device tensors over gloo (staged through the host)."""
+    ints = [int(i) for i in ints]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return ints
+    on_dev = dist.get_backend() == "nccl"
+    meta = torch.tensor(ints if ints else [0], dtype=torch.int64)
+    if on_dev:
+        meta = meta.cuda()
+    dist.broadcast(meta, src=src)
+    with torch.no_grad():
+        for t in tensors:
+            if t.is_cuda and not on_dev:
+                buf = t.detach().cpu()
+                dist.broadcast(buf, src=src)
+                t.copy_(buf.to(t.device))
+            else:
+                dist.broadcast(t.detach(), src=src)
+    return [int(v) for v in meta.tolist()][:len(ints)]
+
+
 def assert_replicas_identical(params: torch.Tensor) -> bool:
     """Debug check: max |params - params_rank0| == 0 on every rank."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

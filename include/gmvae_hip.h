@@ -39,7 +39,7 @@ extern "C" {
 
 #define GMVAE_MAX_HIDDEN 8
 #define GMVAE_TAIL 8          /* floats appended to the gradient buffer */
-#define GMVAE_ABI_VERSION 1
+#define GMVAE_ABI_VERSION 2
 
 enum { GMVAE_MODEL_VAE = 0, GMVAE_MODEL_VAE_GMP = 1, GMVAE_MODEL_GMVAE = 2 };
 
@@ -67,6 +67,12 @@ typedef struct GmvaeDims {
   float raw_sigma_bias;
   float temperature;
   float gen_bias_init;
+  /* Data parallel (no reference counterpart; scripts/runners.py:193 pins one device): global index of this
+   * device's first batch row, rank * B for equal shards, 0 on a single device.  It enters ONLY the Philox counters
+   * of the in-kernel noise (eps, u) and of gmvae_binarize: row b of this device draws what row row0 + b of the
+   * single-device step on the whole global batch draws, so G shards reproduce the 1-device step on G*B rows.
+   * Sizes, layouts and the workspace do not depend on it. */
+  uint64_t row0;
 } GmvaeDims;
 
 /* One tensor of the flat parameter buffer.  Names are the reference's TF
@@ -134,10 +140,14 @@ int gmvae_forward(const GmvaeDims* dims, int model, const uint8_t* x, const floa
  * epsilon is added to the UN-corrected sqrt(v).  t = 1-based step count.
  * t_dev (may be NULL): device pointer overriding t (graph replay).
  * g = grads[i] * grad_scale.  grad_scale_dev (may be NULL): device pointer to
- * a count; when given, grad_scale = 1 / (*grad_scale_dev) overrides. */
+ * a count; when given, grad_scale = 1 / (*grad_scale_dev) overrides.
+ * loss_sum_dev (may be NULL): device pointer to the step's loss sum (tail[0] of the gradient buffer).  When it
+ * holds a non-finite value -- a hand-off of the fused schedule timed out and poisoned the step, on this or (after
+ * the all-reduce) on any rank -- the update is SKIPPED: params, m and v keep their values (the step counter still
+ * advances; the caller sees the NaN loss and the workspace error word). */
 int adam_tf_step(float* params, float* m, float* v, const float* grads, uint64_t P, float lr, float beta1,
                  float beta2, float epsilon, uint64_t t, const uint64_t* t_dev, float grad_scale,
-                 const float* grad_scale_dev, void* stream);
+                 const float* grad_scale_dev, const float* loss_sum_dev, void* stream);
 
 /* One conditional network's MLP (scripts/base.py:66-67,133-135,196-198):
  * out[rows, out_dim] = MLP(concat(in, in2)) (+ gen_bias_init for the decoder).
@@ -153,12 +163,17 @@ int gmvae_mlp_forward(const GmvaeDims* dims, int model, int net, const void* in,
  * pixels: uint8 [n_rows][D] resident in HBM (MNIST: 60000 x 784 = 47 MB); idx: int32 [B] source rows of this batch
  * (an epoch permutation kept on the device) or NULL for rows row0 .. row0+B-1; x_out: uint8 [B][D] of 0/1, the
  * layout gmvae_step takes.  The uniforms are Philox4x32-10 keyed by (seed, step or *step_dev) and the element's
- * position in x_out, so a step is reproducible.  D % 4 == 0; pixels and x_out 4-byte aligned. */
+ * position in the GLOBAL batch (row out_row0 + b, column), so a step is reproducible and a sharded batch draws what
+ * the whole batch would (out_row0 = GmvaeDims::row0).  D % 4 == 0; pixels and x_out 4-byte aligned. */
 int gmvae_binarize(const uint8_t* pixels, uint64_t n_rows, const int32_t* idx, uint64_t row0, int B, int D,
-                   uint64_t seed, uint64_t step, const uint64_t* step_dev, uint8_t* x_out, void* stream);
+                   uint64_t seed, uint64_t step, const uint64_t* step_dev, uint8_t* x_out, uint64_t out_row0,
+                   void* stream);
 
-/* Philox4x32-10 noise: eps ~ N(0,1) [n_eps], u ~ U[tiny,1) [n_u] (either may be NULL/0). */
-int gmvae_noise_fill(float* eps, uint64_t n_eps, float* u, uint64_t n_u, uint64_t seed, uint64_t step,
+/* The noise gmvae_step draws when eps/u are NULL, as arrays: eps ~ N(0,1) [rows][L], u ~ U[tiny,1) [rows][K]
+ * (either pointer may be NULL).  Philox4x32-10, counter = (global row row_base + r, quad of the row, stream, step or
+ * *step_dev), key = seed: gmvae_step(dims, ..., seed, step) with dims->row0 = row_base and rows = B*S draws exactly
+ * these values, in every schedule (tests feed them to the CPU oracle). */
+int gmvae_noise_fill(float* eps, float* u, uint64_t rows, int L, int K, uint64_t row_base, uint64_t seed, uint64_t step,
                      const uint64_t* step_dev, void* stream);
 
 /* utils.cluster_acc (scripts/utils.py:173-191) on device.  scratch: int32
@@ -209,10 +224,13 @@ int gmvae_bench_loop(const GmvaeDims* dims, int model, const uint8_t* x, float* 
  * n_steps >= 1 consecutive steps go into the one graph; `x` then holds n_steps batches back to back
  * ([n_steps][B][D]: the next n_steps batches of the input pipeline).  One launch per n_steps steps amortises
  * the ~6 us the GPU idles between two graph launches (measured, profiles/): the kernels inside a graph run
- * back to back. */
+ * back to back.
+ * tail_log (may be NULL): fp32 [n_steps][GMVAE_TAIL]; step s of a launch also writes its tail (loss sums + count,
+ * all-reduced in the data-parallel graph) to row s: the per-step losses the reference's logging and early-stopping
+ * hooks see (scripts/runners.py:198-200,222-228), read once per launch instead of once per step. */
 int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, int n_steps, float* params, float* m,
                              float* v, float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr,
-                             float beta1, float beta2, float epsilon, void** graph_out);
+                             float beta1, float beta2, float epsilon, float* tail_log, void** graph_out);
 /* The same graph with the input pipeline inside: before each of its n_steps steps, gmvae_binarize draws that
  * step's batch from the resident uint8 `pixels` [n_rows][D] -- rows idx[s][0..B) of the int32 device buffer
  * idx [n_steps][B], which the caller refills (an epoch permutation) before every launch -- into x_scratch
@@ -220,7 +238,7 @@ int gmvae_train_graph_create(const GmvaeDims* dims, int model, const uint8_t* x,
 int gmvae_train_graph_create_pipeline(const GmvaeDims* dims, int model, const uint8_t* pixels, uint64_t n_rows,
                                       const int32_t* idx, uint8_t* x_scratch, int n_steps, float* params, float* m, float* v,
                                       float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr,
-                                      float beta1, float beta2, float epsilon, void** graph_out);
+                                      float beta1, float beta2, float epsilon, float* tail_log, void** graph_out);
 int gmvae_train_graph_launch(void* graph, void* stream);
 int gmvae_train_graph_destroy(void* graph);
 
@@ -239,7 +257,7 @@ int gmvae_dp_step(const GmvaeDims* dims, int model, const uint8_t* x, float* par
                   float beta2, float epsilon, void* comm, void* stream);
 int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, int n_steps, float* params, float* m, float* v,
                           float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1,
-                          float beta2, float epsilon, void* comm, void** graph_out);
+                          float beta2, float epsilon, void* comm, float* tail_log, void** graph_out);
 
 /* Debugging aid: byte offset inside the workspace of a named intermediate ("hy1","hg1","hd1","y",
  * "logits","qp","pp","z","g","dqp","dpp","dlogits","dbuf0".."dbuf2","s1","s4", ...). */

@@ -30,7 +30,7 @@ __all__ = [
     "param_specs", "param_layout", "init_params", "pack", "unpack",
     "softplus", "sigmoid", "forward", "loss_and_grads", "adam_tf_step",
     "train_step", "make_inputs", "flops_per_step", "cluster_acc", "TINY_F32",
-    "philox4x32_10", "binarize", "cluster_acc_from_hist",
+    "philox4x32_10", "binarize", "cluster_acc_from_hist", "noise",
 ]
 
 
@@ -382,18 +382,45 @@ def philox4x32_10(c: np.ndarray, k0: int, k1: int) -> np.ndarray:
     return np.stack(c, axis=-1).astype(np.uint32)
 
 
-def binarize(pixels: np.ndarray, rows: np.ndarray, seed: int, step: int) -> np.ndarray:
+def binarize(pixels: np.ndarray, rows: np.ndarray, seed: int, step: int, out_row0: int = 0) -> np.ndarray:
     """scripts/runners.py:48-51 `_preprocess` for one batch: image = float32(pixel) / 255; x = image < uniform.
-    The uniforms are the HIP path's: Philox4x32-10, counter = (output quad index, 0x40000000, step), key = seed,
-    u = (bits >> 8) * 2^-24.  pixels uint8 [N, D], rows int [B] -> uint8 [B, D] of 0/1 (bit-exact contract)."""
+    The uniforms are the HIP path's: Philox4x32-10, counter = (quad index in the GLOBAL batch, 0x40000000, step),
+    key = seed, u = (bits >> 8) * 2^-24; out_row0 = global index of this batch's first row (a data-parallel shard).
+    pixels uint8 [N, D], rows int [B] -> uint8 [B, D] of 0/1 (bit-exact contract)."""
     B, D = len(rows), pixels.shape[1]
-    q = np.arange(B * D // 4, dtype=np.uint64)
+    q = np.arange(B * D // 4, dtype=np.uint64) + np.uint64(out_row0 * (D // 4))
     c = np.stack([q & np.uint64(0xFFFFFFFF), (q >> np.uint64(32)) | np.uint64(0x40000000),
                   np.full_like(q, step & 0xFFFFFFFF), np.full_like(q, (step >> 32) & 0xFFFFFFFF)], axis=-1).astype(np.uint32)
     r = philox4x32_10(c, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     u = ((r >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).reshape(B, D)
     img = pixels[np.asarray(rows)].astype(np.float32) / np.float32(255.0)
     return (img < u).astype(np.uint8)
+
+
+def noise(rows: int, L: int, K: int, row_base: int, seed: int, step: int) -> Tuple[np.ndarray, np.ndarray]:
+    """The HIP path's in-kernel noise (gmvae_amd/csrc/aux.hpp noise_vals, the stand-in for tf.random_normal /
+    tf.random_uniform inside the TFP samplers at gmvae.py:240,248 and vae.py:171) restated on the CPU:
+    Philox4x32-10, counter = (global row, quad of the row | stream bit, step), key = seed.
+    u [rows, K] = max((bits >> 8) * 2^-24, tiny) is bit-exact; eps [rows, L] is Box-Muller,
+    sqrt(-2 ln(1 - u0)) * (cos, sin)(2 pi u1), which the GPU evaluates with its hardware log2/sin/cos (agreement to a
+    few 1e-6 absolute, not bitwise)."""
+    def bits(n_cols, stream):
+        qpr = (n_cols + 3) // 4
+        row = (np.arange(rows, dtype=np.uint64) + np.uint64(row_base))[:, None].repeat(qpr, 1)
+        quad = np.arange(qpr, dtype=np.uint64)[None, :].repeat(rows, 0)
+        c1 = (quad & np.uint64(0x00FFFFFF)) | (((row >> np.uint64(32)) & np.uint64(0x3F)) << np.uint64(24)) | np.uint64(stream)
+        c = np.stack([row & np.uint64(0xFFFFFFFF), c1, np.full_like(row, step & 0xFFFFFFFF),
+                      np.full_like(row, (step >> 32) & 0xFFFFFFFF)], axis=-1).astype(np.uint32)
+        r = philox4x32_10(c, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)          # [rows, qpr, 4]
+        return (r >> np.uint32(8)).astype(np.float64) * 2.0 ** -24
+    ub = bits(K, 0x80000000).reshape(rows, -1)[:, :K]
+    u = np.maximum(ub.astype(np.float32), np.float32(TINY_F32))
+    eb = bits(L, 0)
+    rad = np.sqrt(-2.0 * np.log(1.0 - eb[..., 0::2]))
+    ang = 2.0 * np.pi * eb[..., 1::2]
+    e = np.stack([rad * np.cos(ang), rad * np.sin(ang)], axis=-1)                     # [rows, qpr, 2 pairs, (cos, sin)]
+    eps = e.reshape(rows, -1)[:, :L].astype(np.float32)
+    return eps, u
 
 
 def cluster_acc_from_hist(hist: np.ndarray) -> float:

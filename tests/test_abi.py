@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol(L):
     for sym in declared:
         assert hasattr(raw, sym), f"{sym} declared in include/gmvae_hip.h but not exported"
     assert declared == set(L.EXPORTS)
-    assert L.lib.gmvae_abi_version() == 1
+    assert L.lib.gmvae_abi_version() == 2
 
 
 @pytest.mark.parametrize("name,d", [
@@ -64,7 +64,7 @@ def test_argument_validation(L):
     big_k = L.make_dims(16, 784, 64, 65, [64])
     assert L.lib.gmvae_param_count(C.byref(big_k), 1, C.byref(pp), None) == -2     # GMP prior: K <= 64
     assert L.lib.gmvae_step(C.byref(cd), 2, None, None, None, None, None, None, 0, 0, None, None) == -1
-    assert L.lib.adam_tf_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, None, 1.0, None, None) == -1
+    assert L.lib.adam_tf_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, None, 1.0, None, None, None) == -1
     n = C.c_int()
     arr = (L.GmvaeParamEntry * 2)()
     assert L.lib.gmvae_param_layout(C.byref(cd), 2, arr, 2, C.byref(n)) == -6

@@ -216,7 +216,7 @@ def test_adam_tf_three_steps(H):
         g = (rng.normal(size=P) * (1e-9 if t == 2 else 1.0)).astype(np.float32)
         gd = H.dev(np.pad(g, (0, 1)) * 8.0)
         L.check(L.lib.adam_tf_step(L.ptr(td), L.ptr(md), L.ptr(vd), L.ptr(gd), P, 1e-3, 0.9, 0.999, 1e-8, t, None,
-                                   1.0 / 8.0, None, L.current_stream()), "adam")
+                                   1.0 / 8.0, None, None, L.current_stream()), "adam")
         th, m, v = O.adam_tf_step(th, m, v, g, t, dtype=np.float32)
         th64, m64, v64 = O.adam_tf_step(th64, m64, v64, g.astype(np.float64), t, dtype=np.float64)
     np.testing.assert_allclose(td.cpu().numpy()[:P], th, rtol=2e-6, atol=2e-7)
@@ -234,26 +234,37 @@ def test_adam_device_counter_and_scale(H):
     tdev = torch.tensor([3, 0], dtype=torch.int64, device="cuda")
     cnt = torch.tensor([4.0], dtype=torch.float32, device="cuda")
     L.check(L.lib.adam_tf_step(L.ptr(td), L.ptr(md), L.ptr(vd), L.ptr(gd), P, 1e-3, 0.9, 0.999, 1e-8, 999, L.ptr(tdev),
-                               123.0, L.ptr(cnt), L.current_stream()), "adam")
+                               123.0, L.ptr(cnt), None, L.current_stream()), "adam")
     th, _, _ = O.adam_tf_step(np.ones(P), np.zeros(P), np.zeros(P), np.full(P, 1.5), 3, dtype=np.float64)
     np.testing.assert_allclose(td.cpu().numpy(), th, rtol=1e-6)
+    # a poisoned step (non-finite loss sum: a hand-off timed out, here or on another rank) must NOT be applied
+    before = (td.clone(), md.clone(), vd.clone())
+    for bad in (float("nan"), float("inf")):
+        loss = torch.tensor([bad], **f32)
+        L.check(L.lib.adam_tf_step(L.ptr(td), L.ptr(md), L.ptr(vd), L.ptr(gd), P, 1e-3, 0.9, 0.999, 1e-8, 4, None, 1.0, None,
+                                   L.ptr(loss), L.current_stream()), "adam")
+    assert all(torch.equal(a, b) for a, b in zip(before, (td, md, vd)))
+    loss = torch.tensor([12.5], **f32)
+    L.check(L.lib.adam_tf_step(L.ptr(td), L.ptr(md), L.ptr(vd), L.ptr(gd), P, 1e-3, 0.9, 0.999, 1e-8, 4, None, 1.0, None,
+                               L.ptr(loss), L.current_stream()), "adam")
+    assert not torch.equal(before[0], td)
 
 
 # ---------------------------------------------------------------- noise
 def test_philox_noise_statistics_and_fast_mode(H):
     L = _L()
-    n = 1 << 20
-    eps = torch.empty(n, dtype=torch.float32, device="cuda")
-    u = torch.empty(n, dtype=torch.float32, device="cuda")
-    L.check(L.lib.gmvae_noise_fill(L.ptr(eps), n, L.ptr(u), n, 7, 0, None, L.current_stream()), "noise")
-    e, uu = eps.cpu().numpy().astype(np.float64), u.cpu().numpy().astype(np.float64)
+    rows, Lz, K = 1 << 14, 64, 10
+    eps = torch.empty(rows, Lz, dtype=torch.float32, device="cuda")
+    u = torch.empty(rows, K, dtype=torch.float32, device="cuda")
+    L.check(L.lib.gmvae_noise_fill(L.ptr(eps), L.ptr(u), rows, Lz, K, 0, 7, 0, None, L.current_stream()), "noise")
+    e, uu = eps.cpu().numpy().astype(np.float64).ravel(), u.cpu().numpy().astype(np.float64).ravel()
     assert abs(e.mean()) < 5e-3 and abs(e.std() - 1) < 5e-3
     assert abs((e ** 3).mean()) < 2e-2 and abs((e ** 4).mean() - 3) < 5e-2
     assert uu.min() >= O.TINY_F32 and uu.max() < 1.0
-    assert abs(uu.mean() - 0.5) < 2e-3 and abs(uu.var() - 1 / 12) < 1e-3
-    eps2 = torch.empty(n, dtype=torch.float32, device="cuda")
-    L.check(L.lib.gmvae_noise_fill(L.ptr(eps2), n, None, 0, 7, 1, None, L.current_stream()), "noise")
-    assert abs(np.corrcoef(e, eps2.cpu().numpy())[0, 1]) < 5e-3        # a new step is a new stream
+    assert abs(uu.mean() - 0.5) < 3e-3 and abs(uu.var() - 1 / 12) < 2e-3
+    eps2 = torch.empty(rows, Lz, dtype=torch.float32, device="cuda")
+    L.check(L.lib.gmvae_noise_fill(L.ptr(eps2), None, rows, Lz, K, 0, 7, 1, None, L.current_stream()), "noise")
+    assert abs(np.corrcoef(e, eps2.cpu().numpy().ravel())[0, 1]) < 5e-3        # a new step is a new stream
     # fast mode of the step: eps/u = NULL -> loss within sampling distance of the parity-mode loss
     d = O.Dims(D=784, L=64, K=10, hidden=(64,))
     p = O.init_params(O.MODEL_GMVAE, d, np.random.default_rng(0))
@@ -264,6 +275,27 @@ def test_philox_noise_statistics_and_fast_mode(H):
     assert abs(t_fast[0] - t_par[0]) / abs(t_par[0]) < 5e-3
     _, t_fast2 = H.hip_step(O.MODEL_GMVAE, d, flat, x, None, None, seed=3, step=5)
     assert t_fast2[0] == t_fast[0]                                         # same (seed, step) -> same bits
+
+
+@pytest.mark.parametrize("rows,Lz,K,row_base", [(64, 64, 10, 0), (33, 5, 3, 7), (16, 8, 64, (1 << 32) + 5), (100, 2, 1, 1024)])
+def test_noise_fill_matches_cpu_restatement(H, rows, Lz, K, row_base):
+    """gmvae_noise_fill against oracle.noise (the NumPy Philox4x32-10, pinned by the Random123 known-answer vectors in
+    tests/test_pipeline.py): the uniforms bit for bit, the Box-Muller normals to the accuracy of the hardware
+    log2/sin/cos; and the stream is keyed by the GLOBAL row, not by the position in the buffer."""
+    L = _L()
+    eps = torch.full((rows, Lz), float("nan"), dtype=torch.float32, device="cuda")
+    u = torch.full((rows, K), float("nan"), dtype=torch.float32, device="cuda")
+    L.check(L.lib.gmvae_noise_fill(L.ptr(eps), L.ptr(u), rows, Lz, K, row_base, 0xDEADBEEF12345, 9, None, L.current_stream()), "noise")
+    e_ref, u_ref = O.noise(rows, Lz, K, row_base, 0xDEADBEEF12345, 9)
+    assert np.array_equal(u.cpu().numpy(), u_ref)
+    np.testing.assert_allclose(eps.cpu().numpy(), e_ref, rtol=0, atol=2e-5)
+    # the second half drawn on its own with the row offset = the second half of the whole
+    h = rows // 2
+    eps2 = torch.empty(rows - h, Lz, dtype=torch.float32, device="cuda")
+    u2 = torch.empty(rows - h, K, dtype=torch.float32, device="cuda")
+    L.check(L.lib.gmvae_noise_fill(L.ptr(eps2), L.ptr(u2), rows - h, Lz, K, row_base + h, 0xDEADBEEF12345, 9, None,
+                                   L.current_stream()), "noise")
+    assert torch.equal(eps2, eps[h:]) and torch.equal(u2, u[h:])
 
 
 def test_cluster_acc_kernel(H):

@@ -61,6 +61,12 @@ def test_hip_binarize_matches_oracle_bit_for_bit(B, D):
         assert np.array_equal(got, O.binarize(pix, rows, seed, step))
     got = binarize(pt, row0=5, batch=B, seed=9, step=1).cpu().numpy()                # contiguous rows, no index
     assert np.array_equal(got, O.binarize(pix, np.arange(5, 5 + B), 9, 1))
+    # a data-parallel shard (global row offset in the Philox counter): the shard of the whole = the shard drawn alone
+    whole = binarize(pt, rows=torch.from_numpy(rows).cuda(), seed=3, step=2)
+    h = B // 2
+    part = binarize(pt, rows=torch.from_numpy(rows[h:]).cuda(), seed=3, step=2, out_row0=h)
+    assert torch.equal(part, whole[h:])
+    assert np.array_equal(part.cpu().numpy(), O.binarize(pix, rows[h:], 3, 2, out_row0=h))
 
 
 @pytest.mark.gpu

@@ -1,0 +1,224 @@
+"""-m gpu: the kernels the benchmark actually times, against the CPU oracle.
+
+bench.py's steady state is an n-step train graph: in-kernel Philox noise, the first layer inside mega_fwd_bwd
+(template instance FLT = 1) on weight images that finalize_adam scattered, the bf16x3 weight-gradient launch and
+TF-Adam fused into the last launch.  These tests replay such graphs and compare with `oracle.train_step` iterated
+over the same batches in fp64, fed with the noise the device drew (gmvae_noise_fill exposes the exact stream:
+same function, same counters), for every hand-off variant of the mega schedule: Q = 4 (B <= 1024), Q = 2
+(B <= 2048), Q = 1 (B = 8192, the unsharded BASELINE configs[3] batch).
+
+Reference lines reproduced: scripts/gmvae.py:238-267 / scripts/vae.py:167-185 (loss), scripts/runners.py:181-183
+(AdamOptimizer.compute_gradients / apply_gradients).  Gates: ELBO of the LAST step <= 1e-4 relative (it is computed
+from parameters that went through n-1 device updates), every gradient tensor of the last step <= 1e-4 of its
+max, parameters after n TF-Adam steps (see _compare_params)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LR = 1e-3
+
+
+def _noise(L, rows, Lz, K, row_base, seed, step, want_u):
+    eps = torch.empty(rows, Lz, dtype=torch.float32, device="cuda")
+    u = torch.empty(rows, K, dtype=torch.float32, device="cuda") if want_u else None
+    L.check(L.lib.gmvae_noise_fill(L.ptr(eps), L.ptr(u), rows, Lz, K, row_base, seed, step, None, L.current_stream()), "noise")
+    torch.cuda.synchronize()
+    return eps.cpu().numpy(), (u.cpu().numpy() if want_u else None)
+
+
+def _oracle_trajectory(L, model, d, flat0, xs, seed, step0=0, row_base=0):
+    """n oracle steps (fp64) on the noise of device steps step0 .. step0+n-1; returns (flat, C_last, g_last, g_first)."""
+    flat = flat0.astype(np.float64)
+    m, v = np.zeros_like(flat), np.zeros_like(flat)
+    g_first = None
+    for t in range(xs.shape[0]):
+        B = xs[t].shape[0]
+        eps, u = _noise(L, B * d.S, d.L, d.K, row_base * d.S, seed, step0 + t, model == O.MODEL_GMVAE)
+        flat, m, v, Cc, g = O.train_step(model, d, flat, m, v, step0 + t + 1, xs[t], eps, u, lr=LR, dtype=np.float64)
+        if g_first is None:
+            g_first = g
+    return flat, Cc, g, g_first
+
+
+def _compare_last_step(model, d, eng, B, Cc, g):
+    P = eng.P
+    buf = eng.grads.cpu().numpy().astype(np.float64)
+    tail = buf[P:]
+    assert tail[4] == B
+    assert abs(tail[0] / B - Cc["loss"]) <= 1e-4 * abs(Cc["loss"]), (tail[0] / B, Cc["loss"])
+    assert abs(tail[1] / B - Cc["nll"]) <= 1e-4 * abs(Cc["nll"])
+    ta = 1e-5 * max(abs(Cc["loss"]), 1.0)
+    assert abs(tail[2] / B - Cc["kl"]) <= ta and abs(tail[3] / B - Cc["nent"]) <= ta
+    lay, _, _ = O.param_layout(model, d)
+    for name, shape, off in lay:
+        n = int(np.prod(shape))
+        got, ref = buf[off:off + n] / B, g[off:off + n]
+        err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6)
+        assert err <= 1e-4, f"{name}: last-step gradient rel-to-max err {err:.2e}"
+
+
+def _compare_params(model, d, eng, flat_ref, g_first, n):
+    """Parameters after n device TF-Adam steps vs the fp64 oracle.  Adam divides by sqrt(v): where a gradient element
+    is far below its tensor's scale (|g| < 1e-3 max|g|, where the 1e-4-of-max gradient gate is no relative statement)
+    the update direction is rounding noise in ANY fp32 implementation, the reference's included, and only the bound
+    of n * lr per step holds; everywhere else the parameters must agree to 5e-5 (lr = 1e-3: 5 % of one step)."""
+    got = eng.params.detach().cpu().numpy().astype(np.float64)
+    diff = np.abs(got - flat_ref)
+    assert np.isfinite(got).all() and diff.max() <= 2.5 * n * LR
+    lay, _, _ = O.param_layout(model, d)
+    n_well = 0
+    for name, shape, off in lay:
+        k = int(np.prod(shape))
+        g1 = np.abs(g_first[off:off + k])
+        well = g1 > 1e-3 * max(g1.max(), 1e-12)
+        n_well += int(well.sum())
+        if well.any():
+            assert diff[off:off + k][well].max() <= 5e-5, f"{name}: max |dtheta| {diff[off:off + k][well].max():.2e}"
+    assert n_well > 0.5 * sum(int(np.prod(s)) for _, s, _ in lay)
+
+
+CASES = [
+    # model, D, L, K, hidden, B, n_steps, note
+    ("gmvae", 784, 64, 10, (64,), 1024, 4),      # BASELINE configs[2]: Q = 4, steps 2..n in-launch first layer (FLT = 1)
+    ("gmvae", 784, 64, 10, (64,), 1000, 3),      # ragged last panel
+    ("gmvae", 784, 64, 10, (64,), 2048, 3),      # Q = 2
+    ("gmvae", 784, 64, 10, (64,), 8192, 3),      # Q = 1: the unsharded configs[3] batch on one GPU
+    ("vae", 784, 2, 1, (64,), 100, 4),           # BASELINE configs[0]
+    ("vae_gmp", 784, 64, 10, (64,), 256, 4),     # BASELINE configs[1]
+    ("gmvae", 784, 16, 10, (64,), 96, 3),        # generic mega instance (not the specialised sizes)
+]
+
+
+@pytest.mark.parametrize("model,D,Lz,K,hidden,B,n", CASES, ids=[f"{c[0]}-L{c[2]}-B{c[5]}" for c in CASES])
+def test_train_graph_matches_oracle_trajectory(model, D, Lz, K, hidden, B, n):
+    from gmvae_amd import _lib as L
+    from gmvae_amd.engine import Engine
+    mid = O.MODEL_NAMES[model]
+    d = O.Dims(D=D, L=Lz, K=K, hidden=hidden)
+    e = Engine(model, D, Lz, K, list(hidden), random_seed=11)
+    flat0 = e.params.detach().cpu().numpy()
+    xs = (np.random.default_rng(B).random((n, B, D)) < 0.87).astype(np.uint8)
+    sx, replay = e.capture_train_step(B, lr=LR, n_steps=n)
+    sx.copy_(torch.from_numpy(xs).cuda())
+    replay()
+    torch.cuda.synchronize()
+    assert e.handoff_timeouts() == 0 and e.global_step == n and int(e.step_dev[0].item()) == n
+    flat_ref, Cc, g, g1 = _oracle_trajectory(L, mid, d, flat0, xs, e.noise_seed)
+    _compare_last_step(mid, d, e, B, Cc, g)
+    _compare_params(mid, d, e, flat_ref, g1, n)
+
+
+def test_second_graph_launch_continues_the_trajectory():
+    """Two launches of a 3-step graph = 6 oracle steps: the device step counter carries the Philox step and Adam's t
+    across launches (sess.run([train_op, global_step]) repeated, scripts/runners.py:231-232)."""
+    from gmvae_amd import _lib as L
+    from gmvae_amd.engine import Engine
+    B, n = 1024, 3
+    d = O.Dims(D=784, L=64, K=10, hidden=(64,))
+    e = Engine("gmvae", 784, 64, 10, [64], random_seed=4)
+    flat0 = e.params.detach().cpu().numpy()
+    xs = (np.random.default_rng(5).random((n, B, 784)) < 0.87).astype(np.uint8)
+    sx, replay = e.capture_train_step(B, lr=LR, n_steps=n)
+    sx.copy_(torch.from_numpy(xs).cuda())
+    replay()
+    replay()
+    torch.cuda.synchronize()
+    flat_ref, Cc, g, g1 = _oracle_trajectory(L, O.MODEL_GMVAE, d, flat0, np.concatenate([xs, xs]), e.noise_seed)
+    _compare_last_step(O.MODEL_GMVAE, d, e, B, Cc, g)
+    _compare_params(O.MODEL_GMVAE, d, e, flat_ref, g1, 2 * n)
+
+
+def test_dp_graph_world1_matches_oracle_trajectory():
+    """The data-parallel train graph (RCCL all-reduce captured inside, adam_tf_img after it) with a one-rank
+    communicator and a NON-ZERO global row offset: the trajectory of a rank that owns rows [3072, 4096) of a global
+    batch, checked against the oracle on the noise rows of exactly those global indices."""
+    from gmvae_amd import _lib as L
+    from gmvae_amd.engine import Engine
+    B, n = 1024, 3
+    d = O.Dims(D=784, L=64, K=10, hidden=(64,))
+    e = Engine("gmvae", 784, 64, 10, [64], random_seed=8)
+    e.rank = 3                                    # as on rank 3 of 8: row0 = 3 * B enters the Philox counters only
+    flat0 = e.params.detach().cpu().numpy()
+    xs = (np.random.default_rng(6).random((n, B, 784)) < 0.87).astype(np.uint8)
+    e.enable_rccl()
+    sx, replay = e.capture_train_step(B, lr=LR, all_reduce=True, n_steps=n)
+    assert e.dp_mode == "rccl-in-hipgraph"
+    sx.copy_(torch.from_numpy(xs).cuda())
+    replay()
+    torch.cuda.synchronize()
+    assert e.handoff_timeouts() == 0
+    flat_ref, Cc, g, g1 = _oracle_trajectory(L, O.MODEL_GMVAE, d, flat0, xs, e.noise_seed, row_base=3 * B)
+    _compare_last_step(O.MODEL_GMVAE, d, e, B, Cc, g)
+    _compare_params(O.MODEL_GMVAE, d, e, flat_ref, g1, n)
+
+
+EAGER = [
+    ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,)), 1024),               # mega schedule, 4 launches
+    ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,)), 64),               # general schedule (bin/run_train.sh sizes)
+    ("gmvae", O.Dims(D=300, L=6, K=7, hidden=(40,), S=3), 24),              # IWAE rows r = b*S + s; L, K not multiples of 4
+    ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(64,)), 256),
+    ("vae", O.Dims(D=128, L=7, K=1, hidden=(20, 20)), 33),
+]
+
+
+@pytest.mark.parametrize("model,d,B", EAGER, ids=[f"{m}-L{d.L}-S{d.S}-B{B}" for m, d, B in EAGER])
+def test_eager_philox_step_matches_oracle(model, d, B):
+    """gmvae_step with eps = u = NULL (in-kernel Philox) in every schedule == the oracle on gmvae_noise_fill's arrays,
+    including a non-zero row offset (a data-parallel shard)."""
+    import hip_util as H
+    from gmvae_amd import _lib as L
+    mid = O.MODEL_NAMES[model]
+    p = O.init_params(mid, d, np.random.default_rng(3))
+    flat = O.pack(mid, d, p, np.float32)
+    x = (np.random.default_rng(B).random((B, d.D)) < 0.87).astype(np.uint8)
+    seed, step, row0 = 0x1234567890AB, 17, 5 * B
+    cd = H.dims_of(d, B)
+    cd.row0 = row0
+    P, _ = L.param_count(cd, mid)
+    params, xd = H.dev(flat, torch.float32), H.dev(x, torch.uint8)
+    grads = torch.full((P + L.TAIL,), float("nan"), dtype=torch.float32, device="cuda")
+    ws = H.workspace(cd, mid)
+    L.check(L.lib.gmvae_step(C.byref(cd), mid, L.ptr(xd), None, None, L.ptr(params), L.ptr(grads), L.ptr(ws), seed, step,
+                             None, L.current_stream()), "gmvae_step")
+    torch.cuda.synchronize()
+    eps, u = _noise(L, B * d.S, d.L, d.K, row0 * d.S, seed, step, mid == O.MODEL_GMVAE)
+    p32 = O.unpack(mid, d, flat.astype(np.float64))
+    Cc, g = O.loss_and_grads(mid, d, p32, x, eps, u, np.float64)
+    buf = grads.cpu().numpy().astype(np.float64)
+    assert abs(buf[P] / B - Cc["loss"]) <= 1e-4 * abs(Cc["loss"])
+    lay, _, _ = O.param_layout(mid, d)
+    for name, shape, off in lay:
+        n = int(np.prod(shape))
+        ref = g[name].ravel()
+        err = np.abs(buf[off:off + n] / B - ref).max() / max(np.abs(ref).max(), 1e-6)
+        assert err <= (5e-4 if d.S > 1 else 1e-4), f"{name}: {err:.2e}"
+
+
+def test_pipeline_graph_matches_oracle_from_raw_pixels():
+    """The train graph that starts from raw uint8 pixels (binarisation inside the graph): oracle.binarize (bit-exact
+    NumPy Philox) -> oracle.train_step on the device's noise, step by step."""
+    from gmvae_amd import _lib as L
+    from gmvae_amd.data import DeviceDataset
+    from gmvae_amd.engine import Engine
+    B, n = 1024, 3
+    d = O.Dims(D=784, L=64, K=10, hidden=(64,))
+    pix = np.random.default_rng(2).integers(0, 256, (5000, 784), dtype=np.uint8)
+    ds = DeviceDataset(pix, shuffle=True, seed=3)
+    e = Engine("gmvae", 784, 64, 10, [64], random_seed=21)
+    flat0 = e.params.detach().cpu().numpy()
+    replay = e.capture_train_pipeline(ds, B, lr=LR, n_steps=n)
+    replay()
+    torch.cuda.synchronize()
+    rows = replay.rows.cpu().numpy()
+    bseed = e.noise_seed ^ Engine.BINARIZE_SEED_XOR
+    xs = np.stack([O.binarize(pix, rows[t], bseed, t) for t in range(n)])
+    assert np.array_equal(replay.batches.cpu().numpy(), xs)
+    flat_ref, Cc, g, g1 = _oracle_trajectory(L, O.MODEL_GMVAE, d, flat0, xs, e.noise_seed)
+    _compare_last_step(O.MODEL_GMVAE, d, e, B, Cc, g)
+    _compare_params(O.MODEL_GMVAE, d, e, flat_ref, g1, n)
