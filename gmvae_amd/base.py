@@ -187,3 +187,14 @@ class ConditionalCategorical(_Conditional):
 
     def __call__(self, *args, **kwargs):
         return RelaxedOneHotCategorical(self._temperature, logits=self.condition(args, **kwargs), name=self._name)
+
+
+def _targets_guard(loss, images, targets):
+    """Every reference call site passes targets = images (scripts/runners.py:127-130).  A distinct tensor is compared ON
+    THE DEVICE and a mismatch turns the loss into NaN: loud, and without the device-to-host sync a torch.equal costs."""
+    if targets is images or (targets.data_ptr() == images.data_ptr() and targets.shape == images.shape):
+        return loss
+    if targets.numel() != images.numel():
+        raise NotImplementedError("targets != images is not used by the reference and not supported")
+    bad = (targets.reshape(images.shape).to(images.device) != images).any()
+    return loss + torch.where(bad, torch.full_like(loss, float("nan")), torch.zeros_like(loss))

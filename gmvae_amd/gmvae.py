@@ -83,10 +83,8 @@ class TrainableGMVAE(GMVAE):
         """Batch-mean loss = nll + kl_div_z + nent (scripts/gmvae.py:223-274); ELBO = -loss
         (the +ln K constant is omitted, as in the reference).  eps [B*S,L] / u [B*S,K]:
         optional explicit noise (parity mode); default is in-kernel Philox."""
-        if targets is not images and not torch.equal(targets, images):
-            raise NotImplementedError("targets != images is not used by the reference and not supported")
         self._last_labels = labels
-        return self._need_engine().loss(images, eps, u)
+        return base._targets_guard(self._need_engine().loss(images, eps, u), images, targets)
 
     def compute_loss(self, images, n_samples=None, labels=None, eps=None, u=None):
         e = self._need_engine()

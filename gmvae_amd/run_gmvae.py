@@ -31,6 +31,9 @@ def build_parser():
     a("--data_dim", type=int, default=784)
     a("--data_dir", default=None, help="directory with mnist.npz or the IDX files; synthetic data otherwise")
     a("--synthetic_size", type=int, default=8192)
+    a("--eager", action="store_true", help="eager launches instead of summarise_every-aligned train graphs")
+    a("--checkpoint_poll_seconds", type=float, default=60.0)     # eval: scripts/utils.py:100-111 sleeps 60 s
+    a("--checkpoint_max_wait", type=float, default=None, help="eval: give up waiting after this many seconds")
     return p
 
 

@@ -103,8 +103,59 @@ def _ckpt(config):
     return os.path.join(_logdir(config), "model.pt")
 
 
+def _save_checkpoint(model, path: str):
+    """Atomic: a reader (run_eval's wait_for_checkpoint, a restart) never sees a half-written file."""
+    tmp = path + ".tmp"
+    torch.save(model.state_dict(), tmp)
+    os.replace(tmp, path)
+
+
+def wait_for_checkpoint(path: str, poll_seconds: float = 60.0, max_wait: float | None = None) -> str:
+    """scripts/utils.py:100-111: loop until a checkpoint exists, sleeping `poll_seconds` (60 s in the reference)
+    between looks.  max_wait (build-side addition, None = forever like the reference) bounds the wait."""
+    t0 = time.time()
+    while not os.path.exists(path):
+        if max_wait is not None and time.time() - t0 >= max_wait:
+            raise FileNotFoundError(f"no checkpoint at {path} after waiting {max_wait:.0f} s")
+        print(f"Checkpoint not found in {os.path.dirname(path)}, sleeping for {poll_seconds:g} seconds.", flush=True)
+        time.sleep(poll_seconds)
+    return path
+
+
+def create_device_dataset(config, split="train", shuffle=True):
+    """The input pipeline of scripts/runners.py:21-62 with the raw uint8 pixels resident in HBM (data.DeviceDataset):
+    this rank's contiguous shard of the split's rows (+ labels), shuffled per epoch on the device; binarisation happens
+    per step on the device (gmvae_binarize: inside the train graph, or as a launch in the eager loop).  Without local
+    MNIST files a synthetic set of intensity 33/255 (P[x = 1] = 0.87 after the reference's inverted rule) stands in."""
+    from .data import DeviceDataset
+    data = _load_mnist(getattr(config, "data_dir", "") or "", split) if getattr(config, "data_dir", None) else None
+    rank, world = (parallel.dist.get_rank(), parallel.dist.get_world_size()) if parallel.dist.is_initialized() else (0, 1)
+    if data is None:
+        n = int(getattr(config, "synthetic_size", 8192))
+        D = int(getattr(config, "data_dim", 784))
+        pix = np.full((n, D), 33, dtype=np.uint8)
+        lab = np.random.default_rng(3).integers(0, 10, n)
+    else:
+        pix, lab = np.ascontiguousarray(data[0]), data[1]
+    a, b = parallel.shard_rows(pix.shape[0], rank, world)
+    return DeviceDataset(pix[a:b], lab[a:b], shuffle=shuffle, seed=(config.random_seed or 0) * 7919 + 17 + rank)
+
+
+def _graph_steps(every: int, cap: int = 32) -> int:
+    """Steps per graph launch: the largest divisor of summarise_every up to `cap`, so that summaries fall on launch
+    boundaries (one host sync per summary, none in between)."""
+    return max(g for g in range(1, max(1, min(cap, every)) + 1) if every % g == 0)
+
+
 def run_train(config):
-    """scripts/runners.py:106-232.  One iteration = the reference's sess.run([train_op, global_step])."""
+    """scripts/runners.py:106-232.  One iteration = the reference's sess.run([train_op, global_step]); here
+    `summarise_every`-aligned hipGraph launches of several steps each: binarisation from the resident pixels, Philox
+    noise, forward, backward, (RCCL all-reduce,) TF-Adam and the per-step loss log all run on the device, and the host
+    looks only at summary steps: the logging hook's line, the early-stopping hook fed with EVERY step's (all-reduced)
+    loss from the log (scripts/utils.py:13-57), the checkpoint timer (save_checkpoint_secs=120, runners.py:226).
+    `config.eager = True` (or GMVAE_EAGER_TRAIN=1) runs the same batches through eager launches instead."""
+    from .data import binarize
+    from .engine import Engine
     rank, world, local = parallel.init_from_env()
     torch.cuda.set_device(local)
     data_dim = int(getattr(config, "data_dim", 784))
@@ -115,37 +166,81 @@ def run_train(config):
         model.load_state_dict(torch.load(_ckpt(config), map_location="cpu"))
         if rank == 0:
             print(f"restored {_ckpt(config)} at step {eng.global_step}")
-    data = create_dataset(config, "train", shuffle=True, repeat=True)
+    eng.sync_replicas()            # default --random_seed=None: every process drew its own init; rank 0's wins
+    ds = create_device_dataset(config, "train", shuffle=True)
+    B, lr, every = int(config.batch_size), float(config.learning_rate), int(config.summarise_every)
+    eager = bool(getattr(config, "eager", False)) or os.environ.get("GMVAE_EAGER_TRAIN") == "1"
+    bseed = eng.noise_seed ^ Engine.BINARIZE_SEED_XOR
+    G = _graph_steps(every)
+    dp_graph = False
+    if world > 1 and not eager:
+        try:
+            eng.enable_rccl()                               # raises on EVERY rank if it fails on any
+            dp_graph = True
+        except Exception as e:
+            if rank == 0:
+                print(f"[run_train] in-library RCCL unavailable ({e}); torch.distributed all-reduce", flush=True)
+    run_train.last_path = "eager" if eager else ("dp-graph" if world > 1 else "pipeline-graph")
     hook = utils.EarlyStoppingHook(config.early_stop_rounds, config.early_stop_threshold)
     last_save, t0, s0 = time.time(), time.time(), eng.global_step
-    losses = []
-    while eng.global_step <= config.max_steps:              # `<=`: the reference runs one extra step (runners.py:231)
-        images, labels = next(data)
-        tail = eng.train_step(images, lr=config.learning_rate)        # fwd + bwd + all-reduce + Adam
-        losses.append(tail[0] / tail[4])                    # device tensor: no per-step host sync
-        if eng.global_step % config.summarise_every == 0 or eng.global_step > config.max_steps:
-            vals = torch.stack(losses).tolist()
-            base = eng.global_step - len(vals)
-            losses = []
-            stop = False
-            for i, v in enumerate(vals):                    # EarlyStoppingHook sees every step's (all-reduced) loss
-                stop = hook.after_run(base + i + 1, v) or stop
-            if rank == 0:
-                rate = (eng.global_step - s0) / max(time.time() - t0, 1e-9)
-                msg = f"Step {eng.global_step}, loss: {vals[-1]:f}  ({rate:.1f} global_step/sec)"
-                if config.model == "gmvae":
-                    q = model.encoder_y(images).distribution.logits
-                    msg += f"  cluster_acc {utils.cluster_acc(q, labels, config.mixture_components).item():.4f}"
-                print(msg, flush=True)
-            if stop:
-                if rank == 0:
-                    print("[Early Stopping Criterion Satisfied]")
-                break
+    logs = []                                               # device tensors [n, TAIL]: no host sync until a summary
+    last_x = last_rows = None
+
+    def run(n):
+        """n training steps on the next n batches of the pipeline."""
+        nonlocal last_x, last_rows
+        while n > 0:
+            g = G if n >= G else 1
+            if eager:
+                rows = ds.next_rows(B)
+                x = binarize(ds.pixels, rows=rows, seed=bseed, step=eng.global_step, out_row0=rank * B)
+                logs.append(eng.train_step(x, lr=lr).clone().view(1, -1))
+                last_x, last_rows, g = x, rows, 1
+            elif world == 1:
+                replay = eng.capture_train_pipeline(ds, B, lr=lr, n_steps=g)
+                replay()
+                logs.append(replay.tail_log.clone())
+                last_x, last_rows = replay.batches[g - 1], replay.rows[g - 1]
+            else:
+                sx, replay = eng.capture_train_step(B, lr=lr, all_reduce=True, n_steps=g)
+                xs = sx if g > 1 else sx.unsqueeze(0)
+                for i in range(g):                          # this launch's batches, binarised on the device
+                    last_rows = ds.next_rows(B)
+                    binarize(ds.pixels, rows=last_rows, seed=bseed, step=eng.global_step + i, out=xs[i], out_row0=rank * B)
+                replay()
+                logs.append(replay.tail_log.clone())
+                last_x = xs[g - 1]
+            n -= g
+
+    stop = False
+    while eng.global_step <= config.max_steps and not stop:  # `<=`: the reference runs one extra step (runners.py:231)
+        n = min(every - eng.global_step % every, config.max_steps + 1 - eng.global_step)
+        run(n)
+        tails = torch.cat(logs).cpu()                       # the summary's host sync
+        logs = []
+        vals = (tails[:, 0] / tails[:, 4]).tolist()
+        base = eng.global_step - len(vals)
+        if eng.handoff_timeouts() or not all(np.isfinite(vals)):
+            raise RuntimeError(f"training step poisoned between steps {base + 1} and {eng.global_step} (hand-off "
+                               f"timeouts: {eng.handoff_timeouts()}; losses finite: {bool(np.all(np.isfinite(vals)))}): "
+                               "the optimizer skipped those updates and the last good checkpoint was kept")
+        for i, v in enumerate(vals):                        # EarlyStoppingHook sees every step's (all-reduced) loss
+            stop = hook.after_run(base + i + 1, v) or stop
+        if rank == 0 and (eng.global_step % every == 0 or eng.global_step > config.max_steps):
+            rate = (eng.global_step - s0) / max(time.time() - t0, 1e-9)
+            msg = f"Step {eng.global_step}, loss: {vals[-1]:f}  ({rate:.1f} global_step/sec)"
+            if config.model == "gmvae" and ds.labels is not None:
+                q = model.encoder_y(last_x).distribution.logits
+                acc = utils.cluster_acc(q, ds.labels[last_rows.long()], config.mixture_components)
+                msg += f"  cluster_acc {acc.item():.4f}"
+            print(msg, flush=True)
+        if stop and rank == 0:
+            print("[Early Stopping Criterion Satisfied]")
         if rank == 0 and time.time() - last_save > 120:     # save_checkpoint_secs=120 (runners.py:226)
-            torch.save(model.state_dict(), _ckpt(config))
+            _save_checkpoint(model, _ckpt(config))
             last_save = time.time()
     if rank == 0:
-        torch.save(model.state_dict(), _ckpt(config))
+        _save_checkpoint(model, _ckpt(config))
     return model
 
 
@@ -153,12 +248,13 @@ def run_train(config):
 def run_eval(config):
     """scripts/runners.py:235-459 without the plots.  Reports the true per-example loss and, under a
     different name, the reference's figure (sum of per-batch MEANS / number of examples,
-    runners.py:298,330-335 -- i.e. roughly loss / batch_size)."""
+    runners.py:298,330-335 -- i.e. roughly loss / batch_size).  Like the reference it WAITS for a checkpoint
+    (scripts/utils.py:100-111, 60 s polls; config.checkpoint_poll_seconds / checkpoint_max_wait adjust that)."""
     rank, world, local = parallel.init_from_env()
     torch.cuda.set_device(local)
     model = create_model(config, int(getattr(config, "data_dim", 784)))
-    if not os.path.exists(_ckpt(config)):
-        raise FileNotFoundError(f"no checkpoint at {_ckpt(config)} (the reference would poll every 60 s)")
+    wait_for_checkpoint(_ckpt(config), float(getattr(config, "checkpoint_poll_seconds", 60.0)),
+                        getattr(config, "checkpoint_max_wait", None))
     model.load_state_dict(torch.load(_ckpt(config), map_location="cpu"))
     eng = model._engine
     tot = torch.zeros(5, device=eng.device)

@@ -68,9 +68,7 @@ class TrainableVAE(VAE):
         """Batch-mean loss = nll + kl_div_z (scripts/vae.py:153-188); ELBO = -loss.
         ``targets`` must be ``images`` (every reference call site passes the same
         tensor, scripts/runners.py:130).  eps: optional N(0,1) noise [B*S, L]."""
-        if targets is not images and not torch.equal(targets, images):
-            raise NotImplementedError("targets != images is not used by the reference and not supported")
-        return self._need_engine().loss(images, eps, None)
+        return base._targets_guard(self._need_engine().loss(images, eps, None), images, targets)
 
     def compute_loss(self, images, n_samples=None, eps=None):
         e = self._need_engine()

@@ -309,4 +309,10 @@ def test_cluster_acc_kernel(H):
     acc = torch.zeros(1, dtype=torch.float32, device="cuda")
     L.check(L.lib.gmvae_cluster_acc(L.ptr(ld), L.ptr(lab), B, K, 10, L.ptr(scratch), L.ptr(acc), L.current_stream()),
             "cluster_acc")
-    assert acc.item() == pytest.approx(O.cluster_acc(logits, labels, K), abs=2.0 / B)
+    # integer work: the [K, n_labels] histogram bit for bit; the accuracy (invariant to the mode tie-break) to fp32 rounding
+    want_hist = np.zeros((K, 10), np.int32)
+    np.add.at(want_hist, (logits.argmax(1), labels), 1)
+    assert np.array_equal(scratch[:K * 10].cpu().numpy().reshape(K, 10), want_hist)
+    assert np.array_equal(scratch[K * 10:].cpu().numpy(), logits.argmax(1))
+    assert acc.item() == pytest.approx(O.cluster_acc(logits, labels, K), abs=1e-6)
+    assert acc.item() == pytest.approx(O.cluster_acc_from_hist(want_hist), abs=1e-6)

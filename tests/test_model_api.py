@@ -91,7 +91,73 @@ def test_gmvae_modules_match_oracle():
     loss = model.run_model(xt, xt, labels, eps=torch.from_numpy(eps), u=torch.from_numpy(u))
     assert loss.item() == pytest.approx(C["loss"], rel=1e-4)
     acc = model.summaries["cluster_acc"].item()
-    assert acc == pytest.approx(O.cluster_acc(C["logits"], labels.numpy(), 4), abs=0.11)
+    # the accuracy is invariant to the mode tie-break, so the device value is the reference's to fp32 rounding
+    assert acc == pytest.approx(O.cluster_acc(_np(q_y.distribution.logits), labels.numpy(), 4), abs=1e-6)
+
+
+def _torch_draws(seed, u_shape=None, eps_shape=None):
+    """The draws base.RelaxedOneHotCategorical.sample / MultivariateNormalDiag.sample make for `seed` (each call seeds
+    a fresh device generator, as the reference passes the same `seed=self.random_seed` to every sampler)."""
+    out = []
+    if u_shape is not None:
+        g = torch.Generator(device="cuda"); g.manual_seed(seed)
+        out.append(torch.rand(u_shape, device="cuda", generator=g).clamp_min(1.1754943508222875e-38).cpu().numpy())
+    if eps_shape is not None:
+        g = torch.Generator(device="cuda"); g.manual_seed(seed)
+        out.append(torch.randn(eps_shape, device="cuda", generator=g).cpu().numpy())
+    return out
+
+
+def test_gmvae_eval_methods_values_match_oracle():
+    """scripts/gmvae.py:109-188 by VALUE: reconstruct_images, transform (a SAMPLED code for the GMVAE),
+    generate_samples(clusters) and generate_sample_images, with the samplers' draws injected into the oracle."""
+    import gmvae_amd
+    from oracle import gmvae_oracle as OO
+    seed, B = 7, 10
+    model = gmvae_amd.create_gmvae(200, 6, mixture_components=4, fcnet_hidden_sizes=[24], sigma_min=0.0,
+                                   raw_sigma_bias=0.5, temperature=0.8, random_seed=seed)
+    d = O.Dims(D=200, L=6, K=4, hidden=(24,), temperature=0.8)
+    p = O.unpack(O.MODEL_GMVAE, d, _np(model.params))
+    x, _, _ = O.make_inputs(d, B)
+    xt = torch.from_numpy(x).cuda()
+    u, eps = _torch_draws(seed, (B, 4), (B, 6))
+    C = O.forward(O.MODEL_GMVAE, d, p, x, eps, u)
+    np.testing.assert_allclose(_np(model.transform(xt)), C["z"], rtol=1e-4, atol=1e-5)                     # gmvae.py:140-149
+    np.testing.assert_allclose(_np(model.reconstruct_images(xt)), OO.sigmoid(C["lam"]), rtol=1e-4, atol=1e-5)   # :109-123
+    # generate_samples(num_samples, clusters): z = mu_p(y_k) + sigma_p(y_k) * eps, rows ordered [sample][cluster]
+    clusters, n = [0, 3, 3], 5
+    y = np.eye(4)[clusters]
+    pp = y @ p["prior_gmm_fcnet/linear_0/w"] + p["prior_gmm_fcnet/linear_0/b"]
+    mu_p, sig_p, _ = OO._normal_head(pp, 6, np.float64(0.5), np.float64(0.0))
+    (eps_g,) = _torch_draws(seed, None, (n, 3, 6))
+    want = (mu_p[None] + sig_p[None] * eps_g).reshape(n * 3, 6)
+    got = model.generate_samples(n, clusters=clusters)
+    np.testing.assert_allclose(_np(got), want, rtol=1e-4, atol=1e-5)                                        # gmvae.py:152-188
+    lam, _ = OO._mlp_fwd({k: np.asarray(v, np.float64) for k, v in p.items()}, "decoder", 2, want)
+    np.testing.assert_allclose(_np(model.generate_sample_images(got)), OO.sigmoid(lam), rtol=1e-4, atol=1e-5)
+    # all K clusters when none are given: K * num_samples rows
+    (eps_a,) = _torch_draws(seed, None, (2, 4, 6))
+    pp = np.eye(4) @ p["prior_gmm_fcnet/linear_0/w"] + p["prior_gmm_fcnet/linear_0/b"]
+    mu_a, sig_a, _ = OO._normal_head(pp, 6, np.float64(0.5), np.float64(0.0))
+    np.testing.assert_allclose(_np(model.generate_samples(2)), (mu_a[None] + sig_a[None] * eps_a).reshape(8, 6), rtol=1e-4, atol=1e-5)
+
+
+def test_vae_eval_methods_values_match_oracle():
+    """scripts/vae.py:80-123: transform returns the MEAN code; reconstruct_images decodes a SAMPLED code."""
+    import gmvae_amd
+    from oracle import gmvae_oracle as OO
+    seed, B = 5, 9
+    model = gmvae_amd.create_vae(784, 8, fcnet_hidden_sizes=[32], sigma_min=0.0, raw_sigma_bias=0.5, random_seed=seed)
+    d = O.Dims(D=784, L=8, K=1, hidden=(32,))
+    p = O.unpack(O.MODEL_VAE, d, _np(model.params))
+    x, _, _ = O.make_inputs(d, B, O.MODEL_VAE)
+    xt = torch.from_numpy(x).cuda()
+    (eps,) = _torch_draws(seed, None, (B, 8))
+    C = O.forward(O.MODEL_VAE, d, p, x, eps)
+    np.testing.assert_allclose(_np(model.transform(xt)), C["mu_q"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(_np(model.reconstruct_images(xt)), OO.sigmoid(C["lam"]), rtol=1e-4, atol=1e-5)
+    (eps_s,) = _torch_draws(seed, None, (4, 8))
+    np.testing.assert_allclose(_np(model.generate_samples(4)), eps_s, rtol=1e-5, atol=1e-6)           # N(0, I) prior
 
 
 def test_state_dict_roundtrip_uses_tf_variable_names():

@@ -26,12 +26,100 @@ def test_early_stopping_hook_semantics():
     assert h.after_run(2, 1.0) is False              # global step went backwards -> reset (recovery)
 
 
+def test_wait_for_checkpoint_polls_like_the_reference(tmp_path):
+    """scripts/utils.py:100-111: loop + sleep until the checkpoint appears (no GPU needed)."""
+    import threading
+    import time
+    from gmvae_amd import runners
+    path = tmp_path / "model.pt"
+    with pytest.raises(FileNotFoundError):
+        runners.wait_for_checkpoint(str(path), poll_seconds=0.01, max_wait=0.05)
+    threading.Timer(0.15, lambda: path.write_bytes(b"x")).start()
+    t0 = time.time()
+    assert runners.wait_for_checkpoint(str(path), poll_seconds=0.02, max_wait=5.0) == str(path)
+    assert 0.1 < time.time() - t0 < 3.0
+    assert runners._graph_steps(50) == 25 and runners._graph_steps(20) == 20 and runners._graph_steps(7) == 7
+    assert runners._graph_steps(1000) == 25 and runners._graph_steps(97) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["gmvae", "vae_gmp"])
+def test_run_train_takes_the_graph_path_and_equals_the_eager_loop(tmp_path, model):
+    """The drop-in loop (scripts/runners.py:222-232) runs summarise_every-aligned pipeline graphs: binarisation, noise,
+    step and Adam on the device.  Same batches through eager launches (config.eager) -> the same trajectory."""
+    import torch
+    from gmvae_amd import runners
+    outs = []
+    for eager in (False, True):
+        args = ["--mode=train", f"--model={model}", "--latent_size=64", "--batch_size=1024", "--max_steps=44",
+                "--summarise_every=15", f"--logdir={tmp_path}/{eager}", "--random_seed=3", "--synthetic_size=5000"]
+        m = run_gmvae.main(args + (["--eager"] if eager else []))
+        assert runners.run_train.last_path == ("eager" if eager else "pipeline-graph")
+        assert m._engine.global_step == 45 and m._engine.handoff_timeouts() == 0
+        outs.append((m._engine.params.detach().clone(), m._engine.grads[m._engine.P:].clone()))
+    assert torch.isfinite(outs[0][0]).all()
+    # 45 Adam steps; the schedules differ in summation order only.  Adam's m / sqrt(v) amplifies that on coordinates
+    # with near-zero gradients (the learned prior's variables), hence a mean gate, a loose max gate and the last loss.
+    diff = (outs[0][0] - outs[1][0]).abs()
+    assert diff.mean().item() < 5e-6 and diff.max().item() < 45 * 1e-3 * 0.05
+    assert abs(outs[0][1][0].item() - outs[1][1][0].item()) < 2e-5 * abs(outs[1][1][0].item())
+
+
+@pytest.mark.gpu
+def test_restart_equivalence_bit_for_bit(tmp_path):
+    """k steps -> checkpoint -> NEW model object restored from it -> k steps == 2k uninterrupted steps, bit for bit
+    (parameters, both Adam slots, step counter, Philox stream position).  MonitoredTrainingSession's restore,
+    scripts/runners.py:222-228; checkpoint keys are the TF variable names."""
+    import numpy as np
+    import torch
+    import gmvae_amd
+    k, B = 5, 256
+    xs = torch.from_numpy((np.random.default_rng(0).random((2 * k, B, 784)) < 0.87).astype(np.uint8)).cuda()
+    mk = lambda: gmvae_amd.create_gmvae(784, 16, mixture_components=10, fcnet_hidden_sizes=[64], sigma_min=0.0,
+                                        raw_sigma_bias=0.5, random_seed=9)
+    a = mk()
+    for i in range(2 * k):
+        a._engine.train_step(xs[i], lr=1e-3)
+    b = mk()
+    for i in range(k):
+        b._engine.train_step(xs[i], lr=1e-3)
+    path = tmp_path / "model.pt"
+    torch.save(b.state_dict(), path)
+    sd = torch.load(path, map_location="cpu")
+    # TF checkpoint names: the variable, its two Adam slots, the optimizer's power accumulators, the step
+    for key in ("encoder_gmm_fcnet/linear_0/w", "encoder_gmm_fcnet/linear_0/w/Adam", "encoder_gmm_fcnet/linear_0/w/Adam_1",
+                "decoder_fcnet/linear_1/b/Adam", "beta1_power", "beta2_power", "global_step"):
+        assert key in sd, key
+    assert sd["encoder_gmm_fcnet/linear_0/w/Adam"].shape == sd["encoder_gmm_fcnet/linear_0/w"].shape == (794, 64)
+    assert float(sd["beta1_power"]) == pytest.approx(0.9 ** (k + 1)) and int(sd["global_step"]) == k
+    c = gmvae_amd.create_gmvae(784, 16, mixture_components=10, fcnet_hidden_sizes=[64], sigma_min=0.0, raw_sigma_bias=0.5,
+                               random_seed=1234)       # another init, another noise seed: everything must come from the file
+    c.load_state_dict(sd)
+    assert c._engine.global_step == k and int(c._engine.step_dev[0].item()) == k
+    # the second half through a multi-step train graph: the graph path restarts from the file too
+    sx, replay = c._engine.capture_train_step(B, lr=1e-3, n_steps=k)
+    sx.copy_(xs[k:])
+    d = mk()
+    d.load_state_dict(sd)
+    for i in range(k, 2 * k):
+        d._engine.train_step(xs[i], lr=1e-3)
+    replay()
+    torch.cuda.synchronize()
+    for got in (d,):
+        assert torch.equal(got._engine.params, a._engine.params)
+        assert torch.equal(got._engine.m, a._engine.m) and torch.equal(got._engine.v, a._engine.v)
+        assert got._engine.global_step == 2 * k
+    assert c._engine.global_step == 2 * k and (c._engine.params - a._engine.params).abs().max().item() < 2e-5
+
+
 @pytest.mark.gpu
 def test_train_then_eval_end_to_end(tmp_path):
     args = ["--model=gmvae", "--latent_size=16", "--batch_size=256", "--max_steps=60", "--summarise_every=20",
             f"--logdir={tmp_path}", "--random_seed=1", "--synthetic_size=2048"]
     model = run_gmvae.main(["--mode=train"] + args)
     assert model._engine.global_step == 61              # `<=` runs one extra step, as the reference does
+    from gmvae_amd import runners
+    assert runners.run_train.last_path == "pipeline-graph"
     res = run_gmvae.main(["--mode=eval"] + args)
     assert res["examples"] == 2048
     assert res["train/loss_per_example"] < 450          # Bernoulli(0.87) data: well below the D ln 2 = 543 start
