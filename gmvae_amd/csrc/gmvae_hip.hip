@@ -18,6 +18,7 @@
 #include "kernels.hpp"
 #include "chain.hpp"
 #include "mega.hpp"
+#include "mega2.hpp"
 
 using namespace gmvae;
 
@@ -129,6 +130,7 @@ struct WS {
   unsigned* sync;               // [0] = per-step epoch of the hand-off, [1] = hand-off timeout flag
   float *img_f, *img_b;         // per-step LDS weight images of chain_fwd / chain_bwd (prepared by aux blocks)
   float *img_m, *dimg;          // mega kernel: small-weight image (odd leading dimensions) + decoder chunk images
+  float *img2f, *img2b, *dimg2; // mega2 kernel: forward / backward operand images, decoder operand images
   int32_t* cl_pred;
   uint64_t bytes;
 };
@@ -168,6 +170,13 @@ static bool mega_ok(const GmvaeDims& d, int model) {
   if (H % 16 || H > 64 || d.L % 2 || d.L > 128 || d.K > 64) return false;      // L even: k-steps of 4 over [mu | raw]
   if (model == GMVAE_MODEL_VAE_GMP && (d.B + kPanel - 1) / kPanel > GMP_PARTS) return false;
   return (size_t)mega_lay(H, d.L, d.K, d.D, model).total * 4 <= 160 * 1024;
+}
+// mega2_fwd_bwd (mega2.hpp): the steady-state launch specialised for the reference's default sizes
+static bool mega2_ok(const GmvaeDims& d, int model) {
+  const char* e = getenv("GMVAE_NO_MEGA2");
+  if (e && atoi(e)) return false;
+  return model == GMVAE_MODEL_GMVAE && mega_ok(d, model) && d.hidden[0] == M2::H && d.L == M2::L && d.K == M2::K &&
+         d.D == M2::D && d.B <= 1024;
 }
 static bool fused_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_FUSED");
@@ -250,6 +259,11 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
       w.xfl = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * 4 * kPanel * 2 * d.hidden[0]));
     w.gstamps = reinterpret_cast<unsigned long long*>(take(2ull * 4 * 2048 * 8));
     w.spans = reinterpret_cast<unsigned long long*>(take(2ull * 2 * 2048 * 2));
+    if (model == GMVAE_MODEL_GMVAE && d.hidden[0] == M2::H && d.L == M2::L && d.K == M2::K && d.D == M2::D && d.B <= 1024) {
+      w.img2f = take(M2::imgF);                  // (not gated by GMVAE_NO_MEGA2: the workspace layout must not depend on a switch)
+      w.img2b = take(M2::imgB);
+      w.dimg2 = take(M2::dimg);
+    }
   }
   w.dz = take(R * Lz);
   w.dqp = take(R * 2 * Lz);
@@ -461,11 +475,11 @@ static void plan_images(const GmvaeDims& d, int model, const Layout& L, const WS
   const int K = d.K, Lz = d.L, D = d.D, H = d.hidden[0];
   const NetL &E = gm ? L.ency : L.enc, &G = L.encg, &Dn = L.dec;
   float* im = w.img_m;
-  auto add_map = [&](long long begin, long long n, int cols, int kind, int base, int ld, int which) {
+  auto add_map = [&](long long begin, long long n, int cols, int kind, int base, int ld, int which, int chunk = -1) {
     if (pl.nmap >= kMaxImgMap || (unsigned long long)n * (unsigned long long)cols >= (1ull << 32)) { pl.map_ok = false; return; }
     ImgMap& m = pl.map[pl.nmap++];
     m.begin = (int)begin; m.end = (int)(begin + n); m.cols = cols; m.kind = kind; m.base = base; m.ld = ld;
-    m.cw = kCW; m.chunk = ml.chunk; m.magic = (unsigned)((1ull << 32) / (unsigned)cols) + 1u; m.which = which;
+    m.cw = kCW; m.chunk = chunk < 0 ? ml.chunk : chunk; m.magic = (unsigned)((1ull << 32) / (unsigned)cols) + 1u; m.which = which;
   };
   auto task = [&](float* dst, int ld, const float* src, int rows, int cols) {      // dense source rows
     ImgTask& t = pl.task[pl.nt++];
@@ -504,6 +518,31 @@ static void plan_images(const GmvaeDims& d, int model, const Layout& L, const WS
   }
   add_map(Dn.w[1], (long long)H * D, D, 1, 0, ml.ldc, 1);
   add_map(Dn.b[1], D, D, 1, H * ml.ldc, ml.ldc, 1);
+  if (mega2_ok(d, model) && w.img2f) {
+    // the steady-state launch is mega2_fwd_bwd: the optimiser scatters into ITS operand images instead (every weight of a
+    // matrix product twice: forward and transposed orientation; kernels.hpp img_dst kinds 2..6)
+    pl.nmap = 0; pl.map_ok = true;
+    const long long Wg0y = (long long)G.w[0] + (long long)D * H;
+    add_map(E.b[0], H, H, 0, M2::b_y0, H, 2);
+    add_map(E.b[1], K, K, 0, M2::b_y1, K, 2);
+    add_map(G.b[0], H, H, 0, M2::b_g0, H, 2);
+    add_map(L.prior.b[0], 2 * Lz, 2 * Lz, 0, M2::b_p, 2 * Lz, 2);
+    add_map(G.b[1], 2 * Lz, 2 * Lz, 0, M2::b_g1, 2 * Lz, 2);
+    add_map(Dn.b[0], H, H, 0, M2::b_d0, H, 2);
+    add_map(E.w[1], (long long)H * K, K, 2, M2::Wy1f, 16, 2);
+    add_map(E.w[1], (long long)H * K, K, 3, M2::Wy1b, 64, 3);
+    add_map(Wg0y, (long long)K * H, H, 2, M2::Wg0yf, 64, 2);
+    add_map(Wg0y, (long long)K * H, H, 3, M2::Wg0yb, 16, 3);
+    add_map(L.prior.w[0], (long long)K * 2 * Lz, 2 * Lz, 2, M2::Wpf, 128, 2);
+    add_map(L.prior.w[0], (long long)K * 2 * Lz, 2 * Lz, 3, M2::Wpb, 16, 3);
+    add_map(G.w[1], (long long)H * 2 * Lz, 2 * Lz, 2, M2::Wg1f, 128, 2);
+    add_map(G.w[1], (long long)H * 2 * Lz, 2 * Lz, 3, M2::Wg1b, 64, 3);
+    add_map(Dn.w[0], (long long)Lz * H, H, 2, M2::Wd0f, 64, 2);
+    add_map(Dn.w[0], (long long)Lz * H, H, 3, M2::Wd0b, 64, 3);
+    add_map(Dn.w[1], (long long)H * D, D, 4, M2::dF, M2::DC, 4, M2::dFq);
+    add_map(Dn.w[1], (long long)H * D, D, 5, M2::dB, 64, 4, M2::dBq);
+    add_map(Dn.b[1], D, D, 6, M2::dbias, 0, 4, M2::dbq);
+  }
   pl.lo = 1 << 30; pl.hi = 0;
   for (int i = 0; i < pl.nmap; ++i) {
     pl.lo = pl.map[i].begin < pl.lo ? pl.map[i].begin : pl.lo;
@@ -530,7 +569,7 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
     fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = a.adam_p ? 1 : 0; fa.count = (float)B;
     fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = nent;
     fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev); fa.tail_log = a.tail_log;
-    fa.nmap = 0; fa.map_lo = fa.map_hi = 0; fa.img0 = fa.img1 = nullptr; fa.epoch_word = nullptr;
+    fa.nmap = 0; fa.map_lo = fa.map_hi = 0; fa.epoch_word = nullptr;
     fa.err_word = (mega_ok(d, a.model) && w.sync) ? w.sync + 1 : nullptr;
     fa.sx = sx;
     if (gmp) {                               // (mega schedule only: one partial per panel)
@@ -544,7 +583,8 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
       plan_images(d, a.model, L, w, ml, a.params, pl);
       fa.epoch_word = w.sync;
       if (pl.map_ok && ml.fl_ok) {
-        fa.nmap = pl.nmap; fa.map_lo = pl.lo; fa.map_hi = pl.hi; fa.img0 = w.img_m; fa.img1 = w.dimg;
+        fa.nmap = pl.nmap; fa.map_lo = pl.lo; fa.map_hi = pl.hi;
+        fa.img[0] = w.img_m; fa.img[1] = w.dimg; fa.img[2] = w.img2f; fa.img[3] = w.img2b; fa.img[4] = w.dimg2;
         for (int i = 0; i < pl.nmap; ++i) { fa.map[i] = pl.map[i]; fa.mbegin[i] = pl.map[i].begin; fa.mend[i] = pl.map[i].end; }
       }
     }
@@ -663,13 +703,26 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       mattr = true;
     }
-    hipLaunchKernelGGL(fn, dim3((B + kPanel - 1) / kPanel * c.Q), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
+    const bool m2 = fl && mega2_ok(d, model) && w.img2f;
+    if (m2) {
+      c.img2f = w.img2f; c.img2b = w.img2b; c.dimg2 = w.dimg2;
+      static bool m2attr = false;
+      if (!m2attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(mega2_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        m2attr = true;
+      }
+      hipLaunchKernelGGL(mega2_fwd_bwd, dim3((B + kPanel - 1) / kPanel * 4), dim3(kMT), (size_t)M2::total * sizeof(float), st, c);
+    } else {
+      hipLaunchKernelGGL(fn, dim3((B + kPanel - 1) / kPanel * c.Q), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
+    }
     cx.check();
     // algorithmic MFMA FLOPs of the launch: forward chain + decoder layer (lambda and its data gradient) + backward chain
     double macs = (double)H * 2 * Lz + (double)Lz * H + 2.0 * H * D + (double)H * Lz + 2.0 * Lz * H;
     if (fl) macs += (double)D * H2;                    // the first layer rides in the launch
     if (gm) macs += (double)H * K + (double)K * H + (double)K * 2 * Lz + (double)(H + 2 * Lz) * K + (double)K * H;
+    if (m2) { cx.mark("mega2_fwd_bwd", 2.0 * B * macs); goto mega_done; }
     cx.mark("mega_fwd_bwd", 2.0 * B * macs);
+  mega_done:;
   }
   // Every weight gradient in one grouped launch.  The uint8-activation problems (bf16 matrix cores) take NS splits
   // of two 64-row staging rounds; the fp32 problems take 2 NS splits of ONE round each: their workgroups, the
@@ -1405,7 +1458,7 @@ int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, floa
     };
     for (int i = 0; i < pr->n; ++i) {
       double us = 0.0;
-      if (!strncmp(pr->name[i], "mega_fwd_bwd", 12)) us = span_of(hsp, 2, 1);
+      if (!strncmp(pr->name[i], "mega", 4)) us = span_of(hsp, 2, 1);
       else if (!strncmp(pr->name[i], "bwd_dw_all", 10)) us = span_of(hsp + nsp, 8, 4);
       else if (!strncmp(pr->name[i], "finalize_adam", 13)) us = span_of(hsp + 2048 * 2, 2, 1);
       acc[i] += us;
@@ -1714,7 +1767,8 @@ static int dp_step_impl(const GmvaeDims* dims, int model, const uint8_t* x, floa
   }
   ImgScatter sc;
   memset(&sc, 0, sizeof(sc));
-  sc.nmap = pl.nmap; sc.lo = pl.lo; sc.hi = pl.hi; sc.img0 = w.img_m; sc.img1 = w.dimg; sc.epoch_word = w.sync;
+  sc.nmap = pl.nmap; sc.lo = pl.lo; sc.hi = pl.hi; sc.epoch_word = w.sync;
+  sc.img[0] = w.img_m; sc.img[1] = w.dimg; sc.img[2] = w.img2f; sc.img[3] = w.img2b; sc.img[4] = w.dimg2;
   for (int i = 0; i < pl.nmap; ++i) { sc.map[i] = pl.map[i]; sc.mbegin[i] = pl.map[i].begin; sc.mend[i] = pl.map[i].end; }
   (void)hipGetLastError();
   hipLaunchKernelGGL(adam_tf_img, dim3((unsigned)((L.P_pad / 4 + 255) / 256)), dim3(256), 0, st, params, m, v, grads,

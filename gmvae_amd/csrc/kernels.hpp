@@ -505,13 +505,37 @@ __global__ void adam_tf(float* __restrict__ p, float* __restrict__ m, float* __r
 // One tensor (or row range of one) that also lives in an LDS-image of the next step's mega_fwd_bwd: flat parameter
 // indices [begin, end), `cols` per source row.  kind 0: img[base + r * ld + c]; kind 1 (decoder output layer, stored
 // as column chunks of `cw`): img[base + (c / cw) * chunk + r * ld + c % cw].
+// Kinds 2..6 are the operand images of mega2_fwd_bwd (mega2.hpp): a matrix product's weight is the MFMA A operand
+// there, stored [contraction / 4][outputs padded to `ld`][contraction % 4], so that a lane's four consecutive
+// contraction steps are ONE 16-byte read:
+//   kind 2: contraction index = r (forward: out = in * W):     img[base + ((r >> 2) * ld + c) * 4 + (r & 3)]
+//   kind 3: contraction index = c (backward: din = dout * W^T): img[base + ((c >> 2) * ld + r) * 4 + (c & 3)]
+//   kinds 4 / 5 / 6: the decoder output layer [H][D] (4: forward, 5: data gradient, 6: its bias), 16-column tiles
+//   dealt round-robin to the panel's 4 workgroups: tile t = c >> 4 belongs to workgroup q = t & 3 as its local tile
+//   t >> 2; lc = ((c >> 6) << 4) | (c & 15) is the column inside that workgroup's part (`chunk` floats per part).
+__host__ __device__ inline int img_dst(const int kind, const int base, const int ld, const int chunk, const int r, const int c) {
+  switch (kind) {
+    case 0: return base + r * ld + c;
+    case 1: return base + (c >> 7) * chunk + r * ld + (c & 127);                  // kCW = 128
+    case 2: return base + (((r >> 2) * ld + c) << 2) + (r & 3);
+    case 3: return base + (((c >> 2) * ld + r) << 2) + (c & 3);
+    default: {
+      const int q = (c >> 4) & 3, lc = ((c >> 6) << 4) | (c & 15);
+      if (kind == 4) return base + q * chunk + (((r >> 2) * ld + lc) << 2) + (r & 3);    // [H/4][ld = 208][4]
+      if (kind == 5) return base + q * chunk + (((lc >> 2) * ld + r) << 2) + (lc & 3);   // [208/4][ld = H][4]
+      return base + q * chunk + lc;                                                       // bias [208]
+    }
+  }
+}
 struct ImgMap {
   int begin, end, cols, kind;
   int base, ld, cw, chunk;
   unsigned magic;             // floor(2^32 / cols) + 1: row = (off * magic) >> 32 (checked on the host for the range)
-  int which;                  // 0: small-weight image, 1: decoder chunk images
+  int which;                  // destination buffer: 0 small-weight image, 1 decoder chunk images; mega2: 2 forward
+                              // image, 3 backward image, 4 decoder operand images
 };
-constexpr int kMaxImgMap = 20;
+constexpr int kMaxImgMap = 24;
+constexpr int kImgBufs = 5;
 
 struct FinalArgs {
   const float* slabs; int nslab; long long P;
@@ -525,7 +549,7 @@ struct FinalArgs {
   // the updated parameters are also scattered into the next step's weight images (then that step needs no
   // image-building launch); nmap = 0: off
   int nmap, map_lo, map_hi;
-  float *img0, *img1;
+  float* img[kImgBufs];       // destination buffers (ImgMap::which)
   unsigned* epoch_word;       // bumped for the next step's in-launch hand-offs
   const unsigned* err_word;   // hand-off timeout flag of this workspace: when set the step is poisoned and NOT applied
   unsigned long long* span;   // measurement: [block][2] wall-clock (100 MHz) at a block's first and last instruction
@@ -653,7 +677,7 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
   while (hit) {
     hit &= hit - 1;
     if (i4 >= e_begin && i4 < e_end) {
-      float* const img = e_which ? a.img1 : a.img0;
+      float* const img = a.img[e_which];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int idx = (int)i4 + j;
@@ -661,8 +685,7 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
           const unsigned off = (unsigned)(idx - e_begin);
           const int r = (int)(((unsigned long long)off * e_magic) >> 32);
           const int c = (int)off - r * e_cols;
-          const int dst = e_kind ? e_base + (c >> 7) * e_chunk + r * e_ld + (c & 127) : e_base + r * e_ld + c;   // kCW = 128
-          img[dst] = pa[j];
+          img[img_dst(e_kind, e_base, e_ld, e_chunk, r, c)] = pa[j];
         }
       }
     }
@@ -681,7 +704,7 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
 // their positions in the next step's weight images (so that step can run its first layer inside mega_fwd_bwd).
 struct ImgScatter {
   int nmap, lo, hi;
-  float *img0, *img1;
+  float* img[kImgBufs];
   unsigned* epoch_word;
   int mbegin[kMaxImgMap], mend[kMaxImgMap];
   ImgMap map[kMaxImgMap];
@@ -725,7 +748,7 @@ __global__ __launch_bounds__(256) void adam_tf_img(float* __restrict__ p, float*
     const int begin = sc.map[k].begin, end = sc.map[k].end, cols = sc.map[k].cols, kind = sc.map[k].kind;
     const int base = sc.map[k].base, ld = sc.map[k].ld, chunk = sc.map[k].chunk;
     const unsigned magic = sc.map[k].magic;
-    float* const img = sc.map[k].which ? sc.img1 : sc.img0;
+    float* const img = sc.img[sc.map[k].which];
     if (i4 < begin || i4 >= end) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -734,7 +757,7 @@ __global__ __launch_bounds__(256) void adam_tf_img(float* __restrict__ p, float*
         const unsigned off = (unsigned)(idx - begin);
         const int r = (int)(((unsigned long long)off * magic) >> 32);
         const int c = (int)off - r * cols;
-        img[kind ? base + (c >> 7) * chunk + r * ld + (c & 127) : base + r * ld + c] = pa[j];   // kCW = 128
+        img[img_dst(kind, base, ld, chunk, r, c)] = pa[j];
       }
     }
   }

@@ -245,6 +245,7 @@ struct MegaArgs {
   unsigned long long seed;
   unsigned long long row0;    // global index of this device's first batch row (GmvaeDims::row0): Philox counter only
   unsigned long long* step_dev;
+  const float *img2f, *img2b, *dimg2;   // mega2_fwd_bwd (mega2.hpp): forward / backward operand images, decoder operand images
 };
 
 // HT, LT, KT, DT, MODEL: compile-time sizes of a specialised instance (0 / -1 = read them from the arguments).

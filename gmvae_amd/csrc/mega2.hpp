@@ -1,0 +1,653 @@
+// mega2_fwd_bwd: the steady-state per-row launch of the GMVAE training step at the reference's default sizes
+// (run_gmvae.py: hidden 64, latent 64, K = 10; MNIST D = 784; batch <= 1024) -- the same work as
+// mega_fwd_bwd<64, 64, 10, 784, 2, 1> (mega.hpp: first layer, forward chain, decoder layer with its data gradient,
+// backward chain; scripts/gmvae.py:238-267 and its reverse pass), re-laid for the 16-row panel's latency chain:
+//
+//   * every matrix product runs TRANSPOSED on the matrix cores: the WEIGHT is the MFMA A operand (16 output features
+//     per tile) and the panel's activations are the B operand (16 batch rows).  With the contraction index of four
+//     consecutive v_mfma_f32_16x16x4_f32 assigned as k = 16 kt + 4 (lane / 16) + s, a lane's four steps are ONE
+//     16-byte LDS read of the weight image ([k / 4][outputs][4], written by finalize_adam's scatter) and ONE 16-byte
+//     read of a ROW-MAJOR activation panel -- and the accumulator it ends with, out[row = lane % 16][4 (lane / 16) + r],
+//     is four consecutive columns of a row: one 16-byte store puts it where the next product and the row-wise stages
+//     read it.  (mega_fwd_bwd kept [k][17] images: 32 four-byte LDS reads and 8 four-byte writes per tile and stage.)
+//   * the decoder layer needs no LDS at all: each wave owns 16-column tiles of the 784 outputs; its weights (forward and
+//     transposed operand images, 2 x 4 KB per tile) are fetched straight into registers long before they are used,
+//     lambda = hd1 Wd1 + b comes out of the matrix core as [4 columns of one row] per lane, the Bernoulli term,
+//     g = sigmoid(lambda) - x and -- the accumulator being exactly the B operand of the data gradient's contraction
+//     over those columns -- dhd1 += g Wd1^T follow without a barrier or an LDS round trip.
+//
+// Grid and hand-offs are mega_fwd_bwd's: 4 workgroups per panel (first-layer columns split four ways, partials exchanged
+// through tagged 8-byte granules; the decoder's column tiles dealt round-robin; quarters 1..3 publish their dhd1 and
+// row-sum partials and leave, quarter 0 runs the backward chain).
+#pragma once
+#include "mega.hpp"
+
+namespace gmvae {
+
+struct M2 {
+  static constexpr int H = 64, L = 64, K = 10, KP = 16, L2 = 128, D = 784, K2 = 12;
+  static constexpr int NT = D / 16;               // 49 decoder column tiles
+  static constexpr int DC = 208;                  // columns of one workgroup's part, padded to 13 tiles
+  // ---- forward operand image (floats): biases, then [contraction / 4][outputs][4] weights
+  static constexpr int b_y0 = 0, b_y1 = 64, b_g0 = 80, b_p = 144, b_g1 = 272, b_d0 = 400;
+  static constexpr int Wy1f = 512;                // [16][16][4]   logits = hy * Wy1      (contraction h, 16 >= K outputs)
+  static constexpr int Wg0yf = Wy1f + 1024;       // [4][64][4]    hg    += y * Wg0[D:]   (contraction k padded to 16)
+  static constexpr int Wpf = Wg0yf + 1024;        // [4][128][4]   pp     = y * Wp
+  static constexpr int imgF_early = Wpf + 2048;   // 4608: what the first stages need
+  static constexpr int Wg1f = imgF_early;         // [16][128][4]  qp     = hg * Wg1
+  static constexpr int Wd0f = Wg1f + 8192;        // [16][64][4]   hd     = z * Wd0
+  static constexpr int imgF = Wd0f + 4096;        // 16896
+  // ---- backward operand image
+  static constexpr int Wd0b = 0;                  // [16][64][4]   dz   = dhd * Wd0^T     (contraction h, outputs l)
+  static constexpr int Wg1b = Wd0b + 4096;        // [32][64][4]   dhg  = dqp * Wg1^T     (contraction 2L, outputs h)
+  static constexpr int Wg0yb = Wg1b + 8192;       // [16][16][4]   dy   = dhg * Wg0[D:]^T (contraction h, outputs k)
+  static constexpr int Wpb = Wg0yb + 1024;        // [32][16][4]   dy  += dpp * Wp^T      (contraction 2L, outputs k)
+  static constexpr int Wy1b = Wpb + 2048;         // [4][64][4]    dhy  = dl * Wy1^T      (contraction k, outputs h)
+  static constexpr int imgB = Wy1b + 1024;        // 16384
+  // ---- decoder operand images in global memory, per workgroup part q: forward [16][DC][4], transposed [DC/4][64][4], bias [DC]
+  static constexpr int dF = 0, dFq = 16 * DC * 4;
+  static constexpr int dB = 4 * dFq, dBq = (DC / 4) * 64 * 4;
+  static constexpr int dbias = dB + 4 * dBq, dbq = DC;
+  static constexpr int dimg = dbias + 4 * dbq;    // floats
+  // ---- LDS map (floats).  Row-major panels of the 16 batch rows; strides = 4 (mod 64): a wave's 16-byte operand reads
+  // (16 rows x 4 column groups) are then nearly conflict-free.
+  static constexpr int ld64 = 68, ld128 = 132, ldk = 20;
+  static constexpr int IMG = 0;
+  static constexpr int P_h1 = IMG + imgF;         // [16][132]  relu(hy) | gx (raw)
+  static constexpr int P_y = P_h1 + 16 * ld128;   // [16][20]
+  static constexpr int P_hg = P_y + 16 * ldk;     // [16][68]
+  static constexpr int P_pp = P_hg + 16 * ld64;   // [16][132]  prior head (mu | raw) -> (t | sigma_p) for the backward chain
+  static constexpr int P_qp = P_pp + 16 * ld128;  // [16][132]  q head -> (sigmoid(raw_q) | sigma_q)
+  static constexpr int P_z = P_qp + 16 * ld128;   // [16][68]
+  static constexpr int P_sp = P_z + 16 * ld64;    // [16][64]   sigmoid(raw_p)
+  static constexpr int P_hd = P_sp + 16 * 64;     // [16][68]
+  static constexpr int P_eps = P_hd + 16 * ld64;  // [16][64]
+  static constexpr int P_u = P_eps + 16 * 64;     // [16][16]
+  static constexpr int P_lg = P_u + 256;          // [16][20]
+  static constexpr int nll = P_lg + 16 * ldk;     // [4][16]: log q, log p, -, nent per row
+  static constexpr int rsum = nll + 64;           // [8][16] Bernoulli row sums per wave
+  static constexpr int red = rsum + 128;          // [8][256] K-split partial tiles
+  static constexpr int dred = red + 2048;         // [8][1024] per-wave partial dhd1 tiles; later the backward panels
+  static constexpr int P_dhd = dred + 8192;       // [16][68]
+  static constexpr int total = P_dhd + 16 * ld64;
+  // backward panels (inside the dred region, which is dead once the partial tiles are summed)
+  static constexpr int P_dz = dred;               // [16][68]
+  static constexpr int P_dqp = P_dz + 16 * ld64;  // [16][132]
+  static constexpr int P_dpp = P_dqp + 16 * ld128;
+  static constexpr int P_dhg = P_dpp + 16 * ld128;
+  static constexpr int P_dl = P_dhg + 16 * ld64;  // [16][20]
+  static_assert(P_dl + 16 * ldk <= P_dhd, "backward panels must fit the dred region");
+  static_assert(total * 4 <= 160 * 1024, "LDS budget");
+  // the in-launch first layer's staging (mega.hpp FL: [2][196][64] weights + [16][226] x image) overlays [0, ...)
+  static constexpr int fl_kq = 196, fl_A = 25088;
+  static_assert(fl_A + 16 * kFlLda <= red, "first-layer staging must end below the scratch that is live during it");
+};
+
+// one 16-output tile `nt` of  out[row][n] = sum_k in[row][k] W[k][n]:  W as a [K/4][NPAD][4] operand image, `in` a
+// row-major panel; KT contraction tiles of 16 starting at kt0.  All operand reads go out before the first MFMA.
+template <int KT, int NPAD>
+__device__ __forceinline__ f32x4 m2_tile(const float* __restrict__ Wimg, const int nt, const float* __restrict__ Pin,
+                                         const int ld, const int kt0, const int ln, const int lk, f32x4 acc) {
+  float4 a[KT], b[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    a[t] = *reinterpret_cast<const float4*>(Wimg + ((((kt0 + t) * 4 + lk) * NPAD + nt * 16 + ln) << 2));
+    b[t] = *reinterpret_cast<const float4*>(Pin + ln * ld + (kt0 + t) * 16 + 4 * lk);
+  }
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b[t].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, b[t].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, b[t].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b[t].w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+__device__ __forceinline__ float4 f4(const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int H = M2::H, L = M2::L, K = M2::K, D = M2::D, L2 = M2::L2, K2 = M2::K2;
+  constexpr int Q = 4, H2f = 2 * H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lk = lane >> 4;
+  const int B = a.B, nP = (B + kPanel - 1) / kPanel;
+  const int bid = blockIdx.x;
+  // producers (quarters 1..3) take the LOWER block ids: a consumer can then never keep its producers off the chip
+  const int q = bid < nP * (Q - 1) ? 1 + bid / nP : 0;
+  const int pnl = bid < nP * (Q - 1) ? bid % nP : bid - nP * (Q - 1);
+  const int r0 = pnl * kPanel;
+  const int nrow = min(kPanel, B - r0);
+  const bool lead = q == 0;
+  if (a.span && tid == 0) a.span[2 * bid] = wall_clock64();
+#define M2_SPAN_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
+  const unsigned spin_limit = *a.err_word ? 0u : (1u << 19);       // bounded spins (see mega.hpp)
+  float* const img = sm + M2::IMG;
+  float *P_h1 = sm + M2::P_h1, *P_y = sm + M2::P_y, *P_hg = sm + M2::P_hg, *P_pp = sm + M2::P_pp, *P_qp = sm + M2::P_qp;
+  float *P_z = sm + M2::P_z, *P_sp = sm + M2::P_sp, *P_hd = sm + M2::P_hd, *P_eps = sm + M2::P_eps, *P_u = sm + M2::P_u;
+  float *P_lg = sm + M2::P_lg, *nllp = sm + M2::nll, *rsum = sm + M2::rsum, *red = sm + M2::red, *dred = sm + M2::dred;
+  float* P_dhd = sm + M2::P_dhd;
+  GMVAE_STAMP(0);
+
+  // ======================================================================= FL: first layer over this quarter's columns
+  // (the staging of mega_fwd_bwd's specialised instance: 49 bursts of 4 weight rows per tensor in two sub-chunks)
+  float flt[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    constexpr int KQ = M2::fl_kq, kq4 = KQ / 4;
+    float* const Wst = sm;
+    float* const A_x = sm + M2::fl_A;
+    const int k0 = q * KQ;
+    const unsigned epoch_fl = *a.epoch_word;
+    const unsigned long long step = a.step_dev[0];
+    constexpr int qer = L / 4, qur = (K + 3) / 4, qe = kPanel * qer, qu = kPanel * qur;
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    unsigned xw[2];
+    const int row_ = lane >> 4, piece = lane & 15;
+    const int src = row_ * 64 + ((piece ^ ((row_ & 1) << 2)) << 2);
+    auto burst = [&](const int first, const int b, const int per) {
+      const int t = b / per, idx = first + b % per;
+      __builtin_amdgcn_global_load_lds((t ? a.w0b : a.w0a) + (long long)k0 * H + (idx << 8) + src, Wst + t * KQ * H + (idx << 8), 16, 0, 0);
+    };
+#pragma unroll
+    for (int j = 0; j < 6; ++j) burst(0, wave + 8 * j, 24);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {               // always two loads per thread (clamped): uniform vmcnt accounting
+      const int i = min(tid + it * kMT, kPanel * kq4 - 1);
+      const int row = i / kq4, k4 = (i - row * kq4) * 4;
+      const unsigned wv = *reinterpret_cast<const unsigned*>(a.x + (long long)min(r0 + row, B - 1) * D + k0 + k4);
+      xw[it] = row < nrow ? wv : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) burst(24, min(wave + 8 * j, 49), 25);
+    if (tid < qe + qu) {                           // this panel's rows of the Philox streams (= gmvae_noise_fill's)
+      const bool is_u = tid >= qe;
+      const int li = is_u ? tid - qe : tid;
+      const int qpr = is_u ? qur : qer;
+      const int row = li / qpr, quad = li - row * qpr;
+      noise_vals(a.row0 + (unsigned long long)(r0 + row), (unsigned)quad, is_u, a.seed, step, nz);
+    }
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                      // the first half and the x bytes are in
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = tid + it * kMT;
+      if (i < kPanel * kq4) {
+        const int row = i / kq4, k4 = (i - row * kq4) * 4;
+        const unsigned w = xw[it];
+        float2* const dst = reinterpret_cast<float2*>(A_x + row * kFlLda + k4);
+        dst[0] = make_float2((float)(w & 0xff), (float)((w >> 8) & 0xff));
+        dst[1] = make_float2((float)((w >> 16) & 0xff), (float)(w >> 24));
+      }
+    }
+    __syncthreads();
+    const int tl = wave & 3;
+    const int swz = ((tl * 16 + ln) ^ ((lk & 1) << 4)) - (tl * 16 + ln);
+    const float* const Wt = (wave < 4 ? Wst : Wst + KQ * H) + swz;
+    acc = tile_ksteps<1, kFlLda>(A_x, Wt, H, 1, tl, 0, 24, 24, lane, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    acc = tile_ksteps<1, kFlLda>(A_x, Wt, H, 1, tl, 24, 49, 49, lane, acc);
+    constexpr int ngr = kPanel * H2f;
+    {
+      unsigned long long* xo = a.xfl + ((long long)pnl * 4 + q) * ngr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        __hip_atomic_store(xo + (lk * 4 + r) * H2f + wave * 16 + ln, ((unsigned long long)epoch_fl << 32) | __float_as_uint(acc[r]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                               // the staging area is dead: the operand image may land on it
+    dma_copy_m(img, a.img2f, M2::imgF, wave, lane);
+    if (tid < qe) {
+      st4(P_eps + tid * 4, make_float4(nz[0], nz[1], nz[2], nz[3]));
+    } else if (tid < qe + qu) {
+      const int li = tid - qe, row = li / qur, k0u = (li - row * qur) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (k0u + j < K) P_u[row * 16 + k0u + j] = nz[j];
+    }
+    if (bid == (int)gridDim.x - 1 && tid == 0) a.step_dev[1] = step;       // the copy finalize_adam reads
+    {
+      const unsigned long long* xp = a.xfl + (long long)pnl * 4 * ngr + (lk * 4) * H2f + wave * 16 + ln;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        unsigned long long gv[2][4];
+        unsigned spins = 0;
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int pq = 0; pq < 2; ++pq) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              gv[pq][r] = __hip_atomic_load(xp + (long long)(2 * half + pq) * ngr + r * H2f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok = ok && (unsigned)(gv[pq][r] >> 32) == epoch_fl;
+            }
+          }
+          if (__all(ok)) break;
+          if (++spins > spin_limit) {
+            if (lane == 0) atomicExch(a.err_word, 1u);
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) gv[pq][r] = 0x7fc00000ull;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          flt[r] += __uint_as_float((unsigned)gv[0][r]);
+          flt[r] += __uint_as_float((unsigned)gv[1][r]);
+        }
+      }
+    }
+  }
+  // ---- decoder operands of this wave's column tiles, straight into registers (used ~10 stages from here)
+  // local tile lt = wave, wave + 8 of this workgroup's part; global tile t = 4 lt + q
+  const int ntq = (M2::NT - q + 3) >> 2;           // 13 tiles for quarter 0, 12 for the others
+  const bool two = wave + 8 < ntq;                 // (wave-uniform) this wave has a second tile
+  float4 wf[2][4], wb[2][4], bias4[2];
+  unsigned xb[2] = {0u, 0u};
+  {
+    const float* const dfq = a.dimg2 + M2::dF + q * M2::dFq;
+    const float* const dbq = a.dimg2 + M2::dB + q * M2::dBq;
+    const float* const bq = a.dimg2 + M2::dbias + q * M2::dbq;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      if (it == 0 || two) {
+        const int lt = wave + 8 * it;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) wf[it][kt] = ld4(dfq + (((kt * 4 + lk) * M2::DC + lt * 16 + ln) << 2));
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) wb[it][ht] = ld4(dbq + (((lt * 4 + lk) * 64 + ht * 16 + ln) << 2));
+        bias4[it] = ld4(bq + lt * 16 + 4 * lk);
+        const int c0 = (4 * lt + q) * 16;
+        xb[it] = *reinterpret_cast<const unsigned*>(a.x + (long long)min(r0 + ln, B - 1) * D + c0 + 4 * lk);
+      }
+    }
+  }
+  // vmcnt retires in order: everything OLDER than these 10 (20) register loads -- the whole operand image -- has landed
+  // once at most that many are outstanding; the loads themselves stay in flight across the next stages.
+  if (two) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  __syncthreads();
+  {                                                // bias + ReLU straight from the (row-major oriented) accumulator
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = lk * 4 + r, col = wave * 16 + ln;
+      if (col < H) {
+        const float h = fmaxf(flt[r] + img[M2::b_y0 + col], 0.f);
+        P_h1[row * M2::ld128 + col] = h;
+        if (lead && row < nrow) a.hy1[(long long)(r0 + row) * H + col] = h;
+      } else {
+        P_h1[row * M2::ld128 + col] = flt[r];
+      }
+    }
+  }
+  __syncthreads();
+  GMVAE_STAMP(1);
+  // ======================================================================= F: forward chain
+  // S1 logits: one 16-output tile, contraction 64 split over waves 0..3
+  if (wave < 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = m2_tile<1, 16>(img + M2::Wy1f, 0, P_h1, M2::ld128, wave, ln, lk, acc);
+    st4(red + wave * 320 + ln * M2::ldk + 4 * lk, f4(acc));
+  }
+  __syncthreads();
+  // S2 Gumbel-softmax + entropy: 16 lanes per row (scripts/gmvae.py:240,262-263)
+  if (tid < 256) {
+    const int row = tid >> 4, k = tid & 15;
+    const bool ok = row < nrow, kv = k < K;
+    float lg = -INFINITY, av = -INFINITY;
+    if (kv) {
+      lg = red[row * M2::ldk + k] + red[320 + row * M2::ldk + k] + red[640 + row * M2::ldk + k] + red[960 + row * M2::ldk + k] +
+           img[M2::b_y1 + k];
+      const float uu = ok ? P_u[row * 16 + k] : 0.5f;
+      av = (lg - flog(-flog(uu))) * a.invT;
+      P_lg[row * M2::ldk + k] = lg;
+    }
+    const float mx = row16_max(av), m2 = row16_max(lg);
+    const float se = row16_sum(kv ? fexp(av - mx) : 0.f), s2 = row16_sum(kv ? fexp(lg - m2) : 0.f);
+    const float lse = mx + flog(se), l2 = m2 + flog(s2);
+    float yv = 0.f, ne = 0.f;
+    if (kv) {
+      yv = fexp(av - lse);
+      const float lp = lg - l2;
+      ne = fexp(lp) * lp;
+      if (ok && lead) a.y[(long long)(r0 + row) * K2 + k] = yv;            // rows of pad4(K) floats
+    }
+    P_y[row * M2::ldk + k] = yv;                                            // columns K..15 are zero
+    ne = row16_sum(ne);
+    if (k == 0) { nllp[3 * kPanel + row] = ne; if (ok && lead) a.nent[r0 + row] = ne; }
+  }
+  __syncthreads();
+  GMVAE_STAMP(2);
+  // S3 prior head (8 tiles) and encoder_gmm hidden (4 tiles), contraction = y (one tile of 16)
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = m2_tile<1, 128>(img + M2::Wpf, wave, P_y, M2::ldk, 0, ln, lk, acc);
+    const int c0 = wave * 16 + 4 * lk;
+    const float4 bb = ld4(img + M2::b_p + c0);
+    st4(P_pp + ln * M2::ld128 + c0, make_float4(acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w));
+    if (wave < 4) {
+      f32x4 ac2 = {0.f, 0.f, 0.f, 0.f};
+      ac2 = m2_tile<1, 64>(img + M2::Wg0yf, wave, P_y, M2::ldk, 0, ln, lk, ac2);
+      const float4 gx = ld4(P_h1 + ln * M2::ld128 + H + c0), bg = ld4(img + M2::b_g0 + c0);
+      const float4 h = make_float4(fmaxf(ac2[0] + gx.x + bg.x, 0.f), fmaxf(ac2[1] + gx.y + bg.y, 0.f),
+                                   fmaxf(ac2[2] + gx.z + bg.z, 0.f), fmaxf(ac2[3] + gx.w + bg.w, 0.f));
+      st4(P_hg + ln * M2::ld64 + c0, h);
+      if (lead && ln < nrow) st4(a.hg1 + (long long)(r0 + ln) * H + c0, h);
+    }
+  }
+  __syncthreads();
+  // S4 q head: 8 tiles, contraction 64
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = m2_tile<4, 128>(img + M2::Wg1f, wave, P_hg, M2::ld64, 0, ln, lk, acc);
+    const int c0 = wave * 16 + 4 * lk;
+    const float4 bb = ld4(img + M2::b_g1 + c0);
+    st4(P_qp + ln * M2::ld128 + c0, make_float4(acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w));
+  }
+  __syncthreads();
+  GMVAE_STAMP(3);
+  // S5 z, log q, log p: 32 lanes per row; the panels are rewritten in place with the backward chain's inputs
+  // (P_qp = [sigmoid(raw_q) | sigma_q], P_pp = [t | sigma_p], P_sp = sigmoid(raw_p)): phase B needs no transcendental
+  {
+    const int row = tid >> 5, sub = tid & 31;
+    const bool ok = row < nrow;
+    float aq = 0.f, ap = 0.f;
+#pragma unroll
+    for (int l = sub; l < L; l += 32) {
+      float* const qr = P_qp + row * M2::ld128;
+      float* const pr = P_pp + row * M2::ld128;
+      const float mu = qr[l];
+      const float vq = qr[L + l] + a.c;
+      const float eq = fexp(-fabsf(vq));
+      const float rq = __builtin_amdgcn_rcpf(1.f + eq);
+      const float sg = fmaxf(fmaxf(vq, 0.f) - flog(rq), a.smin);
+      const float ee = ok ? P_eps[row * 64 + l] : 0.f;
+      const float zz = mu + sg * ee;
+      P_z[row * M2::ld64 + l] = zz;
+      if (ok && lead) a.z[(long long)(r0 + row) * L + l] = zz;
+      qr[l] = vq >= 0.f ? rq : eq * rq;
+      qr[L + l] = sg;
+      aq += -0.5f * ee * ee - 0.5f * kLog2Pi - flog(sg);     // (z - mu) / sigma IS eps
+      const float vp = pr[L + l] + a.c;                      // p(z|y): gmvae.py:258
+      const float ep = fexp(-fabsf(vp));
+      const float rp = __builtin_amdgcn_rcpf(1.f + ep);
+      const float sp = fmaxf(fmaxf(vp, 0.f) - flog(rp), a.smin);
+      const float t = (zz - pr[l]) * __builtin_amdgcn_rcpf(sp);
+      ap += -0.5f * t * t - 0.5f * kLog2Pi - flog(sp);
+      pr[l] = t;
+      pr[L + l] = sp;
+      P_sp[row * 64 + l] = vp >= 0.f ? rp : ep * rp;
+    }
+    aq = row32_sum(aq); ap = row32_sum(ap);
+    if (sub == 0) {
+      nllp[row] = aq; nllp[kPanel + row] = ap;
+      if (ok && lead) { a.logq[r0 + row] = aq; a.logp[r0 + row] = ap; }
+    }
+  }
+  __syncthreads();
+  // S6 decoder hidden: 4 tiles, contraction 64
+  if (wave < 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = m2_tile<4, 64>(img + M2::Wd0f, wave, P_z, M2::ld64, 0, ln, lk, acc);
+    const int c0 = wave * 16 + 4 * lk;
+    const float4 bb = ld4(img + M2::b_d0 + c0);
+    const float4 h = make_float4(fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f), fmaxf(acc[2] + bb.z, 0.f), fmaxf(acc[3] + bb.w, 0.f));
+    st4(P_hd + ln * M2::ld64 + c0, h);
+    if (lead && ln < nrow) st4(a.hd1 + (long long)(r0 + ln) * H + c0, h);
+  }
+  __syncthreads();                                 // the forward image is dead
+  GMVAE_STAMP(4);
+  if (lead) dma_copy_m(img, a.img2b, M2::imgB, wave, lane);       // the backward image lands while the decoder layer runs
+
+  // ======================================================================= D: decoder output layer, in registers
+  f32x4 dacc[4];
+#pragma unroll
+  for (int ht = 0; ht < 4; ++ht) dacc[ht] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float rs = 0.f;
+  {
+    float4 hb[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) hb[kt] = ld4(P_hd + ln * M2::ld64 + kt * 16 + 4 * lk);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int lt = wave + 8 * it;
+      if (lt < ntq) {                               // wave-uniform
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[it][kt].x, hb[kt].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[it][kt].y, hb[kt].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[it][kt].z, hb[kt].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[it][kt].w, hb[kt].w, acc, 0, 0, 0);
+        }
+        // lane = (row ln, columns c0 + 4 lk + r): Bernoulli term and g = sigmoid(lambda) - x, ONE exp, rcp and log each
+        const float bv[4] = {bias4[it].x, bias4[it].y, bias4[it].z, bias4[it].w};
+        const bool ok = ln < nrow;
+        float g[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float lam = acc[r] + bv[r] + a.gen_bias;
+          const float e = __expf(-fabsf(lam));
+          const float rcp = __builtin_amdgcn_rcpf(1.f + e);
+          const float sp = fmaxf(lam, 0.f) - __logf(rcp);
+          const float sgm = lam >= 0.f ? rcp : e * rcp;
+          const float x_ = ok ? (float)((xb[it] >> (8 * r)) & 0xffu) : 0.f;
+          rs += ok ? x_ * lam - sp : 0.f;
+          g[r] = ok ? sgm - x_ : 0.f;
+        }
+        if (ok) st4(a.g + (long long)(r0 + ln) * D + (4 * lt + q) * 16 + 4 * lk, make_float4(g[0], g[1], g[2], g[3]));
+        // dhd1 += g Wd1^T over this tile's 16 columns: the accumulator layout IS the B operand
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+          dacc[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[it][ht].x, g[0], dacc[ht], 0, 0, 0);
+          dacc[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[it][ht].y, g[1], dacc[ht], 0, 0, 0);
+          dacc[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[it][ht].z, g[2], dacc[ht], 0, 0, 0);
+          dacc[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[it][ht].w, g[3], dacc[ht], 0, 0, 0);
+        }
+      }
+    }
+  }
+  GMVAE_STAMP(5);
+  // per-wave partials -> LDS: dhd1 tiles as [ht][lk][row][4] (a linear float4 per thread in the reduction below)
+  rs += __shfl_xor(rs, 16, 64);
+  rs += __shfl_xor(rs, 32, 64);
+  if (lk == 0) rsum[wave * kPanel + ln] = rs;
+#pragma unroll
+  for (int ht = 0; ht < 4; ++ht) st4(dred + wave * 1024 + (((ht * 4 + lk) * 16 + ln) << 2), f4(dacc[ht]));
+  __syncthreads();
+  const unsigned epoch = *a.epoch_word;
+  constexpr int ngr = kPanel * H + kPanel;         // granules one producer publishes: dhd1 partials + row sums
+  // thread t < 256 owns dhd1[row = t & 15][4 (t >> 4) .. + 3]
+  float4 dsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float rsn = 0.f;
+  if (tid < 256) {
+#pragma unroll
+    for (int w = 0; w < kMW; ++w) {
+      const float4 o = ld4(dred + w * 1024 + 4 * tid);
+      dsum.x += o.x; dsum.y += o.y; dsum.z += o.z; dsum.w += o.w;
+    }
+  } else if (tid < 256 + kPanel) {
+#pragma unroll
+    for (int w = 0; w < kMW; ++w) rsn += rsum[w * kPanel + (tid - 256)];
+  }
+  const int orow = tid & 15, ocol = (tid >> 4) << 2;     // for tid < 256
+  if (!lead) {
+    // ------------------------------------------------------------- producer: publish the partials and leave
+    unsigned long long* xo = a.xchg + ((long long)pnl * (Q - 1) + (q - 1)) * ngr;
+    if (tid < 256) {
+      const float dv[4] = {dsum.x, dsum.y, dsum.z, dsum.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __hip_atomic_store(xo + orow * H + ocol + j, ((unsigned long long)epoch << 32) | __float_as_uint(dv[j]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    } else if (tid < 256 + kPanel) {
+      __hip_atomic_store(xo + kPanel * H + (tid - 256), ((unsigned long long)epoch << 32) | __float_as_uint(rsn), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    M2_SPAN_END();
+    return;
+  }
+  // ======================================================================= B: backward chain (quarter 0)
+  {
+    const unsigned long long* xi = a.xchg + (long long)pnl * (Q - 1) * ngr;
+    const bool wd = tid < 256, wn = tid >= 256 && tid < 256 + kPanel;
+    for (int pq = 0; pq < Q - 1; ++pq) {
+      const unsigned long long* xp = xi + (long long)pq * ngr;
+      unsigned long long v[5] = {0, 0, 0, 0, 0};
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+        if (wd) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = __hip_atomic_load(xp + orow * H + ocol + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (unsigned)(v[j] >> 32) == epoch;
+          }
+        }
+        if (wn) {
+          v[4] = __hip_atomic_load(xp + kPanel * H + (tid - 256), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (unsigned)(v[4] >> 32) == epoch;
+        }
+        if (__all(ok)) break;
+        if (++spins > spin_limit) {                          // the producer never ran; flag and go on
+          if (lane == 0) atomicExch(a.err_word, 1u);
+          v[0] = v[1] = v[2] = v[3] = v[4] = 0x7fc00000ull;  // NaN: the step's loss and gradients say so loudly
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      dsum.x += __uint_as_float((unsigned)v[0]); dsum.y += __uint_as_float((unsigned)v[1]);
+      dsum.z += __uint_as_float((unsigned)v[2]); dsum.w += __uint_as_float((unsigned)v[3]);
+      rsn += __uint_as_float((unsigned)v[4]);
+    }
+    if (wd) {                                      // masked top gradient (+ saved for dWd0)
+      const float4 hd = ld4(P_hd + orow * M2::ld64 + ocol);
+      const bool ok = orow < nrow;
+      const float4 d = make_float4((ok && hd.x > 0.f) ? dsum.x : 0.f, (ok && hd.y > 0.f) ? dsum.y : 0.f,
+                                   (ok && hd.z > 0.f) ? dsum.z : 0.f, (ok && hd.w > 0.f) ? dsum.w : 0.f);
+      st4(P_dhd + orow * M2::ld64 + ocol, d);
+      if (ok) st4(a.dhd1 + (long long)(r0 + orow) * H + ocol, d);
+    }
+    if (wn) {
+      const int row = tid - 256;
+      if (row < nrow) {
+        a.logpx[r0 + row] = rsn;
+        a.logw[r0 + row] = rsn + nllp[kPanel + row] - nllp[row] - nllp[3 * kPanel + row];
+      }
+    }
+  }
+  dma_wait();                                      // the backward image
+  __syncthreads();
+  GMVAE_STAMP(6);
+  float *P_dz = sm + M2::P_dz, *P_dqp = sm + M2::P_dqp, *P_dpp = sm + M2::P_dpp, *P_dhg = sm + M2::P_dhg, *P_dl = sm + M2::P_dl;
+  // B1 dz_dec = dhd1 * Wd0^T: 4 tiles, contraction 64
+  if (wave < 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = m2_tile<4, 64>(img + M2::Wd0b, wave, P_dhd, M2::ld64, 0, ln, lk, acc);
+    st4(P_dz + ln * M2::ld64 + wave * 16 + 4 * lk, f4(acc));
+  }
+  __syncthreads();
+  // B2 q / prior heads backward: 32 lanes per row; inputs prepared by S5
+  {
+    const int row = tid >> 5, sub = tid & 31;
+    const bool ok = row < nrow;
+#pragma unroll
+    for (int l = sub; l < L; l += 32) {
+      float dmu = 0.f, draw = 0.f, dmup = 0.f, drawp = 0.f;
+      if (ok) {
+        const float sg = P_qp[row * M2::ld128 + L + l];
+        const float sp = P_pp[row * M2::ld128 + L + l], t = P_pp[row * M2::ld128 + l];
+        const float isp = __builtin_amdgcn_rcpf(sp);
+        const float pterm = t * isp;                   // d(-log p)/dz
+        dmup = -pterm;
+        drawp = (sp > a.smin) ? (1.f - t * t) * isp * P_sp[row * 64 + l] : 0.f;
+        float* dp = a.dpp + (long long)(r0 + row) * L2;
+        dp[l] = dmup; dp[L + l] = drawp;
+        dmu = P_dz[row * M2::ld64 + l] + pterm;
+        const float dsg = dmu * P_eps[row * 64 + l] - __builtin_amdgcn_rcpf(sg);
+        draw = (sg > a.smin) ? dsg * P_qp[row * M2::ld128 + l] : 0.f;
+        float* dq = a.dqp + (long long)(r0 + row) * L2;
+        dq[l] = dmu; dq[L + l] = draw;
+      }
+      P_dqp[row * M2::ld128 + l] = dmu;
+      P_dqp[row * M2::ld128 + L + l] = draw;
+      P_dpp[row * M2::ld128 + l] = dmup;
+      P_dpp[row * M2::ld128 + L + l] = drawp;
+    }
+  }
+  __syncthreads();
+  // B3 dhg = (dqp * Wg1^T) [hg > 0]: 4 tiles, contraction 128 split in two over the wave halves
+  {
+    const int t = wave & 3, kh = wave >> 2;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = m2_tile<4, 64>(img + M2::Wg1b, t, P_dqp, M2::ld128, 4 * kh, ln, lk, acc);
+    if (kh) st4(red + t * 256 + ((lk * 16 + ln) << 2), f4(acc));
+    __syncthreads();
+    if (!kh) {
+      const float4 o = ld4(red + t * 256 + ((lk * 16 + ln) << 2));
+      const int c0 = t * 16 + 4 * lk;
+      const float4 hg = ld4(P_hg + ln * M2::ld64 + c0);
+      const bool ok = ln < nrow;
+      const float4 d = make_float4((ok && hg.x > 0.f) ? acc[0] + o.x : 0.f, (ok && hg.y > 0.f) ? acc[1] + o.y : 0.f,
+                                   (ok && hg.z > 0.f) ? acc[2] + o.z : 0.f, (ok && hg.w > 0.f) ? acc[3] + o.w : 0.f);
+      st4(P_dhg + ln * M2::ld64 + c0, d);
+      if (ok) st4(a.dhg1 + (long long)(r0 + ln) * H + c0, d);
+    }
+  }
+  __syncthreads();
+  // B4 dy = dhg * Wg0[D:]^T + dpp * Wp^T: one tile; the 4 + 8 contraction tiles are spread over the 8 waves
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (wave < 4) {
+      acc = m2_tile<1, 16>(img + M2::Wg0yb, 0, P_dhg, M2::ld64, wave, ln, lk, acc);
+      acc = m2_tile<1, 16>(img + M2::Wpb, 0, P_dpp, M2::ld128, 4 + wave, ln, lk, acc);
+    } else {
+      acc = m2_tile<1, 16>(img + M2::Wpb, 0, P_dpp, M2::ld128, wave - 4, ln, lk, acc);
+    }
+    st4(red + wave * 256 + ((lk * 16 + ln) << 2), f4(acc));
+  }
+  __syncthreads();
+  // B5 softmax backward + entropy gradient
+  if (tid < 256) {
+    const int row = tid >> 4, k = tid & 15;
+    const bool ok = row < nrow, kv = k < K && ok;
+    float dy = 0.f;
+#pragma unroll
+    for (int w = 0; w < kMW; ++w) dy += red[w * 256 + (((k >> 2) * 16 + row) << 2) + (k & 3)];
+    const float lg = kv ? P_lg[row * M2::ldk + k] : -INFINITY;
+    const float yv = kv ? P_y[row * M2::ldk + k] : 0.f;
+    const float m2 = row16_max(lg);
+    const float dot = row16_sum(kv ? yv * dy : 0.f);
+    const float s2 = row16_sum(kv ? fexp(lg - m2) : 0.f);
+    const float l2 = m2 + flog(s2);
+    const float ne = nllp[3 * kPanel + row];
+    float dl = 0.f;
+    if (kv) {
+      const float lp = lg - l2;
+      dl = yv * (dy - dot) * a.invT + fexp(lp) * (lp - ne);
+      a.dlogits[(long long)(r0 + row) * K2 + k] = dl;
+    }
+    P_dl[row * M2::ldk + k] = dl;
+  }
+  __syncthreads();
+  // B6 dhy1 = (dlogits * Wy1^T) [hy1 > 0]: 4 tiles, contraction = k (one tile)
+  if (wave < 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = m2_tile<1, 64>(img + M2::Wy1b, wave, P_dl, M2::ldk, 0, ln, lk, acc);
+    const int c0 = wave * 16 + 4 * lk;
+    const float4 hy = ld4(P_h1 + ln * M2::ld128 + c0);
+    if (ln < nrow)
+      st4(a.dhy1 + (long long)(r0 + ln) * H + c0,
+          make_float4(hy.x > 0.f ? acc[0] : 0.f, hy.y > 0.f ? acc[1] : 0.f, hy.z > 0.f ? acc[2] : 0.f, hy.w > 0.f ? acc[3] : 0.f));
+  }
+  GMVAE_STAMP(7);
+  M2_SPAN_END();
+#undef M2_SPAN_END
+}
+
+}  // namespace gmvae
