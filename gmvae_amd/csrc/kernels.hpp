@@ -636,14 +636,32 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
   }
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   const int nsl = slab_count(a.sx, i4, a.nslab);
-  for (int s0 = 0; s0 < nsl; s0 += 8) {
-    float4 o[8];
+  {
+    // up to 16 slabs go out in ONE batch (a second batch is a second memory round trip of the launch's critical path);
+    // summed in slab order whatever the batching, so the gradient bits do not depend on it
+    float4 o[16];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = *reinterpret_cast<const float4*>(a.slabs + (long long)min(s0 + j, nsl - 1) * a.P + i4);
+    for (int j = 0; j < 8; ++j) o[j] = *reinterpret_cast<const float4*>(a.slabs + (long long)min(j, nsl - 1) * a.P + i4);
+    const bool more = nsl > 8;
+    if (more) {
+#pragma unroll
+      for (int j = 8; j < 16; ++j) o[j] = *reinterpret_cast<const float4*>(a.slabs + (long long)min(j, nsl - 1) * a.P + i4);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float w = s0 + j < nsl ? 1.f : 0.f;
+      const float w = j < nsl ? 1.f : 0.f;
       g.x += w * o[j].x; g.y += w * o[j].y; g.z += w * o[j].z; g.w += w * o[j].w;
+    }
+    if (more) {
+#pragma unroll
+      for (int j = 8; j < 16; ++j) {
+        const float w = j < nsl ? 1.f : 0.f;
+        g.x += w * o[j].x; g.y += w * o[j].y; g.z += w * o[j].z; g.w += w * o[j].w;
+      }
+    }
+    for (int s = 16; s < nsl; ++s) {               // (NS_MAX is 16 today)
+      const float4 t = *reinterpret_cast<const float4*>(a.slabs + (long long)s * a.P + i4);
+      g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
     }
   }
   if (a.gmp_part && i4 >= a.gmp_off && i4 < a.gmp_off + a.gmp_len) {

@@ -130,6 +130,8 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   float *P_lg = sm + M2::P_lg, *nllp = sm + M2::nll, *rsum = sm + M2::rsum, *red = sm + M2::red, *dred = sm + M2::dred;
   float* P_dhd = sm + M2::P_dhd;
   GMVAE_STAMP(0);
+  // diagnostics (tools/handoff_clock.py, GMVAE_STAMPS=5): device wall clock around the two in-launch hand-offs
+#define M2_WC(i) if (a.dbg && a.fine == 5 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8 + (i)] = wall_clock64()
 
   // ======================================================================= FL: first layer over this quarter's columns
   // (the staging of mega_fwd_bwd's specialised instance: 49 bursts of 4 weight rows per tensor in two sub-chunks)
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
         __hip_atomic_store(xo + (lk * 4 + r) * H2f + wave * 16 + ln, ((unsigned long long)epoch_fl << 32) | __float_as_uint(acc[r]),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    M2_WC(5);
     __syncthreads();                               // the staging area is dead: the operand image may land on it
     dma_copy_m(img, a.img2f, M2::imgF, wave, lane);
     if (tid < qe) {
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       }
     }
   }
+  M2_WC(6);
   // ---- decoder operands of this wave's column tiles, straight into registers (used ~10 stages from here)
   // local tile lt = wave, wave + 8 of this workgroup's part; global tile t = 4 lt + q
   const int ntq = (M2::NT - q + 3) >> 2;           // 13 tiles for quarter 0, 12 for the others
@@ -460,6 +464,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
 #pragma unroll
   for (int ht = 0; ht < 4; ++ht) st4(dred + wave * 1024 + (((ht * 4 + lk) * 16 + ln) << 2), f4(dacc[ht]));
   __syncthreads();
+  M2_WC(0);
   const unsigned epoch = *a.epoch_word;
   constexpr int ngr = kPanel * H + kPanel;         // granules one producer publishes: dhd1 partials + row sums
   // thread t < 256 owns dhd1[row = t & 15][4 (t >> 4) .. + 3]
@@ -489,10 +494,12 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       __hip_atomic_store(xo + kPanel * H + (tid - 256), ((unsigned long long)epoch << 32) | __float_as_uint(rsn), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     }
+    M2_WC(1);
     M2_SPAN_END();
     return;
   }
   // ======================================================================= B: backward chain (quarter 0)
+  M2_WC(1);
   {
     const unsigned long long* xi = a.xchg + (long long)pnl * (Q - 1) * ngr;
     const bool wd = tid < 256, wn = tid >= 256 && tid < 256 + kPanel;
@@ -525,6 +532,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       dsum.z += __uint_as_float((unsigned)v[2]); dsum.w += __uint_as_float((unsigned)v[3]);
       rsn += __uint_as_float((unsigned)v[4]);
     }
+    M2_WC(2);
     if (wd) {                                      // masked top gradient (+ saved for dWd0)
       const float4 hd = ld4(P_hd + orow * M2::ld64 + ocol);
       const bool ok = orow < nrow;
@@ -541,8 +549,10 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       }
     }
   }
+  M2_WC(3);
   dma_wait();                                      // the backward image
   __syncthreads();
+  M2_WC(4);
   GMVAE_STAMP(6);
   float *P_dz = sm + M2::P_dz, *P_dqp = sm + M2::P_dqp, *P_dpp = sm + M2::P_dpp, *P_dhg = sm + M2::P_dhg, *P_dl = sm + M2::P_dl;
   // B1 dz_dec = dhd1 * Wd0^T: 4 tiles, contraction 64
