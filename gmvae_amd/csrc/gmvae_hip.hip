@@ -121,6 +121,7 @@ struct WS {
   float* hd[MAXH + 2];   // decoder activations [R, dim[i]]
   float *gx, *logits, *y, *nent, *pp, *qp, *z, *logq, *logp, *logpx, *logw, *rw, *resp, *g, *part;
   float *dbuf[3], *dz, *dqp, *dpp, *dy, *dlogits, *dqb, *slabs, *gmp_part;
+  float *pb, *dsum;        // S > 1: per-row IWAE partials [B][4]; sum over s of encoder_gmm's first-layer gradient [B][H]
   float *s1, *s4;          // split-K slabs of the fused schedule: [NSF][B][2H], [NSF][B][H]
   unsigned long long* stamps;   // diagnostic stamps of the chain kernels: [2][grid][16]
   unsigned long long* xchg;     // mega_fwd_bwd's in-launch hand-off granules: [panels][Q-1][16*H + 16]
@@ -267,6 +268,10 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
   }
   w.dz = take(R * Lz);
   w.dqp = take(R * 2 * Lz);
+  if (d.S > 1) {
+    w.pb = take(B * 4);
+    if (model == GMVAE_MODEL_GMVAE) w.dsum = take(B * maxh);
+  }
   {
     int ns = num_splits(R);
     if ((fused_ok(d, model) || mega_ok(d, model)) && dw_splits(d.B) > ns) ns = dw_splits(d.B);
@@ -1012,9 +1017,14 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   rowk(cx, "row_terms");
   float* tail = a.backward ? a.grads + L.P_pad : a.tail;
   const float* rwS = (S > 1 && a.backward) ? w.rw : nullptr;
+  if (S > 1) {
+    hipLaunchKernelGGL(iwae_rows, dim3((B + 3) / 4), dim3(256), 0, st, w.logw, w.logpx, w.logq, w.logp,
+                       a.backward ? w.rw : (float*)nullptr, w.pb, B, S);
+    rowk(cx, "iwae_rows");
+  }
   hipLaunchKernelGGL(loss_tail, dim3(1), dim3(1024), 0, st, w.logw, w.logpx, w.logq, w.logp,
-                     gm ? w.nent : (const float*)nullptr, (S > 1 && a.backward) ? w.rw : (float*)nullptr, tail, B, S,
-                     a.step_dev);
+                     gm ? w.nent : (const float*)nullptr, (float*)nullptr, tail, B, S, a.step_dev,
+                     S > 1 ? w.pb : (const float*)nullptr);
   rowk(cx, "loss_tail");
   if (a.z_out) hipMemcpyAsync(a.z_out, w.z, (size_t)R * Lz * 4, hipMemcpyDeviceToDevice, st);
   if (a.y_out && gm) hipMemcpyAsync(a.y_out, w.y, (size_t)R * K * 4, hipMemcpyDeviceToDevice, st);
@@ -1066,9 +1076,19 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       pb ^= 1;
     }
     {  // layer 0 of enc_gmm: input is concat(x, y) -- x rows need no gradient
+      // S > 1: the S samples of a batch row share their x, so dW[x part] = x^T (sum_s d_g0[b, s]): the gradient rows are
+      // summed over s first and the product runs over B rows instead of B*S (and on the bf16 matrix cores: the byte
+      // operand is then a plain row-major matrix).  Its bias gradient is the column sum of the same B rows.
+      const float* dg = dcur;
+      if (S > 1) {
+        hipLaunchKernelGGL(sum_over_s, dim3(grid_for((long long)B * G.dim[1], 256, 1 << 22)), dim3(256), 0, st, dcur,
+                           w.dsum, B, S, G.dim[1]);
+        rowk(cx, "sum_over_s");
+        dg = w.dsum;
+      }
       Group g;
       const float* Wy = P + G.w[0] + (uint64_t)D * G.dim[1];
-      g.add(p_tn(a.x, true, D, S, dcur, G.dim[1], D, G.dim[1], R, sl + G.w[0], sl + G.b[0], NS, PP, nullptr));
+      g.add(p_tn(a.x, true, D, 1, dg, G.dim[1], D, G.dim[1], B, sl + G.w[0], sl + G.b[0], NS, PP, nullptr));
       g.add(p_tn(w.y, false, K, 1, dcur, G.dim[1], K, G.dim[1], R, sl + G.w[0] + (uint64_t)D * G.dim[1], nullptr, NS,
                  PP, nullptr));
       Problem p = p_nt(dcur, G.dim[1], Wy, G.dim[1], R, K, G.dim[1], w.dy, K, nullptr, 0);

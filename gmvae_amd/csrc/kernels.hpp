@@ -354,6 +354,33 @@ __global__ void row_terms(const float* __restrict__ part, int nparts, const floa
   }
 }
 
+// IWAE groups (S > 1), one wavefront per batch row b: bound_b = logsumexp_s(log w) - log S, the normalised row weights
+// rw = softmax_s(log w) and the group's sums of the nll / kl terms -> pb[b] = (bound, sum_s -log p(x|z), sum_s (log q - log p)).
+// Fixed-order lane reductions: deterministic.  (loss_tail alone walked the S samples of a row in ONE thread: 111 us of
+// its single workgroup at B = 512, S = 50.)
+__global__ __launch_bounds__(256) void iwae_rows(const float* __restrict__ logw, const float* __restrict__ logpx,
+                                                 const float* __restrict__ logq, const float* __restrict__ logp,
+                                                 float* __restrict__ rw, float* __restrict__ pb, int B, int S) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const long long r0 = (long long)b * S;
+  float mx = -INFINITY;
+  for (int s = lane; s < S; s += 64) mx = fmaxf(mx, logw[r0 + s]);
+  mx = wave_max(mx);
+  float se = 0.f, nl = 0.f, kl = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    se += expf(logw[r0 + s] - mx);
+    nl -= logpx[r0 + s];
+    kl += logq[r0 + s] - logp[r0 + s];
+  }
+  se = wave_sum(se); nl = wave_sum(nl); kl = wave_sum(kl);
+  const float lse = mx + logf(se);
+  if (rw)
+    for (int s = lane; s < S; s += 64) rw[r0 + s] = expf(logw[r0 + s] - lse);
+  if (lane == 0) { pb[4 * b] = lse - logf((float)S); pb[4 * b + 1] = nl; pb[4 * b + 2] = kl; pb[4 * b + 3] = 0.f; }
+}
+
 // One workgroup: per-x IWAE bound logsumexp_s(log w) - log S, normalised row
 // weights rw = softmax_s(log w), and the tail sums
 // [sum_b loss_b, sum nll, sum kl, sum nent, B] (means over s inside a group).
@@ -361,10 +388,19 @@ __global__ void row_terms(const float* __restrict__ part, int nparts, const floa
 __global__ __launch_bounds__(1024) void loss_tail(const float* __restrict__ logw, const float* __restrict__ logpx,
                                                   const float* __restrict__ logq, const float* __restrict__ logp,
                                                   const float* __restrict__ nent, float* __restrict__ rw,
-                                                  float* __restrict__ tail, int B, int S, uint64_t* step_dev) {
+                                                  float* __restrict__ tail, int B, int S, uint64_t* step_dev,
+                                                  const float* __restrict__ pb = nullptr) {
   __shared__ float red[4][1024];
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   const float invS = 1.f / (float)S;
+  if (pb) {                                      // S > 1: the groups were reduced by iwae_rows
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+      a0 -= pb[4 * b];
+      a1 += pb[4 * b + 1] * invS;
+      a2 += pb[4 * b + 2] * invS;
+      a3 += nent ? nent[b] : 0.f;
+    }
+  } else
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     const long long r0 = (long long)b * S;
     float mx = -INFINITY;
