@@ -64,6 +64,8 @@ struct Problem {
   long long split_stride;  // floats between split-K slabs
   float* C;
   int xbf16;               // dW of a uint8 activation (A = x^T, k-major rows of bytes; B = dY fp32 rows): bf16 MFMA path
+  int split3;              // large-tile configuration: fp32 x fp32 products on the bf16 matrix cores (see split3 below):
+                           // 1 = six piece products, 2 = all nine
   float* colsum_out;       // bias gradient riding on a dW problem: column sums of operand b over the tile's k
                            // range, written by the tiles of the first tile row to colsum_out[split][n]
   const float* bias;
@@ -285,6 +287,97 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned short* p) {     // ro
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// ---- fp32 x fp32 products on the bf16 matrix cores ("split3", the 128x128x32 configuration) ----------------------
+// Both operands are written as hi + mid + lo, three bf16 pieces that reproduce the 24-bit significand EXACTLY
+// (truncation splits, exact residuals).  a*b = sum of nine piece products, each exact in fp32; the three smallest
+// (mid*lo, lo*mid, lo*lo <= 2^-23 |a b|, below the rounding of the fp32 product itself) are dropped by default, so a
+// k-step of 16 costs 6 v_mfma_f32_32x32x16_bf16 (192 cycles) instead of 8 v_mfma_f32_32x32x2_f32 (512 cycles), and
+// the accumulation stays fp32.  GMVAE_SPLIT3=9 keeps all nine (every product exact, 288 cycles).
+// LDS images follow the SOURCE orientation, so the staging stores stay 8-byte and coalesced: a k-contiguous operand
+// becomes [mn][kSplitPK] (fragments = plain 16-byte reads), an mn-contiguous one [k][kSplitPM] (fragments through
+// ds_read_b64_tr_b16).  Three planes (hi, mid, lo) of kSplitPlane elements per operand.
+constexpr int kSplitPK = 40;      // [128 mn][32 k + 8]: 80-byte rows, conflict-free 16-byte fragment reads
+constexpr int kSplitPM = 160;     // [32 k][128 mn + 32]: 320-byte rows, the 4 rows of a transposing read tile the banks
+constexpr int kSplitPlane = 128 * kSplitPK;
+static_assert(kSplitPlane == 32 * kSplitPM, "both image orientations use the same plane size");
+
+template <int LD>
+__device__ __forceinline__ bf16x8_t tr_frag_ld(const unsigned short* p) {
+  typedef __attribute__((address_space(3))) s16x4_t* lp;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p + 4 * LD));
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// 4 staged slots of this thread (fp32, 4 consecutive elements along the source's contiguous dimension) -> the three
+// bf16 planes of the operand image
+template <int NS>
+__device__ __forceinline__ void split_store(unsigned short* __restrict__ img, const bool mc, const int tid, const float4 (&r)[NS]) {
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int s = tid + i * kThreads;
+    int off;
+    if (!mc) off = ((s & 3) + 4 * (s >> 5)) * kSplitPK + (((s >> 2) & 7) << 2);       // (mn, 4 k)
+    else off = ((s & 3) + 4 * (s >> 7)) * kSplitPM + (((s >> 2) & 31) << 2);          // (k, 4 mn)
+    const float v[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+    unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned hb = __float_as_uint(v[j]) & 0xffff0000u;
+      const float r1 = v[j] - __uint_as_float(hb);
+      const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+      const float r2 = r1 - __uint_as_float(mb);
+      hi[j] = hb >> 16; mi[j] = mb >> 16; lo[j] = __float_as_uint(r2) >> 16;
+    }
+    *reinterpret_cast<uint2*>(img + off) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+    *reinterpret_cast<uint2*>(img + kSplitPlane + off) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+    *reinterpret_cast<uint2*>(img + 2 * kSplitPlane + off) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+  }
+}
+
+// one staged 32-deep round of a 64x64 wave tile: 2 k-steps of 16, 2 x 2 MFMA tiles, 6 (or 9) piece products each
+template <bool AMC, bool BMC>
+__device__ __forceinline__ void split_round(const unsigned short* __restrict__ Ai, const unsigned short* __restrict__ Bi,
+                                            const int wm0, const int wn0, const int lane, const bool nine,
+                                            f32x16 (&acc)[2][2]) {
+  const int khalf = lane >> 5, l31 = lane & 31;
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int fro = (8 * (g16 >> 1) + (i16 >> 2)) * kSplitPM + 16 * (g16 & 1) + 4 * (i16 & 3);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    bf16x8_t a[2][3], b[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        if (AMC) a[i][pl] = tr_frag_ld<kSplitPM>(Ai + pl * kSplitPlane + ks * 16 * kSplitPM + wm0 + i * 32 + fro);
+        else a[i][pl] = *reinterpret_cast<const bf16x8_t*>(Ai + pl * kSplitPlane + (wm0 + i * 32 + l31) * kSplitPK + ks * 16 + 8 * khalf);
+        if (BMC) b[i][pl] = tr_frag_ld<kSplitPM>(Bi + pl * kSplitPlane + ks * 16 * kSplitPM + wn0 + i * 32 + fro);
+        else b[i][pl] = *reinterpret_cast<const bf16x8_t*>(Bi + pl * kSplitPlane + (wn0 + i * 32 + l31) * kSplitPK + ks * 16 + 8 * khalf);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 c = acc[i][j];
+        if (nine) {                                // the three smallest piece products first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][1], c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+  }
+}
+
 template <class C>
 __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Launch L) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
@@ -363,7 +456,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
   float csum = 0.f;
   constexpr int CSG = kThreads / C::BN;          // k groups of the column-sum threads
   const int cs_n = tid % C::BN, cs_k = tid / C::BN;
-  bool did_bf16 = false;
+  bool did_bf16 = false, did_split = false;
   float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (C::BM == 64 && C::BN == 64 && C::BK == 64) {
     if (L.p[pi].xbf16) {
@@ -501,6 +594,38 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
     op_store<C::BN, kBK, C::LDB, C::NSB>(Bs_, b_mc, tid, rb);               \
   }
 
+    if constexpr (C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2) {
+      const int sp3 = L.p[pi].split3;
+      if (sp3) {                                  // (wave-uniform) this problem runs on the bf16 matrix cores
+        static_assert(6 * kSplitPlane * 2 <= C::LDS_FLOATS * 4, "split3 images must fit the kernel's LDS");
+        unsigned short* const Ai = reinterpret_cast<unsigned short*>(lds);
+        unsigned short* const Bi = Ai + 3 * kSplitPlane;
+        const bool nine = sp3 > 1;
+        __syncthreads();                          // LDS is free
+        GMVAE_GLOAD(0);
+#pragma unroll 1
+        for (int c = 0; c < NC; ++c) {
+          split_store<C::NSA>(Ai, a_mc, tid, ra);
+          split_store<C::NSB>(Bi, b_mc, tid, rb);
+          if (do_colsum) {                        // (operand b is mn-contiguous here: a dW problem) columns 4 ((tid >> 2) & 31)..
+#pragma unroll
+            for (int i = 0; i < C::NSB; ++i) { cs4.x += rb[i].x; cs4.y += rb[i].y; cs4.z += rb[i].z; cs4.w += rb[i].w; }
+          }
+          __syncthreads();
+          if (c + 1 < NC) GMVAE_GLOAD(c + 1);
+          if (a_mc) {
+            if (b_mc) split_round<true, true>(Ai, Bi, wm0, wn0, lane, nine, acc);
+            else split_round<true, false>(Ai, Bi, wm0, wn0, lane, nine, acc);
+          } else {
+            if (b_mc) split_round<false, true>(Ai, Bi, wm0, wn0, lane, nine, acc);
+            else split_round<false, false>(Ai, Bi, wm0, wn0, lane, nine, acc);
+          }
+          __syncthreads();
+        }
+        did_split = true;
+        continue;
+      }
+    }
     __syncthreads();          // LDS is free (first segment: trivially; second: previous loop finished)
     if (sgi == 0) GMVAE_GSTAMP(6);
     GMVAE_GLOAD(0);
@@ -559,14 +684,17 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
           Cs[row * C::LDC + wn0 + j * 32 + l31] = acc[i][j][r];
         }
     if (do_colsum) {
-      if (did_bf16) *reinterpret_cast<float4*>(lds + C::CST + 4 * tid) = cs4;     // (k rows tid>>4 + 16i, columns 4(tid&15)..)
+      if (did_bf16 || did_split) *reinterpret_cast<float4*>(lds + C::CST + 4 * tid) = cs4;     // (k rows tid>>4 + 16i, columns 4(tid&15)..)
       else lds[C::CST + tid] = csum;
     }
   }
   __syncthreads();
   if (do_colsum && tid < C::BN && n0 + tid < L.p[pi].N) {
     float v = 0.f;
-    if (did_bf16) {
+    if (did_split) {                               // column tid: the 8 threads 4 (tid >> 2) + a + 128 b staged its quad
+#pragma unroll
+      for (int g = 0; g < 8; ++g) v += lds[C::CST + 4 * (4 * (tid >> 2) + (g & 3) + 128 * (g >> 2)) + (tid & 3)];
+    } else if (did_bf16) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) v += lds[C::CST + 4 * ((tid >> 2) + 16 * g) + (tid & 3)];
     } else {

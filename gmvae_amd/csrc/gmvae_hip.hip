@@ -405,6 +405,12 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
     for (int s = 0; s < g.L.p[i].nseg; ++s) fl += 2.0 * g.L.p[i].M * g.L.p[i].N * g.L.p[i].seg[s].K;
   int tiles;
   if (cfg == 2) {
+    // the large-tile configuration can run fp32 x fp32 products as bf16 piece products (gemm.hpp split3).  OFF by
+    // default: measured 1.1-1.3x SLOWER than the fp32 MFMA path on the config-5 decoder GEMMs (profiles/round2_notes.md)
+    // -- at one workgroup per CU the per-round fp32 -> 3 x bf16 conversion is not overlapped with the MFMAs.
+    const char* sp = getenv("GMVAE_SPLIT3");
+    const int sp3 = sp ? (atoi(sp) == 9 ? 2 : (atoi(sp) ? 1 : 0)) : 0;
+    for (int i = 0; i < g.L.nprob; ++i) g.L.p[i].split3 = sp3;
     tiles = g.L.total_tiles = tile_up<CfgL>(g.L);
     hipLaunchKernelGGL(gemm_grouped<CfgL>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
   } else if (cfg == 3) {
@@ -590,7 +596,23 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
       if (pl.map_ok && ml.fl_ok) {
         fa.nmap = pl.nmap; fa.map_lo = pl.lo; fa.map_hi = pl.hi;
         fa.img[0] = w.img_m; fa.img[1] = w.dimg; fa.img[2] = w.img2f; fa.img[3] = w.img2b; fa.img[4] = w.dimg2;
-        for (int i = 0; i < pl.nmap; ++i) { fa.map[i] = pl.map[i]; fa.mbegin[i] = pl.map[i].begin; fa.mend[i] = pl.map[i].end; }
+        int n = 0;
+        for (int i = 0; i < pl.nmap; ++i) {
+          const ImgMap& mp = pl.map[i];
+          const int rows = mp.cols > 0 ? (mp.end - mp.begin) / mp.cols : 0;
+          if (mp.kind == 4 && !fa.quad_blocks && rows % 4 == 0 && !getenv("GMVAE_NO_QUAD")) {   // -> quad blocks (kernels.hpp)
+            fa.q_begin = mp.begin; fa.q_end = mp.end; fa.q_rows = rows; fa.q_cols = mp.cols; fa.q_base = mp.base; fa.q_ld = mp.ld;
+            fa.q_chunk = mp.chunk; fa.q_which = mp.which;
+            fa.quad_blocks = ((rows / 4) * mp.cols + 255) / 256;
+            continue;
+          }
+          if (fa.quad_blocks && !fa.q2_kind && mp.begin == fa.q_begin && mp.end == fa.q_end) {       // the same tensor's other image
+            fa.q2_kind = mp.kind; fa.q2_base = mp.base; fa.q2_ld = mp.ld; fa.q2_chunk = mp.chunk; fa.q2_which = mp.which;
+            continue;
+          }
+          fa.map[n] = mp; fa.mbegin[n] = mp.begin; fa.mend[n] = mp.end; ++n;
+        }
+        fa.nmap = n;
       }
     }
     if (a.next_x && a.next_pix && a.next_idx && a.step_dev && a.adam_p) {
@@ -599,7 +621,7 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
       const uint64_t quads = (uint64_t)B * (d.D >> 2);
       fa.bin_blocks = (int)((quads + (uint64_t)kBinQuadsPerThread * 256 - 1) / ((uint64_t)kBinQuadsPerThread * 256));
     }
-    hipLaunchKernelGGL(finalize_adam, dim3((unsigned)((PP / 4 + 255) / 256) + 1 + fa.bin_blocks), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL(finalize_adam, dim3((unsigned)((PP / 4 + 255) / 256) + 1 + fa.bin_blocks + fa.quad_blocks), dim3(256), 0, st, fa);
     rowk(cx, a.adam_p ? "finalize_adam" : "finalize_grads+loss_tail");
     return cx.err;
   }

@@ -493,6 +493,17 @@ __global__ void finalize_grads(const float* __restrict__ slabs, int nslab, long 
 // TF1 AdamOptimizer / ApplyAdam (scripts/runners.py:181-183):
 //   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; theta -= lr_t*m/(sqrt(v)+eps)
 // One launch over the whole flat buffer (multi-tensor by construction).
+// ONE statement of the update for every kernel that applies it (adam_tf, finalize_adam's two thread maps, adam_tf_img):
+// the roundings are pinned with explicit intrinsics, so the same inputs give the same bits whichever kernel ran
+// (the compiler contracts a*b+c differently from one kernel to the next otherwise).
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, const float g, const float gscale, const float lr_t,
+                                            const float omb1, const float omb2, const float eps) {
+  const float gj = __fmul_rn(g, gscale);
+  m = __fmaf_rn(__fsub_rn(gj, m), omb1, m);
+  v = __fmaf_rn(__fmaf_rn(gj, gj, -v), omb2, v);
+  p = __fsub_rn(p, __fdiv_rn(__fmul_rn(m, lr_t), __fadd_rn(__fsqrt_rn(v), eps)));
+}
+
 __global__ void adam_tf(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                         const float* __restrict__ g, long long P, float lr, float b1, float b2, float eps,
                         uint64_t t, const uint64_t* t_dev, float gscale, const float* gscale_dev,
@@ -513,22 +524,12 @@ __global__ void adam_tf(float* __restrict__ p, float* __restrict__ m, float* __r
     float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
     const float ga[4] = {gg.x, gg.y, gg.z, gg.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float gj = ga[j] * gscale;
-      ma[j] += (gj - ma[j]) * omb1;
-      va[j] += (gj * gj - va[j]) * omb2;
-      pa[j] -= ma[j] * lr_t / (sqrtf(va[j]) + eps);
-    }
+    for (int j = 0; j < 4; ++j) adam_update(pa[j], ma[j], va[j], ga[j], gscale, lr_t, omb1, omb2, eps);
     *reinterpret_cast<float4*>(p + i4) = make_float4(pa[0], pa[1], pa[2], pa[3]);
     *reinterpret_cast<float4*>(m + i4) = make_float4(ma[0], ma[1], ma[2], ma[3]);
     *reinterpret_cast<float4*>(v + i4) = make_float4(va[0], va[1], va[2], va[3]);
   } else {
-    for (long long i = i4; i < P; ++i) {
-      const float gj = g[i] * gscale;
-      m[i] += (gj - m[i]) * omb1;
-      v[i] += (gj * gj - v[i]) * omb2;
-      p[i] -= m[i] * lr_t / (sqrtf(v[i]) + eps);
-    }
+    for (long long i = i4; i < P; ++i) adam_update(p[i], m[i], v[i], g[i], gscale, lr_t, omb1, omb2, eps);
   }
 }
 
@@ -598,6 +599,14 @@ struct FinalArgs {
   const int32_t* bin_idx;
   unsigned char* bin_x;
   unsigned long long bin_rows_src, bin_seed, bin_row0;   // bin_row0: global index of the batch's first row (Philox counter)
+  // "quad" blocks (after the binarisation blocks): ONE tensor [q_rows][q_cols] whose image stores the 4 values of 4
+  // consecutive ROWS together (img_dst kind 4: the decoder output layer's forward operand) is updated by threads that
+  // own (4 rows, 1 column) each: their parameter / moment / slab accesses are 4-byte but lane-contiguous, and the
+  // image leaves as ONE 16-byte store per thread, consecutive lanes writing consecutive units.  (Scattered from the
+  // row-major thread map these were 4-byte stores 16 bytes apart whose units four different waves completed:
+  // +2.8 us on this launch, profiles/round2_notes.md.)  The regular blocks skip that tensor's range.
+  int quad_blocks, q_begin, q_end, q_rows, q_cols, q_base, q_ld, q_chunk, q_which;
+  int q2_kind, q2_base, q2_ld, q2_chunk, q2_which;   // a second image of the same tensor (kind 0 = none): 4-byte stores
   SlabX sx;
   int mbegin[kMaxImgMap], mend[kMaxImgMap];   // the ranges again, adjacent: one round of scalar loads finds the entry
   ImgMap map[kMaxImgMap];
@@ -605,7 +614,51 @@ struct FinalArgs {
 __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
 #define GMVAE_FIN_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
   if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x] = wall_clock64();
-  const int nb = gridDim.x - 1 - a.bin_blocks;
+  const int nb = gridDim.x - 1 - a.bin_blocks - a.quad_blocks;
+  if ((int)blockIdx.x > nb + a.bin_blocks) {     // quad blocks: (4 rows, 1 column) of the q_ tensor per thread
+    const int gq = ((int)blockIdx.x - nb - a.bin_blocks - 1) * 256 + (int)threadIdx.x;
+    if (gq >= (a.q_rows >> 2) * a.q_cols) { GMVAE_FIN_END(); return; }
+    const int rq = gq / a.q_cols, c = gq - rq * a.q_cols;
+    const long long i0 = (long long)a.q_begin + (long long)(4 * rq) * a.q_cols + c;
+    float pa[4], ma[4], va[4], ga[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { pa[j] = a.p[i0 + (long long)j * a.q_cols]; ma[j] = a.m[i0 + (long long)j * a.q_cols]; va[j] = a.v[i0 + (long long)j * a.q_cols]; }
+    const int nsl = slab_count(a.sx, (long long)a.q_begin, a.nslab);
+    for (int s0 = 0; s0 < nsl; s0 += 8) {          // 8 slabs x 4 rows of loads in flight; summed in slab order (the regular blocks' order)
+      float o[8][4];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[k][j] = a.slabs[(long long)min(s0 + k, nsl - 1) * a.P + i0 + (long long)j * a.q_cols];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float w = s0 + k < nsl ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ga[j] += w * o[k][j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a.grads[i0 + (long long)j * a.q_cols] = ga[j];
+    if (a.err_word && *a.err_word) { GMVAE_FIN_END(); return; }
+    const unsigned long long t = (a.step_dev ? a.step_dev[1] : 0ull) + 1ull;
+    const float lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, (double)t)) / (1.0 - pow((double)a.b1, (double)t)));
+    const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, gs = 1.f / a.count;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      adam_update(pa[j], ma[j], va[j], ga[j], gs, lr_t, omb1, omb2, a.eps);
+      a.p[i0 + (long long)j * a.q_cols] = pa[j];
+      a.m[i0 + (long long)j * a.q_cols] = ma[j];
+      a.v[i0 + (long long)j * a.q_cols] = va[j];
+    }
+    *reinterpret_cast<float4*>(a.img[a.q_which] + img_dst(4, a.q_base, a.q_ld, a.q_chunk, 4 * rq, c)) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    if (a.q2_kind) {
+      float* const im2 = a.img[a.q2_which];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) im2[img_dst(a.q2_kind, a.q2_base, a.q2_ld, a.q2_chunk, 4 * rq + j, c)] = pa[j];
+    }
+    GMVAE_FIN_END();
+    return;
+  }
   if ((int)blockIdx.x > nb) {                    // the next step's batch: its uniforms are keyed by that step's index
     const unsigned long long step = a.step_dev[1] + 1ull;
     const uint64_t q0 = ((uint64_t)((int)blockIdx.x - nb - 1) * kBinQuadsPerThread) * 256 + threadIdx.x;
@@ -661,7 +714,7 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
   unsigned e_magic = a.map[k0].magic;
   asm volatile("" ::"s"(hit), "s"(e_begin), "s"(e_end), "s"(e_cols), "s"(e_kind), "s"(e_base), "s"(e_ld), "s"(e_chunk),
                "s"(e_which), "s"(e_magic));
-  if (i4 >= a.P) { GMVAE_FIN_END(); return; }
+  if (i4 >= a.P || (a.quad_blocks && i4 >= a.q_begin && i4 < a.q_end)) { GMVAE_FIN_END(); return; }
   // every load of the block goes out before the first wait: parameters and moments, then up to 8 slabs at once
   // (the launch is one wave of blocks: its length is its chain of dependent memory round trips)
   float4 pp = make_float4(0.f, 0.f, 0.f, 0.f), mm = pp, vv = pp;
@@ -718,12 +771,7 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
   float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
   const float ga[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float gj = ga[j] * gs;
-    ma[j] += (gj - ma[j]) * omb1;
-    va[j] += (gj * gj - va[j]) * omb2;
-    pa[j] -= ma[j] * lr_t / (sqrtf(va[j]) + a.eps);
-  }
+  for (int j = 0; j < 4; ++j) adam_update(pa[j], ma[j], va[j], ga[j], gs, lr_t, omb1, omb2, a.eps);
   *reinterpret_cast<float4*>(a.p + i4) = make_float4(pa[0], pa[1], pa[2], pa[3]);
   *reinterpret_cast<float4*>(a.m + i4) = make_float4(ma[0], ma[1], ma[2], ma[3]);
   *reinterpret_cast<float4*>(a.v + i4) = make_float4(va[0], va[1], va[2], va[3]);
@@ -781,12 +829,7 @@ __global__ __launch_bounds__(256) void adam_tf_img(float* __restrict__ p, float*
   float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
   const float ga[4] = {gg.x, gg.y, gg.z, gg.w};
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float gj = ga[j] * gscale;
-    ma[j] += (gj - ma[j]) * omb1;
-    va[j] += (gj * gj - va[j]) * omb2;
-    pa[j] -= ma[j] * lr_t / (sqrtf(va[j]) + eps);
-  }
+  for (int j = 0; j < 4; ++j) adam_update(pa[j], ma[j], va[j], ga[j], gscale, lr_t, omb1, omb2, eps);
   *reinterpret_cast<float4*>(p + i4) = make_float4(pa[0], pa[1], pa[2], pa[3]);
   *reinterpret_cast<float4*>(m + i4) = make_float4(ma[0], ma[1], ma[2], ma[3]);
   *reinterpret_cast<float4*>(v + i4) = make_float4(va[0], va[1], va[2], va[3]);

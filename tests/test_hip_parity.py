@@ -78,6 +78,36 @@ def test_gemm_tn_splitk_bias_row(H, cfg, M, N, K, u8, ns):
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=3e-5 * math.sqrt(K))
 
 
+@pytest.mark.parametrize("terms", ["6", "9"])
+@pytest.mark.parametrize("trans,M,N,K", [(0, 300, 200, 150), (1, 257, 130, 96), (2, 140, 256, 1000)])
+def test_gemm_split3_bf16_piece_products(H, monkeypatch, terms, trans, M, N, K):
+    """The opt-in split3 path of the 128x128 configuration (GMVAE_SPLIT3): fp32 x fp32 as exact bf16 piece products
+    (6 of the 9, or all 9) with fp32 accumulation, for every operand orientation (NN / NT / TN with the bias-gradient
+    column sums): fp32-GEMM accuracy against fp64."""
+    monkeypatch.setenv("GMVAE_SPLIT3", terms)
+    L = _L()
+    rng = np.random.default_rng(M + N + K)
+    if trans == 0:
+        A, W = rng.normal(size=(M, K)).astype(np.float32), rng.normal(size=(K, N)).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64)
+        shape = (M, N)
+    elif trans == 1:
+        A, W = rng.normal(size=(M, K)).astype(np.float32), rng.normal(size=(N, K)).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64).T
+        shape = (M, N)
+    else:
+        A, W = rng.normal(size=(K, M)).astype(np.float32), rng.normal(size=(K, N)).astype(np.float32)
+        ref = np.concatenate([A.astype(np.float64).T @ W, W.astype(np.float64).sum(0, keepdims=True)], 0)
+        shape = (2, M + 1, N)
+    Ad, Wd = H.dev(A), H.dev(W)
+    Cd = torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
+    L.check(L.lib.gmvae_gemm_test(L.ptr(Ad), 0, L.ptr(Wd), L.ptr(Wd) if trans == 2 else None, L.ptr(Cd), M, N, K, trans, 0, 2,
+                                  2 if trans == 2 else 1, L.current_stream()), "gemm_test")
+    got = Cd.cpu().numpy().astype(np.float64)
+    got = got.sum(axis=0) if trans == 2 else got
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=3e-5 * math.sqrt(K))
+
+
 # ------------------------------------------------------------ full step
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
 
