@@ -103,6 +103,15 @@ __device__ __forceinline__ f32x4 m2_tile(const float* __restrict__ Wimg, const i
   }
   return acc;
 }
+// Hand-off granules: one naturally aligned 8-byte {epoch, value} word written by ONE write-through (sc1) store: the
+// data is its own flag (mega.hpp; cdna_hip_programming.md G16 recipe R2).  Measured (tools/handoff_clock.py): a granule
+// is readable on another CU 2.3-2.8 us after its store, whatever the reader does; a second, L2-resident copy written
+// with an ordinary store (readable sooner by a same-XCD reader in isolation) bought nothing once both stores were issued,
+// so there is one copy.  What does matter is the readers' side: all of a lane's granule loads in flight together
+// (branch-free sweeps) and a wave's granules contiguous in memory.
+__device__ __forceinline__ void granule_publish(unsigned long long* p, const unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ float4 f4(const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -124,6 +133,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   if (a.span && tid == 0) a.span[2 * bid] = wall_clock64();
 #define M2_SPAN_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
   const unsigned spin_limit = *a.err_word ? 0u : (1u << 19);       // bounded spins (see mega.hpp)
+  const unsigned epoch0 = *a.epoch_word;           // tag of this step's hand-offs
   float* const img = sm + M2::IMG;
   float *P_h1 = sm + M2::P_h1, *P_y = sm + M2::P_y, *P_hg = sm + M2::P_hg, *P_pp = sm + M2::P_pp, *P_qp = sm + M2::P_qp;
   float *P_z = sm + M2::P_z, *P_sp = sm + M2::P_sp, *P_hd = sm + M2::P_hd, *P_eps = sm + M2::P_eps, *P_u = sm + M2::P_u;
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   float* P_dhd = sm + M2::P_dhd;
   GMVAE_STAMP(0);
   // diagnostics (tools/handoff_clock.py, GMVAE_STAMPS=5): device wall clock around the two in-launch hand-offs
-#define M2_WC(i) if (a.dbg && a.fine == 5 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8 + (i)] = wall_clock64()
+#define M2_WC(i) if (a.dbg && a.fine >= 5 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8 + (i)] = wall_clock64()
 
   // ======================================================================= FL: first layer over this quarter's columns
   // (the staging of mega_fwd_bwd's specialised instance: 49 bursts of 4 weight rows per tensor in two sub-chunks)
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
     float* const Wst = sm;
     float* const A_x = sm + M2::fl_A;
     const int k0 = q * KQ;
-    const unsigned epoch_fl = *a.epoch_word;
+    const unsigned epoch_fl = epoch0;
     const unsigned long long step = a.step_dev[0];
     constexpr int qer = L / 4, qur = (K + 3) / 4, qe = kPanel * qer, qu = kPanel * qur;
     float nz[4] = {0.f, 0.f, 0.f, 0.f};
@@ -196,8 +206,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       unsigned long long* xo = a.xfl + ((long long)pnl * 4 + q) * ngr;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        __hip_atomic_store(xo + (lk * 4 + r) * H2f + wave * 16 + ln, ((unsigned long long)epoch_fl << 32) | __float_as_uint(acc[r]),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        granule_publish(xo + (wave * 4 + r) * 64 + lane, ((unsigned long long)epoch_fl << 32) | __float_as_uint(acc[r]));
     }
     M2_WC(5);
     __syncthreads();                               // the staging area is dead: the operand image may land on it
@@ -212,38 +221,45 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
     }
     if (bid == (int)gridDim.x - 1 && tid == 0) a.step_dev[1] = step;       // the copy finalize_adam reads
     {
-      const unsigned long long* xp = a.xfl + (long long)pnl * 4 * ngr + (lk * 4) * H2f + wave * 16 + ln;
+      // the four quarters' partials (this workgroup's own included): all 16 granules of a lane in ONE sweep, re-read
+      // until every tag carries this step's epoch; summed in quarter order, so every workgroup of the panel gets the same bits
+      const unsigned long long* const xp0 = a.xfl + (long long)pnl * 4 * ngr + (wave * 4) * 64 + lane;
+      unsigned long long gv[4][4];
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned long long* const xp = xp0;
+        // all 16 loads are in flight before the first tag is looked at (left to itself the compiler waits for the
+        // first twelve before it issues the rest: a second memory round trip per sweep)
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        unsigned long long gv[2][4];
-        unsigned spins = 0;
-        for (;;) {
-          bool ok = true;
+        for (int pq = 0; pq < 4; ++pq)
 #pragma unroll
-          for (int pq = 0; pq < 2; ++pq) {
+          for (int r = 0; r < 4; ++r)
+            gv[pq][r] = __hip_atomic_load(xp + (long long)pq * ngr + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_sched_barrier(0);
+        bool ok = true;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              gv[pq][r] = __hip_atomic_load(xp + (long long)(2 * half + pq) * ngr + r * H2f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              ok = ok && (unsigned)(gv[pq][r] >> 32) == epoch_fl;
-            }
-          }
-          if (__all(ok)) break;
-          if (++spins > spin_limit) {
-            if (lane == 0) atomicExch(a.err_word, 1u);
+        for (int pq = 0; pq < 4; ++pq)
 #pragma unroll
-            for (int pq = 0; pq < 2; ++pq)
+          for (int r = 0; r < 4; ++r) ok = ok && (unsigned)(gv[pq][r] >> 32) == epoch_fl;
+        if (__all(ok)) break;
+        if (++spins > spin_limit) {
+          if (lane == 0) atomicExch(a.err_word, 1u);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) gv[pq][r] = 0x7fc00000ull;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(2);
+          for (int pq = 0; pq < 4; ++pq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gv[pq][r] = 0x7fc00000ull;
+          break;
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          flt[r] += __uint_as_float((unsigned)gv[0][r]);
-          flt[r] += __uint_as_float((unsigned)gv[1][r]);
-        }
+        __builtin_amdgcn_s_sleep(2);
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        flt[r] = __uint_as_float((unsigned)gv[0][r]);
+        flt[r] += __uint_as_float((unsigned)gv[1][r]);
+        flt[r] += __uint_as_float((unsigned)gv[2][r]);
+        flt[r] += __uint_as_float((unsigned)gv[3][r]);
+      }
+      if (a.dbg && a.fine >= 5 && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + 14] = spins;
     }
   }
   M2_WC(6);
@@ -413,6 +429,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
 #pragma unroll
   for (int ht = 0; ht < 4; ++ht) dacc[ht] = f32x4{0.f, 0.f, 0.f, 0.f};
   float rs = 0.f;
+  float4 gkeep[2];
   {
     float4 hb[4];
 #pragma unroll
@@ -444,7 +461,10 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
           rs += ok ? x_ * lam - sp : 0.f;
           g[r] = ok ? sgm - x_ : 0.f;
         }
-        if (ok) st4(a.g + (long long)(r0 + ln) * D + (4 * lt + q) * 16 + 4 * lk, make_float4(g[0], g[1], g[2], g[3]));
+        // quarter 0 keeps g in registers until its hand-off polls are through: vmcnt retires in order, so a poll's
+        // data would otherwise wait for the acknowledgement of these stores (measured: 1.8 us per sweep)
+        if (lead) gkeep[it] = make_float4(g[0], g[1], g[2], g[3]);
+        else if (ok) st4(a.g + (long long)(r0 + ln) * D + (4 * lt + q) * 16 + 4 * lk, make_float4(g[0], g[1], g[2], g[3]));
         // dhd1 += g Wd1^T over this tile's 16 columns: the accumulator layout IS the B operand
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
@@ -465,9 +485,11 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   for (int ht = 0; ht < 4; ++ht) st4(dred + wave * 1024 + (((ht * 4 + lk) * 16 + ln) << 2), f4(dacc[ht]));
   __syncthreads();
   M2_WC(0);
-  const unsigned epoch = *a.epoch_word;
+  const unsigned epoch = epoch0;                   // (read at the kernel's start: the word changes between launches only)
   constexpr int ngr = kPanel * H + kPanel;         // granules one producer publishes: dhd1 partials + row sums
-  // thread t < 256 owns dhd1[row = t & 15][4 (t >> 4) .. + 3]
+  // thread t < 256 owns dhd1[row = t & 15][4 (t >> 4) .. + 3]; its four granules are [4 t, 4 t + 4) of a producer's
+  // block, so that a wave's hand-off stores and polls are contiguous in memory (granules laid out [row][col] cost every
+  // lane a cache line of its own: 1.8 us per sweep, tools/handoff_clock.py)
   float4 dsum = make_float4(0.f, 0.f, 0.f, 0.f);
   float rsn = 0.f;
   if (tid < 256) {
@@ -488,11 +510,9 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       const float dv[4] = {dsum.x, dsum.y, dsum.z, dsum.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        __hip_atomic_store(xo + orow * H + ocol + j, ((unsigned long long)epoch << 32) | __float_as_uint(dv[j]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        granule_publish(xo + 4 * tid + j, ((unsigned long long)epoch << 32) | __float_as_uint(dv[j]));
     } else if (tid < 256 + kPanel) {
-      __hip_atomic_store(xo + kPanel * H + (tid - 256), ((unsigned long long)epoch << 32) | __float_as_uint(rsn), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      granule_publish(xo + kPanel * H + (tid - 256), ((unsigned long long)epoch << 32) | __float_as_uint(rsn));
     }
     M2_WC(1);
     M2_SPAN_END();
@@ -503,34 +523,53 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   {
     const unsigned long long* xi = a.xchg + (long long)pnl * (Q - 1) * ngr;
     const bool wd = tid < 256, wn = tid >= 256 && tid < 256 + kPanel;
-    for (int pq = 0; pq < Q - 1; ++pq) {
-      const unsigned long long* xp = xi + (long long)pq * ngr;
-      unsigned long long v[5] = {0, 0, 0, 0, 0};
-      unsigned spins = 0;
-      for (;;) {
-        bool ok = true;
-        if (wd) {
+    // all three producers' granules are requested in ONE sweep (a sweep is a memory round trip)
+    unsigned long long v[Q - 1][5];
+    unsigned spins = 0;
+    // Branch-free sweep: every lane requests four granules of each producer (its own four dhd1 granules, or -- lanes
+    // 256..271 -- its row-sum granule; the others re-read granule 0 and ignore it), so that all twelve loads of a lane
+    // are in flight together.  (With the loads under `if (owner)` the compiler waited inside every branch: up to six
+    // dependent memory round trips per sweep, 1.3-1.8 us.)
+    const int gbase = wd ? 4 * tid : (wn ? kPanel * H + (tid - 256) : 0);
+    const int gstep = wd ? 1 : 0;
+    for (;;) {
+      const unsigned long long* const xs = xi + gbase;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[j] = __hip_atomic_load(xp + orow * H + ocol + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = ok && (unsigned)(v[j] >> 32) == epoch;
-          }
-        }
-        if (wn) {
-          v[4] = __hip_atomic_load(xp + kPanel * H + (tid - 256), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = ok && (unsigned)(v[4] >> 32) == epoch;
-        }
-        if (__all(ok)) break;
-        if (++spins > spin_limit) {                          // the producer never ran; flag and go on
-          if (lane == 0) atomicExch(a.err_word, 1u);
-          v[0] = v[1] = v[2] = v[3] = v[4] = 0x7fc00000ull;  // NaN: the step's loss and gradients say so loudly
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
+      for (int pq = 0; pq < Q - 1; ++pq)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          v[pq][j] = __hip_atomic_load(xs + (long long)pq * ngr + j * gstep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_sched_barrier(0);
+      bool ok = true;
+#pragma unroll
+      for (int pq = 0; pq < Q - 1; ++pq) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ok = ok && ((unsigned)(v[pq][j] >> 32) == epoch || !(wd || wn));
+        v[pq][4] = v[pq][0];                       // (the row-sum lanes' granule)
       }
-      dsum.x += __uint_as_float((unsigned)v[0]); dsum.y += __uint_as_float((unsigned)v[1]);
-      dsum.z += __uint_as_float((unsigned)v[2]); dsum.w += __uint_as_float((unsigned)v[3]);
-      rsn += __uint_as_float((unsigned)v[4]);
+      if (__all(ok)) break;
+      if (++spins > spin_limit) {                          // a producer never ran; flag and go on
+        if (lane == 0) atomicExch(a.err_word, 1u);
+#pragma unroll
+        for (int pq = 0; pq < Q - 1; ++pq)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) v[pq][j] = 0x7fc00000ull;   // NaN: the step's loss and gradients say so loudly
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+#pragma unroll
+    for (int pq = 0; pq < Q - 1; ++pq) {
+      if (wd) {
+        dsum.x += __uint_as_float((unsigned)v[pq][0]); dsum.y += __uint_as_float((unsigned)v[pq][1]);
+        dsum.z += __uint_as_float((unsigned)v[pq][2]); dsum.w += __uint_as_float((unsigned)v[pq][3]);
+      }
+      if (wn) rsn += __uint_as_float((unsigned)v[pq][4]);
+    }
+    if (a.dbg && a.fine >= 5 && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + 15] = spins;       // sweeps that failed
+    if (ln < nrow) {                               // now the decoder tiles' g = sigmoid(lambda) - x
+      st4(a.g + (long long)(r0 + ln) * D + (4 * wave + q) * 16 + 4 * lk, gkeep[0]);
+      if (two) st4(a.g + (long long)(r0 + ln) * D + (4 * (wave + 8) + q) * 16 + 4 * lk, gkeep[1]);
     }
     M2_WC(2);
     if (wd) {                                      // masked top gradient (+ saved for dWd0)

@@ -32,3 +32,5 @@ print("  consumer D end relative to the panel's last producer publish", us(cons[
 print("  consumer: D end -> poll start", us(cons[:, 1] - cons[:, 0]), "| poll", us(cons[:, 2] - cons[:, 1]), "| dhd written", us(cons[:, 3] - cons[:, 2]),
       "| dma_wait + barrier", us(cons[:, 4] - cons[:, 3]))
 print("  panel's last producer publish -> consumer polls done", us(cons[:, 2] - lastp))
+print("  failed sweeps (thread 0): D hand-off, consumers: median", np.median(raw[nP * 3:, 15]), "max", raw[nP * 3:, 15].max(),
+      "| first-layer exchange, all workgroups: median", np.median(raw[:, 14]), "max", raw[:, 14].max())
