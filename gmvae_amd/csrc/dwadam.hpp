@@ -1,0 +1,242 @@
+// dw_adam: every weight (and bias) gradient of the single-hidden-layer step AND the TF-Adam update in ONE launch.
+//
+// Replaces, on the single-device train-graph path, the grouped split-K weight-gradient launch + finalize_adam
+// (scripts/runners.py:181-183: opt.compute_gradients' MatMul-gradient nodes and apply_gradients): a workgroup owns a
+// [64 fan-in rows] x [16 fan-out columns] tile of ONE weight tensor for the WHOLE batch contraction, so no partial
+// slabs exist: the tile's gradient is complete in the workgroup and the optimizer runs in the epilogue (13 MB of slab
+// writes + reads, a kernel boundary and finalize_adam's cold start disappear).
+//
+//   dW[m][n] = sum_b A[b][m] dY[b][n]       A = the layer's input rows (uint8 batch or fp32 activations), dY = the
+//                                           pre-activation gradients mega2_fwd_bwd left; both k-major (row = batch index)
+//
+// Operands go global -> registers -> matrix core, no LDS staging: with v_mfma_f32_16x16x4_f32's k index = 4 consecutive
+// batch rows (lane / 16), a lane's A operand for FOUR m-tiles is one 16-byte load A[b][m0 + 4 (lane % 16) .. +3]
+// (tile t takes the rows m = m0 + 4 i + t: a strided tile), its B operand one 4-byte load dY[b][n0 + lane % 16].
+// The 8 waves split the batch rows; partial tiles meet in LDS in a fixed order (bit-reproducible).  A lane ends with
+// the 4 x 1 block dW[mb .. mb+3][n]: exactly one 16-byte unit of the row-interleaved operand images mega2_fwd_bwd reads
+// (kernels.hpp img_dst kinds 2 / 4), so the update leaves through coalesced stores.  The bias gradient (column sums
+// of dY) rides on the tiles of the first tile row.
+#pragma once
+#include <type_traits>
+
+#include "chain.hpp"
+
+namespace gmvae {
+
+constexpr int kDwMaxT = 10;
+constexpr int kDwThreads = 512, kDwWaves = 8;
+
+struct DwTensor {
+  const void* A;               // [B][lda] uint8 or fp32
+  const float* dY;             // [B][ldy]
+  int lda, ldy, M, N, a_u8;
+  int w_off, b_off;            // flat parameter offsets of W [M][N] and of the bias [N] (b_off < 0: none)
+  int tiles_n, tile_begin;
+  int k1, base1, ld1, chunk1, which1;    // operand images of W (kind 0 = none): kernels.hpp img_dst
+  int k2, base2, ld2, chunk2, which2;
+  int bk, bbase, bchunk, bwhich;         // image of the bias (bk < 0: none; kinds 0 / 6)
+};
+
+struct DwArgs {
+  int ntens, total_tiles, B, pad_;
+  unsigned long long* dbg;     // diagnostic: [block][8] wall-clock stamps (tools/dwstamps.py) or null
+  float ln_b1, ln_b2;          // ln(beta1), ln(beta2) rounded from double
+  int tile_begin[kDwMaxT];
+  DwTensor t[kDwMaxT];
+  FinalArgs fa;                // p, m, v, grads, Adam constants, loss-tail inputs, counters, images, binarisation blocks
+};
+
+// One wave's share [b_lo, b_hi) of the batch contraction for a 64 x 16 tile.  ALL of its operand loads (32 k-steps at
+// B = 1024) are in flight before the first MFMA, and they are BRANCH-FREE (clamped address, value selected
+// afterwards): a load under `if (in range)` makes the compiler wait inside the branch, one memory round trip per load
+// (measured: 13 us for this loop).  The uint8 operand stays packed (one register per k-step) until its MFMAs.
+template <bool U8, class Mid>
+__device__ __forceinline__ void dw_contract(const void* __restrict__ Ap, const float* __restrict__ dY, const int lda, const int ldy,
+                                            const int M, const int N, const int m0, const int n0, const int b_lo, const int b_hi,
+                                            const int ln, const int lk, f32x4 (&acc)[4], float& cs, Mid mid) {
+  const int ma = m0 + 4 * ln;                    // this lane's 4 fan-in rows (one per strided tile)
+  const bool a_ok = ma < M, n_ok = n0 + ln < N;  // (M is a multiple of 4 or the source rows are padded to one)
+  const int mac = min(ma, ((M + 3) & ~3) - 4), nc = min(n0 + ln, N - 1);
+  const unsigned char* const A8 = static_cast<const unsigned char*>(Ap);
+  const float* const A32 = static_cast<const float*>(Ap);
+  constexpr int KB = 32;
+  typedef typename std::conditional<U8, unsigned, float4>::type AT;
+  auto mfma4 = [&](const AT& avs, const float bq) {
+    float4 aq;
+    if constexpr (U8) {
+      const unsigned w = avs;
+      aq = make_float4((float)(w & 0xff), (float)((w >> 8) & 0xff), (float)((w >> 16) & 0xff), (float)(w >> 24));
+    } else {
+      aq = avs;
+    }
+    if (!a_ok) aq = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq, acc[3], 0, 0, 0);
+    cs += bq;
+  };
+  if (b_hi - b_lo == 4 * KB) {
+    // the usual case (B a multiple of 256): one batch, rows b_lo + 4 s + lk, no clamps -- the addresses are a base plus
+    // compile-time multiples of the row stride (the clamped form spent ~6 VALU instructions per load, 64 loads per lane)
+    AT av[KB];
+    float bvv[KB];
+    const unsigned char* const a8 = A8 + (long long)(b_lo + lk) * lda + mac;
+    const float* const a32 = A32 + (long long)(b_lo + lk) * lda + mac;
+    const float* const dy = dY + (long long)(b_lo + lk) * ldy + nc;
+#pragma unroll
+    for (int s = 0; s < KB; ++s) {
+      if constexpr (U8) av[s] = *reinterpret_cast<const unsigned*>(a8 + (long long)(4 * s) * lda);
+      else av[s] = *reinterpret_cast<const float4*>(a32 + (long long)(4 * s) * lda);
+      bvv[s] = dy[(long long)(4 * s) * ldy];
+    }
+#pragma unroll
+    for (int s = 0; s < KB; ++s) mfma4(av[s], n_ok ? bvv[s] : 0.f);
+    return;
+  }
+  for (int b0 = b_lo; b0 < b_hi; b0 += 4 * KB) {
+    AT av[KB];
+    float bvv[KB];
+#pragma unroll
+    for (int s = 0; s < KB; ++s) {
+      const int bc = min(b0 + 4 * s + lk, b_hi - 1);
+      if constexpr (U8) av[s] = *reinterpret_cast<const unsigned*>(A8 + (long long)bc * lda + mac);
+      else av[s] = *reinterpret_cast<const float4*>(A32 + (long long)bc * lda + mac);
+      bvv[s] = dY[(long long)bc * ldy + nc];
+    }
+#pragma unroll
+    for (int s = 0; s < KB; ++s) mfma4(av[s], (b0 + 4 * s + lk < b_hi && n_ok) ? bvv[s] : 0.f);   // a zero B operand also voids the clamped A values
+  }
+}
+
+__global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[kDwWaves * 64 * 16];     // [wave][mt * 4 + r][lane]
+  __shared__ float redcs[kDwWaves * 64];
+  const FinalArgs& fa = a.fa;
+  if (fa.span && threadIdx.x == 0) fa.span[2 * blockIdx.x] = wall_clock64();
+#define DW_END() if (fa.span && threadIdx.x == 0) fa.span[2 * blockIdx.x + 1] = wall_clock64()
+  const int bid = blockIdx.x;
+#define DW_ST(i) if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + (i)] = wall_clock64()
+  DW_ST(0);
+  if (bid >= a.total_tiles) {                    // the loss tail + counters, then the next batch's binarisation blocks
+    if (bid == a.total_tiles) finalize_tail_block(fa, reinterpret_cast<float(*)[256]>(red));
+    else finalize_bin_block(fa, bid - a.total_tiles - 1);
+    DW_END();
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lk = lane >> 4;
+  int ti = 0;
+#pragma unroll
+  for (int i = 1; i < kDwMaxT; ++i)
+    if (i < a.ntens && bid >= a.tile_begin[i]) ti = i;
+  const DwTensor& T = a.t[ti];
+  const int M = T.M, N = T.N, lda = T.lda, ldy = T.ldy, B = a.B;
+  const int tl = bid - T.tile_begin, tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
+  const int m0 = tm * 64, n0 = tn * 16;
+  // ---- epilogue owners (threads 0..255): unit (lane slot l, r) = dW[mb .. mb+3][n]
+  const int el = tid & 63, er = (tid >> 6) & 3;
+  const int mb = m0 + 16 * (el >> 4) + 4 * er, en = n0 + (el & 15);
+  const bool eown = tid < 256 && mb < M && en < N;
+  const bool bown = tm == 0 && T.b_off >= 0 && tid >= 256 && tid < 272 && n0 + (tid - 256) < N;
+  float pp[4] = {0.f, 0.f, 0.f, 0.f}, pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f};
+  float bp = 0.f, bm = 0.f, bv = 0.f, lr_t = 0.f;
+  bool poisoned = false;
+  // what the epilogue needs besides the tile: requested / computed AFTER the contraction (vmcnt retires in order: issued
+  // before it, these loads and the ~100 instructions of alpha_t would sit in front of the first MFMA: +1.5 us measured)
+  auto prologue = [&]() {
+    if (eown) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int mm = min(mb + j, M - 1);
+        const long long i = (long long)T.w_off + (long long)mm * N + en;
+        pp[j] = fa.p[i]; pm[j] = fa.m[i]; pv[j] = fa.v[i];
+      }
+    }
+    if (bown) { const int i = T.b_off + n0 + tid - 256; bp = fa.p[i]; bm = fa.m[i]; bv = fa.v[i]; }
+    // alpha_t = lr sqrt(1 - b2^t) / (1 - b1^t) with 1 - b^t = -expm1(t ln b) (no cancellation; ln b comes in from the
+    // host in double precision): agrees with the double-precision form of adam_tf to ~3e-7 relative, at a fraction of
+    // the two fp64 pow() calls every thread would otherwise make
+    poisoned = fa.err_word && *fa.err_word;
+    const float tf = (float)((fa.step_dev ? fa.step_dev[1] : 0ull) + 1ull);
+    lr_t = fa.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1));
+  };
+  const float omb1 = 1.f - fa.b1, omb2 = 1.f - fa.b2, gs = 1.f / fa.count;
+  DW_ST(1);
+  // ---- the contraction: this wave's share of the batch rows, 4 rows (k) per MFMA step
+  const int rows_w = (((B + kDwWaves - 1) / kDwWaves) + 3) & ~3;
+  const int b_lo = wave * rows_w, b_hi = min(B, b_lo + rows_w);
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float cs = 0.f;
+  if (T.a_u8) dw_contract<true>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+  else dw_contract<false>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+  prologue();                                    // its loads fly while the partial tiles go to LDS and the waves meet
+  DW_ST(2);
+  // ---- the waves' partial tiles meet in LDS (fixed order: bit-reproducible)
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * t + r) * 64 + lane] = acc[t][r];     // lane-contiguous: conflict-free
+  redcs[wave * 64 + lane] = cs;
+  __syncthreads();
+  DW_ST(3);
+  if (eown) {
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < kDwWaves; ++w)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) g[t] += red[(w * 16 + 4 * t + er) * 64 + el];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (mb + j < M) {
+        const long long i = (long long)T.w_off + (long long)(mb + j) * N + en;
+        fa.grads[i] = g[j];
+        if (!poisoned) {
+          adam_update(pp[j], pm[j], pv[j], g[j], gs, lr_t, omb1, omb2, fa.eps);
+          fa.p[i] = pp[j]; fa.m[i] = pm[j]; fa.v[i] = pv[j];
+        }
+      }
+    }
+    if (!poisoned) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (mb + j >= M) pp[j] = 0.f;              // rows past the tensor: the image's padding stays zero
+      if (T.k1 == 2 || T.k1 == 4)
+        *reinterpret_cast<float4*>(fa.img[T.which1] + img_dst(T.k1, T.base1, T.ld1, T.chunk1, mb, en)) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+      else if (T.k1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (mb + j < M) fa.img[T.which1][img_dst(T.k1, T.base1, T.ld1, T.chunk1, mb + j, en)] = pp[j];
+      }
+      if (T.k2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (mb + j < M) fa.img[T.which2][img_dst(T.k2, T.base2, T.ld2, T.chunk2, mb + j, en)] = pp[j];
+      }
+    }
+  }
+  if (bown) {                                    // bias gradient = column sum of dY over the batch
+    const int c = tid - 256;
+    float g = 0.f;
+#pragma unroll
+    for (int w = 0; w < kDwWaves; ++w)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g += redcs[w * 64 + k * 16 + c];
+    const int i = T.b_off + n0 + c;
+    fa.grads[i] = g;
+    if (!poisoned) {
+      adam_update(bp, bm, bv, g, gs, lr_t, omb1, omb2, fa.eps);
+      fa.p[i] = bp; fa.m[i] = bm; fa.v[i] = bv;
+      if (T.bk >= 0) fa.img[T.bwhich][img_dst(T.bk, T.bbase, 0, T.bchunk, 0, n0 + c)] = bp;
+    }
+  }
+  DW_ST(4);
+  if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)ti;
+  DW_END();
+#undef DW_END
+#undef DW_ST
+}
+
+}  // namespace gmvae

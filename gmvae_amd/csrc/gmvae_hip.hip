@@ -8,6 +8,7 @@
 // enqueued on the caller's stream and is hipGraph-capturable.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include <stdio.h>
 #include <dlfcn.h>
 #include <stdlib.h>
@@ -19,6 +20,7 @@
 #include "chain.hpp"
 #include "mega.hpp"
 #include "mega2.hpp"
+#include "dwadam.hpp"
 
 using namespace gmvae;
 
@@ -695,6 +697,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     ax.nblocks = ax.noise_blocks + nt;
     launch_group(cx, g, "fwd_x_first_layers_splitk+aux", env_cfg("GMVAE_P1_CFG", 0), getenv("GMVAE_STAMPS") ? w.gstamps : nullptr);
   }
+  bool m2_ran = false;
   {  // the whole per-row forward + backward in one launch
     MegaArgs c;
     memset(&c, 0, sizeof(c));
@@ -731,6 +734,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       mattr = true;
     }
     const bool m2 = fl && mega2_ok(d, model) && w.img2f;
+    m2_ran = m2;
     if (m2) {
       c.img2f = w.img2f; c.img2b = w.img2b; c.dimg2 = w.dimg2;
       static bool m2attr = false;
@@ -750,6 +754,71 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     if (m2) { cx.mark("mega2_fwd_bwd", 2.0 * B * macs); goto mega_done; }
     cx.mark("mega_fwd_bwd", 2.0 * B * macs);
   mega_done:;
+  }
+  // Single device, steady state of a train graph at the specialised sizes: weight gradients AND the optimizer in one
+  // launch (dwadam.hpp) -- no split-K slabs, no finalize_adam.
+  if (m2_ran && gm && a.adam_p && a.adam_p == a.params && a.step_dev && !getenv("GMVAE_NO_DWADAM")) {
+    ImgPlan pl;
+    plan_images(d, model, L, w, ml, a.params, pl);
+    if (pl.map_ok) {
+      static DwArgs da;                          // (host-side scratch: 3 KB, too large for comfort on the stack next to Launch)
+      memset(&da, 0, sizeof(da));
+      da.B = B;
+      da.dbg = getenv("GMVAE_STAMPS") ? w.gstamps + 3 * 2048 * 8 : nullptr;
+      da.ln_b1 = (float)log((double)a.beta1); da.ln_b2 = (float)log((double)a.beta2);
+      auto add = [&](const void* A, bool u8, int lda, const float* dY, int ldy, int M, int N, uint64_t w_off, long long b_off) {
+        DwTensor& T = da.t[da.ntens];
+        T.A = A; T.a_u8 = u8 ? 1 : 0; T.lda = lda; T.dY = dY; T.ldy = ldy; T.M = M; T.N = N; T.w_off = (int)w_off; T.b_off = (int)b_off;
+        T.tiles_n = (N + 15) / 16; T.tile_begin = da.total_tiles; da.tile_begin[da.ntens] = da.total_tiles;
+        da.total_tiles += ((M + 63) / 64) * T.tiles_n;
+        T.bk = -1;
+        for (int i = 0; i < pl.nmap; ++i) {      // where the optimizer also has to leave the updated values (mega2's operand images)
+          const ImgMap& mp = pl.map[i];
+          if (mp.begin == (int)w_off && mp.end == (int)(w_off + (uint64_t)M * N)) {
+            if (!T.k1) { T.k1 = mp.kind; T.base1 = mp.base; T.ld1 = mp.ld; T.chunk1 = mp.chunk; T.which1 = mp.which; }
+            else { T.k2 = mp.kind; T.base2 = mp.base; T.ld2 = mp.ld; T.chunk2 = mp.chunk; T.which2 = mp.which; }
+          }
+          if (b_off >= 0 && mp.begin == (int)b_off && mp.end == (int)(b_off + N)) { T.bk = mp.kind; T.bbase = mp.base; T.bchunk = mp.chunk; T.bwhich = mp.which; }
+        }
+        // the row-interleaved image (kinds 2 / 4) first: it leaves as one 16-byte store per thread
+        if (T.k2 == 2 || T.k2 == 4) {
+          const int k = T.k1, b_ = T.base1, l_ = T.ld1, c_ = T.chunk1, w_ = T.which1;
+          T.k1 = T.k2; T.base1 = T.base2; T.ld1 = T.ld2; T.chunk1 = T.chunk2; T.which1 = T.which2;
+          T.k2 = k; T.base2 = b_; T.ld2 = l_; T.chunk2 = c_; T.which2 = w_;
+        }
+        da.ntens++;
+      };
+      const int K4 = (int)pad4(K);
+      add(a.x, true, D, w.dbuf[2], H, D, H, E.w[0], (long long)E.b[0]);                                   // dWy0 (+ dby0)
+      add(a.x, true, D, w.dbuf[1], H, D, H, G.w[0], (long long)G.b[0]);                                   // dWg0[x] (+ dbg0)
+      add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1]);                                  // dWd1 (+ dbd1)
+      add(w.y, false, K4, w.dbuf[1], H, K, H, G.w[0] + (uint64_t)D * H, -1);                              // dWg0[y]
+      add(w.he[1], false, H, w.dlogits, K4, H, K, E.w[1], (long long)E.b[1]);                             // dWy1
+      add(w.y, false, K4, w.dpp, 2 * Lz, K, 2 * Lz, L.prior.w[0], (long long)L.prior.b[0]);               // dWp
+      add(w.hg[1], false, H, w.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1]);                        // dWg1
+      add(w.z, false, Lz, w.dbuf[0], H, Lz, H, Dn.w[0], (long long)Dn.b[0]);                              // dWd0
+      FinalArgs& fa = da.fa;
+      fa.P = (long long)L.P_pad; fa.grads = a.grads; fa.p = a.adam_p; fa.m = a.adam_m; fa.v = a.adam_v;
+      fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = 1; fa.count = (float)B;
+      fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = w.nent;
+      fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev); fa.tail_log = a.tail_log;
+      fa.epoch_word = w.sync; fa.err_word = w.sync + 1;
+      fa.img[0] = w.img_m; fa.img[1] = w.dimg; fa.img[2] = w.img2f; fa.img[3] = w.img2b; fa.img[4] = w.dimg2;
+      fa.span = (a.want_spans && w.spans) ? w.spans + 2048 * 2 : nullptr;
+      if (a.next_x && a.next_pix && a.next_idx) {
+        fa.bin_pix = a.next_pix; fa.bin_idx = a.next_idx; fa.bin_x = a.next_x; fa.bin_rows_src = a.next_rows_src;
+        fa.bin_B = B; fa.bin_D = D; fa.bin_seed = a.bin_seed; fa.bin_row0 = d.row0;
+        const uint64_t quads = (uint64_t)B * (D >> 2);
+        fa.bin_blocks = (int)((quads + (uint64_t)kBinQuadsPerThread * 256 - 1) / ((uint64_t)kBinQuadsPerThread * 256));
+      }
+      // the padding words of the flat gradient buffer are never written by the tiles: the buffer is all-reduced / read whole
+      hipLaunchKernelGGL(dw_adam, dim3(da.total_tiles + 1 + fa.bin_blocks), dim3(kDwThreads), 0, st, da);
+      cx.check();
+      double fl_ = 0;
+      for (int i = 0; i < da.ntens; ++i) fl_ += 2.0 * da.t[i].M * da.t[i].N * B;
+      cx.mark("dw_adam", fl_);
+      return cx.err;
+    }
   }
   // Every weight gradient in one grouped launch.  The uint8-activation problems (bf16 matrix cores) take NS splits
   // of two 64-row staging rounds; the fp32 problems take 2 NS splits of ONE round each: their workgroups, the
@@ -1502,7 +1571,7 @@ int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, floa
       double us = 0.0;
       if (!strncmp(pr->name[i], "mega", 4)) us = span_of(hsp, 2, 1);
       else if (!strncmp(pr->name[i], "bwd_dw_all", 10)) us = span_of(hsp + nsp, 8, 4);
-      else if (!strncmp(pr->name[i], "finalize_adam", 13)) us = span_of(hsp + 2048 * 2, 2, 1);
+      else if (!strncmp(pr->name[i], "finalize_adam", 13) || !strncmp(pr->name[i], "dw_adam", 7)) us = span_of(hsp + 2048 * 2, 2, 1);
       acc[i] += us;
     }
   }

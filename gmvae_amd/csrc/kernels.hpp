@@ -611,6 +611,43 @@ struct FinalArgs {
   int mbegin[kMaxImgMap], mend[kMaxImgMap];   // the ranges again, adjacent: one round of scalar loads finds the entry
   ImgMap map[kMaxImgMap];
 };
+// the loss tail (batch sums of the per-row terms), the device step counter and the hand-off tag: one workgroup
+// (256 threads of it) of the step's last launch
+__device__ __forceinline__ void finalize_tail_block(const FinalArgs& a, float (*red)[256]) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (threadIdx.x < 256) {
+    for (int b = threadIdx.x; b < a.B; b += 256) {
+      a0 -= a.logw[b];
+      a1 -= a.logpx[b];
+      a2 += a.logq[b] - a.logp[b];
+      a3 += a.nent ? a.nent[b] : 0.f;
+    }
+    red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2; red[3][threadIdx.x] = a3;
+  }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int j = 0; j < 4; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    a.tail[0] = red[0][0]; a.tail[1] = red[1][0]; a.tail[2] = red[2][0]; a.tail[3] = red[3][0];
+    a.tail[4] = (float)a.B; a.tail[5] = 0.f; a.tail[6] = 0.f; a.tail[7] = 0.f;
+    if (a.tail_log) {
+      a.tail_log[0] = red[0][0]; a.tail_log[1] = red[1][0]; a.tail_log[2] = red[2][0]; a.tail_log[3] = red[3][0];
+      a.tail_log[4] = (float)a.B; a.tail_log[5] = 0.f; a.tail_log[6] = 0.f; a.tail_log[7] = 0.f;
+    }
+    if (a.step_dev) a.step_dev[0] = a.step_dev[1] + 1;
+    if (a.epoch_word) *a.epoch_word += 1u;
+  }
+}
+// block `bb` of the next step's batch binarisation (input pipeline inside the train graph)
+__device__ __forceinline__ void finalize_bin_block(const FinalArgs& a, const int bb) {
+  const unsigned long long step = a.step_dev[1] + 1ull;
+  for (uint64_t q0 = ((uint64_t)bb * kBinQuadsPerThread) * 256 + threadIdx.x; q0 < ((uint64_t)(bb + 1) * kBinQuadsPerThread) * 256;
+       q0 += blockDim.x)
+    binarize_quad(q0, a.bin_pix, a.bin_idx, 0, a.bin_rows_src, a.bin_B, a.bin_D, a.bin_seed, step, a.bin_x, a.bin_row0);
+}
 __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
 #define GMVAE_FIN_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
   if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x] = wall_clock64();
@@ -660,40 +697,13 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
     return;
   }
   if ((int)blockIdx.x > nb) {                    // the next step's batch: its uniforms are keyed by that step's index
-    const unsigned long long step = a.step_dev[1] + 1ull;
-    const uint64_t q0 = ((uint64_t)((int)blockIdx.x - nb - 1) * kBinQuadsPerThread) * 256 + threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < kBinQuadsPerThread; ++j)
-      binarize_quad(q0 + (uint64_t)j * 256, a.bin_pix, a.bin_idx, 0, a.bin_rows_src, a.bin_B, a.bin_D, a.bin_seed, step, a.bin_x, a.bin_row0);
+    finalize_bin_block(a, (int)blockIdx.x - nb - 1);
     GMVAE_FIN_END();
     return;
   }
   if ((int)blockIdx.x == nb) {
     __shared__ float red[4][256];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int b = threadIdx.x; b < a.B; b += 256) {
-      a0 -= a.logw[b];
-      a1 -= a.logpx[b];
-      a2 += a.logq[b] - a.logp[b];
-      a3 += a.nent ? a.nent[b] : 0.f;
-    }
-    red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2; red[3][threadIdx.x] = a3;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o)
-        for (int j = 0; j < 4; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      a.tail[0] = red[0][0]; a.tail[1] = red[1][0]; a.tail[2] = red[2][0]; a.tail[3] = red[3][0];
-      a.tail[4] = (float)a.B; a.tail[5] = 0.f; a.tail[6] = 0.f; a.tail[7] = 0.f;
-      if (a.tail_log) {
-        a.tail_log[0] = red[0][0]; a.tail_log[1] = red[1][0]; a.tail_log[2] = red[2][0]; a.tail_log[3] = red[3][0];
-        a.tail_log[4] = (float)a.B; a.tail_log[5] = 0.f; a.tail_log[6] = 0.f; a.tail_log[7] = 0.f;
-      }
-      if (a.step_dev) a.step_dev[0] = a.step_dev[1] + 1;
-      if (a.epoch_word) *a.epoch_word += 1u;
-    }
+    finalize_tail_block(a, red);
     GMVAE_FIN_END();
     return;
   }
