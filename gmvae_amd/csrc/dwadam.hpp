@@ -30,6 +30,7 @@ struct DwTensor {
   const void* A;               // [B][lda] uint8 or fp32
   const float* dY;             // [B][ldy]
   int lda, ldy, M, N, a_u8;
+  int mu;                      // 16-row strided tiles per workgroup tile (4: 64 rows; 2: 32 rows -- more, lighter workgroups)
   int w_off, b_off;            // flat parameter offsets of W [M][N] and of the bias [N] (b_off < 0: none)
   int tiles_n, tile_begin;
   int k1, base1, ld1, chunk1, which1;    // operand images of W (kind 0 = none): kernels.hpp img_dst
@@ -40,7 +41,7 @@ struct DwTensor {
 struct DwArgs {
   int ntens, total_tiles, B, pad_;
   unsigned long long* dbg;     // diagnostic: [block][8] wall-clock stamps (tools/dwstamps.py) or null
-  float ln_b1, ln_b2;          // ln(beta1), ln(beta2) rounded from double
+  const float* lr_t;           // this step's Adam step size alpha_t, left by mega2_fwd_bwd (mega.hpp MegaArgs::lr_t_out)
   int tile_begin[kDwMaxT];
   DwTensor t[kDwMaxT];
   FinalArgs fa;                // p, m, v, grads, Adam constants, loss-tail inputs, counters, images, binarisation blocks
@@ -50,30 +51,32 @@ struct DwArgs {
 // B = 1024) are in flight before the first MFMA, and they are BRANCH-FREE (clamped address, value selected
 // afterwards): a load under `if (in range)` makes the compiler wait inside the branch, one memory round trip per load
 // (measured: 13 us for this loop).  The uint8 operand stays packed (one register per k-step) until its MFMAs.
-template <bool U8, class Mid>
+template <bool U8, int MU, class Mid>
 __device__ __forceinline__ void dw_contract(const void* __restrict__ Ap, const float* __restrict__ dY, const int lda, const int ldy,
                                             const int M, const int N, const int m0, const int n0, const int b_lo, const int b_hi,
                                             const int ln, const int lk, f32x4 (&acc)[4], float& cs, Mid mid) {
-  const int ma = m0 + 4 * ln;                    // this lane's 4 fan-in rows (one per strided tile)
+  static_assert(MU == 4 || MU == 2, "2 or 4 strided 16-row tiles per workgroup tile");
+  const int ma = m0 + MU * ln;                   // this lane's MU fan-in rows (one per strided tile)
   const bool a_ok = ma < M, n_ok = n0 + ln < N;  // (M is a multiple of 4 or the source rows are padded to one)
-  const int mac = min(ma, ((M + 3) & ~3) - 4), nc = min(n0 + ln, N - 1);
+  const int mac = min(ma, ((M + 3) & ~3) - MU), nc = min(n0 + ln, N - 1);
   const unsigned char* const A8 = static_cast<const unsigned char*>(Ap);
   const float* const A32 = static_cast<const float*>(Ap);
   constexpr int KB = 32;
-  typedef typename std::conditional<U8, unsigned, float4>::type AT;
+  typedef typename std::conditional<MU == 4, typename std::conditional<U8, unsigned, float4>::type,
+                                    typename std::conditional<U8, unsigned short, float2>::type>::type AT;
   auto mfma4 = [&](const AT& avs, const float bq) {
-    float4 aq;
+    float aq[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (U8) {
       const unsigned w = avs;
-      aq = make_float4((float)(w & 0xff), (float)((w >> 8) & 0xff), (float)((w >> 16) & 0xff), (float)(w >> 24));
+#pragma unroll
+      for (int t = 0; t < MU; ++t) aq[t] = (float)((w >> (8 * t)) & 0xff);
+    } else if constexpr (MU == 4) {
+      aq[0] = avs.x; aq[1] = avs.y; aq[2] = avs.z; aq[3] = avs.w;
     } else {
-      aq = avs;
+      aq[0] = avs.x; aq[1] = avs.y;
     }
-    if (!a_ok) aq = make_float4(0.f, 0.f, 0.f, 0.f);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq, acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq, acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq, acc[3], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MU; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? aq[t] : 0.f, bq, acc[t], 0, 0, 0);
     cs += bq;
   };
   if (b_hi - b_lo == 4 * KB) {
@@ -86,8 +89,8 @@ __device__ __forceinline__ void dw_contract(const void* __restrict__ Ap, const f
     const float* const dy = dY + (long long)(b_lo + lk) * ldy + nc;
 #pragma unroll
     for (int s = 0; s < KB; ++s) {
-      if constexpr (U8) av[s] = *reinterpret_cast<const unsigned*>(a8 + (long long)(4 * s) * lda);
-      else av[s] = *reinterpret_cast<const float4*>(a32 + (long long)(4 * s) * lda);
+      if constexpr (U8) av[s] = *reinterpret_cast<const AT*>(a8 + (long long)(4 * s) * lda);
+      else av[s] = *reinterpret_cast<const AT*>(a32 + (long long)(4 * s) * lda);
       bvv[s] = dy[(long long)(4 * s) * ldy];
     }
 #pragma unroll
@@ -100,8 +103,8 @@ __device__ __forceinline__ void dw_contract(const void* __restrict__ Ap, const f
 #pragma unroll
     for (int s = 0; s < KB; ++s) {
       const int bc = min(b0 + 4 * s + lk, b_hi - 1);
-      if constexpr (U8) av[s] = *reinterpret_cast<const unsigned*>(A8 + (long long)bc * lda + mac);
-      else av[s] = *reinterpret_cast<const float4*>(A32 + (long long)bc * lda + mac);
+      if constexpr (U8) av[s] = *reinterpret_cast<const AT*>(A8 + (long long)bc * lda + mac);
+      else av[s] = *reinterpret_cast<const AT*>(A32 + (long long)bc * lda + mac);
       bvv[s] = dY[(long long)bc * ldy + nc];
     }
 #pragma unroll
@@ -121,6 +124,8 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
   if (bid >= a.total_tiles) {                    // the loss tail + counters, then the next batch's binarisation blocks
     if (bid == a.total_tiles) finalize_tail_block(fa, reinterpret_cast<float(*)[256]>(red));
     else finalize_bin_block(fa, bid - a.total_tiles - 1);
+    DW_ST(4);
+    if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + 5] = 99ull;
     DW_END();
     return;
   }
@@ -133,18 +138,23 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
   const DwTensor& T = a.t[ti];
   const int M = T.M, N = T.N, lda = T.lda, ldy = T.ldy, B = a.B;
   const int tl = bid - T.tile_begin, tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
-  const int m0 = tm * 64, n0 = tn * 16;
+  const int MUr = T.mu;
+  const int m0 = tm * 16 * MUr, n0 = tn * 16;
   // ---- epilogue owners (threads 0..255): unit (lane slot l, r) = dW[mb .. mb+3][n]
-  const int el = tid & 63, er = (tid >> 6) & 3;
-  const int mb = m0 + 16 * (el >> 4) + 4 * er, en = n0 + (el & 15);
-  const bool eown = tid < 256 && mb < M && en < N;
+  // (a lane group lk holds the 4 MU consecutive rows m0 + 4 MU lk + o, o = MU r + t for accumulator [tile t][r]; thread
+  //  (lane slot el, unit eu) owns the rows o = 4 eu .. 4 eu + 3 of that group)
+  const int el = tid & 63, eu = (tid >> 6) & 3;
+  const int mb = m0 + 4 * MUr * (el >> 4) + 4 * eu, en = n0 + (el & 15);
+  const bool eown = tid < 64 * MUr && mb < M && en < N;
   const bool bown = tm == 0 && T.b_off >= 0 && tid >= 256 && tid < 272 && n0 + (tid - 256) < N;
   float pp[4] = {0.f, 0.f, 0.f, 0.f}, pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f};
   float bp = 0.f, bm = 0.f, bv = 0.f, lr_t = 0.f;
   bool poisoned = false;
   // what the epilogue needs besides the tile: requested / computed AFTER the contraction (vmcnt retires in order: issued
   // before it, these loads and the ~100 instructions of alpha_t would sit in front of the first MFMA: +1.5 us measured)
+  const bool upd = fa.do_adam != 0;                // data parallel: gradients only (all-reduce and adam_tf_img follow)
   auto prologue = [&]() {
+    if (!upd) return;
     if (eown) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -154,12 +164,8 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
       }
     }
     if (bown) { const int i = T.b_off + n0 + tid - 256; bp = fa.p[i]; bm = fa.m[i]; bv = fa.v[i]; }
-    // alpha_t = lr sqrt(1 - b2^t) / (1 - b1^t) with 1 - b^t = -expm1(t ln b) (no cancellation; ln b comes in from the
-    // host in double precision): agrees with the double-precision form of adam_tf to ~3e-7 relative, at a fraction of
-    // the two fp64 pow() calls every thread would otherwise make
     poisoned = fa.err_word && *fa.err_word;
-    const float tf = (float)((fa.step_dev ? fa.step_dev[1] : 0ull) + 1ull);
-    lr_t = fa.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1));
+    lr_t = *a.lr_t;                                // alpha_t = lr sqrt(1 - b2^t) / (1 - b1^t), computed once by mega2_fwd_bwd
   };
   const float omb1 = 1.f - fa.b1, omb2 = 1.f - fa.b2, gs = 1.f / fa.count;
   DW_ST(1);
@@ -170,8 +176,9 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float cs = 0.f;
-  if (T.a_u8) dw_contract<true>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
-  else dw_contract<false>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+  if (T.a_u8) dw_contract<true, 4>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+  else if (MUr == 4) dw_contract<false, 4>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+  else dw_contract<false, 2>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
   prologue();                                    // its loads fly while the partial tiles go to LDS and the waves meet
   DW_ST(2);
   // ---- the waves' partial tiles meet in LDS (fixed order: bit-reproducible)
@@ -187,19 +194,22 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
 #pragma unroll
     for (int w = 0; w < kDwWaves; ++w)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) g[t] += red[(w * 16 + 4 * t + er) * 64 + el];
+      for (int j = 0; j < 4; ++j) {
+        const int o = 4 * eu + j, r = MUr == 4 ? eu : o >> 1, t = MUr == 4 ? j : o & 1;
+        g[j] += red[(w * 16 + 4 * t + r) * 64 + el];
+      }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (mb + j < M) {
         const long long i = (long long)T.w_off + (long long)(mb + j) * N + en;
         fa.grads[i] = g[j];
-        if (!poisoned) {
+        if (upd && !poisoned) {
           adam_update(pp[j], pm[j], pv[j], g[j], gs, lr_t, omb1, omb2, fa.eps);
           fa.p[i] = pp[j]; fa.m[i] = pm[j]; fa.v[i] = pv[j];
         }
       }
     }
-    if (!poisoned) {
+    if (upd && !poisoned) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (mb + j >= M) pp[j] = 0.f;              // rows past the tensor: the image's padding stays zero
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
       for (int k = 0; k < 4; ++k) g += redcs[w * 64 + k * 16 + c];
     const int i = T.b_off + n0 + c;
     fa.grads[i] = g;
-    if (!poisoned) {
+    if (upd && !poisoned) {
       adam_update(bp, bm, bv, g, gs, lr_t, omb1, omb2, fa.eps);
       fa.p[i] = bp; fa.m[i] = bm; fa.v[i] = bv;
       if (T.bk >= 0) fa.img[T.bwhich][img_dst(T.bk, T.bbase, 0, T.bchunk, 0, n0 + c)] = bp;

@@ -737,6 +737,8 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     m2_ran = m2;
     if (m2) {
       c.img2f = w.img2f; c.img2b = w.img2b; c.dimg2 = w.dimg2;
+      c.lr = a.lr; c.b1 = a.beta1; c.b2 = a.beta2;
+      c.lr_t_out = (a.adam_p && a.adam_p == a.params && a.step_dev) ? reinterpret_cast<float*>(w.sync + 2) : nullptr;
       static bool m2attr = false;
       if (!m2attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(mega2_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -757,7 +759,8 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
   }
   // Single device, steady state of a train graph at the specialised sizes: weight gradients AND the optimizer in one
   // launch (dwadam.hpp) -- no split-K slabs, no finalize_adam.
-  if (m2_ran && gm && a.adam_p && a.adam_p == a.params && a.step_dev && !getenv("GMVAE_NO_DWADAM")) {
+  const bool dw_upd = a.adam_p && a.adam_p == a.params;     // single device: the optimizer runs in the same launch
+  if (m2_ran && gm && (dw_upd || a.dp_images) && a.step_dev && !getenv("GMVAE_NO_DWADAM")) {
     ImgPlan pl;
     plan_images(d, model, L, w, ml, a.params, pl);
     if (pl.map_ok) {
@@ -765,12 +768,14 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       memset(&da, 0, sizeof(da));
       da.B = B;
       da.dbg = getenv("GMVAE_STAMPS") ? w.gstamps + 3 * 2048 * 8 : nullptr;
-      da.ln_b1 = (float)log((double)a.beta1); da.ln_b2 = (float)log((double)a.beta2);
-      auto add = [&](const void* A, bool u8, int lda, const float* dY, int ldy, int M, int N, uint64_t w_off, long long b_off) {
+      da.lr_t = reinterpret_cast<const float*>(w.sync + 2);
+      auto add = [&](const void* A, bool u8, int lda, const float* dY, int ldy, int M, int N, uint64_t w_off, long long b_off,
+                     int mu = 4) {
         DwTensor& T = da.t[da.ntens];
         T.A = A; T.a_u8 = u8 ? 1 : 0; T.lda = lda; T.dY = dY; T.ldy = ldy; T.M = M; T.N = N; T.w_off = (int)w_off; T.b_off = (int)b_off;
+        T.mu = u8 ? 4 : mu;
         T.tiles_n = (N + 15) / 16; T.tile_begin = da.total_tiles; da.tile_begin[da.ntens] = da.total_tiles;
-        da.total_tiles += ((M + 63) / 64) * T.tiles_n;
+        da.total_tiles += ((M + 16 * T.mu - 1) / (16 * T.mu)) * T.tiles_n;
         T.bk = -1;
         for (int i = 0; i < pl.nmap; ++i) {      // where the optimizer also has to leave the updated values (mega2's operand images)
           const ImgMap& mp = pl.map[i];
@@ -791,21 +796,25 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       const int K4 = (int)pad4(K);
       add(a.x, true, D, w.dbuf[2], H, D, H, E.w[0], (long long)E.b[0]);                                   // dWy0 (+ dby0)
       add(a.x, true, D, w.dbuf[1], H, D, H, G.w[0], (long long)G.b[0]);                                   // dWg0[x] (+ dbg0)
-      add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1]);                                  // dWd1 (+ dbd1)
-      add(w.y, false, K4, w.dbuf[1], H, K, H, G.w[0] + (uint64_t)D * H, -1);                              // dWg0[y]
-      add(w.he[1], false, H, w.dlogits, K4, H, K, E.w[1], (long long)E.b[1]);                             // dWy1
-      add(w.y, false, K4, w.dpp, 2 * Lz, K, 2 * Lz, L.prior.w[0], (long long)L.prior.b[0]);               // dWp
-      add(w.hg[1], false, H, w.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1]);                        // dWg1
-      add(w.z, false, Lz, w.dbuf[0], H, Lz, H, Dn.w[0], (long long)Dn.b[0]);                              // dWd0
+      // (32-row tiles for the decoder output layer: 98 lighter workgroups instead of 49 -- with the others 228 <= 256
+      //  CUs, one workgroup each -- and its longer epilogue, two operand images, no longer ends the launch)
+      const int mu = env_cfg("GMVAE_DW_MU", 2);
+      add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1], mu);                              // dWd1 (+ dbd1)
+      add(w.y, false, K4, w.dbuf[1], H, K, H, G.w[0] + (uint64_t)D * H, -1, mu);                          // dWg0[y]
+      add(w.he[1], false, H, w.dlogits, K4, H, K, E.w[1], (long long)E.b[1], mu);                         // dWy1
+      add(w.y, false, K4, w.dpp, 2 * Lz, K, 2 * Lz, L.prior.w[0], (long long)L.prior.b[0], mu);           // dWp
+      add(w.hg[1], false, H, w.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1], mu);                    // dWg1
+      add(w.z, false, Lz, w.dbuf[0], H, Lz, H, Dn.w[0], (long long)Dn.b[0], mu);                          // dWd0
       FinalArgs& fa = da.fa;
       fa.P = (long long)L.P_pad; fa.grads = a.grads; fa.p = a.adam_p; fa.m = a.adam_m; fa.v = a.adam_v;
-      fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = 1; fa.count = (float)B;
+      fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = dw_upd ? 1 : 0; fa.count = (float)B;
       fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = w.nent;
       fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev); fa.tail_log = a.tail_log;
-      fa.epoch_word = w.sync; fa.err_word = w.sync + 1;
+      fa.epoch_word = dw_upd ? w.sync : nullptr;   // (data parallel: adam_tf_img, after the all-reduce, bumps the hand-off tag)
+      fa.err_word = w.sync + 1;
       fa.img[0] = w.img_m; fa.img[1] = w.dimg; fa.img[2] = w.img2f; fa.img[3] = w.img2b; fa.img[4] = w.dimg2;
       fa.span = (a.want_spans && w.spans) ? w.spans + 2048 * 2 : nullptr;
-      if (a.next_x && a.next_pix && a.next_idx) {
+      if (a.next_x && a.next_pix && a.next_idx && dw_upd) {
         fa.bin_pix = a.next_pix; fa.bin_idx = a.next_idx; fa.bin_x = a.next_x; fa.bin_rows_src = a.next_rows_src;
         fa.bin_B = B; fa.bin_D = D; fa.bin_seed = a.bin_seed; fa.bin_row0 = d.row0;
         const uint64_t quads = (uint64_t)B * (D >> 2);
@@ -816,7 +825,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       cx.check();
       double fl_ = 0;
       for (int i = 0; i < da.ntens; ++i) fl_ += 2.0 * da.t[i].M * da.t[i].N * B;
-      cx.mark("dw_adam", fl_);
+      cx.mark(dw_upd ? "dw_adam" : "dw_grads", fl_);
       return cx.err;
     }
   }

@@ -246,6 +246,10 @@ struct MegaArgs {
   unsigned long long row0;    // global index of this device's first batch row (GmvaeDims::row0): Philox counter only
   unsigned long long* step_dev;
   const float *img2f, *img2b, *dimg2;   // mega2_fwd_bwd (mega2.hpp): forward / backward operand images, decoder operand images
+  // mega2_fwd_bwd also leaves this step's Adam step size alpha_t = lr sqrt(1 - b2^t) / (1 - b1^t) (fp64, adam_tf's form) for
+  // dw_adam: one thread of a workgroup that is done early computes it, instead of every thread of the optimizer launch
+  float lr, b1, b2;
+  float* lr_t_out;             // (null: not wanted)
 };
 
 // HT, LT, KT, DT, MODEL: compile-time sizes of a specialised instance (0 / -1 = read them from the arguments).

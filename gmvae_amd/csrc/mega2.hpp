@@ -515,6 +515,10 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       granule_publish(xo + kPanel * H + (tid - 256), ((unsigned long long)epoch << 32) | __float_as_uint(rsn));
     }
     M2_WC(1);
+    if (bid == 0 && tid == 0 && a.lr_t_out) {      // (a producer: off the launch's critical path)
+      const double t = (double)(a.step_dev[0] + 1ull);
+      *a.lr_t_out = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, t)) / (1.0 - pow((double)a.b1, t)));
+    }
     M2_SPAN_END();
     return;
   }

@@ -26,3 +26,5 @@ for ti in range(8):
     if not len(r): continue
     med = lambda a: np.median(a) * 0.01
     print(f"{names[ti]:6s} n={len(r):3d} start {med(r[:,0]-t0):5.2f} | prologue {med(r[:,1]-r[:,0]):5.2f} | contraction {med(r[:,2]-r[:,1]):5.2f} | barrier {med(r[:,3]-r[:,2]):5.2f} | epilogue {med(r[:,4]-r[:,3]):5.2f} | end {med(r[:,4]-t0):5.2f} (max {(r[:,4]-t0).max()*0.01:5.2f})")
+r = raw[raw[:, 5] == 99]
+if len(r): print(f"tail   n={len(r):3d} start {np.median(r[:,0]-t0)*0.01:5.2f} | end {np.median(r[:,4]-t0)*0.01:5.2f} (max {(r[:,4]-t0).max()*0.01:5.2f})")
