@@ -337,16 +337,24 @@ def main():
                 "timing": "in-kernel wall-clock stamps (s_memrealtime): last workgroup end - first workgroup start, "
                           "steady-state step replayed inside a hipGraph" if world == 1 else "hipEvents around eager launches",
                 "levels": [[nm, round(us, 2)] for nm, us, _ in levels]}
-        # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE;
-        # rocprofv3 --pmc cannot run inside this process): profiles/round1_traffic.json, same workload only
+        # HBM-side bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE;
+        # rocprofv3 --pmc cannot run inside this process) and the committed rocprofv3 --kernel-trace --stats average of the
+        # same kernel on the same command (profiles/round2_*, tools/profile_round2.sh) -- default workload only
         try:
-            if (a.model, B, a.hidden, a.layers, a.latent, a.components, a.data_dim, a.n_samples) == ("gmvae", 1024, 64, 1, 64, 10, 784, 1):
-                tj = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))
-                # the instance that runs the first layer itself (template argument FLT = 1): the steady-state launch
-                key = [k for k in tj if "mega_fwd_bwd<64, 64, 10, 784, 2, 1>" in k] if dom[0].startswith("mega") else []
+            if workload_name(a, n_gpus) == "BASELINE configs[2]" and world == 1:
+                kname = "gmvae::" + dom[0] if not dom[0].startswith("gemm") else dom[0]
+                tj = json.load(open(os.path.join(ROOT, "profiles", "round2_traffic.json")))
+                key = [k for k in tj if k.startswith(kname + " ") or k.startswith(kname + "(")]
                 if key:
                     roof["traffic"] = tj[key[0]]["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/round1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                    roof["traffic_source"] = "profiles/round2_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                import csv
+                for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "round2_bench_kernel_stats.csv"))):
+                    if r["Name"].startswith(kname + "("):
+                        us = float(r["AverageNs"]) * 1e-3
+                        roof["rocprof_usec_per_launch"] = us
+                        roof["frac_rocprof"] = dom[2] / us * 1e-6 / PEAK_F32_MFMA_TFLOPS
+                        roof["rocprof_source"] = "profiles/round2_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command; the profiled run is slower than the timed one)"
         except Exception:
             pass
         if a.levels:

@@ -38,8 +38,14 @@ struct DwTensor {
   int bk, bbase, bchunk, bwhich;         // image of the bias (bk < 0: none; kinds 0 / 6)
 };
 
+constexpr int kDwMaxTiles = 512;
 struct DwArgs {
   int ntens, total_tiles, B, pad_;
+  // XCD-aware launch order (speed only): workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own, so
+  // slot b (XCD b % 8) runs tile perm[b], chosen on the host so that the tiles of one XCD share operand columns (an
+  // x-problem's XCD keeps the x columns of "its" row blocks, the decoder layer's the g columns of "its" column tiles)
+  // instead of every XCD fetching every operand once (37.6 MB of fabric reads + writes per launch before, round2 PMC)
+  unsigned short perm[kDwMaxTiles];
   unsigned long long* dbg;     // diagnostic: [block][8] wall-clock stamps (tools/dwstamps.py) or null
   const float* lr_t;           // this step's Adam step size alpha_t, left by mega2_fwd_bwd (mega.hpp MegaArgs::lr_t_out)
   int tile_begin[kDwMaxT];
@@ -131,13 +137,14 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, lk = lane >> 4;
+  const int tile = a.perm[bid];
   int ti = 0;
 #pragma unroll
   for (int i = 1; i < kDwMaxT; ++i)
-    if (i < a.ntens && bid >= a.tile_begin[i]) ti = i;
+    if (i < a.ntens && tile >= a.tile_begin[i]) ti = i;
   const DwTensor& T = a.t[ti];
   const int M = T.M, N = T.N, lda = T.lda, ldy = T.ldy, B = a.B;
-  const int tl = bid - T.tile_begin, tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
+  const int tl = tile - T.tile_begin, tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
   const int MUr = T.mu;
   const int m0 = tm * 16 * MUr, n0 = tn * 16;
   // ---- epilogue owners (threads 0..255): unit (lane slot l, r) = dW[mb .. mb+3][n]

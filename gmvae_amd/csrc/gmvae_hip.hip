@@ -805,6 +805,36 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       add(w.y, false, K4, w.dpp, 2 * Lz, K, 2 * Lz, L.prior.w[0], (long long)L.prior.b[0], mu);           // dWp
       add(w.hg[1], false, H, w.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1], mu);                    // dWg1
       add(w.z, false, Lz, w.dbuf[0], H, Lz, H, Dn.w[0], (long long)Dn.b[0], mu);                          // dWd0
+      {  // XCD-aware order: slot b runs on XCD b % 8 (observed round-robin placement; speed only)
+        static int cls[kDwMaxTiles];             // the XCD a tile would like: the one that shares its larger operand
+        bool used[kDwMaxTiles];
+        const int nt = da.total_tiles <= kDwMaxTiles ? da.total_tiles : 0;
+        for (int i = 0; i < da.ntens; ++i) {
+          const DwTensor& T = da.t[i];
+          const int tiles_m = ((T.M + 16 * T.mu - 1) / (16 * T.mu));
+          for (int tm = 0; tm < tiles_m; ++tm)
+            for (int tn = 0; tn < T.tiles_n; ++tn) {
+              const int t = T.tile_begin + tm * T.tiles_n + tn;
+              if (t < kDwMaxTiles) cls[t] = (tiles_m >= T.tiles_n ? tm : tn) & 7;      // share the operand with more blocks
+            }
+        }
+        for (int t = 0; t < nt; ++t) used[t] = false;
+        const bool xcd = nt > 0 && !getenv("GMVAE_DW_NO_XCD");
+        int next_any = 0;
+        for (int b = 0; b < da.total_tiles && b < kDwMaxTiles; ++b) {
+          int pick = -1;
+          if (xcd) {
+            for (int t = 0; t < nt; ++t)
+              if (!used[t] && cls[t] == (b & 7)) { pick = t; break; }
+            if (pick < 0) { while (next_any < nt && used[next_any]) ++next_any; pick = next_any; }
+            used[pick] = true;
+          } else {
+            pick = b;
+          }
+          da.perm[b] = (unsigned short)pick;
+        }
+        if (da.total_tiles > kDwMaxTiles) { /* cannot happen at these sizes; the launch below is guarded */ }
+      }
       FinalArgs& fa = da.fa;
       fa.P = (long long)L.P_pad; fa.grads = a.grads; fa.p = a.adam_p; fa.m = a.adam_m; fa.v = a.adam_v;
       fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = dw_upd ? 1 : 0; fa.count = (float)B;
@@ -821,6 +851,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         fa.bin_blocks = (int)((quads + (uint64_t)kBinQuadsPerThread * 256 - 1) / ((uint64_t)kBinQuadsPerThread * 256));
       }
       // the padding words of the flat gradient buffer are never written by the tiles: the buffer is all-reduced / read whole
+      if (da.total_tiles > kDwMaxTiles) return GMVAE_E_DIMS;
       hipLaunchKernelGGL(dw_adam, dim3(da.total_tiles + 1 + fa.bin_blocks), dim3(kDwThreads), 0, st, da);
       cx.check();
       double fl_ = 0;
