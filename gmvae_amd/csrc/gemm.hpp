@@ -108,7 +108,7 @@ struct Cfg {
   static constexpr int LDS_FLOATS = LDS0 > XBF ? LDS0 : XBF;
   // waves per SIMD the register allocator must leave room for: the small configuration's launches carry more
   // workgroups than 2 per CU (tiles + auxiliary blocks), and a workgroup that starts late ends the launch late
-  static constexpr int WAVES_EU = (BM * BN <= 32 * 32 || (NBUF == 1 && BM * BN <= 64 * 64)) ? 3 : 1;
+  static constexpr int WAVES_EU = (BM * BN <= 32 * 32 || (NBUF == 1 && BM * BN <= 64 * 64)) ? 3 : (BM * BN >= 128 * 128 ? 2 : 1);
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
   static_assert(NSA >= 1 && NSB >= 1, "tile too small for 256 threads");
   static_assert((BK / WK) % 2 == 0, "k slice per wave must be even");
@@ -216,6 +216,9 @@ __device__ __forceinline__ void op_load(const void* __restrict__ base, const int
 // [kb, ke), 16-byte loads legal, no row broadcast / k scale: no clamps, no selects, shift-only
 // slot arithmetic.  (SQ counters showed the grouped launches VALU-issue-bound on the predicated loader:
 // ~580 VALU instructions per wave around 16 MFMAs, profiles/round1_pmc_sq_per_kernel.txt.)
+// (A variant that also applied the per-k scale of the IWAE row weights here, so that the decoder's dW problem could
+// take this path, made EVERY large-tile launch 6-16 % slower on the same box -- the staging code of this kernel is
+// VALU-issue-sensitive -- and was dropped: A/B in profiles/round2_notes.md.)
 template <int KIND, int BMN, int BK, int NS>
 __device__ __forceinline__ void op_load_fast(const void* __restrict__ base, const int ld, const int mn0, const int k0,
                                              const int tid, float4 (&r)[NS]) {
@@ -378,8 +381,10 @@ __device__ __forceinline__ void split_round(const unsigned short* __restrict__ A
   }
 }
 
-template <class C>
-__global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Launch L) {
+// SP3 = 1: the instance that can run split3 problems (only the 128x128 configuration has one; a kernel of its own, because
+// the piece-product loop's registers would otherwise push the fp32 loop below two workgroups per CU)
+template <class C, int SP3 = 0>
+__global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(const Launch L) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   constexpr int kBK = C::BK;
   const int tid = threadIdx.x;
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
     op_store<C::BN, kBK, C::LDB, C::NSB>(Bs_, b_mc, tid, rb);               \
   }
 
-    if constexpr (C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2) {
+    if constexpr (SP3 && C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2) {
       const int sp3 = L.p[pi].split3;
       if (sp3) {                                  // (wave-uniform) this problem runs on the bf16 matrix cores
         static_assert(6 * kSplitPlane * 2 <= C::LDS_FLOATS * 4, "split3 images must fit the kernel's LDS");
@@ -795,10 +800,16 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = min(nb + j, N - 1);
+          // ONE exp, ONE rcp and ONE log per element give softplus AND the sigmoid (the hardware forms, ~1e-6 relative:
+          // the ELBO tolerance is 1e-4; the libm log1pf / division forms cost ~4x the instructions and were 10 % of
+          // this launch at the config-5 sizes)
           const float lam = v[j] + bias[n] + addconst;
           const float xv = (float)xr[n];
-          rsum += (nb + j < N) ? xv * lam - softplusf_(lam) : 0.f;
-          v[j] = sigmoidf_(lam) - xv;
+          const float e = __expf(-fabsf(lam));
+          const float rcp = __builtin_amdgcn_rcpf(1.f + e);
+          const float sp = fmaxf(lam, 0.f) - __logf(rcp);
+          rsum += (nb + j < N) ? xv * lam - sp : 0.f;
+          v[j] = (lam >= 0.f ? rcp : e * rcp) - xv;
         }
         if (Cout) {
           float* dst = Cout + (long long)m * ldc + nb;

@@ -414,7 +414,8 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
     const int sp3 = sp ? (atoi(sp) == 9 ? 2 : (atoi(sp) ? 1 : 0)) : 0;
     for (int i = 0; i < g.L.nprob; ++i) g.L.p[i].split3 = sp3;
     tiles = g.L.total_tiles = tile_up<CfgL>(g.L);
-    hipLaunchKernelGGL(gemm_grouped<CfgL>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
+    if (sp3) hipLaunchKernelGGL((gemm_grouped<CfgL, 1>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
+    else hipLaunchKernelGGL(gemm_grouped<CfgL>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
   } else if (cfg == 3) {
     tiles = g.L.total_tiles = tile_up<CfgM1>(g.L);
     hipLaunchKernelGGL(gemm_grouped<CfgM1>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
