@@ -33,7 +33,7 @@ struct DwTensor {
   int mu;                      // 16-row strided tiles per workgroup tile (4: 64 rows; 2: 32 rows -- more, lighter workgroups)
   int w_off, b_off;            // flat parameter offsets of W [M][N] and of the bias [N] (b_off < 0: none)
   int tiles_n, tile_begin;
-  int k1, base1, ld1, chunk1, which1;    // operand images of W (kind 0 = none): kernels.hpp img_dst
+  int k1, base1, ld1, chunk1, which1;    // operand images of W (kind -1 = none): kernels.hpp img_dst
   int k2, base2, ld2, chunk2, which2;
   int bk, bbase, bchunk, bwhich;         // image of the bias (bk < 0: none; kinds 0 / 6)
 };
@@ -47,7 +47,8 @@ struct DwArgs {
   // instead of every XCD fetching every operand once (37.6 MB of fabric reads + writes per launch before, round2 PMC)
   unsigned short perm[kDwMaxTiles];
   unsigned long long* dbg;     // diagnostic: [block][8] wall-clock stamps (tools/dwstamps.py) or null
-  const float* lr_t;           // this step's Adam step size alpha_t, left by mega2_fwd_bwd (mega.hpp MegaArgs::lr_t_out)
+  const float* lr_t;           // this step's Adam step size alpha_t, left by mega2_fwd_bwd (mega.hpp MegaArgs::lr_t_out), or null:
+  float ln_b1, ln_b2;          // then alpha_t = lr sqrt(-expm1(t ln b2)) / (-expm1(t ln b1)) per thread (ln b rounded from double)
   int tile_begin[kDwMaxT];
   DwTensor t[kDwMaxT];
   FinalArgs fa;                // p, m, v, grads, Adam constants, loss-tail inputs, counters, images, binarisation blocks
@@ -172,7 +173,12 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
     }
     if (bown) { const int i = T.b_off + n0 + tid - 256; bp = fa.p[i]; bm = fa.m[i]; bv = fa.v[i]; }
     poisoned = fa.err_word && *fa.err_word;
-    lr_t = *a.lr_t;                                // alpha_t = lr sqrt(1 - b2^t) / (1 - b1^t), computed once by mega2_fwd_bwd
+    if (a.lr_t) {
+      lr_t = *a.lr_t;                              // alpha_t = lr sqrt(1 - b2^t) / (1 - b1^t), computed once by mega2_fwd_bwd
+    } else {                                       // 1 - b^t = -expm1(t ln b): no cancellation, ~3e-7 relative to the fp64 form
+      const float tf = (float)((fa.step_dev ? fa.step_dev[1] : 0ull) + 1ull);
+      lr_t = fa.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1));
+    }
   };
   const float omb1 = 1.f - fa.b1, omb2 = 1.f - fa.b2, gs = 1.f / fa.count;
   DW_ST(1);
@@ -222,12 +228,12 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
         if (mb + j >= M) pp[j] = 0.f;              // rows past the tensor: the image's padding stays zero
       if (T.k1 == 2 || T.k1 == 4)
         *reinterpret_cast<float4*>(fa.img[T.which1] + img_dst(T.k1, T.base1, T.ld1, T.chunk1, mb, en)) = make_float4(pp[0], pp[1], pp[2], pp[3]);
-      else if (T.k1) {
+      else if (T.k1 >= 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (mb + j < M) fa.img[T.which1][img_dst(T.k1, T.base1, T.ld1, T.chunk1, mb + j, en)] = pp[j];
       }
-      if (T.k2) {
+      if (T.k2 >= 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (mb + j < M) fa.img[T.which2][img_dst(T.k2, T.base2, T.ld2, T.chunk2, mb + j, en)] = pp[j];

@@ -761,7 +761,9 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
   // Single device, steady state of a train graph at the specialised sizes: weight gradients AND the optimizer in one
   // launch (dwadam.hpp) -- no split-K slabs, no finalize_adam.
   const bool dw_upd = a.adam_p && a.adam_p == a.params;     // single device: the optimizer runs in the same launch
-  if (m2_ran && gm && (dw_upd || a.dp_images) && a.step_dev && !getenv("GMVAE_NO_DWADAM")) {
+  // (every model of the mega schedule whose gradients are all matrix products: the learned mixture prior's variables of
+  //  VAE_GMP come as per-panel partials and keep the split-K launch + finalize_adam)
+  if (fl && !gmp && (dw_upd || a.dp_images) && a.step_dev && !getenv("GMVAE_NO_DWADAM")) {
     ImgPlan pl;
     plan_images(d, model, L, w, ml, a.params, pl);
     if (pl.map_ok) {
@@ -769,7 +771,8 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       memset(&da, 0, sizeof(da));
       da.B = B;
       da.dbg = getenv("GMVAE_STAMPS") ? w.gstamps + 3 * 2048 * 8 : nullptr;
-      da.lr_t = reinterpret_cast<const float*>(w.sync + 2);
+      da.lr_t = m2_ran ? reinterpret_cast<const float*>(w.sync + 2) : nullptr;
+      da.ln_b1 = (float)log((double)a.beta1); da.ln_b2 = (float)log((double)a.beta2);
       auto add = [&](const void* A, bool u8, int lda, const float* dY, int ldy, int M, int N, uint64_t w_off, long long b_off,
                      int mu = 4) {
         DwTensor& T = da.t[da.ntens];
@@ -777,11 +780,11 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         T.mu = u8 ? 4 : mu;
         T.tiles_n = (N + 15) / 16; T.tile_begin = da.total_tiles; da.tile_begin[da.ntens] = da.total_tiles;
         da.total_tiles += ((M + 16 * T.mu - 1) / (16 * T.mu)) * T.tiles_n;
-        T.bk = -1;
+        T.bk = T.k1 = T.k2 = -1;
         for (int i = 0; i < pl.nmap; ++i) {      // where the optimizer also has to leave the updated values (mega2's operand images)
           const ImgMap& mp = pl.map[i];
           if (mp.begin == (int)w_off && mp.end == (int)(w_off + (uint64_t)M * N)) {
-            if (!T.k1) { T.k1 = mp.kind; T.base1 = mp.base; T.ld1 = mp.ld; T.chunk1 = mp.chunk; T.which1 = mp.which; }
+            if (T.k1 < 0) { T.k1 = mp.kind; T.base1 = mp.base; T.ld1 = mp.ld; T.chunk1 = mp.chunk; T.which1 = mp.which; }
             else { T.k2 = mp.kind; T.base2 = mp.base; T.ld2 = mp.ld; T.chunk2 = mp.chunk; T.which2 = mp.which; }
           }
           if (b_off >= 0 && mp.begin == (int)b_off && mp.end == (int)(b_off + N)) { T.bk = mp.kind; T.bbase = mp.base; T.bchunk = mp.chunk; T.bwhich = mp.which; }
@@ -795,16 +798,22 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         da.ntens++;
       };
       const int K4 = (int)pad4(K);
-      add(a.x, true, D, w.dbuf[2], H, D, H, E.w[0], (long long)E.b[0]);                                   // dWy0 (+ dby0)
-      add(a.x, true, D, w.dbuf[1], H, D, H, G.w[0], (long long)G.b[0]);                                   // dWg0[x] (+ dbg0)
-      // (32-row tiles for the decoder output layer: 98 lighter workgroups instead of 49 -- with the others 228 <= 256
-      //  CUs, one workgroup each -- and its longer epilogue, two operand images, no longer ends the launch)
       const int mu = env_cfg("GMVAE_DW_MU", 2);
-      add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1], mu);                              // dWd1 (+ dbd1)
-      add(w.y, false, K4, w.dbuf[1], H, K, H, G.w[0] + (uint64_t)D * H, -1, mu);                          // dWg0[y]
-      add(w.he[1], false, H, w.dlogits, K4, H, K, E.w[1], (long long)E.b[1], mu);                         // dWy1
-      add(w.y, false, K4, w.dpp, 2 * Lz, K, 2 * Lz, L.prior.w[0], (long long)L.prior.b[0], mu);           // dWp
-      add(w.hg[1], false, H, w.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1], mu);                    // dWg1
+      // (32-row tiles for the fp32 problems: more, lighter workgroups -- 240 <= 256 CUs at the default sizes -- and the
+      //  decoder output layer's longer epilogue, two operand images, no longer ends the launch)
+      if (gm) {
+        add(a.x, true, D, w.dbuf[2], H, D, H, E.w[0], (long long)E.b[0]);                                 // dWy0 (+ dby0)
+        add(a.x, true, D, w.dbuf[1], H, D, H, G.w[0], (long long)G.b[0]);                                 // dWg0[x] (+ dbg0)
+        add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1], mu);                            // dWd1 (+ dbd1)
+        add(w.y, false, K4, w.dbuf[1], H, K, H, G.w[0] + (uint64_t)D * H, -1, mu);                        // dWg0[y]
+        add(w.he[1], false, H, w.dlogits, K4, H, K, E.w[1], (long long)E.b[1], mu);                       // dWy1
+        add(w.y, false, K4, w.dpp, 2 * Lz, K, 2 * Lz, L.prior.w[0], (long long)L.prior.b[0], mu);         // dWp
+        add(w.hg[1], false, H, w.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1], mu);                  // dWg1
+      } else {
+        add(a.x, true, D, w.dbuf[1], H, D, H, E.w[0], (long long)E.b[0]);                                 // dWe0 (+ dbe0)
+        add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1], mu);                            // dWd1 (+ dbd1)
+        add(w.he[1], false, H, w.dqp, 2 * Lz, H, 2 * Lz, E.w[1], (long long)E.b[1], mu);                  // dWe1
+      }
       add(w.z, false, Lz, w.dbuf[0], H, Lz, H, Dn.w[0], (long long)Dn.b[0], mu);                          // dWd0
       {  // XCD-aware order: slot b runs on XCD b % 8 (observed round-robin placement; speed only)
         static int cls[kDwMaxTiles];             // the XCD a tile would like: the one that shares its larger operand
@@ -839,7 +848,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       FinalArgs& fa = da.fa;
       fa.P = (long long)L.P_pad; fa.grads = a.grads; fa.p = a.adam_p; fa.m = a.adam_m; fa.v = a.adam_v;
       fa.lr = a.lr; fa.b1 = a.beta1; fa.b2 = a.beta2; fa.eps = a.epsilon; fa.do_adam = dw_upd ? 1 : 0; fa.count = (float)B;
-      fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = w.nent;
+      fa.logw = w.logw; fa.logpx = w.logpx; fa.logq = w.logq; fa.logp = w.logp; fa.nent = gm ? w.nent : nullptr;
       fa.tail = tail; fa.B = B; fa.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev); fa.tail_log = a.tail_log;
       fa.epoch_word = dw_upd ? w.sync : nullptr;   // (data parallel: adam_tf_img, after the all-reduce, bumps the hand-off tag)
       fa.err_word = w.sync + 1;
