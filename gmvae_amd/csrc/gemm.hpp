@@ -25,6 +25,7 @@
 namespace gmvae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MAXP = 8;         // problems per launch
 
@@ -381,9 +382,155 @@ __device__ __forceinline__ void split_round(const unsigned short* __restrict__ A
   }
 }
 
+// ---- the 128x128x32 configuration's interior rounds ("big rounds") -----------------------------------------------
+// For tiles completely inside both fp32 operands and k ranges that are whole 32-deep rounds.  LDS image of an operand
+// round: [8 k-quads][128 mn] units of 16 bytes = the 4 consecutive k of one mn, unit index swizzled
+//     U(kq, mn) = kq * 128 + (mn ^ ((mn >> 4) & 3) ^ ((kq & 3) << 2))
+// so that all three access patterns are bank-conflict-free 16-byte operations: the staging store of a k-contiguous source
+// (a slot IS a unit), of an mn-contiguous source (a thread owns 4 k x 4 mn and writes its 4 transposed units), and the
+// fragment read (lane (h, l31) of v_mfma_f32_32x32x2_f32 takes unit (2g + h, mn0 + l31): its k for the 4 MFMA steps of
+// k-group g -- both operands use the same k order, so the sum is the same set of products).  A round is then 64 MFMAs,
+// 16 ds_read_b128, 8 ds_write_b128 and 8 global_load_dwordx4 per wave (the [k][mn] image of the general loop: 32
+// ds_read2_b32, 32 ds_write_b32), the next k-group's fragments are in flight while one multiplies, and the staging stores
+// of the next round sit in front of the last 16 MFMAs -- nothing but the barrier is outside the matrix pipe's shadow.
+constexpr int kBigBuf = 8192;       // floats per staging buffer: A image | B image
+
+template <bool AMC, bool BMC, bool KS, bool CS>
+__device__ __forceinline__ void big_rounds(float* __restrict__ lds, const float* __restrict__ A, const uint32_t a_ld,
+                                           const float* __restrict__ Bp, const uint32_t b_ld,
+                                           const float* __restrict__ kscale, const int m0, const int n0, const int kb,
+                                           const int NC, const int tid, const int lane, const int wm0, const int wn0,
+                                           f32x16 (&acc)[2][2], float4& cs4) {
+  const int h = lane >> 5, l31 = lane & 31;
+  // staging: element offsets of slot 0, slot stride, round stride; LDS float offsets of this thread's units
+  const uint32_t kq_k = (tid >> 2) & 7, mn_k = (tid & 3) + 4 * (tid >> 5);      // k-contiguous map: (k-quad, mn), slots 32 mn apart
+  const uint32_t kq_m = tid >> 5, q_m = tid & 31;                               // mn-contiguous map: (k-quad, mn-quad), slots = the 4 k
+  uint32_t ea, eb, wa[4], wb[4];
+  const uint32_t a_slot = AMC ? a_ld : 32u * a_ld, a_round = AMC ? 32u * a_ld : 32u;
+  const uint32_t b_slot = BMC ? b_ld : 32u * b_ld, b_round = BMC ? 32u * b_ld : 32u;
+  if (AMC) {
+    ea = (uint32_t)(kb + 4 * kq_m) * a_ld + (uint32_t)m0 + 4 * q_m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wa[j] = 4 * (kq_m * 128 + ((4 * q_m) ^ ((kq_m & 3) << 2)) + (j ^ ((q_m >> 2) & 3)));
+  } else {
+    ea = (uint32_t)(m0 + mn_k) * a_ld + (uint32_t)kb + 4 * kq_k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wa[i] = 4 * (kq_k * 128 + 32 * i + (mn_k ^ (mn_k >> 4) ^ ((i & 1) << 1) ^ ((kq_k & 3) << 2)));
+  }
+  if (BMC) {
+    eb = (uint32_t)(kb + 4 * kq_m) * b_ld + (uint32_t)n0 + 4 * q_m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wb[j] = 4096 + 4 * (kq_m * 128 + ((4 * q_m) ^ ((kq_m & 3) << 2)) + (j ^ ((q_m >> 2) & 3)));
+  } else {
+    eb = (uint32_t)(n0 + mn_k) * b_ld + (uint32_t)kb + 4 * kq_k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wb[i] = 4096 + 4 * (kq_k * 128 + 32 * i + (mn_k ^ (mn_k >> 4) ^ ((i & 1) << 1) ^ ((kq_k & 3) << 2)));
+  }
+  // fragment reads: lane base per (tile parity, k-group parity); the rest is an immediate offset
+  const uint32_t L0 = l31 ^ (l31 >> 4) ^ (h << 2);
+  uint32_t fa_[2][2], fb_[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      const uint32_t x = ((((wm0 >> 5) + i) & 1) << 1) ^ (gp << 3), y = ((((wn0 >> 5) + i) & 1) << 1) ^ (gp << 3);
+      fa_[i][gp] = 4 * (h * 128 + wm0 + 32 * i + (L0 ^ x));
+      fb_[i][gp] = 4096 + 4 * (h * 128 + wn0 + 32 * i + (L0 ^ y));
+    }
+  f32x4 ra[4], rb[4];          // (native vectors: whole-struct copies of HIP's float4 keep the array in scratch)
+  float ks[4] = {1.f, 1.f, 1.f, 1.f};
+  int kk = kb + 4 * (int)kq_m;
+  // (macros, not lambdas: the staging registers must stay plain register arrays)
+#define GMVAE_BIG_GLOAD()                                                                              \
+  {                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(A + ea + i * a_slot);   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Bp + eb + i * b_slot);  \
+    if (KS) {                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) ks[i] = kscale[kk + i];                            \
+      kk += 32;                                                                                        \
+    }                                                                                                  \
+    ea += a_round; eb += b_round;                                                                      \
+  }
+#define GMVAE_BIG_PUT(img_, w_, r_, MC_)                                                               \
+  if (!(MC_)) {                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>((img_) + w_[i]) = r_[i];  \
+  } else { /* 4 k x 4 mn in registers -> the 4 units (4 k of one mn each) */                           \
+    *reinterpret_cast<f32x4*>((img_) + w_[0]) = f32x4{r_[0].x, r_[1].x, r_[2].x, r_[3].x};      \
+    *reinterpret_cast<f32x4*>((img_) + w_[1]) = f32x4{r_[0].y, r_[1].y, r_[2].y, r_[3].y};      \
+    *reinterpret_cast<f32x4*>((img_) + w_[2]) = f32x4{r_[0].z, r_[1].z, r_[2].z, r_[3].z};      \
+    *reinterpret_cast<f32x4*>((img_) + w_[3]) = f32x4{r_[0].w, r_[1].w, r_[2].w, r_[3].w};      \
+  }
+#define GMVAE_BIG_LSTORE(buf_)                                                                         \
+  {                                                                                                    \
+    if (KS) {                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) { rb[i].x *= ks[i]; rb[i].y *= ks[i]; rb[i].z *= ks[i]; rb[i].w *= ks[i]; } \
+    }                                                                                                  \
+    if (CS) {                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) { cs4.x += rb[i].x; cs4.y += rb[i].y; cs4.z += rb[i].z; cs4.w += rb[i].w; } \
+    }                                                                                                  \
+    float* const img_w = lds + (buf_) * kBigBuf;                                                       \
+    GMVAE_BIG_PUT(img_w, wa, ra, AMC)                                                                  \
+    GMVAE_BIG_PUT(img_w, wb, rb, BMC)                                                                  \
+  }
+#define GMVAE_BIG_FREAD(FA_, FB_, g_)                                                                  \
+  {                                                                                                    \
+    FA_[0] = *reinterpret_cast<const f32x4*>(img + fa_[0][(g_) & 1] + 1024 * (g_));                   \
+    FB_[0] = *reinterpret_cast<const f32x4*>(img + fb_[0][(g_) & 1] + 1024 * (g_));                   \
+    FA_[1] = *reinterpret_cast<const f32x4*>(img + fa_[1][(g_) & 1] + 1024 * (g_));                   \
+    FB_[1] = *reinterpret_cast<const f32x4*>(img + fb_[1][(g_) & 1] + 1024 * (g_));                   \
+  }
+#define GMVAE_BIG_STEP(a0_, a1_, b0_, b1_)                                                             \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b0_, acc[0][0], 0, 0, 0);                      \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b1_, acc[0][1], 0, 0, 0);                      \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b0_, acc[1][0], 0, 0, 0);                      \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc[1][1], 0, 0, 0);
+#define GMVAE_BIG_MUL(FA_, FB_)                                                                        \
+  GMVAE_BIG_STEP(FA_[0].x, FA_[1].x, FB_[0].x, FB_[1].x)                                               \
+  GMVAE_BIG_STEP(FA_[0].y, FA_[1].y, FB_[0].y, FB_[1].y)                                               \
+  GMVAE_BIG_STEP(FA_[0].z, FA_[1].z, FB_[0].z, FB_[1].z)                                               \
+  GMVAE_BIG_STEP(FA_[0].w, FA_[1].w, FB_[0].w, FB_[1].w)
+  GMVAE_BIG_GLOAD();
+  GMVAE_BIG_LSTORE(0);
+  __syncthreads();
+  f32x4 pa[2], pb[2], qa[2], qb[2];     // fragments of the even / odd k-groups
+#pragma unroll 1
+  for (int c = 0; c < NC; ++c) {
+    const float* const img = lds + (c & 1) * kBigBuf;
+    const bool more = c + 1 < NC;
+    if (more) GMVAE_BIG_GLOAD();
+    GMVAE_BIG_FREAD(pa, pb, 0);
+    GMVAE_BIG_FREAD(qa, qb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    GMVAE_BIG_MUL(pa, pb);
+    __builtin_amdgcn_sched_barrier(0);
+    GMVAE_BIG_FREAD(pa, pb, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    GMVAE_BIG_MUL(qa, qb);
+    __builtin_amdgcn_sched_barrier(0);
+    GMVAE_BIG_FREAD(qa, qb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    GMVAE_BIG_MUL(pa, pb);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) GMVAE_BIG_LSTORE((c + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    GMVAE_BIG_MUL(qa, qb);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+#undef GMVAE_BIG_GLOAD
+#undef GMVAE_BIG_PUT
+#undef GMVAE_BIG_LSTORE
+#undef GMVAE_BIG_FREAD
+#undef GMVAE_BIG_STEP
+#undef GMVAE_BIG_MUL
+}
+
 // SP3 = 1: the instance that can run split3 problems (only the 128x128 configuration has one; a kernel of its own, because
 // the piece-product loop's registers would otherwise push the fp32 loop below two workgroups per CU)
-template <class C, int SP3 = 0>
+// BIG = 1: the 128x128 instance for launches in which EVERY tile is interior, fp32 and made of whole rounds (the host
+// checks: big_eligible); its only main loop is big_rounds -- a kernel of its own so that the general loop's loaders do
+// not share its register budget.
+template <class C, int SP3 = 0, int BIG = 0>
 __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(const Launch L) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   constexpr int kBK = C::BK;
@@ -461,7 +608,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
   float csum = 0.f;
   constexpr int CSG = kThreads / C::BN;          // k groups of the column-sum threads
   const int cs_n = tid % C::BN, cs_k = tid / C::BN;
-  bool did_bf16 = false, did_split = false;
+  bool did_bf16 = false, did_split = false, did_big = false;
   float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (C::BM == 64 && C::BN == 64 && C::BK == 64) {
     if (L.p[pi].xbf16) {
@@ -631,6 +778,28 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
         continue;
       }
     }
+    if constexpr (BIG) {
+      static_assert(!SP3 && C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2, "big rounds: 128x128x32");
+      __syncthreads();        // LDS is free
+      if (sgi == 0) GMVAE_GSTAMP(6);
+      const float* const Af = static_cast<const float*>(a_ptr);
+      const float* const Bf = static_cast<const float*>(b_ptr);
+#define GMVAE_BIG(AMC_, BMC_, KS_, CS_) \
+  big_rounds<AMC_, BMC_, KS_, CS_>(lds, Af, (uint32_t)a_ld, Bf, (uint32_t)b_ld, kscale, m0, n0, kb, NC, tid, lane, wm0, wn0, acc, cs4)
+      if (!b_mc) {
+        if (a_mc) GMVAE_BIG(true, false, false, false); else GMVAE_BIG(false, false, false, false);
+      } else if (kscale) {
+        if (do_colsum) { if (a_mc) GMVAE_BIG(true, true, true, true); else GMVAE_BIG(false, true, true, true); }
+        else { if (a_mc) GMVAE_BIG(true, true, true, false); else GMVAE_BIG(false, true, true, false); }
+      } else {
+        if (do_colsum) { if (a_mc) GMVAE_BIG(true, true, false, true); else GMVAE_BIG(false, true, false, true); }
+        else { if (a_mc) GMVAE_BIG(true, true, false, false); else GMVAE_BIG(false, true, false, false); }
+      }
+#undef GMVAE_BIG
+      if (do_colsum) did_big = true;
+      if (sgi == 0) GMVAE_GSTAMP(1);
+      continue;
+    }
     __syncthreads();          // LDS is free (first segment: trivially; second: previous loop finished)
     if (sgi == 0) GMVAE_GSTAMP(6);
     GMVAE_GLOAD(0);
@@ -689,7 +858,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
           Cs[row * C::LDC + wn0 + j * 32 + l31] = acc[i][j][r];
         }
     if (do_colsum) {
-      if (did_bf16 || did_split) *reinterpret_cast<float4*>(lds + C::CST + 4 * tid) = cs4;     // (k rows tid>>4 + 16i, columns 4(tid&15)..)
+      if (did_bf16 || did_split || did_big) *reinterpret_cast<float4*>(lds + C::CST + 4 * tid) = cs4;     // (k rows tid>>4 + 16i, columns 4(tid&15)..)
       else lds[C::CST + tid] = csum;
     }
   }
@@ -699,6 +868,9 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
     if (did_split) {                               // column tid: the 8 threads 4 (tid >> 2) + a + 128 b staged its quad
 #pragma unroll
       for (int g = 0; g < 8; ++g) v += lds[C::CST + 4 * (4 * (tid >> 2) + (g & 3) + 128 * (g >> 2)) + (tid & 3)];
+    } else if (did_big) {                          // column tid: threads (tid >> 2) + 32 g hold its quad (k-quads g)
+#pragma unroll
+      for (int g = 0; g < 8; ++g) v += lds[C::CST + 4 * ((tid >> 2) + 32 * g) + (tid & 3)];
     } else if (did_bf16) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) v += lds[C::CST + 4 * ((tid >> 2) + 16 * g) + (tid & 3)];

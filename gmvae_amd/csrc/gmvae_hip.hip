@@ -390,6 +390,24 @@ static int tile_up(Launch& L) {
   return t;
 }
 
+// every tile of the launch can take gemm.hpp's big rounds: interior tiles of fp32 operands read 16 bytes at a time, k
+// ranges made of whole 32-deep rounds, per-k scale / column sums only beside an mn-contiguous operand b
+static bool big_eligible(const Launch& L) {
+  for (int i = 0; i < L.nprob; ++i) {
+    const Problem& p = L.p[i];
+    if (p.xbf16 || p.M % 128 || p.N % 128) return false;
+    for (int s = 0; s < p.nseg; ++s) {
+      const Segment& sg = p.seg[s];
+      if (sg.a.is_u8 || sg.b.is_u8 || !sg.a.vec_ok || !sg.b.vec_ok || sg.a.row_div != 1 || sg.b.row_div != 1) return false;
+      if (sg.a.n_mn < p.M || sg.b.n_mn < p.N || sg.K % 32) return false;
+      if ((sg.kscale || p.colsum_out) && sg.b.k_contig) return false;
+      const unsigned long long ext_a = sg.a.n_mn > sg.K ? sg.a.n_mn : sg.K, ext_b = sg.b.n_mn > sg.K ? sg.b.n_mn : sg.K;
+      if (ext_a * sg.a.ld >= (1ull << 32) || ext_b * sg.b.ld >= (1ull << 32)) return false;      // 32-bit element offsets
+    }
+  }
+  return true;
+}
+
 // returns the chosen tile configuration (0 small, 1 medium, 2 large)
 static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsigned long long* dbg = nullptr) {
   if (g.L.nprob == 0) return 0;
@@ -414,7 +432,9 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
     const int sp3 = sp ? (atoi(sp) == 9 ? 2 : (atoi(sp) ? 1 : 0)) : 0;
     for (int i = 0; i < g.L.nprob; ++i) g.L.p[i].split3 = sp3;
     tiles = g.L.total_tiles = tile_up<CfgL>(g.L);
+    const bool no_big = getenv("GMVAE_NO_BIG") != nullptr;      // diagnostic / A-B: the general loop
     if (sp3) hipLaunchKernelGGL((gemm_grouped<CfgL, 1>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
+    else if (!no_big && big_eligible(g.L)) hipLaunchKernelGGL((gemm_grouped<CfgL, 0, 1>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
     else hipLaunchKernelGGL(gemm_grouped<CfgL>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
   } else if (cfg == 3) {
     tiles = g.L.total_tiles = tile_up<CfgM1>(g.L);

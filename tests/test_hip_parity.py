@@ -108,6 +108,40 @@ def test_gemm_split3_bf16_piece_products(H, monkeypatch, terms, trans, M, N, K):
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=3e-5 * math.sqrt(K))
 
 
+@pytest.mark.parametrize("trans,M,N,K,ns", [(0, 256, 384, 160, 1), (1, 384, 128, 96, 1), (2, 128, 256, 1024, 2),
+                                            (2, 256, 128, 320, 3), (0, 128, 128, 32, 1)])
+def test_gemm_big_rounds_instance(H, monkeypatch, trans, M, N, K, ns):
+    """Launches whose tiles are all interior 128x128 tiles of fp32 operands with whole 32-deep rounds run the big-round
+    instance (gemm.hpp big_rounds: swizzled [k/4][mn][4] LDS images, 16-byte fragment reads): every operand orientation
+    (NN / NT / TN with split-K and the bias-gradient column sums) against fp64 AND against the general loop."""
+    L = _L()
+    rng = np.random.default_rng(M + 3 * N + 7 * K + trans)
+    if trans == 0:
+        A, W = rng.normal(size=(M, K)).astype(np.float32), rng.normal(size=(K, N)).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64)
+        shape = (M, N)
+    elif trans == 1:
+        A, W = rng.normal(size=(M, K)).astype(np.float32), rng.normal(size=(N, K)).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64).T
+        shape = (M, N)
+    else:
+        A, W = rng.normal(size=(K, M)).astype(np.float32), rng.normal(size=(K, N)).astype(np.float32)
+        ref = np.concatenate([A.astype(np.float64).T @ W, W.astype(np.float64).sum(0, keepdims=True)], 0)
+        shape = (ns, M + 1, N)
+    Ad, Wd = H.dev(A), H.dev(W)
+    outs = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("GMVAE_NO_BIG", "1")
+        Cd = torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
+        L.check(L.lib.gmvae_gemm_test(L.ptr(Ad), 0, L.ptr(Wd), L.ptr(Wd) if trans == 2 else None, L.ptr(Cd), M, N, K, trans, 0,
+                                      2, ns, L.current_stream()), "gemm_test")
+        got = Cd.cpu().numpy().astype(np.float64)
+        outs.append(got.sum(axis=0) if trans == 2 else got)
+    np.testing.assert_allclose(outs[0], ref, rtol=2e-5, atol=3e-5 * math.sqrt(K))
+    np.testing.assert_allclose(outs[0], outs[1], rtol=2e-5, atol=3e-5 * math.sqrt(K))
+
+
 # ------------------------------------------------------------ full step
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
 
