@@ -122,6 +122,7 @@ typedef Cfg<128, 128, 32, 2, 2, 1> CfgL;    // MFMA-bound: 64x64 per wave
 // (Single-round variants -- BK = the whole k range of a split, one batch of loads -- were measured and dropped:
 // the staging phase of these launches scales with the bytes requested, not with the number of round trips.)
 
+__device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 __device__ __forceinline__ float sigmoidf_(float v) {
   float e = __expf(-fabsf(v));
   float r = 1.0f / (1.0f + e);
@@ -395,13 +396,17 @@ __device__ __forceinline__ void split_round(const unsigned short* __restrict__ A
 // of the next round sit in front of the last 16 MFMAs -- nothing but the barrier is outside the matrix pipe's shadow.
 constexpr int kBigBuf = 8192;       // floats per staging buffer: A image | B image
 
-template <bool AMC, bool BMC, bool KS, bool CS>
+template <bool AMC, bool BMC>
 __device__ __forceinline__ void big_rounds(float* __restrict__ lds, const float* __restrict__ A, const uint32_t a_ld,
                                            const float* __restrict__ Bp, const uint32_t b_ld,
                                            const float* __restrict__ kscale, const int m0, const int n0, const int kb,
                                            const int NC, const int tid, const int lane, const int wm0, const int wn0,
                                            f32x16 (&acc)[2][2], float4& cs4) {
   const int h = lane >> 5, l31 = lane & 31;
+  // the per-k scale and the column sums ride only beside an mn-contiguous b; both are wave-uniform run-time options (as
+  // template parameters they made ten copies of this loop in one kernel)
+  const bool KS = BMC && kscale != nullptr;
+  constexpr bool CS = BMC;
   // staging: element offsets of slot 0, slot stride, round stride; LDS float offsets of this thread's units
   const uint32_t kq_k = (tid >> 2) & 7, mn_k = (tid & 3) + 4 * (tid >> 5);      // k-contiguous map: (k-quad, mn), slots 32 mn apart
   const uint32_t kq_m = tid >> 5, q_m = tid & 31;                               // mn-contiguous map: (k-quad, mn-quad), slots = the 4 k
@@ -472,57 +477,74 @@ __device__ __forceinline__ void big_rounds(float* __restrict__ lds, const float*
     GMVAE_BIG_PUT(img_w, wa, ra, AMC)                                                                  \
     GMVAE_BIG_PUT(img_w, wb, rb, BMC)                                                                  \
   }
-#define GMVAE_BIG_FREAD(FA_, FB_, g_)                                                                  \
-  {                                                                                                    \
-    FA_[0] = *reinterpret_cast<const f32x4*>(img + fa_[0][(g_) & 1] + 1024 * (g_));                   \
-    FB_[0] = *reinterpret_cast<const f32x4*>(img + fb_[0][(g_) & 1] + 1024 * (g_));                   \
-    FA_[1] = *reinterpret_cast<const f32x4*>(img + fa_[1][(g_) & 1] + 1024 * (g_));                   \
-    FB_[1] = *reinterpret_cast<const f32x4*>(img + fb_[1][(g_) & 1] + 1024 * (g_));                   \
-  }
-#define GMVAE_BIG_STEP(a0_, a1_, b0_, b1_)                                                             \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b0_, acc[0][0], 0, 0, 0);                      \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b1_, acc[0][1], 0, 0, 0);                      \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b0_, acc[1][0], 0, 0, 0);                      \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc[1][1], 0, 0, 0);
-#define GMVAE_BIG_MUL(FA_, FB_)                                                                        \
-  GMVAE_BIG_STEP(FA_[0].x, FA_[1].x, FB_[0].x, FB_[1].x)                                               \
-  GMVAE_BIG_STEP(FA_[0].y, FA_[1].y, FB_[0].y, FB_[1].y)                                               \
-  GMVAE_BIG_STEP(FA_[0].z, FA_[1].z, FB_[0].z, FB_[1].z)                                               \
-  GMVAE_BIG_STEP(FA_[0].w, FA_[1].w, FB_[0].w, FB_[1].w)
+#define GMVAE_BIG_RD(dst_, base_, i_, g_) dst_[i_] = *reinterpret_cast<const f32x4*>(img + base_[i_][(g_) & 1] + 1024 * (g_));
+#define GMVAE_BIG_STEP(FA_, FB_, c_)                                                                    \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA_[0].c_, FB_[0].c_, acc[0][0], 0, 0, 0);           \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA_[0].c_, FB_[1].c_, acc[0][1], 0, 0, 0);           \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA_[1].c_, FB_[0].c_, acc[1][0], 0, 0, 0);           \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA_[1].c_, FB_[1].c_, acc[1][1], 0, 0, 0);           \
+  __builtin_amdgcn_sched_barrier(0);
+  // one k-group's 16 MFMAs with the NEXT group's 4 fragment reads issued between its steps (each in the shadow of
+  // the 4 MFMAs before it)
+#define GMVAE_BIG_MUL_RD(FA_, FB_, NA_, NB_, g_)                                                        \
+  GMVAE_BIG_STEP(FA_, FB_, x) GMVAE_BIG_RD(NA_, fa_, 0, g_) __builtin_amdgcn_sched_barrier(0);          \
+  GMVAE_BIG_STEP(FA_, FB_, y) GMVAE_BIG_RD(NB_, fb_, 0, g_) __builtin_amdgcn_sched_barrier(0);          \
+  GMVAE_BIG_STEP(FA_, FB_, z) GMVAE_BIG_RD(NA_, fa_, 1, g_) __builtin_amdgcn_sched_barrier(0);          \
+  GMVAE_BIG_STEP(FA_, FB_, w) GMVAE_BIG_RD(NB_, fb_, 1, g_) __builtin_amdgcn_sched_barrier(0);
+  f32x4 pa[2], pb[2], qa[2], qb[2];     // fragments of the even / odd k-groups
   GMVAE_BIG_GLOAD();
   GMVAE_BIG_LSTORE(0);
   __syncthreads();
-  f32x4 pa[2], pb[2], qa[2], qb[2];     // fragments of the even / odd k-groups
+  {
+    const float* const img = lds;
+    GMVAE_BIG_RD(pa, fa_, 0, 0) GMVAE_BIG_RD(pb, fb_, 0, 0) GMVAE_BIG_RD(pa, fa_, 1, 0) GMVAE_BIG_RD(pb, fb_, 1, 0)
+  }
 #pragma unroll 1
   for (int c = 0; c < NC; ++c) {
-    const float* const img = lds + (c & 1) * kBigBuf;
     const bool more = c + 1 < NC;
     if (more) GMVAE_BIG_GLOAD();
-    GMVAE_BIG_FREAD(pa, pb, 0);
-    GMVAE_BIG_FREAD(qa, qb, 1);
     __builtin_amdgcn_sched_barrier(0);
-    GMVAE_BIG_MUL(pa, pb);
+    {
+      const float* const img = lds + (c & 1) * kBigBuf;
+      GMVAE_BIG_MUL_RD(pa, pb, qa, qb, 1)
+      GMVAE_BIG_MUL_RD(qa, qb, pa, pb, 2)
+      GMVAE_BIG_MUL_RD(pa, pb, qa, qb, 3)
+    }
+    // last k-group: the next round's staging stores, the round's barrier and the next round's first fragment reads all
+    // sit between its steps (every wave finished reading the buffer being overwritten before the PREVIOUS barrier)
+    // (the MFMA steps stay outside the uniform branches: inside them the compiler keeps two copies of the accumulators)
+    float* const img_w = lds + ((c + 1) & 1) * kBigBuf;
+    GMVAE_BIG_STEP(qa, qb, x)
+    if (more) {
+      if (KS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { rb[i].x *= ks[i]; rb[i].y *= ks[i]; rb[i].z *= ks[i]; rb[i].w *= ks[i]; }
+      }
+      if (CS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { cs4.x += rb[i].x; cs4.y += rb[i].y; cs4.z += rb[i].z; cs4.w += rb[i].w; }
+      }
+      GMVAE_BIG_PUT(img_w, wa, ra, AMC)
+    }
     __builtin_amdgcn_sched_barrier(0);
-    GMVAE_BIG_FREAD(pa, pb, 2);
+    GMVAE_BIG_STEP(qa, qb, y)
+    if (more) { GMVAE_BIG_PUT(img_w, wb, rb, BMC) }
     __builtin_amdgcn_sched_barrier(0);
-    GMVAE_BIG_MUL(qa, qb);
+    GMVAE_BIG_STEP(qa, qb, z)
+    if (more) {
+      __syncthreads();
+      const float* const img = img_w;
+      GMVAE_BIG_RD(pa, fa_, 0, 0) GMVAE_BIG_RD(pb, fb_, 0, 0) GMVAE_BIG_RD(pa, fa_, 1, 0) GMVAE_BIG_RD(pb, fb_, 1, 0)
+    }
     __builtin_amdgcn_sched_barrier(0);
-    GMVAE_BIG_FREAD(qa, qb, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    GMVAE_BIG_MUL(pa, pb);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) GMVAE_BIG_LSTORE((c + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    GMVAE_BIG_MUL(qa, qb);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
+    GMVAE_BIG_STEP(qa, qb, w)
   }
+#undef GMVAE_BIG_RD
+#undef GMVAE_BIG_MUL_RD
 #undef GMVAE_BIG_GLOAD
 #undef GMVAE_BIG_PUT
 #undef GMVAE_BIG_LSTORE
-#undef GMVAE_BIG_FREAD
 #undef GMVAE_BIG_STEP
-#undef GMVAE_BIG_MUL
 }
 
 // SP3 = 1: the instance that can run split3 problems (only the 128x128 configuration has one; a kernel of its own, because
@@ -784,16 +806,12 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
       if (sgi == 0) GMVAE_GSTAMP(6);
       const float* const Af = static_cast<const float*>(a_ptr);
       const float* const Bf = static_cast<const float*>(b_ptr);
-#define GMVAE_BIG(AMC_, BMC_, KS_, CS_) \
-  big_rounds<AMC_, BMC_, KS_, CS_>(lds, Af, (uint32_t)a_ld, Bf, (uint32_t)b_ld, kscale, m0, n0, kb, NC, tid, lane, wm0, wn0, acc, cs4)
+#define GMVAE_BIG(AMC_, BMC_) \
+  big_rounds<AMC_, BMC_>(lds, Af, (uint32_t)a_ld, Bf, (uint32_t)b_ld, kscale, m0, n0, kb, NC, tid, lane, wm0, wn0, acc, cs4)
       if (!b_mc) {
-        if (a_mc) GMVAE_BIG(true, false, false, false); else GMVAE_BIG(false, false, false, false);
-      } else if (kscale) {
-        if (do_colsum) { if (a_mc) GMVAE_BIG(true, true, true, true); else GMVAE_BIG(false, true, true, true); }
-        else { if (a_mc) GMVAE_BIG(true, true, true, false); else GMVAE_BIG(false, true, true, false); }
+        if (a_mc) GMVAE_BIG(true, false); else GMVAE_BIG(false, false);
       } else {
-        if (do_colsum) { if (a_mc) GMVAE_BIG(true, true, false, true); else GMVAE_BIG(false, true, false, true); }
-        else { if (a_mc) GMVAE_BIG(true, true, false, false); else GMVAE_BIG(false, true, false, false); }
+        if (a_mc) GMVAE_BIG(true, true); else GMVAE_BIG(false, true);
       }
 #undef GMVAE_BIG
       if (do_colsum) did_big = true;
@@ -913,6 +931,47 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
         }
         *reinterpret_cast<float4*>(dst0 + (long long)row * ldc + 4 * c4) = v4;
       }
+    } else if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && al16(Cout + soff) && (!bias || al16(bias)) &&
+               (!addsrc || ((ld_add & 3) == 0 && al16(addsrc))) && (!mask || ((ld_mask & 3) == 0 && al16(mask)))) {
+      // interior tile with options: 16-byte loads of every per-element option, FOUR passes' loads in flight at a time
+      // (one pass at a time, each pass waits a full memory round trip: ~20 % of a 16-round tile at the config-5 sizes)
+      constexpr int RPP = kThreads / GPR;        // rows per pass; the column group is the same in every pass
+      constexpr int PB = PASSES >= 4 ? 4 : PASSES;
+      const int c4 = tid % GPR, r0 = tid / GPR, nb = n0 + 4 * c4;
+      const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int pb = 0; pb < PASSES; pb += PB) {
+        float4 a4[PB], k4[PB];
+        float rs[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+          const int m = m0 + r0 + RPP * (pb + q);
+          a4[q] = addsrc ? *reinterpret_cast<const float4*>(addsrc + (long long)(m / add_div) * ld_add + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+          k4[q] = mask ? *reinterpret_cast<const float4*>(mask + (long long)m * ld_mask + nb) : make_float4(1.f, 1.f, 1.f, 1.f);
+          rs[q] = rowscale ? rowscale[m] : 1.f;
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+          const int row = r0 + RPP * (pb + q);
+          float4 v4 = *reinterpret_cast<const float4*>(lds + row * C::LDC + 4 * c4);
+#pragma unroll
+          for (int w = 1; w < C::WK; ++w) {
+            const float4 o = *reinterpret_cast<const float4*>(lds + (w * C::BM + row) * C::LDC + 4 * c4);
+            v4.x += o.x; v4.y += o.y; v4.z += o.z; v4.w += o.w;
+          }
+          float v[4] = {v4.x + b4.x + a4[q].x + addconst, v4.y + b4.y + a4[q].y + addconst, v4.z + b4.z + a4[q].z + addconst,
+                        v4.w + b4.w + a4[q].w + addconst};
+          const float kk[4] = {k4[q].x, k4[q].y, k4[q].z, k4[q].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x = v[j];
+            if (relu) x = fmaxf(x, 0.f);
+            x = kk[j] > 0.f ? x : 0.f;
+            v[j] = x * rs[q];
+          }
+          *reinterpret_cast<float4*>(Cout + soff + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
     } else
 #pragma unroll 1
     for (int ps = 0; ps < PASSES; ++ps) {
@@ -954,6 +1013,50 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
     const unsigned char* xp = L.p[pi].x;
     float* part = L.p[pi].part;
     const int ldx = L.p[pi].ldx, x_div = L.p[pi].x_div, nparts = L.p[pi].nparts;
+    if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && (!Cout || al16(Cout)) && al16(bias) && (ldx & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(xp) & 3) == 0) {
+      // interior tile: the bias quad once, the 4 target bytes of a pass as one word, four passes' loads in flight
+      constexpr int RPP = kThreads / GPR;
+      constexpr int PB = PASSES >= 4 ? 4 : PASSES;
+      const int c4 = tid % GPR, r0 = tid / GPR, nb = n0 + 4 * c4;
+      const float4 b4 = *reinterpret_cast<const float4*>(bias + nb);
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int pb = 0; pb < PASSES; pb += PB) {
+        unsigned xw[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+          const int m = m0 + r0 + RPP * (pb + q);
+          xw[q] = *reinterpret_cast<const unsigned*>(xp + (long long)(m / x_div) * ldx + nb);
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+          const int row = r0 + RPP * (pb + q);
+          float4 v4 = *reinterpret_cast<const float4*>(lds + row * C::LDC + 4 * c4);
+#pragma unroll
+          for (int w = 1; w < C::WK; ++w) {
+            const float4 o = *reinterpret_cast<const float4*>(lds + (w * C::BM + row) * C::LDC + 4 * c4);
+            v4.x += o.x; v4.y += o.y; v4.z += o.z; v4.w += o.w;
+          }
+          float v[4] = {v4.x, v4.y, v4.z, v4.w};
+          float rsum = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float lam = v[j] + bb[j] + addconst;
+            const float xv = (float)((xw[q] >> (8 * j)) & 0xffu);
+            const float e = __expf(-fabsf(lam));
+            const float rcp = __builtin_amdgcn_rcpf(1.f + e);
+            const float sp = fmaxf(lam, 0.f) - __logf(rcp);
+            rsum += xv * lam - sp;
+            v[j] = (lam >= 0.f ? rcp : e * rcp) - xv;
+          }
+          if (Cout) *reinterpret_cast<float4*>(Cout + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+          for (int o = GPR / 2; o > 0; o >>= 1) rsum += __shfl_xor(rsum, o, 64);
+          if (c4 == 0) part[(long long)(m0 + row) * nparts + tn] = rsum;
+        }
+      }
+    } else
 #pragma unroll 1
     for (int ps = 0; ps < PASSES; ++ps) {
       const int gidx = tid + ps * kThreads;

@@ -408,6 +408,43 @@ static bool big_eligible(const Launch& L) {
   return true;
 }
 
+// Estimated duration (us) of a grouped launch under tile configuration C: the larger of its longest tile running alone
+// (rounds x the round time of a workgroup that has its CU to itself -- latency-bound) and of all tiles sharing the 256 CUs
+// (rounds x the round time of a busy CU -- matrix-pipe-bound, padding of partial tiles included through the tile counts;
+// plus a tail when the tiles do not all fit the chip at once).
+// Round times measured with tools/gemm_bench.py / gemm_c5.py (profiles/round2_notes.md): a 128x128x32 round is 4096 MFMA
+// cycles per wave and runs at 0.8 of that busy on the big-round instance (0.64 on the general loop), a 64x64x64 round
+// 2048 cycles at 0.55, a 32x32x128 round 1024 cycles at 0.3.  (Round 1 picked the largest tile that gave >= 192 tiles:
+// a 64 x 512 weight gradient over 25600 rows then ran as 64 tiles of 50 rounds -- 214 us for 3.3 GFLOP.)
+template <class C>
+static double launch_cost(Launch& t, bool big) {
+  const bool isL = C::BM == 128, isM = C::BM == 64;
+  const double busy = isL ? (big ? 2.2 : 2.8) : (isM ? 1.6 : 1.5);        // us per tile-round, CU shared
+  const double alone = isL ? (big ? 2.5 : 3.7) : (isM ? 1.9 : 1.36);      // us per round, one workgroup per CU
+  const double tile_alone = isL ? 4.0 : (isM ? 2.5 : 2.0), tile_busy = isL ? 1.0 : (isM ? 0.4 : 0.2);   // prologue + epilogue
+  tile_up<C>(t);
+  double lat = 0, thr = 0;
+  for (int i = 0; i < t.nprob; ++i) {
+    const Problem& p = t.p[i];
+    double rounds = 0;
+    for (int s = 0; s < p.nseg; ++s) {
+      const int kper = (p.seg[s].K + p.splits - 1) / p.splits;
+      rounds += (kper + C::BK - 1) / C::BK;
+    }
+    const double tiles = (double)p.tiles_m * p.tiles_n * p.splits;
+    const double l = rounds * alone + tile_alone;
+    lat = l > lat ? l : lat;
+    thr += tiles * (rounds * busy + tile_busy);
+  }
+  thr /= 256.0;
+  double tiles_all = 0;
+  for (int i = 0; i < t.nprob; ++i) tiles_all += (double)t.p[i].tiles_m * t.p[i].tiles_n * t.p[i].splits;
+  const double slots = 256.0 * (isL ? 2 : 3);
+  // more tiles than resident workgroups: the last, partly filled wave of tiles adds about half a lone tile
+  if (tiles_all > slots) return thr + 0.5 * lat;
+  return lat > thr ? lat : thr;
+}
+
 // returns the chosen tile configuration (0 small, 1 medium, 2 large)
 static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsigned long long* dbg = nullptr) {
   if (g.L.nprob == 0) return 0;
@@ -416,9 +453,14 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
   if (cfg < 0) cfg = cx.force_cfg;
   if (cfg < 0) {
     Launch t = g.L;
-    if (tile_up<CfgL>(t) >= 192) cfg = 2;
-    else if (tile_up<CfgM>(t) >= 160) cfg = 1;
-    else cfg = 0;
+    if (getenv("GMVAE_CFG_BY_TILES")) {            // (the round-1 rule, kept for A/B)
+      if (tile_up<CfgL>(t) >= 192) cfg = 2;
+      else if (tile_up<CfgM>(t) >= 160) cfg = 1;
+      else cfg = 0;
+    } else {
+      const double tl = launch_cost<CfgL>(t, big_eligible(t)), tm = launch_cost<CfgM>(t, false), ts = launch_cost<CfgS>(t, false);
+      cfg = (tl <= tm && tl <= ts) ? 2 : (tm <= ts ? 1 : 0);
+    }
   }
   double fl = 0;
   for (int i = 0; i < g.L.nprob; ++i)
