@@ -734,8 +734,25 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
   }
   const int Qm = mega_q(B);
-  const bool fl = a.imgs_ready && ml.fl_ok && Qm == 4 && (B + kPanel - 1) / kPanel * 4 <= n_cu &&
-                  (a.adam_p == a.params || a.dp_images) && a.step_dev && gen_eps && w.xfl && !getenv("GMVAE_NO_FL");
+  bool fl = ml.fl_ok && Qm == 4 && (B + kPanel - 1) / kPanel * 4 <= n_cu &&
+            (a.adam_p == a.params || a.dp_images) && a.step_dev && gen_eps && w.xfl && !getenv("GMVAE_NO_FL");
+  if (fl && !a.imgs_ready) {
+    // first step of a train graph / an eager step: the weight images straight from the parameters (kernels.hpp img_build),
+    // then the same launches as every later step
+    ImgPlan pl;
+    plan_images(d, model, L, w, ml, P, pl);
+    if (!pl.map_ok || getenv("GMVAE_NO_IMG_BUILD")) fl = false;
+    else {
+      ImgScatter sc;
+      memset(&sc, 0, sizeof(sc));
+      sc.nmap = pl.nmap; sc.lo = pl.lo; sc.hi = pl.hi; sc.epoch_word = w.sync;
+      sc.img[0] = w.img_m; sc.img[1] = w.dimg; sc.img[2] = w.img2f; sc.img[3] = w.img2b; sc.img[4] = w.dimg2;
+      for (int i = 0; i < pl.nmap; ++i) { sc.map[i] = pl.map[i]; sc.mbegin[i] = pl.map[i].begin; sc.mend[i] = pl.map[i].end; }
+      hipLaunchKernelGGL(img_build, dim3((unsigned)((L.P_pad / 4 + 255) / 256)), dim3(256), 0, st, P, (long long)L.P_pad, sc);
+      cx.check();
+      cx.mark("img_build", 0);
+    }
+  }
   if (!fl) {  // P1: first layer(s) over the uint8 batch as single-round split-K partials + auxiliary workgroups
     Group g;
     Problem p0 = p_nn(a.x, true, D, P + E.w[0], H, B, H, D, w.s1, H2, nullptr, false);
@@ -1273,7 +1290,8 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       float* out = w.dbuf[pb];
       g.add(p_nt(dcur, G.dim[i + 1], P + G.w[i], G.dim[i + 1], R, G.dim[i], G.dim[i + 1], out, G.dim[i], w.hg[i],
                  G.dim[i]));
-      if (!prior_done) { g.add(prior_dw()); prior_done = true; }
+      // (the prior's small weight gradient rides on the layer-0 launch below: here it would be the one problem that keeps
+      // a launch of 128-aligned problems off the big-round GEMM instance)
       launch_group(cx, g, "bwd_enc_gmm");
       dcur = out;
       pb ^= 1;

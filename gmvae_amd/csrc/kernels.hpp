@@ -870,6 +870,42 @@ __global__ __launch_bounds__(256) void adam_tf_img(float* __restrict__ p, float*
   }
 }
 
+// The weight images of the in-launch schedule from the parameters as they are (no update): what the FIRST step of a
+// train graph -- or an eager step -- runs before mega2_fwd_bwd / mega_fwd_bwd<FLT = 1>, so that every step of a graph is
+// the steady-state pair of launches (later steps find the images left by the optimizer's scatter).  Also opens the step:
+// bumps the hand-off tag like the first launch of the general schedule.
+__global__ __launch_bounds__(256) void img_build(const float* __restrict__ p, long long P, const ImgScatter sc) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && sc.epoch_word) *sc.epoch_word += 1u;
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int blo = (int)blockIdx.x * 1024, bhi = blo + 1024;
+  if (i4 >= P || sc.nmap <= 0 || bhi <= sc.lo || blo >= sc.hi) return;
+  const float4 pp = *reinterpret_cast<const float4*>(p + i4);
+  const float pa[4] = {pp.x, pp.y, pp.z, pp.w};
+  unsigned hit = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxImgMap; ++k)
+    if (k < sc.nmap && bhi > sc.mbegin[k] && blo < sc.mend[k]) hit |= 1u << k;
+  while (hit) {
+    const int k = __builtin_ctz(hit);
+    hit &= hit - 1;
+    const int begin = sc.map[k].begin, end = sc.map[k].end, cols = sc.map[k].cols, kind = sc.map[k].kind;
+    const int base = sc.map[k].base, ld = sc.map[k].ld, chunk = sc.map[k].chunk;
+    const unsigned magic = sc.map[k].magic;
+    float* const img = sc.img[sc.map[k].which];
+    if (i4 + 3 < begin || i4 >= end) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = (int)i4 + j;
+      if (idx >= begin && idx < end) {
+        const unsigned off = (unsigned)(idx - begin);
+        const int r = (int)(((unsigned long long)off * magic) >> 32);
+        const int c = (int)off - r * cols;
+        img[img_dst(kind, base, ld, chunk, r, c)] = pa[j];
+      }
+    }
+  }
+}
+
 // auxiliary work without a GEMM: the image tasks of the first step of a train graph
 __global__ __launch_bounds__(kThreads) void aux_only(const Aux ax) { aux_block(ax, (int)blockIdx.x); }
 
