@@ -933,10 +933,11 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
       }
     } else if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && al16(Cout + soff) && (!bias || al16(bias)) &&
                (!addsrc || ((ld_add & 3) == 0 && al16(addsrc))) && (!mask || ((ld_mask & 3) == 0 && al16(mask)))) {
-      // interior tile with options: 16-byte loads of every per-element option, FOUR passes' loads in flight at a time
-      // (one pass at a time, each pass waits a full memory round trip: ~20 % of a 16-round tile at the config-5 sizes)
+      // interior tile with options: 16-byte loads of every per-element option, ALL passes' loads in flight together (the
+      // accumulators are staged, their registers are free): one pass at a time, each pass waits a full memory round trip --
+      // ~20 % of a 16-round tile at the config-5 sizes, most of a 4-round one
       constexpr int RPP = kThreads / GPR;        // rows per pass; the column group is the same in every pass
-      constexpr int PB = PASSES >= 4 ? 4 : PASSES;
+      constexpr int PB = PASSES;          // every pass's loads in flight together: ONE memory round trip per tile
       const int c4 = tid % GPR, r0 = tid / GPR, nb = n0 + 4 * c4;
       const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -1015,9 +1016,9 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
     const int ldx = L.p[pi].ldx, x_div = L.p[pi].x_div, nparts = L.p[pi].nparts;
     if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && (!Cout || al16(Cout)) && al16(bias) && (ldx & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(xp) & 3) == 0) {
-      // interior tile: the bias quad once, the 4 target bytes of a pass as one word, four passes' loads in flight
+      // interior tile: the bias quad once, the 4 target bytes of a pass as one word, all passes' loads in flight
       constexpr int RPP = kThreads / GPR;
-      constexpr int PB = PASSES >= 4 ? 4 : PASSES;
+      constexpr int PB = PASSES;          // every pass's loads in flight together: ONE memory round trip per tile
       const int c4 = tid % GPR, r0 = tid / GPR, nb = n0 + 4 * c4;
       const float4 b4 = *reinterpret_cast<const float4*>(bias + nb);
       const float bb[4] = {b4.x, b4.y, b4.z, b4.w};

@@ -89,12 +89,14 @@ __global__ void y_head_fwd(const float* __restrict__ logits, const float* __rest
 // Backward of the head above:
 //   da = y*(dy - sum_k y dy);  dlogits_b = sum_s da/T + pi*(log pi - sum pi log pi)
 // dy already carries the IWAE row weight; the entropy term has weight sum_s rw = 1.
-__global__ void y_head_bwd(const float* __restrict__ logits, const float* __restrict__ y,
-                           const float* __restrict__ dy, const float* __restrict__ nent,
-                           float* __restrict__ dlogits, int B, int S, int K, float invT) {
-  const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
-  for (int b = blockIdx.x * wpb + (threadIdx.x >> 6); b < B; b += gridDim.x * wpb) {
+// One workgroup of 8 waves per batch row: the waves share the S samples (at S = 50 a single wave per row walked 50
+// dependent load + reduction rounds: 40 us at the config-5 sizes), partial sums meet in LDS.
+__global__ __launch_bounds__(512) void y_head_bwd(const float* __restrict__ logits, const float* __restrict__ y,
+                                                  const float* __restrict__ dy, const float* __restrict__ nent,
+                                                  float* __restrict__ dlogits, int B, int S, int K, float invT) {
+  __shared__ float red[8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const float* lg = logits + (long long)b * K;
     float m2 = -INFINITY;
     for (int k = lane; k < K; k += 64) m2 = fmaxf(m2, lg[k]);
@@ -107,17 +109,23 @@ __global__ void y_head_bwd(const float* __restrict__ logits, const float* __rest
     for (int k0 = 0; k0 < K; k0 += 64) {
       const int k = k0 + lane;
       float acc = 0.f;
-      for (int s = 0; s < S; ++s) {
+      for (int s = wave; s < S; s += 8) {
         const long long r = (long long)b * S + s;
         float dot = 0.f;
         for (int kk = lane; kk < K; kk += 64) dot += y[r * K + kk] * dy[r * K + kk];
         dot = wave_sum(dot);
         if (k < K) acc += y[r * K + k] * (dy[r * K + k] - dot);
       }
-      if (k < K) {
+      red[wave][lane] = acc;
+      __syncthreads();
+      if (wave == 0 && k < K) {
+        float t = red[0][lane];                    // fixed order: the same bits whatever the timing
+#pragma unroll
+        for (int w = 1; w < 8; ++w) t += red[w][lane];
         const float lp = lg[k] - l2;
-        dlogits[(long long)b * K + k] = acc * invT + expf(lp) * (lp - ne);
+        dlogits[(long long)b * K + k] = t * invT + expf(lp) * (lp - ne);
       }
+      __syncthreads();
     }
   }
 }
