@@ -1016,46 +1016,54 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
     const int ldx = L.p[pi].ldx, x_div = L.p[pi].x_div, nparts = L.p[pi].nparts;
     if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && (!Cout || al16(Cout)) && al16(bias) && (ldx & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(xp) & 3) == 0) {
-      // interior tile: the bias quad once, the 4 target bytes of a pass as one word, all passes' loads in flight
+      // interior tile: the bias quad once, the 4 target bytes of a pass as one word; every pass's target word AND staged
+      // accumulator quad are requested before the first is used (ONE memory and ONE LDS round trip per tile), and the row
+      // sums meet through LDS at the end (a butterfly of 5 dependent cross-lane steps per pass was 80 LDS round trips per
+      // tile, each several hundred cycles beside the co-resident workgroup's fragment reads: 22 us of a 77 us tile)
       constexpr int RPP = kThreads / GPR;
-      constexpr int PB = PASSES;          // every pass's loads in flight together: ONE memory round trip per tile
       const int c4 = tid % GPR, r0 = tid / GPR, nb = n0 + 4 * c4;
       const float4 b4 = *reinterpret_cast<const float4*>(bias + nb);
       const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+      unsigned xw[PASSES];
+      f32x4 vv[PASSES];
 #pragma unroll
-      for (int pb = 0; pb < PASSES; pb += PB) {
-        unsigned xw[PB];
+      for (int q = 0; q < PASSES; ++q) {
+        const int m = m0 + r0 + RPP * q;
+        xw[q] = *reinterpret_cast<const unsigned*>(xp + (long long)(m / x_div) * ldx + nb);
+      }
 #pragma unroll
-        for (int q = 0; q < PB; ++q) {
-          const int m = m0 + r0 + RPP * (pb + q);
-          xw[q] = *reinterpret_cast<const unsigned*>(xp + (long long)(m / x_div) * ldx + nb);
+      for (int q = 0; q < PASSES; ++q) {
+        const int row = r0 + RPP * q;
+        vv[q] = *reinterpret_cast<const f32x4*>(lds + row * C::LDC + 4 * c4);
+#pragma unroll
+        for (int w = 1; w < C::WK; ++w) vv[q] += *reinterpret_cast<const f32x4*>(lds + (w * C::BM + row) * C::LDC + 4 * c4);
+      }
+      if (dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); GMVAE_GSTAMP(6); }
+#pragma unroll
+      for (int q = 0; q < PASSES; ++q) {
+        if (q == PASSES / 2) { GMVAE_GSTAMP(7); }
+        const int row = r0 + RPP * q;
+        float v[4] = {vv[q].x, vv[q].y, vv[q].z, vv[q].w};
+        float rsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lam = v[j] + bb[j] + addconst;
+          const float xv = (float)((xw[q] >> (8 * j)) & 0xffu);
+          const float e = __expf(-fabsf(lam));
+          const float rcp = __builtin_amdgcn_rcpf(1.f + e);
+          const float sp = fmaxf(lam, 0.f) - __logf(rcp);
+          rsum += xv * lam - sp;
+          v[j] = (lam >= 0.f ? rcp : e * rcp) - xv;
         }
+        if (Cout) *reinterpret_cast<float4*>(Cout + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
+        lds[row * C::LDC + 4 * c4] = rsum;          // (this thread's own, already consumed, slot of the staged tile)
+      }
+      __syncthreads();
+      if (tid < C::BM) {
+        float t = 0.f;
 #pragma unroll
-        for (int q = 0; q < PB; ++q) {
-          const int row = r0 + RPP * (pb + q);
-          float4 v4 = *reinterpret_cast<const float4*>(lds + row * C::LDC + 4 * c4);
-#pragma unroll
-          for (int w = 1; w < C::WK; ++w) {
-            const float4 o = *reinterpret_cast<const float4*>(lds + (w * C::BM + row) * C::LDC + 4 * c4);
-            v4.x += o.x; v4.y += o.y; v4.z += o.z; v4.w += o.w;
-          }
-          float v[4] = {v4.x, v4.y, v4.z, v4.w};
-          float rsum = 0.f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float lam = v[j] + bb[j] + addconst;
-            const float xv = (float)((xw[q] >> (8 * j)) & 0xffu);
-            const float e = __expf(-fabsf(lam));
-            const float rcp = __builtin_amdgcn_rcpf(1.f + e);
-            const float sp = fmaxf(lam, 0.f) - __logf(rcp);
-            rsum += xv * lam - sp;
-            v[j] = (lam >= 0.f ? rcp : e * rcp) - xv;
-          }
-          if (Cout) *reinterpret_cast<float4*>(Cout + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-          for (int o = GPR / 2; o > 0; o >>= 1) rsum += __shfl_xor(rsum, o, 64);
-          if (c4 == 0) part[(long long)(m0 + row) * nparts + tn] = rsum;
-        }
+        for (int c = 0; c < GPR; ++c) t += lds[tid * C::LDC + 4 * c];
+        part[(long long)(m0 + tid) * nparts + tn] = t;
       }
     } else
 #pragma unroll 1

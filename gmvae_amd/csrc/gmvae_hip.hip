@@ -7,6 +7,8 @@
 // (kernels.hpp).  Nothing here allocates or synchronises; everything is
 // enqueued on the caller's stream and is hipGraph-capturable.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <vector>
 #include <stdint.h>
 #include <math.h>
 #include <stdio.h>
@@ -505,6 +507,16 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
   double fl = 0;
   for (int i = 0; i < g.L.nprob; ++i)
     for (int s = 0; s < g.L.p[i].nseg; ++s) fl += 2.0 * g.L.p[i].M * g.L.p[i].N * g.L.p[i].seg[s].K;
+  unsigned long long* gs_buf = nullptr;
+  if (const char* gn = getenv("GMVAE_GSTAMP_LAUNCH")) {
+    if (!strcmp(gn, name) && !dbg) {
+      static unsigned long long* buf = nullptr;
+      if (!buf) hipMalloc(&buf, (size_t)(1 << 18) * 8 * 8);
+      hipMemsetAsync(buf, 0, (size_t)(1 << 18) * 8 * 8, cx.st);
+      gs_buf = buf;
+      g.L.dbg = buf;
+    }
+  }
   int tiles;
   if (cfg == 2) {
     // the large-tile configuration can run fp32 x fp32 products as bf16 piece products (gemm.hpp split3).  OFF by
@@ -530,6 +542,26 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
   }
   cx.check();
   cx.mark(name, fl);
+  if (gs_buf) {                                   // GMVAE_GSTAMP_LAUNCH=<name>: per-tile phase medians of this launch (eager only)
+    hipStreamSynchronize(cx.st);
+    const int nb = tiles + g.L.aux.nblocks;
+    std::vector<unsigned long long> h((size_t)nb * 8);
+    hipMemcpy(h.data(), gs_buf, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> ph[7];
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int b = g.L.aux.nblocks; b < nb; ++b) {
+      const unsigned long long* r = &h[(size_t)b * 8];
+      if (!r[0] || !r[4]) continue;
+      t0 = r[0] < t0 ? r[0] : t0; t1 = r[4] > t1 ? r[4] : t1;
+      ph[0].push_back((double)(r[1] - r[0])); ph[1].push_back((double)(r[2] - r[1])); ph[2].push_back((double)(r[3] - r[2]));
+      ph[3].push_back((double)(r[4] - r[3])); ph[4].push_back((double)(r[4] - r[0]));
+      if (r[6] > r[3] && r[7] > r[6]) { ph[5].push_back((double)(r[6] - r[3])); ph[6].push_back((double)(r[7] - r[6])); }
+    }
+    auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2] / 100.0; };
+    fprintf(stderr, "[gstamp] %s cfg %d tiles %d: span %.1f us | per tile (median us): prologue %.2f loop %.2f stage %.2f epilogue %.2f total %.2f\n",
+            name, cfg, tiles, (double)(t1 - t0) / 100.0, med(ph[0]), med(ph[1]), med(ph[2]), med(ph[3]), med(ph[4]));
+    if (!ph[5].empty()) fprintf(stderr, "[gstamp]    epilogue: option loads landed +%.2f us, first half of the passes +%.2f us\n", med(ph[5]), med(ph[6]));
+  }
   return cfg;
 }
 static int cfg_bn(int cfg) { return cfg == 2 ? CfgL::BN : ((cfg == 1 || cfg == 3) ? CfgM::BN : CfgS::BN); }
