@@ -217,6 +217,29 @@ def test_config5_shapes_iwae(H):
     H.compare_step(O.MODEL_GMVAE, d, p, x, eps, u, grad_rtol=5e-4)
 
 
+@pytest.mark.parametrize("model", [O.MODEL_GMVAE, O.MODEL_VAE])
+def test_big_round_gemm_inside_the_step_iwae(H, monkeypatch, model):
+    """The big-round GEMM instance inside a step: sizes at which the decoder launches are made of interior 128 x 128
+    tiles (R = B*S = 128 rows, H = 128, D = 256) with the 128 x 128 configuration forced -- forward + Bernoulli
+    epilogue, data gradient with the IWAE row scale, weight gradient with the per-k IWAE scale and the bias-gradient
+    column sums -- against the oracle, and NOT bit-identical to the general loop (evidence that the instance ran)."""
+    monkeypatch.setenv("GMVAE_FORCE_CFG", "2")
+    d = O.Dims(D=256, L=64, K=10, hidden=(128,), S=4)
+    rng = np.random.default_rng(5)
+    p = O.init_params(model, d, rng)
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    x, eps, u = O.make_inputs(d, 32, model)
+    H.compare_step(model, d, p, x, eps, u, grad_rtol=2e-4)
+    flat = O.pack(model, d, p, np.float32)
+    g_big, _ = H.hip_step(model, d, flat, x, eps, u)
+    monkeypatch.setenv("GMVAE_NO_BIG", "1")
+    g_gen, _ = H.hip_step(model, d, flat, x, eps, u)
+    assert not np.array_equal(g_big, g_gen)
+    np.testing.assert_allclose(g_big, g_gen, rtol=0, atol=2e-4 * np.abs(g_gen).max())
+
+
 @pytest.mark.parametrize("env", [{}, {"GMVAE_NO_MEGA": "1"}, {"GMVAE_NO_FUSED": "1"}],
                          ids=["mega", "chain-kernels", "general-schedule"])
 @pytest.mark.parametrize("B,L", [(1024, 64), (40, 16), (7, 8)])
