@@ -1325,6 +1325,16 @@ static int run_step(Ctx& cx, const StepArgs& a) {
 
   // ================================ backward ===============================
   const int NS = num_splits(R);
+  // S > 1: weight gradients whose contraction runs over the B batch rows (the encoder of x, and the x rows of enc_gmm's
+  // first layer after sum_over_s) need only num_splits(B) slabs: finalize_grads then reads 2 instead of 16 slabs for the
+  // two largest tensors of the config-5 sizes, and their launches write as many fewer
+  const int NSB = (S > 1 && !getenv("GMVAE_NSB_OFF")) ? (num_splits(B) < NS ? num_splits(B) : NS) : NS;
+  SlabX sxb;
+  memset(&sxb, 0, sizeof(sxb));
+  sxb.ns = NSB;
+  auto brange = [&](uint64_t b, uint64_t n) {
+    if (NSB != NS && sxb.n < kSlabRanges) { sxb.b[sxb.n] = (int)b; sxb.e[sxb.n] = (int)(b + pad4(n)); sxb.n++; }
+  };
   const long long PP = (long long)L.P_pad;
   float* sl = w.slabs;
   int pb = 0;
@@ -1381,7 +1391,9 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       }
       Group g;
       const float* Wy = P + G.w[0] + (uint64_t)D * G.dim[1];
-      g.add(p_tn(a.x, true, D, 1, dg, G.dim[1], D, G.dim[1], B, sl + G.w[0], sl + G.b[0], NS, PP, nullptr));
+      const int nsx = (S > 1 && sxb.n + 2 <= kSlabRanges) ? NSB : NS;
+      if (nsx != NS) { brange(G.w[0], (uint64_t)D * G.dim[1]); brange(G.b[0], G.dim[1]); }
+      g.add(p_tn(a.x, true, D, 1, dg, G.dim[1], D, G.dim[1], B, sl + G.w[0], sl + G.b[0], nsx, PP, nullptr));
       g.add(p_tn(w.y, false, K, 1, dcur, G.dim[1], K, G.dim[1], R, sl + G.w[0] + (uint64_t)D * G.dim[1], nullptr, NS,
                  PP, nullptr));
       Problem p = p_nt(dcur, G.dim[1], Wy, G.dim[1], R, K, G.dim[1], w.dy, K, nullptr, 0);
@@ -1416,7 +1428,9 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   for (int i = E.nl - 1; i >= 0; --i) {   // enc_y (GMVAE) / encoder (VAE): rows = B
     Group g;
     const void* act = (i == 0) ? (const void*)a.x : (const void*)w.he[i];
-    g.add(p_tn(act, i == 0, E.dim[i], 1, dcur, E.dim[i + 1], E.dim[i], E.dim[i + 1], B, sl + E.w[i], sl + E.b[i], NS,
+    const int nse = (S > 1 && sxb.n + 2 <= kSlabRanges) ? NSB : NS;
+    if (nse != NS) { brange(E.w[i], (uint64_t)E.dim[i] * E.dim[i + 1]); brange(E.b[i], E.dim[i + 1]); }
+    g.add(p_tn(act, i == 0, E.dim[i], 1, dcur, E.dim[i + 1], E.dim[i], E.dim[i + 1], B, sl + E.w[i], sl + E.b[i], nse,
                PP, nullptr));
     float* out = nullptr;
     if (i > 0) {
@@ -1433,7 +1447,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     const int KLp = (int)pad4((uint64_t)K * Lz);
     hipLaunchKernelGGL(finalize_grads, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, sl, NS, PP, a.grads,
                        gmp ? w.gmp_part : (const float*)nullptr, GMP_PARTS, gmp ? 2 * KLp + (int)pad4(K) : 0,
-                       (long long)L.loc, SlabX{});
+                       (long long)L.loc, sxb);
     rowk(cx, "finalize_grads");
   }
   return cx.err;

@@ -462,14 +462,15 @@ __device__ __forceinline__ float4 slab_sum4(const float* __restrict__ p, const l
 
 // Parameter ranges whose weight gradients were split over fewer slabs than the rest (the uint8-activation
 // problems of the fused dW launch run on the bf16 matrix cores and take half the splits of the fp32 ones).
+constexpr int kSlabRanges = 8;
 struct SlabX {
   int n, ns;                  // ranges in use; slabs of those ranges
-  int b[4], e[4];             // [begin, end) flat parameter indices, multiples of 4
+  int b[kSlabRanges], e[kSlabRanges];   // [begin, end) flat parameter indices, multiples of 4
 };
 __device__ __forceinline__ int slab_count(const SlabX& sx, const long long i4, const int dflt) {
   int ns = dflt;
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < kSlabRanges; ++k)
     if (k < sx.n && i4 >= sx.b[k] && i4 < sx.e[k]) ns = sx.ns;
   return ns;
 }
