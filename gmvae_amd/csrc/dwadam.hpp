@@ -49,6 +49,11 @@ struct DwArgs {
   unsigned long long* dbg;     // diagnostic: [block][8] wall-clock stamps (tools/dwstamps.py) or null
   const float* lr_t;           // this step's Adam step size alpha_t, left by mega2_fwd_bwd (mega.hpp MegaArgs::lr_t_out), or null:
   float ln_b1, ln_b2;          // then alpha_t = lr sqrt(-expm1(t ln b2)) / (-expm1(t ln b1)) per thread (ln b rounded from double)
+  // VAE_GMP: the learned mixture prior's variables (loc, raw scale, mixture logits: one contiguous parameter range) have
+  // no matrix-product gradient -- mega_fwd_bwd leaves one partial per panel (fa.gmp_part); gmp_blocks extra workgroups
+  // (after the binarisation blocks) sum them in panel order, apply the update and write the variables' LDS-image copies
+  int gmp_blocks, gmp_nmap;
+  ImgMap gmp_map[3];
   int tile_begin[kDwMaxT];
   DwTensor t[kDwMaxT];
   FinalArgs fa;                // p, m, v, grads, Adam constants, loss-tail inputs, counters, images, binarisation blocks
@@ -130,7 +135,37 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
   DW_ST(0);
   if (bid >= a.total_tiles) {                    // the loss tail + counters, then the next batch's binarisation blocks
     if (bid == a.total_tiles) finalize_tail_block(fa, reinterpret_cast<float(*)[256]>(red));
-    else finalize_bin_block(fa, bid - a.total_tiles - 1);
+    else if (bid - a.total_tiles - 1 < fa.bin_blocks) finalize_bin_block(fa, bid - a.total_tiles - 1);
+    else {                                         // mixture-prior variables: partials -> gradient -> TF-Adam -> image
+      const int e = (bid - a.total_tiles - 1 - fa.bin_blocks) * kDwThreads + (int)threadIdx.x;
+      if (e < fa.gmp_len) {
+        const long long i = fa.gmp_off + e;
+        float g = 0.f;
+        for (int k = 0; k < fa.gmp_n; ++k) g += fa.gmp_part[(long long)k * fa.gmp_len + e];
+        fa.grads[i] = g;
+        const bool poisoned = fa.err_word && *fa.err_word;
+        if (fa.do_adam && !poisoned) {
+          float lr_t;
+          if (a.lr_t) lr_t = *a.lr_t;
+          else {
+            const float tf = (float)((fa.step_dev ? fa.step_dev[1] : 0ull) + 1ull);
+            lr_t = fa.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1));
+          }
+          float pp = fa.p[i], pm = fa.m[i], pv = fa.v[i];
+          adam_update(pp, pm, pv, g, 1.f / fa.count, lr_t, 1.f - fa.b1, 1.f - fa.b2, fa.eps);
+          fa.p[i] = pp; fa.m[i] = pm; fa.v[i] = pv;
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (k < a.gmp_nmap && i >= a.gmp_map[k].begin && i < a.gmp_map[k].end) {
+              const ImgMap& mp = a.gmp_map[k];
+              const unsigned off = (unsigned)(i - mp.begin);
+              const int r = (int)(((unsigned long long)off * mp.magic) >> 32);
+              const int c = (int)off - r * mp.cols;
+              fa.img[mp.which][img_dst(mp.kind, mp.base, mp.ld, mp.chunk, r, c)] = pp;
+            }
+        }
+      }
+    }
     DW_ST(4);
     if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + 5] = 99ull;
     DW_END();

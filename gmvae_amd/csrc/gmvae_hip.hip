@@ -914,7 +914,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
   const bool dw_upd = a.adam_p && a.adam_p == a.params;     // single device: the optimizer runs in the same launch
   // (every model of the mega schedule whose gradients are all matrix products: the learned mixture prior's variables of
   //  VAE_GMP come as per-panel partials and keep the split-K launch + finalize_adam)
-  if (fl && !gmp && (dw_upd || a.dp_images) && a.step_dev && !getenv("GMVAE_NO_DWADAM")) {
+  if (fl && (!gmp || !getenv("GMVAE_NO_DWADAM_GMP")) && (dw_upd || a.dp_images) && a.step_dev && !getenv("GMVAE_NO_DWADAM")) {
     ImgPlan pl;
     plan_images(d, model, L, w, ml, a.params, pl);
     if (pl.map_ok) {
@@ -1011,9 +1011,16 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         const uint64_t quads = (uint64_t)B * (D >> 2);
         fa.bin_blocks = (int)((quads + (uint64_t)kBinQuadsPerThread * 256 - 1) / ((uint64_t)kBinQuadsPerThread * 256));
       }
+      if (gmp) {                                 // the prior variables: per-panel partials of mega_fwd_bwd
+        const int KLp = (int)pad4((uint64_t)K * Lz);
+        fa.gmp_part = w.gmp_part; fa.gmp_n = (B + kPanel - 1) / kPanel; fa.gmp_len = 2 * KLp + (int)pad4(K); fa.gmp_off = (long long)L.loc;
+        da.gmp_blocks = (fa.gmp_len + kDwThreads - 1) / kDwThreads;
+        for (int i = 0; i < pl.nmap && da.gmp_nmap < 3; ++i)
+          if (pl.map[i].begin >= fa.gmp_off && pl.map[i].end <= fa.gmp_off + fa.gmp_len) da.gmp_map[da.gmp_nmap++] = pl.map[i];
+      }
       // the padding words of the flat gradient buffer are never written by the tiles: the buffer is all-reduced / read whole
       if (da.total_tiles > kDwMaxTiles) return GMVAE_E_DIMS;
-      hipLaunchKernelGGL(dw_adam, dim3(da.total_tiles + 1 + fa.bin_blocks), dim3(kDwThreads), 0, st, da);
+      hipLaunchKernelGGL(dw_adam, dim3(da.total_tiles + 1 + fa.bin_blocks + da.gmp_blocks), dim3(kDwThreads), 0, st, da);
       cx.check();
       double fl_ = 0;
       for (int i = 0; i < da.ntens; ++i) fl_ += 2.0 * da.t[i].M * da.t[i].N * B;
