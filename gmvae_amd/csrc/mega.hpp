@@ -90,7 +90,8 @@ __host__ __device__ inline MegaLay mega_lay(int H, int L, int K, int D, int mode
     m.fl_W = 0;
     m.fl_A = GMVAE_P256(nw * m.fl_kq * H);
     m.fl_ok = (m.fl_A + kPanel * kFlLda <= m.nll) && m.fl_kq <= kFlLda && D % 16 == 0 && nw * H <= 128 && H % 16 == 0 && L % 2 == 0 &&
-              H == 64 && (m.fl_kq * H) % 256 == 0 && kPanel * m.fl_kq / 4 <= 2 * kMT && L % 4 == 0 && 4 * L + (model == 2 ? 4 * ((K + 3) & ~3) : 0) <= kMT;
+              H == 64 && (m.fl_kq * H) % 256 == 0 && kPanel * m.fl_kq / 4 <= 2 * kMT &&
+              kPanel * ((L + 3) / 4) + (model == 2 ? kPanel * ((K + 3) / 4) : 0) <= kMT;
   }
   return m;
 }
@@ -327,8 +328,8 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     const int kn = max(0, min(KQ, D - k0));        // rows of this quarter that exist (the last quarter may be short)
     const unsigned epoch_fl = *a.epoch_word;
     const unsigned long long step = a.step_dev[0];
-    // noise items of this panel: one quad of one row each (L % 4 == 0 here; K is padded to quads per row)
-    const int qer = L / 4, qur = gm ? (K + 3) / 4 : 0;
+    // noise items of this panel: one quad of one row each (L and K are padded to quads per row, as in gmvae_noise_fill)
+    const int qer = (L + 3) / 4, qur = gm ? (K + 3) / 4 : 0;
     const int qe = kPanel * qer, qu = kPanel * qur;
     float nz[4] = {0.f, 0.f, 0.f, 0.f};
     const int ntile = H2f / 16, tpw = H / 16;      // tiles; tiles per weight tensor
@@ -438,7 +439,14 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     GMVAE_FL(6);
     dma_copy_m(sm, a.img, f.img_early, wave, lane);
     if (tid < qe) {
-      *reinterpret_cast<float4*>(P_eps + tid * 4) = make_float4(nz[0], nz[1], nz[2], nz[3]);
+      if ((L & 3) == 0) {
+        *reinterpret_cast<float4*>(P_eps + tid * 4) = make_float4(nz[0], nz[1], nz[2], nz[3]);
+      } else {                                       // ragged latent size (the reference's VAE example: L = 2)
+        const int row = tid / qer, l0 = (tid - row * qer) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (l0 + j < L) P_eps[row * L + l0 + j] = nz[j];
+      }
     } else if (tid < qe + qu) {
       const int li = tid - qe, row = li / max(qur, 1), k0u = (li - row * qur) * 4;
 #pragma unroll
