@@ -768,7 +768,7 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
   const int KLp = (int)pad4((uint64_t)d.K * d.L);
   hipLaunchKernelGGL(finalize_grads, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, sl, NS, PP, a.grads,
                      gmp ? w.gmp_part : (const float*)nullptr, (B + kPanel - 1) / kPanel,
-                     gmp ? 2 * KLp + (int)pad4(d.K) : 0, (long long)L.loc, sx);
+                     gmp ? 2 * KLp + (int)pad4(d.K) : 0, (long long)L.loc, sx, AdamTail{});
   rowk(cx, "finalize_grads");
   if (a.adam_p && a.step_dev) {           // VAE_GMP in the graph path: its prior partials need finalize_grads first
     hipLaunchKernelGGL(adam_tf, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, a.adam_p, a.adam_m, a.adam_v,
@@ -1231,7 +1231,10 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   if (a.backward && mega_ok(d, model)) return run_step_mega(cx, a, L, w, eps, u, ge, gu);
   if (fused_ok(d, model) && !a.z_out && !a.y_out && !a.logits_out)
     return run_step_fused(cx, a, L, w, eps, u, ge, gu);
-  if (ge || gu) {
+  // (general schedule: the Philox fill rides as auxiliary workgroups of the first GEMM launch below; GMVAE_NOISE_LAUNCH=1
+  //  keeps it a launch of its own)
+  const bool noise_aux = (ge || gu) && !getenv("GMVAE_NOISE_LAUNCH");
+  if ((ge || gu) && !noise_aux) {
     const uint64_t q = noise_items(ge, gu, (uint64_t)R, Lz, K);
     hipLaunchKernelGGL(noise_fill, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, ge, gu, (uint64_t)R, Lz, K,
                        (uint64_t)d.row0 * S, a.seed, a.step, a.step_dev);
@@ -1247,7 +1250,17 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     if (gm)
       g.add(p_nn(a.x, true, D, P + L.encg.w[0], L.encg.dim[1], B, L.encg.dim[1], D, w.gx, L.encg.dim[1], nullptr,
                  false));
-    launch_group(cx, g, "fwd_x_first_layers");
+    if (noise_aux) {
+      Aux& ax = g.L.aux;
+      ax.eps = ge; ax.u = gu; ax.n_rows = (unsigned long long)R; ax.nL = Lz; ax.nK = K; ax.row_base = (unsigned long long)d.row0 * S;
+      ax.seed = a.seed; ax.step = a.step;
+      ax.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
+      ax.epoch_word = nullptr;
+      ax.noise_blocks = (int)((noise_items(ge, gu, (uint64_t)R, Lz, K) + kThreads - 1) / kThreads);
+      ax.ntasks = 0;
+      ax.nblocks = ax.noise_blocks;
+    }
+    launch_group(cx, g, noise_aux ? "fwd_x_first_layers+noise" : "fwd_x_first_layers");
   }
   for (int i = 1; i < E.nl; ++i) {
     Group g;
@@ -1452,10 +1465,16 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   {
     const bool gmp = model == GMVAE_MODEL_VAE_GMP;
     const int KLp = (int)pad4((uint64_t)K * Lz);
+    AdamTail adt;
+    memset(&adt, 0, sizeof(adt));
+    if (a.adam_p && a.step_dev) {                 // train graph / gmvae_train_step: the optimizer in the same launch
+      adt.p = a.adam_p; adt.m = a.adam_m; adt.v = a.adam_v; adt.lr = a.lr; adt.b1 = a.beta1; adt.b2 = a.beta2; adt.eps = a.epsilon;
+      adt.t_dev = a.step_dev; adt.tail_log = a.tail_log;
+    }
     hipLaunchKernelGGL(finalize_grads, dim3((unsigned)((PP / 4 + 255) / 256)), dim3(256), 0, st, sl, NS, PP, a.grads,
                        gmp ? w.gmp_part : (const float*)nullptr, GMP_PARTS, gmp ? 2 * KLp + (int)pad4(K) : 0,
-                       (long long)L.loc, sxb);
-    rowk(cx, "finalize_grads");
+                       (long long)L.loc, sxb, adt);
+    rowk(cx, adt.p ? "finalize_grads_adam" : "finalize_grads");
   }
   return cx.err;
 }
@@ -1911,7 +1930,8 @@ static int train_graph_create(const GmvaeDims* dims, int model, const uint8_t* p
         rc = gmvae_binarize(pixels, n_rows, idx + (size_t)s * dims->B, 0, dims->B, dims->D, bseed, 0, step_dev, xs,
                             dims->row0, cs);
       if (rc) break;
-      if (fused_ok(*dims, model) || mega_ok(*dims, model)) {
+      if (fused_ok(*dims, model) || mega_ok(*dims, model) || !getenv("GMVAE_GENERAL_UNFUSED")) {
+        // (the general schedule too: its last launch, finalize_grads, applies TF-Adam and logs the tail)
         // every step after the first finds its weight images written by the step before it (same graph, nothing in between)
         const bool nxt = ride && s + 1 < n_steps;
         rc = step_with_adam(dims, model, xs, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, cs, s > 0,

@@ -460,6 +460,21 @@ __device__ __forceinline__ float4 slab_sum4(const float* __restrict__ p, const l
   return r;
 }
 
+// ---------------------------------------------------------------- Adam
+// TF1 AdamOptimizer / ApplyAdam (scripts/runners.py:181-183, SURVEY.md A13):
+//   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; theta -= lr_t*m/(sqrt(v)+eps)
+// One launch over the whole flat buffer (multi-tensor by construction).
+// ONE statement of the update for every kernel that applies it (adam_tf, finalize_adam's two thread maps, adam_tf_img):
+// the roundings are pinned with explicit intrinsics, so the same inputs give the same bits whichever kernel ran
+// (the compiler contracts a*b+c differently from one kernel to the next otherwise).
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, const float g, const float gscale, const float lr_t,
+                                            const float omb1, const float omb2, const float eps) {
+  const float gj = __fmul_rn(g, gscale);
+  m = __fmaf_rn(__fsub_rn(gj, m), omb1, m);
+  v = __fmaf_rn(__fmaf_rn(gj, gj, -v), omb2, v);
+  p = __fsub_rn(p, __fdiv_rn(__fmul_rn(m, lr_t), __fadd_rn(__fsqrt_rn(v), eps)));
+}
+
 // Parameter ranges whose weight gradients were split over fewer slabs than the rest (the uint8-activation
 // problems of the fused dW launch run on the bf16 matrix cores and take half the splits of the fp32 ones).
 constexpr int kSlabRanges = 8;
@@ -477,10 +492,20 @@ __device__ __forceinline__ int slab_count(const SlabX& sx, const long long i4, c
 
 // grads[i] = sum over the split-K slabs (fixed order => bit-reproducible),
 // and the mixture-prior partials where present.
+// With `ad.p` set the TF-Adam update follows in the same launch (general schedule inside a train graph: the step's
+// loss tail and counter are already final -- loss_tail ran before the backward launches -- so t = *t_dev, the scale is
+// 1 / tail[4] and a non-finite loss sum skips the update; block 0 also copies the tail to this step's log slot).
+struct AdamTail {
+  float *p, *m, *v;
+  float lr, b1, b2, eps;
+  const uint64_t* t_dev;
+  float* tail_log;
+};
 __global__ void finalize_grads(const float* __restrict__ slabs, int nslab, long long P, float* __restrict__ grads,
                                const float* __restrict__ gmp_part, int gmp_n, int gmp_len, long long gmp_off,
-                               const SlabX sx) {
+                               const SlabX sx, const AdamTail ad) {
   const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (ad.p && ad.tail_log && blockIdx.x == 0 && threadIdx.x < 8) ad.tail_log[threadIdx.x] = grads[P + threadIdx.x];
   if (i4 >= P) return;
   float4 a = slab_sum4(slabs + i4, P, slab_count(sx, i4, nslab));
   if (gmp_part && i4 >= gmp_off && i4 < gmp_off + gmp_len) {
@@ -496,21 +521,21 @@ __global__ void finalize_grads(const float* __restrict__ slabs, int nslab, long 
     a = acc;
   }
   *reinterpret_cast<float4*>(grads + i4) = a;
-}
-
-// ---------------------------------------------------------------- Adam
-// TF1 AdamOptimizer / ApplyAdam (scripts/runners.py:181-183, SURVEY.md A13):
-//   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; theta -= lr_t*m/(sqrt(v)+eps)
-// One launch over the whole flat buffer (multi-tensor by construction).
-// ONE statement of the update for every kernel that applies it (adam_tf, finalize_adam's two thread maps, adam_tf_img):
-// the roundings are pinned with explicit intrinsics, so the same inputs give the same bits whichever kernel ran
-// (the compiler contracts a*b+c differently from one kernel to the next otherwise).
-__device__ __forceinline__ void adam_update(float& p, float& m, float& v, const float g, const float gscale, const float lr_t,
-                                            const float omb1, const float omb2, const float eps) {
-  const float gj = __fmul_rn(g, gscale);
-  m = __fmaf_rn(__fsub_rn(gj, m), omb1, m);
-  v = __fmaf_rn(__fmaf_rn(gj, gj, -v), omb2, v);
-  p = __fsub_rn(p, __fdiv_rn(__fmul_rn(m, lr_t), __fadd_rn(__fsqrt_rn(v), eps)));
+  if (ad.p) {
+    if (!__builtin_isfinite(grads[P])) return;       // poisoned step: keep params, m, v
+    const unsigned long long t = *ad.t_dev;
+    const float gscale = 1.f / grads[P + 4];
+    const float lr_t = (float)((double)ad.lr * sqrt(1.0 - pow((double)ad.b2, (double)t)) / (1.0 - pow((double)ad.b1, (double)t)));
+    const float omb1 = 1.f - ad.b1, omb2 = 1.f - ad.b2;
+    float4 pp = *reinterpret_cast<float4*>(ad.p + i4), mm = *reinterpret_cast<float4*>(ad.m + i4), vv = *reinterpret_cast<float4*>(ad.v + i4);
+    float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+    const float ga[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) adam_update(pa[j], ma[j], va[j], ga[j], gscale, lr_t, omb1, omb2, ad.eps);
+    *reinterpret_cast<float4*>(ad.p + i4) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    *reinterpret_cast<float4*>(ad.m + i4) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+    *reinterpret_cast<float4*>(ad.v + i4) = make_float4(va[0], va[1], va[2], va[3]);
+  }
 }
 
 __global__ void adam_tf(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
@@ -880,7 +905,7 @@ __global__ __launch_bounds__(256) void adam_tf_img(float* __restrict__ p, float*
 }
 
 // The weight images of the in-launch schedule from the parameters as they are (no update): what the FIRST step of a
-// train graph -- or an eager step -- runs before mega2_fwd_bwd / mega_fwd_bwd<FLT = 1>, so that every step of a graph is
+// train graph -- runs before mega2_fwd_bwd / mega_fwd_bwd<FLT = 1>, so that every step of a graph is
 // the steady-state pair of launches (later steps find the images left by the optimizer's scatter).  Also opens the step:
 // bumps the hand-off tag like the first launch of the general schedule.
 __global__ __launch_bounds__(256) void img_build(const float* __restrict__ p, long long P, const ImgScatter sc) {

@@ -119,7 +119,8 @@ int gmvae_workspace_bytes(const GmvaeDims* dims, int model, uint64_t* bytes);
  *         (nll/kl are averaged over S inside a row group) -- one RCCL
  *         all-reduce(SUM) of this buffer makes it global; adam_tf_step's
  *         grad_scale = 1/tail[4] turns sums into the reference's batch means.
- *   step_dev (may be NULL): device-resident step counter for hipGraph replay.
+ *   step_dev (may be NULL): device-resident step counter for hipGraph replay: TWO uint64 words, [0] the counter,
+ *         [1] a scratch copy the step's launches hand to each other (every entry point that takes step_dev).
  *         When given it overrides `step` for the Philox stream and is
  *         incremented once per call (after the noise is drawn), so that
  *         adam_tf_step(t_dev = step_dev) later on the stream sees t = step+1.
