@@ -84,7 +84,7 @@ struct Launch {
   int nprob;
   int total_tiles;         // the FIRST aux_nblocks workgroups run aux_block() (they start at once), the GEMM tiles follow
   int aux_nblocks;         // copy of aux.nblocks
-  int pad_;
+  int aux_last;            // auxiliary workgroups after the tiles instead of before them
   unsigned long long* dbg; // diagnostic: [block][8] wall-clock stamps (100 MHz) or nullptr
   int tile_begin[MAXP];    // copy of p[i].tile_begin
   Problem p[MAXP];
@@ -563,7 +563,11 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
   const unsigned long long t_in = wall_clock64();
   unsigned long long* const dbg = L.dbg;
   const int auxn = L.aux_nblocks, nprob = L.nprob;
-  const int bid = (int)blockIdx.x - auxn;
+  // aux_last: the tiles come first and the auxiliary workgroups follow (a launch of few, long tiles: the Philox fill of
+  // the general schedule then runs on the CUs the tiles leave idle instead of in front of them)
+  const int ntl = L.total_tiles;
+  const int aux_i = L.aux_last ? (int)blockIdx.x - ntl : (int)blockIdx.x;
+  const int bid = L.aux_last ? ((int)blockIdx.x < ntl ? (int)blockIdx.x : -1) : (int)blockIdx.x - auxn;
   int pi = 0, tb = 0;
 #pragma unroll
   for (int i = 1; i < MAXP; ++i) {
@@ -576,7 +580,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
 #define GMVAE_GSTAMP(i) if (dbg && tid == 0) dbg[(size_t)blockIdx.x * 8 + (i)] = wall_clock64()
   if (dbg && tid == 0) dbg[(size_t)blockIdx.x * 8] = t_in;
   if (bid < 0) {                                // auxiliary work riding on this launch (aux.hpp)
-    aux_block(L.aux, (int)blockIdx.x);
+    aux_block(L.aux, aux_i);
     GMVAE_GSTAMP(4);
     if (dbg && tid == 0) dbg[(size_t)blockIdx.x * 8 + 5] = 100;
     return;

@@ -499,7 +499,7 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
       bool first = true;
       for (int k = 2; k >= 0; --k)
         if (used[k]) {
-          if (first) { sub[k].L.aux = g.L.aux; first = false; }        // auxiliary workgroups ride on the first launch
+          if (first) { sub[k].L.aux = g.L.aux; sub[k].L.aux_last = g.L.aux_last; first = false; }   // auxiliary workgroups ride on the first launch
           last = launch_group(cx, sub[k], name, k, dbg);
         }
       return last;
@@ -1271,6 +1271,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       ax.noise_blocks = (int)((noise_items(ge, gu, (uint64_t)R, Lz, K) + kThreads - 1) / kThreads);
       ax.ntasks = 0;
       ax.nblocks = ax.noise_blocks;
+      g.L.aux_last = 1;
     }
     launch_group(cx, g, noise_aux ? "fwd_x_first_layers+noise" : "fwd_x_first_layers");
   }
