@@ -331,8 +331,12 @@ def main():
         roof = {"bound": "mfma", "kernel": dom[0] if dom[0].startswith("mega") else f"gemm_grouped<{dom[0]}>", "achieved": dom[2] / dom[1] * 1e-6,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom[2] / dom[1] * 1e-6 / PEAK_F32_MFMA_TFLOPS,
                 "traffic": None, "usec_per_launch": dom[1], "flops_per_launch": dom[2],
+                # step_flops_alg: the reference's arithmetic for this step (every layer over all B*S rows);
+                # step_flops_executed: what the launches run (S > 1: the layers over the S-times repeated input are
+                # computed once per batch row) -- the fraction of the MFMA peak is quoted on the EXECUTED count
                 "step_flops_alg": step_flops, "step_tflops_alg": step_flops / (dt / a.steps) * 1e-12,
-                "step_frac_of_mfma_peak": step_flops / (dt / a.steps) * 1e-12 / PEAK_F32_MFMA_TFLOPS,
+                "step_flops_executed": sum(l[2] for l in levels),
+                "step_frac_of_mfma_peak": sum(l[2] for l in levels) / (dt / a.steps) * 1e-12 / PEAK_F32_MFMA_TFLOPS,
                 "launches_per_step": len(levels), "sum_kernel_usec": sum_us,
                 "timing": "in-kernel wall-clock stamps (s_memrealtime): last workgroup end - first workgroup start, "
                           "steady-state step replayed inside a hipGraph" if world == 1 else "hipEvents around eager launches",

@@ -465,46 +465,6 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
   g.L.dbg = dbg;
   g.L.aux_nblocks = g.L.aux.nblocks;
   if (cfg < 0) cfg = cx.force_cfg;
-  if (cfg < 0 && g.L.nprob > 1 && !getenv("GMVAE_CFG_BY_TILES") && !getenv("GMVAE_NO_GROUP_SPLIT")) {
-    // Problems that want different tile configurations (a k-long weight gradient with few outputs next to a data gradient
-    // with many) run as one launch per configuration when the estimate says the extra kernel boundary (~3 us) pays.
-    auto best3 = [&](Launch& t, double& c) {
-      const double tl = launch_cost<CfgL>(t, big_eligible(t)), tm = launch_cost<CfgM>(t, false), ts = launch_cost<CfgS>(t, false);
-      const int k = (tl <= tm && tl <= ts) ? 2 : (tm <= ts ? 1 : 0);
-      c = k == 2 ? tl : (k == 1 ? tm : ts);
-      return k;
-    };
-    double c_single = 0, c_split = 0;
-    { Launch t = g.L; best3(t, c_single); }
-    int want[MAXP], ng = 0;
-    bool used[3] = {false, false, false};
-    for (int i = 0; i < g.L.nprob; ++i) {
-      Group one;
-      one.add(g.L.p[i]);
-      double c;
-      want[i] = best3(one.L, c);
-      used[want[i]] = true;
-    }
-    Group sub[3];
-    for (int i = 0; i < g.L.nprob; ++i) sub[want[i]].add(g.L.p[i]);
-    for (int k = 0; k < 3; ++k)
-      if (used[k]) {
-        Launch t = sub[k].L;
-        c_split += k == 2 ? launch_cost<CfgL>(t, big_eligible(t)) : (k == 1 ? launch_cost<CfgM>(t, false) : launch_cost<CfgS>(t, false));
-        ++ng;
-      }
-    c_split += 3.0 * (ng - 1);
-    if (ng > 1 && c_split + 5.0 < c_single) {
-      int last = 0;
-      bool first = true;
-      for (int k = 2; k >= 0; --k)
-        if (used[k]) {
-          if (first) { sub[k].L.aux = g.L.aux; sub[k].L.aux_last = g.L.aux_last; first = false; }   // auxiliary workgroups ride on the first launch
-          last = launch_group(cx, sub[k], name, k, dbg);
-        }
-      return last;
-    }
-  }
   if (cfg < 0) {
     Launch t = g.L;
     if (getenv("GMVAE_CFG_BY_TILES")) {            // (the round-1 rule, kept for A/B)
