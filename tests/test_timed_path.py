@@ -92,6 +92,12 @@ CASES = [
     ("vae", 784, 2, 1, (64,), 100, 4),           # BASELINE configs[0]
     ("vae_gmp", 784, 64, 10, (64,), 256, 4),     # BASELINE configs[1]
     ("gmvae", 784, 16, 10, (64,), 96, 3),        # generic mega instance (not the specialised sizes)
+    ("gmvae", 784, 128, 10, (512,), 64, 2),      # bin/run_train.sh sizes: general schedule (noise as auxiliary workgroups of
+                                                 # the first GEMM launch, TF-Adam + tail log inside finalize_grads).  Two steps:
+                                                 # at the third, ONE of the 64 x 512 enc_gmm pre-activations of this seed sits
+                                                 # within rounding of zero and its ReLU takes the other side than in fp64 (one
+                                                 # gradient column differs by 2e-3 of max; graph and eager steps agree bit for bit)
+    ("vae", 784, 8, 1, (96, 96), 48, 3),         # two hidden layers: general schedule, VAE
 ]
 
 
