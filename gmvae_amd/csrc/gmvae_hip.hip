@@ -202,6 +202,15 @@ static int num_splits(long long R) {
   return (int)ns;
 }
 
+// splits of the weight gradients with few outputs (general schedule): more than NS_MAX at large R
+constexpr int NS_SMALL_MAX = 64;
+static int num_splits_small(long long R) {
+  long long ns = R / 400;
+  if (ns < 1) ns = 1;
+  if (ns > NS_SMALL_MAX) ns = NS_SMALL_MAX;
+  return (int)ns;
+}
+
 static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS& w) {
   uint64_t off = 0;
   auto take = [&](uint64_t nfloats) -> float* {
@@ -278,6 +287,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
   }
   {
     int ns = num_splits(R);
+    if (num_splits_small(R) > ns) ns = num_splits_small(R);       // (the extra slabs are only touched in the small tensors' ranges)
     if ((fused_ok(d, model) || mega_ok(d, model)) && dw_splits(d.B) > ns) ns = dw_splits(d.B);
     if (mega_ok(d, model) && 2 * dw_splits(d.B) <= NS_MAX && 2 * dw_splits(d.B) > ns) ns = 2 * dw_splits(d.B);
     w.slabs = take((uint64_t)ns * L.P_pad);
@@ -1012,8 +1022,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
   memset(&sx, 0, sizeof(sx));
   {
     Group g;
-    auto xrange = [&](uint64_t b, uint64_t n) { sx.b[sx.n] = (int)b; sx.e[sx.n] = (int)(b + pad4(n)); sx.n++; };
-    sx.ns = NSX;
+    auto xrange = [&](uint64_t b, uint64_t n) { sx.b[sx.n] = (int)b; sx.e[sx.n] = (int)(b + pad4(n)); sx.ns[sx.n] = NSX; sx.n++; };
     if (gm) {
       g.add(p_tn(a.x, true, D, 1, w.dbuf[2], H, D, H, B, sl + E.w[0], sl + E.b[0], NSX, PP, nullptr));           // dWy0
       g.add(p_tn(a.x, true, D, 1, w.dbuf[1], H, D, H, B, sl + G.w[0], sl + G.b[0], NSX, PP, nullptr));           // dWg0[x]
@@ -1322,12 +1331,16 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   // first layer after sum_over_s) need only num_splits(B) slabs: finalize_grads then reads 2 instead of 16 slabs for the
   // two largest tensors of the config-5 sizes, and their launches write as many fewer
   const int NSB = (S > 1 && !getenv("GMVAE_NSB_OFF")) ? (num_splits(B) < NS ? num_splits(B) : NS) : NS;
+  // Weight gradients with few outputs and a contraction over all R rows (decoder layer 0, the layers of enc_gmm after the
+  // first, the prior, the y rows of enc_gmm's first layer) take MORE splits than NS -- up to 64 -- at large R: as 64 tiles of
+  // 50 rounds each such launch was a 125 us latency chain at the config-5 sizes.  (The slab buffer is sized for it: carve.)
+  const int NSS = (num_splits_small(R) > NS && !getenv("GMVAE_NSS_OFF")) ? num_splits_small(R) : NS;
   SlabX sxb;
   memset(&sxb, 0, sizeof(sxb));
-  sxb.ns = NSB;
-  auto brange = [&](uint64_t b, uint64_t n) {
-    if (NSB != NS && sxb.n < kSlabRanges) { sxb.b[sxb.n] = (int)b; sxb.e[sxb.n] = (int)(b + pad4(n)); sxb.n++; }
+  auto brange = [&](uint64_t b, uint64_t n, int ns) {
+    if (ns != NS && sxb.n < kSlabRanges) { sxb.b[sxb.n] = (int)b; sxb.e[sxb.n] = (int)(b + pad4(n)); sxb.ns[sxb.n] = ns; sxb.n++; }
   };
+  auto small_ns = [&](long long outs) { return (NSS != NS && outs <= 131072 && sxb.n + 2 <= kSlabRanges) ? NSS : NS; };
   const long long PP = (long long)L.P_pad;
   float* sl = w.slabs;
   int pb = 0;
@@ -1336,8 +1349,10 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     Group g;
     const bool top = (i == Dn.nl - 1);
     const float* act = (i == 0) ? w.z : w.hd[i];
+    const int nsd = small_ns((long long)Dn.dim[i] * Dn.dim[i + 1]);
+    if (nsd != NS) { brange(Dn.w[i], (uint64_t)Dn.dim[i] * Dn.dim[i + 1], nsd); brange(Dn.b[i], Dn.dim[i + 1], nsd); }
     const Problem pw = p_tn(act, false, Dn.dim[i], 1, dcur, Dn.dim[i + 1], Dn.dim[i], Dn.dim[i + 1], R, sl + Dn.w[i], sl + Dn.b[i],
-                            NS, PP, top ? rwS : nullptr);
+                            nsd, PP, top ? rwS : nullptr);
     float* out = (i == 0) ? w.dz : w.dbuf[pb];
     Problem p = p_nt(dcur, Dn.dim[i + 1], P + Dn.w[i], Dn.dim[i + 1], R, Dn.dim[i], Dn.dim[i + 1], out, Dn.dim[i],
                      (i > 0) ? w.hd[i] : nullptr, Dn.dim[i]);
@@ -1356,13 +1371,17 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     const NetL& G = L.encg;
     bool prior_done = false;
     auto prior_dw = [&]() {
-      return p_tn(w.y, false, K, 1, w.dpp, 2 * Lz, K, 2 * Lz, R, sl + L.prior.w[0], sl + L.prior.b[0], NS, PP, nullptr);
+      const int nsp = small_ns((long long)K * 2 * Lz);
+      if (nsp != NS) { brange(L.prior.w[0], (uint64_t)K * 2 * Lz, nsp); brange(L.prior.b[0], 2 * Lz, nsp); }
+      return p_tn(w.y, false, K, 1, w.dpp, 2 * Lz, K, 2 * Lz, R, sl + L.prior.w[0], sl + L.prior.b[0], nsp, PP, nullptr);
     };
     dcur = w.dqp;
     for (int i = G.nl - 1; i >= 1; --i) {
       Group g;
+      const int nsg = small_ns((long long)G.dim[i] * G.dim[i + 1]);
+      if (nsg != NS) { brange(G.w[i], (uint64_t)G.dim[i] * G.dim[i + 1], nsg); brange(G.b[i], G.dim[i + 1], nsg); }
       g.add(p_tn(w.hg[i], false, G.dim[i], 1, dcur, G.dim[i + 1], G.dim[i], G.dim[i + 1], R, sl + G.w[i], sl + G.b[i],
-                 NS, PP, nullptr));
+                 nsg, PP, nullptr));
       float* out = w.dbuf[pb];
       g.add(p_nt(dcur, G.dim[i + 1], P + G.w[i], G.dim[i + 1], R, G.dim[i], G.dim[i + 1], out, G.dim[i], w.hg[i],
                  G.dim[i]));
@@ -1386,9 +1405,11 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       Group g;
       const float* Wy = P + G.w[0] + (uint64_t)D * G.dim[1];
       const int nsx = (S > 1 && sxb.n + 2 <= kSlabRanges) ? NSB : NS;
-      if (nsx != NS) { brange(G.w[0], (uint64_t)D * G.dim[1]); brange(G.b[0], G.dim[1]); }
+      if (nsx != NS) { brange(G.w[0], (uint64_t)D * G.dim[1], nsx); brange(G.b[0], G.dim[1], nsx); }
       g.add(p_tn(a.x, true, D, 1, dg, G.dim[1], D, G.dim[1], B, sl + G.w[0], sl + G.b[0], nsx, PP, nullptr));
-      g.add(p_tn(w.y, false, K, 1, dcur, G.dim[1], K, G.dim[1], R, sl + G.w[0] + (uint64_t)D * G.dim[1], nullptr, NS,
+      const int nsy = small_ns((long long)K * G.dim[1]);
+      if (nsy != NS) brange(G.w[0] + (uint64_t)D * G.dim[1], (uint64_t)K * G.dim[1], nsy);
+      g.add(p_tn(w.y, false, K, 1, dcur, G.dim[1], K, G.dim[1], R, sl + G.w[0] + (uint64_t)D * G.dim[1], nullptr, nsy,
                  PP, nullptr));
       Problem p = p_nt(dcur, G.dim[1], Wy, G.dim[1], R, K, G.dim[1], w.dy, K, nullptr, 0);
       p.nseg = 2;                                   // dy = d_g0 Wg0[D:,:]^T + d_prior Wp^T
@@ -1423,7 +1444,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     Group g;
     const void* act = (i == 0) ? (const void*)a.x : (const void*)w.he[i];
     const int nse = (S > 1 && sxb.n + 2 <= kSlabRanges) ? NSB : NS;
-    if (nse != NS) { brange(E.w[i], (uint64_t)E.dim[i] * E.dim[i + 1]); brange(E.b[i], E.dim[i + 1]); }
+    if (nse != NS) { brange(E.w[i], (uint64_t)E.dim[i] * E.dim[i + 1], nse); brange(E.b[i], E.dim[i + 1], nse); }
     g.add(p_tn(act, i == 0, E.dim[i], 1, dcur, E.dim[i + 1], E.dim[i], E.dim[i + 1], B, sl + E.w[i], sl + E.b[i], nse,
                PP, nullptr));
     float* out = nullptr;

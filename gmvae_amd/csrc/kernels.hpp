@@ -477,16 +477,17 @@ __device__ __forceinline__ void adam_update(float& p, float& m, float& v, const 
 
 // Parameter ranges whose weight gradients were split over fewer slabs than the rest (the uint8-activation
 // problems of the fused dW launch run on the bf16 matrix cores and take half the splits of the fp32 ones).
-constexpr int kSlabRanges = 8;
+constexpr int kSlabRanges = 16;
 struct SlabX {
-  int n, ns;                  // ranges in use; slabs of those ranges
+  int n;                      // ranges in use
   int b[kSlabRanges], e[kSlabRanges];   // [begin, end) flat parameter indices, multiples of 4
+  int ns[kSlabRanges];        // slabs written for that range (fewer OR more than the launch's default)
 };
 __device__ __forceinline__ int slab_count(const SlabX& sx, const long long i4, const int dflt) {
   int ns = dflt;
 #pragma unroll
   for (int k = 0; k < kSlabRanges; ++k)
-    if (k < sx.n && i4 >= sx.b[k] && i4 < sx.e[k]) ns = sx.ns;
+    if (k < sx.n && i4 >= sx.b[k] && i4 < sx.e[k]) ns = sx.ns[k];
   return ns;
 }
 
