@@ -1913,6 +1913,16 @@ static int train_graph_create(const GmvaeDims* dims, int model, const uint8_t* p
   int rc = 0;
   he = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
   if (he != hipSuccess) rc = (int)he;
+  // the launch's batches: one kernel in front of the steps (kernels.hpp binarize_batches); GMVAE_BIN_PER_STEP=1 keeps the
+  // per-step forms (a launch per batch, or extra workgroups of the optimizer launch in the mega schedule)
+  const bool bin_all = pixels && !getenv("GMVAE_BIN_PER_STEP");
+  if (rc == 0 && bin_all) {
+    const uint64_t q = (uint64_t)n_steps * dims->B * (uint64_t)(dims->D >> 2);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(binarize_batches, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, cs, pixels, idx, n_rows, dims->B, dims->D,
+                       n_steps, seed ^ 0x62696e6172697a65ull, step_dev, x, dims->row0);
+    rc = (int)hipGetLastError();
+  }
   if (rc == 0) {
     for (int s = 0; s < n_steps && rc == 0; ++s) {
       uint8_t* xs = x + s * xstride;
@@ -1920,8 +1930,8 @@ static int train_graph_create(const GmvaeDims* dims, int model, const uint8_t* p
       // only the first batch of a launch is a launch of its own; batch s + 1 is drawn by extra workgroups of step s's
       // finalize_adam launch (same values: the uniforms are keyed by the consuming step's index).
       const uint64_t bseed = seed ^ 0x62696e6172697a65ull;
-      const bool ride = pixels && mega_ok(*dims, model) && !getenv("GMVAE_NO_BIN_RIDE");
-      if (pixels && (!ride || s == 0))
+      const bool ride = pixels && !bin_all && mega_ok(*dims, model) && !getenv("GMVAE_NO_BIN_RIDE");
+      if (pixels && !bin_all && (!ride || s == 0))
         rc = gmvae_binarize(pixels, n_rows, idx + (size_t)s * dims->B, 0, dims->B, dims->D, bseed, 0, step_dev, xs,
                             dims->row0, cs);
       if (rc) break;

@@ -941,6 +941,20 @@ __global__ __launch_bounds__(256) void img_build(const float* __restrict__ p, lo
   }
 }
 
+// Input pipeline of a train graph: ALL of a launch's batches binarised by its first kernel.  The uniforms are keyed by
+// (seed, the CONSUMING step's index, global pixel quad), none of which depends on the training state, so batch j of the
+// launch (consumed by step *step_dev + j) needs no ordering with the steps before it.  (As extra workgroups of every
+// step's optimizer launch the same work cost 3.5 us per step; up front it is ~0.4.)
+__global__ void binarize_batches(const unsigned char* __restrict__ pixels, const int32_t* __restrict__ idx, uint64_t n_rows_src,
+                                 int B, int D, int n_batches, uint64_t seed, const uint64_t* step_dev,
+                                 unsigned char* __restrict__ x, uint64_t out_row0) {
+  const uint64_t qpb = (uint64_t)B * (uint64_t)(D >> 2);
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t j = q / qpb;
+  if (j >= (uint64_t)n_batches) return;
+  binarize_quad(q - j * qpb, pixels, idx + j * (uint64_t)B, 0, n_rows_src, B, D, seed, *step_dev + j, x + j * (uint64_t)B * D, out_row0);
+}
+
 // auxiliary work without a GEMM: the image tasks of the first step of a train graph
 __global__ __launch_bounds__(kThreads) void aux_only(const Aux ax) { aux_block(ax, (int)blockIdx.x); }
 
