@@ -208,6 +208,8 @@ static int num_splits_small(long long R) {
   long long ns = R / 400;
   if (ns < 1) ns = 1;
   if (ns > NS_SMALL_MAX) ns = NS_SMALL_MAX;
+  const char* e = getenv("GMVAE_NSPLIT_SMALL");      // (tests: the many-splits path at sizes the oracle covers)
+  if (e && atoi(e) >= 1 && atoi(e) <= NS_SMALL_MAX) ns = atoi(e);
   return (int)ns;
 }
 

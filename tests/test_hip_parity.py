@@ -240,6 +240,22 @@ def test_big_round_gemm_inside_the_step_iwae(H, monkeypatch, model):
     np.testing.assert_allclose(g_big, g_gen, rtol=0, atol=2e-4 * np.abs(g_gen).max())
 
 
+def test_many_splits_for_small_weight_gradients_and_few_for_batch_row_ones(H, monkeypatch):
+    """General schedule, S > 1: the per-range slab counts of finalize_grads -- weight gradients contracted over the B batch
+    rows written to num_splits(B) slabs, those with few outputs and a contraction over all B*S rows to MORE slabs than the
+    rest (forced here at a size the oracle covers; by default from R = 6800 rows) -- against the oracle."""
+    monkeypatch.setenv("GMVAE_NSPLIT_SMALL", "12")            # R = 1200 rows: 4 slabs by default, 1 for the B = 300-row products
+    d = O.Dims(D=96, L=12, K=7, hidden=(40, 24), S=4)
+    rng = np.random.default_rng(9)
+    for model in (O.MODEL_GMVAE, O.MODEL_VAE, O.MODEL_VAE_GMP):
+        p = O.init_params(model, d, rng)
+        for k in p:
+            if k.endswith("/b"):
+                p[k] = rng.normal(0, 0.05, p[k].shape)
+        x, eps, u = O.make_inputs(d, 300, model)
+        H.compare_step(model, d, p, x, eps, u, grad_rtol=2e-4)
+
+
 @pytest.mark.parametrize("env", [{}, {"GMVAE_NO_MEGA": "1"}, {"GMVAE_NO_FUSED": "1"}],
                          ids=["mega", "chain-kernels", "general-schedule"])
 @pytest.mark.parametrize("B,L", [(1024, 64), (40, 16), (7, 8)])
