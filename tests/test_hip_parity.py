@@ -207,6 +207,40 @@ def test_step_matches_oracle(H, name, d, B):
     H.compare_step(model, d, p, x, eps, u)
 
 
+def _random_cases(n, seed):
+    """Seeded random model shapes (widths that are and are not multiples of the 32 / 64 / 128 tile sizes, 0-3 hidden
+    layers, IWAE samples, batches from one ragged panel to a few hundred rows): the tile-configuration choice, the
+    big-round eligibility, the slab-count ranges and the schedules' size gates all depend on them."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        model = ["gmvae", "vae", "vae_gmp"][i % 3]
+        nl = int(rng.integers(0, 4))
+        hidden = tuple(int(rng.choice([16, 24, 40, 64, 96, 128, 200])) for _ in range(nl))
+        d = O.Dims(D=int(rng.choice([64, 100, 128, 256, 300, 784])), L=int(rng.choice([2, 5, 8, 16, 30, 64])),
+                   K=1 if model == "vae" else int(rng.choice([2, 7, 10, 16, 33])), hidden=hidden,
+                   S=int(rng.choice([1, 1, 2, 3])), temperature=float(rng.choice([1.0, 0.7])))
+        out.append((model, d, int(rng.choice([1, 7, 16, 50, 128, 257]))))
+    return out
+
+
+RANDOM_CASES = _random_cases(18, 20261004)
+
+
+@pytest.mark.parametrize("name,d,B", RANDOM_CASES, ids=[f"{n}-D{d.D}-L{d.L}-K{d.K}-H{'x'.join(map(str, d.hidden)) or 'none'}-S{d.S}-B{B}"
+                                                         for n, d, B in RANDOM_CASES])
+def test_step_matches_oracle_on_random_shapes(H, name, d, B):
+    model = O.MODEL_NAMES[name]
+    rng = np.random.default_rng(B * 131 + d.D)
+    p = O.init_params(model, d, rng)
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    x, eps, u = O.make_inputs(d, B, model)
+    H.compare_step(model, d, p, x, eps, u, grad_rtol=3e-4 if d.S > 1 else 1e-4)
+
+
+
 def test_config5_shapes_iwae(H):
     """BASELINE config 5 shapes (D=3072, K=64, S=50, H=512) at a batch the oracle finishes in seconds.
     ELBO at 1e-4; gradients at 5e-4: log w ~ -2100 has an fp32 ulp of 2.4e-4, which the IWAE weights
