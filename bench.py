@@ -359,6 +359,13 @@ def main():
                         roof["rocprof_usec_per_launch"] = us
                         roof["frac_rocprof"] = dom[2] / us * 1e-6 / PEAK_F32_MFMA_TFLOPS
                         roof["rocprof_source"] = "profiles/round2_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command; the profiled run is slower than the timed one)"
+            elif a.config == "configs4_shard" and world == 1:
+                # the config-5 shard's dominant launch: the 128x128 GEMM launch with the most fabric traffic (decoder backward)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "round2_traffic_config5.json")))
+                big = [v["hbm_bytes_per_launch"] for k, v in tj.items() if "gemm_grouped<gmvae::Cfg<128, 128" in k]
+                if big and dom[0] == "bwd_dec_top":
+                    roof["traffic"] = max(big)
+                    roof["traffic_source"] = "profiles/round2_traffic_config5.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         except Exception:
             pass
         if a.levels:

@@ -13,4 +13,5 @@ python3 tools/pmc_summary.py $S/pmc_FETCH_SIZE/pmc_counter_collection.csv $S/pmc
   $S/pmc_SQ_BUSY_CYCLES/pmc_counter_collection.csv $S/pmc_SQ_WAVE_CYCLES/pmc_counter_collection.csv > profiles/round2_pmc_per_kernel.txt
 python3 tools/traffic_from_pmc.py $S/pmc_FETCH_SIZE/pmc_counter_collection.csv $S/pmc_WRITE_SIZE/pmc_counter_collection.csv profiles/round2_traffic.json
 cp $S/pmc_config5_summary.txt profiles/round2_pmc_config5_clock_mfma.txt
+cp $S/pmc_config5_traffic.json profiles/round2_traffic_config5.json
 ls -la profiles/round2_*

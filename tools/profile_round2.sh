@@ -21,5 +21,6 @@ du -sh $O; find $O -name "*.csv" | head -40
 # config-5 shard: effective clock and matrix-pipe utilisation in cycles per GEMM launch
 bash $R/tools/pmc_config5.sh > $O/pmc_config5.log 2>&1 || { echo FAILED pmc_config5; tail -5 $O/pmc_config5.log; }
 cp $R/gpurun_out/pmc_c5/summary.txt $O/pmc_config5_summary.txt 2>/dev/null
-rm -rf $R/gpurun_out/pmc_c5/run
+cp $R/gpurun_out/pmc_c5/traffic.json $O/pmc_config5_traffic.json 2>/dev/null
+rm -rf $R/gpurun_out/pmc_c5/run $R/gpurun_out/pmc_c5/FETCH_SIZE $R/gpurun_out/pmc_c5/WRITE_SIZE
 du -sh $O
