@@ -65,6 +65,7 @@ struct Problem {
   long long split_stride;  // floats between split-K slabs
   float* C;
   int xbf16;               // dW of a uint8 activation (A = x^T, k-major rows of bytes; B = dY fp32 rows): bf16 MFMA path
+  int xorder;              // tile order inside the launch (gemm_grouped: 0 split/tn/tm, 1 all tn of a tm on one XCD, 2 all tm of a (split, tn))
   int split3;              // large-tile configuration: fp32 x fp32 products on the bf16 matrix cores (see split3 below):
                            // 1 = six piece products, 2 = all nine
   float* colsum_out;       // bias gradient riding on a dW problem: column sums of operand b over the tile's k
@@ -607,11 +608,34 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
   asm volatile("" ::"s"(splits), "s"(tiles_n), "s"(nseg), "s"(a_ptr), "s"(a_ld), "s"(a_n), "s"(a_div),
                "s"(akind), "s"(b_ptr), "s"(b_ld), "s"(b_n), "s"(b_div), "s"(bkind), "s"(kscale), "s"(K));
 
-  int t = bid - tb;
-  const int split = t % splits;
-  t /= splits;
-  const int tn = t % tiles_n;
-  const int tm = t / tiles_n;
+  // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (observed; speed only), each with an L2 of its own, and
+  // the ~64 tiles an XCD runs at a time walk k together: what they share is fetched once.  xorder 0: split fastest, then
+  // tn, then tm (an XCD keeps a few B column blocks and streams every A row block: right when B is small).  xorder 1
+  // (A much taller than B is wide: a data gradient): the tiles of one tm -- all tn -- are consecutive on ONE XCD, so its 64
+  // concurrent tiles are 64 / tiles_n row blocks x all column blocks instead of 64 row blocks x one column block.  xorder 2
+  // (B much wider than A is tall: a weight gradient): the tiles of one (split, tn) -- all tm -- likewise.  (Config 5's
+  // decoder backward launch moved 3.0 GB through the fabric for 0.9 GB of operands with xorder 0.)
+  int tm, tn, split;
+  {
+    const int t = bid - tb;
+    const int xo = L.p[pi].xorder;
+    if (xo == 0) {
+      split = t % splits;
+      const int u = t / splits;
+      tn = u % tiles_n;
+      tm = u / tiles_n;
+    } else {
+      const int tiles_m_ = L.p[pi].tiles_m;
+      const int gs = xo == 1 ? tiles_n * splits : tiles_m_;                 // tiles per group
+      const int ng = xo == 1 ? tiles_m_ : tiles_n * splits;                 // groups
+      const int full = ng & ~7;                                             // groups dealt 8 at a time, one per XCD
+      int grp, mem;
+      if (t < full * gs) { const int j = t >> 3; grp = (j / gs) * 8 + (t & 7); mem = j % gs; }
+      else { const int t2 = t - full * gs; grp = full + t2 / gs; mem = t2 % gs; }
+      if (xo == 1) { tm = grp; split = mem % splits; tn = mem / splits; }
+      else { tm = mem; split = grp % splits; tn = grp / splits; }
+    }
+  }
   const int m0 = tm * C::BM, n0 = tn * C::BN;
 
   const int wk = wave / (C::WM * C::WN);

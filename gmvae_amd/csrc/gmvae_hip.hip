@@ -392,10 +392,17 @@ struct Group {
 template <class C>
 static int tile_up(Launch& L) {
   int t = 0;
+  static const bool xorder_on = !getenv("GMVAE_NO_XORDER");
   for (int i = 0; i < L.nprob; ++i) {
     Problem& p = L.p[i];
     p.tiles_m = (p.M + C::BM - 1) / C::BM;
     p.tiles_n = (p.N + C::BN - 1) / C::BN;
+    // XCD-aware tile order (gemm.hpp): only where it matters -- many tiles and one operand much larger than the other
+    p.xorder = 0;
+    if (xorder_on && C::BM == 128 && (long long)p.tiles_m * p.tiles_n * p.splits >= 512) {
+      if (p.tiles_m >= 16 * p.tiles_n && p.tiles_n * p.splits <= 16) p.xorder = 1;
+      else if (p.tiles_n >= 4 * p.tiles_m && p.tiles_m <= 16) p.xorder = 2;
+    }
     p.tile_begin = t;
     L.tile_begin[i] = t;
     p.nparts = p.tiles_n;
