@@ -626,14 +626,17 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
       tm = u / tiles_n;
     } else {
       const int tiles_m_ = L.p[pi].tiles_m;
-      const int gs = xo == 1 ? tiles_n * splits : tiles_m_;                 // tiles per group
-      const int ng = xo == 1 ? tiles_m_ : tiles_n * splits;                 // groups
+      // (xorder 3, both operands large: groups of 8 column tiles of one tm, the groups of one block of 8 column tiles
+      //  consecutive -- an XCD's 64 concurrent tiles are then 8 row blocks x 8 column blocks)
+      const int gs = xo == 1 ? tiles_n * splits : (xo == 2 ? tiles_m_ : 8 * splits);                 // tiles per group
+      const int ng = xo == 1 ? tiles_m_ : (xo == 2 ? tiles_n * splits : tiles_m_ * (tiles_n >> 3));  // groups
       const int full = ng & ~7;                                             // groups dealt 8 at a time, one per XCD
       int grp, mem;
       if (t < full * gs) { const int j = t >> 3; grp = (j / gs) * 8 + (t & 7); mem = j % gs; }
       else { const int t2 = t - full * gs; grp = full + t2 / gs; mem = t2 % gs; }
       if (xo == 1) { tm = grp; split = mem % splits; tn = mem / splits; }
-      else { tm = mem; split = grp % splits; tn = grp / splits; }
+      else if (xo == 2) { tm = mem; split = grp % splits; tn = grp / splits; }
+      else { tm = grp % tiles_m_; split = mem % splits; tn = (grp / tiles_m_) * 8 + mem / splits; }
     }
   }
   const int m0 = tm * C::BM, n0 = tn * C::BN;

@@ -402,6 +402,7 @@ static int tile_up(Launch& L) {
     if (xorder_on && C::BM == 128 && (long long)p.tiles_m * p.tiles_n * p.splits >= 512) {
       if (p.tiles_m >= 16 * p.tiles_n && p.tiles_n * p.splits <= 16) p.xorder = 1;
       else if (p.tiles_n >= 4 * p.tiles_m && p.tiles_m <= 16) p.xorder = 2;
+      else if (p.tiles_m >= 64 && p.tiles_n >= 16 && (p.tiles_n & 7) == 0 && p.splits == 1) p.xorder = 3;
     }
     p.tile_begin = t;
     L.tile_begin[i] = t;

@@ -112,7 +112,7 @@ def test_gemm_split3_bf16_piece_products(H, monkeypatch, terms, trans, M, N, K):
                                             (2, 256, 128, 320, 3), (0, 128, 128, 32, 1),
                                             # >= 512 tiles: the XCD-aware tile orders (all tn of a tm / all tm of a (split, tn)
                                             # consecutive on one XCD), group counts that are no multiple of 8
-                                            (1, 128 * 131, 512, 64, 1), (2, 512, 128 * 43, 96, 3)])
+                                            (1, 128 * 131, 512, 64, 1), (2, 512, 128 * 43, 96, 3), (0, 128 * 67, 128 * 16, 64, 1)])
 def test_gemm_big_rounds_instance(H, monkeypatch, trans, M, N, K, ns):
     """Launches whose tiles are all interior 128x128 tiles of fp32 operands with whole 32-deep rounds run the big-round
     instance (gemm.hpp big_rounds: swizzled [k/4][mn][4] LDS images, 16-byte fragment reads): every operand orientation
