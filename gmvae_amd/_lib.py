@@ -26,7 +26,8 @@ class GmvaeDims(C.Structure):
     _fields_ = [("B", C.c_int32), ("D", C.c_int32), ("L", C.c_int32), ("K", C.c_int32), ("S", C.c_int32),
                 ("n_hidden", C.c_int32), ("hidden", C.c_int32 * MAX_HIDDEN),
                 ("sigma_min", C.c_float), ("raw_sigma_bias", C.c_float), ("temperature", C.c_float),
-                ("gen_bias_init", C.c_float), ("row0", C.c_uint64)]
+                ("gen_bias_init", C.c_float), ("row0", C.c_uint64),
+                ("gen_bias_vec", C.c_void_p), ("gen_bias_len", C.c_int32), ("reserved_", C.c_int32)]   # ABI v3
 
 
 class GmvaeParamEntry(C.Structure):
@@ -92,7 +93,10 @@ def check(rc: int, what: str):
     raise GmvaeError(f"{what}: hipError_t {rc}")
 
 
-def make_dims(B, D, L, K, hidden, S=1, sigma_min=0.0, raw_sigma_bias=0.5, temperature=1.0, gen_bias_init=0.0, row0=0):
+def make_dims(B, D, L, K, hidden, S=1, sigma_min=0.0, raw_sigma_bias=0.5, temperature=1.0, gen_bias_init=0.0, row0=0,
+              gen_bias_vec=None):
+    """gen_bias_vec: fp32 device tensor [D] (ConditionalBernoulli's vector bias_init, scripts/base.py:102-103) or None;
+    the caller keeps it alive for as long as the dims are used."""
     hidden = list(hidden)
     if len(hidden) > MAX_HIDDEN:
         raise ValueError(f"at most {MAX_HIDDEN} hidden layers")
@@ -103,6 +107,10 @@ def make_dims(B, D, L, K, hidden, S=1, sigma_min=0.0, raw_sigma_bias=0.5, temper
     d.sigma_min, d.raw_sigma_bias = float(sigma_min), float(raw_sigma_bias)
     d.temperature, d.gen_bias_init = float(temperature), float(gen_bias_init)
     d.row0 = int(row0)          # data parallel: global index of this device's first batch row (Philox counters only)
+    if gen_bias_vec is not None:
+        if gen_bias_vec.numel() != int(D) or not gen_bias_vec.is_cuda or not gen_bias_vec.is_contiguous():
+            raise ValueError(f"gen_bias_vec must be a contiguous fp32 device tensor of {D} elements")
+        d.gen_bias_vec, d.gen_bias_len = gen_bias_vec.data_ptr(), int(D)
     return d
 
 

@@ -28,6 +28,21 @@ def _check_relu(fn):
                               f"hidden_activation_fn={fn!r} is not supported")
 
 
+# scripts/base.py:12 DEFAULT_INITIALIZERS = {'w': xavier, 'b': zeros}: what Engine.init_parameters draws.  A custom
+# `initializers` dict maps 'w' and/or 'b' to a callable shape -> array-like (the stand-in for a TF initializer op, which
+# cannot exist here); it is applied to the network's tensors of the flat parameter buffer when the conditional is bound.
+DEFAULT_INITIALIZERS = {"w": "xavier_uniform", "b": "zeros"}
+
+
+def _check_initializers(init):
+    if init is None or init is DEFAULT_INITIALIZERS or init == DEFAULT_INITIALIZERS:
+        return None
+    if not isinstance(init, dict) or not init or any(k not in ("w", "b") or not callable(v) for k, v in init.items()):
+        raise TypeError("initializers must be None, base.DEFAULT_INITIALIZERS or a dict mapping 'w' / 'b' to callables "
+                        f"shape -> array (scripts/base.py:18,49-50); got {init!r}")
+    return dict(init)
+
+
 def _gen(seed, device):
     if seed is None:
         return None
@@ -120,8 +135,9 @@ class MixtureSameFamily:
 
 # -------------------------------------------------- conditional networks
 class _Conditional:
-    def __init__(self, size, hidden_layer_sizes, hidden_activation_fn, name):
+    def __init__(self, size, hidden_layer_sizes, hidden_activation_fn, name, initializers=None):
         _check_relu(hidden_activation_fn)
+        self._initializers = _check_initializers(initializers)
         self._name, self._size = name, size
         self._hidden = None if hidden_layer_sizes is None else list(hidden_layer_sizes)
         self._engine = None
@@ -131,6 +147,19 @@ class _Conditional:
         """Attach to the flat parameter buffer (the factories do this; it stands in
         for Sonnet's lazy variable creation, scripts/base.py:47-60)."""
         self._engine, self._net = engine, net_id
+        if self._initializers:                      # custom initializers: re-draw this network's tensors
+            prefix = self._name + "_fcnet/"
+            hit = False
+            with torch.no_grad():
+                for name, view in engine.views().items():
+                    fn = self._initializers.get(name[-1]) if name.startswith(prefix) else None
+                    if fn is not None:
+                        val = torch.as_tensor(fn(tuple(view.shape)), dtype=torch.float32).reshape(view.shape)
+                        view.copy_(val.to(view.device))
+                        hit = True
+            if not hit:
+                raise ValueError(f"{self._name}: no variables named {prefix}* in the engine's parameter layout")
+            engine.drop_graphs()                    # (captured graphs hold weight images of the old values)
         return self
 
     def _mlp(self, tensor_list):
@@ -149,7 +178,7 @@ class _Conditional:
 class ConditionalNormal(_Conditional):
     def __init__(self, size, hidden_layer_sizes=None, initializers=None, sigma_min=0.0, raw_sigma_bias=0.25,
                  hidden_activation_fn=torch.relu, name="cond_normal"):
-        super().__init__(size, hidden_layer_sizes, hidden_activation_fn, name)
+        super().__init__(size, hidden_layer_sizes, hidden_activation_fn, name, initializers)
         self._sigma_min, self._raw_sigma_bias = sigma_min, raw_sigma_bias
 
     def condition(self, tensor_list, **unused_kwargs):
@@ -166,11 +195,13 @@ class ConditionalNormal(_Conditional):
 class ConditionalBernoulli(_Conditional):
     def __init__(self, size, hidden_layer_sizes=None, initializers=None, bias_init=0.0,
                  hidden_activation_fn=torch.relu, name="cond_bernoulli"):
-        super().__init__(size, hidden_layer_sizes, hidden_activation_fn, name)
+        super().__init__(size, hidden_layer_sizes, hidden_activation_fn, name, initializers)
         self._bias_init = bias_init
 
     def condition(self, tensor_list, **unused_kwargs):
-        return self._mlp(tensor_list)        # + bias_init is applied inside gmvae_mlp_forward (gen_bias_init)
+        # + bias_init (scalar or vector, scripts/base.py:135) is applied inside gmvae_mlp_forward: the Engine this
+        # conditional is bound to was created with the same value (gen_bias_init / gen_bias_vec of GmvaeDims)
+        return self._mlp(tensor_list)
 
     def __call__(self, *args, **kwargs):
         return IndependentBernoulli(self.condition(args, **kwargs), name=self._name)
@@ -179,7 +210,7 @@ class ConditionalBernoulli(_Conditional):
 class ConditionalCategorical(_Conditional):
     def __init__(self, size, hidden_layer_sizes=None, temperature=1.0, initializers=None,
                  hidden_activation_fn=torch.relu, name="cond_categorical"):
-        super().__init__(size, hidden_layer_sizes, hidden_activation_fn, name)
+        super().__init__(size, hidden_layer_sizes, hidden_activation_fn, name, initializers)
         self._temperature = temperature
 
     def condition(self, tensor_list, **unused_kwargs):

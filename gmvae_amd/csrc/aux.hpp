@@ -142,7 +142,7 @@ __device__ __forceinline__ void mat_fill(float* __restrict__ dst, const int ld, 
   }
 }
 
-// Dynamic binarisation of the input pipeline (scripts/runners.py:48-51 `_preprocess`), one quad (4 consecutive pixels
+// Dynamic binarisation of the input pipeline (scripts/runners.py:44-47 `_preprocess`), one quad (4 consecutive pixels
 // of one output row): image = cast(pixel, float32) / 255.; x = image < uniform(shape)  (so P[x = 1] = 1 - pixel/255).
 // One 4-byte load, one Philox4x32-10 call (counter = output quad index, stream tag 0x40000000, key = seed, step), one
 // 4-byte store.

@@ -71,6 +71,7 @@ struct Problem {
   float* colsum_out;       // bias gradient riding on a dW problem: column sums of operand b over the tile's k
                            // range, written by the tiles of the first tile row to colsum_out[split][n]
   const float* bias;
+  const float* bias2;      // second per-column constant (ConditionalBernoulli's vector bias_init, scripts/base.py:135) or nullptr
   const float* addsrc;
   const float* mask;       // keep where mask > 0
   const float* rowscale;
@@ -935,6 +936,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
   const int M = L.p[pi].M, N = L.p[pi].N, ldc = L.p[pi].ldc, epi = L.p[pi].epi;
   float* Cout = L.p[pi].C;
   const float* bias = L.p[pi].bias;
+  const float* bias2 = L.p[pi].bias2;
   const float addconst = L.p[pi].addconst;
   constexpr int GPR = C::BN / 4;                 // groups per row (8, 16 or 32 consecutive lanes)
   constexpr int PASSES = C::BM * GPR / kThreads;
@@ -946,7 +948,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
     const long long soff = (long long)split * L.p[pi].split_stride;
     // plain slab / matrix store of an interior tile (every weight-gradient tile but the edge ones): no per-element
     // options, all passes unrolled, 16-byte stores
-    const bool plain = !bias && !addsrc && !mask && !rowscale && !relu && addconst == 0.f && m0 + C::BM <= M &&
+    const bool plain = !bias && !bias2 && !addsrc && !mask && !rowscale && !relu && addconst == 0.f && m0 + C::BM <= M &&
                        n0 + C::BN <= N && (ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(Cout + soff) & 15) == 0);
     if (plain) {
       float* const dst0 = Cout + soff + (long long)m0 * ldc + n0;
@@ -962,7 +964,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
         }
         *reinterpret_cast<float4*>(dst0 + (long long)row * ldc + 4 * c4) = v4;
       }
-    } else if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && al16(Cout + soff) && (!bias || al16(bias)) &&
+    } else if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && al16(Cout + soff) && (!bias || al16(bias)) && (!bias2 || al16(bias2)) &&
                (!addsrc || ((ld_add & 3) == 0 && al16(addsrc))) && (!mask || ((ld_mask & 3) == 0 && al16(mask)))) {
       // interior tile with options: 16-byte loads of every per-element option, ALL passes' loads in flight together (the
       // accumulators are staged, their registers are free): one pass at a time, each pass waits a full memory round trip --
@@ -970,7 +972,8 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
       constexpr int RPP = kThreads / GPR;        // rows per pass; the column group is the same in every pass
       constexpr int PB = PASSES;          // every pass's loads in flight together: ONE memory round trip per tile
       const int c4 = tid % GPR, r0 = tid / GPR, nb = n0 + 4 * c4;
-      const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias2) { const float4 c4v = *reinterpret_cast<const float4*>(bias2 + nb); b4.x += c4v.x; b4.y += c4v.y; b4.z += c4v.z; b4.w += c4v.w; }
 #pragma unroll
       for (int pb = 0; pb < PASSES; pb += PB) {
         float4 a4[PB], k4[PB];
@@ -1025,6 +1028,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
           const int n = min(nb + j, N - 1);
           float x = v[j];
           if (bias) x += bias[n];
+          if (bias2) x += bias2[n];
           if (addsrc) x += addsrc[(long long)(m / add_div) * ld_add + n];
           x += addconst;
           if (relu) x = fmaxf(x, 0.f);
@@ -1045,7 +1049,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
     const unsigned char* xp = L.p[pi].x;
     float* part = L.p[pi].part;
     const int ldx = L.p[pi].ldx, x_div = L.p[pi].x_div, nparts = L.p[pi].nparts;
-    if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && (!Cout || al16(Cout)) && al16(bias) && (ldx & 3) == 0 &&
+    if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && (!Cout || al16(Cout)) && al16(bias) && (!bias2 || al16(bias2)) && (ldx & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(xp) & 3) == 0) {
       // interior tile: the bias quad once, the 4 target bytes of a pass as one word; every pass's target word AND staged
       // accumulator quad are requested before the first is used (ONE memory and ONE LDS round trip per tile), and the row
@@ -1053,7 +1057,8 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
       // tile, each several hundred cycles beside the co-resident workgroup's fragment reads: 22 us of a 77 us tile)
       constexpr int RPP = kThreads / GPR;
       const int c4 = tid % GPR, r0 = tid / GPR, nb = n0 + 4 * c4;
-      const float4 b4 = *reinterpret_cast<const float4*>(bias + nb);
+      float4 b4 = *reinterpret_cast<const float4*>(bias + nb);
+      if (bias2) { const float4 c4v = *reinterpret_cast<const float4*>(bias2 + nb); b4.x += c4v.x; b4.y += c4v.y; b4.z += c4v.z; b4.w += c4v.w; }
       const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
       unsigned xw[PASSES];
       f32x4 vv[PASSES];
@@ -1091,10 +1096,12 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
       }
       __syncthreads();
       if (tid < C::BM) {
-        float t = 0.f;
+        // (fp64: the row's partial sum grows to ~0.7 x BN; S > 1 turns the ABSOLUTE error of log w into a relative error
+        //  of every gradient, and 32 sequential fp32 adds at that magnitude were its largest remaining piece)
+        double t = 0.0;
 #pragma unroll
-        for (int c = 0; c < GPR; ++c) t += lds[tid * C::LDC + 4 * c];
-        part[(long long)(m0 + tid) * nparts + tn] = t;
+        for (int c = 0; c < GPR; ++c) t += (double)lds[tid * C::LDC + 4 * c];
+        part[(long long)(m0 + tid) * nparts + tn] = (float)t;
       }
     } else
 #pragma unroll 1
@@ -1118,7 +1125,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
           // ONE exp, ONE rcp and ONE log per element give softplus AND the sigmoid (the hardware forms, ~1e-6 relative:
           // the ELBO tolerance is 1e-4; the libm log1pf / division forms cost ~4x the instructions and were 10 % of
           // this launch at the config-5 sizes)
-          const float lam = v[j] + bias[n] + addconst;
+          const float lam = v[j] + bias[n] + (bias2 ? bias2[n] : 0.f) + addconst;
           const float xv = (float)xr[n];
           const float e = __expf(-fabsf(lam));
           const float rcp = __builtin_amdgcn_rcpf(1.f + e);

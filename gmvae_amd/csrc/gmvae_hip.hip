@@ -91,8 +91,8 @@ static int check_dims(const GmvaeDims* d, int model) {
   if (d->n_hidden < 0 || d->n_hidden > MAXH) return GMVAE_E_DIMS;
   for (int i = 0; i < d->n_hidden; ++i)
     if (d->hidden[i] < 1) return GMVAE_E_DIMS;
-  if (model == GMVAE_MODEL_VAE_GMP && (d->K > 64 || (2LL * d->K * (d->L | 1) + 64 + 4LL * 64 * d->L) * 4 > 150 * 1024))
-    return GMVAE_E_DIMS;
+  if (d->gen_bias_vec ? d->gen_bias_len != d->D : d->gen_bias_len != 0) return GMVAE_E_DIMS;
+  if (d->gen_bias_vec && (reinterpret_cast<uintptr_t>(d->gen_bias_vec) & 3)) return GMVAE_E_ALIGN;
   if ((long long)d->B * d->S > (1LL << 30)) return GMVAE_E_DIMS;
   return 0;
 }
@@ -125,6 +125,8 @@ struct WS {
   float* hd[MAXH + 2];   // decoder activations [R, dim[i]]
   float *gx, *logits, *y, *nent, *pp, *qp, *z, *logq, *logp, *logpx, *logw, *rw, *resp, *g, *part;
   float *dbuf[3], *dz, *dqp, *dpp, *dy, *dlogits, *dqb, *slabs, *gmp_part;
+  float *gmp_inv, *gmp_cst;     // tiled mixture log-prob (any K, L): 1 / softplus(raw_scale_diag) [K][L], per-component constants [K]
+  double* lw64;            // S > 1: log w per row in fp64 (kernels.hpp row_terms / iwae_rows)
   float *pb, *dsum;        // S > 1: per-row IWAE partials [B][4]; sum over s of encoder_gmm's first-layer gradient [B][H]
   float *s1, *s4;          // split-K slabs of the fused schedule: [NSF][B][2H], [NSF][B][H]
   unsigned long long* stamps;   // diagnostic stamps of the chain kernels: [2][grid][16]
@@ -171,6 +173,7 @@ static bool mega_ok(const GmvaeDims& d, int model) {
   const char* e2 = getenv("GMVAE_NO_FUSED");
   if (e2 && atoi(e2)) return false;
   if (d.n_hidden != 1 || d.S != 1 || d.D % 16) return false;
+  if (d.gen_bias_vec) return false;            // the vector bias_init is applied by the grouped GEMM's epilogue (Problem::bias2)
   const int H = d.hidden[0];
   if (H % 16 || H > 64 || d.L % 2 || d.L > 128 || d.K > 64) return false;      // L even: k-steps of 4 over [mu | raw]
   if (model == GMVAE_MODEL_VAE_GMP && (d.B + kPanel - 1) / kPanel > GMP_PARTS) return false;
@@ -245,6 +248,8 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     if (model == GMVAE_MODEL_VAE_GMP) {
       w.resp = take(R * K);
       w.gmp_part = take((uint64_t)GMP_PARTS * (2 * pad4(K * Lz) + pad4(K)));
+      w.gmp_inv = take(pad4(K * Lz));
+      w.gmp_cst = take(pad4(K));
     }
   }
   for (int i = 1; i < L.dec.nl; ++i) w.hd[i] = take(R * L.dec.dim[i]);
@@ -285,6 +290,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
   w.dqp = take(R * 2 * Lz);
   if (d.S > 1) {
     w.pb = take(B * 4);
+    w.lw64 = reinterpret_cast<double*>(take(2 * R));
     if (model == GMVAE_MODEL_GMVAE) w.dsum = take(B * maxh);
   }
   {
@@ -1148,6 +1154,7 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
     Problem p = p_nn(w.hd[1], false, H, P + Dn.w[1], D, B, D, H, a.backward ? w.g : nullptr, D, P + Dn.b[1], false);
     p.epi = EPI_BERNOULLI;
     p.addconst = d.gen_bias_init;
+    p.bias2 = d.gen_bias_vec;
     p.x = a.x; p.ldx = D; p.x_div = 1; p.part = w.part;
     g.add(p);
     const int bn = cfg_bn(launch_group(cx, g, "fwd_dec_bernoulli"));
@@ -1290,11 +1297,21 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   if (prior == PRIOR_GMP) {
     int Kp = 1;
     while (Kp < K) Kp <<= 1;
-    const int nw = 4, rpw = 64 / Kp;
+    const int nw = 4, rpw = Kp <= 64 ? 64 / Kp : 0;
     const size_t sh = (size_t)(2 * K * (Lz | 1) + 64 + nw * rpw * Lz) * sizeof(float);
-    hipLaunchKernelGGL(mixture_logprob_lse, dim3(grid_for(R, nw * rpw, 1024)), dim3(64 * nw), sh, st, w.z,
-                       P + L.loc, P + L.rawscale, P + L.mixlog, w.logp, w.resp, R, Lz, K, Kp);
-    rowk(cx, "mixture_logprob_lse");
+    // the LDS-resident form needs K <= 64 and the (loc, 1/s) image inside the default 64 KB of dynamic LDS; any other
+    // size (scripts/vae.py:231-244 bounds neither K nor L) takes the tiled form
+    if (K > 64 || sh > 64 * 1024 || getenv("GMVAE_GMP_TILED")) {
+      hipLaunchKernelGGL(gmp_consts, dim3(K), dim3(256), 0, st, P + L.rawscale, P + L.mixlog, w.gmp_inv, w.gmp_cst, Lz, K);
+      rowk(cx, "gmp_consts");
+      hipLaunchKernelGGL(mixture_logprob_tiled, dim3(grid_for(R, 16, 2048)), dim3(256), 0, st, w.z, P + L.loc, w.gmp_inv,
+                         w.gmp_cst, w.logp, w.resp, R, Lz, K);
+      rowk(cx, "mixture_logprob_tiled");
+    } else {
+      hipLaunchKernelGGL(mixture_logprob_lse, dim3(grid_for(R, nw * rpw, 1024)), dim3(64 * nw), sh, st, w.z,
+                         P + L.loc, P + L.rawscale, P + L.mixlog, w.logp, w.resp, R, Lz, K, Kp);
+      rowk(cx, "mixture_logprob_lse");
+    }
   }
   int nparts = 1;
   const NetL& Dn = L.dec;
@@ -1310,6 +1327,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
                        P + Dn.b[i], false);
       p.epi = EPI_BERNOULLI;
       p.addconst = d.gen_bias_init;
+      p.bias2 = d.gen_bias_vec;
       p.x = a.x; p.ldx = D; p.x_div = S; p.part = w.part;
       g.add(p);
       const int bn = cfg_bn(launch_group(cx, g, "fwd_dec_bernoulli"));
@@ -1317,12 +1335,12 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     }
   }
   hipLaunchKernelGGL(row_terms, dim3(grid_for(R, 256, 1 << 22)), dim3(256), 0, st, w.part, nparts, w.logq, w.logp,
-                     gm ? w.nent : (const float*)nullptr, S, w.logpx, w.logw, a.row_terms, R);
+                     gm ? w.nent : (const float*)nullptr, S, w.logpx, w.logw, a.row_terms, R, S > 1 ? w.lw64 : (double*)nullptr);
   rowk(cx, "row_terms");
   float* tail = a.backward ? a.grads + L.P_pad : a.tail;
   const float* rwS = (S > 1 && a.backward) ? w.rw : nullptr;
   if (S > 1) {
-    hipLaunchKernelGGL(iwae_rows, dim3((B + 3) / 4), dim3(256), 0, st, w.logw, w.logpx, w.logq, w.logp,
+    hipLaunchKernelGGL(iwae_rows, dim3((B + 3) / 4), dim3(256), 0, st, w.lw64, w.logpx, w.logq, w.logp,
                        a.backward ? w.rw : (float*)nullptr, w.pb, B, S);
     rowk(cx, "iwae_rows");
   }
@@ -1658,7 +1676,7 @@ int gmvae_mlp_forward(const GmvaeDims* dims, int model, int net, const void* in,
       const void* a = (i == 0) ? in : (const void*)hbuf[i];
       Problem p = p_nn(a, i == 0 && in_is_u8, N->dim[i], P + N->w[i], N->dim[i + 1], rows, N->dim[i + 1], N->dim[i],
                        o, N->dim[i + 1], P + N->b[i], !last);
-      if (last && net == GMVAE_NET_DECODER) p.addconst = d.gen_bias_init;
+      if (last && net == GMVAE_NET_DECODER) { p.addconst = d.gen_bias_init; p.bias2 = d.gen_bias_vec; }
       g.add(p);
       launch_group(cx, g, "mlp");
     }

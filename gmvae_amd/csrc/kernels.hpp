@@ -244,6 +244,90 @@ __global__ void mixture_logprob_lse(const float* __restrict__ z, const float* __
   }
 }
 
+// ---- the same log-prob for ANY K and L (scripts/vae.py:231-244 puts no bound on mixture_components / latent_size): the
+// component parameters do not have to fit LDS.  gmp_consts prepares inv[k][l] = 1 / softplus(raw_scale_diag) and
+// cst[k] = log_softmax(mixture_logits)_k - sum_l log s_kl - L/2 log 2 pi (one workgroup per component);
+// mixture_logprob_tiled gives a workgroup 16 rows, walks the components 16 at a time and the latent dimension 64 at a
+// time through LDS tiles (thread = (row, component of the tile)), keeps a running (max, sum) pair per row for the K-way
+// logsumexp (16-lane shuffles), parks the component terms in `resp` and turns them into responsibilities in a second
+// sweep by the same threads.  Bound: HBM/L2 (every row tile re-reads loc and inv: 8 K L bytes per 16 rows).
+__global__ __launch_bounds__(256) void gmp_consts(const float* __restrict__ raw_scale, const float* __restrict__ mixlog,
+                                                  float* __restrict__ inv, float* __restrict__ cst, int L, int K) {
+  __shared__ float red[3][4];
+  const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float ls = 0.f, mx = -INFINITY;
+  for (int l = tid; l < L; l += 256) {
+    const float s = softplusf_(raw_scale[(long long)k * L + l]);
+    inv[(long long)k * L + l] = 1.f / s;
+    ls += logf(s);
+  }
+  for (int j = tid; j < K; j += 256) mx = fmaxf(mx, mixlog[j]);
+  ls = wave_sum(ls);
+  mx = wave_max(mx);
+  if (lane == 0) { red[0][wave] = ls; red[1][wave] = mx; }
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  float se = 0.f;
+  for (int j = tid; j < K; j += 256) se += expf(mixlog[j] - mx);
+  se = wave_sum(se);
+  if (lane == 0) red[2][wave] = se;
+  __syncthreads();
+  if (tid == 0) {
+    const float lse = mx + logf(red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+    cst[k] = mixlog[k] - lse - (red[0][0] + red[0][1] + red[0][2] + red[0][3]) - 0.5f * kLog2Pi * (float)L;
+  }
+}
+
+__global__ __launch_bounds__(256) void mixture_logprob_tiled(const float* __restrict__ z, const float* __restrict__ loc,
+                                                             const float* __restrict__ inv, const float* __restrict__ cst,
+                                                             float* __restrict__ logp, float* __restrict__ resp, int R, int L,
+                                                             int K) {
+  constexpr int RT = 16, KT = 16, LC = 64, LD = LC + 1;
+  __shared__ float zt[RT * LD], lt[KT * LD], it[KT * LD];
+  const int tid = threadIdx.x, rr = tid >> 4, kk = tid & 15;
+  for (int r0 = blockIdx.x * RT; r0 < R; r0 += gridDim.x * RT) {
+    const int r = r0 + rr;
+    float M = -INFINITY, Ssum = 0.f;
+    for (int k0 = 0; k0 < K; k0 += KT) {
+      float a = 0.f;
+      for (int l0 = 0; l0 < L; l0 += LC) {
+        __syncthreads();
+        for (int i = tid; i < RT * LC; i += 256) {
+          const int row = i / LC, l = i % LC;
+          const bool okl = l0 + l < L;
+          zt[row * LD + l] = (okl && r0 + row < R) ? z[(long long)(r0 + row) * L + l0 + l] : 0.f;
+          const bool okk = okl && k0 + row < K;
+          lt[row * LD + l] = okk ? loc[(long long)(k0 + row) * L + l0 + l] : 0.f;
+          it[row * LD + l] = okk ? inv[(long long)(k0 + row) * L + l0 + l] : 0.f;
+        }
+        __syncthreads();
+        const int nl = min(LC, L - l0);
+        for (int l = 0; l < nl; ++l) {
+          const float t = (zt[rr * LD + l] - lt[kk * LD + l]) * it[kk * LD + l];
+          a += t * t;
+        }
+      }
+      const bool kv = k0 + kk < K;
+      const float comp = kv ? cst[k0 + kk] - 0.5f * a : -INFINITY;
+      if (kv && r < R) resp[(long long)r * K + k0 + kk] = comp;
+      float mt = comp;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) mt = fmaxf(mt, __shfl_xor(mt, o, 64));
+      const float Mn = fmaxf(M, mt);                 // (finite from the first tile on: component k0 is always valid)
+      float e = kv ? expf(comp - Mn) : 0.f;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+      Ssum = Ssum * expf(M - Mn) + e;
+      M = Mn;
+    }
+    const float lse = M + logf(Ssum);
+    if (r < R) {
+      if (kk == 0) logp[r] = lse;
+      for (int k = kk; k < K; k += KT) resp[(long long)r * K + k] = expf(resp[(long long)r * K + k] - lse);
+    }
+  }
+}
+
 // Backward seeds at z, w = IWAE row weight (1 at S=1):
 //   dmu_q = dz_dec + w*prior_term ; dsig_q = dmu_q*eps - w/sig_q ;
 //   draw_q = dsig_q*sigmoid(raw_q + c)*[softplus > sigma_min]
@@ -343,15 +427,22 @@ __global__ void sum_over_s(const float* __restrict__ in, float* __restrict__ out
 // ---------------------------------------------------------------- loss
 // log w_r = log p(x|z) + log p(z|.) - log q(z|.) - nent_b  (gmvae.py:254-267,
 // vae.py:177-185; A15 for S>1).  logpx = sum of the decoder epilogue partials.
+// logw64 (S > 1): the same sum kept in fp64.  |log w| ~ D ln 2 (2100 at D = 3072) has an fp32 ulp of 2.4e-4, and the IWAE
+// weights softmax_s(log w) -- hence every gradient -- inherit the ABSOLUTE error of log w; iwae_rows forms the weights from
+// fp64 differences to the row group's maximum, so only the fp32 error of the per-tile partial sums (|part| ~ 90) is left.
 __global__ void row_terms(const float* __restrict__ part, int nparts, const float* __restrict__ logq,
                           const float* __restrict__ logp, const float* __restrict__ nent, int S,
-                          float* __restrict__ logpx, float* __restrict__ logw, float* __restrict__ terms4, int R) {
+                          float* __restrict__ logpx, float* __restrict__ logw, float* __restrict__ terms4, int R,
+                          double* __restrict__ logw64 = nullptr) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
-  float a = 0.f;
-  for (int i = 0; i < nparts; ++i) a += part[(long long)r * nparts + i];
+  double a64 = 0.0;
+  for (int i = 0; i < nparts; ++i) a64 += (double)part[(long long)r * nparts + i];
+  const float a = (float)a64;
   const float ne = nent ? nent[r / S] : 0.f;
-  const float lw = a + logp[r] - logq[r] - ne;
+  const double lw64 = a64 + (double)logp[r] - (double)logq[r] - (double)ne;
+  const float lw = (float)lw64;
+  if (logw64) logw64[r] = lw64;
   logpx[r] = a;
   logw[r] = lw;
   if (terms4) {
@@ -366,27 +457,28 @@ __global__ void row_terms(const float* __restrict__ part, int nparts, const floa
 // rw = softmax_s(log w) and the group's sums of the nll / kl terms -> pb[b] = (bound, sum_s -log p(x|z), sum_s (log q - log p)).
 // Fixed-order lane reductions: deterministic.  (loss_tail alone walked the S samples of a row in ONE thread: 111 us of
 // its single workgroup at B = 512, S = 50.)
-__global__ __launch_bounds__(256) void iwae_rows(const float* __restrict__ logw, const float* __restrict__ logpx,
+__global__ __launch_bounds__(256) void iwae_rows(const double* __restrict__ logw64, const float* __restrict__ logpx,
                                                  const float* __restrict__ logq, const float* __restrict__ logp,
                                                  float* __restrict__ rw, float* __restrict__ pb, int B, int S) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const long long r0 = (long long)b * S;
-  float mx = -INFINITY;
-  for (int s = lane; s < S; s += 64) mx = fmaxf(mx, logw[r0 + s]);
-  mx = wave_max(mx);
+  double mx = -INFINITY;
+  for (int s = lane; s < S; s += 64) mx = fmax(mx, logw64[r0 + s]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
   float se = 0.f, nl = 0.f, kl = 0.f;
   for (int s = lane; s < S; s += 64) {
-    se += expf(logw[r0 + s] - mx);
+    se += expf((float)(logw64[r0 + s] - mx));     // differences formed in fp64: no ulp(|log w|) left in the weights
     nl -= logpx[r0 + s];
     kl += logq[r0 + s] - logp[r0 + s];
   }
   se = wave_sum(se); nl = wave_sum(nl); kl = wave_sum(kl);
-  const float lse = mx + logf(se);
+  const float lrel = logf(se);
   if (rw)
-    for (int s = lane; s < S; s += 64) rw[r0 + s] = expf(logw[r0 + s] - lse);
-  if (lane == 0) { pb[4 * b] = lse - logf((float)S); pb[4 * b + 1] = nl; pb[4 * b + 2] = kl; pb[4 * b + 3] = 0.f; }
+    for (int s = lane; s < S; s += 64) rw[r0 + s] = expf((float)(logw64[r0 + s] - mx) - lrel);
+  if (lane == 0) { pb[4 * b] = (float)(mx + (double)lrel - (double)logf((float)S)); pb[4 * b + 1] = nl; pb[4 * b + 2] = kl; pb[4 * b + 3] = 0.f; }
 }
 
 // One workgroup: per-x IWAE bound logsumexp_s(log w) - log S, normalised row

@@ -19,7 +19,7 @@ from . import _lib as L
 
 def binarize(pixels: torch.Tensor, rows: Optional[torch.Tensor] = None, row0: int = 0, batch: Optional[int] = None,
              seed: int = 0, step: int = 0, out: Optional[torch.Tensor] = None, out_row0: int = 0) -> torch.Tensor:
-    """x[b, :] = (pixels[rows[b], :] / 255 < U) as uint8 0/1 (runners.py:48-51).  `rows`: int32 device tensor of
+    """x[b, :] = (pixels[rows[b], :] / 255 < U) as uint8 0/1 (runners.py:44-47).  `rows`: int32 device tensor of
     source rows, or None for rows row0 .. row0+batch-1.  The uniforms are Philox4x32-10 keyed by (seed, step) and the
     element's position in the global batch (out_row0 = this shard's first row: rank * B under data parallelism)."""
     dev = L.require_gpu()

@@ -40,7 +40,9 @@ class _ElboFn(torch.autograd.Function):
 class Engine:
     def __init__(self, model: str, data_size: int, latent_size: int, mixture_components: int,
                  hidden: Sequence[int], n_samples: int = 1, sigma_min: float = 0.0, raw_sigma_bias: float = 0.5,
-                 temperature: float = 1.0, gen_bias_init: float = 0.0, random_seed: Optional[int] = None):
+                 temperature: float = 1.0, gen_bias_init=0.0, random_seed: Optional[int] = None):
+        """gen_bias_init: a scalar or a vector of data_size values (scripts/base.py:102-103: "a scalar or vector Tensor
+        that is added to the output of the fully connected network", e.g. the logit of the training-set mean)."""
         self.device = L.require_gpu()
         # data parallel: this process's shard index.  Row b of a local batch of B rows is global row rank*B + b for the
         # Philox counters (GmvaeDims.row0), so G ranks draw the noise of ONE step on the global batch of G*B rows.
@@ -51,8 +53,18 @@ class Engine:
         self.model = L.MODEL_IDS[model]
         self.D, self.Lz, self.K, self.S = int(data_size), int(latent_size), int(mixture_components), int(n_samples)
         self.hidden = [int(h) for h in hidden]
+        self.gen_bias_vec = None
+        if not isinstance(gen_bias_init, (int, float)):
+            gb = torch.as_tensor(gen_bias_init, dtype=torch.float32).reshape(-1)
+            if gb.numel() == 1:
+                gen_bias_init = float(gb.item())
+            elif gb.numel() == self.D:
+                self.gen_bias_vec = gb.to(self.device).contiguous()
+                gen_bias_init = 0.0
+            else:
+                raise ValueError(f"gen_bias_init must be a scalar or a vector of data_size = {self.D} values, got {gb.numel()}")
         self.hp = dict(sigma_min=sigma_min, raw_sigma_bias=raw_sigma_bias, temperature=temperature,
-                       gen_bias_init=gen_bias_init)
+                       gen_bias_init=float(gen_bias_init))
         d0 = self.dims(1)
         self.P, self.P_real = L.param_count(d0, self.model)
         self.layout = L.param_layout(d0, self.model)
@@ -73,7 +85,7 @@ class Engine:
     def dims(self, B: int, S: Optional[int] = None, row0: Optional[int] = None):
         """GmvaeDims for a local batch of B rows; row0 = global index of its first row (default rank * B)."""
         return L.make_dims(B, self.D, self.Lz, self.K, self.hidden, S=self.S if S is None else S,
-                           row0=self.rank * B if row0 is None else int(row0), **self.hp)
+                           row0=self.rank * B if row0 is None else int(row0), gen_bias_vec=self.gen_bias_vec, **self.hp)
 
     def sync_replicas(self, src: int = 0):
         """Data parallel: every rank takes rank `src`'s parameters, Adam moments, step counter and noise seed (the
@@ -430,7 +442,7 @@ class Engine:
 
     def capture_train_pipeline(self, dataset, B: int, lr: float = 1e-3, n_steps: int = 16):
         """A train graph that starts from the RAW pixels (gmvae_train_graph_create_pipeline): each of its n_steps
-        steps first binarises its own batch on the device (scripts/runners.py:48-51), rows taken from `dataset`
+        steps first binarises its own batch on the device (scripts/runners.py:44-47), rows taken from `dataset`
         (gmvae_amd.data.DeviceDataset: resident uint8 pixels + an epoch permutation on the device).  Returns
         replay(): refills the row indices (device-to-device) and launches the graph; nothing crosses PCIe."""
         n_steps = int(n_steps)

@@ -21,8 +21,8 @@ def build_parser():
     a("--early_stop_rounds", type=int, default=1000)
     a("--early_stop_threshold", type=float, default=0.001)
     a("--summarise_every", type=int, default=50)
-    a("--gpu_id", default="0")                          # accepted for compatibility; LOCAL_RANK selects the device
-    a("--gpu_num", default="0")
+    a("--gpu_id", default="0")                          # index INTO --gpu_num's list (runners.select_device); a launcher's
+    a("--gpu_num", default="0")                         # LOCAL_RANK takes precedence (one process per GPU)
     a("--num_samples", type=int, default=10)            # eval prior draws (NOT IWAE samples)
     a("--num_generations", type=int, default=10)
     a("--split", default="train", choices=["train", "test"])

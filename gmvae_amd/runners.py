@@ -93,6 +93,23 @@ def create_model(config, data_dim):
     raise ValueError(f"unknown model {config.model!r}")
 
 
+def select_device(config, local_rank: int) -> int:
+    """The device of this process.  Under a launcher (LOCAL_RANK set: one process per GPU) it is the local rank.
+    Otherwise the reference's flags decide (scripts/run_gmvae.py:45-48, scripts/runners.py:193,209): `--gpu_num` is the
+    comma-separated list of visible physical devices (gpu_options.visible_device_list) and `--gpu_id` indexes INTO that
+    list (tf.device('/gpu:<gpu_id>'))."""
+    if "LOCAL_RANK" in os.environ:
+        return int(local_rank)
+    visible = [int(t) for t in str(getattr(config, "gpu_num", "0") or "0").split(",") if t.strip() != ""] or [0]
+    idx = int(getattr(config, "gpu_id", "0") or 0)
+    if not 0 <= idx < len(visible):
+        raise ValueError(f"--gpu_id={idx} does not index the visible device list --gpu_num={visible}")
+    dev = visible[idx]
+    if not 0 <= dev < torch.cuda.device_count():
+        raise ValueError(f"--gpu_num names device {dev}, but this host has {torch.cuda.device_count()} GPU(s)")
+    return dev
+
+
 def _logdir(config):
     """<logdir>/<model>/h<hidden>_n<layers>_z<latent> (scripts/runners.py:212-217)."""
     return os.path.join(config.logdir, config.model,
@@ -157,7 +174,7 @@ def run_train(config):
     from .data import binarize
     from .engine import Engine
     rank, world, local = parallel.init_from_env()
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(select_device(config, local))
     data_dim = int(getattr(config, "data_dim", 784))
     model = create_model(config, data_dim)
     eng = model._engine
@@ -251,22 +268,24 @@ def run_eval(config):
     runners.py:298,330-335 -- i.e. roughly loss / batch_size).  Like the reference it WAITS for a checkpoint
     (scripts/utils.py:100-111, 60 s polls; config.checkpoint_poll_seconds / checkpoint_max_wait adjust that)."""
     rank, world, local = parallel.init_from_env()
-    torch.cuda.set_device(local)
-    model = create_model(config, int(getattr(config, "data_dim", 784)))
+    torch.cuda.set_device(select_device(config, local))
+    data_dim = int(getattr(config, "data_dim", 784))
+    model = create_model(config, data_dim)
     wait_for_checkpoint(_ckpt(config), float(getattr(config, "checkpoint_poll_seconds", 60.0)),
                         getattr(config, "checkpoint_max_wait", None))
     model.load_state_dict(torch.load(_ckpt(config), map_location="cpu"))
     eng = model._engine
     tot = torch.zeros(5, device=eng.device)
-    ref_sum, n_batches, codes, ys = 0.0, 0, [], []
+    ref_sum, n_batches, codes, labs = 0.0, 0, [], []
     for images, labels in create_dataset(config, config.split, shuffle=False, repeat=False):
         o = eng.forward(images)
         tot += o["tail"][:5]
         ref_sum += (o["tail"][0] / o["tail"][4]).item()
         n_batches += 1
-        codes.append(o["z"])
-        if o["y"] is not None:
-            ys.append(o["y"])
+        # z = model.transform(flat_inputs) (runners.py:274): the VAE's MEAN code (vae.py:108-114), the GMVAE's SAMPLED
+        # code (gmvae.py:140-149) -- the forward pass's z is exactly that sample
+        codes.append(o["z"] if config.model == "gmvae" else model.transform(images))
+        labs.append(labels)
     if world > 1:
         parallel.dist.all_reduce(tot)
     n = tot[4].item()
@@ -276,4 +295,20 @@ def run_eval(config):
     if rank == 0:
         for k, v in res.items():
             print(f"{k}: {v}")
+    # The tensors the reference's evaluation graph also produces (scripts/runners.py:274-292) and hands to its plots
+    # (which are out of scope): the latent state and labels over the split, `num_samples` draws from the prior and
+    # `num_generations` decoded prior draws; for the GMVAE additionally the decoded draws of ONE random component k,
+    # stacked on the unconditional ones (runners.py:285-292).
+    img_shape = (28, 28, 1) if data_dim == 784 else (data_dim, 1, 1)
+    res["latent_state"] = torch.cat(codes) if codes else None
+    res["labels"] = torch.cat(labs) if labs else None
+    res["samples"] = model.generate_samples(num_samples=int(config.num_samples))
+    sample_images = utils.unflatten_tensor(model.generate_sample_images(num_samples=int(config.num_generations)), img_shape)
+    if config.model == "gmvae":
+        k = int(np.random.randint(0, high=config.mixture_components))
+        samples_k = model.generate_samples(num_samples=int(config.num_generations) * int(config.mixture_components), clusters=[k])
+        sample_images_k = utils.unflatten_tensor(model.generate_sample_images(samples_k, name="sample_images_k"), img_shape)
+        sample_images = torch.stack((sample_images, sample_images_k), dim=0)
+        res["sampled_cluster"] = k
+    res["sample_images"] = sample_images
     return res

@@ -39,7 +39,7 @@ extern "C" {
 
 #define GMVAE_MAX_HIDDEN 8
 #define GMVAE_TAIL 8          /* floats appended to the gradient buffer */
-#define GMVAE_ABI_VERSION 2
+#define GMVAE_ABI_VERSION 3
 
 enum { GMVAE_MODEL_VAE = 0, GMVAE_MODEL_VAE_GMP = 1, GMVAE_MODEL_GMVAE = 2 };
 
@@ -73,6 +73,14 @@ typedef struct GmvaeDims {
    * single-device step on the whole global batch draws, so G shards reproduce the 1-device step on G*B rows.
    * Sizes, layouts and the workspace do not depend on it. */
   uint64_t row0;
+  /* ABI v3 -- vector bias_init of ConditionalBernoulli (scripts/base.py:102-103 "a scalar or vector Tensor that is added
+   * to the output of the fully connected network", e.g. the logit of the training-set mean; added at base.py:135):
+   * device pointer to gen_bias_len == D fp32 values, or NULL / 0 for the scalar form alone.  The decoder logits are
+   * MLP(z) + gen_bias_init + gen_bias_vec[j].  It is a constant of the model (no gradient), read by the decoder
+   * output layer's epilogue; steps with a vector run the schedules whose decoder layer is a grouped-GEMM launch. */
+  const float* gen_bias_vec;
+  int32_t gen_bias_len;
+  int32_t reserved_;
 } GmvaeDims;
 
 /* One tensor of the flat parameter buffer.  Names are the reference's TF
@@ -159,7 +167,7 @@ int gmvae_mlp_forward(const GmvaeDims* dims, int model, int net, const void* in,
                       const float* in2, int rows, const float* params, float* out, void* workspace,
                       void* stream);
 
-/* Dynamic binarisation of the reference's input pipeline on the device (scripts/runners.py:48-51 `_preprocess`:
+/* Dynamic binarisation of the reference's input pipeline on the device (scripts/runners.py:44-47 `_preprocess`:
  * image = pixel / 255.; x = image < uniform -- note P[x = 1] = 1 - pixel/255 -- re-drawn on every pass).
  * pixels: uint8 [n_rows][D] resident in HBM (MNIST: 60000 x 784 = 47 MB); idx: int32 [B] source rows of this batch
  * (an epoch permutation kept on the device) or NULL for rows row0 .. row0+B-1; x_out: uint8 [B][D] of 0/1, the

@@ -45,7 +45,7 @@ class Dims:
     sigma_min: float = 0.0           # runners.py:84
     raw_sigma_bias: float = 0.5      # runners.py:85
     temperature: float = 1.0         # runners.py:86
-    gen_bias_init: float = 0.0       # gmvae.py:285 / vae.py:199
+    gen_bias_init: object = 0.0      # gmvae.py:285 / vae.py:199; scalar, or a vector [D] (base.py:102-103 "scalar or vector Tensor")
 
 
 # --------------------------------------------------------------------------
@@ -231,7 +231,7 @@ def forward(model: int, d: Dims, p: Dict[str, np.ndarray], x: np.ndarray,
         C.update(resp=np.exp(comp - logp[:, None]), gmp_t=t, gmp_s=s, lnw=lnw)
 
     lam, hs_d = _mlp_fwd(p, "decoder", nl, z)                      # gmvae.py:251 / vae.py:174
-    lam = lam + dtype(d.gen_bias_init)                             # base.py:135
+    lam = lam + np.asarray(d.gen_bias_init, dtype)                 # base.py:135 (scalar or [D] vector, broadcast over rows)
     logpx = (xr * lam - softplus(lam)).sum(axis=1)                 # A8, gmvae.py:254
 
     nent_r = np.repeat(nent_b, S) if S > 1 else nent_b
@@ -383,7 +383,7 @@ def philox4x32_10(c: np.ndarray, k0: int, k1: int) -> np.ndarray:
 
 
 def binarize(pixels: np.ndarray, rows: np.ndarray, seed: int, step: int, out_row0: int = 0) -> np.ndarray:
-    """scripts/runners.py:48-51 `_preprocess` for one batch: image = float32(pixel) / 255; x = image < uniform.
+    """scripts/runners.py:44-47 `_preprocess` for one batch: image = float32(pixel) / 255; x = image < uniform.
     The uniforms are the HIP path's: Philox4x32-10, counter = (quad index in the GLOBAL batch, 0x40000000, step),
     key = seed, u = (bits >> 8) * 2^-24; out_row0 = global index of this batch's first row (a data-parallel shard).
     pixels uint8 [N, D], rows int [B] -> uint8 [B, D] of 0/1 (bit-exact contract)."""

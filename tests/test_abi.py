@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol(L):
     for sym in declared:
         assert hasattr(raw, sym), f"{sym} declared in include/gmvae_hip.h but not exported"
     assert declared == set(L.EXPORTS)
-    assert L.lib.gmvae_abi_version() == 2
+    assert L.lib.gmvae_abi_version() == 3
 
 
 @pytest.mark.parametrize("name,d", [
@@ -62,7 +62,14 @@ def test_argument_validation(L):
     bad = L.make_dims(0, 784, 64, 10, [64])
     assert L.lib.gmvae_param_count(C.byref(bad), 2, C.byref(pp), None) == -2
     big_k = L.make_dims(16, 784, 64, 65, [64])
-    assert L.lib.gmvae_param_count(C.byref(big_k), 1, C.byref(pp), None) == -2     # GMP prior: K <= 64
+    assert L.lib.gmvae_param_count(C.byref(big_k), 1, C.byref(pp), None) == 0      # GMP prior: any K (tiled log-prob)
+    vec = L.make_dims(16, 784, 64, 10, [64])
+    vec.gen_bias_len = 10                                                          # ABI v3: a length without a vector,
+    assert L.lib.gmvae_param_count(C.byref(vec), 2, C.byref(pp), None) == -2       # or one that is not D, is refused
+    vec.gen_bias_vec, vec.gen_bias_len = 4096, 783
+    assert L.lib.gmvae_param_count(C.byref(vec), 2, C.byref(pp), None) == -2
+    vec.gen_bias_len = 784                                                         # (host-side size queries never read it)
+    assert L.lib.gmvae_param_count(C.byref(vec), 2, C.byref(pp), None) == 0
     assert L.lib.gmvae_step(C.byref(cd), 2, None, None, None, None, None, None, 0, 0, None, None) == -1
     assert L.lib.adam_tf_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, None, 1.0, None, None, None) == -1
     n = C.c_int()
@@ -70,3 +77,39 @@ def test_argument_validation(L):
     assert L.lib.gmvae_param_layout(C.byref(cd), 2, arr, 2, C.byref(n)) == -6
     with pytest.raises(ValueError):
         L.make_dims(1, 1, 1, 1, [1] * 9)
+
+
+def test_dims_struct_matches_the_header(L):
+    """The ctypes mirror of GmvaeDims has the header's field order (ABI v3 appended gen_bias_vec / gen_bias_len)."""
+    hdr = open(os.path.join(ROOT, "include", "gmvae_hip.h")).read()
+    body = re.search(r"typedef struct GmvaeDims \{(.*?)\} GmvaeDims;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"(\w+)(?:\[\w+\])?;", body)
+    assert names == [f[0] for f in L.GmvaeDims._fields_]
+    assert C.sizeof(L.GmvaeDims) == 6 * 4 + 8 * 4 + 4 * 4 + 8 + 8 + 4 + 4
+
+
+def test_initializers_and_device_flags_are_checked_on_the_host(monkeypatch):
+    """scripts/base.py:18,49-50 `initializers`: None / the default pass, anything else must be a dict of callables
+    (and is applied at bind time); scripts/run_gmvae.py:45-48 --gpu_id indexes --gpu_num's visible list."""
+    import torch
+    from types import SimpleNamespace
+    from gmvae_amd import base, runners
+    base.ConditionalNormal(4, [8], initializers=None)
+    base.ConditionalBernoulli(4, [8], initializers=base.DEFAULT_INITIALIZERS)
+    for bad in ({"w": 3}, {"q": lambda s: 0}, "xavier", {}):
+        with pytest.raises(TypeError):
+            base.ConditionalCategorical(4, [8], initializers=bad)
+    with pytest.raises(NotImplementedError):
+        base.ConditionalNormal(4, [8], hidden_activation_fn=torch.tanh)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    sel = runners.select_device
+    assert sel(SimpleNamespace(gpu_id="0", gpu_num="0"), 0) == 0
+    assert sel(SimpleNamespace(gpu_id="1", gpu_num="2,3"), 0) == 3
+    with pytest.raises(ValueError):
+        sel(SimpleNamespace(gpu_id="2", gpu_num="2,3"), 0)
+    with pytest.raises(ValueError):
+        sel(SimpleNamespace(gpu_id="0", gpu_num="7"), 0)
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    assert sel(SimpleNamespace(gpu_id="0", gpu_num="0"), 1) == 1

@@ -159,8 +159,8 @@ def test_step_matches_golden(H, path):
     gs, tail = H.hip_step(model, d, z["params"], z["x"], z["eps"], u)
     assert abs(tail[0] / B - z["loss"]) <= 1e-4 * abs(z["loss"])
     assert abs(tail[1] / B - z["nll"]) <= 1e-4 * abs(z["nll"])
-    assert abs(tail[2] / B - z["kl"]) <= 2e-3
-    assert abs(tail[3] / B - z["nent"]) <= 1e-4
+    assert abs(tail[2] / B - z["kl"]) <= 1e-4 * max(abs(float(z["kl"])), 1.0)
+    assert abs(tail[3] / B - z["nent"]) <= 1e-4 * max(abs(float(z["nent"])), 1.0)
     lay, P, _ = O.param_layout(model, d)
     for name, shape, off in lay:
         n = int(np.prod(shape))
@@ -240,18 +240,19 @@ def test_step_matches_oracle_on_random_shapes(H, name, d, B):
         if k.endswith("/b"):
             p[k] = rng.normal(0, 0.05, p[k].shape)
     x, eps, u = O.make_inputs(d, B, model)
-    H.compare_step(model, d, p, x, eps, u, grad_rtol=3e-4 if d.S > 1 else 1e-4)
+    H.compare_step(model, d, p, x, eps, u)
 
 
 
 def test_config5_shapes_iwae(H):
     """BASELINE config 5 shapes (D=3072, K=64, S=50, H=512) at a batch the oracle finishes in seconds.
-    ELBO at 1e-4; gradients at 5e-4: log w ~ -2100 has an fp32 ulp of 2.4e-4, which the IWAE weights
-    exp(log w - lse) inherit -- the fp32 NumPy oracle itself is 7e-5 off its fp64 self here."""
+    ELBO and every gradient tensor at 1e-4.  log w ~ -2100 has an fp32 ulp of 2.4e-4 and the IWAE weights
+    exp(log w - lse) inherit the ABSOLUTE error of log w, so the device keeps log w in fp64 from the per-tile partial sums
+    on (kernels.hpp row_terms / iwae_rows) and forms the weights from differences to the group's maximum."""
     d = O.Dims(D=3072, L=64, K=64, hidden=(512,), S=50)
     p = O.init_params(O.MODEL_GMVAE, d, np.random.default_rng(0))
     x, eps, u = O.make_inputs(d, 8)
-    H.compare_step(O.MODEL_GMVAE, d, p, x, eps, u, grad_rtol=5e-4)
+    H.compare_step(O.MODEL_GMVAE, d, p, x, eps, u)
 
 
 @pytest.mark.parametrize("model", [O.MODEL_GMVAE, O.MODEL_VAE])
@@ -268,7 +269,7 @@ def test_big_round_gemm_inside_the_step_iwae(H, monkeypatch, model):
         if k.endswith("/b"):
             p[k] = rng.normal(0, 0.05, p[k].shape)
     x, eps, u = O.make_inputs(d, 32, model)
-    H.compare_step(model, d, p, x, eps, u, grad_rtol=2e-4)
+    H.compare_step(model, d, p, x, eps, u)
     flat = O.pack(model, d, p, np.float32)
     g_big, _ = H.hip_step(model, d, flat, x, eps, u)
     monkeypatch.setenv("GMVAE_NO_BIG", "1")
@@ -290,7 +291,7 @@ def test_many_splits_for_small_weight_gradients_and_few_for_batch_row_ones(H, mo
             if k.endswith("/b"):
                 p[k] = rng.normal(0, 0.05, p[k].shape)
         x, eps, u = O.make_inputs(d, 300, model)
-        H.compare_step(model, d, p, x, eps, u, grad_rtol=2e-4)
+        H.compare_step(model, d, p, x, eps, u)
 
 
 @pytest.mark.parametrize("env", [{}, {"GMVAE_NO_MEGA": "1"}, {"GMVAE_NO_FUSED": "1"}],

@@ -1,4 +1,4 @@
-"""the input pipeline's dynamic binarisation (scripts/runners.py:48-51) and the
+"""the input pipeline's dynamic binarisation (scripts/runners.py:44-47) and the
 data-parallel definition of cluster_acc (scripts/utils.py:173-191).  CPU part: the oracle's Philox generator against
 the published Random123 known-answer vectors, the binarisation's statistics, the histogram form of cluster_acc.
 GPU part (-m gpu): the HIP kernel against the oracle, bit for bit."""

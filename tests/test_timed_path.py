@@ -53,8 +53,8 @@ def _compare_last_step(model, d, eng, B, Cc, g):
     assert tail[4] == B
     assert abs(tail[0] / B - Cc["loss"]) <= 1e-4 * abs(Cc["loss"]), (tail[0] / B, Cc["loss"])
     assert abs(tail[1] / B - Cc["nll"]) <= 1e-4 * abs(Cc["nll"])
-    ta = 1e-5 * max(abs(Cc["loss"]), 1.0)
-    assert abs(tail[2] / B - Cc["kl"]) <= ta and abs(tail[3] / B - Cc["nent"]) <= ta
+    assert abs(tail[2] / B - Cc["kl"]) <= 1e-4 * max(abs(Cc["kl"]), 1.0), (tail[2] / B, Cc["kl"])       # each term relative to
+    assert abs(tail[3] / B - Cc["nent"]) <= 1e-4 * max(abs(Cc["nent"]), 1.0), (tail[3] / B, Cc["nent"])  # itself
     lay, _, _ = O.param_layout(model, d)
     for name, shape, off in lay:
         n = int(np.prod(shape))
@@ -203,7 +203,7 @@ def test_eager_philox_step_matches_oracle(model, d, B):
         n = int(np.prod(shape))
         ref = g[name].ravel()
         err = np.abs(buf[off:off + n] / B - ref).max() / max(np.abs(ref).max(), 1e-6)
-        assert err <= (5e-4 if d.S > 1 else 1e-4), f"{name}: {err:.2e}"
+        assert err <= 1e-4, f"{name}: {err:.2e}"
 
 
 def test_pipeline_graph_matches_oracle_from_raw_pixels():
@@ -275,4 +275,4 @@ def test_config5_shard_full_size_properties():
     for name, shape, off in lay:
         n = int(np.prod(shape))
         ref = g[name].ravel()
-        assert np.abs(small[off:off + n] / 8 - ref).max() <= 5e-4 * max(np.abs(ref).max(), 1e-6), name
+        assert np.abs(small[off:off + n] / 8 - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6), name
