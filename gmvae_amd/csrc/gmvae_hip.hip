@@ -132,7 +132,7 @@ struct WS {
   unsigned long long* stamps;   // diagnostic stamps of the chain kernels: [2][grid][16]
   unsigned long long* xchg;     // mega_fwd_bwd's in-launch hand-off granules: [panels][Q-1][16*H + 16]
   unsigned long long* xfl;      // mega_fwd_bwd's first-layer exchange granules: [panels][4][16 * H2]
-  unsigned long long* spans;    // measurement: [2 kernels][2048 blocks][2] wall-clock stamps (mega_fwd_bwd, finalize_adam)
+  unsigned long long* spans;    // measurement: [2 slots][2 kernels][2048 blocks][2] wall-clock stamps (mega_fwd_bwd, finalize_adam / dw_adam)
   unsigned long long* gstamps;  // diagnostic stamps of the grouped-GEMM launches: [4 slots][2048 blocks][8]
   unsigned* sync;               // [0] = per-step epoch of the hand-off, [1] = hand-off timeout flag
   float *img_f, *img_b;         // per-step LDS weight images of chain_fwd / chain_bwd (prepared by aux blocks)
@@ -279,7 +279,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     if (ml.fl_ok)
       w.xfl = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * 4 * kPanel * 2 * d.hidden[0]));
     w.gstamps = reinterpret_cast<unsigned long long*>(take(2ull * 4 * 2048 * 8));
-    w.spans = reinterpret_cast<unsigned long long*>(take(2ull * 2 * 2048 * 2));
+    w.spans = reinterpret_cast<unsigned long long*>(take(2ull * 2 * 2 * 2048 * 2));
     if (model == GMVAE_MODEL_GMVAE && d.hidden[0] == M2::H && d.L == M2::L && d.K == M2::K && d.D == M2::D && d.B <= 1024) {
       w.img2f = take(M2::imgF);                  // (not gated by GMVAE_NO_MEGA2: the workspace layout must not depend on a switch)
       w.img2b = take(M2::imgB);
@@ -591,6 +591,7 @@ struct StepArgs {
   // touched the parameters since: the step may skip its first launch (mega_fwd_bwd runs the first layer itself)
   bool imgs_ready = false;
   bool want_spans = false;     // measurement: every launch of the step records per-workgroup wall-clock stamps
+  int span_slot = 0;           // ... into this slot of WS::spans (two consecutive steps can be stamped)
   bool dp_images = false;      // data-parallel graph: the Adam launch after the all-reduce scatters the weight images
   // input pipeline inside the train graph: the NEXT step's batch is binarised by auxiliary workgroups of this step's
   // weight-gradient launch (mega schedule)
@@ -722,7 +723,7 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
       const int KLp = (int)pad4((uint64_t)d.K * d.L);
       fa.gmp_part = w.gmp_part; fa.gmp_n = (B + kPanel - 1) / kPanel; fa.gmp_len = 2 * KLp + (int)pad4(d.K); fa.gmp_off = (long long)L.loc;
     }
-    fa.span = (a.want_spans && w.spans) ? w.spans + 2048 * 2 : nullptr;
+    fa.span = (a.want_spans && w.spans) ? w.spans + (size_t)a.span_slot * 2 * 2048 * 2 + 2048 * 2 : nullptr;
     if (mega_ok(d, a.model) && a.adam_p && a.adam_p == a.params) {      // the next step's weight images ride on the update
       const MegaLay ml = mega_lay(d.hidden[0], d.L, d.K, d.D, a.model);
       ImgPlan pl;
@@ -865,7 +866,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     c.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
     c.Q = Qm; c.xchg = w.xchg; c.epoch_word = w.sync; c.err_word = w.sync + 1;
     c.dbg = getenv("GMVAE_STAMPS") ? w.stamps : nullptr;
-    c.span = a.want_spans ? w.spans : nullptr;
+    c.span = a.want_spans ? w.spans + (size_t)a.span_slot * 2 * 2048 * 2 : nullptr;
     c.fine = getenv("GMVAE_STAMPS") ? atoi(getenv("GMVAE_STAMPS")) : 0;
     // the reference's default sizes (run_gmvae.py: latent 64, hidden 64, K 10; MNIST D 784) run a specialised instance
     typedef void (*MegaFn)(const MegaArgs);
@@ -1002,7 +1003,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       fa.epoch_word = dw_upd ? w.sync : nullptr;   // (data parallel: adam_tf_img, after the all-reduce, bumps the hand-off tag)
       fa.err_word = w.sync + 1;
       fa.img[0] = w.img_m; fa.img[1] = w.dimg; fa.img[2] = w.img2f; fa.img[3] = w.img2b; fa.img[4] = w.dimg2;
-      fa.span = (a.want_spans && w.spans) ? w.spans + 2048 * 2 : nullptr;
+      fa.span = (a.want_spans && w.spans) ? w.spans + (size_t)a.span_slot * 2 * 2048 * 2 + 2048 * 2 : nullptr;
       if (a.next_x && a.next_pix && a.next_idx && dw_upd) {
         fa.bin_pix = a.next_pix; fa.bin_idx = a.next_idx; fa.bin_x = a.next_x; fa.bin_rows_src = a.next_rows_src;
         fa.bin_B = B; fa.bin_D = D; fa.bin_seed = a.bin_seed; fa.bin_row0 = d.row0;
@@ -1761,23 +1762,27 @@ int gmvae_step_profile(const GmvaeDims* dims, int model, const uint8_t* x, const
 
 int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
                         float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, int iters,
-                        int max_levels, int* n_levels, char* names, float* usec, double* flops, void* stream) {
+                        int max_levels, int* n_levels, char* names, float* usec, float* usec_timeline, double* flops,
+                        void* stream) {
   if (int e = check_dims(dims, model)) return e;
   if (!x || !params || !m || !v || !grads || !workspace || !step_dev || !n_levels || !names || !usec || !flops)
     return GMVAE_E_NULL;
   if (iters < 1) return GMVAE_E_DIMS;
-  if (!(fused_ok(*dims, model) || mega_ok(*dims, model))) return GMVAE_E_DIMS;
+  if (!mega_ok(*dims, model)) return GMVAE_E_DIMS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   Prof* pr = new Prof();
-  for (int i = 0; i <= MAX_LEVELS; ++i) hipEventCreate(&pr->ev[i]);
-  double acc[MAX_LEVELS] = {0};
+  double acc[MAX_LEVELS] = {0}, acc_tl[MAX_LEVELS] = {0};
   int rc = 0;
-  // Two steps in ONE captured graph: an untimed one that leaves the weight images behind, then the steady-state
-  // step, whose launches record per-workgroup wall-clock stamps (s_memrealtime, 100 MHz, one clock for the whole
-  // device): a launch's duration is last end - first start over its workgroups.  Replayed `iters` times, so the
-  // kernels run back to back as in the train graph.  (hipEventRecord nodes inside a captured graph return no
-  // elapsed time on this stack, and eager launches with events in between add ~10 us of idle per launch.)
-  if (!mega_ok(*dims, model)) { delete pr; return GMVAE_E_DIMS; }
+  // Three steps in ONE captured graph: an untimed one that leaves the weight images behind, then two steady-state
+  // steps whose launches record per-workgroup wall-clock stamps (s_memrealtime, 100 MHz, one clock for the whole
+  // device) into two slots.  Per launch of the FIRST stamped step two durations come out:
+  //   usec          = last workgroup end - first workgroup start (the in-kernel span);
+  //   usec_timeline = first workgroup start of the NEXT launch (the following step's first launch for the last one)
+  //                   - its own first workgroup start: the launch's share of the step's timeline, dispatch and
+  //                   end-of-kernel write-back included -- the interval rocprofv3 reports, and the shares add up to the step.
+  // Replayed `iters` times, so the kernels run back to back as in the train graph.  (hipEventRecord nodes inside a
+  // captured graph return no elapsed time on this stack, and eager launches with events in between add ~10 us of idle
+  // per launch.)
   pr->events = false;
   Layout L;
   build_layout(*dims, model, L);
@@ -1786,30 +1791,31 @@ int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, floa
   hipStream_t cs = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  auto two_steps = [&](hipStream_t s) {
-    for (int it = 0; it < 2 && rc == 0; ++it) {
+  auto steps3 = [&](hipStream_t s) {
+    for (int it = 0; it < 3 && rc == 0; ++it) {
       Ctx cx;
       cx.st = s;
       cx.prof = pr;
-      pr->n = 0;
-      pr->active = it > 0;
+      if (it < 2) pr->n = 0;
+      pr->active = it == 1;
       StepArgs a = {dims, model, x, nullptr, nullptr, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
                     seed, 0, step_dev, true};
       a.adam_p = params; a.adam_m = m; a.adam_v = v; a.lr = lr; a.imgs_ready = it > 0; a.want_spans = it > 0;
+      a.span_slot = it == 2 ? 1 : 0;
       rc = run_step(cx, a);
     }
   };
   bool graphed = false;
   if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess) {
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-      two_steps(cs);
+      steps3(cs);
       const hipError_t he = hipStreamEndCapture(cs, &graph);
       if (rc == 0 && he == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) graphed = true;
     }
     (void)hipGetLastError();
   }
   if (!graphed) rc = 0;
-  const size_t nsp = 2 * 2048 * 2, ngs = 2048 * 8;
+  const size_t nsp = 2 * 2 * 2048 * 2, ngs = 2048 * 8, slot = 2 * 2048 * 2;
   unsigned long long* hsp = new unsigned long long[nsp + ngs];
   for (int it = 0; it < iters && rc == 0; ++it) {
     hipMemsetAsync(w.spans, 0, nsp * 8, st);
@@ -1817,28 +1823,35 @@ int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, floa
     if (graphed) {
       if (hipGraphLaunch(exec, st) != hipSuccess) { rc = (int)hipGetLastError(); break; }
     } else {
-      two_steps(st);
+      steps3(st);
     }
     hipStreamSynchronize(st);
     hipMemcpy(hsp, w.spans, nsp * 8, hipMemcpyDeviceToHost);
     hipMemcpy(hsp + nsp, w.gstamps + 2048 * 8, ngs * 8, hipMemcpyDeviceToHost);
-    auto span_of = [&](const unsigned long long* p, int stride, int e_off) {
-      unsigned long long lo = ~0ull, hi = 0;
+    auto first_last = [&](const unsigned long long* p, int stride, int e_off, unsigned long long& lo, unsigned long long& hi) {
+      lo = ~0ull; hi = 0;
       for (int b = 0; b < 2048; ++b) {
         const unsigned long long s0 = p[(size_t)b * stride], s1 = p[(size_t)b * stride + e_off];
         if (!s0 || !s1) continue;
         lo = s0 < lo ? s0 : lo;
         hi = s1 > hi ? s1 : hi;
       }
-      return hi > lo ? (double)(hi - lo) * 0.01 : 0.0;          // 100 MHz ticks -> microseconds
     };
+    unsigned long long start[MAX_LEVELS + 1] = {0};
     for (int i = 0; i < pr->n; ++i) {
-      double us = 0.0;
-      if (!strncmp(pr->name[i], "mega", 4)) us = span_of(hsp, 2, 1);
-      else if (!strncmp(pr->name[i], "bwd_dw_all", 10)) us = span_of(hsp + nsp, 8, 4);
-      else if (!strncmp(pr->name[i], "finalize_adam", 13) || !strncmp(pr->name[i], "dw_adam", 7)) us = span_of(hsp + 2048 * 2, 2, 1);
-      acc[i] += us;
+      unsigned long long lo = ~0ull, hi = 0;
+      if (!strncmp(pr->name[i], "mega", 4)) first_last(hsp, 2, 1, lo, hi);
+      else if (!strncmp(pr->name[i], "bwd_dw_all", 10)) first_last(hsp + nsp, 8, 4, lo, hi);
+      else if (!strncmp(pr->name[i], "finalize_adam", 13) || !strncmp(pr->name[i], "dw_adam", 7)) first_last(hsp + 2048 * 2, 2, 1, lo, hi);
+      if (hi > lo) { acc[i] += (double)(hi - lo) * 0.01; start[i] = lo; }       // 100 MHz ticks -> microseconds
     }
+    {  // the next step's first stamped launch closes the last launch's share (steady state: the same launch sequence)
+      unsigned long long lo = ~0ull, hi = 0;
+      if (pr->n > 0 && !strncmp(pr->name[0], "mega", 4)) first_last(hsp + slot, 2, 1, lo, hi);
+      start[pr->n] = hi > lo ? lo : 0;
+    }
+    for (int i = 0; i < pr->n; ++i)
+      if (start[i] && start[i + 1] > start[i]) acc_tl[i] += (double)(start[i + 1] - start[i]) * 0.01;
   }
   delete[] hsp;
   if (exec) hipGraphExecDestroy(exec);
@@ -1849,9 +1862,9 @@ int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, floa
   for (int i = 0; i < n; ++i) {
     memcpy(names + (size_t)i * 48, pr->name[i], 48);
     usec[i] = (float)(acc[i] / iters);
+    if (usec_timeline) usec_timeline[i] = (float)(acc_tl[i] / iters);
     flops[i] = pr->flops[i];
   }
-  for (int i = 0; i <= MAX_LEVELS; ++i) hipEventDestroy(pr->ev[i]);
   delete pr;
   return rc;
 }

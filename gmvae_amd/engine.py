@@ -79,6 +79,7 @@ class Engine:
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
         self._graph_gen = 0                     # bumped by drop_graphs: replay closures of dropped graphs raise
+        self.safe_schedule = False              # use_safe_schedule(): the schedules without mutual waits
         self.init_parameters(random_seed)
 
     # ------------------------------------------------------------ parameters
@@ -288,7 +289,8 @@ class Engine:
         import torch.distributed as dist
         self.step(x, eps, u, row0=row0)
         if all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grads)         # ONE collective: grads + loss sums + count
+            from . import parallel
+            parallel.all_reduce_flat(self.grads)     # ONE collective: grads + loss sums + count
         self.adam(lr)
         return self.grads[self.P:]
 
@@ -405,13 +407,14 @@ class Engine:
             self._graphs[key] = (static_x, replay, None)
             return static_x, replay
         if do_ar:
+            from . import parallel
             self.dp_mode = "torch.distributed"
             batches = [static_x] if n_steps == 1 else list(static_x.unbind(0))
 
             def replay():
                 for i, xb in enumerate(batches):
                     self.step(xb, use_step_dev=True)
-                    dist.all_reduce(self.grads)
+                    parallel.all_reduce_flat(self.grads)
                     self.adam(lr, use_step_dev=True)
                     self.global_step += 1
                     tail_log[i].copy_(self.grads[self.P:])
@@ -501,6 +504,25 @@ class Engine:
                 bad += int(w.item() != 0)
         return bad
 
+    def inject_handoff_fault(self):
+        """Test / diagnostics hook: set the hand-off error word of every workspace, exactly what a timed-out wait of the
+        fused schedule leaves behind (a co-tenant or a partitioned device kept part of a panel's workgroups off the chip)."""
+        for key, ws in self._ws.items():
+            w = self._sync_word(key, ws)
+            if w is not None:
+                w.fill_(1)
+
+    def use_safe_schedule(self):
+        """Switch this process to the schedules WITHOUT mutual waits between workgroups (first layer as its own launch,
+        one workgroup per panel: GMVAE_NO_FL=1, GMVAE_MEGA_Q=1), destroy the captured graphs and clear the error words.
+        Slower (4 launches per step instead of 2), never stalling: what run_train and bench.py degrade to when a hand-off
+        of the fused schedule timed out."""
+        import os
+        os.environ["GMVAE_NO_FL"] = "1"
+        os.environ["GMVAE_MEGA_Q"] = "1"
+        self.safe_schedule = True
+        self.drop_graphs(clear_handoff_errors=True)
+
     def drop_graphs(self, clear_handoff_errors: bool = True):
         """Destroy every captured train graph (they are re-captured on the next capture_* call, under whatever
         GMVAE_* schedule switches are set by then; replay closures handed out before raise from now on) and,
@@ -527,24 +549,27 @@ class Engine:
             pass
 
     def profile_train_levels(self, x, lr: float = 1e-3, iters: int = 20):
-        """Per-launch timing of the steady-state training step of a train graph (gmvae_train_profile).
-        Advances the optimizer by 2 * iters steps (each repetition is an untimed step + the timed one)."""
+        """Per-launch timing of the steady-state training step of a train graph (gmvae_train_profile): a list of
+        (name, in-kernel span us, algorithmic FLOPs, timeline share us).  The timeline share runs from the launch's first
+        workgroup start to the next launch's (dispatch + end-of-kernel write-back included: what rocprofv3 reports); the
+        shares add up to the step.  Advances the optimizer by 3 * iters steps."""
         x = self._prep_x(x)
         d, ws = self._workspace(x.shape[0])
         self.step_dev.fill_(self.global_step)
         n = C.c_int()
         names = C.create_string_buffer(96 * 48)
         usec = (C.c_float * 96)()
+        usec_tl = (C.c_float * 96)()
         flops = (C.c_double * 96)()
         rc = L.lib.gmvae_train_profile(C.byref(d), self.model, L.ptr(x), L.ptr(self.params), L.ptr(self.m), L.ptr(self.v),
                                        L.ptr(self.grads), L.ptr(ws), self.noise_seed, L.ptr(self.step_dev), lr, iters, 96,
-                                       C.byref(n), names, usec, flops, L.current_stream())
+                                       C.byref(n), names, usec, usec_tl, flops, L.current_stream())
         L.check(rc, "gmvae_train_profile")
-        self.global_step += 2 * iters
+        self.global_step += 3 * iters
         out = []
         for i in range(n.value):
             nm = names.raw[i * 48:(i + 1) * 48].split(b"\0")[0].decode()
-            out.append((nm, float(usec[i]), float(flops[i])))
+            out.append((nm, float(usec[i]), float(flops[i]), float(usec_tl[i])))
         return out
 
     def profile_levels(self, x, iters: int = 20):

@@ -28,8 +28,8 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:                        # GMVAE_DIST_BACKEND=gloo: several ranks on ONE device (tests; RCCL refuses that)
+            backend = os.environ.get("GMVAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, device_id=torch.device("cuda", local))
@@ -46,10 +46,18 @@ def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def all_reduce_flat(buf: torch.Tensor) -> torch.Tensor:
-    """The step's single collective: SUM of the flat [P + TAIL] buffer over all ranks, in place."""
+def all_reduce_flat(buf: torch.Tensor, op=None) -> torch.Tensor:
+    """The step's single collective: SUM (or `op`) of the flat [P + TAIL] buffer over all ranks, in place.  RCCL reduces
+    device tensors where they lie; over gloo (CPU collectives: tests with several ranks on one device) a device tensor is
+    staged through the host."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        op = dist.ReduceOp.SUM if op is None else op
+        if buf.is_cuda and dist.get_backend() != "nccl":
+            host = buf.detach().cpu()
+            dist.all_reduce(host, op=op)
+            buf.copy_(host.to(buf.device))
+        else:
+            dist.all_reduce(buf, op=op)
     return buf
 
 

@@ -190,7 +190,7 @@ def run_train(config):
     bseed = eng.noise_seed ^ Engine.BINARIZE_SEED_XOR
     G = _graph_steps(every)
     dp_graph = False
-    if world > 1 and not eager:
+    if world > 1 and not eager and parallel.dist.get_backend() == "nccl":     # (in-library RCCL: one device per rank)
         try:
             eng.enable_rccl()                               # raises on EVERY rank if it fails on any
             dp_graph = True
@@ -198,6 +198,7 @@ def run_train(config):
             if rank == 0:
                 print(f"[run_train] in-library RCCL unavailable ({e}); torch.distributed all-reduce", flush=True)
     run_train.last_path = "eager" if eager else ("dp-graph" if world > 1 else "pipeline-graph")
+    run_train.degraded = False
     hook = utils.EarlyStoppingHook(config.early_stop_rounds, config.early_stop_threshold)
     last_save, t0, s0 = time.time(), time.time(), eng.global_step
     logs = []                                               # device tensors [n, TAIL]: no host sync until a summary
@@ -237,12 +238,38 @@ def run_train(config):
         logs = []
         vals = (tails[:, 0] / tails[:, 4]).tolist()
         base = eng.global_step - len(vals)
-        if eng.handoff_timeouts() or not all(np.isfinite(vals)):
-            raise RuntimeError(f"training step poisoned between steps {base + 1} and {eng.global_step} (hand-off "
-                               f"timeouts: {eng.handoff_timeouts()}; losses finite: {bool(np.all(np.isfinite(vals)))}): "
-                               "the optimizer skipped those updates and the last good checkpoint was kept")
+        fault = getattr(config, "fault_hook", None)         # (tests: called with the engine after every summary block)
+        poisoned = bool(eng.handoff_timeouts()) or not all(np.isfinite(vals))
+        if world > 1:                                       # every rank takes the same branch (the tails are all-reduced,
+            flag = torch.tensor([int(poisoned)], device=eng.device)      # the error word is per device)
+            parallel.all_reduce_flat(flag, op=parallel.dist.ReduceOp.MAX)
+            poisoned = bool(flag.item())
+        if poisoned:
+            # A hand-off of the fused schedule timed out: something else holds part of the chip (a co-tenant, a
+            # partitioned device).  The poisoned steps carry NaN losses and the optimizer SKIPPED them (params, m, v
+            # untouched), so the model is intact.  Like MonitoredTrainingSession recovering from a failed step
+            # (scripts/runners.py:222-232) the loop goes on -- once: re-captured on the schedule without mutual waits.
+            if eng.safe_schedule:
+                raise RuntimeError(f"training step poisoned between steps {base + 1} and {eng.global_step} although the "
+                                   f"schedule without mutual waits is in use (hand-off timeouts: {eng.handoff_timeouts()}; "
+                                   f"losses finite: {bool(np.all(np.isfinite(vals)))}); the last good checkpoint was kept")
+            bad = [i for i, v in enumerate(vals) if not np.isfinite(v)]
+            rewind = bool(bad) and bad == list(range(bad[0], len(vals)))      # the poisoned steps are the block's tail:
+            if rewind:                                                        # run them again (new batches, same noise keys)
+                eng.global_step = base + bad[0]
+                eng.step_dev.fill_(eng.global_step)
+            if rank == 0:
+                print(f"[run_train] hand-off timeout: {len(bad)} step(s) of {base + 1}..{base + len(vals)} skipped by the "
+                      f"optimizer; continuing from step {eng.global_step} on the schedule without mutual waits", flush=True)
+            eng.use_safe_schedule()
+            run_train.degraded = True
+            vals = [v for v in vals if np.isfinite(v)]
         for i, v in enumerate(vals):                        # EarlyStoppingHook sees every step's (all-reduced) loss
             stop = hook.after_run(base + i + 1, v) or stop
+        if fault is not None:
+            fault(eng)
+        if not vals:
+            continue
         if rank == 0 and (eng.global_step % every == 0 or eng.global_step > config.max_steps):
             rate = (eng.global_step - s0) / max(time.time() - t0, 1e-9)
             msg = f"Step {eng.global_step}, loss: {vals[-1]:f}  ({rate:.1f} global_step/sec)"
@@ -287,7 +314,7 @@ def run_eval(config):
         codes.append(o["z"] if config.model == "gmvae" else model.transform(images))
         labs.append(labels)
     if world > 1:
-        parallel.dist.all_reduce(tot)
+        parallel.all_reduce_flat(tot)
     n = tot[4].item()
     res = {f"{config.split}/loss_per_example": tot[0].item() / n, f"{config.split}/nll": tot[1].item() / n,
            f"{config.split}/kl_div_z": tot[2].item() / n, f"{config.split}/nent": tot[3].item() / n,

@@ -49,7 +49,8 @@ def cluster_acc(logits, labels, no_components, n_labels: int = 10, all_reduce: b
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             hist = scratch[:K * n_labels].clone().view(K, n_labels)     # the kernel's histogram: ranks' counts add
-            dist.all_reduce(hist)
+            from . import parallel
+            parallel.all_reduce_flat(hist)
             return cluster_acc_from_hist(hist)
     return acc[0]
 

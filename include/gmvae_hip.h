@@ -209,12 +209,16 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
  * microseconds and the algorithmic FLOPs (2*M*N*K summed over its GEMMs,
  * 0 for row-local kernels).  Synchronises the stream: measurement only.
  * gmvae_train_profile does the same for the steady-state TRAINING step of a train graph (Philox noise, TF-Adam
- * fused into the last launch, first layer inside mega_fwd_bwd where that schedule applies): a two-step graph (an
- * untimed step, then the timed one with an event-record node between its launches) replayed `iters` times, so the
- * kernels run back to back as in a train graph; it advances params / m / v / *step_dev like 2 * iters real steps. */
+ * fused into the last launch, first layer inside mega_fwd_bwd where that schedule applies): a three-step graph (an
+ * untimed step, then two steps whose launches stamp the device wall clock per workgroup) replayed `iters` times, so
+ * the kernels run back to back as in a train graph; it advances params / m / v / *step_dev like 3 * iters real steps.
+ * usec = in-kernel span (last workgroup end - first workgroup start); usec_timeline (may be NULL) = the launch's share
+ * of the step's timeline: first workgroup start of the NEXT launch - its own (dispatch and end-of-kernel write-back
+ * included: the interval rocprofv3 --kernel-trace reports; the shares of a step's launches add up to the step). */
 int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
                         float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, int iters,
-                        int max_levels, int* n_levels, char* names, float* usec, double* flops, void* stream);
+                        int max_levels, int* n_levels, char* names, float* usec, float* usec_timeline, double* flops,
+                        void* stream);
 int gmvae_step_profile(const GmvaeDims* dims, int model, const uint8_t* x, const float* eps, const float* u,
                        const float* params, float* grads, void* workspace, uint64_t seed, int iters,
                        int max_levels, int* n_levels, char* names, float* usec, double* flops, void* stream);

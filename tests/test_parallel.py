@@ -282,3 +282,81 @@ def test_rccl_multi_step_graph_world1_tracks_eager_steps():
     assert e.handoff_timeouts() == 0 and torch.isfinite(e.params).all()
     assert (e.params - ref.params).abs().max().item() < 2e-5
     assert abs(e.grads[e.P].item() - ref.grads[ref.P].item()) < 1e-4 * abs(ref.grads[ref.P].item())
+
+
+# ------------------------------------------------------------------------------------------------ world 2 on ONE GPU
+def _spawn_ranks(tmp_path, argv, world=2, timeout=420):
+    """`world` fresh child processes of tests/dp_child.py (gloo, all on cuda:0, no mutual waits inside a launch)."""
+    import subprocess
+    import sys
+    port = _free_port()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world),
+                   LOCAL_RANK="0", GMVAE_DIST_BACKEND="gloo", GMVAE_NO_FL="1", GMVAE_MEGA_Q="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "dp_child.py")] + [str(a) for a in argv],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                   # exactly the PIDs started here
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} exited {p.returncode}:\n{o[-3000:]}"
+    return [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), map_location="cpu") for r in range(world)], outs
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_product_path_equals_the_global_batch_trajectory(tmp_path, monkeypatch):
+    """The data-parallel PRODUCT path with world = 2 on hardware: two fresh processes, default seeding
+    (random_seed=None: different initial weights), Engine.sync_replicas() + train_step(all_reduce=True) on their row shards
+    of the same global batches.  Replicas must end bit-identical, and equal (fp32 summation order) to ONE process stepping
+    the whole global batch from the same start: the Philox counters hold the global row, so the noise is the same."""
+    from gmvae_amd.engine import Engine
+    n, B = 5, 512
+    res, _ = _spawn_ranks(tmp_path, ["engine", tmp_path, n, B])
+    a, b = res
+    assert a["start"]["differed"] or b["start"]["differed"]              # the ranks did start from different draws
+    assert torch.equal(a["start"]["params"], b["start"]["params"]) and a["start"]["noise_seed"] == b["start"]["noise_seed"]
+    for k in ("params", "m", "v", "tails"):
+        assert torch.equal(a[k], b[k]), f"replicas differ in {k}"
+    assert a["global_step"] == b["global_step"] == n and a["timeouts"] == b["timeouts"] == 0
+    assert float(a["tails"][-1, 4]) == 2 * B                              # the all-reduced count is the global batch
+    # one process, the global batch
+    monkeypatch.setenv("GMVAE_NO_FL", "1")
+    monkeypatch.setenv("GMVAE_MEGA_Q", "1")
+    e = Engine("gmvae", 784, 64, 10, [64], random_seed=0)
+    with torch.no_grad():
+        e.params.copy_(a["start"]["params"].cuda())
+    e.noise_seed = a["start"]["noise_seed"]
+    xs = (np.random.default_rng(77).random((n, 2 * B, 784)) < 0.87).astype(np.uint8)
+    tails = [e.train_step(torch.from_numpy(xs[t]).cuda(), lr=1e-3).clone().cpu() for t in range(n)]
+    tails = torch.stack(tails)
+    torch.cuda.synchronize()
+    rel = (tails[:, 0] - a["tails"][:, 0]).abs() / a["tails"][:, 0].abs()
+    assert rel.max().item() < 5e-6, rel                                   # per-step loss sums of the global batch
+    # n TF-Adam steps at lr = 1e-3; the two computations differ in summation order only, which Adam's m / sqrt(v) amplifies
+    # on coordinates with near-zero gradients: a mean gate and a loose max gate (as tests/test_runner.py)
+    diff = (e.params.detach().cpu() - a["params"]).abs()
+    assert diff.mean().item() < 5e-6 and diff.max().item() < n * 1e-3 * 0.2, (diff.mean().item(), diff.max().item())
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_run_gmvae_train(tmp_path):
+    """`run_gmvae --mode=train` with WORLD_SIZE = 2 (default flags' seeding: --random_seed unset): the start state is
+    broadcast, every rank applies the same all-reduced gradient, the replicas stay bit-identical and the loss falls."""
+    args = ["--mode=train", "--model=gmvae", "--latent_size=64", "--batch_size=512", "--max_steps=39", "--summarise_every=10",
+            f"--logdir={tmp_path}/log", "--synthetic_size=4096"]
+    res, outs = _spawn_ranks(tmp_path, ["runner", tmp_path] + args)
+    a, b = res
+    for k in ("params", "m", "v"):
+        assert torch.equal(a[k], b[k]), f"replicas differ in {k}"
+    assert a["global_step"] == b["global_step"] == 40 and a["path"] == "dp-graph" and a["timeouts"] == 0
+    assert a["dp_mode"] == "torch.distributed"                            # (gloo: the all-reduce between two eager halves)
+    assert torch.isfinite(a["params"]).all() and 0 < a["loss"] < 500      # from D ln 2 - ln K = 541
+    assert os.path.exists(os.path.join(tmp_path, "log", "gmvae", "h64_n1_z64", "model.pt"))
+    assert "Step 40" in outs[0]

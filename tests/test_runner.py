@@ -125,3 +125,59 @@ def test_train_then_eval_end_to_end(tmp_path):
     assert res["train/loss_per_example"] < 450          # Bernoulli(0.87) data: well below the D ln 2 = 543 start
     assert res["train/reference_misnormalised_loss_per_example"] == pytest.approx(
         res["train/loss_per_example"] / 256, rel=0.05)
+    # the tensors the reference's eval graph also produces (scripts/runners.py:274-292): latent state + labels over the
+    # split, num_samples prior draws ([num_samples * K, L] for the GMVAE), decoded draws stacked with ONE component's
+    import torch
+    assert res["latent_state"].shape == (2048, 16) and res["labels"].shape == (2048,)
+    assert res["samples"].shape == (10 * 10, 16) and torch.isfinite(res["samples"]).all()
+    assert res["sample_images"].shape == (2, 10 * 10, 28, 28, 1) and 0 <= res["sampled_cluster"] < 10
+    assert float(res["sample_images"].min()) >= 0.0 and float(res["sample_images"].max()) <= 1.0      # Bernoulli means
+
+
+@pytest.mark.gpu
+def test_run_train_degrades_to_the_safe_schedule_instead_of_dying(tmp_path, monkeypatch):
+    """A hand-off timeout of the fused schedule (fault hook: the error word a timed-out wait leaves behind) must not end
+    training (MonitoredTrainingSession recovers, scripts/runners.py:222-232): run_train drops its
+    graphs, re-captures on the schedule without mutual waits, goes on from the last good step and logs once.  A second
+    fault on the safe schedule is an error."""
+    import torch
+    from gmvae_amd import runners
+    for k in ("GMVAE_NO_FL", "GMVAE_MEGA_Q"):
+        monkeypatch.delenv(k, raising=False)
+    calls = []
+
+    def fault_once(eng):
+        calls.append(eng.global_step)
+        if len(calls) == 1:
+            eng.inject_handoff_fault()
+
+    base = ["--mode=train", "--model=gmvae", "--latent_size=64", "--batch_size=1024", "--max_steps=59", "--summarise_every=20",
+            "--random_seed=2", "--synthetic_size=4096"]
+    cfg = run_gmvae.build_parser().parse_args(base + [f"--logdir={tmp_path}/a"])
+    cfg.fault_hook = fault_once
+    try:
+        m = runners.run_train(cfg)
+        e = m._engine
+        assert runners.run_train.degraded and e.safe_schedule and e.handoff_timeouts() == 0
+        assert e.global_step == 60 and torch.isfinite(e.params).all() and (tmp_path / "a/gmvae/h64_n1_z64/model.pt").exists()
+        assert calls[0] == 20 and len(calls) >= 3
+        last = (e.grads[e.P] / e.grads[e.P + 4]).item()
+        assert 0 < last < 500                                # it kept training: D ln 2 - ln K = 541 at the start
+        # a clean run of the same seed on the fast schedule ends close by (the faulted block's steps were either
+        # complete or skipped and re-run on other batches)
+        monkeypatch.delenv("GMVAE_NO_FL", raising=False)
+        monkeypatch.delenv("GMVAE_MEGA_Q", raising=False)
+        cfg2 = run_gmvae.build_parser().parse_args(base + [f"--logdir={tmp_path}/b"])
+        m2 = runners.run_train(cfg2)
+        assert not runners.run_train.degraded and not m2._engine.safe_schedule
+        last2 = (m2._engine.grads[m2._engine.P] / m2._engine.grads[m2._engine.P + 4]).item()
+        assert abs(last - last2) < 0.05 * abs(last2)
+        # a fault that persists on the safe schedule raises
+        cfg3 = run_gmvae.build_parser().parse_args(base + [f"--logdir={tmp_path}/c"])
+        cfg3.fault_hook = lambda eng: eng.inject_handoff_fault()
+        with pytest.raises(RuntimeError, match="without mutual waits"):
+            runners.run_train(cfg3)
+    finally:
+        import os
+        os.environ.pop("GMVAE_NO_FL", None)
+        os.environ.pop("GMVAE_MEGA_Q", None)
