@@ -115,6 +115,22 @@ __device__ __forceinline__ void granule_publish(unsigned long long* p, const uns
 __device__ __forceinline__ float4 f4(const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// A launch OUTPUT in global memory (nothing in this launch reads it back; the next launch does, from other CUs): stored
+// WRITE-THROUGH (sc1), so the bytes leave for memory while the launch is still running instead of waiting dirty in the
+// XCD's L2 for the end-of-kernel write-back that the next launch's start sits behind.  (Inline asm: uncounted by the
+// compiler's vmcnt bookkeeping, which only makes its own waits stricter -- retirement is in order; `s_nop 1`: the data
+// registers may be rewritten right after, cdna_hip_programming.md 5.7 item 1.)
+#ifndef M2_WT
+#define M2_WT 1
+#endif
+__device__ __forceinline__ void st4o(float* p, const float4 v) {
+#if M2_WT
+  const f32x4 t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#else
+  st4(p, v);
+#endif
+}
 
 __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -299,7 +315,6 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       if (col < H) {
         const float h = fmaxf(flt[r] + img[M2::b_y0 + col], 0.f);
         P_h1[row * M2::ld128 + col] = h;
-        if (lead && row < nrow) a.hy1[(long long)(r0 + row) * H + col] = h;
       } else {
         P_h1[row * M2::ld128 + col] = flt[r];
       }
@@ -307,6 +322,10 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   }
   __syncthreads();
   GMVAE_STAMP(1);
+  if (lead && tid < 256) {                         // hy1 (kept for dWy1) leaves as 16-byte write-through stores
+    const int row = tid >> 4, c = (tid & 15) << 2;
+    if (row < nrow) st4o(a.hy1 + (long long)(r0 + row) * H + c, ld4(P_h1 + row * M2::ld128 + c));
+  }
   // ======================================================================= F: forward chain
   // S1 logits: one 16-output tile, contraction 64 split over waves 0..3
   if (wave < 4) {
@@ -357,7 +376,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       const float4 h = make_float4(fmaxf(ac2[0] + gx.x + bg.x, 0.f), fmaxf(ac2[1] + gx.y + bg.y, 0.f),
                                    fmaxf(ac2[2] + gx.z + bg.z, 0.f), fmaxf(ac2[3] + gx.w + bg.w, 0.f));
       st4(P_hg + ln * M2::ld64 + c0, h);
-      if (lead && ln < nrow) st4(a.hg1 + (long long)(r0 + ln) * H + c0, h);
+      if (lead && ln < nrow) st4o(a.hg1 + (long long)(r0 + ln) * H + c0, h);
     }
   }
   __syncthreads();
@@ -389,7 +408,6 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       const float ee = ok ? P_eps[row * 64 + l] : 0.f;
       const float zz = mu + sg * ee;
       P_z[row * M2::ld64 + l] = zz;
-      if (ok && lead) a.z[(long long)(r0 + row) * L + l] = zz;
       qr[l] = vq >= 0.f ? rq : eq * rq;
       qr[L + l] = sg;
       aq += -0.5f * ee * ee - 0.5f * kLog2Pi - flog(sg);     // (z - mu) / sigma IS eps
@@ -410,6 +428,10 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
     }
   }
   __syncthreads();
+  if (lead && tid >= 256) {                        // z (kept for dWd0): waves 4..7, which have no tile in S6
+    const int t2 = tid - 256, row = t2 >> 4, c = (t2 & 15) << 2;
+    if (row < nrow) st4o(a.z + (long long)(r0 + row) * L + c, ld4(P_z + row * M2::ld64 + c));
+  }
   // S6 decoder hidden: 4 tiles, contraction 64
   if (wave < 4) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -418,7 +440,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
     const float4 bb = ld4(img + M2::b_d0 + c0);
     const float4 h = make_float4(fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f), fmaxf(acc[2] + bb.z, 0.f), fmaxf(acc[3] + bb.w, 0.f));
     st4(P_hd + ln * M2::ld64 + c0, h);
-    if (lead && ln < nrow) st4(a.hd1 + (long long)(r0 + ln) * H + c0, h);
+    if (lead && ln < nrow) st4o(a.hd1 + (long long)(r0 + ln) * H + c0, h);
   }
   __syncthreads();                                 // the forward image is dead
   GMVAE_STAMP(4);
@@ -464,7 +486,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
         // quarter 0 keeps g in registers until its hand-off polls are through: vmcnt retires in order, so a poll's
         // data would otherwise wait for the acknowledgement of these stores (measured: 1.8 us per sweep)
         if (lead) gkeep[it] = make_float4(g[0], g[1], g[2], g[3]);
-        else if (ok) st4(a.g + (long long)(r0 + ln) * D + (4 * lt + q) * 16 + 4 * lk, make_float4(g[0], g[1], g[2], g[3]));
+        else if (ok) st4o(a.g + (long long)(r0 + ln) * D + (4 * lt + q) * 16 + 4 * lk, make_float4(g[0], g[1], g[2], g[3]));
         // dhd1 += g Wd1^T over this tile's 16 columns: the accumulator layout IS the B operand
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
@@ -572,8 +594,8 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
     }
     if (a.dbg && a.fine >= 5 && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + 15] = spins;       // sweeps that failed
     if (ln < nrow) {                               // now the decoder tiles' g = sigmoid(lambda) - x
-      st4(a.g + (long long)(r0 + ln) * D + (4 * wave + q) * 16 + 4 * lk, gkeep[0]);
-      if (two) st4(a.g + (long long)(r0 + ln) * D + (4 * (wave + 8) + q) * 16 + 4 * lk, gkeep[1]);
+      st4o(a.g + (long long)(r0 + ln) * D + (4 * wave + q) * 16 + 4 * lk, gkeep[0]);
+      if (two) st4o(a.g + (long long)(r0 + ln) * D + (4 * (wave + 8) + q) * 16 + 4 * lk, gkeep[1]);
     }
     M2_WC(2);
     if (wd) {                                      // masked top gradient (+ saved for dWd0)
@@ -582,7 +604,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       const float4 d = make_float4((ok && hd.x > 0.f) ? dsum.x : 0.f, (ok && hd.y > 0.f) ? dsum.y : 0.f,
                                    (ok && hd.z > 0.f) ? dsum.z : 0.f, (ok && hd.w > 0.f) ? dsum.w : 0.f);
       st4(P_dhd + orow * M2::ld64 + ocol, d);
-      if (ok) st4(a.dhd1 + (long long)(r0 + orow) * H + ocol, d);
+      if (ok) st4o(a.dhd1 + (long long)(r0 + orow) * H + ocol, d);
     }
     if (wn) {
       const int row = tid - 256;
@@ -619,13 +641,9 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
         const float pterm = t * isp;                   // d(-log p)/dz
         dmup = -pterm;
         drawp = (sp > a.smin) ? (1.f - t * t) * isp * P_sp[row * 64 + l] : 0.f;
-        float* dp = a.dpp + (long long)(r0 + row) * L2;
-        dp[l] = dmup; dp[L + l] = drawp;
         dmu = P_dz[row * M2::ld64 + l] + pterm;
         const float dsg = dmu * P_eps[row * 64 + l] - __builtin_amdgcn_rcpf(sg);
         draw = (sg > a.smin) ? dsg * P_qp[row * M2::ld128 + l] : 0.f;
-        float* dq = a.dqp + (long long)(r0 + row) * L2;
-        dq[l] = dmu; dq[L + l] = draw;
       }
       P_dqp[row * M2::ld128 + l] = dmu;
       P_dqp[row * M2::ld128 + L + l] = draw;
@@ -634,6 +652,13 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
     }
   }
   __syncthreads();
+  {                                                // dqp, dpp (kept for dWg1, dWp): one 16-byte write-through store each per thread
+    const int row = tid >> 5, c = (tid & 31) << 2;
+    if (row < nrow) {
+      st4o(a.dqp + (long long)(r0 + row) * L2 + c, ld4(P_dqp + row * M2::ld128 + c));
+      st4o(a.dpp + (long long)(r0 + row) * L2 + c, ld4(P_dpp + row * M2::ld128 + c));
+    }
+  }
   // B3 dhg = (dqp * Wg1^T) [hg > 0]: 4 tiles, contraction 128 split in two over the wave halves
   {
     const int t = wave & 3, kh = wave >> 2;
@@ -649,7 +674,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       const float4 d = make_float4((ok && hg.x > 0.f) ? acc[0] + o.x : 0.f, (ok && hg.y > 0.f) ? acc[1] + o.y : 0.f,
                                    (ok && hg.z > 0.f) ? acc[2] + o.z : 0.f, (ok && hg.w > 0.f) ? acc[3] + o.w : 0.f);
       st4(P_dhg + ln * M2::ld64 + c0, d);
-      if (ok) st4(a.dhg1 + (long long)(r0 + ln) * H + c0, d);
+      if (ok) st4o(a.dhg1 + (long long)(r0 + ln) * H + c0, d);
     }
   }
   __syncthreads();
@@ -695,8 +720,8 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
     const int c0 = wave * 16 + 4 * lk;
     const float4 hy = ld4(P_h1 + ln * M2::ld128 + c0);
     if (ln < nrow)
-      st4(a.dhy1 + (long long)(r0 + ln) * H + c0,
-          make_float4(hy.x > 0.f ? acc[0] : 0.f, hy.y > 0.f ? acc[1] : 0.f, hy.z > 0.f ? acc[2] : 0.f, hy.w > 0.f ? acc[3] : 0.f));
+      st4o(a.dhy1 + (long long)(r0 + ln) * H + c0,
+           make_float4(hy.x > 0.f ? acc[0] : 0.f, hy.y > 0.f ? acc[1] : 0.f, hy.z > 0.f ? acc[2] : 0.f, hy.w > 0.f ? acc[3] : 0.f));
   }
   GMVAE_STAMP(7);
   M2_SPAN_END();
