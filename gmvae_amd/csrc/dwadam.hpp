@@ -40,7 +40,8 @@ struct DwTensor {
 
 constexpr int kDwMaxTiles = 512;
 struct DwArgs {
-  int ntens, total_tiles, B, pad_;
+  int ntens, total_tiles, B;
+  int u8x3;                    // the uint8-activation problems on the bf16 matrix cores (exact bf16x3 form; GMVAE_NO_DW_U8X3 = fp32 MFMA)
   // XCD-aware launch order (speed only): workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own, so
   // slot b (XCD b % 8) runs tile perm[b], chosen on the host so that the tiles of one XCD share operand columns (an
   // x-problem's XCD keeps the x columns of "its" row blocks, the decoder layer's the g columns of "its" column tiles)
@@ -121,6 +122,67 @@ __device__ __forceinline__ void dw_contract(const void* __restrict__ Ap, const f
     }
 #pragma unroll
     for (int s = 0; s < KB; ++s) mfma4(av[s], (b0 + 4 * s + lk < b_hi && n_ok) ? bvv[s] : 0.f);   // a zero B operand also voids the clamped A values
+  }
+}
+
+// The uint8-activation problems (dW = x^T dY, x the batch) on the bf16 matrix cores, EXACT: x is exact in bf16 (8
+// significant bits) and dY = hi + mid + lo, three bf16 pieces that reproduce its 24-bit significand (truncation splits,
+// exact residuals), so every product is exact and the fp32 accumulation is the only rounding -- as on the fp32 MFMA path,
+// at 3 v_mfma_f32_16x16x32_bf16 (16 cycles each) per 32 batch rows and tile instead of 8 v_mfma_f32_16x16x4_f32 (32
+// cycles each): 2 waves x 128 MFMAs x 32 cycles per SIMD (3.5 us, the launch's critical path) become 2 x 48 x 16.
+// No transposition is needed for the 8-elements-per-lane operands: WHICH batch row is contraction index (lane group h,
+// element j) of an MFMA is free as long as A and B agree -- row b_lo + 32 blk + 4 j + h, i.e. exactly the rows the
+// register-direct loads of the fp32 form already hold (k-step s = 8 blk + j of lane group h).  Per block of 8 k-steps a
+// lane repacks: A tile t = bf16(byte t of its 8 packed words) (v_cvt_f32_ubyte + v_perm), B = the three pieces of its 8
+// dY values (and / sub / perm): ~100 VALU instructions beside 12 MFMAs.
+__device__ __forceinline__ unsigned pack_hi16(const float f1, const float f0) {     // (bf16 bits of f0) | (bf16 bits of f1) << 16, truncating
+  return __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+}
+__device__ __forceinline__ void dw_contract_u8x3(const unsigned char* __restrict__ A8, const float* __restrict__ dY, const int lda,
+                                                 const int ldy, const int M, const int N, const int m0, const int n0, const int b_lo,
+                                                 const int ln, const int lk, f32x4 (&acc)[4], float& cs) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int ma = m0 + 4 * ln;
+  const bool a_ok = ma < M, n_ok = n0 + ln < N;
+  const int mac = min(ma, ((M + 3) & ~3) - 4), nc = min(n0 + ln, N - 1);
+  constexpr int KB = 32;
+  unsigned av[KB];
+  float bvv[KB];
+  const unsigned char* const a8 = A8 + (long long)(b_lo + lk) * lda + mac;
+  const float* const dy = dY + (long long)(b_lo + lk) * ldy + nc;
+#pragma unroll
+  for (int s = 0; s < KB; ++s) {
+    av[s] = *reinterpret_cast<const unsigned*>(a8 + (long long)(4 * s) * lda);
+    bvv[s] = dy[(long long)(4 * s) * ldy];
+  }
+#pragma unroll
+  for (int blk = 0; blk < KB / 8; ++blk) {
+    u32x4 bh, bm, bl;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      const float v0 = n_ok ? bvv[8 * blk + 2 * jp] : 0.f, v1 = n_ok ? bvv[8 * blk + 2 * jp + 1] : 0.f;
+      cs += v0; cs += v1;
+      bh[jp] = pack_hi16(v1, v0);
+      const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u), r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
+      bm[jp] = pack_hi16(r1, r0);
+      const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+      bl[jp] = pack_hi16(s1, s0);
+    }
+    const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bm = __builtin_bit_cast(bf16x8, bm), Bl = __builtin_bit_cast(bf16x8, bl);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      u32x4 aw;
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+        const float f0 = (float)((av[8 * blk + 2 * jp] >> (8 * t)) & 0xffu), f1 = (float)((av[8 * blk + 2 * jp + 1] >> (8 * t)) & 0xffu);
+        aw[jp] = a_ok ? pack_hi16(f1, f0) : 0u;
+      }
+      const bf16x8 At = __builtin_bit_cast(bf16x8, aw);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(At, Bl, acc[t], 0, 0, 0);      // smallest pieces first
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(At, Bm, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(At, Bh, acc[t], 0, 0, 0);
+    }
   }
 }
 
@@ -224,7 +286,9 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float cs = 0.f;
-  if (T.a_u8) dw_contract<true, 4>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+  if (T.a_u8 && b_hi - b_lo == 128 && a.u8x3)
+    dw_contract_u8x3(static_cast<const unsigned char*>(T.A), T.dY, lda, ldy, M, N, m0, n0, b_lo, ln, lk, acc, cs);
+  else if (T.a_u8) dw_contract<true, 4>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
   else if (MUr == 4) dw_contract<false, 4>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
   else dw_contract<false, 2>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
   prologue();                                    // its loads fly while the partial tiles go to LDS and the waves meet

@@ -920,6 +920,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       static DwArgs da;                          // (host-side scratch: 3 KB, too large for comfort on the stack next to Launch)
       memset(&da, 0, sizeof(da));
       da.B = B;
+      da.u8x3 = getenv("GMVAE_NO_DW_U8X3") ? 0 : 1;
       da.dbg = getenv("GMVAE_STAMPS") ? w.gstamps + 3 * 2048 * 8 : nullptr;
       da.lr_t = m2_ran ? reinterpret_cast<const float*>(w.sync + 2) : nullptr;
       da.ln_b1 = (float)log((double)a.beta1); da.ln_b2 = (float)log((double)a.beta2);
