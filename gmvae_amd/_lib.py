@@ -72,6 +72,7 @@ def _load():
         "gmvae_workspace_offset": ([dp, i32, C.c_char_p, C.POINTER(u64)], i32),
         "gmvae_binarize": ([vp, u64, vp, u64, i32, i32, u64, u64, vp, vp, u64, vp], i32),
         "gmvae_kernel_occupancy": ([i32, C.POINTER(i32)], i32),
+        "gmvae_debug_sk_stamps": ([vp], i32),
         "gmvae_train_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, i32, i32, C.POINTER(i32), vp, vp, vp, vp, vp], i32),
         "gmvae_step_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),
     }

@@ -23,6 +23,7 @@
 #include "mega.hpp"
 #include "mega2.hpp"
 #include "dwadam.hpp"
+#include "skinny.hpp"
 
 using namespace gmvae;
 
@@ -33,6 +34,7 @@ constexpr int NS_MAX = 16;
 constexpr int MAX_LEVELS = 96;
 constexpr int GMP_PARTS = 64;
 constexpr int kMegaQMax = 4;
+constexpr int kSkNs1 = 4;        // slabs of the skinny schedule's first layer (contraction split); <= skinny.hpp kSkNs1x
 
 // Workgroups that share one 16-row panel of mega_fwd_bwd (they split its decoder chunks): as many as keep the
 // whole grid co-resident on the chip's 256 CUs (one 150 KB-LDS workgroup per CU).
@@ -125,6 +127,7 @@ struct WS {
   float* hd[MAXH + 2];   // decoder activations [R, dim[i]]
   float *gx, *logits, *y, *nent, *pp, *qp, *z, *logq, *logp, *logpx, *logw, *rw, *resp, *g, *part;
   float *dbuf[3], *dz, *dqp, *dpp, *dy, *dlogits, *dqb, *slabs, *gmp_part;
+  float *sk_s1, *sk_lqp, *sk_part;   // skinny schedule: first-layer slabs [ns1][B][2H]; log q / log p partials [2][L/16][B]; logpx partials [B][D/16]
   float *gmp_inv, *gmp_cst;     // tiled mixture log-prob (any K, L): 1 / softplus(raw_scale_diag) [K][L], per-component constants [K]
   double* lw64;            // S > 1: log w per row in fp64 (kernels.hpp row_terms / iwae_rows)
   float *pb, *dsum;        // S > 1: per-row IWAE partials [B][4]; sum over s of encoder_gmm's first-layer gradient [B][H]
@@ -185,6 +188,16 @@ static bool mega2_ok(const GmvaeDims& d, int model) {
   if (e && atoi(e)) return false;
   return model == GMVAE_MODEL_GMVAE && mega_ok(d, model) && d.hidden[0] == M2::H && d.L == M2::L && d.K == M2::K &&
          d.D == M2::D && d.B <= 1024;
+}
+// the skinny schedule (skinny.hpp): GMVAE, one WIDE hidden layer, a SMALL batch -- bin/run_train.sh's sizes
+static bool skinny_ok(const GmvaeDims& d, int model) {
+  const char* e = getenv("GMVAE_NO_SKINNY");
+  if (e && atoi(e)) return false;
+  if (model != GMVAE_MODEL_GMVAE || d.n_hidden != 1 || d.S != 1) return false;
+  const int H = d.hidden[0];
+  int maxb = 128;
+  if (const char* mb = getenv("GMVAE_SKINNY_MAXB")) maxb = atoi(mb);
+  return H % 64 == 0 && H <= 1024 && d.D % 16 == 0 && d.L % 16 == 0 && d.L <= 256 && d.K <= 16 && d.B <= maxb;
 }
 static bool fused_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_FUSED");
@@ -285,6 +298,11 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
       w.img2b = take(M2::imgB);
       w.dimg2 = take(M2::dimg);
     }
+  }
+  if (skinny_ok(d, model)) {
+    w.sk_s1 = take((uint64_t)kSkNs1 * B * 2 * d.hidden[0]);
+    w.sk_lqp = take(2ull * ((Lz + 15) / 16) * B);
+    w.sk_part = take(B * ((D + 15) / 16));
   }
   w.dz = take(R * Lz);
   w.dqp = take(R * 2 * Lz);
@@ -1207,6 +1225,79 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
   return finish_fused(cx, a, L, w, tail, NS, B);
 }
 
+static unsigned long long* g_sk_dbg = nullptr;
+// ---- the skinny schedule (skinny.hpp): 10 launches, every weight matrix crosses the fabric once per pass
+static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, const float* eps, const float* u,
+                           float* gen_eps, float* gen_u) {
+  const GmvaeDims& d = *a.d;
+  const int B = d.B, K = d.K, Lz = d.L, D = d.D, H = d.hidden[0];
+  hipStream_t st = cx.st;
+  static SkArgs s;                               // (host-side scratch, ~1 KB)
+  memset(&s, 0, sizeof(s));
+  const NetL &E = L.ency, &G = L.encg, &Dn = L.dec;
+  s.B = B; s.D = D; s.H = H; s.L = Lz; s.K = K; s.K4 = (int)pad4(K);
+  s.ns1 = kSkNs1; s.nparts = D / 16;
+  s.c = d.raw_sigma_bias; s.smin = d.sigma_min; s.invT = 1.f / d.temperature; s.gen_bias = d.gen_bias_init;
+  s.gen_bias_vec = d.gen_bias_vec;
+  s.x = a.x; s.P = a.params;
+  s.Wy0 = (long long)E.w[0]; s.by0 = (long long)E.b[0]; s.Wy1 = (long long)E.w[1]; s.by1 = (long long)E.b[1];
+  s.Wp = (long long)L.prior.w[0]; s.bp = (long long)L.prior.b[0];
+  s.Wg0 = (long long)G.w[0]; s.bg0 = (long long)G.b[0]; s.Wg1 = (long long)G.w[1]; s.bg1 = (long long)G.b[1];
+  s.Wd0 = (long long)Dn.w[0]; s.bd0 = (long long)Dn.b[0]; s.Wd1 = (long long)Dn.w[1]; s.bd1 = (long long)Dn.b[1];
+  s.s1 = w.sk_s1; s.hy = w.he[1]; s.hg = w.hg[1]; s.y = w.y; s.logits = w.logits; s.nent = w.nent; s.pp = w.pp; s.qp = w.qp;
+  s.z = w.z; s.hd = w.hd[1]; s.g = w.g; s.part = w.sk_part; s.lqp = w.sk_lqp;
+  s.dhd = w.dbuf[0]; s.dqp = w.dqp; s.dpp = w.dpp; s.dhg = w.dbuf[1]; s.dlogits = w.dlogits; s.dhy = w.dbuf[2];
+  s.eps = eps; s.u = u; s.eps_w = gen_eps; s.u_w = gen_u; s.gen_eps = gen_eps ? 1 : 0; s.gen_u = gen_u ? 1 : 0;
+  s.seed = a.seed; s.step = a.step; s.row0 = d.row0; s.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
+  s.grads = a.grads; s.ap = a.adam_p; s.am = a.adam_m; s.av = a.adam_v;
+  s.lr = a.lr; s.b1 = a.beta1; s.b2 = a.beta2; s.aeps = a.epsilon;
+  s.ln_b1 = (float)log((double)a.beta1); s.ln_b2 = (float)log((double)a.beta2);
+  s.tail = a.grads + L.P_pad; s.tail_log = a.tail_log;
+  s.logpx = w.logpx; s.logq = w.logq; s.logp = w.logp; s.logw = w.logw;
+  auto add = [&](const void* A, bool u8, int lda, const float* dY, int ldy, int M, int N, uint64_t w_off, long long b_off) {
+    SkTensor& T = s.t[s.ntens++];
+    T.A = A; T.a_u8 = u8 ? 1 : 0; T.lda = lda; T.dY = dY; T.ldy = ldy; T.M = M; T.N = N; T.w_off = (int)w_off; T.b_off = (int)b_off;
+    T.vec = (N % 4 == 0 && ldy % 4 == 0) ? 1 : 0;            // 16-byte optimizer accesses ([16 x 64] tiles) where rows allow
+    T.tiles_n = T.vec ? (N + 63) / 64 : (N + 15) / 16; T.tile_begin = s.total_tiles;
+    s.total_tiles += (T.vec ? (M + 15) / 16 : (M + 63) / 64) * T.tiles_n;
+  };
+  add(a.x, true, D, s.dhy, H, D, H, E.w[0], (long long)E.b[0]);                                        // dWy0 (+ dby0)
+  add(a.x, true, D, s.dhg, H, D, H, G.w[0], (long long)G.b[0]);                                        // dWg0[x] (+ dbg0)
+  add(s.hd, false, H, s.g, D, H, D, Dn.w[1], (long long)Dn.b[1]);                                      // dWd1 (+ dbd1)
+  add(s.hg, false, H, s.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1]);                            // dWg1
+  add(s.z, false, Lz, s.dhd, H, Lz, H, Dn.w[0], (long long)Dn.b[0]);                                   // dWd0
+  add(s.y, false, s.K4, s.dhg, H, K, H, G.w[0] + (uint64_t)D * H, -1);                                 // dWg0[y]
+  add(s.hy, false, H, s.dlogits, s.K4, H, K, E.w[1], (long long)E.b[1]);                               // dWy1
+  add(s.y, false, s.K4, s.dpp, 2 * Lz, K, 2 * Lz, L.prior.w[0], (long long)L.prior.b[0]);              // dWp
+  const int nrt = (B + 15) / 16;
+  const double fB = 2.0 * B;
+  s.dbg = g_sk_dbg;                                // diagnostic: tools/skstamps.py (null unless gmvae_debug_sk_stamps(NULL) ran)
+  const int empty_mode = getenv("GMVAE_SK_EMPTY") ? atoi(getenv("GMVAE_SK_EMPTY")) : 0;     // (diagnostic, tools/micro)
+  auto launch = [&](auto kern, int grid, int threads, size_t sh, const char* name, double fl) {
+    if (empty_mode == 2) hipLaunchKernelGGL(sk_gemm<SK_EMPTY>, dim3(grid), dim3(kSkThreads), 0, st, s);      // same grids, no work
+    else if (empty_mode == 3) { int tiny[2] = {1, 2}; (void)tiny; hipLaunchKernelGGL(sk_tiny, dim3(grid), dim3(256), 0, st, (float*)nullptr, 1); }
+    else
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), sh, st, s);
+    cx.check();
+    cx.mark(name, fl);
+  };
+  launch(sk_gemm<SK_F1>, (2 * H / 64) * nrt * s.ns1, kSkThreads, 0, "sk_first_layers", fB * D * 2 * H);
+  const int eps_blocks = gen_eps ? (int)(((long long)B * ((Lz + 3) / 4) + 255) / 256) : 0;       // extra workgroups: the eps rows
+  launch(H <= 512 ? sk_ypath<2> : sk_ypath<4>, B + eps_blocks, 256, 0, "sk_y_path", fB * ((double)H * K + K * H + K * 2.0 * Lz));
+  launch(sk_gemm<SK_F3>, (Lz / 16) * nrt, kSkThreads, 0, "sk_q_head_z", fB * H * 2 * Lz);
+  launch(sk_gemm<SK_F4>, (H / 64) * nrt, kSkThreads, 0, "sk_dec_hidden", fB * Lz * H);
+  if (empty_mode == 1) launch(sk_gemm<SK_EMPTY>, (H / 64) * nrt, kSkThreads, 0, "sk_empty", 0.0);     // (diagnostic)
+  launch(sk_gemm<SK_F5>, (D / 16) * nrt, kSkThreads, 0, "sk_dec_bernoulli", fB * H * D);
+  launch(sk_gemm<SK_B1>, (H / 16) * nrt, kSkThreads, 0, "sk_bwd_dhd", fB * D * H);
+  launch(sk_gemm<SK_B2>, (Lz / 16) * nrt, kSkThreads, 0, "sk_bwd_dz_heads", fB * H * Lz);
+  launch(sk_gemm<SK_B3>, (H / 32) * nrt, kSkThreads, 0, "sk_bwd_dhg", fB * 2 * Lz * H);
+  launch(H <= 512 ? sk_ybwd<2> : sk_ybwd<4>, B, 256, 0, "sk_y_path_bwd", fB * ((double)(H + 2 * Lz) * K + K * H));
+  double fw = 0;
+  for (int i = 0; i < s.ntens; ++i) fw += 2.0 * s.t[i].M * s.t[i].N * B;
+  launch(sk_dw, (s.total_tiles + kSkWaves - 1) / kSkWaves + 1, kSkThreads, 0, s.ap ? "sk_dw_adam" : "sk_dw", fw);
+  return cx.err;
+}
+
 static int run_step(Ctx& cx, const StepArgs& a) {
   const GmvaeDims& d = *a.d;
   const int model = a.model;
@@ -1229,6 +1320,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   if (ge) eps = ge;
   if (gu) u = gu;
   if (a.backward && mega_ok(d, model)) return run_step_mega(cx, a, L, w, eps, u, ge, gu);
+  if (a.backward && skinny_ok(d, model)) return run_step_skinny(cx, a, L, w, eps, u, ge, gu);
   if (fused_ok(d, model) && !a.z_out && !a.y_out && !a.logits_out)
     return run_step_fused(cx, a, L, w, eps, u, ge, gu);
   // (general schedule: the Philox fill rides as auxiliary workgroups of the first GEMM launch below; GMVAE_NOISE_LAUNCH=1
@@ -2038,6 +2130,19 @@ int gmvae_train_graph_destroy(void* graph) {
   hipGraphDestroy(tg->graph);
   delete tg;
   return 0;
+}
+
+/* debugging aid: copies the skinny schedule's stamp buffer ([10][256][8] uint64, GMVAE_SK_STAMPS=1) to the host */
+int gmvae_debug_sk_stamps(unsigned long long* host_out) {
+  if (!host_out) {                                 // arm: allocate the buffer (outside any stream capture); later captures stamp into it
+    if (!g_sk_dbg) {
+      if (hipMalloc(&g_sk_dbg, (size_t)10 * 256 * 8 * 8) != hipSuccess) return GMVAE_E_NULL;
+      hipMemset(g_sk_dbg, 0, (size_t)10 * 256 * 8 * 8);
+    }
+    return 0;
+  }
+  if (!g_sk_dbg) return GMVAE_E_NULL;
+  return (int)hipMemcpy(host_out, g_sk_dbg, (size_t)10 * 256 * 8 * 8, hipMemcpyDeviceToHost);
 }
 
 /* debugging aid: resident workgroups per CU as the runtime computes them */

@@ -1,0 +1,821 @@
+// The "skinny" schedule: the GMVAE training step for a SMALL batch and WIDE hidden layers -- the one training
+// configuration the reference ships (bin/run_train.sh:3-14: batch 64, hidden 512, latent 128; scripts/gmvae.py:238-267 and
+// its reverse pass, scripts/runners.py:181-183 for the optimizer).
+//
+// At 64 rows the activations are a few hundred KB and the 5 MB of weights are the operands that matter: every layer is
+// a [B <= 128] x K x N product whose weight matrix should cross the fabric ONCE, spread over as many CUs as the layer
+// has 16-column tiles, and whose activation operand is L2-resident.  The general schedule ran each such layer through
+// the grouped GEMM's 32 x 32 x 128 tiles (7 serial staging rounds for K = 784: 11 us per launch, 19 launches, 185 us
+// per step).  Here a workgroup owns a [16 rows] x [16 .. 64 columns] output tile for the whole contraction, its 8 waves
+// split the contraction, and operands go global -> registers -> matrix core with 16-byte loads along the contraction:
+// which element of the contraction is MFMA step q of lane group h is free as long as A and B agree, so a lane's four
+// consecutive k (one 16-byte load of the activation row, or 4 bytes of the uint8 batch) serve four consecutive
+// v_mfma_f32_16x16x4_f32 with k = 16 g + 4 h + q.  Partial tiles meet in LDS in wave order (bit-reproducible) and the
+// layer's row-wise work (bias, ReLU, the q / prior heads, the Bernoulli term, their reverse forms) is the epilogue of the
+// tile that produced its inputs.  10 launches:
+//   F1 first layers over the uint8 batch (split over the contraction into ns1 slabs)   F2 y path, one wave per row
+//   F3 q head + z + log q / log p partials   F4 decoder hidden   F5 decoder output + Bernoulli term + g = sigmoid - x
+//   B1 dhd   B2 dz + the heads' reverse   B3 dhg   B4 dy -> dlogits -> dhy, one wave per row
+//   W  every weight / bias gradient (contraction over the <= 128 batch rows: one 64 x 16 tile per WAVE) + TF-Adam + loss tail
+// Bound: HBM/L2 latency per launch (a launch moves 0.1 - 2 MB), then the optimizer's 9 x 4 P bytes (47 MB at H = 512).
+#pragma once
+#include "dwadam.hpp"
+
+namespace gmvae {
+
+constexpr int kSkThreads = 512, kSkWaves = 8;
+constexpr int kSkNs1x = 4;      // upper bound of SkArgs::ns1 (first-layer slabs)
+
+struct SkTensor {              // one weight tensor of the W launch
+  const void* A;               // [B][lda] uint8 or fp32: the layer's input rows
+  const float* dY;             // [B][ldy]: the pre-activation gradients
+  int lda, ldy, M, N, a_u8;
+  int w_off, b_off;            // flat parameter offsets of W [M][N] and of its bias [N] (b_off < 0: none)
+  int tiles_n, tile_begin;
+  int vec;                     // N % 4 == 0: [16 x 64] tiles, 4 consecutive columns per lane (16-byte optimizer accesses)
+};
+constexpr int kSkMaxT = 10;
+
+struct SkArgs {
+  int B, D, H, L, K, K4;       // K4 = pad4(K): row stride of y and dlogits
+  int ns1, nparts;             // first-layer slabs; logpx partials per row
+  float c, smin, invT, gen_bias;
+  const float* gen_bias_vec;
+  const unsigned char* x;
+  const float* P;              // flat parameters
+  long long Wy0, by0, Wy1, by1, Wp, bp, Wg0, bg0, Wg1, bg1, Wd0, bd0, Wd1, bd1;
+  float *s1, *hy, *hg, *y, *logits, *nent, *pp, *qp, *z, *hd, *g, *part, *lqp;
+  float *dhd, *dqp, *dpp, *dhg, *dlogits, *dhy;
+  const float *eps, *u;        // the step's noise (external arrays, or the workspace arrays F2 fills when gen_noise)
+  float *eps_w, *u_w;
+  int gen_eps, gen_u;          // F2 draws that array with Philox (aux.hpp noise_vals) instead of reading an external one
+  unsigned long long seed, step, row0;
+  unsigned long long* step_dev;
+  // W launch
+  int ntens, total_tiles;
+  SkTensor t[kSkMaxT];
+  float *grads, *ap, *am, *av; // ap != null: TF-Adam in the epilogue
+  float lr, b1, b2, aeps, ln_b1, ln_b2;
+  float *tail, *tail_log;
+  float *logpx, *logq, *logp, *logw;
+  unsigned long long* dbg;     // diagnostic (GMVAE_SK_STAMPS): [10 launches][256 blocks][8] device wall-clock stamps (100 MHz)
+};
+#define SK_STAMP(slot, i) if (a.dbg && threadIdx.x == 0 && blockIdx.x < 256) a.dbg[((size_t)(slot) * 256 + blockIdx.x) * 8 + (i)] = wall_clock64()
+
+enum { SK_F1 = 0, SK_F3, SK_F4, SK_F5, SK_B1, SK_B2, SK_B3, SK_EMPTY };
+
+// ---- contraction pieces: one wave's share (k-groups kg = kg_lo + wave, + 8, ... < kg_hi; a k-group = 16 contraction steps).
+// The wave's groups run in batches of 4, 2, 1 (compile-time sizes): every load of a batch is in flight before its first MFMA,
+// and no matrix instruction is spent on an absent group (a layer with K = 128 has ONE group per wave).
+template <class F>
+__device__ __forceinline__ void sk_groups(const int kg_lo, const int kg_hi, const int wave, F&& body) {
+  const int kg = kg_lo + wave;
+  const int n = kg < kg_hi ? (kg_hi - kg + kSkWaves - 1) / kSkWaves : 0;
+  int done = 0;
+  for (; n - done >= 4; done += 4) body(std::integral_constant<int, 4>{}, kg + kSkWaves * done);
+  if (n - done >= 2) { body(std::integral_constant<int, 2>{}, kg + kSkWaves * done); done += 2; }
+  if (n - done >= 1) body(std::integral_constant<int, 1>{}, kg + kSkWaves * done);
+}
+// NN, 4 strided column tiles: out[row][n0 + 4 i + t] for lane column i: W k-major [K][ldw], one 16-byte load of W per k
+template <bool U8>
+__device__ __forceinline__ void sk_nn4(const void* __restrict__ Ap, const long long arow, const float* __restrict__ W, const int ldw,
+                                       const int ncol, const int kg_lo, const int kg_hi, const int wave, const int lk,
+                                       f32x4 (&acc)[4]) {
+  sk_groups(kg_lo, kg_hi, wave, [&](auto ng, const int kgb) {
+    constexpr int NG = decltype(ng)::value;
+    float4 av[NG], bv[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int k = 16 * (kgb + g * kSkWaves) + 4 * lk;
+      if constexpr (U8) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(Ap) + arow + k);
+        av[g] = make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
+      } else {
+        av[g] = *reinterpret_cast<const float4*>(static_cast<const float*>(Ap) + arow + k);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[g][q] = *reinterpret_cast<const float4*>(W + (long long)(k + q) * ldw + ncol);
+    }
+    __builtin_amdgcn_sched_barrier(0);             // every load of the batch is issued before its first MFMA
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float aq[4] = {av[g].x, av[g].y, av[g].z, av[g].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q].w, acc[3], 0, 0, 0);
+      }
+    }
+  });
+}
+// NN, NU plain column tiles at columns col[t] (4-byte loads of W: the q head's (mu, raw) column pairs)
+template <int NU>
+__device__ __forceinline__ void sk_nnp(const float* __restrict__ A, const long long arow, const float* __restrict__ W, const int ldw,
+                                       const int (&col)[NU], const int kg_lo, const int kg_hi, const int wave, const int lk,
+                                       f32x4 (&acc)[4]) {
+  sk_groups(kg_lo, kg_hi, wave, [&](auto ng, const int kgb) {
+    constexpr int NG = decltype(ng)::value;
+    float4 av[NG];
+    float bv[NG][4][NU];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int k = 16 * (kgb + g * kSkWaves) + 4 * lk;
+      av[g] = *reinterpret_cast<const float4*>(A + arow + k);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < NU; ++t) bv[g][q][t] = W[(long long)(k + q) * ldw + col[t]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float aq[4] = {av[g].x, av[g].y, av[g].z, av[g].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < NU; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q][t], acc[t], 0, 0, 0);
+    }
+  });
+}
+// NT (data gradients): out[row][j] = sum_c A[row][c] W[j][c], W rows contraction-contiguous: 16-byte loads of both
+template <int NU>
+__device__ __forceinline__ void sk_nt(const float* __restrict__ A, const long long arow, const float* __restrict__ W, const int ldw,
+                                      const int (&wrow)[NU], const int kg_lo, const int kg_hi, const int wave, const int lk,
+                                      f32x4 (&acc)[4]) {
+  sk_groups(kg_lo, kg_hi, wave, [&](auto ng, const int kgb) {
+    constexpr int NG = decltype(ng)::value;
+    float4 av[NG], bv[NG][NU];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int k = 16 * (kgb + g * kSkWaves) + 4 * lk;
+      av[g] = *reinterpret_cast<const float4*>(A + arow + k);
+#pragma unroll
+      for (int t = 0; t < NU; ++t) bv[g][t] = *reinterpret_cast<const float4*>(W + (long long)wrow[t] * ldw + k);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int t = 0; t < NU; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].x, bv[g][t].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].y, bv[g][t].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].z, bv[g][t].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].w, bv[g][t].w, acc[t], 0, 0, 0);
+      }
+    }
+  });
+}
+
+// launch outputs leave write-through (mega2.hpp st4o): nothing waits dirty in L2 for the end-of-kernel write-back, which
+// at ten short launches per step is most of a step (measured: tools/micro/launch_floor.hip, profiles/round3_notes.md)
+__device__ __forceinline__ void st1o(float* p, const float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ float sk_row16_sum(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+__global__ void sk_tiny(float* p, int n) { if (n < 0) p[0] = 1.f; }       // (diagnostic: a launch with 12 bytes of arguments)
+
+// One matrix-product launch of the schedule.  Grid: column tiles x row tiles (x ns1 slabs for F1); a workgroup = one
+// 16-row output tile; tiles are NN4 (16 x 64, strided columns), pairs (F3) or plain 16-column tiles (NT forms).
+template <int ST>
+__global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[kSkWaves * 16 * 64];      // [wave][4 t + r][lane]
+  if constexpr (ST == SK_EMPTY) { if (a.B < 0) red[0] = 0.f; return; }       // (diagnostic: the cost of a launch that does nothing)
+  constexpr int SLOT = ST == SK_F1 ? 0 : ST == SK_F3 ? 2 : ST == SK_F4 ? 3 : ST == SK_F5 ? 4 : ST == SK_B1 ? 5 : ST == SK_B2 ? 6 : 7;
+  SK_STAMP(SLOT, 0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lk = lane >> 4;
+  const int B = a.B, D = a.D, H = a.H, L = a.L;
+  const int nrt = (B + 15) >> 4;
+  constexpr int NU = (ST == SK_F1 || ST == SK_F4) ? 4 : (ST == SK_F3 || ST == SK_B3) ? 2 : 1;
+  const int nct = ST == SK_F1 ? (2 * H) / 64 : ST == SK_F3 ? L / 16 : ST == SK_F4 ? H / 64 : ST == SK_F5 ? D / 16
+                : ST == SK_B1 ? H / 16 : ST == SK_B2 ? L / 16 : H / 32;
+  const int bid = blockIdx.x;
+  const int ct = bid % nct, rt = (bid / nct) % nrt, ks = bid / (nct * nrt);
+  const int r0 = rt * 16;
+  const int rowc = min(r0 + ln, B - 1);           // this lane's activation row (clamped; rows >= B are masked at the stores)
+  const float* const P = a.P;
+  // ---- the epilogue's inputs (threads 0..255 own one accumulator register of one lane slot each: see below) are
+  // requested FIRST: they do not depend on the contraction, and behind the waves' meeting in LDS they were a memory
+  // round trip of their own (1.2 - 1.6 us of a 4 - 6 us launch, tools/skstamps.py)
+  const int el = tid & 63, er = (tid >> 6) & 3;   // owner of accumulator register er of lane slot el
+  const int row = r0 + 4 * (el >> 4) + er, ec = el & 15;
+  const bool rok = row < B;
+  const long long rr = rok ? row : B - 1;
+  float pf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float4 pf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 256) {
+    if constexpr (ST == SK_F3) {
+      const int l = ct * 16 + ec;
+      pf[0] = P[a.bg1 + l]; pf[1] = P[a.bg1 + L + l]; pf[2] = a.eps[rr * L + l];
+      pf[3] = a.pp[rr * 2 * L + l]; pf[4] = a.pp[rr * 2 * L + L + l];
+    } else if constexpr (ST == SK_F4) {
+      pf4 = *reinterpret_cast<const float4*>(P + a.bd0 + ct * 64 + 4 * ec);
+    } else if constexpr (ST == SK_F5) {
+      const int n = ct * 16 + ec;
+      pf[0] = P[a.bd1 + n] + (a.gen_bias_vec ? a.gen_bias_vec[n] : 0.f);
+      pf[1] = (float)a.x[rr * D + n];
+    } else if constexpr (ST == SK_B1) {
+      pf[0] = a.hd[rr * H + ct * 16 + ec];
+    } else if constexpr (ST == SK_B3) {
+      pf[0] = a.hg[rr * H + ct * 32 + ec]; pf[1] = a.hg[rr * H + ct * 32 + 16 + ec];
+    } else if constexpr (ST == SK_B2) {
+      const int l = ct * 16 + ec;
+      pf[0] = a.qp[rr * 2 * L + L + l]; pf[1] = a.z[rr * L + l]; pf[2] = a.pp[rr * 2 * L + l];
+      pf[3] = a.pp[rr * 2 * L + L + l]; pf[4] = a.eps[rr * L + l];
+    }
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (ST == SK_F1) {
+    const int c0 = ct * 64, kgs = D / 16;
+    const int kg_lo = (int)((long long)kgs * ks / a.ns1), kg_hi = (int)((long long)kgs * (ks + 1) / a.ns1);
+    const float* W = c0 < H ? P + a.Wy0 + c0 : P + a.Wg0 + (c0 - H);
+    sk_nn4<true>(a.x, (long long)rowc * D, W, H, 4 * ln, kg_lo, kg_hi, wave, lk, acc);
+  } else if constexpr (ST == SK_F3) {
+    const int col[2] = {ct * 16 + ln, L + ct * 16 + ln};
+    sk_nnp<2>(a.hg, (long long)rowc * H, P + a.Wg1, 2 * L, col, 0, H / 16, wave, lk, acc);
+  } else if constexpr (ST == SK_F4) {
+    sk_nn4<false>(a.z, (long long)rowc * L, P + a.Wd0 + ct * 64, H, 4 * ln, 0, L / 16, wave, lk, acc);
+  } else if constexpr (ST == SK_F5) {             // 16-column tiles: D / 16 x row tiles workgroups (the widest layer on the most CUs)
+    const int col[1] = {ct * 16 + ln};
+    sk_nnp<1>(a.hd, (long long)rowc * H, P + a.Wd1, D, col, 0, H / 16, wave, lk, acc);
+  } else if constexpr (ST == SK_B1) {             // dhd = g Wd1^T: out column j = hidden unit, W row j of Wd1 [H][D]
+    const int wr[1] = {ct * 16 + ln};
+    sk_nt<1>(a.g, (long long)rowc * D, P + a.Wd1, D, wr, 0, D / 16, wave, lk, acc);
+  } else if constexpr (ST == SK_B2) {             // dz = dhd Wd0^T: W row l of Wd0 [L][H]
+    const int wr[1] = {ct * 16 + ln};
+    sk_nt<1>(a.dhd, (long long)rowc * H, P + a.Wd0, H, wr, 0, H / 16, wave, lk, acc);
+  } else {                                        // B3: dhg = dqp Wg1^T: W row h of Wg1 [H][2L]
+    const int wr[2] = {ct * 32 + ln, ct * 32 + 16 + ln};
+    sk_nt<2>(a.dqp, (long long)rowc * 2 * L, P + a.Wg1, 2 * L, wr, 0, (2 * L) / 16, wave, lk, acc);
+  }
+  SK_STAMP(SLOT, 1);
+  // ---- the waves' partial tiles meet in LDS (fixed order)
+#pragma unroll
+  for (int t = 0; t < NU; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * t + r) * 64 + lane] = acc[t][r];
+  __syncthreads();
+  SK_STAMP(SLOT, 2);
+  if (tid >= 256) return;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < kSkWaves; ++w)
+#pragma unroll
+    for (int t = 0; t < NU; ++t) v[t] += red[(w * 16 + 4 * t + er) * 64 + el];
+  // ---- epilogues
+  if constexpr (ST == SK_F1) {
+    if (rok) st4o(a.s1 + ((long long)ks * B + row) * 2 * H + ct * 64 + 4 * ec, make_float4(v[0], v[1], v[2], v[3]));
+  } else if constexpr (ST == SK_F3) {
+    // ConditionalNormal heads (scripts/base.py:66-72), z = mu + sigma eps (gmvae.py:248), log q and log p(z|y) terms
+    // (gmvae.py:258) of this tile's 16 latent dimensions; row sums over the tile -> lqp[.][tile][row]
+    const int l = ct * 16 + ec;
+    // (hardware exp / log / rcp forms as mega2.hpp S5: ~1e-6 relative, one pass of each per head)
+    const float mu = v[0] + pf[0], raw = v[1] + pf[1];
+    const float vq = raw + a.c, eq = fexp(-fabsf(vq)), rq = __builtin_amdgcn_rcpf(1.f + eq);
+    const float sg = fmaxf(fmaxf(vq, 0.f) - flog(rq), a.smin);
+    const float zz = mu + sg * pf[2];
+    const float e = (zz - mu) * __builtin_amdgcn_rcpf(sg);       // from z, not eps (A7)
+    float aq = -0.5f * e * e - 0.5f * kLog2Pi - flog(sg);
+    const float mp = pf[3], vp = pf[4] + a.c, ep = fexp(-fabsf(vp)), rp = __builtin_amdgcn_rcpf(1.f + ep);
+    const float sp = fmaxf(fmaxf(vp, 0.f) - flog(rp), a.smin);
+    const float t = (zz - mp) * __builtin_amdgcn_rcpf(sp);
+    float ap = -0.5f * t * t - 0.5f * kLog2Pi - flog(sp);
+    if (rok) { st1o(a.qp + (long long)row * 2 * L + l, mu); st1o(a.qp + (long long)row * 2 * L + L + l, raw); st1o(a.z + (long long)row * L + l, zz); }
+    aq = sk_row16_sum(aq); ap = sk_row16_sum(ap);
+    if (ec == 0 && rok) { st1o(a.lqp + (long long)ct * B + row, aq); st1o(a.lqp + (long long)(L / 16 + ct) * B + row, ap); }
+  } else if constexpr (ST == SK_F4) {
+    const int n = ct * 64 + 4 * ec;
+    if (rok) st4o(a.hd + (long long)row * H + n,
+                  make_float4(fmaxf(v[0] + pf4.x, 0.f), fmaxf(v[1] + pf4.y, 0.f), fmaxf(v[2] + pf4.z, 0.f), fmaxf(v[3] + pf4.w, 0.f)));
+  } else if constexpr (ST == SK_F5) {
+    // logits = MLP(z) + bias_init (scripts/base.py:135); Independent(Bernoulli).log_prob (gmvae.py:254) and its gradient
+    const float lam = v[0] + pf[0] + a.gen_bias;
+    const float xv = pf[1];
+    const float e = __expf(-fabsf(lam));
+    const float rcp = __builtin_amdgcn_rcpf(1.f + e);
+    const float sp = fmaxf(lam, 0.f) - __logf(rcp);
+    float rs = xv * lam - sp;
+    if (rok) st1o(a.g + (long long)row * D + ct * 16 + ec, (lam >= 0.f ? rcp : e * rcp) - xv);
+    rs = sk_row16_sum(rs);
+    if (ec == 0 && rok) st1o(a.part + (long long)row * a.nparts + ct, rs);
+  } else if constexpr (ST == SK_B1) {
+    if (rok) st1o(a.dhd + (long long)row * H + ct * 16 + ec, pf[0] > 0.f ? v[0] : 0.f);
+  } else if constexpr (ST == SK_B3) {
+    if (rok) {
+      st1o(a.dhg + (long long)row * H + ct * 32 + ec, pf[0] > 0.f ? v[0] : 0.f);
+      st1o(a.dhg + (long long)row * H + ct * 32 + 16 + ec, pf[1] > 0.f ? v[1] : 0.f);
+    }
+  } else {                                        // B2: reverse of the two heads, per (row, latent dim)
+    const int l = ct * 16 + ec;
+    if (rok) {
+      const float rawq = pf[0] + a.c, eq = fexp(-fabsf(rawq)), rq = __builtin_amdgcn_rcpf(1.f + eq);
+      const float spq = fmaxf(rawq, 0.f) - flog(rq), sg = fmaxf(spq, a.smin);     // softplus, and rq / eq rq = its derivative
+      const float zz = pf[1];
+      const float mp = pf[2], rawp = pf[3] + a.c, ep = fexp(-fabsf(rawp)), rp = __builtin_amdgcn_rcpf(1.f + ep);
+      const float spp = fmaxf(rawp, 0.f) - flog(rp), sp = fmaxf(spp, a.smin);
+      const float isp = __builtin_amdgcn_rcpf(sp);
+      const float t = (zz - mp) * isp;
+      const float pterm = t * isp;
+      const float dmu = v[0] + pterm;
+      const float dsg = dmu * pf[4] - __builtin_amdgcn_rcpf(sg);
+      st1o(a.dqp + (long long)row * 2 * L + l, dmu);
+      st1o(a.dqp + (long long)row * 2 * L + L + l, (spq > a.smin) ? dsg * (rawq >= 0.f ? rq : eq * rq) : 0.f);
+      st1o(a.dpp + (long long)row * 2 * L + l, -pterm);
+      st1o(a.dpp + (long long)row * 2 * L + L + l, (spp > a.smin) ? (1.f - t * t) * isp * (rawp >= 0.f ? rp : ep * rp) : 0.f);
+    }
+  }
+  SK_STAMP(SLOT, 3);
+}
+
+// block-wide sums of 16 per-thread partials (256 threads): DPP row sums (16 lanes), the 16 rows' sums meet in LDS and
+// thread k < 16 adds them in row order: it returns the k-th total (other threads: 0).  One barrier.  (A butterfly of
+// ds_bpermute shuffles per value was 2.5 us of these 6 - 9 us kernels.)
+__device__ __forceinline__ float sk_block_sum16(const float (&p)[16], float* __restrict__ sh /* [16][16] */, const int tid) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float v = row16_sum(p[k]);
+    if ((tid & 15) == 15) sh[k * 16 + (tid >> 4)] = v;       // (the DPP row-rotation sum ends in every lane of the row)
+  }
+  __syncthreads();
+  float tot = 0.f;
+  if (tid < 16) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tot += sh[tid * 16 + j];
+  }
+  return tot;
+}
+
+// F2: the y path, one workgroup (256 threads) per batch row: this row's Philox noise; hy = relu(sum of the first-layer
+// slabs + b) and the x part of encoder_gmm's first layer; logits = hy Wy1 + b; RelaxedOneHotCategorical.sample and the
+// entropy term (scripts/gmvae.py:238-240,262-263, as kernels.hpp y_head_fwd); hg = relu(gx + y Wg0[D:] + b); the prior
+// head pp = y Wp + b (gmvae.py:243).  K <= 16.  A thread owns hidden units tid + 256 i (i < NI) and prior-head columns
+// tid + 256 j (j < 2); EVERY global load of the kernel -- slabs, biases, the three small weight matrices' entries for the
+// thread's columns, the uniform -- is issued at its start (none depends on another), so the kernel is ONE memory round
+// trip, the logits' block sum, the softmax in wave 0 and the stores.
+template <int NI>
+__global__ __launch_bounds__(256) void sk_ypath(const SkArgs a) {
+  __shared__ float rsh[256], ysh[16], ush[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int B = a.B, H = a.H, L = a.L, K = a.K, H2 = 2 * H, L2 = 2 * L;
+  if ((int)blockIdx.x >= B) {                     // extra workgroups: the eps rows (Box-Muller) beside the rows' critical path
+    const unsigned long long step = a.step_dev ? a.step_dev[0] : a.step;
+    const int qe = (L + 3) / 4;
+    const long long i = (long long)(blockIdx.x - B) * 256 + tid;
+    if (i < (long long)B * qe) {
+      const int r = (int)(i / qe), quad = (int)(i - (long long)r * qe);
+      float nz[4];
+      noise_vals(a.row0 + (unsigned long long)r, (unsigned)quad, false, a.seed, step, nz);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (quad * 4 + j < L) st1o(a.eps_w + (long long)r * L + quad * 4 + j, nz[j]);
+    }
+    return;
+  }
+  const int row = blockIdx.x;
+  const float* const P = a.P;
+  SK_STAMP(1, 0);
+  const unsigned long long step = a.step_dev ? a.step_dev[0] : a.step;
+  if (blockIdx.x == 0 && tid == 0 && a.step_dev) a.step_dev[1] = step;       // the copy the W launch reads
+  // ---- all loads
+  float sy[NI][kSkNs1x], sg[NI][kSkNs1x], by[NI], bg[NI], wy[NI][16], wg[NI][16], wp[2][16], bp[2];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = min(tid + 256 * i, H - 1);
+#pragma unroll
+    for (int s2 = 0; s2 < kSkNs1x; ++s2) {
+      const long long o = ((long long)min(s2, a.ns1 - 1) * B + row) * H2 + c;
+      sy[i][s2] = a.s1[o];
+      sg[i][s2] = a.s1[o + H];
+    }
+    by[i] = P[a.by0 + c];
+    bg[i] = P[a.bg0 + c];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int kc = min(k, K - 1);                 // (branch-free; surplus entries meet zeros below)
+      wy[i][k] = P[a.Wy1 + (long long)c * K + kc];
+      wg[i][k] = P[a.Wg0 + (long long)(a.D + kc) * H + c];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int jc = min(tid + 256 * j, L2 - 1);
+    bp[j] = P[a.bp + jc];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wp[j][k] = P[a.Wp + (long long)min(k, K - 1) * L2 + jc];
+  }
+  const float b1v = P[a.by1 + min(lane, K - 1)];
+  const float u_ext = a.gen_u ? 0.5f : a.u[(long long)row * K + min(lane, K - 1)];
+  // ---- this row's uniforms (wave 3; the eps rows are drawn by the launch's extra workgroups)
+  if (a.gen_u && tid >= 192 && tid - 192 < (K + 3) / 4) {
+    const int quad = tid - 192;
+    float nz[4];
+    noise_vals(a.row0 + (unsigned long long)row, (unsigned)quad, true, a.seed, step, nz);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (quad * 4 + j < K) { st1o(a.u_w + (long long)row * K + quad * 4 + j, nz[j]); ush[quad * 4 + j] = nz[j]; }
+  }
+  // ---- hy, the logits' partial sums; gx stays in registers (the same thread finishes hg for the same hidden units)
+  float p[16], gx[NI];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) p[k] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    float t = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < kSkNs1x; ++s2) { t += s2 < a.ns1 ? sy[i][s2] : 0.f; g2 += s2 < a.ns1 ? sg[i][s2] : 0.f; }
+    const bool on = tid + 256 * i < H;
+    t = on ? fmaxf(t + by[i], 0.f) : 0.f;
+    gx[i] = g2 + bg[i];
+    if (on) st1o(a.hy + (long long)row * H + tid + 256 * i, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p[k] += t * wy[i][k];
+  }
+  SK_STAMP(1, 1);
+  const float ptot = sk_block_sum16(p, rsh, tid);  // (its barrier also publishes ush)
+  SK_STAMP(1, 2);
+  if (wave == 0) {
+    const bool kv = lane < K;
+    const float lg = kv ? ptot + b1v : -INFINITY;
+    const float uu = kv ? (a.gen_u ? ush[lane] : u_ext) : 0.5f;
+    const float av = kv ? (lg - logf(-logf(uu))) * a.invT : -INFINITY;
+    const float mx = wave_max(av), m2 = wave_max(lg);
+    const float se = wave_sum(kv ? expf(av - mx) : 0.f), s2 = wave_sum(kv ? expf(lg - m2) : 0.f);
+    const float lse = mx + logf(se), l2 = m2 + logf(s2);
+    float yv = 0.f, ne = 0.f;
+    if (kv) {
+      yv = expf(av - lse);
+      const float lp = lg - l2;
+      ne = expf(lp) * lp;
+      st1o(a.logits + (long long)row * K + lane, lg);
+    }
+    ne = wave_sum(ne);
+    if (lane < a.K4) st1o(a.y + (long long)row * a.K4 + lane, yv);            // rows of pad4(K) floats, the padding zero
+    if (lane == 0) st1o(a.nent + row, ne);
+    if (lane < 16) ysh[lane] = yv;
+  }
+  __syncthreads();
+  float yk[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) yk[k] = ysh[k];      // (zero for k >= K)
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    float v = gx[i];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += yk[k] * wg[i][k];
+    if (tid + 256 * i < H) st1o(a.hg + (long long)row * H + tid + 256 * i, fmaxf(v, 0.f));
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float v = bp[j];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += yk[k] * wp[j][k];
+    if (tid + 256 * j < L2) st1o(a.pp + (long long)row * L2 + tid + 256 * j, v);
+  }
+  SK_STAMP(1, 3);
+}
+
+// B4: one workgroup per row: dy = dhg Wg0[D:]^T + dpp Wp^T, the reverse of the Gumbel-softmax and of the entropy term
+// (kernels.hpp y_head_bwd at S = 1) -> dlogits, then dhy = (dlogits Wy1^T) [hy > 0].  Same thread map and
+// load discipline as sk_ypath: every global load at the start.
+template <int NI>
+__global__ __launch_bounds__(256) void sk_ybwd(const SkArgs a) {
+  __shared__ float rsh[256], dls[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = a.H, L2 = 2 * a.L, K = a.K;
+  const int row = blockIdx.x;
+  const float* const P = a.P;
+  SK_STAMP(8, 0);
+  float dg[NI], hv[NI], wy[NI][16], wg[NI][16], wp[2][16], dp[2];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = min(tid + 256 * i, H - 1);
+    dg[i] = a.dhg[(long long)row * H + c];
+    hv[i] = a.hy[(long long)row * H + c];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int kc = min(k, K - 1);
+      wy[i][k] = P[a.Wy1 + (long long)c * K + kc];
+      wg[i][k] = P[a.Wg0 + (long long)(a.D + kc) * H + c];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int jc = min(tid + 256 * j, L2 - 1);
+    dp[j] = a.dpp[(long long)row * L2 + jc];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wp[j][k] = P[a.Wp + (long long)min(k, K - 1) * L2 + jc];
+  }
+  const float lg_ = a.logits[(long long)row * K + min(lane, K - 1)];
+  const float yv_ = a.y[(long long)row * a.K4 + min(lane, K - 1)];
+  const float ne = a.nent[row];
+  float p[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) p[k] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const float dv = tid + 256 * i < H ? dg[i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p[k] += dv * wg[i][k];
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float dv = tid + 256 * j < L2 ? dp[j] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p[k] += dv * wp[j][k];
+  }
+  SK_STAMP(8, 1);
+  const float dy = sk_block_sum16(p, rsh, tid);
+  SK_STAMP(8, 2);
+  if (wave == 0) {
+    const bool kv = lane < K;
+    const float lg = kv ? lg_ : -INFINITY;
+    const float yv = kv ? yv_ : 0.f;
+    const float m2 = wave_max(lg);
+    const float s2 = wave_sum(kv ? expf(lg - m2) : 0.f);
+    const float l2 = m2 + logf(s2);
+    const float dot = wave_sum(kv ? yv * dy : 0.f);
+    float dl = 0.f;
+    if (kv) {
+      const float lp = lg - l2;
+      dl = yv * (dy - dot) * a.invT + expf(lp) * (lp - ne);
+    }
+    if (lane < a.K4) st1o(a.dlogits + (long long)row * a.K4 + lane, dl);      // padding columns zero
+    if (lane < 16) dls[lane] = dl;
+  }
+  __syncthreads();
+  float dk[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) dk[k] = dls[k];      // (zero for k >= K)
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += dk[k] * wy[i][k];
+    if (tid + 256 * i < H) st1o(a.dhy + (long long)row * H + tid + 256 * i, hv[i] > 0.f ? v : 0.f);
+  }
+  SK_STAMP(8, 3);
+}
+
+// One [16 x 64] tile of dW = A^T dY (+ the bias gradient on the first tile row) and its TF-Adam update, by ONE wave, for
+// tensors whose row length N is a multiple of 4: the lane's B operand is a 16-byte load of four consecutive columns (four
+// strided column tiles) and its accumulators are dW[m0 + 4 lk + r][n0 + 4 ln .. + 3], so every access of the optimizer
+// -- p, m, v in, p, m, v and the gradient out -- is a 16-byte access and a lane group covers 256 contiguous bytes of a row.
+__device__ __forceinline__ void sk_dw_tile_v(const SkArgs& a, const SkTensor& T, const int tm, const int tn, const int ln, const int lk) {
+  const int B = a.B, M = T.M, N = T.N, lda = T.lda, ldy = T.ldy;
+  const int m0 = tm * 16, n0 = tn * 64;
+  const int n = n0 + 4 * ln;
+  const bool n_ok = n < N;
+  const int nc = min(n, N - 4), mc = min(m0 + ln, M - 1);
+  const bool upd = a.ap != nullptr;
+  float4 pp[4], pm[4], pv[4];
+  if (upd) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long i = (long long)T.w_off + (long long)min(m0 + 4 * lk + r, M - 1) * N + nc;
+      pp[r] = *reinterpret_cast<const float4*>(a.ap + i);
+      pm[r] = *reinterpret_cast<const float4*>(a.am + i);
+      pv[r] = *reinterpret_cast<const float4*>(a.av + i);
+    }
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned char* const A8 = static_cast<const unsigned char*>(T.A);
+  const float* const A32 = static_cast<const float*>(T.A);
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    float av[16];
+    float4 bv[16];
+    if (T.a_u8) {
+      unsigned char ab[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int b = min(b0 + 4 * s + lk, B - 1);
+        ab[s] = A8[(long long)b * lda + mc];
+        bv[s] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) av[s] = (float)ab[s];
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int b = min(b0 + 4 * s + lk, B - 1);
+        av[s] = A32[(long long)b * lda + mc];
+        bv[s] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const bool on = b0 + 4 * s + lk < B && n_ok;      // a zero B operand also voids clamped rows / columns
+      const float4 bq = on ? bv[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float aq = m0 + ln < M ? av[s] : 0.f;
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bq.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bq.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bq.z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bq.w, acc[3], 0, 0, 0);
+      cs.x += bq.x; cs.y += bq.y; cs.z += bq.z; cs.w += bq.w;
+    }
+  }
+  float lr_t = 0.f;
+  if (upd) {
+    const float tf = (float)((a.step_dev ? a.step_dev[1] : a.step) + 1ull);
+    lr_t = a.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1));
+  }
+  const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, gs = 1.f / (float)B;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + 4 * lk + r;
+    const float gq[4] = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    if (upd) {
+      adam_update(pp[r].x, pm[r].x, pv[r].x, gq[0], gs, lr_t, omb1, omb2, a.aeps);
+      adam_update(pp[r].y, pm[r].y, pv[r].y, gq[1], gs, lr_t, omb1, omb2, a.aeps);
+      adam_update(pp[r].z, pm[r].z, pv[r].z, gq[2], gs, lr_t, omb1, omb2, a.aeps);
+      adam_update(pp[r].w, pm[r].w, pv[r].w, gq[3], gs, lr_t, omb1, omb2, a.aeps);
+    }
+    if (m < M && n_ok) {
+      const long long i = (long long)T.w_off + (long long)m * N + n;
+      *reinterpret_cast<float4*>(a.grads + i) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+      if (upd) {
+        *reinterpret_cast<float4*>(a.ap + i) = pp[r];
+        *reinterpret_cast<float4*>(a.am + i) = pm[r];
+        *reinterpret_cast<float4*>(a.av + i) = pv[r];
+      }
+    }
+  }
+  if (tm == 0 && T.b_off >= 0) {                  // bias gradient: column sums of dY over the batch rows
+    cs.x += __shfl_xor(cs.x, 16, 64); cs.y += __shfl_xor(cs.y, 16, 64); cs.z += __shfl_xor(cs.z, 16, 64); cs.w += __shfl_xor(cs.w, 16, 64);
+    cs.x += __shfl_xor(cs.x, 32, 64); cs.y += __shfl_xor(cs.y, 32, 64); cs.z += __shfl_xor(cs.z, 32, 64); cs.w += __shfl_xor(cs.w, 32, 64);
+    if (lk == 0 && n_ok) {
+      const long long i = (long long)T.b_off + n;
+      *reinterpret_cast<float4*>(a.grads + i) = cs;
+      if (upd) {
+        float4 bp = *reinterpret_cast<const float4*>(a.ap + i), bm = *reinterpret_cast<const float4*>(a.am + i), bvv = *reinterpret_cast<const float4*>(a.av + i);
+        adam_update(bp.x, bm.x, bvv.x, cs.x, gs, lr_t, omb1, omb2, a.aeps);
+        adam_update(bp.y, bm.y, bvv.y, cs.y, gs, lr_t, omb1, omb2, a.aeps);
+        adam_update(bp.z, bm.z, bvv.z, cs.z, gs, lr_t, omb1, omb2, a.aeps);
+        adam_update(bp.w, bm.w, bvv.w, cs.w, gs, lr_t, omb1, omb2, a.aeps);
+        *reinterpret_cast<float4*>(a.ap + i) = bp; *reinterpret_cast<float4*>(a.am + i) = bm; *reinterpret_cast<float4*>(a.av + i) = bvv;
+      }
+    }
+  }
+}
+
+// W: every weight and bias gradient + TF-Adam (scripts/runners.py:181-183).  The contraction runs over the <= 128 batch
+// rows only, so a [64 x 16] tile of dW = A^T dY is ONE wave's work (16 MFMA steps of 4 rows per 64 rows, 4 strided 16-row
+// tiles as in dwadam.hpp) and a workgroup carries 8 tiles; nothing meets in LDS.  The optimizer runs on the accumulator
+// registers: per (tile, register) the 16 lanes of a lane group touch 64 contiguous bytes of p, m, v and the gradient.
+// Bound: the optimizer's traffic (7 x 4 P bytes: 37 MB at H = 512).  The last workgroup is the loss tail.
+__global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
+  __shared__ float red[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lk = lane >> 4;
+  const int B = a.B;
+  const int ntw = (a.total_tiles + kSkWaves - 1) / kSkWaves;
+  SK_STAMP(9, 0);
+  if ((int)blockIdx.x == ntw) {                   // ---- loss tail: per-row terms from the partials, batch sums, counters
+    const unsigned long long dbg_c0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int nlt = a.L / 16;
+    if (tid < 256) {
+      for (int b = tid; b < B; b += 256) {
+        float lpx = 0.f, lq = 0.f, lp = 0.f;
+        for (int i = 0; i < a.nparts; ++i) lpx += a.part[(long long)b * a.nparts + i];
+        for (int i = 0; i < nlt; ++i) { lq += a.lqp[(long long)i * B + b]; lp += a.lqp[(long long)(nlt + i) * B + b]; }
+        const float ne = a.nent[b];
+        const float lw = lpx + lp - lq - ne;
+        a.logpx[b] = lpx; a.logq[b] = lq; a.logp[b] = lp; a.logw[b] = lw;
+        a0 -= lw; a1 -= lpx; a2 += lq - lp; a3 += ne;
+      }
+      red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2; red[3][tid] = a3;
+    }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o)
+        for (int j = 0; j < 4; ++j) red[j][tid] += red[j][tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const unsigned long long dbg_c1 = __builtin_amdgcn_s_memtime(), dbg_r1 = __builtin_amdgcn_s_memrealtime();
+      const float tl[8] = {red[0][0], red[1][0], red[2][0], red[3][0], (float)B, 0.f, (float)(dbg_c1 - dbg_c0), (float)(dbg_r1 - dbg_r0)};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a.tail[j] = tl[j]; if (a.tail_log) a.tail_log[j] = tl[j]; }
+      if (a.step_dev) a.step_dev[0] = a.step_dev[1] + 1ull;
+    }
+    return;
+  }
+  const int tile = blockIdx.x * kSkWaves + wave;
+  if (tile >= a.total_tiles) return;
+  int ti = 0;
+#pragma unroll
+  for (int i = 1; i < kSkMaxT; ++i)
+    if (i < a.ntens && tile >= a.t[i].tile_begin) ti = i;
+  const SkTensor& T = a.t[ti];
+  const int M = T.M, N = T.N, lda = T.lda, ldy = T.ldy;
+  const int tl = tile - T.tile_begin, tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
+  if (T.vec) { sk_dw_tile_v(a, T, tm, tn, ln, lk); SK_STAMP(9, 3); return; }
+  const int m0 = tm * 64, n0 = tn * 16;
+  const int ma = m0 + 4 * ln;
+  const bool a_ok = ma < M, n_ok = n0 + ln < N;
+  const int mac = min(ma, ((M + 3) & ~3) - 4), nc = min(n0 + ln, N - 1);      // (source rows hold pad4(M) elements)
+  // the lane's 16 (p, m, v) triples are requested BEFORE the contraction's operands (they depend on nothing): the optimizer's
+  // 7 x 4 P bytes are the launch's bound, and behind the contraction they were a second, serial memory phase
+  const bool upd = a.ap != nullptr;
+  const int n = n0 + ln;
+  float pp[4][4], pm[4][4], pv[4][4];
+  if (upd) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = min(m0 + 4 * (4 * lk + r) + t, M - 1);
+        const long long i = (long long)T.w_off + (long long)m * N + min(n, N - 1);
+        pp[t][r] = a.ap[i]; pm[t][r] = a.am[i]; pv[t][r] = a.av[i];
+      }
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float cs = 0.f;
+  const unsigned char* const A8 = static_cast<const unsigned char*>(T.A);
+  const float* const A32 = static_cast<const float*>(T.A);
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    float4 av[16];
+    float bv[16];
+    if (T.a_u8) {                                  // (the operand type decides OUTSIDE the unrolled loads: a branch per load
+      unsigned aw[16];                             //  serialises them, one memory round trip each)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int b = min(b0 + 4 * s + lk, B - 1);
+        aw[s] = *reinterpret_cast<const unsigned*>(A8 + (long long)b * lda + mac);
+        bv[s] = T.dY[(long long)b * ldy + nc];
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        av[s] = make_float4((float)(aw[s] & 0xffu), (float)((aw[s] >> 8) & 0xffu), (float)((aw[s] >> 16) & 0xffu), (float)(aw[s] >> 24));
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int b = min(b0 + 4 * s + lk, B - 1);
+        av[s] = *reinterpret_cast<const float4*>(A32 + (long long)b * lda + mac);
+        bv[s] = T.dY[(long long)b * ldy + nc];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float bq = (b0 + 4 * s + lk < B && n_ok) ? bv[s] : 0.f;       // a zero B operand also voids clamped rows
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? av[s].x : 0.f, bq, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? av[s].y : 0.f, bq, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? av[s].z : 0.f, bq, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? av[s].w : 0.f, bq, acc[3], 0, 0, 0);
+      cs += bq;
+    }
+  }
+  SK_STAMP(9, 1);
+  // ---- TF-Adam (ApplyAdam form: kernels.hpp adam_update), then every store
+  float lr_t = 0.f;
+  if (upd) {                                      // 1 - b^t = -expm1(t ln b): no cancellation (dwadam.hpp)
+    const float tf = (float)((a.step_dev ? a.step_dev[1] : a.step) + 1ull);
+    lr_t = a.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1));
+  }
+  const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, gs = 1.f / (float)B;
+  if (upd) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) adam_update(pp[t][r], pm[t][r], pv[t][r], acc[t][r], gs, lr_t, omb1, omb2, a.aeps);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 4 * (4 * lk + r) + t;     // accumulator [t][r] of lane (ln, lk): strided tile t, tile row 4 lk + r
+      if (m < M && n_ok) {
+        const long long i = (long long)T.w_off + (long long)m * N + n;
+        a.grads[i] = acc[t][r];
+        if (upd) { a.ap[i] = pp[t][r]; a.am[i] = pm[t][r]; a.av[i] = pv[t][r]; }
+      }
+    }
+  if (tm == 0 && T.b_off >= 0) {                  // bias gradient: column sums of dY over the batch rows
+    cs += __shfl_xor(cs, 16, 64);
+    cs += __shfl_xor(cs, 32, 64);
+    if (lk == 0 && n_ok) {
+      const long long i = (long long)T.b_off + n;
+      a.grads[i] = cs;
+      if (upd) {
+        float pp = a.ap[i], pm = a.am[i], pv = a.av[i];
+        adam_update(pp, pm, pv, cs, gs, lr_t, omb1, omb2, a.aeps);
+        a.ap[i] = pp; a.am[i] = pm; a.av[i] = pv;
+      }
+    }
+  }
+  SK_STAMP(9, 3);
+}
+
+}  // namespace gmvae

@@ -276,6 +276,11 @@ int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, in
  * "logits","qp","pp","z","g","dqp","dpp","dlogits","dbuf0".."dbuf2","s1","s4", ...). */
 int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, uint64_t* byte_offset);
 
+/* Debugging aid: device wall-clock stamps of the skinny schedule's launches ([10 launches][256 blocks][8] uint64 at
+ * 100 MHz).  host_out == NULL arms it (allocates the buffer; steps enqueued or captured afterwards stamp into it);
+ * otherwise the buffer is copied to host_out.  tools/skstamps.py. */
+int gmvae_debug_sk_stamps(unsigned long long* host_out);
+
 /* Debugging aid: resident workgroups per CU the HIP runtime reports for a kernel of the library
  * (which: 0/1/2 = grouped GEMM small/medium/large configuration, 3 = mega_fwd_bwd, 4 = finalize_adam). */
 int gmvae_kernel_occupancy(int which, int* blocks_per_cu);

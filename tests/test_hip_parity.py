@@ -457,3 +457,41 @@ def test_cluster_acc_kernel(H):
     assert np.array_equal(scratch[K * 10:].cpu().numpy(), logits.argmax(1))
     assert acc.item() == pytest.approx(O.cluster_acc(logits, labels, K), abs=1e-6)
     assert acc.item() == pytest.approx(O.cluster_acc_from_hist(want_hist), abs=1e-6)
+
+
+SKINNY_CASES = [
+    ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,)), 64),                                   # bin/run_train.sh:3-14
+    ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,)), 50),                                   # ragged last row tile
+    ("gmvae", O.Dims(D=256, L=32, K=7, hidden=(128,), temperature=0.6), 100),                   # other widths, 7 row tiles
+    ("gmvae", O.Dims(D=400, L=16, K=16, hidden=(64,), sigma_min=0.8, raw_sigma_bias=0.25, gen_bias_init=-0.4), 9),  # clamp active
+    ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(192,)), 128),                                   # the largest batch it takes
+]
+
+
+@pytest.mark.parametrize("name,d,B", SKINNY_CASES, ids=[f"D{d.D}-L{d.L}-K{d.K}-H{d.hidden[0]}-B{B}" for _, d, B in SKINNY_CASES])
+def test_skinny_schedule_matches_oracle(H, monkeypatch, name, d, B):
+    """The small-batch / wide-layer schedule (csrc/skinny.hpp: 10 launches, register-direct tiles) against the oracle --
+    forced where the mega schedule would otherwise take the sizes (H = 64) -- and NOT bit-identical to the general
+    schedule (evidence that it ran); with external noise and with the in-kernel Philox draw."""
+    monkeypatch.setenv("GMVAE_NO_MEGA", "1")
+    monkeypatch.setenv("GMVAE_NO_FUSED", "1")
+    model = O.MODEL_NAMES[name]
+    rng = np.random.default_rng(B)
+    p = O.init_params(model, d, rng)
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    x, eps, u = O.make_inputs(d, B, model)
+    H.compare_step(model, d, p, x, eps, u)
+    flat = O.pack(model, d, p, np.float32)
+    g_sk, t_sk = H.hip_step(model, d, flat, x, eps, u)
+    monkeypatch.setenv("GMVAE_NO_SKINNY", "1")
+    g_gen, t_gen = H.hip_step(model, d, flat, x, eps, u)
+    lay, _, _ = O.param_layout(model, d)
+    same = True
+    for nm, shape, off in lay:                      # (the alignment padding between tensors is never written by this schedule)
+        n = int(np.prod(shape))
+        same = same and np.array_equal(g_sk[off:off + n], g_gen[off:off + n])
+        np.testing.assert_allclose(g_sk[off:off + n], g_gen[off:off + n], rtol=0, atol=2e-4 * np.abs(g_gen[off:off + n]).max(), err_msg=nm)
+    assert not same
+    np.testing.assert_allclose(t_sk[:5], t_gen[:5], rtol=2e-6)
