@@ -444,18 +444,19 @@ __global__ __launch_bounds__(256) void sk_ypath(const SkArgs a) {
     const bool kv = lane < K;
     const float lg = kv ? ptot + b1v : -INFINITY;
     const float uu = kv ? (a.gen_u ? ush[lane] : u_ext) : 0.5f;
-    const float av = kv ? (lg - logf(-logf(uu))) * a.invT : -INFINITY;
-    const float mx = wave_max(av), m2 = wave_max(lg);
-    const float se = wave_sum(kv ? expf(av - mx) : 0.f), s2 = wave_sum(kv ? expf(lg - m2) : 0.f);
-    const float lse = mx + logf(se), l2 = m2 + logf(s2);
+    // (hardware log / exp forms as mega2.hpp S2; lanes 0..15 hold the row: DPP row reductions)
+    const float av = kv ? (lg - flog(-flog(uu))) * a.invT : -INFINITY;
+    const float mx = row16_max(av), m2 = row16_max(lg);
+    const float se = row16_sum(kv ? fexp(av - mx) : 0.f), s2 = row16_sum(kv ? fexp(lg - m2) : 0.f);
+    const float lse = mx + flog(se), l2 = m2 + flog(s2);
     float yv = 0.f, ne = 0.f;
     if (kv) {
-      yv = expf(av - lse);
+      yv = fexp(av - lse);
       const float lp = lg - l2;
-      ne = expf(lp) * lp;
+      ne = fexp(lp) * lp;
       st1o(a.logits + (long long)row * K + lane, lg);
     }
-    ne = wave_sum(ne);
+    ne = row16_sum(ne);
     if (lane < a.K4) st1o(a.y + (long long)row * a.K4 + lane, yv);            // rows of pad4(K) floats, the padding zero
     if (lane == 0) st1o(a.nent + row, ne);
     if (lane < 16) ysh[lane] = yv;
@@ -537,14 +538,14 @@ __global__ __launch_bounds__(256) void sk_ybwd(const SkArgs a) {
     const bool kv = lane < K;
     const float lg = kv ? lg_ : -INFINITY;
     const float yv = kv ? yv_ : 0.f;
-    const float m2 = wave_max(lg);
-    const float s2 = wave_sum(kv ? expf(lg - m2) : 0.f);
-    const float l2 = m2 + logf(s2);
-    const float dot = wave_sum(kv ? yv * dy : 0.f);
+    const float m2 = row16_max(lg);
+    const float s2 = row16_sum(kv ? fexp(lg - m2) : 0.f);
+    const float l2 = m2 + flog(s2);
+    const float dot = row16_sum(kv ? yv * dy : 0.f);
     float dl = 0.f;
     if (kv) {
       const float lp = lg - l2;
-      dl = yv * (dy - dot) * a.invT + expf(lp) * (lp - ne);
+      dl = yv * (dy - dot) * a.invT + fexp(lp) * (lp - ne);
     }
     if (lane < a.K4) st1o(a.dlogits + (long long)row * a.K4 + lane, dl);      // padding columns zero
     if (lane < 16) dls[lane] = dl;
@@ -641,12 +642,10 @@ __device__ __forceinline__ void sk_dw_tile_v(const SkArgs& a, const SkTensor& T,
     }
     if (m < M && n_ok) {
       const long long i = (long long)T.w_off + (long long)m * N + n;
-      *reinterpret_cast<float4*>(a.grads + i) = make_float4(gq[0], gq[1], gq[2], gq[3]);
-      if (upd) {
-        *reinterpret_cast<float4*>(a.ap + i) = pp[r];
-        *reinterpret_cast<float4*>(a.am + i) = pm[r];
-        *reinterpret_cast<float4*>(a.av + i) = pv[r];
-      }
+      // write-through (mega2.hpp st4o): 5 x 4 P bytes of dirty lines would otherwise wait for the end-of-kernel write-back,
+      // in front of the next step's first launch
+      st4o(a.grads + i, make_float4(gq[0], gq[1], gq[2], gq[3]));
+      if (upd) { st4o(a.ap + i, pp[r]); st4o(a.am + i, pm[r]); st4o(a.av + i, pv[r]); }
     }
   }
   if (tm == 0 && T.b_off >= 0) {                  // bias gradient: column sums of dY over the batch rows
@@ -677,7 +676,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, lk = lane >> 4;
   const int B = a.B;
-  const int ntw = (a.total_tiles + kSkWaves - 1) / kSkWaves;
+  const int ntw = (int)gridDim.x - 1;             // tile workgroups; the last workgroup is the loss tail
   SK_STAMP(9, 0);
   if ((int)blockIdx.x == ntw) {                   // ---- loss tail: per-row terms from the partials, batch sums, counters
     const unsigned long long dbg_c0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
@@ -710,8 +709,10 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
     }
     return;
   }
-  const int tile = blockIdx.x * kSkWaves + wave;
-  if (tile >= a.total_tiles) return;
+  // a workgroup's 8 waves take 8 CONSECUTIVE tiles (one row of tiles of a tensor: they share the A rows and write
+  // neighbouring rows of p, m, v).  Measured alternatives, both slower: tiles dealt round-robin over 256 workgroups (no
+  // shared lines: 70 vs 60 us per step), consecutive tiles walking down a column of tiles (62)
+  for (int tile = blockIdx.x * kSkWaves + wave; tile < a.total_tiles; tile += ntw * kSkWaves) {
   int ti = 0;
 #pragma unroll
   for (int i = 1; i < kSkMaxT; ++i)
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
   const SkTensor& T = a.t[ti];
   const int M = T.M, N = T.N, lda = T.lda, ldy = T.ldy;
   const int tl = tile - T.tile_begin, tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
-  if (T.vec) { sk_dw_tile_v(a, T, tm, tn, ln, lk); SK_STAMP(9, 3); return; }
+  if (T.vec) { sk_dw_tile_v(a, T, tm, tn, ln, lk); continue; }
   const int m0 = tm * 64, n0 = tn * 16;
   const int ma = m0 + 4 * ln;
   const bool a_ok = ma < M, n_ok = n0 + ln < N;
@@ -814,6 +815,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
         a.ap[i] = pp; a.am[i] = pm; a.av[i] = pv;
       }
     }
+  }
   }
   SK_STAMP(9, 3);
 }
