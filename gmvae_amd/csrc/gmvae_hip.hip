@@ -1261,14 +1261,6 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
     T.tiles_n = T.vec ? (N + 63) / 64 : (N + 15) / 16; T.tile_begin = s.total_tiles;
     s.total_tiles += (T.vec ? (M + 15) / 16 : (M + 63) / 64) * T.tiles_n;
   };
-  add(a.x, true, D, s.dhy, H, D, H, E.w[0], (long long)E.b[0]);                                        // dWy0 (+ dby0)
-  add(a.x, true, D, s.dhg, H, D, H, G.w[0], (long long)G.b[0]);                                        // dWg0[x] (+ dbg0)
-  add(s.hd, false, H, s.g, D, H, D, Dn.w[1], (long long)Dn.b[1]);                                      // dWd1 (+ dbd1)
-  add(s.hg, false, H, s.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1]);                            // dWg1
-  add(s.z, false, Lz, s.dhd, H, Lz, H, Dn.w[0], (long long)Dn.b[0]);                                   // dWd0
-  add(s.y, false, s.K4, s.dhg, H, K, H, G.w[0] + (uint64_t)D * H, -1);                                 // dWg0[y]
-  add(s.hy, false, H, s.dlogits, s.K4, H, K, E.w[1], (long long)E.b[1]);                               // dWy1
-  add(s.y, false, s.K4, s.dpp, 2 * Lz, K, 2 * Lz, L.prior.w[0], (long long)L.prior.b[0]);              // dWp
   const int nrt = (B + 15) / 16;
   const double fB = 2.0 * B;
   s.dbg = g_sk_dbg;                                // diagnostic: tools/skstamps.py (null unless gmvae_debug_sk_stamps(NULL) ran)
@@ -1288,13 +1280,60 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   launch(sk_gemm<SK_F4>, (H / 64) * nrt, kSkThreads, 0, "sk_dec_hidden", fB * Lz * H);
   if (empty_mode == 1) launch(sk_gemm<SK_EMPTY>, (H / 64) * nrt, kSkThreads, 0, "sk_empty", 0.0);     // (diagnostic)
   launch(sk_gemm<SK_F5>, (D / 16) * nrt, kSkThreads, 0, "sk_dec_bernoulli", fB * H * D);
+  // The W launch can run in three parts: a weight's update may start once (a) its two operands are final and (b) every
+  // launch of this step that READS the weight is through -- the decoder's weights after B2, encoder_gmm's second layer after
+  // B3 -- on a side stream beside the rest of the backward pass (fork / join with events: parallel branches of the hipGraph),
+  // which takes 45 % of the optimizer's traffic off the critical path.  MEASURED AND OFF: on this stack a fork / join pair
+  // inside a graph costs far more than it hides (94.3 vs 60.8 us per step, A/B on one box); GMVAE_SK_FORK=1 enables it.
+  static hipStream_t side = nullptr;
+  static hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join = nullptr;
+  static const bool want_fork = getenv("GMVAE_SK_FORK") != nullptr;
+  bool fork = want_fork && !cx.prof;
+  if (fork && !side) {
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_fork[1], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
+      side = nullptr;
+      (void)hipGetLastError();
+    }
+  }
+  if (!side) fork = false;
+  auto launch_dw = [&](hipStream_t on, int part, bool tail) {     // part 0: decoder weights, 1: encoder_gmm layer 1, 2: the rest (+ everything not forked)
+    s.ntens = 0; s.total_tiles = 0; s.has_tail = tail ? 1 : 0;
+    if (part == 0 || (part == 2 && !fork)) {
+      add(s.hd, false, H, s.g, D, H, D, Dn.w[1], (long long)Dn.b[1]);                                    // dWd1 (+ dbd1)
+      add(s.z, false, Lz, s.dhd, H, Lz, H, Dn.w[0], (long long)Dn.b[0]);                                 // dWd0
+    }
+    if (part == 1 || (part == 2 && !fork)) add(s.hg, false, H, s.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1]);      // dWg1
+    if (part == 2) {
+      add(a.x, true, D, s.dhy, H, D, H, E.w[0], (long long)E.b[0]);                                      // dWy0 (+ dby0)
+      add(a.x, true, D, s.dhg, H, D, H, G.w[0], (long long)G.b[0]);                                      // dWg0[x] (+ dbg0)
+      add(s.y, false, s.K4, s.dhg, H, K, H, G.w[0] + (uint64_t)D * H, -1);                               // dWg0[y]
+      add(s.hy, false, H, s.dlogits, s.K4, H, K, E.w[1], (long long)E.b[1]);                             // dWy1
+      add(s.y, false, s.K4, s.dpp, 2 * Lz, K, 2 * Lz, L.prior.w[0], (long long)L.prior.b[0]);            // dWp
+    }
+    double fw = 0;
+    for (int i = 0; i < s.ntens; ++i) fw += 2.0 * s.t[i].M * s.t[i].N * B;
+    hipLaunchKernelGGL(sk_dw, dim3((s.total_tiles + kSkWaves - 1) / kSkWaves + (tail ? 1 : 0)), dim3(kSkThreads), 0, on, s);
+    cx.check();
+    cx.mark(part == 0 ? "sk_dw_decoder" : part == 1 ? "sk_dw_enc_gmm1" : (s.ap ? "sk_dw_adam" : "sk_dw"), fw);
+  };
   launch(sk_gemm<SK_B1>, (H / 16) * nrt, kSkThreads, 0, "sk_bwd_dhd", fB * D * H);
   launch(sk_gemm<SK_B2>, (Lz / 16) * nrt, kSkThreads, 0, "sk_bwd_dz_heads", fB * H * Lz);
+  if (fork) {
+    hipEventRecord(ev_fork[0], st);
+    hipStreamWaitEvent(side, ev_fork[0], 0);
+    launch_dw(side, 0, false);
+  }
   launch(sk_gemm<SK_B3>, (H / 32) * nrt, kSkThreads, 0, "sk_bwd_dhg", fB * 2 * Lz * H);
+  if (fork) {
+    hipEventRecord(ev_fork[1], st);
+    hipStreamWaitEvent(side, ev_fork[1], 0);
+    launch_dw(side, 1, false);
+    hipEventRecord(ev_join, side);
+  }
   launch(H <= 512 ? sk_ybwd<2> : sk_ybwd<4>, B, 256, 0, "sk_y_path_bwd", fB * ((double)(H + 2 * Lz) * K + K * H));
-  double fw = 0;
-  for (int i = 0; i < s.ntens; ++i) fw += 2.0 * s.t[i].M * s.t[i].N * B;
-  launch(sk_dw, (s.total_tiles + kSkWaves - 1) / kSkWaves + 1, kSkThreads, 0, s.ap ? "sk_dw_adam" : "sk_dw", fw);
+  if (fork) hipStreamWaitEvent(st, ev_join, 0);                  // join: the step ends when all three W parts have
+  launch_dw(st, 2, true);
   return cx.err;
 }
 

@@ -53,6 +53,7 @@ struct SkArgs {
   unsigned long long* step_dev;
   // W launch
   int ntens, total_tiles;
+  int has_tail;                // W launch: its last workgroup is the loss tail (the launch that ends the step)
   SkTensor t[kSkMaxT];
   float *grads, *ap, *am, *av; // ap != null: TF-Adam in the epilogue
   float lr, b1, b2, aeps, ln_b1, ln_b2;
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, lk = lane >> 4;
   const int B = a.B;
-  const int ntw = (int)gridDim.x - 1;             // tile workgroups; the last workgroup is the loss tail
+  const int ntw = (int)gridDim.x - (a.has_tail ? 1 : 0);      // tile workgroups; then the loss tail, if this launch carries it
   SK_STAMP(9, 0);
   if ((int)blockIdx.x == ntw) {                   // ---- loss tail: per-row terms from the partials, batch sums, counters
     const unsigned long long dbg_c0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();

@@ -192,9 +192,11 @@ def test_hip_step_sharded_sum_equals_full_batch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model,Lz,K,Bg,G", [("gmvae", 64, 10, 1024, 2), ("gmvae", 64, 10, 2048, 4), ("gmvae", 16, 10, 250, 2),
-                                            ("vae_gmp", 64, 10, 512, 2), ("gmvae", 6, 7, 96, 3)])
-def test_virtual_ranks_with_row_offsets_sum_to_the_full_batch_philox_step(model, Lz, K, Bg, G):
+@pytest.mark.parametrize("model,Lz,K,Bg,G,Hd", [("gmvae", 64, 10, 1024, 2, 64), ("gmvae", 64, 10, 2048, 4, 64), ("gmvae", 16, 10, 250, 2, 64),
+                                               ("vae_gmp", 64, 10, 512, 2, 64), ("gmvae", 6, 7, 96, 3, 64),
+                                               ("gmvae", 128, 10, 128, 2, 512),      # bin/run_train.sh sizes: the skinny schedule
+                                               ("gmvae", 32, 7, 100, 3, 128)])       # (ragged row tiles, three shards)
+def test_virtual_ranks_with_row_offsets_sum_to_the_full_batch_philox_step(model, Lz, K, Bg, G, Hd):
     """In-kernel Philox noise (eps = u = NULL) under data parallelism: G 'virtual ranks' on one GPU, each stepping
     its row shard with GmvaeDims.row0 = its first global row, leave gradient sums that add up to the single-device
     step on the whole batch with row0 = 0 -- same seed, same step, same eps/u rows."""
@@ -202,10 +204,15 @@ def test_virtual_ranks_with_row_offsets_sum_to_the_full_batch_philox_step(model,
     import hip_util as H
     from gmvae_amd import _lib as L
     mid = O.MODEL_NAMES[model]
-    d = O.Dims(D=784, L=Lz, K=K, hidden=(64,))
+    d = O.Dims(D=784, L=Lz, K=K, hidden=(Hd,))
     flat = O.pack(mid, d, O.init_params(mid, d, np.random.default_rng(1)), np.float32)
     x = (np.random.default_rng(2).random((Bg, 784)) < 0.87).astype(np.uint8)
     params = H.dev(flat, torch.float32)
+    lay, _, _ = O.param_layout(mid, d)
+    real = np.zeros(flat.size + L.TAIL, bool)                  # (the alignment padding between tensors is not part of the contract)
+    for _, shape, off in lay:
+        real[off:off + int(np.prod(shape))] = True
+    real[flat.size:] = True
 
     def run(xs, row0):
         cd = H.dims_of(d, xs.shape[0])
@@ -217,7 +224,9 @@ def test_virtual_ranks_with_row_offsets_sum_to_the_full_batch_philox_step(model,
         L.check(L.lib.gmvae_step(C.byref(cd), mid, L.ptr(xd), None, None, L.ptr(params), L.ptr(grads), L.ptr(ws), 99, 4, None,
                                  L.current_stream()), "gmvae_step")
         torch.cuda.synchronize()
-        return grads.cpu().numpy().astype(np.float64)
+        g = grads.cpu().numpy().astype(np.float64)
+        assert np.isfinite(g[real]).all()
+        return np.where(real, g, 0.0)
 
     full = run(x, 0)
     acc = 0.0
