@@ -135,7 +135,7 @@ struct WS {
   unsigned long long* stamps;   // diagnostic stamps of the chain kernels: [2][grid][16]
   unsigned long long* xchg;     // mega_fwd_bwd's in-launch hand-off granules: [panels][Q-1][16*H + 16]
   unsigned long long* xfl;      // mega_fwd_bwd's first-layer exchange granules: [panels][4][16 * H2]
-  unsigned long long* spans;    // measurement: [2 slots][2 kernels][2048 blocks][2] wall-clock stamps (mega_fwd_bwd, finalize_adam / dw_adam)
+  unsigned long long* spans;    // measurement: [2 slots][3 kernels][2048 blocks][2] wall-clock stamps (mega_fwd_bwd, finalize_adam / dw_adam, fl_split)
   unsigned long long* gstamps;  // diagnostic stamps of the grouped-GEMM launches: [4 slots][2048 blocks][8]
   unsigned* sync;               // [0] = per-step epoch of the hand-off, [1] = hand-off timeout flag
   float *img_f, *img_b;         // per-step LDS weight images of chain_fwd / chain_bwd (prepared by aux blocks)
@@ -292,7 +292,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     if (ml.fl_ok)
       w.xfl = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * 4 * kPanel * 2 * d.hidden[0]));
     w.gstamps = reinterpret_cast<unsigned long long*>(take(2ull * 4 * 2048 * 8));
-    w.spans = reinterpret_cast<unsigned long long*>(take(2ull * 2 * 2 * 2048 * 2));
+    w.spans = reinterpret_cast<unsigned long long*>(take(2ull * 2 * 3 * 2048 * 2));
     if (model == GMVAE_MODEL_GMVAE && d.hidden[0] == M2::H && d.L == M2::L && d.K == M2::K && d.D == M2::D && d.B <= 1024) {
       w.img2f = take(M2::imgF);                  // (not gated by GMVAE_NO_MEGA2: the workspace layout must not depend on a switch)
       w.img2b = take(M2::imgB);
@@ -741,7 +741,7 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
       const int KLp = (int)pad4((uint64_t)d.K * d.L);
       fa.gmp_part = w.gmp_part; fa.gmp_n = (B + kPanel - 1) / kPanel; fa.gmp_len = 2 * KLp + (int)pad4(d.K); fa.gmp_off = (long long)L.loc;
     }
-    fa.span = (a.want_spans && w.spans) ? w.spans + (size_t)a.span_slot * 2 * 2048 * 2 + 2048 * 2 : nullptr;
+    fa.span = (a.want_spans && w.spans) ? w.spans + (size_t)a.span_slot * 3 * 2048 * 2 + 2048 * 2 : nullptr;
     if (mega_ok(d, a.model) && a.adam_p && a.adam_p == a.params) {      // the next step's weight images ride on the update
       const MegaLay ml = mega_lay(d.hidden[0], d.L, d.K, d.D, a.model);
       ImgPlan pl;
@@ -866,7 +866,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     ax.nblocks = ax.noise_blocks + nt;
     launch_group(cx, g, "fwd_x_first_layers_splitk+aux", env_cfg("GMVAE_P1_CFG", 0), getenv("GMVAE_STAMPS") ? w.gstamps : nullptr);
   }
-  bool m2_ran = false;
+  bool m2_ran = false, fl_slab = false;
   {  // the whole per-row forward + backward in one launch
     MegaArgs c;
     memset(&c, 0, sizeof(c));
@@ -884,7 +884,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     c.step_dev = reinterpret_cast<unsigned long long*>(a.step_dev);
     c.Q = Qm; c.xchg = w.xchg; c.epoch_word = w.sync; c.err_word = w.sync + 1;
     c.dbg = getenv("GMVAE_STAMPS") ? w.stamps : nullptr;
-    c.span = a.want_spans ? w.spans + (size_t)a.span_slot * 2 * 2048 * 2 : nullptr;
+    c.span = a.want_spans ? w.spans + (size_t)a.span_slot * 3 * 2048 * 2 : nullptr;
     c.fine = getenv("GMVAE_STAMPS") ? atoi(getenv("GMVAE_STAMPS")) : 0;
     // the reference's default sizes (run_gmvae.py: latent 64, hidden 64, K 10; MNIST D 784) run a specialised instance
     typedef void (*MegaFn)(const MegaArgs);
@@ -904,23 +904,39 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     }
     const bool m2 = fl && mega2_ok(d, model) && w.img2f;
     m2_ran = m2;
+    // round 3, measured and OFF (GMVAE_FLSPLIT=1 enables it): the first layer as a launch of its own in front of
+    // mega2_fwd_bwd (skinny.hpp fl_split).  A/B on one box: 37.8 vs 36.5 us per step -- fl_split 4.3 us span + a 1.6 us
+    // boundary, mega2_fwd_bwd only 4.5 us shorter (22.2 -> 17.7): its forward operand image (66 KB of LDS-DMA per
+    // workgroup), hidden behind the exchange wait before, is then on the launch's critical path.
+    fl_slab = m2 && NSF == 4 && H2 % 32 == 0 && D % 16 == 0 && getenv("GMVAE_FLSPLIT") != nullptr;
     if (m2) {
       c.img2f = w.img2f; c.img2b = w.img2b; c.dimg2 = w.dimg2;
       c.lr = a.lr; c.b1 = a.beta1; c.b2 = a.beta2;
       c.lr_t_out = (a.adam_p && a.adam_p == a.params && a.step_dev) ? reinterpret_cast<float*>(w.sync + 2) : nullptr;
       static bool m2attr = false;
       if (!m2attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(mega2_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(mega2_fwd_bwd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(mega2_fwd_bwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         m2attr = true;
       }
-      hipLaunchKernelGGL(mega2_fwd_bwd, dim3((B + kPanel - 1) / kPanel * 4), dim3(kMT), (size_t)M2::total * sizeof(float), st, c);
+      if (fl_slab) {
+        FlSplitArgs fa;
+        fa.x = a.x; fa.w0a = c.w0a; fa.w0b = c.w0b; fa.s1 = w.s1; fa.B = B; fa.D = D; fa.H = H; fa.ns = NSF;
+        fa.span = a.want_spans ? w.spans + (size_t)a.span_slot * 3 * 2048 * 2 + 2 * 2048 * 2 : nullptr;
+        hipLaunchKernelGGL(fl_split, dim3((H2 / 32) * ((B + 63) / 64) * NSF), dim3(kSkThreads), 0, st, fa);
+        cx.check();
+        cx.mark("fl_split", 2.0 * B * (double)D * H2);
+        hipLaunchKernelGGL(mega2_fwd_bwd<1>, dim3((B + kPanel - 1) / kPanel * 4), dim3(kMT), (size_t)M2::total * sizeof(float), st, c);
+      } else {
+        hipLaunchKernelGGL(mega2_fwd_bwd<0>, dim3((B + kPanel - 1) / kPanel * 4), dim3(kMT), (size_t)M2::total * sizeof(float), st, c);
+      }
     } else {
       hipLaunchKernelGGL(fn, dim3((B + kPanel - 1) / kPanel * c.Q), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
     }
     cx.check();
     // algorithmic MFMA FLOPs of the launch: forward chain + decoder layer (lambda and its data gradient) + backward chain
     double macs = (double)H * 2 * Lz + (double)Lz * H + 2.0 * H * D + (double)H * Lz + 2.0 * Lz * H;
-    if (fl) macs += (double)D * H2;                    // the first layer rides in the launch
+    if (fl && !fl_slab) macs += (double)D * H2;        // the first layer rides in the launch
     if (gm) macs += (double)H * K + (double)K * H + (double)K * 2 * Lz + (double)(H + 2 * Lz) * K + (double)K * H;
     if (m2) { cx.mark("mega2_fwd_bwd", 2.0 * B * macs); goto mega_done; }
     cx.mark("mega_fwd_bwd", 2.0 * B * macs);
@@ -1022,7 +1038,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       fa.epoch_word = dw_upd ? w.sync : nullptr;   // (data parallel: adam_tf_img, after the all-reduce, bumps the hand-off tag)
       fa.err_word = w.sync + 1;
       fa.img[0] = w.img_m; fa.img[1] = w.dimg; fa.img[2] = w.img2f; fa.img[3] = w.img2b; fa.img[4] = w.dimg2;
-      fa.span = (a.want_spans && w.spans) ? w.spans + (size_t)a.span_slot * 2 * 2048 * 2 + 2048 * 2 : nullptr;
+      fa.span = (a.want_spans && w.spans) ? w.spans + (size_t)a.span_slot * 3 * 2048 * 2 + 2048 * 2 : nullptr;
       if (a.next_x && a.next_pix && a.next_idx && dw_upd) {
         fa.bin_pix = a.next_pix; fa.bin_idx = a.next_idx; fa.bin_x = a.next_x; fa.bin_rows_src = a.next_rows_src;
         fa.bin_B = B; fa.bin_D = D; fa.bin_seed = a.bin_seed; fa.bin_row0 = d.row0;
@@ -1947,7 +1963,7 @@ int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, floa
     (void)hipGetLastError();
   }
   if (!graphed) rc = 0;
-  const size_t nsp = 2 * 2 * 2048 * 2, ngs = 2048 * 8, slot = 2 * 2048 * 2;
+  const size_t nsp = 2 * 3 * 2048 * 2, ngs = 2048 * 8, slot = 3 * 2048 * 2;
   unsigned long long* hsp = new unsigned long long[nsp + ngs];
   for (int it = 0; it < iters && rc == 0; ++it) {
     hipMemsetAsync(w.spans, 0, nsp * 8, st);
@@ -1975,11 +1991,13 @@ int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, floa
       if (!strncmp(pr->name[i], "mega", 4)) first_last(hsp, 2, 1, lo, hi);
       else if (!strncmp(pr->name[i], "bwd_dw_all", 10)) first_last(hsp + nsp, 8, 4, lo, hi);
       else if (!strncmp(pr->name[i], "finalize_adam", 13) || !strncmp(pr->name[i], "dw_adam", 7)) first_last(hsp + 2048 * 2, 2, 1, lo, hi);
+      else if (!strncmp(pr->name[i], "fl_split", 8)) first_last(hsp + 2 * 2048 * 2, 2, 1, lo, hi);
       if (hi > lo) { acc[i] += (double)(hi - lo) * 0.01; start[i] = lo; }       // 100 MHz ticks -> microseconds
     }
     {  // the next step's first stamped launch closes the last launch's share (steady state: the same launch sequence)
       unsigned long long lo = ~0ull, hi = 0;
       if (pr->n > 0 && !strncmp(pr->name[0], "mega", 4)) first_last(hsp + slot, 2, 1, lo, hi);
+      else if (pr->n > 0 && !strncmp(pr->name[0], "fl_split", 8)) first_last(hsp + slot + 2 * 2048 * 2, 2, 1, lo, hi);
       start[pr->n] = hi > lo ? lo : 0;
     }
     for (int i = 0; i < pr->n; ++i)

@@ -281,3 +281,11 @@ def test_config5_shard_full_size_properties():
         n = int(np.prod(shape))
         ref = g[name].ravel()
         assert np.abs(small[off:off + n] / 8 - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6), name
+
+
+def test_first_layer_as_its_own_launch_matches_oracle(monkeypatch):
+    """GMVAE_FLSPLIT=1: the first layer as a launch of its own (csrc/skinny.hpp fl_split) feeding mega2_fwd_bwd<SLAB> from four
+    slabs -- measured slower than the in-launch form and off by default, kept correct: same trajectory gates."""
+    monkeypatch.setenv("GMVAE_FLSPLIT", "1")
+    trajectory_case("gmvae", 784, 64, 10, (64,), 1024, 4)
+    trajectory_case("gmvae", 784, 64, 10, (64,), 1000, 3)

@@ -1,4 +1,4 @@
-for i in 1 2; do
- GMVAE_SK_NO_FORK=1 python tools/step_time.py run_train 1.0 2>&1 | tail -1 | cut -c1-60
- python tools/step_time.py run_train 1.0 2>&1 | tail -1 | cut -c1-60
+for i in 1 2 3; do
+ GMVAE_NO_FLSPLIT=1 python tools/step_time.py configs2 1.0 2>&1 | tail -1 | cut -c1-200
+ python tools/step_time.py configs2 1.0 2>&1 | tail -1 | cut -c1-260
 done
