@@ -370,22 +370,40 @@ def main():
         # step -- and (b) the in-kernel span (last workgroup end - first workgroup start).  `achieved` / `frac` use (a),
         # so that the committed rocprofv3 average of the same kernel (profiles/) must agree with it.  Other schedules /
         # N > 1: hipEvents around eager launches.
-        try:
-            levels = eng.profile_train_levels(x, lr=1e-3, iters=30) if world == 1 else eng.profile_levels(x, iters=30)
-        except Exception:
+        levels = None
+        if world == 1:
+            try:
+                levels = eng.profile_train_levels(x, lr=1e-3, iters=30)
+            except Exception:
+                levels = None
+            if levels is None:                           # the skinny schedule stamps the device clock in its own buffer
+                try:
+                    sk = eng.profile_skinny_levels(x)
+                except Exception:
+                    sk = None
+                if sk:
+                    fl = {n: f for n, _, f in eng.profile_levels(x, iters=2)}
+                    fl["sk_dw_adam"] = fl.get("sk_dw", 0.0)
+                    known = sum(l[3] for l in sk[:-1])
+                    levels = [(n, sp, fl.get(n, 0.0), sh if sh is not None else max(t_step_us - known, sp)) for n, sp, _, sh in sk]
+        if levels is None:
             levels = eng.profile_levels(x, iters=30)
         levels = [tuple(l) + ((0.0,) if len(l) == 3 else ()) for l in levels]      # (name, span us, flops, timeline us)
         have_tl = all(l[3] > 0 for l in levels)
         dur = (lambda l: l[3]) if have_tl else (lambda l: l[1])
         gemms = [l for l in levels if l[2] > 0]          # launches that do MFMA work (grouped GEMMs, mega kernel)
         dom = max(gemms, key=dur)
+        SK_KERNELS = {"sk_first_layers": "void gmvae::sk_gemm<0>", "sk_q_head_z": "void gmvae::sk_gemm<1>", "sk_dec_hidden": "void gmvae::sk_gemm<2>",
+                      "sk_dec_bernoulli": "void gmvae::sk_gemm<3>", "sk_bwd_dhd": "void gmvae::sk_gemm<4>", "sk_bwd_dz_heads": "void gmvae::sk_gemm<5>",
+                      "sk_bwd_dhg": "void gmvae::sk_gemm<6>", "sk_y_path": "void gmvae::sk_ypath<", "sk_y_path_bwd": "void gmvae::sk_ybwd<",
+                      "sk_dw_adam": "gmvae::sk_dw", "sk_dw": "gmvae::sk_dw"}
         step_flops = flops_per_step(a.model, d.D, d.L, d.K, hidden, d.S, B)
         # Bytes_alg(step) = B D (uint8 batch) + 9 * 4 P (read params; write grads; Adam reads p, m, v, g and
         # writes p, m, v); noise is generated in-kernel
         step_bytes = float(B * d.D + 36 * eng.P_real)
         t_mfma_us = step_flops / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6
         t_hbm_us = step_bytes / (PEAK_HBM_GBS * 1e9) * 1e6
-        roof = {"bound": "mfma", "kernel": dom[0] if dom[0].startswith("mega") else f"gemm_grouped<{dom[0]}>",
+        roof = {"bound": "mfma", "kernel": dom[0] if dom[0].startswith(("mega", "sk_", "dw_", "fl_")) else f"gemm_grouped<{dom[0]}>",
                 "achieved": dom[2] / dur(dom) * 1e-6, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": dom[2] / dur(dom) * 1e-6 / PEAK_F32_MFMA_TFLOPS,
                 "traffic": None, "usec_per_launch": dur(dom), "flops_per_launch": dom[2],
@@ -407,6 +425,13 @@ def main():
                 "launches_per_step": len(levels), "sum_launch_usec": sum(dur(l) for l in levels),
                 "levels": [[nm, round(us, 2), round(tl, 2)] for nm, us, _, tl in levels],
                 "levels_columns": ["launch", "usec_in_kernel_span", "usec_timeline_share"]}
+        if dom[0].startswith("sk_dw"):
+            # the skinny schedule's longest launch is the weight-gradient + TF-Adam launch: bound by HBM, not by the matrix
+            # pipes -- algorithmic bytes = 7 x 4 P (p, m, v in; p, m, v and the gradient out), SURVEY.md 8(d)'s optimizer term
+            w_bytes = 28.0 * eng.P_real
+            roof.update({"bound": "hbm", "achieved": w_bytes / dur(dom) * 1e-3, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": w_bytes / dur(dom) * 1e-3 / PEAK_HBM_GBS, "bytes_per_launch": w_bytes,
+                         "frac_in_kernel_span": w_bytes / dom[1] * 1e-3 / PEAK_HBM_GBS})
         # Committed evidence of the same command (tools/profile_round.sh -> profiles/roundN_*): rocprofv3 --kernel-trace
         # --stats average per kernel, and HBM-side bytes per launch from separate --pmc passes (FETCH_SIZE x2 on gfx950 +
         # WRITE_SIZE; rocprofv3 --pmc cannot run inside this process).  Keyed by workload; the newest round present wins.
@@ -422,19 +447,20 @@ def main():
                 for r in csv.DictReader(open(stats[-1])):
                     kern_us[r["Name"]] = float(r["AverageNs"]) * 1e-3
                 roof["rocprof_source"] = os.path.relpath(stats[-1], ROOT) + " (rocprofv3 --kernel-trace --stats of this command; a profiled run is slower than the timed one)"
-            kname = ("gmvae::" + dom[0]) if dom[0].startswith(("mega", "dw_")) else None
-            hit = [k for k in kern_us if kname and k.startswith(kname + "(")]
+            kname = ("gmvae::" + dom[0]) if dom[0].startswith(("mega", "dw_")) else SK_KERNELS.get(dom[0])
+            hit = [k for k in kern_us if kname and k.startswith(kname + ("(" if not kname.endswith("<") else ""))]
             if hit:
                 roof["rocprof_usec_per_launch"] = kern_us[hit[0]]
-                roof["frac_rocprof"] = dom[2] / kern_us[hit[0]] * 1e-6 / PEAK_F32_MFMA_TFLOPS
+                roof["frac_rocprof"] = (roof["bytes_per_launch"] / kern_us[hit[0]] * 1e-3 / PEAK_HBM_GBS if roof["bound"] == "hbm"
+                                        else dom[2] / kern_us[hit[0]] * 1e-6 / PEAK_F32_MFMA_TFLOPS)
             traf = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_traffic{'' if tag == 'bench' else '_' + str(tag)}.json"))) if tag else []
             if traf:
                 tj = json.load(open(traf[-1]))
                 roof["traffic_source"] = os.path.relpath(traf[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, separate passes)"
                 per = {}
                 for nm, _, _, _ in levels:
-                    kn = "gmvae::" + nm
-                    k2 = [k for k in tj if k.startswith(kn + "(") or k.startswith(kn + " ")]
+                    kn = SK_KERNELS.get(nm, "gmvae::" + nm)
+                    k2 = [k for k in tj if k.startswith(kn + "(") or k.startswith(kn + " ") or (kn.endswith("<") and k.startswith(kn))]
                     if k2:
                         per[nm] = tj[k2[0]]["hbm_bytes_per_launch"]
                 if dom[0] in per:

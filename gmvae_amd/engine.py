@@ -589,3 +589,40 @@ class Engine:
             nm = names.raw[i * 48:(i + 1) * 48].split(b"\0")[0].decode()
             out.append((nm, float(usec[i]), float(flops[i])))
         return out
+
+    def profile_skinny_levels(self, x, lr: float = 1e-3, n_steps: int = 8, launches: int = 60):
+        """Per-launch durations of the skinny schedule (csrc/skinny.hpp) inside a replayed train graph, from the device
+        wall-clock stamps its kernels leave (gmvae_debug_sk_stamps): [(name, in-kernel span us, None, timeline share us)],
+        the share running from the launch's first workgroup start to the next launch's (the last launch: to the next step's
+        first).  Returns None when the configuration does not take that schedule.  Advances training by the replayed steps."""
+        import numpy as np
+        if L.lib.gmvae_debug_sk_stamps(None) != 0:
+            return None
+        x = self._prep_x(x)
+        B = x.shape[0]
+        self.drop_graphs(clear_handoff_errors=False)              # graphs captured before the buffer existed do not stamp
+        sx, replay = self.capture_train_step(B, lr=lr, n_steps=n_steps)
+        sx.copy_(x.unsqueeze(0).expand(n_steps, -1, -1) if n_steps > 1 else x)
+        for _ in range(launches):
+            replay()
+        torch.cuda.synchronize()
+        buf = np.zeros(10 * 256 * 8, np.uint64)
+        L.check(L.lib.gmvae_debug_sk_stamps(buf.ctypes.data_as(C.c_void_p)), "gmvae_debug_sk_stamps")
+        st = buf.reshape(10, 256, 8).astype(np.float64)
+        names = ["sk_first_layers", "sk_y_path", "sk_q_head_z", "sk_dec_hidden", "sk_dec_bernoulli", "sk_bwd_dhd", "sk_bwd_dz_heads",
+                 "sk_bwd_dhg", "sk_y_path_bwd", "sk_dw_adam"]
+        starts, ends = [], []
+        for i in range(10):
+            r = st[i][st[i][:, 0] > 0]
+            if not len(r):
+                return None
+            starts.append(r[:, 0].min())
+            ends.append(r[:, 3].max())
+        if not all(starts[i + 1] > starts[i] for i in range(9)):
+            return None                                            # (stamps of different steps: a launch was mid-flight)
+        step_us = None
+        out = []
+        for i in range(10):
+            share = (starts[i + 1] - starts[i]) * 0.01 if i < 9 else None
+            out.append([names[i], (ends[i] - starts[i]) * 0.01, None, share])
+        return out

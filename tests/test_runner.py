@@ -181,3 +181,24 @@ def test_run_train_degrades_to_the_safe_schedule_instead_of_dying(tmp_path, monk
         import os
         os.environ.pop("GMVAE_NO_FL", None)
         os.environ.pop("GMVAE_MEGA_Q", None)
+
+
+@pytest.mark.gpu
+def test_run_train_at_the_reference_shipped_sizes(tmp_path):
+    """bin/run_train.sh:3-14 (latent 128, hidden 512, batch 64): the loop runs pipeline graphs of the skinny schedule
+    (csrc/skinny.hpp) and equals the eager loop on the same batches."""
+    import torch
+    from gmvae_amd import runners
+    outs = []
+    for eager in (False, True):
+        args = ["--mode=train", "--model=gmvae", "--latent_size=128", "--hidden_size=512", "--batch_size=64", "--max_steps=29",
+                "--summarise_every=10", f"--logdir={tmp_path}/{eager}", "--random_seed=4", "--synthetic_size=2048"]
+        m = run_gmvae.main(args + (["--eager"] if eager else []))
+        assert runners.run_train.last_path == ("eager" if eager else "pipeline-graph") and m._engine.global_step == 30
+        outs.append((m._engine.params.detach().clone(), (m._engine.grads[m._engine.P] / m._engine.grads[m._engine.P + 4]).item()))
+    assert torch.isfinite(outs[0][0]).all() and 0 < outs[0][1] < 560
+    # same launches up to the optimizer: the graph's W launch applies TF-Adam itself (alpha_t from expm1f), the eager loop
+    # calls adam_tf_step (alpha_t from fp64 pow): ~3e-7 relative on the step size, 30 steps
+    diff = (outs[0][0] - outs[1][0]).abs()
+    assert diff.mean().item() < 1e-6 and diff.max().item() < 30 * 1e-3 * 0.05
+    assert abs(outs[0][1] - outs[1][1]) < 2e-5 * abs(outs[1][1])
