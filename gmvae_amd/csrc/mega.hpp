@@ -103,6 +103,22 @@ __device__ __forceinline__ float dpp_mov(const float v) {
   const int i = __builtin_bit_cast(int, v);
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false));
 }
+// A launch OUTPUT in global memory (nothing in this launch reads it back; the next launch does, from other CUs): stored
+// WRITE-THROUGH (sc1), so the bytes leave for memory while the launch is still running instead of waiting dirty in the
+// XCD's L2 for the end-of-kernel write-back that the next launch's start sits behind.  (Inline asm: uncounted by the
+// compiler's vmcnt bookkeeping, which only makes its own waits stricter -- retirement is in order; `s_nop 1`: the data
+// registers may be rewritten right after, cdna_hip_programming.md 5.7 item 1.)
+#ifndef M2_WT
+#define M2_WT 1
+#endif
+__device__ __forceinline__ void st4o(float* p, const float4 v) {
+#if M2_WT
+  const f32x4 t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
 __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
   return v;
@@ -820,7 +836,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       if (row < nrow && c0 + c4 < D) {
         const float4 gv = make_float4(A_g[(c4 + 0) * kLDA + row], A_g[(c4 + 1) * kLDA + row], A_g[(c4 + 2) * kLDA + row],
                                       A_g[(c4 + 3) * kLDA + row]);
-        *reinterpret_cast<float4*>(a.g + (long long)(r0 + row) * D + c0 + c4) = gv;
+        st4o(a.g + (long long)(r0 + row) * D + c0 + c4, gv);             // write-through: read by the NEXT launch only
       }
     }
     // dhd1 += g_chunk * Wd1_chunk^T   (B(k = column, n = h) = Wc[h*ldc + column]); each tile's K split over 2 waves

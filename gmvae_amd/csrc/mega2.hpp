@@ -115,22 +115,7 @@ __device__ __forceinline__ void granule_publish(unsigned long long* p, const uns
 __device__ __forceinline__ float4 f4(const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
-// A launch OUTPUT in global memory (nothing in this launch reads it back; the next launch does, from other CUs): stored
-// WRITE-THROUGH (sc1), so the bytes leave for memory while the launch is still running instead of waiting dirty in the
-// XCD's L2 for the end-of-kernel write-back that the next launch's start sits behind.  (Inline asm: uncounted by the
-// compiler's vmcnt bookkeeping, which only makes its own waits stricter -- retirement is in order; `s_nop 1`: the data
-// registers may be rewritten right after, cdna_hip_programming.md 5.7 item 1.)
-#ifndef M2_WT
-#define M2_WT 1
-#endif
-__device__ __forceinline__ void st4o(float* p, const float4 v) {
-#if M2_WT
-  const f32x4 t = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
-#else
-  st4(p, v);
-#endif
-}
+// (st4o -- a launch output as a 16-byte write-through store -- lives in mega.hpp)
 
 // SLAB = 1 (round 3): the first layer ran as a launch of its own (skinny.hpp fl_split) and left NS slabs of the
 // pre-activations; the panel's workgroups sum their rows in slab order (identical bits in all four) instead of pulling a
