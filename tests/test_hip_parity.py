@@ -464,7 +464,9 @@ SKINNY_CASES = [
     ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,)), 50),                                   # ragged last row tile
     ("gmvae", O.Dims(D=256, L=32, K=7, hidden=(128,), temperature=0.6), 100),                   # other widths, 7 row tiles
     ("gmvae", O.Dims(D=400, L=16, K=16, hidden=(64,), sigma_min=0.8, raw_sigma_bias=0.25, gen_bias_init=-0.4), 9),  # clamp active
-    ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(192,)), 128),                                   # the largest batch it takes
+    ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(192,)), 128),
+    ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(256,)), 600),                                  # 38 row tiles, ragged; 10 row chunks in W
+    ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,)), 1024),                                 # the largest batch it takes by default
 ]
 
 
