@@ -202,3 +202,36 @@ def test_run_train_at_the_reference_shipped_sizes(tmp_path):
     diff = (outs[0][0] - outs[1][0]).abs()
     assert diff.mean().item() < 1e-6 and diff.max().item() < 30 * 1e-3 * 0.05
     assert abs(outs[0][1] - outs[1][1]) < 2e-5 * abs(outs[1][1])
+
+
+FLAG_SWEEP = [   # model, latent, hidden, layers, batch: the schedules a reference user's flag choices land on
+    ("gmvae", 8, 64, 1, 16),        # scripts/run_gmvae.py defaults: mega schedule, one ragged panel
+    ("gmvae", 8, 128, 1, 32),       # latent 8 with a wider layer: general schedule
+    ("gmvae", 32, 256, 1, 48),      # skinny schedule, ragged row tiles
+    ("gmvae", 16, 64, 2, 40),       # two hidden layers: general schedule
+    ("vae", 2, 64, 1, 100),         # BASELINE configs[0]
+    ("vae", 16, 256, 2, 24),
+    ("vae_gmp", 64, 64, 1, 256),    # BASELINE configs[1]
+    ("vae_gmp", 24, 128, 1, 30),    # general schedule with the learned mixture prior
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,latent,hidden,layers,batch", FLAG_SWEEP, ids=[f"{m}-z{l}-h{h}x{n}-b{b}" for m, l, h, n, b in FLAG_SWEEP])
+def test_train_then_eval_over_the_flag_space(tmp_path, model, latent, hidden, layers, batch):
+    """`run_gmvae --mode=train` then `--mode=eval` for flag combinations that land on every schedule (mega, skinny, chain,
+    general; one and two hidden layers; all three models): the loss falls from its start, the checkpoint round-trips, the
+    evaluation's per-example loss is finite and below the untrained value."""
+    import math
+    args = [f"--model={model}", f"--latent_size={latent}", f"--hidden_size={hidden}", f"--num_layers={layers}",
+            f"--batch_size={batch}", "--max_steps=59", "--summarise_every=20", f"--logdir={tmp_path}", "--random_seed=5",
+            "--synthetic_size=1024", "--mixture_components=10"]
+    m = run_gmvae.main(["--mode=train"] + args)
+    e = m._engine
+    assert e.global_step == 60 and e.handoff_timeouts() == 0
+    last = (e.grads[e.P] / e.grads[e.P + 4]).item()
+    start = 784 * math.log(2.0)                      # ~ the untrained loss (GMVAE: minus ln K)
+    assert math.isfinite(last) and last < 0.9 * start
+    res = run_gmvae.main(["--mode=eval"] + args)
+    assert res["examples"] == 1024 and math.isfinite(res["train/loss_per_example"]) and res["train/loss_per_example"] < 0.9 * start
+    assert res["latent_state"].shape == (1024, latent)
