@@ -68,6 +68,11 @@ struct Problem {
   int xorder;              // tile order inside the launch (gemm_grouped: 0 split/tn/tm, 1 all tn of a tm on one XCD, 2 all tm of a (split, tn))
   int split3;              // large-tile configuration: fp32 x fp32 products on the bf16 matrix cores (see split3 below):
                            // 1 = six piece products, 2 = all nine
+  int planes;              // operands of seg[0] are bf16 plane triples (hi, mid, lo as written by split_planes / the Bernoulli
+                           // epilogue's C3): a.ptr / b.ptr name plane 0 (16-bit elements, ld in elements); plane_rounds below
+  long long a_pstride, b_pstride;   // 16-bit elements between the planes of a / b
+  unsigned short* C3;      // EPI_BERNOULLI: (sigmoid - x) written as planes [3][M][ldc] of 16-bit pieces (beside or instead of C)
+  long long c3_stride;
   float* colsum_out;       // bias gradient riding on a dW problem: column sums of operand b over the tile's k
                            // range, written by the tiles of the first tile row to colsum_out[split][n]
   const float* bias;
@@ -107,7 +112,8 @@ struct Cfg {
   static constexpr int OPS = NBUF * (LDA + LDB) * BK;               // floats, NBUF staging buffers
   static constexpr int CST = WK * BM * LDC;                          // floats, C staging
   static constexpr int XBF = (BM == 64 && BN == 64 && BK == 64) ? 4 * 64 * 96 / 2 : 0;     // the bf16 path's 4 images [64][96] x 2 B
-  static constexpr int LDS0 = OPS > CST + 4 * kThreads ? OPS : CST + 4 * kThreads;          // + column-sum partials
+  static constexpr int CSP = BM >= 128 ? 8 : 4;                      // column-sum partials per thread (plane_rounds: 8)
+  static constexpr int LDS0 = OPS > CST + CSP * kThreads ? OPS : CST + CSP * kThreads;
   static constexpr int LDS_FLOATS = LDS0 > XBF ? LDS0 : XBF;
   // waves per SIMD the register allocator must leave room for: the small configuration's launches carry more
   // workgroups than 2 per CU (tiles + auxiliary blocks), and a workgroup that starts late ends the launch late
@@ -382,6 +388,114 @@ __device__ __forceinline__ void split_round(const unsigned short* __restrict__ A
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
         acc[i][j] = c;
       }
+  }
+}
+
+// ---- operands split ONCE by their producer ("planes") ------------------------------------------------------------
+// split3 above pays ~450 VALU instructions per thread and round for the fp32 -> 3 x bf16 conversion, un-overlapped at one
+// workgroup per CU: 1.1 - 1.3x slower than the fp32 MFMA loop.  Here the three pieces of every operand element already
+// lie in memory as three 16-bit planes (written by split_planes below or by the Bernoulli epilogue's C3 output), a round
+// is 12 16-byte loads and 12 16-byte LDS stores per thread with no arithmetic, and the images and the piece-product
+// round (split_round) are split3's.  6 x 48 v_mfma_f32_32x32x16_bf16 cycles per 32-deep round: 1536 against 4096.
+// The per-k scale of an IWAE weight gradient cannot ride on the pieces: the producer writes the planes of the SCALED
+// activation (split_planes' rowscale) and `kscale` only weighs the bias gradient's column sums here.
+template <bool MC>
+__device__ __forceinline__ void plane_map(const int tid, const uint32_t ld, const int mn0, const int kb, uint32_t& e0,
+                                          uint32_t& slot, uint32_t& round, uint32_t (&w)[2]) {
+  if (!MC) {            // [mn][k]: 4 chunks of 8 k per row; this thread: rows (tid >> 2) and + 64
+    e0 = (uint32_t)(mn0 + (tid >> 2)) * ld + (uint32_t)kb + 8u * (tid & 3);
+    slot = 64u * ld; round = 32u;
+    w[0] = (uint32_t)(tid >> 2) * kSplitPK + 8u * (tid & 3);
+    w[1] = w[0] + 64u * kSplitPK;
+  } else {              // [k][mn]: 16 chunks of 8 mn per k row; this thread: k rows (tid >> 4) and + 16
+    e0 = (uint32_t)(kb + (tid >> 4)) * ld + (uint32_t)mn0 + 8u * (tid & 15);
+    slot = 16u * ld; round = 32u * ld;
+    w[0] = (uint32_t)(tid >> 4) * kSplitPM + 8u * (tid & 15);
+    w[1] = w[0] + 16u * kSplitPM;
+  }
+}
+
+template <bool AMC, bool BMC>
+__device__ __forceinline__ void plane_rounds(unsigned short* __restrict__ img, const unsigned short* __restrict__ A,
+                                             const uint32_t a_ld, const long long a_ps, const unsigned short* __restrict__ Bp,
+                                             const uint32_t b_ld, const long long b_ps, const float* __restrict__ kscale,
+                                             const bool do_cs, const int m0, const int n0, const int kb, const int NC,
+                                             const int tid, const int lane, const int wm0, const int wn0,
+                                             f32x16 (&acc)[2][2], float (&cs8)[8]) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  unsigned short* const Ai = img;
+  unsigned short* const Bi = img + 3 * kSplitPlane;
+  uint32_t ea, eb, a_slot, b_slot, a_round, b_round, wa[2], wb[2];
+  plane_map<AMC>(tid, a_ld, m0, kb, ea, a_slot, a_round, wa);
+  plane_map<BMC>(tid, b_ld, n0, kb, eb, b_slot, b_round, wb);
+  u32x4 ra[3][2], rb[3][2];
+  int kk = kb + (tid >> 4);                       // (column sums: this thread's k rows of an mn-contiguous b)
+#define GMVAE_PL_GLOAD()                                                                                   \
+  {                                                                                                        \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                       \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+        ra[pl][i] = *reinterpret_cast<const u32x4*>(A + pl * a_ps + ea + i * a_slot);                      \
+        rb[pl][i] = *reinterpret_cast<const u32x4*>(Bp + pl * b_ps + eb + i * b_slot);                     \
+      }                                                                                                    \
+    ea += a_round; eb += b_round;                                                                          \
+  }
+#define GMVAE_PL_LSTORE()                                                                                  \
+  {                                                                                                        \
+    if (BMC && do_cs) {                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+        const float sc = kscale ? kscale[kk + 16 * i] : 1.f;                                               \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
+          const unsigned h = rb[0][i][q], m = rb[1][i][q], l = rb[2][i][q];                                \
+          cs8[2 * q] += sc * ((__uint_as_float(l << 16) + __uint_as_float(m << 16)) + __uint_as_float(h << 16));                      \
+          cs8[2 * q + 1] += sc * ((__uint_as_float(l & 0xffff0000u) + __uint_as_float(m & 0xffff0000u)) + __uint_as_float(h & 0xffff0000u)); \
+        }                                                                                                  \
+      }                                                                                                    \
+      kk += 32;                                                                                            \
+    }                                                                                                      \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                       \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+        *reinterpret_cast<u32x4*>(Ai + pl * kSplitPlane + wa[i]) = ra[pl][i];                              \
+        *reinterpret_cast<u32x4*>(Bi + pl * kSplitPlane + wb[i]) = rb[pl][i];                              \
+      }                                                                                                    \
+  }
+  GMVAE_PL_GLOAD();
+  GMVAE_PL_LSTORE();
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < NC; ++c) {
+    const bool more = c + 1 < NC;
+    if (more) GMVAE_PL_GLOAD();
+    split_round<AMC, BMC>(Ai, Bi, wm0, wn0, lane, false, acc);
+    __syncthreads();                              // every wave is done with the only image
+    if (more) GMVAE_PL_LSTORE();
+    __syncthreads();
+  }
+#undef GMVAE_PL_GLOAD
+#undef GMVAE_PL_LSTORE
+}
+
+// fp32 [rows][ld] (x rowscale[row]) -> three planes of 16-bit pieces hi, mid, lo (truncation splits with exact residuals:
+// hi + mid + lo == the fp32 value, bit for bit); n a multiple of 8, 16-byte aligned
+__global__ __launch_bounds__(256) void split_planes(const float* __restrict__ src, const float* __restrict__ rowscale,
+                                                     const int ld, const long long n, unsigned short* __restrict__ dst,
+                                                     const long long pstride) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  for (long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; e < n; e += (long long)gridDim.x * 256 * 8) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + e), v1 = *reinterpret_cast<const f32x4*>(src + e + 4);
+    const float sc = rowscale ? rowscale[e / ld] : 1.f;
+    const float v[8] = {v0.x * sc, v0.y * sc, v0.z * sc, v0.w * sc, v1.x * sc, v1.y * sc, v1.z * sc, v1.w * sc};
+    unsigned hi[8], mi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned hb = __float_as_uint(v[j]) & 0xffff0000u;
+      const float r1 = v[j] - __uint_as_float(hb);
+      const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+      const float r2 = r1 - __uint_as_float(mb);
+      hi[j] = hb >> 16; mi[j] = mb >> 16; lo[j] = __float_as_uint(r2) >> 16;
+    }
+    *reinterpret_cast<u32x4*>(dst + e) = u32x4{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16)};
+    *reinterpret_cast<u32x4*>(dst + pstride + e) = u32x4{mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16)};
+    *reinterpret_cast<u32x4*>(dst + 2 * pstride + e) = u32x4{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16)};
   }
 }
 
@@ -662,8 +776,9 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
   float csum = 0.f;
   constexpr int CSG = kThreads / C::BN;          // k groups of the column-sum threads
   const int cs_n = tid % C::BN, cs_k = tid / C::BN;
-  bool did_bf16 = false, did_split = false, did_big = false;
+  bool did_bf16 = false, did_split = false, did_big = false, did_planes = false;
   float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if constexpr (C::BM == 64 && C::BN == 64 && C::BK == 64) {
     if (L.p[pi].xbf16) {
       did_bf16 = true;
@@ -832,7 +947,28 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
         continue;
       }
     }
-    if constexpr (BIG) {
+    if constexpr (BIG == 2) {                     // every problem of the launch has pre-split operands (host: planes_eligible)
+      static_assert(!SP3 && C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2, "plane rounds: 128x128x32");
+      static_assert(6 * kSplitPlane * 2 <= C::LDS_FLOATS * 4, "plane images must fit the kernel's LDS");
+      __syncthreads();        // LDS is free
+      if (sgi == 0) GMVAE_GSTAMP(6);
+      const unsigned short* const Ah = static_cast<const unsigned short*>(a_ptr);
+      const unsigned short* const Bh = static_cast<const unsigned short*>(b_ptr);
+      const long long a_ps = L.p[pi].a_pstride, b_ps = L.p[pi].b_pstride;
+#define GMVAE_PL(AMC_, BMC_) \
+  plane_rounds<AMC_, BMC_>(reinterpret_cast<unsigned short*>(lds), Ah, (uint32_t)a_ld, a_ps, Bh, (uint32_t)b_ld, b_ps, kscale, \
+                           do_colsum, m0, n0, kb, NC, tid, lane, wm0, wn0, acc, cs8)
+      if (!b_mc) {
+        if (a_mc) GMVAE_PL(true, false); else GMVAE_PL(false, false);
+      } else {
+        if (a_mc) GMVAE_PL(true, true); else GMVAE_PL(false, true);
+      }
+#undef GMVAE_PL
+      if (do_colsum) did_planes = true;
+      if (sgi == 0) GMVAE_GSTAMP(1);
+      continue;
+    }
+    if constexpr (BIG == 1) {
       static_assert(!SP3 && C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2, "big rounds: 128x128x32");
       __syncthreads();        // LDS is free
       if (sgi == 0) GMVAE_GSTAMP(6);
@@ -908,14 +1044,22 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
           Cs[row * C::LDC + wn0 + j * 32 + l31] = acc[i][j][r];
         }
     if (do_colsum) {
-      if (did_bf16 || did_split || did_big) *reinterpret_cast<float4*>(lds + C::CST + 4 * tid) = cs4;     // (k rows tid>>4 + 16i, columns 4(tid&15)..)
+      if (did_planes) {                            // (k rows tid >> 4 + 16 i, columns 8 (tid & 15)..)
+        if constexpr (C::CSP == 8) {
+          *reinterpret_cast<float4*>(lds + C::CST + 8 * tid) = make_float4(cs8[0], cs8[1], cs8[2], cs8[3]);
+          *reinterpret_cast<float4*>(lds + C::CST + 8 * tid + 4) = make_float4(cs8[4], cs8[5], cs8[6], cs8[7]);
+        }
+      } else if (did_bf16 || did_split || did_big) *reinterpret_cast<float4*>(lds + C::CST + 4 * tid) = cs4;     // (k rows tid>>4 + 16i, columns 4(tid&15)..)
       else lds[C::CST + tid] = csum;
     }
   }
   __syncthreads();
   if (do_colsum && tid < C::BN && n0 + tid < L.p[pi].N) {
     float v = 0.f;
-    if (did_split) {                               // column tid: the 8 threads 4 (tid >> 2) + a + 128 b staged its quad
+    if (did_planes) {                              // column tid: threads (tid >> 3) + 16 g hold its chunk
+#pragma unroll
+      for (int g = 0; g < 16; ++g) v += lds[C::CST + 8 * ((tid >> 3) + 16 * g) + (tid & 7)];
+    } else if (did_split) {                        // column tid: the 8 threads 4 (tid >> 2) + a + 128 b staged its quad
 #pragma unroll
       for (int g = 0; g < 8; ++g) v += lds[C::CST + 4 * (4 * (tid >> 2) + (g & 3) + 128 * (g >> 2)) + (tid & 3)];
     } else if (did_big) {                          // column tid: threads (tid >> 2) + 32 g hold its quad (k-quads g)
@@ -1049,6 +1193,8 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
     const unsigned char* xp = L.p[pi].x;
     float* part = L.p[pi].part;
     const int ldx = L.p[pi].ldx, x_div = L.p[pi].x_div, nparts = L.p[pi].nparts;
+    unsigned short* const C3 = L.p[pi].C3;         // (only set for launches whose tiles are all interior: planes_eligible)
+    const long long c3s = L.p[pi].c3_stride;
     if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && (!Cout || al16(Cout)) && al16(bias) && (!bias2 || al16(bias2)) && (ldx & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(xp) & 3) == 0) {
       // interior tile: the bias quad once, the 4 target bytes of a pass as one word; every pass's target word AND staged
@@ -1092,6 +1238,21 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
           v[j] = (lam >= 0.f ? rcp : e * rcp) - xv;
         }
         if (Cout) *reinterpret_cast<float4*>(Cout + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
+        if (C3) {                                   // the three 16-bit pieces of (sigmoid - x), one plane each (plane_rounds' operand)
+          unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned hb = __float_as_uint(v[j]) & 0xffff0000u;
+            const float r1 = v[j] - __uint_as_float(hb);
+            const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(mb);
+            hi[j] = hb >> 16; mi[j] = mb >> 16; lo[j] = __float_as_uint(r2) >> 16;
+          }
+          unsigned short* const d3 = C3 + (long long)(m0 + row) * ldc + nb;
+          *reinterpret_cast<uint2*>(d3) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+          *reinterpret_cast<uint2*>(d3 + c3s) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+          *reinterpret_cast<uint2*>(d3 + 2 * c3s) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+        }
         lds[row * C::LDC + 4 * c4] = rsum;          // (this thread's own, already consumed, slot of the staged tile)
       }
       __syncthreads();

@@ -141,6 +141,8 @@ struct WS {
   float *img_f, *img_b;         // per-step LDS weight images of chain_fwd / chain_bwd (prepared by aux blocks)
   float *img_m, *dimg;          // mega kernel: small-weight image (odd leading dimensions) + decoder chunk images
   float *img2f, *img2b, *dimg2; // mega2 kernel: forward / backward operand images, decoder operand images
+  unsigned short *hd3, *g3, *w3;   // general schedule, large top decoder layer: planes of 16-bit pieces (gemm.hpp plane_rounds) of its
+                                   // input activation [3][R][H], of (sigmoid - x) [3][R][D] and of its weight [3][H][D]
   int32_t* cl_pred;
   uint64_t bytes;
 };
@@ -229,6 +231,19 @@ static int num_splits_small(long long R) {
   const char* e = getenv("GMVAE_NSPLIT_SMALL");      // (tests: the many-splits path at sizes the oracle covers)
   if (e && atoi(e) >= 1 && atoi(e) <= NS_SMALL_MAX) ns = atoi(e);
   return (int)ns;
+}
+
+// The top decoder layer's three GEMMs (logits, data gradient, weight gradient) on the bf16 matrix cores from operands split
+// once by their producers (gemm.hpp plane_rounds): interior 128-tiles in every orientation, and enough rows to pay for the
+// split launches (measured at the config-5 shard, tools/gemm_planes.py: 1.45 - 1.65x the fp32 MFMA instance per GEMM).
+static bool planes_ok(const GmvaeDims& d, const Layout& L) {
+  const char* e = getenv("GMVAE_NO_PLANES");
+  if (e && atoi(e)) return false;
+  const long long R = (long long)d.B * d.S;
+  const int Ht = L.dec.dim[L.dec.nl - 1];
+  long long minr = 4096;
+  if (const char* m = getenv("GMVAE_PLANES_MINROWS")) minr = atoll(m);     // (tests: the plane path at sizes the oracle covers)
+  return L.dec.nl >= 2 && R >= minr && R % 128 == 0 && d.D % 128 == 0 && Ht % 128 == 0 && R * d.D < (1ll << 32);
 }
 
 static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS& w) {
@@ -321,6 +336,15 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     w.slabs = take((uint64_t)ns * L.P_pad);
   }
   w.cl_pred = reinterpret_cast<int32_t*>(take(B));
+  {
+    // (sized by the dims alone, not by GMVAE_NO_PLANES / GMVAE_PLANES_MINROWS: the workspace layout must not depend on a switch)
+    const uint64_t Ht = L.dec.dim[L.dec.nl - 1];
+    if (L.dec.nl >= 2 && R % 128 == 0 && D % 128 == 0 && Ht % 128 == 0 && R * D < (1ull << 32)) {
+      w.hd3 = reinterpret_cast<unsigned short*>(take((3 * R * Ht + 1) / 2));
+      w.g3 = reinterpret_cast<unsigned short*>(take((3 * R * D + 1) / 2));
+      w.w3 = reinterpret_cast<unsigned short*>(take((3 * Ht * D + 1) / 2));
+    }
+  }
   w.bytes = off;
 }
 
@@ -456,6 +480,25 @@ static bool big_eligible(const Launch& L) {
   return true;
 }
 
+// every problem of the launch reads pre-split operands (gemm.hpp plane_rounds): interior 128 x 128 tiles, whole 32-deep
+// rounds, 16-byte chunks of eight 16-bit pieces
+static bool planes_eligible(const Launch& L) {
+  for (int i = 0; i < L.nprob; ++i) {
+    const Problem& p = L.p[i];
+    if (!p.planes || p.xbf16 || p.nseg != 1 || p.M % 128 || p.N % 128) return false;
+    const Segment& sg = p.seg[0];
+    if (sg.a.row_div != 1 || sg.b.row_div != 1 || sg.a.n_mn < p.M || sg.b.n_mn < p.N || sg.K % 32) return false;
+    if (sg.a.ld % 8 || sg.b.ld % 8 || (reinterpret_cast<uintptr_t>(sg.a.ptr) & 15) || (reinterpret_cast<uintptr_t>(sg.b.ptr) & 15)) return false;
+    if ((p.a_pstride & 7) || (p.b_pstride & 7)) return false;
+    if (p.colsum_out && sg.b.k_contig) return false;
+    const int kper = ((sg.K + p.splits - 1) / p.splits + 31) / 32 * 32;
+    if (sg.K % kper && (sg.K % kper) % 32) return false;
+    const unsigned long long ext_a = sg.a.n_mn > sg.K ? sg.a.n_mn : sg.K, ext_b = sg.b.n_mn > sg.K ? sg.b.n_mn : sg.K;
+    if (ext_a * sg.a.ld >= (1ull << 32) || ext_b * sg.b.ld >= (1ull << 32)) return false;
+  }
+  return L.nprob > 0;
+}
+
 // Estimated duration (us) of a grouped launch under tile configuration C: the larger of its longest tile running alone
 // (rounds x the round time of a workgroup that has its CU to itself -- latency-bound) and of all tiles sharing the 256 CUs
 // (rounds x the round time of a busy CU -- matrix-pipe-bound, padding of partial tiles included through the tile counts;
@@ -510,6 +553,12 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
   }
   g.L.dbg = dbg;
   g.L.aux_nblocks = g.L.aux.nblocks;
+  bool planes = g.L.p[0].planes != 0;
+  for (int i = 1; i < g.L.nprob; ++i) planes = planes && g.L.p[i].planes;
+  if (planes) {
+    if (!planes_eligible(g.L)) { cx.err = cx.err ? cx.err : GMVAE_E_DIMS; return 2; }      // (the host only marks problems it checked)
+    cfg = 2;
+  }
   if (cfg < 0) cfg = cx.force_cfg;
   if (cfg < 0) {
     Launch t = g.L;
@@ -545,7 +594,8 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
     for (int i = 0; i < g.L.nprob; ++i) g.L.p[i].split3 = sp3;
     tiles = g.L.total_tiles = tile_up<CfgL>(g.L);
     const bool no_big = getenv("GMVAE_NO_BIG") != nullptr;      // diagnostic / A-B: the general loop
-    if (sp3) hipLaunchKernelGGL((gemm_grouped<CfgL, 1>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
+    if (planes) hipLaunchKernelGGL((gemm_grouped<CfgL, 0, 2>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
+    else if (sp3) hipLaunchKernelGGL((gemm_grouped<CfgL, 1>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
     else if (!no_big && big_eligible(g.L)) hipLaunchKernelGGL((gemm_grouped<CfgL, 0, 1>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
     else hipLaunchKernelGGL(gemm_grouped<CfgL>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
   } else if (cfg == 3) {
@@ -1367,6 +1417,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   const bool gm = model == GMVAE_MODEL_GMVAE;
   const float c = d.raw_sigma_bias, smin = d.sigma_min;
   hipStream_t st = cx.st;
+  const bool planes = planes_ok(d, L) && w.hd3 != nullptr;
 
   // ---- noise (fast mode): Philox for eps and u -- its own launch in the general schedule, auxiliary
   // workgroups of the first GEMM launch in the fused one
@@ -1480,6 +1531,18 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       p.addconst = d.gen_bias_init;
       p.bias2 = d.gen_bias_vec;
       p.x = a.x; p.ldx = D; p.x_div = S; p.part = w.part;
+      if (planes) {
+        // both operands as planes of 16-bit pieces (the weight's are shared with the data gradient below), (sigmoid - x)
+        // leaves as planes only: its two consumers are plane GEMMs
+        const long long nh = (long long)R * Dn.dim[i], nw = (long long)Dn.dim[i] * D;
+        hipLaunchKernelGGL(split_planes, dim3(grid_for(nh, 2048, 8192)), dim3(256), 0, st, in, (const float*)nullptr, Dn.dim[i], nh, w.hd3, nh);
+        hipLaunchKernelGGL(split_planes, dim3(grid_for(nw, 2048, 8192)), dim3(256), 0, st, P + Dn.w[i], (const float*)nullptr, D, nw, w.w3, nw);
+        rowk(cx, "split_planes");
+        p.seg[0].a.ptr = w.hd3; p.seg[0].b.ptr = w.w3;
+        p.planes = 1; p.a_pstride = nh; p.b_pstride = nw;
+        p.C = nullptr;
+        p.C3 = a.backward ? w.g3 : nullptr; p.c3_stride = (long long)R * D;
+      }
       g.add(p);
       const int bn = cfg_bn(launch_group(cx, g, "fwd_dec_bernoulli"));
       nparts = (D + bn - 1) / bn;
@@ -1536,7 +1599,21 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     Problem p = p_nt(dcur, Dn.dim[i + 1], P + Dn.w[i], Dn.dim[i + 1], R, Dn.dim[i], Dn.dim[i + 1], out, Dn.dim[i],
                      (i > 0) ? w.hd[i] : nullptr, Dn.dim[i]);
     p.rowscale = top ? rwS : nullptr;
-    g.add(pw);
+    if (top && planes) {
+      const long long nh = (long long)R * Dn.dim[i], nw = (long long)Dn.dim[i] * D, ng = (long long)R * D;
+      if (rwS) {           // IWAE: the row weights ride on the activation's pieces (they cannot scale pieces inside the loop)
+        hipLaunchKernelGGL(split_planes, dim3(grid_for(nh, 2048, 8192)), dim3(256), 0, st, act, rwS, Dn.dim[i], nh, w.hd3, nh);
+        rowk(cx, "split_planes_rw");
+      }
+      Problem pw3 = pw;
+      pw3.seg[0].a.ptr = w.hd3; pw3.seg[0].b.ptr = w.g3;
+      pw3.planes = 1; pw3.a_pstride = nh; pw3.b_pstride = ng;      // (seg[0].kscale = rwS now only weighs the column sums)
+      p.seg[0].a.ptr = w.g3; p.seg[0].b.ptr = w.w3;
+      p.planes = 1; p.a_pstride = ng; p.b_pstride = nw;
+      g.add(pw3);
+    } else {
+      g.add(pw);
+    }
     g.add(p);
     launch_group(cx, g, top ? "bwd_dec_top" : "bwd_dec");
     dcur = out;
@@ -1857,6 +1934,33 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
   Ctx cx;
   cx.st = static_cast<hipStream_t>(stream);
   Group g;
+  if (cfg == 4 || cfg == 5) {
+    // the pre-split ("planes") instance: cfg 4 splits both operands into scratch planes first, cfg 5 reuses the planes of
+    // the previous cfg-4 call (timing the GEMM alone).  M, N multiples of 128, K of 32 (TN: rows K of 32 x splitk).
+    static unsigned short *pa = nullptr, *pb = nullptr;
+    static size_t cap_a = 0, cap_b = 0;
+    if (a_is_u8) return GMVAE_E_DIMS;
+    const size_t na = (size_t)M * K, nb = (size_t)N * K;
+    if (na % 8 || nb % 8) return GMVAE_E_DIMS;
+    if (na > cap_a) { if (pa) hipFree(pa); if (hipMalloc(&pa, 3 * na * 2) != hipSuccess) return GMVAE_E_ALIGN; cap_a = na; }
+    if (nb > cap_b) { if (pb) hipFree(pb); if (hipMalloc(&pb, 3 * nb * 2) != hipSuccess) return GMVAE_E_ALIGN; cap_b = nb; }
+    if (cfg == 4) {
+      hipLaunchKernelGGL(split_planes, dim3(grid_for((long long)na, 2048, 8192)), dim3(256), 0, cx.st, static_cast<const float*>(A),
+                         (const float*)nullptr, trans == 2 ? M : K, (long long)na, pa, (long long)na);
+      hipLaunchKernelGGL(split_planes, dim3(grid_for((long long)nb, 2048, 8192)), dim3(256), 0, cx.st, W, (const float*)nullptr,
+                         trans == 1 ? K : N, (long long)nb, pb, (long long)nb);
+    }
+    Problem p;
+    const float* fa = reinterpret_cast<const float*>(pa);
+    const float* fb = reinterpret_cast<const float*>(pb);
+    if (trans == 0) p = p_nn(fa, false, K, fb, N, M, N, K, C, N, bias, relu != 0);
+    else if (trans == 1) p = p_nt(fa, K, fb, K, M, N, K, C, N, nullptr, 0);
+    else p = p_tn(fa, false, M, 1, fb, N, M, N, K, C, bias ? C + (size_t)M * N : nullptr, splitk, (long long)(M + 1) * N, nullptr);
+    p.planes = 1; p.a_pstride = (long long)na; p.b_pstride = (long long)nb;
+    g.add(p);
+    launch_group(cx, g, "gemm_test_planes", 2);
+    return cx.err;
+  }
   if (trans == 0) {
     g.add(p_nn(A, a_is_u8 != 0, K, W, N, M, N, K, C, N, bias, relu != 0));
   } else if (trans == 1) {

@@ -145,6 +145,41 @@ def test_gemm_big_rounds_instance(H, monkeypatch, trans, M, N, K, ns):
     np.testing.assert_allclose(outs[0], outs[1], rtol=2e-5, atol=3e-5 * math.sqrt(K))
 
 
+@pytest.mark.parametrize("trans,M,N,K,ns", [(0, 256, 384, 160, 1), (1, 384, 128, 96, 1), (2, 128, 256, 1024, 2),
+                                            (2, 256, 128, 320, 3), (0, 128, 128, 32, 1), (1, 128 * 131, 512, 64, 1),
+                                            (2, 512, 128 * 43, 96, 3), (0, 128 * 67, 128 * 16, 64, 1)])
+def test_gemm_plane_rounds_instance(H, trans, M, N, K, ns):
+    """Operands split ONCE into three planes of 16-bit pieces (gemm.hpp split_planes) and multiplied as six exact bf16 piece
+    products with fp32 accumulation (plane_rounds, `cfg` 4 of gmvae_gemm_test): every operand orientation (NN / NT / TN with
+    split-K and the bias-gradient column sums) to fp32-GEMM accuracy against fp64, and no further from it than the fp32 MFMA
+    instance is."""
+    L = _L()
+    rng = np.random.default_rng(M + 3 * N + 7 * K + trans)
+    if trans == 0:
+        A, W = rng.normal(size=(M, K)).astype(np.float32), rng.normal(size=(K, N)).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64)
+        shape = (M, N)
+    elif trans == 1:
+        A, W = rng.normal(size=(M, K)).astype(np.float32), rng.normal(size=(N, K)).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64).T
+        shape = (M, N)
+    else:
+        A, W = rng.normal(size=(K, M)).astype(np.float32), rng.normal(size=(K, N)).astype(np.float32)
+        ref = np.concatenate([A.astype(np.float64).T @ W, W.astype(np.float64).sum(0, keepdims=True)], 0)
+        shape = (ns, M + 1, N)
+    Ad, Wd = H.dev(A), H.dev(W)
+    err = []
+    for cfg in (4, 2):
+        Cd = torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
+        L.check(L.lib.gmvae_gemm_test(L.ptr(Ad), 0, L.ptr(Wd), L.ptr(Wd) if trans == 2 else None, L.ptr(Cd), M, N, K, trans, 0,
+                                      cfg, ns, L.current_stream()), "gemm_test")
+        got = Cd.cpu().numpy().astype(np.float64)
+        got = got.sum(axis=0) if trans == 2 else got
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=3e-5 * math.sqrt(K))
+        err.append(np.abs(got - ref).max())
+    assert err[0] <= 2.0 * err[1] + 1e-6, err
+
+
 # ------------------------------------------------------------ full step
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
 
@@ -276,6 +311,31 @@ def test_big_round_gemm_inside_the_step_iwae(H, monkeypatch, model):
     g_gen, _ = H.hip_step(model, d, flat, x, eps, u)
     assert not np.array_equal(g_big, g_gen)
     np.testing.assert_allclose(g_big, g_gen, rtol=0, atol=2e-4 * np.abs(g_gen).max())
+
+
+@pytest.mark.parametrize("model,S,hidden", [(O.MODEL_GMVAE, 4, (128,)), (O.MODEL_VAE, 1, (64, 128)), (O.MODEL_VAE_GMP, 2, (128,))])
+def test_plane_gemms_inside_the_step(H, monkeypatch, model, S, hidden):
+    """The top decoder layer's three GEMMs on pre-split operands (gemm.hpp plane_rounds; by default from 4096 rows, forced
+    here at R = B*S = 128 / 256 rows, H = 128, D = 256): the hidden activation and the weight split by split_planes,
+    (sigmoid - x) written as planes by the Bernoulli epilogue, the IWAE row weights riding on the activation's pieces and
+    weighing the bias gradient's column sums -- against the oracle at the step's gates, NOT bit-identical to the fp32 MFMA
+    instance (evidence that the path ran) and as close to it as fp32 rounding."""
+    monkeypatch.setenv("GMVAE_PLANES_MINROWS", "128")
+    d = O.Dims(D=256, L=64, K=10, hidden=hidden, S=S)
+    rng = np.random.default_rng(6)
+    p = O.init_params(model, d, rng)
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    B = 256 // S if S > 1 else 128
+    x, eps, u = O.make_inputs(d, B, model)
+    H.compare_step(model, d, p, x, eps, u)
+    flat = O.pack(model, d, p, np.float32)
+    g_pl, _ = H.hip_step(model, d, flat, x, eps, u)
+    monkeypatch.setenv("GMVAE_NO_PLANES", "1")
+    g_f32, _ = H.hip_step(model, d, flat, x, eps, u)
+    assert not np.array_equal(g_pl, g_f32)
+    np.testing.assert_allclose(g_pl, g_f32, rtol=0, atol=2e-5 * np.abs(g_f32).max())
 
 
 def test_many_splits_for_small_weight_gradients_and_few_for_batch_row_ones(H, monkeypatch):
