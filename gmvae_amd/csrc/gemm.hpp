@@ -397,6 +397,10 @@ __device__ __forceinline__ void split_round(const unsigned short* __restrict__ A
 // lie in memory as three 16-bit planes (written by split_planes below or by the Bernoulli epilogue's C3 output), a round
 // is 12 16-byte loads and 12 16-byte LDS stores per thread with no arithmetic, and the images and the piece-product
 // round (split_round) are split3's.  6 x 48 v_mfma_f32_32x32x16_bf16 cycles per 32-deep round: 1536 against 4096.
+// (Measured and dropped: 16-deep rounds in two LDS buffers with one barrier per round and the next fragments read behind
+// it -- 8-25 % SLOWER on the config-5 GEMMs: a k-contiguous operand then arrives as 32-byte pieces of 128-byte lines, and
+// a wave issues at most one MFMA per 32 cycles whatever its neighbour does (tools/micro/mfma_chain.hip), so the second
+// workgroup of a CU hides none of the first one's barrier and staging gaps.)
 // The per-k scale of an IWAE weight gradient cannot ride on the pieces: the producer writes the planes of the SCALED
 // activation (split_planes' rowscale) and `kscale` only weighs the bias gradient's column sums here.
 template <bool MC>
