@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 peak (v_mfma_f32_32x32x16_bf16)
 
 
 # Named workloads (per-GPU shapes).  configs0..2 = BASELINE.json configs[0..2]; configs4_shard = the per-GPU shard of
@@ -425,6 +426,16 @@ def main():
                 "launches_per_step": len(levels), "sum_launch_usec": sum(dur(l) for l in levels),
                 "levels": [[nm, round(us, 2), round(tl, 2)] for nm, us, _, tl in levels],
                 "levels_columns": ["launch", "usec_in_kernel_span", "usec_timeline_share"]}
+        from gmvae_amd import _lib as LIB
+        schedule = LIB.step_schedule(eng.dims(B), eng.model)
+        roof["schedule"] = schedule
+        if schedule.endswith("+planes") and dom[0] in ("fwd_dec_bernoulli", "bwd_dec_top"):
+            # the launch multiplies fp32 values as SIX bf16 piece products per product on pre-split operands (gemm.hpp
+            # plane_rounds): its matrix-pipe peak is the dense bf16 peak / 6 in fp32-equivalent FLOP/s
+            pk = PEAK_BF16_MFMA_TFLOPS / 6.0
+            roof.update({"peak": pk, "frac": roof["achieved"] / pk, "frac_in_kernel_span": dom[2] / dom[1] * 1e-6 / pk,
+                         "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product; fp32 accumulation",
+                         "frac_of_f32_mfma_peak": roof["achieved"] / PEAK_F32_MFMA_TFLOPS})
         if dom[0].startswith("sk_dw"):
             # the skinny schedule's longest launch is the weight-gradient + TF-Adam launch: bound by HBM, not by the matrix
             # pipes -- algorithmic bytes = 7 x 4 P (p, m, v in; p, m, v and the gradient out), SURVEY.md 8(d)'s optimizer term
@@ -452,7 +463,7 @@ def main():
             if hit:
                 roof["rocprof_usec_per_launch"] = kern_us[hit[0]]
                 roof["frac_rocprof"] = (roof["bytes_per_launch"] / kern_us[hit[0]] * 1e-3 / PEAK_HBM_GBS if roof["bound"] == "hbm"
-                                        else dom[2] / kern_us[hit[0]] * 1e-6 / PEAK_F32_MFMA_TFLOPS)
+                                        else dom[2] / kern_us[hit[0]] * 1e-6 / roof["peak"])
             traf = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_traffic{'' if tag == 'bench' else '_' + str(tag)}.json"))) if tag else []
             if traf:
                 tj = json.load(open(traf[-1]))
@@ -495,7 +506,7 @@ def main():
             "ms_per_step_median_of_repeats": region_ms[len(region_ms) // 2] if region_ms else None,
             "ms_per_step_repeats": [round(v, 5) for v in region_ms] if region_ms else None,
             "steps_per_graph_launch": unit, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if not (roof or {}).get("schedule", "").endswith("+planes") else "f32 (products as 6 bf16 piece products, fp32 accumulation)", "data": "synthetic",
             "config": {"workload": f"{a.model} train step (noise+fwd+bwd+allreduce+TF-Adam), D={d.D} K={d.K} "
                                    f"L={d.L} hidden={hidden} S={d.S}, batch {B}/GPU x {n_gpus} GPU "
                                    f"({workload_name(a, n_gpus)})",

@@ -72,6 +72,7 @@ def _load():
         "gmvae_workspace_offset": ([dp, i32, C.c_char_p, C.POINTER(u64)], i32),
         "gmvae_binarize": ([vp, u64, vp, u64, i32, i32, u64, u64, vp, vp, u64, vp], i32),
         "gmvae_kernel_occupancy": ([i32, C.POINTER(i32)], i32),
+        "gmvae_step_schedule": ([dp, i32, vp], i32),
         "gmvae_debug_sk_stamps": ([vp], i32),
         "gmvae_train_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, i32, i32, C.POINTER(i32), vp, vp, vp, vp, vp], i32),
         "gmvae_step_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),
@@ -158,3 +159,10 @@ def rccl_path():
 def current_stream():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def step_schedule(dims, model):
+    """Name of the schedule a training step of these sizes takes (include/gmvae_hip.h gmvae_step_schedule)."""
+    buf = C.create_string_buffer(48)
+    check(lib.gmvae_step_schedule(C.byref(dims), int(model), buf), "gmvae_step_schedule")
+    return buf.value.decode()

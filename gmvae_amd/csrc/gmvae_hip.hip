@@ -243,7 +243,10 @@ static bool planes_ok(const GmvaeDims& d, const Layout& L) {
   const int Ht = L.dec.dim[L.dec.nl - 1];
   long long minr = 4096;
   if (const char* m = getenv("GMVAE_PLANES_MINROWS")) minr = atoll(m);     // (tests: the plane path at sizes the oracle covers)
-  return L.dec.nl >= 2 && R >= minr && R % 128 == 0 && d.D % 128 == 0 && Ht % 128 == 0 && R * d.D < (1ll << 32);
+  // (below ~4096 rows, or with a contraction of a few rounds, the split launches and the tile prologues eat the gain: measured
+  //  only at the config-5 shard's 25600 x 3072 x 512; the forced test sizes set GMVAE_PLANES_MINROWS)
+  const bool big = getenv("GMVAE_PLANES_MINROWS") != nullptr || (Ht >= 256 && d.D >= 512);
+  return L.dec.nl >= 2 && big && R >= minr && R % 128 == 0 && d.D % 128 == 0 && Ht % 128 == 0 && R * d.D < (1ll << 32);
 }
 
 static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS& w) {
@@ -2309,6 +2312,21 @@ int gmvae_debug_sk_stamps(unsigned long long* host_out) {
 }
 
 /* debugging aid: resident workgroups per CU as the runtime computes them */
+int gmvae_step_schedule(const GmvaeDims* dims, int model, char* out48) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!out48) return GMVAE_E_NULL;
+  const GmvaeDims& d = *dims;
+  Layout L;
+  build_layout(d, model, L);
+  const char* nm = "general";
+  if (mega_ok(d, model)) nm = mega2_ok(d, model) ? "mega2" : "mega";
+  else if (skinny_ok(d, model)) nm = "skinny";
+  else if (fused_ok(d, model)) nm = "fused";
+  const bool gen = !strcmp(nm, "general");
+  snprintf(out48, 48, "%s%s", nm, (gen && planes_ok(d, L)) ? "+planes" : "");
+  return 0;
+}
+
 int gmvae_kernel_occupancy(int which, int* blocks_per_cu) {
   if (!blocks_per_cu) return GMVAE_E_NULL;
   hipError_t e;

@@ -281,6 +281,12 @@ int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, u
  * otherwise the buffer is copied to host_out.  tools/skstamps.py. */
 int gmvae_debug_sk_stamps(unsigned long long* host_out);
 
+/* Which schedule a TRAINING step of these sizes takes, as text (<= 47 chars + NUL into out48): "mega2", "mega", "skinny",
+ * "fused" or "general", with "+planes" appended where the top decoder layer's GEMMs run as bf16 piece products on pre-split
+ * operands (gemm.hpp plane_rounds).  Host-side, reads the same environment switches as the step.  bench.py prices its
+ * roofline line with it. */
+int gmvae_step_schedule(const GmvaeDims* dims, int model, char* out48);
+
 /* Debugging aid: resident workgroups per CU the HIP runtime reports for a kernel of the library
  * (which: 0/1/2 = grouped GEMM small/medium/large configuration, 3 = mega_fwd_bwd, 4 = finalize_adam). */
 int gmvae_kernel_occupancy(int which, int* blocks_per_cu);

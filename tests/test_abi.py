@@ -113,3 +113,18 @@ def test_initializers_and_device_flags_are_checked_on_the_host(monkeypatch):
         sel(SimpleNamespace(gpu_id="0", gpu_num="7"), 0)
     monkeypatch.setenv("LOCAL_RANK", "1")
     assert sel(SimpleNamespace(gpu_id="0", gpu_num="0"), 1) == 1
+
+
+def test_step_schedule_names(L, monkeypatch):
+    """gmvae_step_schedule: which schedule a training step of given sizes takes (host-side; bench.py prices its roofline
+    with it) -- the reference defaults, bin/run_train.sh's sizes, the config-5 shard, two hidden layers."""
+    for k in ("GMVAE_NO_MEGA", "GMVAE_NO_MEGA2", "GMVAE_NO_SKINNY", "GMVAE_NO_FUSED", "GMVAE_NO_PLANES", "GMVAE_PLANES_MINROWS"):
+        monkeypatch.delenv(k, raising=False)
+    G = L.MODEL_IDS["gmvae"]
+    assert L.step_schedule(L.make_dims(1024, 784, 64, 10, [64]), G) == "mega2"
+    assert L.step_schedule(L.make_dims(256, 784, 64, 10, [64]), L.MODEL_IDS["vae_gmp"]) == "mega"
+    assert L.step_schedule(L.make_dims(64, 784, 128, 10, [512]), G) == "skinny"
+    assert L.step_schedule(L.make_dims(512, 3072, 64, 64, [512], S=50), G) == "general+planes"
+    assert L.step_schedule(L.make_dims(40, 784, 16, 10, [64, 64]), G) == "general"
+    monkeypatch.setenv("GMVAE_NO_PLANES", "1")
+    assert L.step_schedule(L.make_dims(512, 3072, 64, 64, [512], S=50), G) == "general"
