@@ -464,6 +464,14 @@ def main():
                 roof["rocprof_usec_per_launch"] = kern_us[hit[0]]
                 roof["frac_rocprof"] = (roof["bytes_per_launch"] / kern_us[hit[0]] * 1e-3 / PEAK_HBM_GBS if roof["bound"] == "hbm"
                                         else dom[2] / kern_us[hit[0]] * 1e-6 / roof["peak"])
+            pl = [k for k in kern_us if k.startswith("void gmvae::gemm_grouped<gmvae::Cfg<128, 128, 32, 2, 2, 1, 2>, 0, 2>")]
+            if not hit and pl and schedule.endswith("+planes") and dom[0] in ("fwd_dec_bernoulli", "bwd_dec_top"):
+                # the plane instance runs exactly two launches per step (logits + Bernoulli; weight and data gradient): the
+                # committed average is over both, so the fraction is priced on both launches' FLOPs together
+                both = [l for l in levels if l[0] in ("fwd_dec_bernoulli", "bwd_dec_top")]
+                roof["rocprof_usec_per_launch"] = kern_us[pl[0]]
+                roof["rocprof_note"] = "average over the two plane launches of a step (fwd_dec_bernoulli, bwd_dec_top); frac_rocprof = their FLOPs / (2 x average)"
+                roof["frac_rocprof"] = sum(l[2] for l in both) / (len(both) * kern_us[pl[0]]) * 1e-6 / roof["peak"]
             traf = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_traffic{'' if tag == 'bench' else '_' + str(tag)}.json"))) if tag else []
             if traf:
                 tj = json.load(open(traf[-1]))
