@@ -13,4 +13,4 @@ python3 tools/pmc_summary.py $S/pmc_FETCH_SIZE/pmc_counter_collection.csv $S/pmc
 python3 tools/traffic_from_pmc.py $S/pmc_FETCH_SIZE/pmc_counter_collection.csv $S/pmc_WRITE_SIZE/pmc_counter_collection.csv profiles/round${RN}_traffic.json
 python3 tools/traffic_from_pmc.py $S/pmcrt_FETCH_SIZE/pmc_counter_collection.csv $S/pmcrt_WRITE_SIZE/pmc_counter_collection.csv profiles/round${RN}_traffic_run_train_sizes.json
 ls -la profiles/round${RN}_*
-bash tools/pmc_config5_traffic.sh   # -> gpurun_out/pmc_c5/traffic.{json,txt} -> profiles/round3_traffic_config5_shard.*
+# (on the GPU box: bash tools/pmc_config5_traffic.sh -> gpurun_out/pmc_c5/traffic.{json,txt}; copied by hand to profiles/round${RN}_traffic_config5_shard.*)
