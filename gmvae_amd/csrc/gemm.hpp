@@ -398,9 +398,10 @@ __device__ __forceinline__ void split_round(const unsigned short* __restrict__ A
 // is 12 16-byte loads and 12 16-byte LDS stores per thread with no arithmetic, and the images and the piece-product
 // round (split_round) are split3's.  6 x 48 v_mfma_f32_32x32x16_bf16 cycles per 32-deep round: 1536 against 4096.
 // (Measured and dropped: 16-deep rounds in two LDS buffers with one barrier per round and the next fragments read behind
-// it -- 8-25 % SLOWER on the config-5 GEMMs: a k-contiguous operand then arrives as 32-byte pieces of 128-byte lines, and
-// a wave issues at most one MFMA per 32 cycles whatever its neighbour does (tools/micro/mfma_chain.hip), so the second
-// workgroup of a CU hides none of the first one's barrier and staging gaps.)
+// it -- 8-25 % SLOWER on the config-5 GEMMs: a k-contiguous operand then arrives as 32-byte pieces of 128-byte lines and a
+// round's fixed costs are paid twice as often.  Counters of the loop kept (profiles/round3_pmc_config5_mfma.txt): matrix
+// pipes busy 43-46 % of cycles at 2.1 GHz; per workgroup and round 48 KB go into LDS through 16-byte stores (~79 B/clk/CU)
+// and 96 KB of fragments come out -- with two workgroups per CU that is ~2000 LDS cycles beside 1536 matrix cycles.)
 // The per-k scale of an IWAE weight gradient cannot ride on the pieces: the producer writes the planes of the SCALED
 // activation (split_planes' rowscale) and `kscale` only weighs the bias gradient's column sums here.
 template <bool MC>

@@ -47,5 +47,11 @@ int main() {
 #define RUN(NCH, TH) { chains<NCH><<<256, TH>>>(out, cyc, iters); chains<NCH><<<256, TH>>>(out, cyc, iters); hipDeviceSynchronize(); \
     hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost); printf("%d chain(s), %d wave(s) per SIMD: %.1f ticks*ratio = %.1f cycles per MFMA per wave\n", NCH, TH / 256, (double)h[0] / (4.0 * iters), (double)h[0] / (4.0 * iters) * tick); }
   RUN(1, 256) RUN(2, 256) RUN(4, 256) RUN(1, 512) RUN(2, 512) RUN(4, 512)
+  // whole-launch throughput by HIP events (every CU busy): bf16 TFLOP/s with one and with two waves per SIMD
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+#define THR(NCH, TH) { const int it2 = 40000; chains<NCH><<<256, TH>>>(out, cyc, it2); hipEventRecord(e0); chains<NCH><<<256, TH>>>(out, cyc, it2); hipEventRecord(e1); \
+    hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); \
+    printf("%d chain(s), %d wave(s) per SIMD: %.3f ms -> %.0f TFLOP/s bf16 (%.1f ns per MFMA per wave)\n", NCH, TH / 256, ms, 256.0 * (TH / 64) * 4.0 * it2 * 32768.0 / (ms * 1e-3) * 1e-12, ms * 1e6 / (4.0 * it2)); }
+  THR(1, 256) THR(4, 256) THR(1, 512) THR(4, 512)
   return 0;
 }
