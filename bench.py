@@ -458,8 +458,15 @@ def main():
                 for r in csv.DictReader(open(stats[-1])):
                     kern_us[r["Name"]] = float(r["AverageNs"]) * 1e-3
                 roof["rocprof_source"] = os.path.relpath(stats[-1], ROOT) + " (rocprofv3 --kernel-trace --stats of this command; a profiled run is slower than the timed one)"
+            def is_kernel(k, kn):
+                # rocprofv3 names: "gmvae::dw_adam(gmvae::DwArgs)", "void gmvae::mega2_fwd_bwd<0>(gmvae::MegaArgs)", "void gmvae::sk_gemm<1>(...)"
+                if not kn:
+                    return False
+                kn = kn[5:] if kn.startswith("void ") else kn
+                k = k[5:] if k.startswith("void ") else k
+                return k.startswith(kn) and (kn.endswith(">") or kn.endswith("<") or k[len(kn):len(kn) + 1] in ("(", "<", " "))
             kname = ("gmvae::" + dom[0]) if dom[0].startswith(("mega", "dw_")) else SK_KERNELS.get(dom[0])
-            hit = [k for k in kern_us if kname and k.startswith(kname + ("(" if not kname.endswith("<") else ""))]
+            hit = [k for k in kern_us if is_kernel(k, kname)]
             if hit:
                 roof["rocprof_usec_per_launch"] = kern_us[hit[0]]
                 roof["frac_rocprof"] = (roof["bytes_per_launch"] / kern_us[hit[0]] * 1e-3 / PEAK_HBM_GBS if roof["bound"] == "hbm"
@@ -479,7 +486,7 @@ def main():
                 per = {}
                 for nm, _, _, _ in levels:
                     kn = SK_KERNELS.get(nm, "gmvae::" + nm)
-                    k2 = [k for k in tj if k.startswith(kn + "(") or k.startswith(kn + " ") or (kn.endswith("<") and k.startswith(kn))]
+                    k2 = [k for k in tj if is_kernel(k, kn)]
                     if k2:
                         per[nm] = tj[k2[0]]["hbm_bytes_per_launch"]
                 if dom[0] in per:
