@@ -73,6 +73,7 @@ struct Problem {
   long long a_pstride, b_pstride;   // 16-bit elements between the planes of a / b
   unsigned short* C3;      // EPI_BERNOULLI: (sigmoid - x) written as planes [3][M][ldc] of 16-bit pieces (beside or instead of C)
   long long c3_stride;
+  int c3_b16;              // C3 in the blocked-by-16 layout of plane_rounds3: element (m, n) at ((n >> 4) M + m) 16 + (n & 15)
   float* colsum_out;       // bias gradient riding on a dW problem: column sums of operand b over the tile's k
                            // range, written by the tiles of the first tile row to colsum_out[split][n]
   const float* bias;
@@ -426,7 +427,7 @@ __device__ __forceinline__ void plane_rounds(unsigned short* __restrict__ img, c
                                              const uint32_t b_ld, const long long b_ps, const float* __restrict__ kscale,
                                              const bool do_cs, const int m0, const int n0, const int kb, const int NC,
                                              const int tid, const int lane, const int wm0, const int wn0,
-                                             f32x16 (&acc)[2][2], float (&cs8)[8]) {
+                                             f32x16 (&acc)[2][2], float (&cs8)[8], const int dbgf = 0) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   unsigned short* const Ai = img;
   unsigned short* const Bi = img + 3 * kSplitPlane;
@@ -469,14 +470,178 @@ __device__ __forceinline__ void plane_rounds(unsigned short* __restrict__ img, c
 #pragma unroll 1
   for (int c = 0; c < NC; ++c) {
     const bool more = c + 1 < NC;
-    if (more) GMVAE_PL_GLOAD();
+    if (more && !(dbgf & 2)) GMVAE_PL_GLOAD();
     split_round<AMC, BMC>(Ai, Bi, wm0, wn0, lane, false, acc);
     __syncthreads();                              // every wave is done with the only image
-    if (more) GMVAE_PL_LSTORE();
+    if (more && !(dbgf & 4)) GMVAE_PL_LSTORE();
     __syncthreads();
   }
 #undef GMVAE_PL_GLOAD
 #undef GMVAE_PL_LSTORE
+}
+
+// ---- plane rounds, third form: LDS-DMA into a ring of three 16-deep buffers ------------------------------------------
+// Timing experiments on plane_rounds (tools/gemm_planes_dbg.py, results discarded): without its global loads the loop is
+// 17-22 % shorter, without its LDS stores 10 %, without both 25-34 % -- and what is left (fragment reads, MFMAs, two barriers
+// per round) still runs the matrix pipes at ~65 %: the 48 staging registers leave no room to read the next k-step's
+// fragments behind the current MFMAs.  Here nothing is staged through registers:
+//  * the planes lie in memory BLOCKED by 16 along their contiguous dimension ("B16": element (r, c) of a [Rows][Cols] matrix at
+//    ((c >> 4) Rows + r) 16 + (c & 15)), so a [128 mn] x [16 k] tile of a k-contiguous use is ONE contiguous 4 KB piece and
+//    a [16 k] x [128 mn] tile of an mn-contiguous use is eight contiguous 512-byte pieces: every wave-instruction of the
+//    staging moves whole 128-byte lines in both orientations;
+//  * global_load_lds_dwordx4 writes them straight into LDS (1 KB per wave-instruction, 6 per wave and round), three rounds
+//    deep: round c + 3 is requested when round c's buffer has been read by every wave, and waited for two rounds later;
+//  * the LDS position of a chunk inside its 1 KB piece is chosen per lane (the source address is per lane, the
+//    destination is lane order): a k-contiguous image [128][16] swaps the two 16-byte halves of a row in every other
+//    group of 8 rows, an mn-contiguous one [8 column blocks][16 k][16 mn] rotates the k rows of odd blocks by 4 -- both
+//    make the fragment reads (ds_read_b128 / ds_read_b64_tr_b16) bank-conflict-free without padding;
+//  * two sets of fragment registers: the next round's 12 fragments are read behind the round's barrier in the shadow of
+//    its last 12 MFMAs.  One barrier per 24 MFMAs, LDS counter only.
+constexpr int kP3Op = 3 * 2048;                 // 16-bit elements per operand image: 3 planes of 128 x 16
+constexpr int kP3Buf = 2 * kP3Op;               // A | B
+constexpr int kP3Ring = 3;
+
+template <bool MC>
+__device__ __forceinline__ uint32_t p3_src(const int wave, const int lane, const uint32_t rows, const int mn0, const int k0) {
+  const int p = 64 * wave + lane;               // this lane's 16-byte unit of the plane image (lane order = LDS order)
+  if (!MC) {
+    const int row = p >> 1, kh = (p & 1) ^ ((row >> 3) & 1);
+    return ((uint32_t)(k0 >> 4) * rows + (uint32_t)(mn0 + row)) * 16u + 8u * kh;
+  } else {
+    const int blk = p >> 5, kr = (p >> 1) & 15, half = p & 1, k = (kr - 4 * (blk & 1)) & 15;
+    return ((uint32_t)((mn0 >> 4) + blk) * rows + (uint32_t)(k0 + k)) * 16u + 8u * half;
+  }
+}
+
+template <bool MC>
+__device__ __forceinline__ bf16x8_t p3_frag(const unsigned short* __restrict__ op, const int base0, const int base1) {
+  if (!MC) {
+    return *reinterpret_cast<const bf16x8_t*>(op + base0);
+  } else {
+    typedef __attribute__((address_space(3))) s16x4_t* lp;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(op + base0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(op + base1));
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+
+template <bool AMC, bool BMC>
+__device__ __forceinline__ void plane_rounds3(unsigned short* __restrict__ img, const unsigned short* __restrict__ A,
+                                              const uint32_t a_rows, const long long a_ps, const unsigned short* __restrict__ Bp,
+                                              const uint32_t b_rows, const long long b_ps, const float* __restrict__ kscale,
+                                              const bool do_cs, const int m0, const int n0, const int kb, const int NC16,
+                                              const int tid, const int lane, const int wave, const int wm0, const int wn0,
+                                              f32x16 (&acc)[2][2], float (&cs8)[8]) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  // staging: source element offsets of this lane's unit (round 0) and their advance per round
+  uint32_t ea = p3_src<AMC>(wave, lane, a_rows, m0, kb), eb = p3_src<BMC>(wave, lane, b_rows, n0, kb);
+  const uint32_t a_round = AMC ? 256u : 16u * a_rows, b_round = BMC ? 256u : 16u * b_rows;
+  // fragment reads: lane bases inside an operand image (+ 512 i + 2048 plane as immediates)
+  int fa0, fa1, fb0, fb1;
+  {
+    const int l31 = lane & 31, g16 = lane >> 4, i16 = lane & 15;
+    const int kc = (l31)*16 + 8 * ((lane >> 5) ^ ((l31 >> 3) & 1));
+    const int kr0 = 8 * (g16 >> 1) + (i16 >> 2), rot = 4 * (g16 & 1);
+    const int mc0 = (g16 & 1) * 256 + ((kr0 + rot) & 15) * 16 + 4 * (i16 & 3), mc1 = (g16 & 1) * 256 + ((kr0 + 4 + rot) & 15) * 16 + 4 * (i16 & 3);
+    fa0 = AMC ? (wm0 >> 4) * 256 + mc0 : wm0 * 16 + kc;
+    fa1 = AMC ? (wm0 >> 4) * 256 + mc1 : 0;
+    fb0 = BMC ? (wn0 >> 4) * 256 + mc0 : wn0 * 16 + kc;
+    fb1 = BMC ? (wn0 >> 4) * 256 + mc1 : 0;
+  }
+  // column sums (bias gradient; b mn-contiguous): thread (k = tid >> 4, 8 columns 8 (tid & 15)..) reads its chunk back from LDS
+  const int cs_k = tid >> 4, cs_ch = tid & 15;
+  const int cs_off = (cs_ch >> 1) * 256 + ((cs_k + 4 * ((cs_ch >> 1) & 1)) & 15) * 16 + 8 * (cs_ch & 1);
+  int kk = kb + cs_k;
+#define GMVAE_P3_DMA(buf_)                                                                                 \
+  {                                                                                                        \
+    unsigned short* const d_ = img + (buf_) * kP3Buf + wave * 512;                                         \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                     \
+      __builtin_amdgcn_global_load_lds(A + pl * a_ps + ea, d_ + pl * 2048, 16, 0, 0);                      \
+      __builtin_amdgcn_global_load_lds(Bp + pl * b_ps + eb, d_ + kP3Op + pl * 2048, 16, 0, 0);             \
+    }                                                                                                      \
+    ea += a_round; eb += b_round;                                                                          \
+  }
+#define GMVAE_P3_FRAGS(FA_, FB_, buf_)                                                                     \
+  {                                                                                                        \
+    const unsigned short* const ia_ = img + (buf_) * kP3Buf;                                               \
+    const unsigned short* const ib_ = ia_ + kP3Op;                                                         \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                   \
+        FA_[i][pl] = p3_frag<AMC>(ia_ + pl * 2048 + i * 512, fa0, fa1);                                    \
+        FB_[i][pl] = p3_frag<BMC>(ib_ + pl * 2048 + i * 512, fb0, fb1);                                    \
+      }                                                                                                    \
+  }
+#define GMVAE_P3_TILE(FA_, FB_, i_, j_)                                                                    \
+  {                                                                                                        \
+    f32x16 c_ = acc[i_][j_];                                                                               \
+    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA_[i_][0], FB_[j_][2], c_, 0, 0, 0);                     \
+    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA_[i_][2], FB_[j_][0], c_, 0, 0, 0);                     \
+    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA_[i_][1], FB_[j_][1], c_, 0, 0, 0);                     \
+    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA_[i_][0], FB_[j_][1], c_, 0, 0, 0);                     \
+    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA_[i_][1], FB_[j_][0], c_, 0, 0, 0);                     \
+    c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA_[i_][0], FB_[j_][0], c_, 0, 0, 0);                     \
+    acc[i_][j_] = c_;                                                                                      \
+  }
+  // LDS read instructions behind each of a round's last 12 MFMAs: 12 (both k-contiguous), 18 or 24 (both transposing) in all
+  constexpr int kRdA = (AMC ? 1 : 0) + (BMC ? 1 : 0) + 1, kRdB = (AMC ? 1 : 0) + (BMC ? 1 : 0) + ((!AMC && !BMC) ? 1 : 0);
+#define GMVAE_P3_SG(n_) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, n_, 0);
+  // round c_: its fragments are in CUR; buffer bc_ = c_ % 3 holds its images, bn_ = (c_ + 1) % 3 the next round's
+#define GMVAE_P3_ROUND(CA_, CB_, NA_, NB_, c_, bc_, bn_)                                                   \
+  {                                                                                                        \
+    if (BMC && do_cs) {                                                                                    \
+      const unsigned short* const ib_ = img + (bc_) * kP3Buf + kP3Op + cs_off;                             \
+      const u32x4 h_ = *reinterpret_cast<const u32x4*>(ib_), m_ = *reinterpret_cast<const u32x4*>(ib_ + 2048),   \
+                  l_ = *reinterpret_cast<const u32x4*>(ib_ + 4096);                                        \
+      const float sc = kscale ? kscale[kk] : 1.f;                                                          \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+        cs8[2 * q] += sc * ((__uint_as_float(l_[q] << 16) + __uint_as_float(m_[q] << 16)) + __uint_as_float(h_[q] << 16));                            \
+        cs8[2 * q + 1] += sc * ((__uint_as_float(l_[q] & 0xffff0000u) + __uint_as_float(m_[q] & 0xffff0000u)) + __uint_as_float(h_[q] & 0xffff0000u)); \
+      }                                                                                                    \
+      kk += 16;                                                                                            \
+    }                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    GMVAE_P3_TILE(CA_, CB_, 0, 0)                                                                          \
+    GMVAE_P3_TILE(CA_, CB_, 0, 1)                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if ((c_) + 2 < NC16) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");          \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
+    if ((c_) + 3 < NC16) GMVAE_P3_DMA(bc_)                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    /* the next round's fragments, one (k-contiguous) or two (transposing) LDS reads behind each of the last 12 MFMAs; */ \
+    /* in the last round they read a buffer nobody uses (unconditional: the reads and the MFMAs stay one block) */        \
+    GMVAE_P3_FRAGS(NA_, NB_, bn_)                                                                          \
+    GMVAE_P3_TILE(CA_, CB_, 1, 0)                                                                          \
+    GMVAE_P3_TILE(CA_, CB_, 1, 1)                                                                          \
+    GMVAE_P3_SG(kRdA) GMVAE_P3_SG(kRdA) GMVAE_P3_SG(kRdA) GMVAE_P3_SG(kRdA) GMVAE_P3_SG(kRdA) GMVAE_P3_SG(kRdA)            \
+    GMVAE_P3_SG(kRdB) GMVAE_P3_SG(kRdB) GMVAE_P3_SG(kRdB) GMVAE_P3_SG(kRdB) GMVAE_P3_SG(kRdB) GMVAE_P3_SG(kRdB)            \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+  }
+  bf16x8_t fa[2][3], fb[2][3], ga[2][3], gb[2][3];
+  GMVAE_P3_DMA(0)
+  GMVAE_P3_DMA(1)                                // (NC16 >= 2)
+  if (NC16 > 2) {
+    GMVAE_P3_DMA(2)
+    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");    // round 0 has landed, two rounds stay in flight
+  } else {
+    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+  }
+  GMVAE_P3_FRAGS(fa, fb, 0)
+  int bc = 0;                                    // ring position of round c (runtime: three buffers, two fragment sets)
+#pragma unroll 1
+  for (int c = 0; c < NC16; c += 2) {            // (NC16 is even: k ranges are whole 32-deep rounds)
+    const int b1 = bc == 2 ? 0 : bc + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+    GMVAE_P3_ROUND(fa, fb, ga, gb, c, bc, b1)
+    GMVAE_P3_ROUND(ga, gb, fa, fb, c + 1, b1, b2)
+    bc = b2;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (the caller reuses LDS)
+#undef GMVAE_P3_DMA
+#undef GMVAE_P3_FRAGS
+#undef GMVAE_P3_TILE
+#undef GMVAE_P3_ROUND
+#undef GMVAE_P3_SG
 }
 
 // fp32 [rows][ld] (x rowscale[row]) -> three planes of 16-bit pieces hi, mid, lo (truncation splits with exact residuals:
@@ -498,9 +663,10 @@ __global__ __launch_bounds__(256) void split_planes(const float* __restrict__ sr
       const float r2 = r1 - __uint_as_float(mb);
       hi[j] = hb >> 16; mi[j] = mb >> 16; lo[j] = __float_as_uint(r2) >> 16;
     }
-    *reinterpret_cast<u32x4*>(dst + e) = u32x4{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16)};
-    *reinterpret_cast<u32x4*>(dst + pstride + e) = u32x4{mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16)};
-    *reinterpret_cast<u32x4*>(dst + 2 * pstride + e) = u32x4{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16)};
+    const long long o = e;
+    *reinterpret_cast<u32x4*>(dst + o) = u32x4{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16)};
+    *reinterpret_cast<u32x4*>(dst + pstride + o) = u32x4{mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16)};
+    *reinterpret_cast<u32x4*>(dst + 2 * pstride + o) = u32x4{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16)};
   }
 }
 
@@ -960,15 +1126,31 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
       const unsigned short* const Ah = static_cast<const unsigned short*>(a_ptr);
       const unsigned short* const Bh = static_cast<const unsigned short*>(b_ptr);
       const long long a_ps = L.p[pi].a_pstride, b_ps = L.p[pi].b_pstride;
+      static_assert(kP3Ring * kP3Buf * 2 <= C::LDS_FLOATS * 4, "plane_rounds3's ring must fit the kernel's LDS");
+      const int pform = L.p[pi].planes;             // bit 0: natural plane layout (plane_rounds), bit 1: blocked by 16 (plane_rounds3)
+      if (pform & 2) {
+        // (B16 layout: the leading extent of an operand's matrix = its mn extent when k-contiguous, its k extent otherwise)
+        const uint32_t a_rows = a_mc ? (uint32_t)K : (uint32_t)a_n, b_rows = b_mc ? (uint32_t)K : (uint32_t)b_n;
+#define GMVAE_PL3(AMC_, BMC_) \
+  plane_rounds3<AMC_, BMC_>(reinterpret_cast<unsigned short*>(lds), Ah, a_rows, a_ps, Bh, b_rows, b_ps, kscale, do_colsum, m0, n0, kb, \
+                            2 * NC, tid, lane, wave, wm0, wn0, acc, cs8)
+        if (!b_mc) {
+          if (a_mc) GMVAE_PL3(true, false); else GMVAE_PL3(false, false);
+        } else {
+          if (a_mc) GMVAE_PL3(true, true); else GMVAE_PL3(false, true);
+        }
+#undef GMVAE_PL3
+      } else {
 #define GMVAE_PL(AMC_, BMC_) \
   plane_rounds<AMC_, BMC_>(reinterpret_cast<unsigned short*>(lds), Ah, (uint32_t)a_ld, a_ps, Bh, (uint32_t)b_ld, b_ps, kscale, \
-                           do_colsum, m0, n0, kb, NC, tid, lane, wm0, wn0, acc, cs8)
-      if (!b_mc) {
-        if (a_mc) GMVAE_PL(true, false); else GMVAE_PL(false, false);
-      } else {
-        if (a_mc) GMVAE_PL(true, true); else GMVAE_PL(false, true);
-      }
+                           do_colsum, m0, n0, kb, NC, tid, lane, wm0, wn0, acc, cs8, pform >> 4)
+        if (!b_mc) {
+          if (a_mc) GMVAE_PL(true, false); else GMVAE_PL(false, false);
+        } else {
+          if (a_mc) GMVAE_PL(true, true); else GMVAE_PL(false, true);
+        }
 #undef GMVAE_PL
+      }
       if (do_colsum) did_planes = true;
       if (sgi == 0) GMVAE_GSTAMP(1);
       continue;
@@ -1200,6 +1382,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
     const int ldx = L.p[pi].ldx, x_div = L.p[pi].x_div, nparts = L.p[pi].nparts;
     unsigned short* const C3 = L.p[pi].C3;         // (only set for launches whose tiles are all interior: planes_eligible)
     const long long c3s = L.p[pi].c3_stride;
+    const bool c3_b16 = L.p[pi].c3_b16 != 0;       // planes blocked by 16 along n (plane_rounds3's layout)
     if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && (!Cout || al16(Cout)) && al16(bias) && (!bias2 || al16(bias2)) && (ldx & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(xp) & 3) == 0) {
       // interior tile: the bias quad once, the 4 target bytes of a pass as one word; every pass's target word AND staged
@@ -1253,7 +1436,8 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
             const float r2 = r1 - __uint_as_float(mb);
             hi[j] = hb >> 16; mi[j] = mb >> 16; lo[j] = __float_as_uint(r2) >> 16;
           }
-          unsigned short* const d3 = C3 + (long long)(m0 + row) * ldc + nb;
+          unsigned short* const d3 = c3_b16 ? C3 + ((long long)(nb >> 4) * M + (m0 + row)) * 16 + (nb & 15)
+                                            : C3 + (long long)(m0 + row) * ldc + nb;
           *reinterpret_cast<uint2*>(d3) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
           *reinterpret_cast<uint2*>(d3 + c3s) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
           *reinterpret_cast<uint2*>(d3 + 2 * c3s) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
@@ -1319,6 +1503,41 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
   GMVAE_GSTAMP(4);
   if (L.dbg && tid == 0) L.dbg[(size_t)blockIdx.x * 8 + 5] = pi;
 #undef GMVAE_GSTAMP
+}
+
+// The same split into plane_rounds3's layout: planes blocked by 16 along the contiguous dimension -- element (r, c) of the
+// [rows][ld] source at ((c >> 4) rows + r) 16 + (c & 15).  One thread per (row, 16-column block), rows fastest: a wave writes
+// 2 KB contiguous per plane and reads 64-byte pieces of consecutive rows (ld a multiple of 16).
+__global__ __launch_bounds__(256) void split_planes_b16(const float* __restrict__ src, const float* __restrict__ rowscale,
+                                                         const int ld, const int rows, unsigned short* __restrict__ dst,
+                                                         const long long pstride) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const long long items = (long long)rows * (ld >> 4);
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
+    const long long cb = it / rows, r = it - cb * rows;
+    const float* const sp = src + r * ld + cb * 16;
+    const float sc = rowscale ? rowscale[r] : 1.f;
+    f32x4 q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = *reinterpret_cast<const f32x4*>(sp + 4 * j);
+    unsigned hi[16], mi[16], lo[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float v = q[j >> 2][j & 3] * sc;
+      const unsigned hb = __float_as_uint(v) & 0xffff0000u;
+      const float r1 = v - __uint_as_float(hb);
+      const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+      const float r2 = r1 - __uint_as_float(mb);
+      hi[j] = hb >> 16; mi[j] = mb >> 16; lo[j] = __float_as_uint(r2) >> 16;
+    }
+    unsigned short* const dp = dst + it * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<u32x4*>(dp + 8 * h) = u32x4{hi[8 * h] | (hi[8 * h + 1] << 16), hi[8 * h + 2] | (hi[8 * h + 3] << 16), hi[8 * h + 4] | (hi[8 * h + 5] << 16), hi[8 * h + 6] | (hi[8 * h + 7] << 16)};
+      *reinterpret_cast<u32x4*>(dp + pstride + 8 * h) = u32x4{mi[8 * h] | (mi[8 * h + 1] << 16), mi[8 * h + 2] | (mi[8 * h + 3] << 16), mi[8 * h + 4] | (mi[8 * h + 5] << 16), mi[8 * h + 6] | (mi[8 * h + 7] << 16)};
+      *reinterpret_cast<u32x4*>(dp + 2 * pstride + 8 * h) = u32x4{lo[8 * h] | (lo[8 * h + 1] << 16), lo[8 * h + 2] | (lo[8 * h + 3] << 16), lo[8 * h + 4] | (lo[8 * h + 5] << 16), lo[8 * h + 6] | (lo[8 * h + 7] << 16)};
+    }
+  }
 }
 
 }  // namespace gmvae

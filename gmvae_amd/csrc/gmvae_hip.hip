@@ -483,6 +483,21 @@ static bool big_eligible(const Launch& L) {
   return true;
 }
 
+// layout of the plane operands and the loop that reads them: 2 = blocked by 16 along the contiguous dimension, LDS-DMA ring
+// (gemm.hpp plane_rounds3); 1 = natural row-major planes staged through registers (plane_rounds).  GMVAE_PLANES_FORM picks.
+static int planes_form() {
+  const int f = env_cfg("GMVAE_PLANES_FORM", 2);
+  return f == 1 ? 1 : 2;
+}
+
+static int grid_for(long long items, int per_block, int cap = 4096);
+static void launch_split(hipStream_t st, int form, const float* src, const float* rowscale, int ld, long long n, unsigned short* dst) {
+  if (form == 2)
+    hipLaunchKernelGGL(split_planes_b16, dim3(grid_for(n / 16, 256, 16384)), dim3(256), 0, st, src, rowscale, ld, (int)(n / ld), dst, n);
+  else
+    hipLaunchKernelGGL(split_planes, dim3(grid_for(n, 2048, 8192)), dim3(256), 0, st, src, rowscale, ld, n, dst, n);
+}
+
 // every problem of the launch reads pre-split operands (gemm.hpp plane_rounds): interior 128 x 128 tiles, whole 32-deep
 // rounds, 16-byte chunks of eight 16-bit pieces
 static bool planes_eligible(const Launch& L) {
@@ -491,6 +506,7 @@ static bool planes_eligible(const Launch& L) {
     if (!p.planes || p.xbf16 || p.nseg != 1 || p.M % 128 || p.N % 128) return false;
     const Segment& sg = p.seg[0];
     if (sg.a.row_div != 1 || sg.b.row_div != 1 || sg.a.n_mn < p.M || sg.b.n_mn < p.N || sg.K % 32) return false;
+    if ((p.planes & 2) && (sg.a.ld % 16 || sg.b.ld % 16)) return false;
     if (sg.a.ld % 8 || sg.b.ld % 8 || (reinterpret_cast<uintptr_t>(sg.a.ptr) & 15) || (reinterpret_cast<uintptr_t>(sg.b.ptr) & 15)) return false;
     if ((p.a_pstride & 7) || (p.b_pstride & 7)) return false;
     if (p.colsum_out && sg.b.k_contig) return false;
@@ -637,7 +653,7 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
 }
 static int cfg_bn(int cfg) { return cfg == 2 ? CfgL::BN : ((cfg == 1 || cfg == 3) ? CfgM::BN : CfgS::BN); }
 
-static int grid_for(long long items, int per_block, int cap = 4096) {
+static int grid_for(long long items, int per_block, int cap) {
   long long g = (items + per_block - 1) / per_block;
   if (g < 1) g = 1;
   if (g > cap) g = cap;
@@ -1421,6 +1437,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   const float c = d.raw_sigma_bias, smin = d.sigma_min;
   hipStream_t st = cx.st;
   const bool planes = planes_ok(d, L) && w.hd3 != nullptr;
+  const int pform = planes_form();
 
   // ---- noise (fast mode): Philox for eps and u -- its own launch in the general schedule, auxiliary
   // workgroups of the first GEMM launch in the fused one
@@ -1538,13 +1555,14 @@ static int run_step(Ctx& cx, const StepArgs& a) {
         // both operands as planes of 16-bit pieces (the weight's are shared with the data gradient below), (sigmoid - x)
         // leaves as planes only: its two consumers are plane GEMMs
         const long long nh = (long long)R * Dn.dim[i], nw = (long long)Dn.dim[i] * D;
-        hipLaunchKernelGGL(split_planes, dim3(grid_for(nh, 2048, 8192)), dim3(256), 0, st, in, (const float*)nullptr, Dn.dim[i], nh, w.hd3, nh);
-        hipLaunchKernelGGL(split_planes, dim3(grid_for(nw, 2048, 8192)), dim3(256), 0, st, P + Dn.w[i], (const float*)nullptr, D, nw, w.w3, nw);
+        const int b16 = pform == 2;
+        launch_split(st, pform, in, nullptr, Dn.dim[i], nh, w.hd3);
+        launch_split(st, pform, P + Dn.w[i], nullptr, D, nw, w.w3);
         rowk(cx, "split_planes");
         p.seg[0].a.ptr = w.hd3; p.seg[0].b.ptr = w.w3;
-        p.planes = 1; p.a_pstride = nh; p.b_pstride = nw;
+        p.planes = pform; p.a_pstride = nh; p.b_pstride = nw;
         p.C = nullptr;
-        p.C3 = a.backward ? w.g3 : nullptr; p.c3_stride = (long long)R * D;
+        p.C3 = a.backward ? w.g3 : nullptr; p.c3_stride = (long long)R * D; p.c3_b16 = b16;
       }
       g.add(p);
       const int bn = cfg_bn(launch_group(cx, g, "fwd_dec_bernoulli"));
@@ -1605,14 +1623,14 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     if (top && planes) {
       const long long nh = (long long)R * Dn.dim[i], nw = (long long)Dn.dim[i] * D, ng = (long long)R * D;
       if (rwS) {           // IWAE: the row weights ride on the activation's pieces (they cannot scale pieces inside the loop)
-        hipLaunchKernelGGL(split_planes, dim3(grid_for(nh, 2048, 8192)), dim3(256), 0, st, act, rwS, Dn.dim[i], nh, w.hd3, nh);
+        launch_split(st, pform, act, rwS, Dn.dim[i], nh, w.hd3);
         rowk(cx, "split_planes_rw");
       }
       Problem pw3 = pw;
       pw3.seg[0].a.ptr = w.hd3; pw3.seg[0].b.ptr = w.g3;
-      pw3.planes = 1; pw3.a_pstride = nh; pw3.b_pstride = ng;      // (seg[0].kscale = rwS now only weighs the column sums)
+      pw3.planes = pform; pw3.a_pstride = nh; pw3.b_pstride = ng;      // (seg[0].kscale = rwS now only weighs the column sums)
       p.seg[0].a.ptr = w.g3; p.seg[0].b.ptr = w.w3;
-      p.planes = 1; p.a_pstride = ng; p.b_pstride = nw;
+      p.planes = pform; p.a_pstride = ng; p.b_pstride = nw;
       g.add(pw3);
     } else {
       g.add(pw);
@@ -1947,11 +1965,10 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
     if (na % 8 || nb % 8) return GMVAE_E_DIMS;
     if (na > cap_a) { if (pa) hipFree(pa); if (hipMalloc(&pa, 3 * na * 2) != hipSuccess) return GMVAE_E_ALIGN; cap_a = na; }
     if (nb > cap_b) { if (pb) hipFree(pb); if (hipMalloc(&pb, 3 * nb * 2) != hipSuccess) return GMVAE_E_ALIGN; cap_b = nb; }
+    const int pform = planes_form();
     if (cfg == 4) {
-      hipLaunchKernelGGL(split_planes, dim3(grid_for((long long)na, 2048, 8192)), dim3(256), 0, cx.st, static_cast<const float*>(A),
-                         (const float*)nullptr, trans == 2 ? M : K, (long long)na, pa, (long long)na);
-      hipLaunchKernelGGL(split_planes, dim3(grid_for((long long)nb, 2048, 8192)), dim3(256), 0, cx.st, W, (const float*)nullptr,
-                         trans == 1 ? K : N, (long long)nb, pb, (long long)nb);
+      launch_split(cx.st, pform, static_cast<const float*>(A), nullptr, trans == 2 ? M : K, (long long)na, pa);
+      launch_split(cx.st, pform, W, nullptr, trans == 1 ? K : N, (long long)nb, pb);
     }
     Problem p;
     const float* fa = reinterpret_cast<const float*>(pa);
@@ -1959,7 +1976,8 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
     if (trans == 0) p = p_nn(fa, false, K, fb, N, M, N, K, C, N, bias, relu != 0);
     else if (trans == 1) p = p_nt(fa, K, fb, K, M, N, K, C, N, nullptr, 0);
     else p = p_tn(fa, false, M, 1, fb, N, M, N, K, C, bias ? C + (size_t)M * N : nullptr, splitk, (long long)(M + 1) * N, nullptr);
-    p.planes = 1; p.a_pstride = (long long)na; p.b_pstride = (long long)nb;
+    p.planes = pform | (env_cfg("GMVAE_PLANES_DBG", 0) << 4);     // (timing experiments: 2 = no global loads, 4 = no LDS stores in the loop)
+    p.a_pstride = (long long)na; p.b_pstride = (long long)nb;
     g.add(p);
     launch_group(cx, g, "gemm_test_planes", 2);
     return cx.err;
