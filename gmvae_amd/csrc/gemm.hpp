@@ -496,7 +496,12 @@ __device__ __forceinline__ void plane_rounds(unsigned short* __restrict__ img, c
 //    group of 8 rows, an mn-contiguous one [8 column blocks][16 k][16 mn] rotates the k rows of odd blocks by 4 -- both
 //    make the fragment reads (ds_read_b128 / ds_read_b64_tr_b16) bank-conflict-free without padding;
 //  * two sets of fragment registers: the next round's 12 fragments are read behind the round's barrier in the shadow of
-//    its last 12 MFMAs.  One barrier per 24 MFMAs, LDS counter only.
+//    its last 12 MFMAs (sched_group_barrier: 2 ds_read_b128 or 3 ds_read_b64_tr_b16 per MFMA; the reads are
+//    UNCONDITIONAL so that they and the MFMAs stay one basic block -- under a uniform `if` the transposing forms ran
+//    1.6x slower).  One barrier per 24 MFMAs, LDS counter only.
+// Timing experiments on this loop (results discarded; 25600x512x3072 / 512x3072x25600, us): whole loop 404 / 429, without
+// the DMAs 347 / 331, with neither DMAs nor fragment reads nor barriers 307 / 306 -- the MFMA stream, the tile prologue /
+// epilogue and the tail of a launch whose tiles are no multiple of the 512 resident workgroups (800 tiles: 1.56 waves).
 constexpr int kP3Op = 3 * 2048;                 // 16-bit elements per operand image: 3 planes of 128 x 16
 constexpr int kP3Buf = 2 * kP3Op;               // A | B
 constexpr int kP3Ring = 3;
@@ -584,8 +589,10 @@ __device__ __forceinline__ void plane_rounds3(unsigned short* __restrict__ img, 
     c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA_[i_][0], FB_[j_][0], c_, 0, 0, 0);                     \
     acc[i_][j_] = c_;                                                                                      \
   }
-  // LDS read instructions behind each of a round's last 12 MFMAs: 12 (both k-contiguous), 18 or 24 (both transposing) in all
-  constexpr int kRdA = (AMC ? 1 : 0) + (BMC ? 1 : 0) + 1, kRdB = (AMC ? 1 : 0) + (BMC ? 1 : 0) + ((!AMC && !BMC) ? 1 : 0);
+  // LDS read instructions behind the first of a round's last 12 MFMAs -- 12 ds_read_b128 (both k-contiguous): 2 behind each of
+  // 6; 6 + 12 ds_read_b64_tr_b16: 3 behind each of 6; 24 transposing: 3 behind each of 8 (the rates MI355X_MICROARCH.md gives
+  // as free beside an MFMA) -- so that the last reads have 4-6 MFMAs to land before the next round multiplies them
+  constexpr int kRdA = (AMC || BMC) ? 3 : 2, kRdB = (AMC && BMC) ? 3 : 0;
 #define GMVAE_P3_SG(n_) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, n_, 0);
   // round c_: its fragments are in CUR; buffer bc_ = c_ % 3 holds its images, bn_ = (c_ + 1) % 3 the next round's
 #define GMVAE_P3_ROUND(CA_, CB_, NA_, NB_, c_, bc_, bn_)                                                   \
@@ -615,7 +622,7 @@ __device__ __forceinline__ void plane_rounds3(unsigned short* __restrict__ img, 
     GMVAE_P3_TILE(CA_, CB_, 1, 0)                                                                          \
     GMVAE_P3_TILE(CA_, CB_, 1, 1)                                                                          \
     GMVAE_P3_SG(kRdA) GMVAE_P3_SG(kRdA) GMVAE_P3_SG(kRdA) GMVAE_P3_SG(kRdA) GMVAE_P3_SG(kRdA) GMVAE_P3_SG(kRdA)            \
-    GMVAE_P3_SG(kRdB) GMVAE_P3_SG(kRdB) GMVAE_P3_SG(kRdB) GMVAE_P3_SG(kRdB) GMVAE_P3_SG(kRdB) GMVAE_P3_SG(kRdB)            \
+    GMVAE_P3_SG(kRdB) GMVAE_P3_SG(kRdB) GMVAE_P3_SG(0) GMVAE_P3_SG(0) GMVAE_P3_SG(0) GMVAE_P3_SG(0)                        \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
   }
   bf16x8_t fa[2][3], fb[2][3], ga[2][3], gb[2][3];

@@ -10,6 +10,6 @@ if len(sys.argv) > 1:
         print(f"  {name}: {us:8.1f} us", end="")
     print()
 else:
-    for f in ("0", "2", "4", "6"):
+    for f in ("0", "2", "6", "14"):
         print("DBG", f, end=": ", flush=True)
         subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, GMVAE_PLANES_DBG=f))
