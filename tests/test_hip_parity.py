@@ -148,11 +148,14 @@ def test_gemm_big_rounds_instance(H, monkeypatch, trans, M, N, K, ns):
 @pytest.mark.parametrize("trans,M,N,K,ns", [(0, 256, 384, 160, 1), (1, 384, 128, 96, 1), (2, 128, 256, 1024, 2),
                                             (2, 256, 128, 320, 3), (0, 128, 128, 32, 1), (1, 128 * 131, 512, 64, 1),
                                             (2, 512, 128 * 43, 96, 3), (0, 128 * 67, 128 * 16, 64, 1)])
-def test_gemm_plane_rounds_instance(H, trans, M, N, K, ns):
-    """Operands split ONCE into three planes of 16-bit pieces (gemm.hpp split_planes) and multiplied as six exact bf16 piece
-    products with fp32 accumulation (plane_rounds, `cfg` 4 of gmvae_gemm_test): every operand orientation (NN / NT / TN with
-    split-K and the bias-gradient column sums) to fp32-GEMM accuracy against fp64, and no further from it than the fp32 MFMA
-    instance is."""
+@pytest.mark.parametrize("form", ["2", "1"])
+def test_gemm_plane_rounds_instance(H, monkeypatch, form, trans, M, N, K, ns):
+    """Operands split ONCE into three planes of 16-bit pieces (gemm.hpp split_planes / split_planes_b16) and multiplied as six
+    exact bf16 piece products with fp32 accumulation (`cfg` 4 of gmvae_gemm_test) -- form 2: planes blocked by 16, LDS-DMA ring
+    (plane_rounds3, the default); form 1: row-major planes staged through registers (plane_rounds) -- every operand orientation
+    (NN / NT / TN with split-K and the bias-gradient column sums) to fp32-GEMM accuracy against fp64, and no further from it
+    than the fp32 MFMA instance is."""
+    monkeypatch.setenv("GMVAE_PLANES_FORM", form)
     L = _L()
     rng = np.random.default_rng(M + 3 * N + 7 * K + trans)
     if trans == 0:
@@ -314,13 +317,15 @@ def test_big_round_gemm_inside_the_step_iwae(H, monkeypatch, model):
 
 
 @pytest.mark.parametrize("model,S,hidden", [(O.MODEL_GMVAE, 4, (128,)), (O.MODEL_VAE, 1, (64, 128)), (O.MODEL_VAE_GMP, 2, (128,))])
-def test_plane_gemms_inside_the_step(H, monkeypatch, model, S, hidden):
+@pytest.mark.parametrize("form", ["2", "1"])
+def test_plane_gemms_inside_the_step(H, monkeypatch, form, model, S, hidden):
     """The top decoder layer's three GEMMs on pre-split operands (gemm.hpp plane_rounds; by default from 4096 rows, forced
     here at R = B*S = 128 / 256 rows, H = 128, D = 256): the hidden activation and the weight split by split_planes,
     (sigmoid - x) written as planes by the Bernoulli epilogue, the IWAE row weights riding on the activation's pieces and
     weighing the bias gradient's column sums -- against the oracle at the step's gates, NOT bit-identical to the fp32 MFMA
     instance (evidence that the path ran) and as close to it as fp32 rounding."""
     monkeypatch.setenv("GMVAE_PLANES_MINROWS", "128")
+    monkeypatch.setenv("GMVAE_PLANES_FORM", form)
     d = O.Dims(D=256, L=64, K=10, hidden=hidden, S=S)
     rng = np.random.default_rng(6)
     p = O.init_params(model, d, rng)
