@@ -1513,37 +1513,38 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
 }
 
 // The same split into plane_rounds3's layout: planes blocked by 16 along the contiguous dimension -- element (r, c) of the
-// [rows][ld] source at ((c >> 4) rows + r) 16 + (c & 15).  One thread per (row, 16-column block), rows fastest: a wave writes
-// 2 KB contiguous per plane and reads 64-byte pieces of consecutive rows (ld a multiple of 16).
+// [rows][ld] source at ((c >> 4) rows + r) 16 + (c & 15).  A wave takes 16 rows x 32 columns (two blocks): lane l reads the 8
+// floats (row l >> 2, columns 8 (l & 3)..) -- 4 lanes cover one whole 128-byte line -- and writes ONE 16-byte chunk per plane;
+// a store instruction of the wave then covers two contiguous 512-byte pieces (rows % 16 == 0, ld % 16 == 0; the upper block of
+// a 16-column remainder is masked).
 __global__ __launch_bounds__(256) void split_planes_b16(const float* __restrict__ src, const float* __restrict__ rowscale,
                                                          const int ld, const int rows, unsigned short* __restrict__ dst,
                                                          const long long pstride) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  const long long items = (long long)rows * (ld >> 4);
-  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long long)gridDim.x * 256) {
-    const long long cb = it / rows, r = it - cb * rows;
-    const float* const sp = src + r * ld + cb * 16;
+  const int npair = (ld + 31) >> 5, ngrp = rows >> 4, lane = threadIdx.x & 63;
+  const long long waves = (long long)ngrp * npair;
+  for (long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < waves; wv += (long long)gridDim.x * 4) {
+    const long long cp = wv / ngrp, rg = wv - cp * ngrp;       // row groups fastest: consecutive waves write consecutive pieces
+    const long long r = rg * 16 + (lane >> 2);
+    const int c = (int)cp * 32 + 8 * (lane & 3);
+    if (c >= ld) continue;
+    const float* const sp = src + r * ld + c;
     const float sc = rowscale ? rowscale[r] : 1.f;
-    f32x4 q[4];
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(sp), q1 = *reinterpret_cast<const f32x4*>(sp + 4);
+    const float v[8] = {q0.x * sc, q0.y * sc, q0.z * sc, q0.w * sc, q1.x * sc, q1.y * sc, q1.z * sc, q1.w * sc};
+    unsigned hi[8], mi[8], lo[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) q[j] = *reinterpret_cast<const f32x4*>(sp + 4 * j);
-    unsigned hi[16], mi[16], lo[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float v = q[j >> 2][j & 3] * sc;
-      const unsigned hb = __float_as_uint(v) & 0xffff0000u;
-      const float r1 = v - __uint_as_float(hb);
+    for (int j = 0; j < 8; ++j) {
+      const unsigned hb = __float_as_uint(v[j]) & 0xffff0000u;
+      const float r1 = v[j] - __uint_as_float(hb);
       const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
       const float r2 = r1 - __uint_as_float(mb);
       hi[j] = hb >> 16; mi[j] = mb >> 16; lo[j] = __float_as_uint(r2) >> 16;
     }
-    unsigned short* const dp = dst + it * 16;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      *reinterpret_cast<u32x4*>(dp + 8 * h) = u32x4{hi[8 * h] | (hi[8 * h + 1] << 16), hi[8 * h + 2] | (hi[8 * h + 3] << 16), hi[8 * h + 4] | (hi[8 * h + 5] << 16), hi[8 * h + 6] | (hi[8 * h + 7] << 16)};
-      *reinterpret_cast<u32x4*>(dp + pstride + 8 * h) = u32x4{mi[8 * h] | (mi[8 * h + 1] << 16), mi[8 * h + 2] | (mi[8 * h + 3] << 16), mi[8 * h + 4] | (mi[8 * h + 5] << 16), mi[8 * h + 6] | (mi[8 * h + 7] << 16)};
-      *reinterpret_cast<u32x4*>(dp + 2 * pstride + 8 * h) = u32x4{lo[8 * h] | (lo[8 * h + 1] << 16), lo[8 * h + 2] | (lo[8 * h + 3] << 16), lo[8 * h + 4] | (lo[8 * h + 5] << 16), lo[8 * h + 6] | (lo[8 * h + 7] << 16)};
-    }
+    unsigned short* const dp = dst + ((long long)(c >> 4) * rows + r) * 16 + (c & 15);
+    *reinterpret_cast<u32x4*>(dp) = u32x4{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16)};
+    *reinterpret_cast<u32x4*>(dp + pstride) = u32x4{mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16)};
+    *reinterpret_cast<u32x4*>(dp + 2 * pstride) = u32x4{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16)};
   }
 }
 

@@ -493,7 +493,7 @@ static int planes_form() {
 static int grid_for(long long items, int per_block, int cap = 4096);
 static void launch_split(hipStream_t st, int form, const float* src, const float* rowscale, int ld, long long n, unsigned short* dst) {
   if (form == 2)
-    hipLaunchKernelGGL(split_planes_b16, dim3(grid_for(n / 16, 256, 16384)), dim3(256), 0, st, src, rowscale, ld, (int)(n / ld), dst, n);
+    hipLaunchKernelGGL(split_planes_b16, dim3(grid_for(n / ld / 16 * ((ld + 31) / 32), 4, 16384)), dim3(256), 0, st, src, rowscale, ld, (int)(n / ld), dst, n);
   else
     hipLaunchKernelGGL(split_planes, dim3(grid_for(n, 2048, 8192)), dim3(256), 0, st, src, rowscale, ld, n, dst, n);
 }
