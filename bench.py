@@ -394,7 +394,7 @@ def main():
         dur = (lambda l: l[3]) if have_tl else (lambda l: l[1])
         gemms = [l for l in levels if l[2] > 0]          # launches that do MFMA work (grouped GEMMs, mega kernel)
         dom = max(gemms, key=dur)
-        SK_KERNELS = {"sk_first_layers": "void gmvae::sk_gemm<0>", "sk_q_head_z": "void gmvae::sk_gemm<1>", "sk_dec_hidden": "void gmvae::sk_gemm<2>",
+        SK_KERNELS = {"sk_first_layers": "void gmvae::sk_gemm<0>", "sk_first_layer": "void gmvae::sk_gemm<0>", "sk_q_head_z": "void gmvae::sk_gemm<1>", "sk_dec_hidden": "void gmvae::sk_gemm<2>",
                       "sk_dec_bernoulli": "void gmvae::sk_gemm<3>", "sk_bwd_dhd": "void gmvae::sk_gemm<4>", "sk_bwd_dz_heads": "void gmvae::sk_gemm<5>",
                       "sk_bwd_dhg": "void gmvae::sk_gemm<6>", "sk_y_path": "void gmvae::sk_ypath<", "sk_y_path_bwd": "void gmvae::sk_ybwd<",
                       "sk_dw_adam": "gmvae::sk_dw", "sk_dw": "gmvae::sk_dw"}

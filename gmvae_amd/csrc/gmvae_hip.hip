@@ -195,7 +195,9 @@ static bool mega2_ok(const GmvaeDims& d, int model) {
 static bool skinny_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_SKINNY");
   if (e && atoi(e)) return false;
-  if (model != GMVAE_MODEL_GMVAE || d.n_hidden != 1 || d.S != 1) return false;
+  // GMVAE, and the VAE with the standard-normal prior (no y path: eight launches); the learned mixture prior of VAE_GMP is not
+  // column-local and stays on the general schedule
+  if ((model != GMVAE_MODEL_GMVAE && model != GMVAE_MODEL_VAE) || d.n_hidden != 1 || d.S != 1) return false;
   const int H = d.hidden[0];
   // measured against the general schedule at H = 256 / 512, L = 128 (tools/sk_sweep.py, one box): 2.9x faster at B = 32..64,
   // 2.2x at 256, 1.7x at 512, 1.2 - 1.4x at 1024; not measured beyond
@@ -1321,17 +1323,20 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   hipStream_t st = cx.st;
   static SkArgs s;                               // (host-side scratch, ~1 KB)
   memset(&s, 0, sizeof(s));
-  const NetL &E = L.ency, &G = L.encg, &Dn = L.dec;
+  const bool vae = a.model == GMVAE_MODEL_VAE;
+  // (VAE: the one encoder stands in for both of the GMVAE's: SkArgs::model)
+  const NetL &E = vae ? L.enc : L.ency, &G = vae ? L.enc : L.encg, &Dn = L.dec;
+  s.model = a.model;
   s.B = B; s.D = D; s.H = H; s.L = Lz; s.K = K; s.K4 = (int)pad4(K);
-  s.ns1 = kSkNs1; s.nparts = D / 16;
+  s.ns1 = vae ? 1 : kSkNs1; s.nparts = D / 16;
   s.c = d.raw_sigma_bias; s.smin = d.sigma_min; s.invT = 1.f / d.temperature; s.gen_bias = d.gen_bias_init;
   s.gen_bias_vec = d.gen_bias_vec;
   s.x = a.x; s.P = a.params;
   s.Wy0 = (long long)E.w[0]; s.by0 = (long long)E.b[0]; s.Wy1 = (long long)E.w[1]; s.by1 = (long long)E.b[1];
-  s.Wp = (long long)L.prior.w[0]; s.bp = (long long)L.prior.b[0];
+  if (!vae) { s.Wp = (long long)L.prior.w[0]; s.bp = (long long)L.prior.b[0]; }
   s.Wg0 = (long long)G.w[0]; s.bg0 = (long long)G.b[0]; s.Wg1 = (long long)G.w[1]; s.bg1 = (long long)G.b[1];
   s.Wd0 = (long long)Dn.w[0]; s.bd0 = (long long)Dn.b[0]; s.Wd1 = (long long)Dn.w[1]; s.bd1 = (long long)Dn.b[1];
-  s.s1 = w.sk_s1; s.hy = w.he[1]; s.hg = w.hg[1]; s.y = w.y; s.logits = w.logits; s.nent = w.nent; s.pp = w.pp; s.qp = w.qp;
+  s.s1 = w.sk_s1; s.hy = w.he[1]; s.hg = vae ? w.he[1] : w.hg[1]; s.y = w.y; s.logits = w.logits; s.nent = w.nent; s.pp = w.pp; s.qp = w.qp;
   s.z = w.z; s.hd = w.hd[1]; s.g = w.g; s.part = w.sk_part; s.lqp = w.sk_lqp;
   s.dhd = w.dbuf[0]; s.dqp = w.dqp; s.dpp = w.dpp; s.dhg = w.dbuf[1]; s.dlogits = w.dlogits; s.dhy = w.dbuf[2];
   s.eps = eps; s.u = u; s.eps_w = gen_eps; s.u_w = gen_u; s.gen_eps = gen_eps ? 1 : 0; s.gen_u = gen_u ? 1 : 0;
@@ -1360,9 +1365,14 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
     cx.check();
     cx.mark(name, fl);
   };
+  if (vae) {
+    const int eps_blocks = gen_eps ? (int)(((long long)B * ((Lz + 3) / 4) + kSkThreads - 1) / kSkThreads) : 0;
+    launch(sk_gemm<SK_F1>, (H / 64) * nrt + eps_blocks, kSkThreads, 0, "sk_first_layer", fB * D * H);
+  } else {
   launch(sk_gemm<SK_F1>, (2 * H / 64) * nrt * s.ns1, kSkThreads, 0, "sk_first_layers", fB * D * 2 * H);
   const int eps_blocks = gen_eps ? (int)(((long long)B * ((Lz + 3) / 4) + 255) / 256) : 0;       // extra workgroups: the eps rows
   launch(H <= 512 ? sk_ypath<2> : sk_ypath<4>, B + eps_blocks, 256, 0, "sk_y_path", fB * ((double)H * K + K * H + K * 2.0 * Lz));
+  }
   launch(sk_gemm<SK_F3>, (Lz / 16) * nrt, kSkThreads, 0, "sk_q_head_z", fB * H * 2 * Lz);
   launch(sk_gemm<SK_F4>, (H / 64) * nrt, kSkThreads, 0, "sk_dec_hidden", fB * Lz * H);
   if (empty_mode == 1) launch(sk_gemm<SK_EMPTY>, (H / 64) * nrt, kSkThreads, 0, "sk_empty", 0.0);     // (diagnostic)
@@ -1391,7 +1401,9 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
       add(s.z, false, Lz, s.dhd, H, Lz, H, Dn.w[0], (long long)Dn.b[0]);                                 // dWd0
     }
     if (part == 1 || (part == 2 && !fork)) add(s.hg, false, H, s.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1]);      // dWg1
-    if (part == 2) {
+    if (part == 2 && vae) {
+      add(a.x, true, D, s.dhg, H, D, H, E.w[0], (long long)E.b[0]);                                      // dWe0 (+ dbe0)
+    } else if (part == 2) {
       add(a.x, true, D, s.dhy, H, D, H, E.w[0], (long long)E.b[0]);                                      // dWy0 (+ dby0)
       add(a.x, true, D, s.dhg, H, D, H, G.w[0], (long long)G.b[0]);                                      // dWg0[x] (+ dbg0)
       add(s.y, false, s.K4, s.dhg, H, K, H, G.w[0] + (uint64_t)D * H, -1);                               // dWg0[y]
@@ -1418,7 +1430,7 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
     launch_dw(side, 1, false);
     hipEventRecord(ev_join, side);
   }
-  launch(H <= 512 ? sk_ybwd<2> : sk_ybwd<4>, B, 256, 0, "sk_y_path_bwd", fB * ((double)(H + 2 * Lz) * K + K * H));
+  if (!vae) launch(H <= 512 ? sk_ybwd<2> : sk_ybwd<4>, B, 256, 0, "sk_y_path_bwd", fB * ((double)(H + 2 * Lz) * K + K * H));
   if (fork) hipStreamWaitEvent(st, ev_join, 0);                  // join: the step ends when all three W parts have
   launch_dw(st, 2, true);
   return cx.err;

@@ -37,6 +37,10 @@ struct SkTensor {              // one weight tensor of the W launch
 constexpr int kSkMaxT = 10;
 
 struct SkArgs {
+  int model;                   // 2 GMVAE (ten launches); 0 VAE with the standard-normal prior (scripts/vae.py:167-185): no y path -- F1 is
+                               // the whole first layer (bias + ReLU in its epilogue, the eps rows in extra workgroups), the "y" / "g"
+                               // names below then all mean the one encoder: Wy0 / by0 its first layer, Wg1 / bg1 its head, hy = hg its
+                               // hidden activation, dhg its gradient; pp, dpp, nent, s1 are unused (eight launches)
   int B, D, H, L, K, K4;       // K4 = pad4(K): row stride of y and dlogits
   int ns1, nparts;             // first-layer slabs; logpx partials per row
   float c, smin, invT, gen_bias;
@@ -193,9 +197,27 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
   const int B = a.B, D = a.D, H = a.H, L = a.L;
   const int nrt = (B + 15) >> 4;
   constexpr int NU = (ST == SK_F1 || ST == SK_F4) ? 4 : (ST == SK_F3 || ST == SK_B3) ? 2 : 1;
-  const int nct = ST == SK_F1 ? (2 * H) / 64 : ST == SK_F3 ? L / 16 : ST == SK_F4 ? H / 64 : ST == SK_F5 ? D / 16
+  const bool vae = a.model == 0;
+  const int nct = ST == SK_F1 ? (vae ? H : 2 * H) / 64 : ST == SK_F3 ? L / 16 : ST == SK_F4 ? H / 64 : ST == SK_F5 ? D / 16
                 : ST == SK_B1 ? H / 16 : ST == SK_B2 ? L / 16 : H / 32;
   const int bid = blockIdx.x;
+  if constexpr (ST == SK_F1) {
+    if (bid >= nct * nrt * a.ns1) {               // VAE: extra workgroups draw the eps rows (the GMVAE's ride on F2)
+      const unsigned long long step = a.step_dev ? a.step_dev[0] : a.step;
+      const int qe = (L + 3) / 4;
+      const long long i = (long long)(bid - nct * nrt * a.ns1) * kSkThreads + tid;
+      if (i < (long long)B * qe) {
+        const int r = (int)(i / qe), quad = (int)(i - (long long)r * qe);
+        float nz[4];
+        noise_vals(a.row0 + (unsigned long long)r, (unsigned)quad, false, a.seed, step, nz);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (quad * 4 + j < L) st1o(a.eps_w + (long long)r * L + quad * 4 + j, nz[j]);
+      }
+      return;
+    }
+    if (vae && bid == 0 && tid == 0 && a.step_dev) a.step_dev[1] = a.step_dev[0];     // the copy the W launch reads
+  }
   const int ct = bid % nct, rt = (bid / nct) % nrt, ks = bid / (nct * nrt);
   const int r0 = rt * 16;
   const int rowc = min(r0 + ln, B - 1);           // this lane's activation row (clamped; rows >= B are masked at the stores)
@@ -210,10 +232,12 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
   float pf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float4 pf4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < 256) {
-    if constexpr (ST == SK_F3) {
+    if constexpr (ST == SK_F1) {
+      if (vae) pf4 = *reinterpret_cast<const float4*>(P + a.by0 + ct * 64 + 4 * ec);
+    } else if constexpr (ST == SK_F3) {
       const int l = ct * 16 + ec;
       pf[0] = P[a.bg1 + l]; pf[1] = P[a.bg1 + L + l]; pf[2] = a.eps[rr * L + l];
-      pf[3] = a.pp[rr * 2 * L + l]; pf[4] = a.pp[rr * 2 * L + L + l];
+      if (!vae) { pf[3] = a.pp[rr * 2 * L + l]; pf[4] = a.pp[rr * 2 * L + L + l]; }
     } else if constexpr (ST == SK_F4) {
       pf4 = *reinterpret_cast<const float4*>(P + a.bd0 + ct * 64 + 4 * ec);
     } else if constexpr (ST == SK_F5) {
@@ -226,8 +250,8 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
       pf[0] = a.hg[rr * H + ct * 32 + ec]; pf[1] = a.hg[rr * H + ct * 32 + 16 + ec];
     } else if constexpr (ST == SK_B2) {
       const int l = ct * 16 + ec;
-      pf[0] = a.qp[rr * 2 * L + L + l]; pf[1] = a.z[rr * L + l]; pf[2] = a.pp[rr * 2 * L + l];
-      pf[3] = a.pp[rr * 2 * L + L + l]; pf[4] = a.eps[rr * L + l];
+      pf[0] = a.qp[rr * 2 * L + L + l]; pf[1] = a.z[rr * L + l]; pf[4] = a.eps[rr * L + l];
+      if (!vae) { pf[2] = a.pp[rr * 2 * L + l]; pf[3] = a.pp[rr * 2 * L + L + l]; }
     }
   }
   f32x4 acc[4];
@@ -272,7 +296,10 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     for (int t = 0; t < NU; ++t) v[t] += red[(w * 16 + 4 * t + er) * 64 + el];
   // ---- epilogues
   if constexpr (ST == SK_F1) {
-    if (rok) st4o(a.s1 + ((long long)ks * B + row) * 2 * H + ct * 64 + 4 * ec, make_float4(v[0], v[1], v[2], v[3]));
+    if (vae) {                                    // the whole layer: hidden activation of the encoder (scripts/base.py:47-60,67)
+      if (rok) st4o(a.hy + (long long)row * H + ct * 64 + 4 * ec,
+                    make_float4(fmaxf(v[0] + pf4.x, 0.f), fmaxf(v[1] + pf4.y, 0.f), fmaxf(v[2] + pf4.z, 0.f), fmaxf(v[3] + pf4.w, 0.f)));
+    } else if (rok) st4o(a.s1 + ((long long)ks * B + row) * 2 * H + ct * 64 + 4 * ec, make_float4(v[0], v[1], v[2], v[3]));
   } else if constexpr (ST == SK_F3) {
     // ConditionalNormal heads (scripts/base.py:66-72), z = mu + sigma eps (gmvae.py:248), log q and log p(z|y) terms
     // (gmvae.py:258) of this tile's 16 latent dimensions; row sums over the tile -> lqp[.][tile][row]
@@ -284,10 +311,15 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     const float zz = mu + sg * pf[2];
     const float e = (zz - mu) * __builtin_amdgcn_rcpf(sg);       // from z, not eps (A7)
     float aq = -0.5f * e * e - 0.5f * kLog2Pi - flog(sg);
-    const float mp = pf[3], vp = pf[4] + a.c, ep = fexp(-fabsf(vp)), rp = __builtin_amdgcn_rcpf(1.f + ep);
-    const float sp = fmaxf(fmaxf(vp, 0.f) - flog(rp), a.smin);
-    const float t = (zz - mp) * __builtin_amdgcn_rcpf(sp);
-    float ap = -0.5f * t * t - 0.5f * kLog2Pi - flog(sp);
+    float ap;
+    if (vae) {                                    // standard-normal prior (scripts/vae.py:247-250)
+      ap = -0.5f * zz * zz - 0.5f * kLog2Pi;
+    } else {
+      const float mp = pf[3], vp = pf[4] + a.c, ep = fexp(-fabsf(vp)), rp = __builtin_amdgcn_rcpf(1.f + ep);
+      const float sp = fmaxf(fmaxf(vp, 0.f) - flog(rp), a.smin);
+      const float t = (zz - mp) * __builtin_amdgcn_rcpf(sp);
+      ap = -0.5f * t * t - 0.5f * kLog2Pi - flog(sp);
+    }
     if (rok) { st1o(a.qp + (long long)row * 2 * L + l, mu); st1o(a.qp + (long long)row * 2 * L + L + l, raw); st1o(a.z + (long long)row * L + l, zz); }
     aq = sk_row16_sum(aq); ap = sk_row16_sum(ap);
     if (ec == 0 && rok) { st1o(a.lqp + (long long)ct * B + row, aq); st1o(a.lqp + (long long)(L / 16 + ct) * B + row, ap); }
@@ -319,6 +351,12 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
       const float rawq = pf[0] + a.c, eq = fexp(-fabsf(rawq)), rq = __builtin_amdgcn_rcpf(1.f + eq);
       const float spq = fmaxf(rawq, 0.f) - flog(rq), sg = fmaxf(spq, a.smin);     // softplus, and rq / eq rq = its derivative
       const float zz = pf[1];
+      if (vae) {                                  // standard-normal prior: d(-log p)/dz = z, nothing to send to a prior network
+        const float dmu = v[0] + zz;
+        const float dsg = dmu * pf[4] - __builtin_amdgcn_rcpf(sg);
+        st1o(a.dqp + (long long)row * 2 * L + l, dmu);
+        st1o(a.dqp + (long long)row * 2 * L + L + l, (spq > a.smin) ? dsg * (rawq >= 0.f ? rq : eq * rq) : 0.f);
+      } else {
       const float mp = pf[2], rawp = pf[3] + a.c, ep = fexp(-fabsf(rawp)), rp = __builtin_amdgcn_rcpf(1.f + ep);
       const float spp = fmaxf(rawp, 0.f) - flog(rp), sp = fmaxf(spp, a.smin);
       const float isp = __builtin_amdgcn_rcpf(sp);
@@ -330,6 +368,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
       st1o(a.dqp + (long long)row * 2 * L + L + l, (spq > a.smin) ? dsg * (rawq >= 0.f ? rq : eq * rq) : 0.f);
       st1o(a.dpp + (long long)row * 2 * L + l, -pterm);
       st1o(a.dpp + (long long)row * 2 * L + L + l, (spp > a.smin) ? (1.f - t * t) * isp * (rawp >= 0.f ? rp : ep * rp) : 0.f);
+      }
     }
   }
   SK_STAMP(SLOT, 3);
@@ -688,7 +727,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
         float lpx = 0.f, lq = 0.f, lp = 0.f;
         for (int i = 0; i < a.nparts; ++i) lpx += a.part[(long long)b * a.nparts + i];
         for (int i = 0; i < nlt; ++i) { lq += a.lqp[(long long)i * B + b]; lp += a.lqp[(long long)(nlt + i) * B + b]; }
-        const float ne = a.nent[b];
+        const float ne = a.nent ? a.nent[b] : 0.f;      // (VAE: no entropy term)
         const float lw = lpx + lp - lq - ne;
         a.logpx[b] = lpx; a.logq[b] = lq; a.logp[b] = lp; a.logw[b] = lw;
         a0 -= lw; a1 -= lpx; a2 += lq - lp; a3 += ne;

@@ -611,18 +611,19 @@ class Engine:
         st = buf.reshape(10, 256, 8).astype(np.float64)
         names = ["sk_first_layers", "sk_y_path", "sk_q_head_z", "sk_dec_hidden", "sk_dec_bernoulli", "sk_bwd_dhd", "sk_bwd_dz_heads",
                  "sk_bwd_dhg", "sk_y_path_bwd", "sk_dw_adam"]
-        starts, ends = [], []
+        starts, ends, present = [], [], []
         for i in range(10):
             r = st[i][st[i][:, 0] > 0]
             if not len(r):
-                return None
+                continue                                           # (the VAE has no y path: slots 1 and 8 stay empty)
+            present.append(names[i])
             starts.append(r[:, 0].min())
             ends.append(r[:, 3].max())
-        if not all(starts[i + 1] > starts[i] for i in range(9)):
+        n = len(present)
+        if n < 8 or not all(starts[i + 1] > starts[i] for i in range(n - 1)):
             return None                                            # (stamps of different steps: a launch was mid-flight)
-        step_us = None
         out = []
-        for i in range(10):
-            share = (starts[i + 1] - starts[i]) * 0.01 if i < 9 else None
-            out.append([names[i], (ends[i] - starts[i]) * 0.01, None, share])
+        for i in range(n):
+            share = (starts[i + 1] - starts[i]) * 0.01 if i < n - 1 else None
+            out.append([present[i], (ends[i] - starts[i]) * 0.01, None, share])
         return out

@@ -532,10 +532,15 @@ SKINNY_CASES = [
     ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(192,)), 128),
     ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(256,)), 600),                                  # 38 row tiles, ragged; 10 row chunks in W
     ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,)), 1024),                                 # the largest batch it takes by default
+    # the VAE with the standard-normal prior (scripts/vae.py:167-185): eight launches, no y path
+    ("vae", O.Dims(D=784, L=128, K=1, hidden=(512,)), 64),
+    ("vae", O.Dims(D=784, L=16, K=1, hidden=(512,)), 100),                                       # BASELINE configs[0] at H = 512, ragged
+    ("vae", O.Dims(D=256, L=32, K=1, hidden=(128,), sigma_min=0.7, raw_sigma_bias=0.25, gen_bias_init=0.3), 37),
+    ("vae", O.Dims(D=784, L=64, K=1, hidden=(256,)), 512),
 ]
 
 
-@pytest.mark.parametrize("name,d,B", SKINNY_CASES, ids=[f"D{d.D}-L{d.L}-K{d.K}-H{d.hidden[0]}-B{B}" for _, d, B in SKINNY_CASES])
+@pytest.mark.parametrize("name,d,B", SKINNY_CASES, ids=[f"{n}-D{d.D}-L{d.L}-K{d.K}-H{d.hidden[0]}-B{B}" for n, d, B in SKINNY_CASES])
 def test_skinny_schedule_matches_oracle(H, monkeypatch, name, d, B):
     """The small-batch / wide-layer schedule (csrc/skinny.hpp: 10 launches, register-direct tiles) against the oracle --
     forced where the mega schedule would otherwise take the sizes (H = 64) -- and NOT bit-identical to the general

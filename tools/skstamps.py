@@ -8,7 +8,7 @@ from gmvae_amd import _lib as L
 from gmvae_amd.engine import Engine
 L.check(L.lib.gmvae_debug_sk_stamps(None), "arm")
 e = Engine("gmvae", 784, 128, 10, [512], random_seed=0)
-B, G = 64, 8
+B, G = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), 8
 sx, replay = e.capture_train_step(B, 1e-3, n_steps=G)
 sx.copy_(torch.from_numpy((np.random.default_rng(0).random((G, B, 784)) < 0.87).astype(np.uint8)).cuda())
 for _ in range(300): replay()
