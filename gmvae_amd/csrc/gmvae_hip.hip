@@ -203,7 +203,8 @@ static bool skinny_ok(const GmvaeDims& d, int model) {
   // 2.2x at 256, 1.7x at 512, 1.2 - 1.4x at 1024; not measured beyond
   int maxb = 1024;
   if (const char* mb = getenv("GMVAE_SKINNY_MAXB")) maxb = atoi(mb);
-  return H % 64 == 0 && H <= 1024 && d.D % 16 == 0 && d.L % 16 == 0 && d.L <= 256 && d.K <= 16 && d.B <= maxb;
+  // (L a multiple of 4: 16-byte loads along latent rows; a ragged last tile of 16 latent dimensions is masked)
+  return H % 64 == 0 && H <= 1024 && d.D % 16 == 0 && d.L % 4 == 0 && d.L >= 4 && d.L <= 256 && d.K <= 16 && d.B <= maxb;
 }
 static bool fused_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_FUSED");
@@ -1373,7 +1374,7 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   const int eps_blocks = gen_eps ? (int)(((long long)B * ((Lz + 3) / 4) + 255) / 256) : 0;       // extra workgroups: the eps rows
   launch(H <= 512 ? sk_ypath<2> : sk_ypath<4>, B + eps_blocks, 256, 0, "sk_y_path", fB * ((double)H * K + K * H + K * 2.0 * Lz));
   }
-  launch(sk_gemm<SK_F3>, (Lz / 16) * nrt, kSkThreads, 0, "sk_q_head_z", fB * H * 2 * Lz);
+  launch(sk_gemm<SK_F3>, ((Lz + 15) / 16) * nrt, kSkThreads, 0, "sk_q_head_z", fB * H * 2 * Lz);
   launch(sk_gemm<SK_F4>, (H / 64) * nrt, kSkThreads, 0, "sk_dec_hidden", fB * Lz * H);
   if (empty_mode == 1) launch(sk_gemm<SK_EMPTY>, (H / 64) * nrt, kSkThreads, 0, "sk_empty", 0.0);     // (diagnostic)
   launch(sk_gemm<SK_F5>, (D / 16) * nrt, kSkThreads, 0, "sk_dec_bernoulli", fB * H * D);
@@ -1417,7 +1418,7 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
     cx.mark(part == 0 ? "sk_dw_decoder" : part == 1 ? "sk_dw_enc_gmm1" : (s.ap ? "sk_dw_adam" : "sk_dw"), fw);
   };
   launch(sk_gemm<SK_B1>, (H / 16) * nrt, kSkThreads, 0, "sk_bwd_dhd", fB * D * H);
-  launch(sk_gemm<SK_B2>, (Lz / 16) * nrt, kSkThreads, 0, "sk_bwd_dz_heads", fB * H * Lz);
+  launch(sk_gemm<SK_B2>, ((Lz + 15) / 16) * nrt, kSkThreads, 0, "sk_bwd_dz_heads", fB * H * Lz);
   if (fork) {
     hipEventRecord(ev_fork[0], st);
     hipStreamWaitEvent(side, ev_fork[0], 0);

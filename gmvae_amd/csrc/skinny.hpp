@@ -82,22 +82,26 @@ __device__ __forceinline__ void sk_groups(const int kg_lo, const int kg_hi, cons
   if (n - done >= 1) body(std::integral_constant<int, 1>{}, kg + kSkWaves * done);
 }
 // NN, 4 strided column tiles: out[row][n0 + 4 i + t] for lane column i: W k-major [K][ldw], one 16-byte load of W per k
-template <bool U8>
+// MK: the contraction extent kmax is no multiple of 16 (a multiple of 4): quads at k >= kmax are loaded from the last valid quad
+// (clamped address, branch-free) and their A values replaced by 0
+template <bool U8, bool MK = false>
 __device__ __forceinline__ void sk_nn4(const void* __restrict__ Ap, const long long arow, const float* __restrict__ W, const int ldw,
                                        const int ncol, const int kg_lo, const int kg_hi, const int wave, const int lk,
-                                       f32x4 (&acc)[4]) {
+                                       f32x4 (&acc)[4], const int kmax = 0) {
   sk_groups(kg_lo, kg_hi, wave, [&](auto ng, const int kgb) {
     constexpr int NG = decltype(ng)::value;
     float4 av[NG], bv[NG][4];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const int k = 16 * (kgb + g * kSkWaves) + 4 * lk;
+      const int k0 = 16 * (kgb + g * kSkWaves) + 4 * lk;
+      const int k = MK ? min(k0, kmax - 4) : k0;
       if constexpr (U8) {
         const unsigned w = *reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(Ap) + arow + k);
         av[g] = make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
       } else {
         av[g] = *reinterpret_cast<const float4*>(static_cast<const float*>(Ap) + arow + k);
       }
+      if (MK && k0 >= kmax) av[g] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int q = 0; q < 4; ++q) bv[g][q] = *reinterpret_cast<const float4*>(W + (long long)(k + q) * ldw + ncol);
     }
@@ -145,17 +149,19 @@ __device__ __forceinline__ void sk_nnp(const float* __restrict__ A, const long l
   });
 }
 // NT (data gradients): out[row][j] = sum_c A[row][c] W[j][c], W rows contraction-contiguous: 16-byte loads of both
-template <int NU>
+template <int NU, bool MK = false>
 __device__ __forceinline__ void sk_nt(const float* __restrict__ A, const long long arow, const float* __restrict__ W, const int ldw,
                                       const int (&wrow)[NU], const int kg_lo, const int kg_hi, const int wave, const int lk,
-                                      f32x4 (&acc)[4]) {
+                                      f32x4 (&acc)[4], const int kmax = 0) {
   sk_groups(kg_lo, kg_hi, wave, [&](auto ng, const int kgb) {
     constexpr int NG = decltype(ng)::value;
     float4 av[NG], bv[NG][NU];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const int k = 16 * (kgb + g * kSkWaves) + 4 * lk;
+      const int k0 = 16 * (kgb + g * kSkWaves) + 4 * lk;
+      const int k = MK ? min(k0, kmax - 4) : k0;
       av[g] = *reinterpret_cast<const float4*>(A + arow + k);
+      if (MK && k0 >= kmax) av[g] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int t = 0; t < NU; ++t) bv[g][t] = *reinterpret_cast<const float4*>(W + (long long)wrow[t] * ldw + k);
     }
@@ -198,8 +204,8 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
   const int nrt = (B + 15) >> 4;
   constexpr int NU = (ST == SK_F1 || ST == SK_F4) ? 4 : (ST == SK_F3 || ST == SK_B3) ? 2 : 1;
   const bool vae = a.model == 0;
-  const int nct = ST == SK_F1 ? (vae ? H : 2 * H) / 64 : ST == SK_F3 ? L / 16 : ST == SK_F4 ? H / 64 : ST == SK_F5 ? D / 16
-                : ST == SK_B1 ? H / 16 : ST == SK_B2 ? L / 16 : H / 32;
+  const int nct = ST == SK_F1 ? (vae ? H : 2 * H) / 64 : ST == SK_F3 ? (L + 15) / 16 : ST == SK_F4 ? H / 64 : ST == SK_F5 ? D / 16
+                : ST == SK_B1 ? H / 16 : ST == SK_B2 ? (L + 15) / 16 : H / 32;
   const int bid = blockIdx.x;
   if constexpr (ST == SK_F1) {
     if (bid >= nct * nrt * a.ns1) {               // VAE: extra workgroups draw the eps rows (the GMVAE's ride on F2)
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     if constexpr (ST == SK_F1) {
       if (vae) pf4 = *reinterpret_cast<const float4*>(P + a.by0 + ct * 64 + 4 * ec);
     } else if constexpr (ST == SK_F3) {
-      const int l = ct * 16 + ec;
+      const int l = min(ct * 16 + ec, L - 1);      // (a ragged last tile of latent dimensions: clamped here, masked at the stores)
       pf[0] = P[a.bg1 + l]; pf[1] = P[a.bg1 + L + l]; pf[2] = a.eps[rr * L + l];
       if (!vae) { pf[3] = a.pp[rr * 2 * L + l]; pf[4] = a.pp[rr * 2 * L + L + l]; }
     } else if constexpr (ST == SK_F4) {
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     } else if constexpr (ST == SK_B3) {
       pf[0] = a.hg[rr * H + ct * 32 + ec]; pf[1] = a.hg[rr * H + ct * 32 + 16 + ec];
     } else if constexpr (ST == SK_B2) {
-      const int l = ct * 16 + ec;
+      const int l = min(ct * 16 + ec, L - 1);
       pf[0] = a.qp[rr * 2 * L + L + l]; pf[1] = a.z[rr * L + l]; pf[4] = a.eps[rr * L + l];
       if (!vae) { pf[2] = a.pp[rr * 2 * L + l]; pf[3] = a.pp[rr * 2 * L + L + l]; }
     }
@@ -263,10 +269,12 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     const float* W = c0 < H ? P + a.Wy0 + c0 : P + a.Wg0 + (c0 - H);
     sk_nn4<true>(a.x, (long long)rowc * D, W, H, 4 * ln, kg_lo, kg_hi, wave, lk, acc);
   } else if constexpr (ST == SK_F3) {
-    const int col[2] = {ct * 16 + ln, L + ct * 16 + ln};
+    const int lc = min(ct * 16 + ln, L - 1);
+    const int col[2] = {lc, L + lc};
     sk_nnp<2>(a.hg, (long long)rowc * H, P + a.Wg1, 2 * L, col, 0, H / 16, wave, lk, acc);
   } else if constexpr (ST == SK_F4) {
-    sk_nn4<false>(a.z, (long long)rowc * L, P + a.Wd0 + ct * 64, H, 4 * ln, 0, L / 16, wave, lk, acc);
+    if (L & 15) sk_nn4<false, true>(a.z, (long long)rowc * L, P + a.Wd0 + ct * 64, H, 4 * ln, 0, (L + 15) / 16, wave, lk, acc, L);
+    else sk_nn4<false>(a.z, (long long)rowc * L, P + a.Wd0 + ct * 64, H, 4 * ln, 0, L / 16, wave, lk, acc);
   } else if constexpr (ST == SK_F5) {             // 16-column tiles: D / 16 x row tiles workgroups (the widest layer on the most CUs)
     const int col[1] = {ct * 16 + ln};
     sk_nnp<1>(a.hd, (long long)rowc * H, P + a.Wd1, D, col, 0, H / 16, wave, lk, acc);
@@ -274,11 +282,12 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     const int wr[1] = {ct * 16 + ln};
     sk_nt<1>(a.g, (long long)rowc * D, P + a.Wd1, D, wr, 0, D / 16, wave, lk, acc);
   } else if constexpr (ST == SK_B2) {             // dz = dhd Wd0^T: W row l of Wd0 [L][H]
-    const int wr[1] = {ct * 16 + ln};
+    const int wr[1] = {min(ct * 16 + ln, L - 1)};
     sk_nt<1>(a.dhd, (long long)rowc * H, P + a.Wd0, H, wr, 0, H / 16, wave, lk, acc);
   } else {                                        // B3: dhg = dqp Wg1^T: W row h of Wg1 [H][2L]
     const int wr[2] = {ct * 32 + ln, ct * 32 + 16 + ln};
-    sk_nt<2>(a.dqp, (long long)rowc * 2 * L, P + a.Wg1, 2 * L, wr, 0, (2 * L) / 16, wave, lk, acc);
+    if ((2 * L) & 15) sk_nt<2, true>(a.dqp, (long long)rowc * 2 * L, P + a.Wg1, 2 * L, wr, 0, (2 * L + 15) / 16, wave, lk, acc, 2 * L);
+    else sk_nt<2>(a.dqp, (long long)rowc * 2 * L, P + a.Wg1, 2 * L, wr, 0, (2 * L) / 16, wave, lk, acc);
   }
   SK_STAMP(SLOT, 1);
   // ---- the waves' partial tiles meet in LDS (fixed order)
@@ -304,6 +313,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     // ConditionalNormal heads (scripts/base.py:66-72), z = mu + sigma eps (gmvae.py:248), log q and log p(z|y) terms
     // (gmvae.py:258) of this tile's 16 latent dimensions; row sums over the tile -> lqp[.][tile][row]
     const int l = ct * 16 + ec;
+    const bool lok = l < L;
     // (hardware exp / log / rcp forms as mega2.hpp S5: ~1e-6 relative, one pass of each per head)
     const float mu = v[0] + pf[0], raw = v[1] + pf[1];
     const float vq = raw + a.c, eq = fexp(-fabsf(vq)), rq = __builtin_amdgcn_rcpf(1.f + eq);
@@ -320,9 +330,9 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
       const float t = (zz - mp) * __builtin_amdgcn_rcpf(sp);
       ap = -0.5f * t * t - 0.5f * kLog2Pi - flog(sp);
     }
-    if (rok) { st1o(a.qp + (long long)row * 2 * L + l, mu); st1o(a.qp + (long long)row * 2 * L + L + l, raw); st1o(a.z + (long long)row * L + l, zz); }
-    aq = sk_row16_sum(aq); ap = sk_row16_sum(ap);
-    if (ec == 0 && rok) { st1o(a.lqp + (long long)ct * B + row, aq); st1o(a.lqp + (long long)(L / 16 + ct) * B + row, ap); }
+    if (rok && lok) { st1o(a.qp + (long long)row * 2 * L + l, mu); st1o(a.qp + (long long)row * 2 * L + L + l, raw); st1o(a.z + (long long)row * L + l, zz); }
+    aq = sk_row16_sum(lok ? aq : 0.f); ap = sk_row16_sum(lok ? ap : 0.f);
+    if (ec == 0 && rok) { st1o(a.lqp + (long long)ct * B + row, aq); st1o(a.lqp + (long long)((L + 15) / 16 + ct) * B + row, ap); }
   } else if constexpr (ST == SK_F4) {
     const int n = ct * 64 + 4 * ec;
     if (rok) st4o(a.hd + (long long)row * H + n,
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     }
   } else {                                        // B2: reverse of the two heads, per (row, latent dim)
     const int l = ct * 16 + ec;
-    if (rok) {
+    if (rok && l < L) {
       const float rawq = pf[0] + a.c, eq = fexp(-fabsf(rawq)), rq = __builtin_amdgcn_rcpf(1.f + eq);
       const float spq = fmaxf(rawq, 0.f) - flog(rq), sg = fmaxf(spq, a.smin);     // softplus, and rq / eq rq = its derivative
       const float zz = pf[1];
@@ -721,7 +731,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
   if ((int)blockIdx.x == ntw) {                   // ---- loss tail: per-row terms from the partials, batch sums, counters
     const unsigned long long dbg_c0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const int nlt = a.L / 16;
+    const int nlt = (a.L + 15) / 16;
     if (tid < 256) {
       for (int b = tid; b < B; b += 256) {
         float lpx = 0.f, lq = 0.f, lp = 0.f;

@@ -532,6 +532,12 @@ SKINNY_CASES = [
     ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(192,)), 128),
     ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(256,)), 600),                                  # 38 row tiles, ragged; 10 row chunks in W
     ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,)), 1024),                                 # the largest batch it takes by default
+    # latent sizes that are no multiple of 16 (scripts/run_gmvae.py:17 default latent_size = 8): ragged latent tiles, masked k-groups
+    ("gmvae", O.Dims(D=784, L=8, K=10, hidden=(256,)), 64),
+    ("gmvae", O.Dims(D=784, L=20, K=10, hidden=(128,)), 40),
+    ("gmvae", O.Dims(D=256, L=4, K=5, hidden=(64,)), 33),
+    ("vae", O.Dims(D=784, L=8, K=1, hidden=(512,)), 100),
+    ("vae", O.Dims(D=784, L=24, K=1, hidden=(128,)), 70),
     # the VAE with the standard-normal prior (scripts/vae.py:167-185): eight launches, no y path
     ("vae", O.Dims(D=784, L=128, K=1, hidden=(512,)), 64),
     ("vae", O.Dims(D=784, L=16, K=1, hidden=(512,)), 100),                                       # BASELINE configs[0] at H = 512, ragged
