@@ -195,16 +195,18 @@ static bool mega2_ok(const GmvaeDims& d, int model) {
 static bool skinny_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_SKINNY");
   if (e && atoi(e)) return false;
-  // GMVAE, and the VAE with the standard-normal prior (no y path: eight launches); the learned mixture prior of VAE_GMP is not
-  // column-local and stays on the general schedule
-  if ((model != GMVAE_MODEL_GMVAE && model != GMVAE_MODEL_VAE) || d.n_hidden != 1 || d.S != 1) return false;
+  // GMVAE; the VAE with the standard-normal prior (no y path: eight launches); VAE_GMP (the learned mixture prior is not
+  // column-local: its log-density, its share of dz and its variables' gradients stay three row kernels: eleven launches)
+  if (d.n_hidden != 1 || d.S != 1) return false;
   const int H = d.hidden[0];
   // measured against the general schedule at H = 256 / 512, L = 128 (tools/sk_sweep.py, one box): 2.9x faster at B = 32..64,
   // 2.2x at 256, 1.7x at 512, 1.2 - 1.4x at 1024; not measured beyond
   int maxb = 1024;
   if (const char* mb = getenv("GMVAE_SKINNY_MAXB")) maxb = atoi(mb);
   // (L a multiple of 4: 16-byte loads along latent rows; a ragged last tile of 16 latent dimensions is masked)
-  return H % 64 == 0 && H <= 1024 && d.D % 16 == 0 && d.L % 4 == 0 && d.L >= 4 && d.L <= 256 && d.K <= 16 && d.B <= maxb;
+  // (K <= 16: the y path's per-row softmax in 16 lanes -- GMVAE only; the mixture prior's K is the row kernels' business)
+  return H % 64 == 0 && H <= 1024 && d.D % 16 == 0 && d.L % 4 == 0 && d.L >= 4 && d.L <= 256 &&
+         (model != GMVAE_MODEL_GMVAE || d.K <= 16) && d.B <= maxb;
 }
 static bool fused_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_FUSED");
@@ -1317,6 +1319,28 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
 
 static unsigned long long* g_sk_dbg = nullptr;
 // ---- the skinny schedule (skinny.hpp): 10 launches, every weight matrix crosses the fabric once per pass
+// log p(z) under the learned mixture prior (scripts/vae.py:231-244) and the responsibilities: z -> w.logp, w.resp
+static void launch_mixture_logprob(Ctx& cx, WS& w, const float* P, const Layout& L, int R, int Lz, int K) {
+  hipStream_t st = cx.st;
+  int Kp = 1;
+  while (Kp < K) Kp <<= 1;
+  const int nw = 4, rpw = Kp <= 64 ? 64 / Kp : 0;
+  const size_t sh = (size_t)(2 * K * (Lz | 1) + 64 + nw * rpw * Lz) * sizeof(float);
+  // the LDS-resident form needs K <= 64 and the (loc, 1/s) image inside the default 64 KB of dynamic LDS; any other
+  // size (scripts/vae.py:231-244 bounds neither K nor L) takes the tiled form
+  if (K > 64 || sh > 64 * 1024 || getenv("GMVAE_GMP_TILED")) {
+    hipLaunchKernelGGL(gmp_consts, dim3(K), dim3(256), 0, st, P + L.rawscale, P + L.mixlog, w.gmp_inv, w.gmp_cst, Lz, K);
+    rowk(cx, "gmp_consts");
+    hipLaunchKernelGGL(mixture_logprob_tiled, dim3(grid_for(R, 16, 2048)), dim3(256), 0, st, w.z, P + L.loc, w.gmp_inv,
+                       w.gmp_cst, w.logp, w.resp, R, Lz, K);
+    rowk(cx, "mixture_logprob_tiled");
+  } else {
+    hipLaunchKernelGGL(mixture_logprob_lse, dim3(grid_for(R, nw * rpw, 1024)), dim3(64 * nw), sh, st, w.z,
+                       P + L.loc, P + L.rawscale, P + L.mixlog, w.logp, w.resp, R, Lz, K, Kp);
+    rowk(cx, "mixture_logprob_lse");
+  }
+}
+
 static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, const float* eps, const float* u,
                            float* gen_eps, float* gen_u) {
   const GmvaeDims& d = *a.d;
@@ -1324,10 +1348,15 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   hipStream_t st = cx.st;
   static SkArgs s;                               // (host-side scratch, ~1 KB)
   memset(&s, 0, sizeof(s));
-  const bool vae = a.model == GMVAE_MODEL_VAE;
+  const bool vae = a.model != GMVAE_MODEL_GMVAE, gmp = a.model == GMVAE_MODEL_VAE_GMP;
   // (VAE: the one encoder stands in for both of the GMVAE's: SkArgs::model)
   const NetL &E = vae ? L.enc : L.ency, &G = vae ? L.enc : L.encg, &Dn = L.dec;
   s.model = a.model;
+  if (gmp) {
+    s.dz = w.dz; s.gmp_part = w.gmp_part;
+    s.gmp_n = B / 4 < 16 ? 16 : (B / 4 > GMP_PARTS ? GMP_PARTS : B / 4);       // strips of ~4 rows (gmp_param_bwd walks a strip serially), 16 .. GMP_PARTS
+    s.gmp_len = 2 * (int)pad4((uint64_t)K * Lz) + (int)pad4(K); s.gmp_off = (long long)L.loc;
+  }
   s.B = B; s.D = D; s.H = H; s.L = Lz; s.K = K; s.K4 = (int)pad4(K);
   s.ns1 = vae ? 1 : kSkNs1; s.nparts = D / 16;
   s.c = d.raw_sigma_bias; s.smin = d.sigma_min; s.invT = 1.f / d.temperature; s.gen_bias = d.gen_bias_init;
@@ -1375,6 +1404,7 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   launch(H <= 512 ? sk_ypath<2> : sk_ypath<4>, B + eps_blocks, 256, 0, "sk_y_path", fB * ((double)H * K + K * H + K * 2.0 * Lz));
   }
   launch(sk_gemm<SK_F3>, ((Lz + 15) / 16) * nrt, kSkThreads, 0, "sk_q_head_z", fB * H * 2 * Lz);
+  if (gmp) launch_mixture_logprob(cx, w, a.params, L, B, Lz, K);
   launch(sk_gemm<SK_F4>, (H / 64) * nrt, kSkThreads, 0, "sk_dec_hidden", fB * Lz * H);
   if (empty_mode == 1) launch(sk_gemm<SK_EMPTY>, (H / 64) * nrt, kSkThreads, 0, "sk_empty", 0.0);     // (diagnostic)
   launch(sk_gemm<SK_F5>, (D / 16) * nrt, kSkThreads, 0, "sk_dec_bernoulli", fB * H * D);
@@ -1413,12 +1443,21 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
     }
     double fw = 0;
     for (int i = 0; i < s.ntens; ++i) fw += 2.0 * s.t[i].M * s.t[i].N * B;
-    hipLaunchKernelGGL(sk_dw, dim3((s.total_tiles + kSkWaves - 1) / kSkWaves + (tail ? 1 : 0)), dim3(kSkThreads), 0, on, s);
+    const int gmp_wgs = (s.gmp_part && tail) ? (s.gmp_len + kSkThreads - 1) / kSkThreads : 0;      // (sk_dw derives the same count)
+    hipLaunchKernelGGL(sk_dw, dim3((s.total_tiles + kSkWaves - 1) / kSkWaves + (tail ? 1 : 0) + gmp_wgs), dim3(kSkThreads), 0, on, s);
     cx.check();
     cx.mark(part == 0 ? "sk_dw_decoder" : part == 1 ? "sk_dw_enc_gmm1" : (s.ap ? "sk_dw_adam" : "sk_dw"), fw);
   };
   launch(sk_gemm<SK_B1>, (H / 16) * nrt, kSkThreads, 0, "sk_bwd_dhd", fB * D * H);
   launch(sk_gemm<SK_B2>, ((Lz + 15) / 16) * nrt, kSkThreads, 0, "sk_bwd_dz_heads", fB * H * Lz);
+  if (gmp) {                                     // the mixture prior's share of dz and the q head's reverse; its variables' gradients
+    hipLaunchKernelGGL(z_head_bwd, dim3(grid_for(B, 4)), dim3(256), 0, st, w.dz, w.qp, 1, (const float*)nullptr, eps, w.z, (const float*)nullptr,
+                       w.resp, a.params + L.loc, a.params + L.rawscale, w.dqp, (float*)nullptr, B, Lz, K, (int)PRIOR_GMP, d.raw_sigma_bias, d.sigma_min);
+    rowk(cx, "z_head_bwd");
+    hipLaunchKernelGGL(gmp_param_bwd, dim3(s.gmp_n), dim3(256), 0, st, w.z, w.resp, (const float*)nullptr, a.params + L.loc,
+                       a.params + L.rawscale, a.params + L.mixlog, w.gmp_part, B, Lz, K, (int)pad4((uint64_t)K * Lz));
+    rowk(cx, "gmp_param_bwd");
+  }
   if (fork) {
     hipEventRecord(ev_fork[0], st);
     hipStreamWaitEvent(side, ev_fork[0], 0);
@@ -1529,25 +1568,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   hipLaunchKernelGGL(z_head_fwd, dim3(grid_for(R, 4)), dim3(256), 0, st, w.qp, qp_div, w.pp, eps, w.z, w.logq,
                      w.logp, R, Lz, prior, c, smin);
   rowk(cx, "z_head_fwd");
-  if (prior == PRIOR_GMP) {
-    int Kp = 1;
-    while (Kp < K) Kp <<= 1;
-    const int nw = 4, rpw = Kp <= 64 ? 64 / Kp : 0;
-    const size_t sh = (size_t)(2 * K * (Lz | 1) + 64 + nw * rpw * Lz) * sizeof(float);
-    // the LDS-resident form needs K <= 64 and the (loc, 1/s) image inside the default 64 KB of dynamic LDS; any other
-    // size (scripts/vae.py:231-244 bounds neither K nor L) takes the tiled form
-    if (K > 64 || sh > 64 * 1024 || getenv("GMVAE_GMP_TILED")) {
-      hipLaunchKernelGGL(gmp_consts, dim3(K), dim3(256), 0, st, P + L.rawscale, P + L.mixlog, w.gmp_inv, w.gmp_cst, Lz, K);
-      rowk(cx, "gmp_consts");
-      hipLaunchKernelGGL(mixture_logprob_tiled, dim3(grid_for(R, 16, 2048)), dim3(256), 0, st, w.z, P + L.loc, w.gmp_inv,
-                         w.gmp_cst, w.logp, w.resp, R, Lz, K);
-      rowk(cx, "mixture_logprob_tiled");
-    } else {
-      hipLaunchKernelGGL(mixture_logprob_lse, dim3(grid_for(R, nw * rpw, 1024)), dim3(64 * nw), sh, st, w.z,
-                         P + L.loc, P + L.rawscale, P + L.mixlog, w.logp, w.resp, R, Lz, K, Kp);
-      rowk(cx, "mixture_logprob_lse");
-    }
-  }
+  if (prior == PRIOR_GMP) launch_mixture_logprob(cx, w, P, L, R, Lz, K);
   int nparts = 1;
   const NetL& Dn = L.dec;
   for (int i = 0; i < Dn.nl; ++i) {

@@ -63,6 +63,14 @@ struct SkArgs {
   float lr, b1, b2, aeps, ln_b1, ln_b2;
   float *tail, *tail_log;
   float *logpx, *logq, *logp, *logw;
+  // model 1 (VAE_GMP, the learned mixture prior of scripts/vae.py:231-244): log p(z) is not column-local -- F3 leaves only
+  // log q, mixture_logprob_* (kernels.hpp) writes logp[row] and the responsibilities, B2 leaves dz in `dz` for z_head_bwd,
+  // gmp_param_bwd leaves gmp_n partial gradients of the prior's variables (rows of gmp_len floats at flat offset gmp_off),
+  // which the loss-tail workgroup sums and updates
+  float* dz;
+  const float* gmp_part;
+  int gmp_n, gmp_len;
+  long long gmp_off;
   unsigned long long* dbg;     // diagnostic (GMVAE_SK_STAMPS): [10 launches][256 blocks][8] device wall-clock stamps (100 MHz)
 };
 #define SK_STAMP(slot, i) if (a.dbg && threadIdx.x == 0 && blockIdx.x < 256) a.dbg[((size_t)(slot) * 256 + blockIdx.x) * 8 + (i)] = wall_clock64()
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
   const int B = a.B, D = a.D, H = a.H, L = a.L;
   const int nrt = (B + 15) >> 4;
   constexpr int NU = (ST == SK_F1 || ST == SK_F4) ? 4 : (ST == SK_F3 || ST == SK_B3) ? 2 : 1;
-  const bool vae = a.model == 0;
+  const bool vae = a.model != 2;                 // (VAE and VAE_GMP: one encoder, no y path)
   const int nct = ST == SK_F1 ? (vae ? H : 2 * H) / 64 : ST == SK_F3 ? (L + 15) / 16 : ST == SK_F4 ? H / 64 : ST == SK_F5 ? D / 16
                 : ST == SK_B1 ? H / 16 : ST == SK_B2 ? (L + 15) / 16 : H / 32;
   const int bid = blockIdx.x;
@@ -322,7 +330,9 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     const float e = (zz - mu) * __builtin_amdgcn_rcpf(sg);       // from z, not eps (A7)
     float aq = -0.5f * e * e - 0.5f * kLog2Pi - flog(sg);
     float ap;
-    if (vae) {                                    // standard-normal prior (scripts/vae.py:247-250)
+    if (a.model == 1) {                           // learned mixture prior: mixture_logprob_* after this launch
+      ap = 0.f;
+    } else if (vae) {                             // standard-normal prior (scripts/vae.py:247-250)
       ap = -0.5f * zz * zz - 0.5f * kLog2Pi;
     } else {
       const float mp = pf[3], vp = pf[4] + a.c, ep = fexp(-fabsf(vp)), rp = __builtin_amdgcn_rcpf(1.f + ep);
@@ -361,7 +371,9 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
       const float rawq = pf[0] + a.c, eq = fexp(-fabsf(rawq)), rq = __builtin_amdgcn_rcpf(1.f + eq);
       const float spq = fmaxf(rawq, 0.f) - flog(rq), sg = fmaxf(spq, a.smin);     // softplus, and rq / eq rq = its derivative
       const float zz = pf[1];
-      if (vae) {                                  // standard-normal prior: d(-log p)/dz = z, nothing to send to a prior network
+      if (a.model == 1) {                         // learned mixture prior: z_head_bwd (kernels.hpp) takes it from here
+        st1o(a.dz + (long long)row * L + l, v[0]);
+      } else if (vae) {                           // standard-normal prior: d(-log p)/dz = z, nothing to send to a prior network
         const float dmu = v[0] + zz;
         const float dsg = dmu * pf[4] - __builtin_amdgcn_rcpf(sg);
         st1o(a.dqp + (long long)row * 2 * L + l, dmu);
@@ -726,7 +738,36 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, lk = lane >> 4;
   const int B = a.B;
-  const int ntw = (int)gridDim.x - (a.has_tail ? 1 : 0);      // tile workgroups; then the loss tail, if this launch carries it
+  const int gmp_wgs = (a.gmp_part && a.has_tail) ? (a.gmp_len + kSkThreads - 1) / kSkThreads : 0;
+  const int ntw = (int)gridDim.x - (a.has_tail ? 1 : 0) - gmp_wgs;      // tile workgroups; then the loss tail, if this launch carries it; then
+                                                                        // (VAE_GMP) the workgroups that update the mixture prior's variables
+  if ((int)blockIdx.x >= ntw + (a.has_tail ? 1 : 0)) {
+    const int i = ((int)blockIdx.x - ntw - (a.has_tail ? 1 : 0)) * kSkThreads + tid;
+    // VAE_GMP: the mixture prior's variables (loc, raw scale, mixture logits: scripts/vae.py:233-238) have no matrix-product
+    // gradient: gmp_param_bwd left gmp_n partials in the flat layout's order; sum them in partial order, update
+    const int KL = a.K * a.L, KLp = (KL + 3) & ~3;
+    const bool valid = i < a.gmp_len && (i < KL || (i >= KLp && i < KLp + KL) || (i >= 2 * KLp && i < 2 * KLp + a.K));
+    if (!valid) return;                               // (alignment padding between the three tensors)
+    const float tf = (float)((a.step_dev ? a.step_dev[1] : a.step) + 1ull);
+    const float lr_t = a.ap ? a.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1)) : 0.f;
+    const long long o = a.gmp_off + i;
+    float pw = 0.f, pm = 0.f, pv = 0.f;
+    if (a.ap) { pw = a.ap[o]; pm = a.am[o]; pv = a.av[o]; }
+    float gsum = 0.f;
+    for (int g0 = 0; g0 < a.gmp_n; g0 += 16) {        // 16 partials in flight at a time (one by one: 16 dependent round trips each)
+      float pv16[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) pv16[j] = a.gmp_part[(long long)min(g0 + j, a.gmp_n - 1) * a.gmp_len + i];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) gsum += g0 + j < a.gmp_n ? pv16[j] : 0.f;
+    }
+    a.grads[o] = gsum;
+    if (a.ap) {
+      adam_update(pw, pm, pv, gsum, 1.f / (float)B, lr_t, 1.f - a.b1, 1.f - a.b2, a.aeps);
+      a.ap[o] = pw; a.am[o] = pm; a.av[o] = pv;
+    }
+    return;
+  }
   SK_STAMP(9, 0);
   if ((int)blockIdx.x == ntw) {                   // ---- loss tail: per-row terms from the partials, batch sums, counters
     const unsigned long long dbg_c0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
@@ -737,6 +778,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
         float lpx = 0.f, lq = 0.f, lp = 0.f;
         for (int i = 0; i < a.nparts; ++i) lpx += a.part[(long long)b * a.nparts + i];
         for (int i = 0; i < nlt; ++i) { lq += a.lqp[(long long)i * B + b]; lp += a.lqp[(long long)(nlt + i) * B + b]; }
+        if (a.model == 1) lp = a.logp[b];               // (VAE_GMP: the mixture log-density, written by mixture_logprob_*)
         const float ne = a.nent ? a.nent[b] : 0.f;      // (VAE: no entropy term)
         const float lw = lpx + lp - lq - ne;
         a.logpx[b] = lpx; a.logq[b] = lq; a.logp[b] = lp; a.logw[b] = lw;

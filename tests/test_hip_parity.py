@@ -543,6 +543,12 @@ SKINNY_CASES = [
     ("vae", O.Dims(D=784, L=16, K=1, hidden=(512,)), 100),                                       # BASELINE configs[0] at H = 512, ragged
     ("vae", O.Dims(D=256, L=32, K=1, hidden=(128,), sigma_min=0.7, raw_sigma_bias=0.25, gen_bias_init=0.3), 37),
     ("vae", O.Dims(D=784, L=64, K=1, hidden=(256,)), 512),
+    # VAE_GMP: the learned mixture prior's log-density, its share of dz and its variables' gradients as row kernels between the
+    # skinny launches (eleven launches), the variables' update in the loss-tail workgroup
+    ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(512,)), 256),                                  # BASELINE configs[1] at H = 512
+    ("vae_gmp", O.Dims(D=784, L=128, K=10, hidden=(512,)), 64),
+    ("vae_gmp", O.Dims(D=256, L=20, K=7, hidden=(128,), sigma_min=0.6, raw_sigma_bias=0.25), 45),
+    ("vae_gmp", O.Dims(D=400, L=16, K=80, hidden=(64,)), 30),                                    # K > 64: the tiled mixture log-density
 ]
 
 

@@ -102,6 +102,7 @@ CASES = [
     ("vae", 784, 128, 1, (512,), 64, 4, 12),     # the VAE at bin/run_train.sh's sizes: skinny schedule, eight launches
     ("vae", 784, 32, 1, (256,), 200, 3, 12),     # skinny VAE, ragged row tiles, in-kernel eps rows over several extra workgroups
     ("gmvae", 784, 8, 10, (256,), 64, 4, 12),    # skinny, the reference's default latent size (a ragged tile of latent dimensions)
+    ("vae_gmp", 784, 64, 10, (512,), 256, 4, 12),  # skinny VAE_GMP (BASELINE configs[1] at H = 512): the prior's variables updated in the tail
 ]
 
 

@@ -16,7 +16,7 @@ def t(model, L, K, H, B, env=None):
     for _ in range(50): replay()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / (50 * G)
-for (m, L, K, H, B) in [("vae", 128, 1, 512, 64), ("vae", 2, 1, 512, 100), ("vae", 16, 1, 512, 100), ("vae", 64, 1, 512, 256), ("vae", 64, 1, 256, 1024)]:
+for (m, L, K, H, B) in [("vae_gmp", 64, 10, 512, 256), ("vae_gmp", 128, 10, 512, 64), ("vae", 128, 1, 512, 64), ("vae", 2, 1, 512, 100), ("vae", 16, 1, 512, 100), ("vae", 64, 1, 512, 256), ("vae", 64, 1, 256, 1024)]:
     a = t(m, L, K, H, B)
     b = t(m, L, K, H, B, {"GMVAE_NO_SKINNY": "1"})
     print(f"{m} L={L} H={H} B={B}: skinny-or-default {a:7.2f} us/step | GMVAE_NO_SKINNY {b:7.2f}", flush=True)
