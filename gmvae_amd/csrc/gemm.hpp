@@ -651,7 +651,22 @@ __device__ __forceinline__ void plane_rounds3(unsigned short* __restrict__ img, 
 #undef GMVAE_P3_SG
 }
 
-// fp32 [rows][ld] (x rowscale[row]) -> three planes of 16-bit pieces hi, mid, lo (truncation splits with exact residuals:
+// Two fp32 values -> their three 16-bit pieces, packed pairwise (element 0 in the low half): round-to-nearest-even pieces
+// (v_cvt_pk_bf16_f32: one instruction per pair) with exact residuals -- v - hi is a multiple of ulp(v) below 2^-8 |v|, so
+// it has <= 16 significant bits; the second residual <= 8, which a bf16 holds -- so hi + mid + lo == v bit for bit, as
+// with the truncation splits above at 5.5 instead of 14 instructions per element.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(const float v0, const float v1, unsigned& hi, unsigned& mi, unsigned& lo) {
+  const f32x2_t v = {v0, v1};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  const f32x2_t r1 = {v0 - __uint_as_float(hi << 16), v1 - __uint_as_float(hi & 0xffff0000u)};
+  mi = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
+  const f32x2_t r2 = {r1.x - __uint_as_float(mi << 16), r1.y - __uint_as_float(mi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
+}
+
+// fp32 [rows][ld] (x rowscale[row]) -> three planes of 16-bit pieces hi, mid, lo (exact residuals:
 // hi + mid + lo == the fp32 value, bit for bit); n a multiple of 8, 16-byte aligned
 __global__ __launch_bounds__(256) void split_planes(const float* __restrict__ src, const float* __restrict__ rowscale,
                                                      const int ld, const long long n, unsigned short* __restrict__ dst,
@@ -661,19 +676,13 @@ __global__ __launch_bounds__(256) void split_planes(const float* __restrict__ sr
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + e), v1 = *reinterpret_cast<const f32x4*>(src + e + 4);
     const float sc = rowscale ? rowscale[e / ld] : 1.f;
     const float v[8] = {v0.x * sc, v0.y * sc, v0.z * sc, v0.w * sc, v1.x * sc, v1.y * sc, v1.z * sc, v1.w * sc};
-    unsigned hi[8], mi[8], lo[8];
+    unsigned hi[4], mi[4], lo[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned hb = __float_as_uint(v[j]) & 0xffff0000u;
-      const float r1 = v[j] - __uint_as_float(hb);
-      const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-      const float r2 = r1 - __uint_as_float(mb);
-      hi[j] = hb >> 16; mi[j] = mb >> 16; lo[j] = __float_as_uint(r2) >> 16;
-    }
+    for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], hi[j], mi[j], lo[j]);
     const long long o = e;
-    *reinterpret_cast<u32x4*>(dst + o) = u32x4{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16)};
-    *reinterpret_cast<u32x4*>(dst + pstride + o) = u32x4{mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16)};
-    *reinterpret_cast<u32x4*>(dst + 2 * pstride + o) = u32x4{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16)};
+    *reinterpret_cast<u32x4*>(dst + o) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<u32x4*>(dst + pstride + o) = u32x4{mi[0], mi[1], mi[2], mi[3]};
+    *reinterpret_cast<u32x4*>(dst + 2 * pstride + o) = u32x4{lo[0], lo[1], lo[2], lo[3]};
   }
 }
 
@@ -1434,20 +1443,14 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
         }
         if (Cout) *reinterpret_cast<float4*>(Cout + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
         if (C3) {                                   // the three 16-bit pieces of (sigmoid - x), one plane each (plane_rounds' operand)
-          unsigned hi[4], mi[4], lo[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const unsigned hb = __float_as_uint(v[j]) & 0xffff0000u;
-            const float r1 = v[j] - __uint_as_float(hb);
-            const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-            const float r2 = r1 - __uint_as_float(mb);
-            hi[j] = hb >> 16; mi[j] = mb >> 16; lo[j] = __float_as_uint(r2) >> 16;
-          }
+          unsigned hi[2], mi[2], lo[2];
+          split_pair(v[0], v[1], hi[0], mi[0], lo[0]);
+          split_pair(v[2], v[3], hi[1], mi[1], lo[1]);
           unsigned short* const d3 = c3_b16 ? C3 + ((long long)(nb >> 4) * M + (m0 + row)) * 16 + (nb & 15)
                                             : C3 + (long long)(m0 + row) * ldc + nb;
-          *reinterpret_cast<uint2*>(d3) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-          *reinterpret_cast<uint2*>(d3 + c3s) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
-          *reinterpret_cast<uint2*>(d3 + 2 * c3s) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+          *reinterpret_cast<uint2*>(d3) = make_uint2(hi[0], hi[1]);
+          *reinterpret_cast<uint2*>(d3 + c3s) = make_uint2(mi[0], mi[1]);
+          *reinterpret_cast<uint2*>(d3 + 2 * c3s) = make_uint2(lo[0], lo[1]);
         }
         lds[row * C::LDC + 4 * c4] = rsum;          // (this thread's own, already consumed, slot of the staged tile)
       }
@@ -1532,19 +1535,13 @@ __global__ __launch_bounds__(256) void split_planes_b16(const float* __restrict_
     const float sc = rowscale ? rowscale[r] : 1.f;
     const f32x4 q0 = *reinterpret_cast<const f32x4*>(sp), q1 = *reinterpret_cast<const f32x4*>(sp + 4);
     const float v[8] = {q0.x * sc, q0.y * sc, q0.z * sc, q0.w * sc, q1.x * sc, q1.y * sc, q1.z * sc, q1.w * sc};
-    unsigned hi[8], mi[8], lo[8];
+    unsigned hi[4], mi[4], lo[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned hb = __float_as_uint(v[j]) & 0xffff0000u;
-      const float r1 = v[j] - __uint_as_float(hb);
-      const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-      const float r2 = r1 - __uint_as_float(mb);
-      hi[j] = hb >> 16; mi[j] = mb >> 16; lo[j] = __float_as_uint(r2) >> 16;
-    }
+    for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], hi[j], mi[j], lo[j]);
     unsigned short* const dp = dst + ((long long)(c >> 4) * rows + r) * 16 + (c & 15);
-    *reinterpret_cast<u32x4*>(dp) = u32x4{hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16)};
-    *reinterpret_cast<u32x4*>(dp + pstride) = u32x4{mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16), mi[4] | (mi[5] << 16), mi[6] | (mi[7] << 16)};
-    *reinterpret_cast<u32x4*>(dp + 2 * pstride) = u32x4{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16)};
+    *reinterpret_cast<u32x4*>(dp) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<u32x4*>(dp + pstride) = u32x4{mi[0], mi[1], mi[2], mi[3]};
+    *reinterpret_cast<u32x4*>(dp + 2 * pstride) = u32x4{lo[0], lo[1], lo[2], lo[3]};
   }
 }
 
