@@ -4,7 +4,9 @@
 // shapes, operand layouts and epilogues) so that a whole dependency level of
 // the training step (e.g. dW and dX of one layer) is a single kernel boundary.
 // Arithmetic is v_mfma_f32_32x32x2_f32: exact fp32 products and fp32
-// accumulation (the 1e-4 ELBO tolerance rules out bf16 inputs).
+// accumulation (the 1e-4 ELBO tolerance rules out bf16 INPUTS) -- or, for the
+// largest launches, the same products as six exact bf16 piece products per
+// fp32 product on operands their producers split once (plane_rounds3 below).
 //
 // Replaces: snt.nets.MLP MatMul/BiasAdd/Relu nodes (scripts/base.py:47-60,
 // 67,135,198), their TF autodiff counterparts (scripts/runners.py:182) and the
