@@ -239,14 +239,17 @@ def test_pipeline_graph_matches_oracle_from_raw_pixels():
     _compare_params(O.MODEL_GMVAE, d, e, flat_ref, g1, n)
 
 
-def test_config5_shard_full_size_properties():
+def test_config5_shard_full_size_properties(monkeypatch):
     """BASELINE configs[4] per-GPU shard at FULL size (D = 3072, K = 64, S = 50, H = 512, B = 512: 25,600 sample rows;
     the oracle needs minutes there), through size-independent properties:
       * known answer: all-zero parameters -> loss = D ln 2 - ln K = 2125.189256 for any data and noise, kl = 0, nent = -ln K
         (SURVEY.md section 4), at S = 50 (the IWAE bound of identical samples is the single-sample bound);
       * random parameters: finite loss and gradients, and the gradient SUMS of two half batches (row offsets 0 / 256 in the
         Philox counters) add up to the full batch's -- the data-parallel identity at full size;
-      * the oracle comparison runs on the first 8 rows with the device's own noise (same kernels, same schedule)."""
+      * the top decoder layer's plane GEMMs (bf16 piece products on pre-split operands: what runs at this size) against the
+        fp32 MFMA instance on the same step: loss to 1e-6, every gradient tensor to 2e-5 of its maximum;
+      * the oracle comparison runs on the first 8 rows with the device's own noise (same kernels, same schedule; 400 sample
+        rows: the fp32 instance)."""
     import ctypes as C
     import math
     import hip_util as H
@@ -276,6 +279,15 @@ def test_config5_shard_full_size_properties():
     halves = run(flat, x[:256], 0) + run(flat, x[256:], 256)
     assert abs(halves[P] - full[P]) <= 1e-5 * abs(full[P])
     assert np.abs(halves[:P] - full[:P]).max() <= 1e-4 * np.abs(full[:P]).max()
+    assert L.step_schedule(H.dims_of(d, B), mid) == "general+planes"
+    monkeypatch.setenv("GMVAE_NO_PLANES", "1")
+    f32 = run(flat, x, 0)
+    monkeypatch.delenv("GMVAE_NO_PLANES")
+    assert not np.array_equal(f32[:P], full[:P])
+    assert abs(f32[P] - full[P]) <= 1e-6 * abs(full[P])
+    for name, shape, off in lay:
+        n = int(np.prod(shape))
+        assert np.abs(f32[off:off + n] - full[off:off + n]).max() <= 2e-5 * max(np.abs(f32[off:off + n]).max(), 1e-6), name
     # oracle on the first 8 rows, with the noise the device drew for global rows 0..7
     small = run(flat, x[:8], 0)
     eps, u = _noise(L, 8 * d.S, d.L, d.K, 0, 5, 2, True)
