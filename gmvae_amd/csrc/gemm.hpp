@@ -73,7 +73,8 @@ struct Problem {
   int planes;              // operands of seg[0] are bf16 plane triples (hi, mid, lo as written by split_planes / the Bernoulli
                            // epilogue's C3): a.ptr / b.ptr name plane 0 (16-bit elements, ld in elements); plane_rounds below
   long long a_pstride, b_pstride;   // 16-bit elements between the planes of a / b
-  unsigned short* C3;      // EPI_BERNOULLI: (sigmoid - x) written as planes [3][M][ldc] of 16-bit pieces (beside or instead of C)
+  unsigned short* C3;      // EPI_BERNOULLI: (sigmoid - x) written as planes [3][M][ldc] of 16-bit pieces (beside or instead of C);
+                           // EPI_STORE with per-element options (bias / ReLU ...): the stored values also as planes (beside C)
   long long c3_stride;
   int c3_b16;              // C3 in the blocked-by-16 layout of plane_rounds3: element (m, n) at ((n >> 4) M + m) 16 + (n & 15)
   float* colsum_out;       // bias gradient riding on a dW problem: column sums of operand b over the tile's k
@@ -301,6 +302,21 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned short* p) {     // ro
   typedef short s16x8_t __attribute__((ext_vector_type(8)));
   const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// Two fp32 values -> their three 16-bit pieces, packed pairwise (element 0 in the low half): round-to-nearest-even pieces
+// (v_cvt_pk_bf16_f32: one instruction per pair) with exact residuals -- v - hi is a multiple of ulp(v) below 2^-8 |v|, so
+// it has <= 16 significant bits; the second residual <= 8, which a bf16 holds -- so hi + mid + lo == v bit for bit, as
+// with the truncation splits above at 5.5 instead of 14 instructions per element.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(const float v0, const float v1, unsigned& hi, unsigned& mi, unsigned& lo) {
+  const f32x2_t v = {v0, v1};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  const f32x2_t r1 = {v0 - __uint_as_float(hi << 16), v1 - __uint_as_float(hi & 0xffff0000u)};
+  mi = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
+  const f32x2_t r2 = {r1.x - __uint_as_float(mi << 16), r1.y - __uint_as_float(mi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
 }
 
 // ---- fp32 x fp32 products on the bf16 matrix cores ("split3", the 128x128x32 configuration) ----------------------
@@ -651,21 +667,6 @@ __device__ __forceinline__ void plane_rounds3(unsigned short* __restrict__ img, 
 #undef GMVAE_P3_TILE
 #undef GMVAE_P3_ROUND
 #undef GMVAE_P3_SG
-}
-
-// Two fp32 values -> their three 16-bit pieces, packed pairwise (element 0 in the low half): round-to-nearest-even pieces
-// (v_cvt_pk_bf16_f32: one instruction per pair) with exact residuals -- v - hi is a multiple of ulp(v) below 2^-8 |v|, so
-// it has <= 16 significant bits; the second residual <= 8, which a bf16 holds -- so hi + mid + lo == v bit for bit, as
-// with the truncation splits above at 5.5 instead of 14 instructions per element.
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_pair(const float v0, const float v1, unsigned& hi, unsigned& mi, unsigned& lo) {
-  const f32x2_t v = {v0, v1};
-  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-  const f32x2_t r1 = {v0 - __uint_as_float(hi << 16), v1 - __uint_as_float(hi & 0xffff0000u)};
-  mi = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
-  const f32x2_t r2 = {r1.x - __uint_as_float(mi << 16), r1.y - __uint_as_float(mi & 0xffff0000u)};
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
 }
 
 // fp32 [rows][ld] (x rowscale[row]) -> three planes of 16-bit pieces hi, mid, lo (exact residuals:
@@ -1295,6 +1296,9 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
     const float* rowscale = L.p[pi].rowscale;
     const int relu = L.p[pi].relu, ld_add = L.p[pi].ld_add, add_div = L.p[pi].add_div, ld_mask = L.p[pi].ld_mask;
     const long long soff = (long long)split * L.p[pi].split_stride;
+    unsigned short* const C3s = L.p[pi].C3;        // (EPI_STORE with bias / ReLU: the activation also leaves as planes; never with splits)
+    const long long c3ss = L.p[pi].c3_stride;
+    const bool c3s_b16 = L.p[pi].c3_b16 != 0;
     // plain slab / matrix store of an interior tile (every weight-gradient tile but the edge ones): no per-element
     // options, all passes unrolled, 16-byte stores
     const bool plain = !bias && !bias2 && !addsrc && !mask && !rowscale && !relu && addconst == 0.f && m0 + C::BM <= M &&
@@ -1354,6 +1358,16 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
             v[j] = x * rs[q];
           }
           *reinterpret_cast<float4*>(Cout + soff + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
+          if (C3s) {                                // the output also as planes of 16-bit pieces: the next layer's plane GEMM operand
+            unsigned hi[2], mi[2], lo[2];
+            split_pair(v[0], v[1], hi[0], mi[0], lo[0]);
+            split_pair(v[2], v[3], hi[1], mi[1], lo[1]);
+            unsigned short* const d3 = c3s_b16 ? C3s + ((long long)(nb >> 4) * M + (m0 + row)) * 16 + (nb & 15)
+                                               : C3s + (long long)(m0 + row) * ldc + nb;
+            *reinterpret_cast<uint2*>(d3) = make_uint2(hi[0], hi[1]);
+            *reinterpret_cast<uint2*>(d3 + c3ss) = make_uint2(mi[0], mi[1]);
+            *reinterpret_cast<uint2*>(d3 + 2 * c3ss) = make_uint2(lo[0], lo[1]);
+          }
         }
       }
     } else
@@ -1391,6 +1405,16 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
           if (nb + 1 < N) dst[1] = v[1];
           if (nb + 2 < N) dst[2] = v[2];
           if (nb + 3 < N) dst[3] = v[3];
+        }
+        if (C3s) {                                  // (edge / unaligned tiles: the pieces one by one)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (nb + j >= N) break;
+            unsigned hi, mi, lo;
+            split_pair(v[j], 0.f, hi, mi, lo);
+            const long long o = c3s_b16 ? ((long long)((nb + j) >> 4) * M + m) * 16 + ((nb + j) & 15) : (long long)m * ldc + nb + j;
+            C3s[o] = (unsigned short)hi; C3s[o + c3ss] = (unsigned short)mi; C3s[o + 2 * c3ss] = (unsigned short)lo;
+          }
         }
       }
     }

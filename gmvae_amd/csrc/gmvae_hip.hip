@@ -1571,12 +1571,19 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   if (prior == PRIOR_GMP) launch_mixture_logprob(cx, w, P, L, R, Lz, K);
   int nparts = 1;
   const NetL& Dn = L.dec;
+  bool hd3_fused = false;
   for (int i = 0; i < Dn.nl; ++i) {
     Group g;
     const float* in = (i == 0) ? w.z : w.hd[i];
     if (i < Dn.nl - 1) {
-      g.add(p_nn(in, false, Dn.dim[i], P + Dn.w[i], Dn.dim[i + 1], R, Dn.dim[i + 1], Dn.dim[i], w.hd[i + 1],
-                 Dn.dim[i + 1], P + Dn.b[i], true));
+      Problem ph = p_nn(in, false, Dn.dim[i], P + Dn.w[i], Dn.dim[i + 1], R, Dn.dim[i + 1], Dn.dim[i], w.hd[i + 1],
+                        Dn.dim[i + 1], P + Dn.b[i], true);
+      if (planes && i == Dn.nl - 2 && !getenv("GMVAE_PLANES_NO_FUSED_SPLIT")) {
+        // the top layer's input activation leaves this launch's epilogue as planes too (no split launch over R x H)
+        ph.C3 = w.hd3; ph.c3_stride = (long long)R * Dn.dim[i + 1]; ph.c3_b16 = pform == 2;
+        hd3_fused = true;
+      }
+      g.add(ph);
       launch_group(cx, g, "fwd_dec");
     } else {  // logits -> Bernoulli log-prob partials + (sigmoid(logit) - x)
       Problem p = p_nn(in, false, Dn.dim[i], P + Dn.w[i], D, R, D, Dn.dim[i], a.backward ? w.g : nullptr, D,
@@ -1590,7 +1597,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
         // leaves as planes only: its two consumers are plane GEMMs
         const long long nh = (long long)R * Dn.dim[i], nw = (long long)Dn.dim[i] * D;
         const int b16 = pform == 2;
-        launch_split(st, pform, in, nullptr, Dn.dim[i], nh, w.hd3);
+        if (!hd3_fused) launch_split(st, pform, in, nullptr, Dn.dim[i], nh, w.hd3);
         launch_split(st, pform, P + Dn.w[i], nullptr, D, nw, w.w3);
         rowk(cx, "split_planes");
         p.seg[0].a.ptr = w.hd3; p.seg[0].b.ptr = w.w3;
