@@ -552,6 +552,40 @@ SKINNY_CASES = [
 ]
 
 
+def _random_skinny_cases(n, seed):
+    """Seeded random shapes INSIDE the skinny schedule's gates (one hidden layer of 64 .. 320 in steps of 64, latent sizes that
+    are multiples of 4, K <= 16 for the GMVAE, batches from one row to a few ragged row tiles), all three models."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        model = ["gmvae", "vae", "vae_gmp"][i % 3]
+        d = O.Dims(D=int(rng.choice([64, 112, 256, 400, 784])), L=int(rng.choice([4, 8, 12, 16, 28, 36, 64])),
+                   K=1 if model == "vae" else int(rng.choice([2, 3, 7, 10, 16])), hidden=(int(rng.choice([64, 128, 192, 320])),),
+                   temperature=float(rng.choice([1.0, 0.7])), sigma_min=float(rng.choice([0.0, 0.0, 0.5])))
+        out.append((model, d, int(rng.choice([1, 5, 16, 31, 77, 150]))))
+    return out
+
+
+RANDOM_SKINNY_CASES = _random_skinny_cases(15, 20261005)
+
+
+@pytest.mark.parametrize("name,d,B", RANDOM_SKINNY_CASES, ids=[f"{n}-D{d.D}-L{d.L}-K{d.K}-H{d.hidden[0]}-B{B}" for n, d, B in RANDOM_SKINNY_CASES])
+def test_skinny_schedule_on_random_shapes(H, monkeypatch, name, d, B):
+    """The skinny schedule (forced where the mega schedule would take H = 64) against the oracle on random eligible shapes."""
+    monkeypatch.setenv("GMVAE_NO_MEGA", "1")
+    monkeypatch.setenv("GMVAE_NO_FUSED", "1")
+    L = _L()
+    model = O.MODEL_NAMES[name]
+    assert L.step_schedule(H.dims_of(d, B), model) == "skinny"
+    rng = np.random.default_rng(B * 17 + d.D + d.L)
+    p = O.init_params(model, d, rng)
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    x, eps, u = O.make_inputs(d, B, model)
+    H.compare_step(model, d, p, x, eps, u)
+
+
 @pytest.mark.parametrize("name,d,B", SKINNY_CASES, ids=[f"{n}-D{d.D}-L{d.L}-K{d.K}-H{d.hidden[0]}-B{B}" for n, d, B in SKINNY_CASES])
 def test_skinny_schedule_matches_oracle(H, monkeypatch, name, d, B):
     """The small-batch / wide-layer schedule (csrc/skinny.hpp: 10 launches, register-direct tiles) against the oracle --
