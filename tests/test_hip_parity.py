@@ -343,6 +343,41 @@ def test_plane_gemms_inside_the_step(H, monkeypatch, form, model, S, hidden):
     np.testing.assert_allclose(g_pl, g_f32, rtol=0, atol=2e-5 * np.abs(g_f32).max())
 
 
+def _random_plane_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        model = ["gmvae", "vae", "vae_gmp"][i % 3]
+        S = int(rng.choice([1, 2, 4]))
+        R = int(rng.choice([128, 256, 384]))
+        hidden = tuple([int(rng.choice([64, 96]))] * int(rng.integers(0, 2)) + [int(rng.choice([128, 256]))])
+        d = O.Dims(D=int(rng.choice([128, 256, 384])), L=int(rng.choice([8, 20, 64])), K=1 if model == "vae" else int(rng.choice([3, 10])),
+                   hidden=hidden, S=S)
+        out.append((model, d, R // S))
+    return out
+
+
+RANDOM_PLANE_CASES = _random_plane_cases(9, 20261006)
+
+
+@pytest.mark.parametrize("name,d,B", RANDOM_PLANE_CASES, ids=[f"{n}-D{d.D}-L{d.L}-H{'x'.join(map(str, d.hidden))}-S{d.S}-B{B}" for n, d, B in RANDOM_PLANE_CASES])
+def test_plane_gemms_on_random_shapes(H, monkeypatch, name, d, B):
+    """The plane path (forced from 128 rows) on random eligible shapes -- one or two hidden layers (the activation's planes from
+    the producing GEMM's epilogue either way), IWAE samples, all three models -- against the oracle."""
+    monkeypatch.setenv("GMVAE_PLANES_MINROWS", "128")
+    monkeypatch.setenv("GMVAE_NO_SKINNY", "1")
+    L = _L()
+    model = O.MODEL_NAMES[name]
+    assert L.step_schedule(H.dims_of(d, B), model) == "general+planes"
+    rng = np.random.default_rng(B + d.D)
+    p = O.init_params(model, d, rng)
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    x, eps, u = O.make_inputs(d, B, model)
+    H.compare_step(model, d, p, x, eps, u)
+
+
 def test_many_splits_for_small_weight_gradients_and_few_for_batch_row_ones(H, monkeypatch):
     """General schedule, S > 1: the per-range slab counts of finalize_grads -- weight gradients contracted over the B batch
     rows written to num_splits(B) slabs, those with few outputs and a contraction over all B*S rows to MORE slabs than the
