@@ -35,6 +35,9 @@ CONFIGS = {
     "configs2": dict(model="gmvae", batch=1024, latent=64, components=10, hidden=64, layers=1, data_dim=784, n_samples=1),
     "configs4_shard": dict(model="gmvae", batch=512, latent=64, components=64, hidden=512, layers=1, data_dim=3072, n_samples=50),
     "run_train": dict(model="gmvae", batch=64, latent=128, components=10, hidden=512, layers=1, data_dim=784, n_samples=1),
+    # H = 512 (bin/run_train.sh:6) is the "realistic point" of configs[1] / configs[2]
+    "configs1_h512": dict(model="vae_gmp", batch=256, latent=64, components=10, hidden=512, layers=1, data_dim=784, n_samples=1),
+    "configs2_h512": dict(model="gmvae", batch=1024, latent=64, components=10, hidden=512, layers=1, data_dim=784, n_samples=1),
 }
 
 
@@ -46,7 +49,8 @@ def workload_name(a, n_gpus):
             if name == "configs2":
                 return "BASELINE configs[2]" if n_gpus == 1 else f"BASELINE configs[3] shape: 1024 rows per GPU x {n_gpus}"
             return {"configs0": "BASELINE configs[0]", "configs1": "BASELINE configs[1]",
-                    "configs4_shard": "per-GPU shard of BASELINE configs[4]", "run_train": "bin/run_train.sh sizes"}[name]
+                    "configs4_shard": "per-GPU shard of BASELINE configs[4]", "run_train": "bin/run_train.sh sizes",
+                    "configs1_h512": "BASELINE configs[1] at hidden 512", "configs2_h512": "BASELINE configs[2] at hidden 512"}[name]
     return "custom sizes"
 
 
@@ -86,6 +90,10 @@ def parse():
     ap.add_argument("--allow-fallback", action="store_true",
                     help="N > 1: accept a slower data-parallel path (eager C-side step or torch.distributed all-reduce) when "
                          "the RCCL all-reduce cannot be captured inside the hipGraph; without it such a run exits non-zero")
+    ap.add_argument("--safe-schedule", action="store_true",
+                    help="start on the schedule without waits between the workgroups of a launch (GMVAE_SCHED_SAFE): what a run "
+                         "that shares its GPU needs (tests: two ranks on one device)")
+    ap.add_argument("--no-iwae-bound", action="store_true", help="skip the -log p(x) IWAE bound (S = 50) of the parity block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--levels", action="store_true", help="also print the per-launch table to stderr")
@@ -179,11 +187,26 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # GMVAE_DIST_BACKEND=gloo: several ranks on ONE device (tests; RCCL refuses that) -- the all-reduce is then staged
+    # through the host (gmvae_amd.parallel.all_reduce_flat) and the line says so (config.all_reduce, "fallback")
+    backend = os.environ.get("GMVAE_DIST_BACKEND") or "nccl"
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     n_gpus = world
+
+    def dev_all_reduce(t, op):                      # small control tensors: on the device over RCCL, through the host over gloo
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+            return t
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        return h.to(t.device)
 
     from types import SimpleNamespace
     from gmvae_amd.engine import Engine
@@ -196,6 +219,8 @@ def main():
     # replicas START different; sync_replicas() makes rank 0's parameters, moments, step and noise seed everyone's.  The
     # noise itself differs per rank by construction: the Philox counter holds the GLOBAL row (rank * B + b).
     eng = Engine(a.model, d.D, d.L, d.K, hidden, n_samples=d.S, random_seed=0 if world == 1 else None)
+    if a.safe_schedule:
+        eng.use_safe_schedule()
     eng.sync_replicas()
     # synthetic MNIST-shaped batch: Bernoulli(0.87) uint8, per-rank shard of the global batch
     x_np = (np.random.default_rng(1234 + rank).random((B, d.D)) < 0.87).astype(np.uint8)
@@ -217,20 +242,45 @@ def main():
     if rank == 0:
         elbo_cpu = cpu_parity(a.model, dims, flat0, x_np, eps_np, u_np)
         parity = {"elbo_hip": elbo_hip, "elbo_cpu_fp64": elbo_cpu, "rel_err": float(abs(elbo_hip - elbo_cpu) / abs(elbo_cpu))}
+        if not a.no_iwae_bound:
+            # BASELINE.json's metric also names the -log p(x) IWAE bound at K = 10: the S = 50 importance-weighted bound of the
+            # same model (the step's parameters) on a fixed seeded batch of 256 rows, HIP forward path vs the fp64 oracle on
+            # identical (x, eps, u).  A forward-only evaluation (gmvae_forward), outside the timed region.
+            try:
+                S_iw = 50
+                B_iw = max(8, min(256, B, int(2e7 // (d.D * S_iw))))      # (bounds the oracle's share of the run to seconds)
+                rn2 = np.random.default_rng(4242)
+                eps_iw = rn2.standard_normal((B_iw * S_iw, d.L)).astype(np.float32)
+                u_iw = None
+                if a.model == "gmvae":
+                    u_iw = np.clip(rn2.uniform(tiny, 1.0, (B_iw * S_iw, d.K)).astype(np.float32), tiny, np.nextafter(np.float32(1), np.float32(0)))
+                fw = eng.forward(x[:B_iw], torch.from_numpy(eps_iw), None if u_iw is None else torch.from_numpy(u_iw), n_samples=S_iw)
+                torch.cuda.synchronize()
+                t_iw = fw["tail"].cpu().numpy().astype(np.float64)
+                iw_hip = float(t_iw[0] / t_iw[4])
+                iw_cpu = -cpu_parity(a.model, dict(dims, S=S_iw), flat0, x_np[:B_iw], eps_iw, u_iw)
+                parity["iwae_bound"] = {"neg_log_px_bound_hip": iw_hip, "neg_log_px_bound_cpu_fp64": iw_cpu, "n_samples": S_iw,
+                                        "rows": B_iw, "rel_err": float(abs(iw_hip - iw_cpu) / abs(iw_cpu)),
+                                        "single_sample_neg_elbo_hip": -elbo_hip}
+            except Exception as e:                  # (never let the secondary figure take the line down)
+                parity["iwae_bound"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- the timed loop
     use_graph = not a.no_graph
+    fallbacks = []
+
     def fallback(why):
-        """A slower data-parallel path than the one the line is supposed to measure: an error unless --allow-fallback.
-        (Every decision that leads here is taken jointly by all ranks -- Engine._agree -- so they all exit or all go on.)"""
+        """A slower data-parallel path than the one the line is supposed to measure.  The run GOES ON and the JSON line is
+        printed either way -- with "fallback": true, the reasons, and config.all_reduce naming the path actually timed -- so
+        that an unattended multi-GPU run can never return nothing; without --allow-fallback the process then exits non-zero.
+        (Every decision that leads here is taken jointly by all ranks -- Engine._agree -- so they all take the same path.)"""
+        fallbacks.append(why)
         if rank == 0:
             print(f"[bench] {why}", file=sys.stderr)
-        if not a.allow_fallback:
-            if world > 1:
-                dist.destroy_process_group()
-            raise SystemExit(f"bench.py --gpus {world}: {why}; pass --allow-fallback to measure the slower path anyway")
 
-    if world > 1:
+    if world > 1 and backend != "nccl":
+        fallback(f"GMVAE_DIST_BACKEND={backend}: the all-reduce is staged through the host between two eager halves of the step")
+    elif world > 1:
         try:
             eng.enable_rccl()           # RCCL communicator inside libgmvae_hip.so: step + all-reduce + Adam in one graph
         except Exception as e:
@@ -260,7 +310,7 @@ def main():
             fallback(f"graph capture failed ({type(e).__name__}: {e}): eager launches")
             use_graph = False
             multi_fn = None
-        if world > 1 and use_graph and getattr(eng, "dp_mode", None) != "rccl-in-hipgraph":
+        if world > 1 and use_graph and getattr(eng, "dp_mode", None) != "rccl-in-hipgraph" and not fallbacks:
             fallback(f"the RCCL all-reduce was not captured inside the hipGraph (data-parallel mode: {getattr(eng, 'dp_mode', None)})")
     if not use_graph:
         def step_fn():
@@ -283,17 +333,24 @@ def main():
             run_steps(2 * G)
             torch.cuda.synchronize()
     else:
-        # every rank must issue the SAME number of steps (each contains a collective): fixed count, not wall time
-        run_steps(4000)
-        torch.cuda.synchronize()
+        # every rank must issue the SAME number of steps (each contains a collective): whole rounds of 2 G steps until
+        # ANY rank's clock says 0.75 s (one all-reduced stop flag per round), at most 4000 steps
+        t_pre, done = time.perf_counter(), 0
+        while done < 4000:
+            run_steps(2 * G)
+            torch.cuda.synchronize()
+            done += 2 * G
+            stop = torch.tensor([1 if time.perf_counter() - t_pre >= 0.75 else 0], dtype=torch.int32, device="cuda")
+            if bool(dev_all_reduce(stop, dist.ReduceOp.MAX).item()):
+                break
     # Safety net for unattended runs: the 3-launch schedule's workgroups wait for each other inside mega_fwd_bwd and
     # need the whole chip.  If a wait ever timed out during the pre-warm (something else held CUs), every rank
     # switches to the schedule without mutual waits and re-captures -- slower, never stalling.
     bad = torch.tensor([eng.handoff_timeouts()], dtype=torch.int32, device="cuda")
     if world > 1:
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        bad = dev_all_reduce(bad, dist.ReduceOp.MAX)
     safe_schedule = bool(bad.item())
-    if safe_schedule and use_graph:
+    if safe_schedule and use_graph and not eng.safe_schedule:
         if rank == 0:
             print("[bench] a hand-off of the fused schedule timed out during the pre-warm (something else holds part of the "
                   "chip): switching to the schedule without mutual waits -- reported as config.safe_schedule", file=sys.stderr)
@@ -308,6 +365,7 @@ def main():
             xs.copy_(torch.from_numpy((np.random.default_rng(4321 + rank).random((G, B, d.D)) < 0.87).astype(np.uint8)))
         run_steps(2 * G)
         torch.cuda.synchronize()
+    safe_schedule = bool(eng.safe_schedule)
     run_steps(a.warmup)
     torch.cuda.synchronize()
     if world > 1:
@@ -322,8 +380,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        dt = dev_all_reduce(t, dist.ReduceOp.MAX).item()
     final_tail = eng.grads[eng.P:].cpu().numpy().astype(np.float64)
     # ---- a short timed region (the driver runs --steps 20: ONE graph launch, 0.8 ms, a single host-clock sample) is
     # repeated: >= 10 more regions of the same K steps, each bracketed like the contract's; median alongside `value`
@@ -356,9 +413,7 @@ def main():
     replicas_identical = None
     if world > 1:                                   # every rank must hold bit-identical parameters
         cs = eng.params.detach().double().sum().reshape(1)
-        lo, hi = cs.clone(), cs.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        lo, hi = dev_all_reduce(cs.clone(), dist.ReduceOp.MIN), dev_all_reduce(cs.clone(), dist.ReduceOp.MAX)
         replicas_identical = bool((lo == hi).item())
     value = n_gpus * B * d.S * a.steps / dt
 
@@ -451,7 +506,8 @@ def main():
             import glob
             tag = {"BASELINE configs[2]": "bench", "per-GPU shard of BASELINE configs[4]": "config5_shard",
                    "bin/run_train.sh sizes": "run_train_sizes", "BASELINE configs[1]": "configs1",
-                   "BASELINE configs[0]": "configs0"}.get(workload_name(a, n_gpus)) if world == 1 else None
+                   "BASELINE configs[0]": "configs0", "BASELINE configs[1] at hidden 512": "configs1_h512",
+                   "BASELINE configs[2] at hidden 512": "configs2_h512"}.get(workload_name(a, n_gpus)) if world == 1 else None
             stats = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_{tag}_kernel_stats.csv"))) if tag else []
             kern_us = {}
             if stats:
@@ -526,13 +582,18 @@ def main():
                                    f"L={d.L} hidden={hidden} S={d.S}, batch {B}/GPU x {n_gpus} GPU "
                                    f"({workload_name(a, n_gpus)})",
                        "global_batch": B * n_gpus, "parallelism": f"dp{n_gpus}", "hipgraph": use_graph, "input_pipeline_on_device": bool(a.pipeline and world == 1), "safe_schedule": safe_schedule,
-                       "all_reduce": getattr(eng, "dp_mode", None), "replicas_identical": replicas_identical},
+                       "all_reduce": getattr(eng, "dp_mode", None) if use_graph or world == 1 else "torch.distributed (eager)",
+                       "dist_backend": backend if world > 1 else None, "replicas_identical": replicas_identical},
+            "fallback": bool(fallbacks), "fallback_reasons": fallbacks or None,
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "final_loss": final_tail[0] / max(final_tail[4], 1.0),
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if fallbacks and not a.allow_fallback:
+        # the line above carries the slower path's number, marked; the exit code says it is not the path asked for
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

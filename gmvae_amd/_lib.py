@@ -27,7 +27,7 @@ class GmvaeDims(C.Structure):
                 ("n_hidden", C.c_int32), ("hidden", C.c_int32 * MAX_HIDDEN),
                 ("sigma_min", C.c_float), ("raw_sigma_bias", C.c_float), ("temperature", C.c_float),
                 ("gen_bias_init", C.c_float), ("row0", C.c_uint64),
-                ("gen_bias_vec", C.c_void_p), ("gen_bias_len", C.c_int32), ("reserved_", C.c_int32)]   # ABI v3
+                ("gen_bias_vec", C.c_void_p), ("gen_bias_len", C.c_int32), ("sched_flags", C.c_int32)]   # ABI v4
 
 
 class GmvaeParamEntry(C.Structure):
@@ -74,6 +74,7 @@ def _load():
         "gmvae_kernel_occupancy": ([i32, C.POINTER(i32)], i32),
         "gmvae_step_schedule": ([dp, i32, vp], i32),
         "gmvae_debug_sk_stamps": ([vp], i32),
+        "gmvae_debug_sk_stamps_free": ([], i32),
         "gmvae_train_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, i32, i32, C.POINTER(i32), vp, vp, vp, vp, vp], i32),
         "gmvae_step_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),
     }
@@ -95,8 +96,11 @@ def check(rc: int, what: str):
     raise GmvaeError(f"{what}: hipError_t {rc}")
 
 
+SCHED_SAFE = 1        # GmvaeDims.sched_flags: only schedules without waits between the workgroups of a launch
+
+
 def make_dims(B, D, L, K, hidden, S=1, sigma_min=0.0, raw_sigma_bias=0.5, temperature=1.0, gen_bias_init=0.0, row0=0,
-              gen_bias_vec=None):
+              gen_bias_vec=None, sched_flags=0):
     """gen_bias_vec: fp32 device tensor [D] (ConditionalBernoulli's vector bias_init, scripts/base.py:102-103) or None;
     the caller keeps it alive for as long as the dims are used."""
     hidden = list(hidden)
@@ -108,6 +112,7 @@ def make_dims(B, D, L, K, hidden, S=1, sigma_min=0.0, raw_sigma_bias=0.5, temper
         d.hidden[i] = int(h)
     d.sigma_min, d.raw_sigma_bias = float(sigma_min), float(raw_sigma_bias)
     d.temperature, d.gen_bias_init = float(temperature), float(gen_bias_init)
+    d.sched_flags = int(sched_flags)
     d.row0 = int(row0)          # data parallel: global index of this device's first batch row (Philox counters only)
     if gen_bias_vec is not None:
         if gen_bias_vec.numel() != int(D) or not gen_bias_vec.is_cuda or not gen_bias_vec.is_contiguous():

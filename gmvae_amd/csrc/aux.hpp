@@ -167,7 +167,6 @@ __device__ __forceinline__ void binarize_quad(const uint64_t q, const unsigned c
   }
   *reinterpret_cast<uint32_t*>(x + (uint64_t)b * D + d4) = o;
 }
-constexpr int kBinQuadsPerThread = 4;      // as extra workgroups of finalize_adam: 1024 quads (4 KB of pixels) each
 
 // ------------------------------------------------------------ aux blocks
 constexpr int kMaxImgTasks = 32;

@@ -52,12 +52,12 @@ struct DwArgs {
   float ln_b1, ln_b2;          // then alpha_t = lr sqrt(-expm1(t ln b2)) / (-expm1(t ln b1)) per thread (ln b rounded from double)
   // VAE_GMP: the learned mixture prior's variables (loc, raw scale, mixture logits: one contiguous parameter range) have
   // no matrix-product gradient -- mega_fwd_bwd leaves one partial per panel (fa.gmp_part); gmp_blocks extra workgroups
-  // (after the binarisation blocks) sum them in panel order, apply the update and write the variables' LDS-image copies
+  // (after the tail block) sum them in panel order, apply the update and write the variables' LDS-image copies
   int gmp_blocks, gmp_nmap;
   ImgMap gmp_map[3];
   int tile_begin[kDwMaxT];
   DwTensor t[kDwMaxT];
-  FinalArgs fa;                // p, m, v, grads, Adam constants, loss-tail inputs, counters, images, binarisation blocks
+  FinalArgs fa;                // p, m, v, grads, Adam constants, loss-tail inputs, counters, images
 };
 
 // One wave's share [b_lo, b_hi) of the batch contraction for a 64 x 16 tile.  ALL of its operand loads (32 k-steps at
@@ -195,11 +195,10 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
   const int bid = blockIdx.x;
 #define DW_ST(i) if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + (i)] = wall_clock64()
   DW_ST(0);
-  if (bid >= a.total_tiles) {                    // the loss tail + counters, then the next batch's binarisation blocks
+  if (bid >= a.total_tiles) {                    // the loss tail + counters, then the mixture prior's workgroups
     if (bid == a.total_tiles) finalize_tail_block(fa, reinterpret_cast<float(*)[256]>(red));
-    else if (bid - a.total_tiles - 1 < fa.bin_blocks) finalize_bin_block(fa, bid - a.total_tiles - 1);
     else {                                         // mixture-prior variables: partials -> gradient -> TF-Adam -> image
-      const int e = (bid - a.total_tiles - 1 - fa.bin_blocks) * kDwThreads + (int)threadIdx.x;
+      const int e = (bid - a.total_tiles - 1) * kDwThreads + (int)threadIdx.x;
       if (e < fa.gmp_len) {
         const long long i = fa.gmp_off + e;
         float g = 0.f;

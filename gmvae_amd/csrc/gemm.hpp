@@ -68,15 +68,13 @@ struct Problem {
   float* C;
   int xbf16;               // dW of a uint8 activation (A = x^T, k-major rows of bytes; B = dY fp32 rows): bf16 MFMA path
   int xorder;              // tile order inside the launch (gemm_grouped: 0 split/tn/tm, 1 all tn of a tm on one XCD, 2 all tm of a (split, tn))
-  int split3;              // large-tile configuration: fp32 x fp32 products on the bf16 matrix cores (see split3 below):
-                           // 1 = six piece products, 2 = all nine
   int planes;              // operands of seg[0] are bf16 plane triples (hi, mid, lo as written by split_planes / the Bernoulli
-                           // epilogue's C3): a.ptr / b.ptr name plane 0 (16-bit elements, ld in elements); plane_rounds below
+                           // epilogue's C3): a.ptr / b.ptr name plane 0 (16-bit elements); plane_rounds3 below
   long long a_pstride, b_pstride;   // 16-bit elements between the planes of a / b
   unsigned short* C3;      // EPI_BERNOULLI: (sigmoid - x) written as planes [3][M][ldc] of 16-bit pieces (beside or instead of C);
                            // EPI_STORE with per-element options (bias / ReLU ...): the stored values also as planes (beside C)
   long long c3_stride;
-  int c3_b16;              // C3 in the blocked-by-16 layout of plane_rounds3: element (m, n) at ((n >> 4) M + m) 16 + (n & 15)
+                           // (always in plane_rounds3's blocked-by-16 layout: element (m, n) at ((n >> 4) M + m) 16 + (n & 15))
   float* colsum_out;       // bias gradient riding on a dW problem: column sums of operand b over the tile's k
                            // range, written by the tiles of the first tile row to colsum_out[split][n]
   const float* bias;
@@ -116,7 +114,7 @@ struct Cfg {
   static constexpr int OPS = NBUF * (LDA + LDB) * BK;               // floats, NBUF staging buffers
   static constexpr int CST = WK * BM * LDC;                          // floats, C staging
   static constexpr int XBF = (BM == 64 && BN == 64 && BK == 64) ? 4 * 64 * 96 / 2 : 0;     // the bf16 path's 4 images [64][96] x 2 B
-  static constexpr int CSP = BM >= 128 ? 8 : 4;                      // column-sum partials per thread (plane_rounds: 8)
+  static constexpr int CSP = BM >= 128 ? 8 : 4;                      // column-sum partials per thread (plane_rounds3: 8)
   static constexpr int LDS0 = OPS > CST + CSP * kThreads ? OPS : CST + CSP * kThreads;
   static constexpr int LDS_FLOATS = LDS0 > XBF ? LDS0 : XBF;
   // waves per SIMD the register allocator must leave room for: the small configuration's launches carry more
@@ -319,190 +317,24 @@ __device__ __forceinline__ void split_pair(const float v0, const float v1, unsig
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
 }
 
-// ---- fp32 x fp32 products on the bf16 matrix cores ("split3", the 128x128x32 configuration) ----------------------
-// Both operands are written as hi + mid + lo, three bf16 pieces that reproduce the 24-bit significand EXACTLY
-// (truncation splits, exact residuals).  a*b = sum of nine piece products, each exact in fp32; the three smallest
-// (mid*lo, lo*mid, lo*lo <= 2^-23 |a b|, below the rounding of the fp32 product itself) are dropped by default, so a
-// k-step of 16 costs 6 v_mfma_f32_32x32x16_bf16 (192 cycles) instead of 8 v_mfma_f32_32x32x2_f32 (512 cycles), and
-// the accumulation stays fp32.  GMVAE_SPLIT3=9 keeps all nine (every product exact, 288 cycles).
-// LDS images follow the SOURCE orientation, so the staging stores stay 8-byte and coalesced: a k-contiguous operand
-// becomes [mn][kSplitPK] (fragments = plain 16-byte reads), an mn-contiguous one [k][kSplitPM] (fragments through
-// ds_read_b64_tr_b16).  Three planes (hi, mid, lo) of kSplitPlane elements per operand.
-constexpr int kSplitPK = 40;      // [128 mn][32 k + 8]: 80-byte rows, conflict-free 16-byte fragment reads
-constexpr int kSplitPM = 160;     // [32 k][128 mn + 32]: 320-byte rows, the 4 rows of a transposing read tile the banks
-constexpr int kSplitPlane = 128 * kSplitPK;
-static_assert(kSplitPlane == 32 * kSplitPM, "both image orientations use the same plane size");
-
-template <int LD>
-__device__ __forceinline__ bf16x8_t tr_frag_ld(const unsigned short* p) {
-  typedef __attribute__((address_space(3))) s16x4_t* lp;
-  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p));
-  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p + 4 * LD));
-  typedef short s16x8_t __attribute__((ext_vector_type(8)));
-  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8_t, v);
-}
-
-// 4 staged slots of this thread (fp32, 4 consecutive elements along the source's contiguous dimension) -> the three
-// bf16 planes of the operand image
-template <int NS>
-__device__ __forceinline__ void split_store(unsigned short* __restrict__ img, const bool mc, const int tid, const float4 (&r)[NS]) {
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    const int s = tid + i * kThreads;
-    int off;
-    if (!mc) off = ((s & 3) + 4 * (s >> 5)) * kSplitPK + (((s >> 2) & 7) << 2);       // (mn, 4 k)
-    else off = ((s & 3) + 4 * (s >> 7)) * kSplitPM + (((s >> 2) & 31) << 2);          // (k, 4 mn)
-    const float v[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-    unsigned hi[4], mi[4], lo[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned hb = __float_as_uint(v[j]) & 0xffff0000u;
-      const float r1 = v[j] - __uint_as_float(hb);
-      const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-      const float r2 = r1 - __uint_as_float(mb);
-      hi[j] = hb >> 16; mi[j] = mb >> 16; lo[j] = __float_as_uint(r2) >> 16;
-    }
-    *reinterpret_cast<uint2*>(img + off) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-    *reinterpret_cast<uint2*>(img + kSplitPlane + off) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
-    *reinterpret_cast<uint2*>(img + 2 * kSplitPlane + off) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
-  }
-}
-
-// one staged 32-deep round of a 64x64 wave tile: 2 k-steps of 16, 2 x 2 MFMA tiles, 6 (or 9) piece products each
-template <bool AMC, bool BMC>
-__device__ __forceinline__ void split_round(const unsigned short* __restrict__ Ai, const unsigned short* __restrict__ Bi,
-                                            const int wm0, const int wn0, const int lane, const bool nine,
-                                            f32x16 (&acc)[2][2]) {
-  const int khalf = lane >> 5, l31 = lane & 31;
-  const int g16 = lane >> 4, i16 = lane & 15;
-  const int fro = (8 * (g16 >> 1) + (i16 >> 2)) * kSplitPM + 16 * (g16 & 1) + 4 * (i16 & 3);
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    bf16x8_t a[2][3], b[2][3];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        if (AMC) a[i][pl] = tr_frag_ld<kSplitPM>(Ai + pl * kSplitPlane + ks * 16 * kSplitPM + wm0 + i * 32 + fro);
-        else a[i][pl] = *reinterpret_cast<const bf16x8_t*>(Ai + pl * kSplitPlane + (wm0 + i * 32 + l31) * kSplitPK + ks * 16 + 8 * khalf);
-        if (BMC) b[i][pl] = tr_frag_ld<kSplitPM>(Bi + pl * kSplitPlane + ks * 16 * kSplitPM + wn0 + i * 32 + fro);
-        else b[i][pl] = *reinterpret_cast<const bf16x8_t*>(Bi + pl * kSplitPlane + (wn0 + i * 32 + l31) * kSplitPK + ks * 16 + 8 * khalf);
-      }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f32x16 c = acc[i][j];
-        if (nine) {                                // the three smallest piece products first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][1], c, 0, 0, 0);
-        }
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
-  }
-}
 
 // ---- operands split ONCE by their producer ("planes") ------------------------------------------------------------
-// split3 above pays ~450 VALU instructions per thread and round for the fp32 -> 3 x bf16 conversion, un-overlapped at one
-// workgroup per CU: 1.1 - 1.3x slower than the fp32 MFMA loop.  Here the three pieces of every operand element already
-// lie in memory as three 16-bit planes (written by split_planes below or by the Bernoulli epilogue's C3 output), a round
-// is 12 16-byte loads and 12 16-byte LDS stores per thread with no arithmetic, and the images and the piece-product
-// round (split_round) are split3's.  6 x 48 v_mfma_f32_32x32x16_bf16 cycles per 32-deep round: 1536 against 4096.
-// (Measured and dropped: 16-deep rounds in two LDS buffers with one barrier per round and the next fragments read behind
-// it -- 8-25 % SLOWER on the config-5 GEMMs: a k-contiguous operand then arrives as 32-byte pieces of 128-byte lines and a
-// round's fixed costs are paid twice as often.  Counters of the loop kept (profiles/round3_pmc_config5_mfma.txt): matrix
-// pipes busy 43-46 % of cycles at 2.1 GHz; per workgroup and round 48 KB go into LDS through 16-byte stores (~79 B/clk/CU)
-// and 96 KB of fragments come out -- with two workgroups per CU that is ~2000 LDS cycles beside 1536 matrix cycles.)
+// fp32 x fp32 products on the bf16 matrix cores: both operands are written as hi + mid + lo, three 16-bit pieces that
+// reproduce the 24-bit significand EXACTLY (split_pair above); a*b = sum of nine piece products, each exact in fp32; the
+// three smallest (mid*lo, lo*mid, lo*lo <= 2^-23 |a b|, below the rounding of the fp32 product itself) are dropped, so a
+// k-step of 16 costs 6 v_mfma_f32_32x32x16_bf16 (192 cycles) instead of 8 v_mfma_f32_32x32x2_f32 (512 cycles) and the
+// accumulation stays fp32.  The split happens ONCE, outside the GEMM: the three pieces of every operand element lie in
+// memory as three 16-bit planes (written by split_planes_b16 below, by a producing GEMM's C3 epilogue or by the Bernoulli
+// epilogue).  (Measured and removed in round 4: converting per tile inside the loop -- 1.1 - 1.3x SLOWER than the fp32 MFMA
+// loop -- and a first plane loop over row-major planes staged through 48 registers -- 8 - 25 % slower than the one below;
+// profiles/round3_notes.md.)
 // The per-k scale of an IWAE weight gradient cannot ride on the pieces: the producer writes the planes of the SCALED
-// activation (split_planes' rowscale) and `kscale` only weighs the bias gradient's column sums here.
-template <bool MC>
-__device__ __forceinline__ void plane_map(const int tid, const uint32_t ld, const int mn0, const int kb, uint32_t& e0,
-                                          uint32_t& slot, uint32_t& round, uint32_t (&w)[2]) {
-  if (!MC) {            // [mn][k]: 4 chunks of 8 k per row; this thread: rows (tid >> 2) and + 64
-    e0 = (uint32_t)(mn0 + (tid >> 2)) * ld + (uint32_t)kb + 8u * (tid & 3);
-    slot = 64u * ld; round = 32u;
-    w[0] = (uint32_t)(tid >> 2) * kSplitPK + 8u * (tid & 3);
-    w[1] = w[0] + 64u * kSplitPK;
-  } else {              // [k][mn]: 16 chunks of 8 mn per k row; this thread: k rows (tid >> 4) and + 16
-    e0 = (uint32_t)(kb + (tid >> 4)) * ld + (uint32_t)mn0 + 8u * (tid & 15);
-    slot = 16u * ld; round = 32u * ld;
-    w[0] = (uint32_t)(tid >> 4) * kSplitPM + 8u * (tid & 15);
-    w[1] = w[0] + 16u * kSplitPM;
-  }
-}
+// activation (split_planes_b16's rowscale) and `kscale` only weighs the bias gradient's column sums here.
 
-template <bool AMC, bool BMC>
-__device__ __forceinline__ void plane_rounds(unsigned short* __restrict__ img, const unsigned short* __restrict__ A,
-                                             const uint32_t a_ld, const long long a_ps, const unsigned short* __restrict__ Bp,
-                                             const uint32_t b_ld, const long long b_ps, const float* __restrict__ kscale,
-                                             const bool do_cs, const int m0, const int n0, const int kb, const int NC,
-                                             const int tid, const int lane, const int wm0, const int wn0,
-                                             f32x16 (&acc)[2][2], float (&cs8)[8], const int dbgf = 0) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  unsigned short* const Ai = img;
-  unsigned short* const Bi = img + 3 * kSplitPlane;
-  uint32_t ea, eb, a_slot, b_slot, a_round, b_round, wa[2], wb[2];
-  plane_map<AMC>(tid, a_ld, m0, kb, ea, a_slot, a_round, wa);
-  plane_map<BMC>(tid, b_ld, n0, kb, eb, b_slot, b_round, wb);
-  u32x4 ra[3][2], rb[3][2];
-  int kk = kb + (tid >> 4);                       // (column sums: this thread's k rows of an mn-contiguous b)
-#define GMVAE_PL_GLOAD()                                                                                   \
-  {                                                                                                        \
-    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                       \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
-        ra[pl][i] = *reinterpret_cast<const u32x4*>(A + pl * a_ps + ea + i * a_slot);                      \
-        rb[pl][i] = *reinterpret_cast<const u32x4*>(Bp + pl * b_ps + eb + i * b_slot);                     \
-      }                                                                                                    \
-    ea += a_round; eb += b_round;                                                                          \
-  }
-#define GMVAE_PL_LSTORE()                                                                                  \
-  {                                                                                                        \
-    if (BMC && do_cs) {                                                                                    \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
-        const float sc = kscale ? kscale[kk + 16 * i] : 1.f;                                               \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
-          const unsigned h = rb[0][i][q], m = rb[1][i][q], l = rb[2][i][q];                                \
-          cs8[2 * q] += sc * ((__uint_as_float(l << 16) + __uint_as_float(m << 16)) + __uint_as_float(h << 16));                      \
-          cs8[2 * q + 1] += sc * ((__uint_as_float(l & 0xffff0000u) + __uint_as_float(m & 0xffff0000u)) + __uint_as_float(h & 0xffff0000u)); \
-        }                                                                                                  \
-      }                                                                                                    \
-      kk += 32;                                                                                            \
-    }                                                                                                      \
-    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                       \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
-        *reinterpret_cast<u32x4*>(Ai + pl * kSplitPlane + wa[i]) = ra[pl][i];                              \
-        *reinterpret_cast<u32x4*>(Bi + pl * kSplitPlane + wb[i]) = rb[pl][i];                              \
-      }                                                                                                    \
-  }
-  GMVAE_PL_GLOAD();
-  GMVAE_PL_LSTORE();
-  __syncthreads();
-#pragma unroll 1
-  for (int c = 0; c < NC; ++c) {
-    const bool more = c + 1 < NC;
-    if (more && !(dbgf & 2)) GMVAE_PL_GLOAD();
-    split_round<AMC, BMC>(Ai, Bi, wm0, wn0, lane, false, acc);
-    __syncthreads();                              // every wave is done with the only image
-    if (more && !(dbgf & 4)) GMVAE_PL_LSTORE();
-    __syncthreads();
-  }
-#undef GMVAE_PL_GLOAD
-#undef GMVAE_PL_LSTORE
-}
-
-// ---- plane rounds, third form: LDS-DMA into a ring of three 16-deep buffers ------------------------------------------
-// Timing experiments on plane_rounds (tools/gemm_planes_dbg.py, results discarded): without its global loads the loop is
-// 17-22 % shorter, without its LDS stores 10 %, without both 25-34 % -- and what is left (fragment reads, MFMAs, two barriers
-// per round) still runs the matrix pipes at ~65 %: the 48 staging registers leave no room to read the next k-step's
-// fragments behind the current MFMAs.  Here nothing is staged through registers:
+// ---- plane rounds: LDS-DMA into a ring of three 16-deep buffers ------------------------------------------------------
+// (The removed register-staged loop, timing experiments with results discarded: without its global loads 17-22 % shorter,
+// without its LDS stores 10 %, without both 25-34 % -- and what was left still ran the matrix pipes at ~65 %: 48 staging
+// registers left no room to read the next k-step's fragments behind the current MFMAs.)  Here nothing is staged through registers:
 //  * the planes lie in memory BLOCKED by 16 along their contiguous dimension ("B16": element (r, c) of a [Rows][Cols] matrix at
 //    ((c >> 4) Rows + r) 16 + (c & 15)), so a [128 mn] x [16 k] tile of a k-contiguous use is ONE contiguous 4 KB piece and
 //    a [16 k] x [128 mn] tile of an mn-contiguous use is eight contiguous 512-byte pieces: every wave-instruction of the
@@ -669,25 +501,6 @@ __device__ __forceinline__ void plane_rounds3(unsigned short* __restrict__ img, 
 #undef GMVAE_P3_SG
 }
 
-// fp32 [rows][ld] (x rowscale[row]) -> three planes of 16-bit pieces hi, mid, lo (exact residuals:
-// hi + mid + lo == the fp32 value, bit for bit); n a multiple of 8, 16-byte aligned
-__global__ __launch_bounds__(256) void split_planes(const float* __restrict__ src, const float* __restrict__ rowscale,
-                                                     const int ld, const long long n, unsigned short* __restrict__ dst,
-                                                     const long long pstride) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  for (long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; e < n; e += (long long)gridDim.x * 256 * 8) {
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + e), v1 = *reinterpret_cast<const f32x4*>(src + e + 4);
-    const float sc = rowscale ? rowscale[e / ld] : 1.f;
-    const float v[8] = {v0.x * sc, v0.y * sc, v0.z * sc, v0.w * sc, v1.x * sc, v1.y * sc, v1.z * sc, v1.w * sc};
-    unsigned hi[4], mi[4], lo[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], hi[j], mi[j], lo[j]);
-    const long long o = e;
-    *reinterpret_cast<u32x4*>(dst + o) = u32x4{hi[0], hi[1], hi[2], hi[3]};
-    *reinterpret_cast<u32x4*>(dst + pstride + o) = u32x4{mi[0], mi[1], mi[2], mi[3]};
-    *reinterpret_cast<u32x4*>(dst + 2 * pstride + o) = u32x4{lo[0], lo[1], lo[2], lo[3]};
-  }
-}
 
 // ---- the 128x128x32 configuration's interior rounds ("big rounds") -----------------------------------------------
 // For tiles completely inside both fp32 operands and k ranges that are whole 32-deep rounds.  LDS image of an operand
@@ -853,13 +666,11 @@ __device__ __forceinline__ void big_rounds(float* __restrict__ lds, const float*
 #undef GMVAE_BIG_STEP
 }
 
-// SP3 = 1: the instance that can run split3 problems (only the 128x128 configuration has one; a kernel of its own, because
-// the piece-product loop's registers would otherwise push the fp32 loop below two workgroups per CU)
 // BIG = 1: the 128x128 instance for launches in which EVERY tile is interior, fp32 and made of whole rounds (the host
 // checks: big_eligible); its only main loop is big_rounds -- a kernel of its own so that the general loop's loaders do
-// not share its register budget.
-template <class C, int SP3 = 0, int BIG = 0>
-__global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(const Launch L) {
+// not share its register budget.  BIG = 2: every problem of the launch reads pre-split planes (plane_rounds3).
+template <class C, int BIG = 0>
+__global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Launch L) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   constexpr int kBK = C::BK;
   const int tid = threadIdx.x;
@@ -966,7 +777,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
   float csum = 0.f;
   constexpr int CSG = kThreads / C::BN;          // k groups of the column-sum threads
   const int cs_n = tid % C::BN, cs_k = tid / C::BN;
-  bool did_bf16 = false, did_split = false, did_big = false, did_planes = false;
+  bool did_bf16 = false, did_big = false, did_planes = false;
   float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if constexpr (C::BM == 64 && C::BN == 64 && C::BK == 64) {
@@ -1105,49 +916,15 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
     op_store<C::BN, kBK, C::LDB, C::NSB>(Bs_, b_mc, tid, rb);               \
   }
 
-    if constexpr (SP3 && C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2) {
-      const int sp3 = L.p[pi].split3;
-      if (sp3) {                                  // (wave-uniform) this problem runs on the bf16 matrix cores
-        static_assert(6 * kSplitPlane * 2 <= C::LDS_FLOATS * 4, "split3 images must fit the kernel's LDS");
-        unsigned short* const Ai = reinterpret_cast<unsigned short*>(lds);
-        unsigned short* const Bi = Ai + 3 * kSplitPlane;
-        const bool nine = sp3 > 1;
-        __syncthreads();                          // LDS is free
-        GMVAE_GLOAD(0);
-#pragma unroll 1
-        for (int c = 0; c < NC; ++c) {
-          split_store<C::NSA>(Ai, a_mc, tid, ra);
-          split_store<C::NSB>(Bi, b_mc, tid, rb);
-          if (do_colsum) {                        // (operand b is mn-contiguous here: a dW problem) columns 4 ((tid >> 2) & 31)..
-#pragma unroll
-            for (int i = 0; i < C::NSB; ++i) { cs4.x += rb[i].x; cs4.y += rb[i].y; cs4.z += rb[i].z; cs4.w += rb[i].w; }
-          }
-          __syncthreads();
-          if (c + 1 < NC) GMVAE_GLOAD(c + 1);
-          if (a_mc) {
-            if (b_mc) split_round<true, true>(Ai, Bi, wm0, wn0, lane, nine, acc);
-            else split_round<true, false>(Ai, Bi, wm0, wn0, lane, nine, acc);
-          } else {
-            if (b_mc) split_round<false, true>(Ai, Bi, wm0, wn0, lane, nine, acc);
-            else split_round<false, false>(Ai, Bi, wm0, wn0, lane, nine, acc);
-          }
-          __syncthreads();
-        }
-        did_split = true;
-        continue;
-      }
-    }
     if constexpr (BIG == 2) {                     // every problem of the launch has pre-split operands (host: planes_eligible)
-      static_assert(!SP3 && C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2, "plane rounds: 128x128x32");
-      static_assert(6 * kSplitPlane * 2 <= C::LDS_FLOATS * 4, "plane images must fit the kernel's LDS");
+      static_assert(C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2, "plane rounds: 128x128x32");
       __syncthreads();        // LDS is free
       if (sgi == 0) GMVAE_GSTAMP(6);
       const unsigned short* const Ah = static_cast<const unsigned short*>(a_ptr);
       const unsigned short* const Bh = static_cast<const unsigned short*>(b_ptr);
       const long long a_ps = L.p[pi].a_pstride, b_ps = L.p[pi].b_pstride;
       static_assert(kP3Ring * kP3Buf * 2 <= C::LDS_FLOATS * 4, "plane_rounds3's ring must fit the kernel's LDS");
-      const int pform = L.p[pi].planes;             // bit 0: natural plane layout (plane_rounds), bit 1: blocked by 16 (plane_rounds3)
-      if (pform & 2) {
+      {
         // (B16 layout: the leading extent of an operand's matrix = its mn extent when k-contiguous, its k extent otherwise)
         const uint32_t a_rows = a_mc ? (uint32_t)K : (uint32_t)a_n, b_rows = b_mc ? (uint32_t)K : (uint32_t)b_n;
 #define GMVAE_PL3(AMC_, BMC_) \
@@ -1159,23 +936,13 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
           if (a_mc) GMVAE_PL3(true, true); else GMVAE_PL3(false, true);
         }
 #undef GMVAE_PL3
-      } else {
-#define GMVAE_PL(AMC_, BMC_) \
-  plane_rounds<AMC_, BMC_>(reinterpret_cast<unsigned short*>(lds), Ah, (uint32_t)a_ld, a_ps, Bh, (uint32_t)b_ld, b_ps, kscale, \
-                           do_colsum, m0, n0, kb, NC, tid, lane, wm0, wn0, acc, cs8, pform >> 4)
-        if (!b_mc) {
-          if (a_mc) GMVAE_PL(true, false); else GMVAE_PL(false, false);
-        } else {
-          if (a_mc) GMVAE_PL(true, true); else GMVAE_PL(false, true);
-        }
-#undef GMVAE_PL
       }
       if (do_colsum) did_planes = true;
       if (sgi == 0) GMVAE_GSTAMP(1);
       continue;
     }
     if constexpr (BIG == 1) {
-      static_assert(!SP3 && C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2, "big rounds: 128x128x32");
+      static_assert(C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2, "big rounds: 128x128x32");
       __syncthreads();        // LDS is free
       if (sgi == 0) GMVAE_GSTAMP(6);
       const float* const Af = static_cast<const float*>(a_ptr);
@@ -1255,7 +1022,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
           *reinterpret_cast<float4*>(lds + C::CST + 8 * tid) = make_float4(cs8[0], cs8[1], cs8[2], cs8[3]);
           *reinterpret_cast<float4*>(lds + C::CST + 8 * tid + 4) = make_float4(cs8[4], cs8[5], cs8[6], cs8[7]);
         }
-      } else if (did_bf16 || did_split || did_big) *reinterpret_cast<float4*>(lds + C::CST + 4 * tid) = cs4;     // (k rows tid>>4 + 16i, columns 4(tid&15)..)
+      } else if (did_bf16 || did_big) *reinterpret_cast<float4*>(lds + C::CST + 4 * tid) = cs4;     // (k rows tid>>4 + 16i, columns 4(tid&15)..)
       else lds[C::CST + tid] = csum;
     }
   }
@@ -1265,9 +1032,6 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
     if (did_planes) {                              // column tid: threads (tid >> 3) + 16 g hold its chunk
 #pragma unroll
       for (int g = 0; g < 16; ++g) v += lds[C::CST + 8 * ((tid >> 3) + 16 * g) + (tid & 7)];
-    } else if (did_split) {                        // column tid: the 8 threads 4 (tid >> 2) + a + 128 b staged its quad
-#pragma unroll
-      for (int g = 0; g < 8; ++g) v += lds[C::CST + 4 * (4 * (tid >> 2) + (g & 3) + 128 * (g >> 2)) + (tid & 3)];
     } else if (did_big) {                          // column tid: threads (tid >> 2) + 32 g hold its quad (k-quads g)
 #pragma unroll
       for (int g = 0; g < 8; ++g) v += lds[C::CST + 4 * ((tid >> 2) + 32 * g) + (tid & 3)];
@@ -1298,7 +1062,6 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
     const long long soff = (long long)split * L.p[pi].split_stride;
     unsigned short* const C3s = L.p[pi].C3;        // (EPI_STORE with bias / ReLU: the activation also leaves as planes; never with splits)
     const long long c3ss = L.p[pi].c3_stride;
-    const bool c3s_b16 = L.p[pi].c3_b16 != 0;
     // plain slab / matrix store of an interior tile (every weight-gradient tile but the edge ones): no per-element
     // options, all passes unrolled, 16-byte stores
     const bool plain = !bias && !bias2 && !addsrc && !mask && !rowscale && !relu && addconst == 0.f && m0 + C::BM <= M &&
@@ -1362,8 +1125,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
             unsigned hi[2], mi[2], lo[2];
             split_pair(v[0], v[1], hi[0], mi[0], lo[0]);
             split_pair(v[2], v[3], hi[1], mi[1], lo[1]);
-            unsigned short* const d3 = c3s_b16 ? C3s + ((long long)(nb >> 4) * M + (m0 + row)) * 16 + (nb & 15)
-                                               : C3s + (long long)(m0 + row) * ldc + nb;
+            unsigned short* const d3 = C3s + ((long long)(nb >> 4) * M + (m0 + row)) * 16 + (nb & 15);
             *reinterpret_cast<uint2*>(d3) = make_uint2(hi[0], hi[1]);
             *reinterpret_cast<uint2*>(d3 + c3ss) = make_uint2(mi[0], mi[1]);
             *reinterpret_cast<uint2*>(d3 + 2 * c3ss) = make_uint2(lo[0], lo[1]);
@@ -1412,7 +1174,7 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
             if (nb + j >= N) break;
             unsigned hi, mi, lo;
             split_pair(v[j], 0.f, hi, mi, lo);
-            const long long o = c3s_b16 ? ((long long)((nb + j) >> 4) * M + m) * 16 + ((nb + j) & 15) : (long long)m * ldc + nb + j;
+            const long long o = ((long long)((nb + j) >> 4) * M + m) * 16 + ((nb + j) & 15);
             C3s[o] = (unsigned short)hi; C3s[o + c3ss] = (unsigned short)mi; C3s[o + 2 * c3ss] = (unsigned short)lo;
           }
         }
@@ -1424,7 +1186,6 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
     const int ldx = L.p[pi].ldx, x_div = L.p[pi].x_div, nparts = L.p[pi].nparts;
     unsigned short* const C3 = L.p[pi].C3;         // (only set for launches whose tiles are all interior: planes_eligible)
     const long long c3s = L.p[pi].c3_stride;
-    const bool c3_b16 = L.p[pi].c3_b16 != 0;       // planes blocked by 16 along n (plane_rounds3's layout)
     if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && (!Cout || al16(Cout)) && al16(bias) && (!bias2 || al16(bias2)) && (ldx & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(xp) & 3) == 0) {
       // interior tile: the bias quad once, the 4 target bytes of a pass as one word; every pass's target word AND staged
@@ -1468,12 +1229,11 @@ __global__ __launch_bounds__(kThreads, SP3 ? 1 : C::WAVES_EU) void gemm_grouped(
           v[j] = (lam >= 0.f ? rcp : e * rcp) - xv;
         }
         if (Cout) *reinterpret_cast<float4*>(Cout + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
-        if (C3) {                                   // the three 16-bit pieces of (sigmoid - x), one plane each (plane_rounds' operand)
+        if (C3) {                                   // the three 16-bit pieces of (sigmoid - x), one plane each (plane_rounds3's operand)
           unsigned hi[2], mi[2], lo[2];
           split_pair(v[0], v[1], hi[0], mi[0], lo[0]);
           split_pair(v[2], v[3], hi[1], mi[1], lo[1]);
-          unsigned short* const d3 = c3_b16 ? C3 + ((long long)(nb >> 4) * M + (m0 + row)) * 16 + (nb & 15)
-                                            : C3 + (long long)(m0 + row) * ldc + nb;
+          unsigned short* const d3 = C3 + ((long long)(nb >> 4) * M + (m0 + row)) * 16 + (nb & 15);
           *reinterpret_cast<uint2*>(d3) = make_uint2(hi[0], hi[1]);
           *reinterpret_cast<uint2*>(d3 + c3s) = make_uint2(mi[0], mi[1]);
           *reinterpret_cast<uint2*>(d3 + 2 * c3s) = make_uint2(lo[0], lo[1]);

@@ -38,11 +38,15 @@ constexpr int kSkNs1 = 4;        // slabs of the skinny schedule's first layer (
 
 // Workgroups that share one 16-row panel of mega_fwd_bwd (they split its decoder chunks): as many as keep the
 // whole grid co-resident on the chip's 256 CUs (one 150 KB-LDS workgroup per CU).
-static int mega_q(int B) {
-  const int panels = (B + 15) / 16;
+// GmvaeDims::sched_flags & GMVAE_SCHED_SAFE: the schedules in which no workgroup waits for another of its own launch
+// (one workgroup per panel, the first layer as a launch of its own) -- what a caller degrades to after a hand-off timeout
+static bool sched_safe(const GmvaeDims& d) { return (d.sched_flags & GMVAE_SCHED_SAFE) != 0; }
+static int mega_q(const GmvaeDims& d) {
+  const int panels = (d.B + 15) / 16;
   int q = panels * 4 <= 256 ? 4 : panels * 2 <= 256 ? 2 : 1;
-  const char* e = getenv("GMVAE_MEGA_Q");
+  const char* e = getenv("GMVAE_MEGA_Q");          // (tests / diagnostics)
   if (e && atoi(e) >= 1 && atoi(e) <= kMegaQMax) q = atoi(e);
+  if (sched_safe(d)) q = 1;
   return q;
 }
 
@@ -155,34 +159,30 @@ static int dw_splits(long long B) {
   long long ns = B / 128;
   if (ns < 1) ns = 1;
   if (ns > NS_MAX) ns = NS_MAX;
-  const char* e = getenv("GMVAE_NSPLIT");
-  if (e && atoi(e) >= 1 && atoi(e) <= NS_MAX) ns = atoi(e);
   return (int)ns;
 }
 static int fwd_splits(int D) {
-  int ns = (D + 255) / 256;
-  const char* e = getenv("GMVAE_FWD_SPLITS");      // tuning hook (tools/sweep.sh)
-  if (e && atoi(e) >= 1) ns = atoi(e);
+  const int ns = (D + 255) / 256;
   return ns < 1 ? 1 : (ns > NS_MAX ? NS_MAX : ns);
 }
-static int env_cfg(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return (e && e[0]) ? atoi(e) : dflt;
-}
-static bool fused_ok(const GmvaeDims& d, int model);
 // the single-launch per-row kernel (mega.hpp), all three models: one hidden layer <= 64, S = 1, 16-byte aligned
 // x rows, its LDS budget, and (VAE_GMP) one prior-gradient partial per workgroup
-static bool mega_ok(const GmvaeDims& d, int model) {
-  const char* e = getenv("GMVAE_NO_MEGA");
-  if (e && atoi(e)) return false;
-  const char* e2 = getenv("GMVAE_NO_FUSED");
-  if (e2 && atoi(e2)) return false;
+// (the *_shape predicates read the dims only: carve() sizes the workspace with them, so that its layout never depends on an
+//  environment switch; the *_ok forms add the switches and choose the schedule)
+static bool mega_shape(const GmvaeDims& d, int model) {
   if (d.n_hidden != 1 || d.S != 1 || d.D % 16) return false;
   if (d.gen_bias_vec) return false;            // the vector bias_init is applied by the grouped GEMM's epilogue (Problem::bias2)
   const int H = d.hidden[0];
   if (H % 16 || H > 64 || d.L % 2 || d.L > 128 || d.K > 64) return false;      // L even: k-steps of 4 over [mu | raw]
   if (model == GMVAE_MODEL_VAE_GMP && (d.B + kPanel - 1) / kPanel > GMP_PARTS) return false;
   return (size_t)mega_lay(H, d.L, d.K, d.D, model).total * 4 <= 160 * 1024;
+}
+static bool mega_ok(const GmvaeDims& d, int model) {
+  const char* e = getenv("GMVAE_NO_MEGA");
+  if (e && atoi(e)) return false;
+  const char* e2 = getenv("GMVAE_NO_FUSED");
+  if (e2 && atoi(e2)) return false;
+  return mega_shape(d, model);
 }
 // mega2_fwd_bwd (mega2.hpp): the steady-state launch specialised for the reference's default sizes
 static bool mega2_ok(const GmvaeDims& d, int model) {
@@ -192,38 +192,43 @@ static bool mega2_ok(const GmvaeDims& d, int model) {
          d.D == M2::D && d.B <= 1024;
 }
 // the skinny schedule (skinny.hpp): GMVAE, one WIDE hidden layer, a SMALL batch -- bin/run_train.sh's sizes
-static bool skinny_ok(const GmvaeDims& d, int model) {
-  const char* e = getenv("GMVAE_NO_SKINNY");
-  if (e && atoi(e)) return false;
+constexpr int kSkMaxB = 4096;       // hard bound of the skinny schedule's batch (its buffers are carved up to here)
+static bool skinny_shape(const GmvaeDims& d, int model) {
   // GMVAE; the VAE with the standard-normal prior (no y path: eight launches); VAE_GMP (the learned mixture prior is not
   // column-local: its log-density, its share of dz and its variables' gradients stay three row kernels: eleven launches)
   if (d.n_hidden != 1 || d.S != 1) return false;
   const int H = d.hidden[0];
   // measured against the general schedule at H = 256 / 512, L = 128 (tools/sk_sweep.py, one box): 2.9x faster at B = 32..64,
   // 2.2x at 256, 1.7x at 512, 1.2 - 1.4x at 1024; not measured beyond
-  int maxb = 1024;
-  if (const char* mb = getenv("GMVAE_SKINNY_MAXB")) maxb = atoi(mb);
   // (L a multiple of 4: 16-byte loads along latent rows; a ragged last tile of 16 latent dimensions is masked)
   // (K <= 16: the y path's per-row softmax in 16 lanes -- GMVAE only; the mixture prior's K is the row kernels' business)
   return H % 64 == 0 && H <= 1024 && d.D % 16 == 0 && d.L % 4 == 0 && d.L >= 4 && d.L <= 256 &&
-         (model != GMVAE_MODEL_GMVAE || d.K <= 16) && d.B <= maxb;
+         (model != GMVAE_MODEL_GMVAE || d.K <= 16) && d.B <= kSkMaxB;
 }
-static bool fused_ok(const GmvaeDims& d, int model) {
-  const char* e = getenv("GMVAE_NO_FUSED");
+static bool skinny_ok(const GmvaeDims& d, int model) {
+  const char* e = getenv("GMVAE_NO_SKINNY");
   if (e && atoi(e)) return false;
+  int maxb = 1024;
+  if (const char* mb = getenv("GMVAE_SKINNY_MAXB")) maxb = atoi(mb) < kSkMaxB ? atoi(mb) : kSkMaxB;     // (tools/sk_sweep.py)
+  return skinny_shape(d, model) && d.B <= maxb;
+}
+static bool fused_shape(const GmvaeDims& d, int model) {
   if (model != GMVAE_MODEL_GMVAE || d.n_hidden != 1 || d.S != 1) return false;
   const int H = d.hidden[0];
   if (H % 16 || H > 64 || d.L % 8 || d.L > 128 || d.K > 64) return false;
   const int f = fwd_lay(H, d.L, d.K).total, b = bwd_lay(H, d.L, d.K).total;
   return (size_t)(f > b ? f : b) * 4 <= 156 * 1024;
 }
+static bool fused_ok(const GmvaeDims& d, int model) {
+  const char* e = getenv("GMVAE_NO_FUSED");
+  if (e && atoi(e)) return false;
+  return fused_shape(d, model);
+}
 
 static int num_splits(long long R) {
   long long ns = R / 256;
   if (ns < 1) ns = 1;
   if (ns > NS_MAX) ns = NS_MAX;
-  const char* e = getenv("GMVAE_NSPLIT");
-  if (e && atoi(e) >= 1 && atoi(e) <= NS_MAX) ns = atoi(e);
   return (int)ns;
 }
 
@@ -298,14 +303,14 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
   w.dbuf[0] = take(R * maxh);
   w.dbuf[1] = take(R * maxh);
   w.dbuf[2] = take(R * maxh);
-  if (fused_ok(d, model)) {
+  if (fused_shape(d, model)) {
     w.s1 = take((uint64_t)fwd_splits(d.D) * B * 2 * d.hidden[0]);
     w.s4 = take((uint64_t)fwd_splits(d.D) * B * d.hidden[0]);
     w.stamps = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * 16 * 2));
     w.img_f = take((uint64_t)fwd_lay(d.hidden[0], d.L, d.K).img);
     w.img_b = take((uint64_t)bwd_lay(d.hidden[0], d.L, d.K).img);
   }
-  if (mega_ok(d, model)) {
+  if (mega_shape(d, model)) {
     const MegaLay ml = mega_lay(d.hidden[0], d.L, d.K, d.D, model);
     w.img_m = take((uint64_t)ml.img);
     w.dimg = take((uint64_t)ml.nch * ml.chunk);
@@ -324,7 +329,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
       w.dimg2 = take(M2::dimg);
     }
   }
-  if (skinny_ok(d, model)) {
+  if (skinny_shape(d, model)) {       // (sized by the dims alone: no switch, no batch bound below kSkMaxB)
     w.sk_s1 = take((uint64_t)kSkNs1 * B * 2 * d.hidden[0]);
     w.sk_lqp = take(2ull * ((Lz + 15) / 16) * B);
     w.sk_part = take(B * ((D + 15) / 16));
@@ -339,8 +344,8 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
   {
     int ns = num_splits(R);
     if (num_splits_small(R) > ns) ns = num_splits_small(R);       // (the extra slabs are only touched in the small tensors' ranges)
-    if ((fused_ok(d, model) || mega_ok(d, model)) && dw_splits(d.B) > ns) ns = dw_splits(d.B);
-    if (mega_ok(d, model) && 2 * dw_splits(d.B) <= NS_MAX && 2 * dw_splits(d.B) > ns) ns = 2 * dw_splits(d.B);
+    if ((fused_shape(d, model) || mega_shape(d, model)) && dw_splits(d.B) > ns) ns = dw_splits(d.B);
+    if (mega_shape(d, model) && 2 * dw_splits(d.B) <= NS_MAX && 2 * dw_splits(d.B) > ns) ns = 2 * dw_splits(d.B);
     w.slabs = take((uint64_t)ns * L.P_pad);
   }
   w.cl_pred = reinterpret_cast<int32_t*>(take(B));
@@ -406,8 +411,7 @@ static Problem p_tn(const void* Act, bool u8, int lda, int a_div, const float* d
   p.C = dW; p.ldc = n_out; p.colsum_out = db;
   p.splits = ns; p.split_stride = slab_stride;
   // uint8 activations with plain 4-aligned extents take the bf16 matrix-core path of the medium tile configuration
-  p.xbf16 = (u8 && a_div == 1 && !kscale && p.seg[0].a.vec_ok && p.seg[0].b.vec_ok && n_in % 4 == 0 && n_out % 4 == 0 &&
-             !getenv("GMVAE_NO_XBF16")) ? 1 : 0;
+  p.xbf16 = (u8 && a_div == 1 && !kscale && p.seg[0].a.vec_ok && p.seg[0].b.vec_ok && n_in % 4 == 0 && n_out % 4 == 0) ? 1 : 0;
   return p;
 }
 
@@ -450,14 +454,13 @@ struct Group {
 template <class C>
 static int tile_up(Launch& L) {
   int t = 0;
-  static const bool xorder_on = !getenv("GMVAE_NO_XORDER");
   for (int i = 0; i < L.nprob; ++i) {
     Problem& p = L.p[i];
     p.tiles_m = (p.M + C::BM - 1) / C::BM;
     p.tiles_n = (p.N + C::BN - 1) / C::BN;
     // XCD-aware tile order (gemm.hpp): only where it matters -- many tiles and one operand much larger than the other
     p.xorder = 0;
-    if (xorder_on && C::BM == 128 && (long long)p.tiles_m * p.tiles_n * p.splits >= 512) {
+    if (C::BM == 128 && (long long)p.tiles_m * p.tiles_n * p.splits >= 512) {
       if (p.tiles_m >= 16 * p.tiles_n && p.tiles_n * p.splits <= 16) p.xorder = 1;
       else if (p.tiles_n >= 4 * p.tiles_m && p.tiles_m <= 16) p.xorder = 2;
       else if (p.tiles_m >= 64 && p.tiles_n >= 16 && (p.tiles_n & 7) == 0 && p.splits == 1) p.xorder = 3;
@@ -488,19 +491,10 @@ static bool big_eligible(const Launch& L) {
   return true;
 }
 
-// layout of the plane operands and the loop that reads them: 2 = blocked by 16 along the contiguous dimension, LDS-DMA ring
-// (gemm.hpp plane_rounds3); 1 = natural row-major planes staged through registers (plane_rounds).  GMVAE_PLANES_FORM picks.
-static int planes_form() {
-  const int f = env_cfg("GMVAE_PLANES_FORM", 2);
-  return f == 1 ? 1 : 2;
-}
-
 static int grid_for(long long items, int per_block, int cap = 4096);
-static void launch_split(hipStream_t st, int form, const float* src, const float* rowscale, int ld, long long n, unsigned short* dst) {
-  if (form == 2)
-    hipLaunchKernelGGL(split_planes_b16, dim3(grid_for(n / ld / 16 * ((ld + 31) / 32), 4, 16384)), dim3(256), 0, st, src, rowscale, ld, (int)(n / ld), dst, n);
-  else
-    hipLaunchKernelGGL(split_planes, dim3(grid_for(n, 2048, 8192)), dim3(256), 0, st, src, rowscale, ld, n, dst, n);
+// fp32 [rows][ld] (x rowscale[row]) -> three planes of 16-bit pieces in plane_rounds3's blocked-by-16 layout
+static void launch_split(hipStream_t st, const float* src, const float* rowscale, int ld, long long n, unsigned short* dst) {
+  hipLaunchKernelGGL(split_planes_b16, dim3(grid_for(n / ld / 16 * ((ld + 31) / 32), 4, 16384)), dim3(256), 0, st, src, rowscale, ld, (int)(n / ld), dst, n);
 }
 
 // every problem of the launch reads pre-split operands (gemm.hpp plane_rounds): interior 128 x 128 tiles, whole 32-deep
@@ -511,7 +505,7 @@ static bool planes_eligible(const Launch& L) {
     if (!p.planes || p.xbf16 || p.nseg != 1 || p.M % 128 || p.N % 128) return false;
     const Segment& sg = p.seg[0];
     if (sg.a.row_div != 1 || sg.b.row_div != 1 || sg.a.n_mn < p.M || sg.b.n_mn < p.N || sg.K % 32) return false;
-    if ((p.planes & 2) && (sg.a.ld % 16 || sg.b.ld % 16)) return false;
+    if (sg.a.ld % 16 || sg.b.ld % 16) return false;
     if (sg.a.ld % 8 || sg.b.ld % 8 || (reinterpret_cast<uintptr_t>(sg.a.ptr) & 15) || (reinterpret_cast<uintptr_t>(sg.b.ptr) & 15)) return false;
     if ((p.a_pstride & 7) || (p.b_pstride & 7)) return false;
     if (p.colsum_out && sg.b.k_contig) return false;
@@ -563,7 +557,7 @@ static double launch_cost(Launch& t, bool big) {
 // returns the chosen tile configuration (0 small, 1 medium, 2 large)
 static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsigned long long* dbg = nullptr) {
   if (g.L.nprob == 0) return 0;
-  if (g.L.nprob > 1 && !getenv("GMVAE_NO_LPT")) {
+  if (g.L.nprob > 1) {
     // Longest tiles first: tiles are dispatched in index order and a launch ends with its last tiles, so the problems
     // go in descending order of the k extent one tile walks (config 5's decoder backward launch: the data gradient's
     // tiles run 96 rounds, a split of the weight gradient's 50 -- 1443 -> 1368 us with the data gradient first).
@@ -586,14 +580,8 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
   if (cfg < 0) cfg = cx.force_cfg;
   if (cfg < 0) {
     Launch t = g.L;
-    if (getenv("GMVAE_CFG_BY_TILES")) {            // (the round-1 rule, kept for A/B)
-      if (tile_up<CfgL>(t) >= 192) cfg = 2;
-      else if (tile_up<CfgM>(t) >= 160) cfg = 1;
-      else cfg = 0;
-    } else {
-      const double tl = launch_cost<CfgL>(t, big_eligible(t)), tm = launch_cost<CfgM>(t, false), ts = launch_cost<CfgS>(t, false);
-      cfg = (tl <= tm && tl <= ts) ? 2 : (tm <= ts ? 1 : 0);
-    }
+    const double tl = launch_cost<CfgL>(t, big_eligible(t)), tm = launch_cost<CfgM>(t, false), ts = launch_cost<CfgS>(t, false);
+    cfg = (tl <= tm && tl <= ts) ? 2 : (tm <= ts ? 1 : 0);
   }
   double fl = 0;
   for (int i = 0; i < g.L.nprob; ++i)
@@ -610,17 +598,10 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
   }
   int tiles;
   if (cfg == 2) {
-    // the large-tile configuration can run fp32 x fp32 products as bf16 piece products (gemm.hpp split3).  OFF by
-    // default: measured 1.1-1.3x SLOWER than the fp32 MFMA path on the config-5 decoder GEMMs (profiles/round2_notes.md)
-    // -- at one workgroup per CU the per-round fp32 -> 3 x bf16 conversion is not overlapped with the MFMAs.
-    const char* sp = getenv("GMVAE_SPLIT3");
-    const int sp3 = sp ? (atoi(sp) == 9 ? 2 : (atoi(sp) ? 1 : 0)) : 0;
-    for (int i = 0; i < g.L.nprob; ++i) g.L.p[i].split3 = sp3;
     tiles = g.L.total_tiles = tile_up<CfgL>(g.L);
     const bool no_big = getenv("GMVAE_NO_BIG") != nullptr;      // diagnostic / A-B: the general loop
-    if (planes) hipLaunchKernelGGL((gemm_grouped<CfgL, 0, 2>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
-    else if (sp3) hipLaunchKernelGGL((gemm_grouped<CfgL, 1>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
-    else if (!no_big && big_eligible(g.L)) hipLaunchKernelGGL((gemm_grouped<CfgL, 0, 1>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
+    if (planes) hipLaunchKernelGGL((gemm_grouped<CfgL, 2>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
+    else if (!no_big && big_eligible(g.L)) hipLaunchKernelGGL((gemm_grouped<CfgL, 1>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
     else hipLaunchKernelGGL(gemm_grouped<CfgL>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
   } else if (cfg == 3) {
     tiles = g.L.total_tiles = tile_up<CfgM1>(g.L);
@@ -687,13 +668,7 @@ struct StepArgs {
   bool want_spans = false;     // measurement: every launch of the step records per-workgroup wall-clock stamps
   int span_slot = 0;           // ... into this slot of WS::spans (two consecutive steps can be stamped)
   bool dp_images = false;      // data-parallel graph: the Adam launch after the all-reduce scatters the weight images
-  // input pipeline inside the train graph: the NEXT step's batch is binarised by auxiliary workgroups of this step's
-  // weight-gradient launch (mega schedule)
   float* tail_log = nullptr;   // train graph: this step's slot of the per-step tail log (may be null)
-  const uint8_t* next_pix = nullptr;
-  const int32_t* next_idx = nullptr;
-  uint8_t* next_x = nullptr;
-  uint64_t next_rows_src = 0, bin_seed = 0;
 };
 
 static void rowk(Ctx& cx, const char* name) {
@@ -830,7 +805,7 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
         for (int i = 0; i < pl.nmap; ++i) {
           const ImgMap& mp = pl.map[i];
           const int rows = mp.cols > 0 ? (mp.end - mp.begin) / mp.cols : 0;
-          if (mp.kind == 4 && !fa.quad_blocks && rows % 4 == 0 && !getenv("GMVAE_NO_QUAD")) {   // -> quad blocks (kernels.hpp)
+          if (mp.kind == 4 && !fa.quad_blocks && rows % 4 == 0) {   // -> quad blocks (kernels.hpp)
             fa.q_begin = mp.begin; fa.q_end = mp.end; fa.q_rows = rows; fa.q_cols = mp.cols; fa.q_base = mp.base; fa.q_ld = mp.ld;
             fa.q_chunk = mp.chunk; fa.q_which = mp.which;
             fa.quad_blocks = ((rows / 4) * mp.cols + 255) / 256;
@@ -845,13 +820,7 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
         fa.nmap = n;
       }
     }
-    if (a.next_x && a.next_pix && a.next_idx && a.step_dev && a.adam_p) {
-      fa.bin_pix = a.next_pix; fa.bin_idx = a.next_idx; fa.bin_x = a.next_x; fa.bin_rows_src = a.next_rows_src;
-      fa.bin_B = B; fa.bin_D = d.D; fa.bin_seed = a.bin_seed; fa.bin_row0 = d.row0;
-      const uint64_t quads = (uint64_t)B * (d.D >> 2);
-      fa.bin_blocks = (int)((quads + (uint64_t)kBinQuadsPerThread * 256 - 1) / ((uint64_t)kBinQuadsPerThread * 256));
-    }
-    hipLaunchKernelGGL(finalize_adam, dim3((unsigned)((PP / 4 + 255) / 256) + 1 + fa.bin_blocks + fa.quad_blocks), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL(finalize_adam, dim3((unsigned)((PP / 4 + 255) / 256) + 1 + fa.quad_blocks), dim3(256), 0, st, fa);
     rowk(cx, a.adam_p ? "finalize_adam" : "finalize_grads+loss_tail");
     return cx.err;
   }
@@ -898,15 +867,15 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
   }
-  const int Qm = mega_q(B);
+  const int Qm = mega_q(d);
   bool fl = ml.fl_ok && Qm == 4 && (B + kPanel - 1) / kPanel * 4 <= n_cu &&
-            (a.adam_p == a.params || a.dp_images) && a.step_dev && gen_eps && w.xfl && !getenv("GMVAE_NO_FL");
+            (a.adam_p == a.params || a.dp_images) && a.step_dev && gen_eps && w.xfl && !getenv("GMVAE_NO_FL") && !sched_safe(d);
   if (fl && !a.imgs_ready) {
     // first step of a train graph / an eager step: the weight images straight from the parameters (kernels.hpp img_build),
     // then the same launches as every later step
     ImgPlan pl;
     plan_images(d, model, L, w, ml, P, pl);
-    if (!pl.map_ok || getenv("GMVAE_NO_IMG_BUILD")) fl = false;
+    if (!pl.map_ok) fl = false;
     else {
       ImgScatter sc;
       memset(&sc, 0, sizeof(sc));
@@ -940,9 +909,9 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     for (int i = 0; i < nt; ++i) ax.task[i] = pl.task[i];
     ax.ntasks = nt;
     ax.nblocks = ax.noise_blocks + nt;
-    launch_group(cx, g, "fwd_x_first_layers_splitk+aux", env_cfg("GMVAE_P1_CFG", 0), getenv("GMVAE_STAMPS") ? w.gstamps : nullptr);
+    launch_group(cx, g, "fwd_x_first_layers_splitk+aux", 0, getenv("GMVAE_STAMPS") ? w.gstamps : nullptr);
   }
-  bool m2_ran = false, fl_slab = false;
+  bool m2_ran = false;
   {  // the whole per-row forward + backward in one launch
     MegaArgs c;
     memset(&c, 0, sizeof(c));
@@ -964,7 +933,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     c.fine = getenv("GMVAE_STAMPS") ? atoi(getenv("GMVAE_STAMPS")) : 0;
     // the reference's default sizes (run_gmvae.py: latent 64, hidden 64, K 10; MNIST D 784) run a specialised instance
     typedef void (*MegaFn)(const MegaArgs);
-    const bool spec = H == 64 && Lz == 64 && K == 10 && D == 784 && (gm || gmp) && !getenv("GMVAE_MEGA_GENERIC");
+    const bool spec = H == 64 && Lz == 64 && K == 10 && D == 784 && (gm || gmp);
     const MegaFn fns[6] = {mega_fwd_bwd<0, 0, 0, 0, -1, 0>,      mega_fwd_bwd<0, 0, 0, 0, -1, 1>,
                            mega_fwd_bwd<64, 64, 10, 784, 2, 0>, mega_fwd_bwd<64, 64, 10, 784, 2, 1>,
                            mega_fwd_bwd<64, 64, 10, 784, 1, 0>, mega_fwd_bwd<64, 64, 10, 784, 1, 1>};
@@ -980,39 +949,23 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     }
     const bool m2 = fl && mega2_ok(d, model) && w.img2f;
     m2_ran = m2;
-    // round 3, measured and OFF (GMVAE_FLSPLIT=1 enables it): the first layer as a launch of its own in front of
-    // mega2_fwd_bwd (skinny.hpp fl_split).  A/B on one box: 37.8 vs 36.5 us per step -- fl_split 4.3 us span + a 1.6 us
-    // boundary, mega2_fwd_bwd only 4.5 us shorter (22.2 -> 17.7): its forward operand image (66 KB of LDS-DMA per
-    // workgroup), hidden behind the exchange wait before, is then on the launch's critical path.
-    fl_slab = m2 && NSF == 4 && H2 % 32 == 0 && D % 16 == 0 && getenv("GMVAE_FLSPLIT") != nullptr;
     if (m2) {
       c.img2f = w.img2f; c.img2b = w.img2b; c.dimg2 = w.dimg2;
       c.lr = a.lr; c.b1 = a.beta1; c.b2 = a.beta2;
       c.lr_t_out = (a.adam_p && a.adam_p == a.params && a.step_dev) ? reinterpret_cast<float*>(w.sync + 2) : nullptr;
       static bool m2attr = false;
       if (!m2attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(mega2_fwd_bwd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(mega2_fwd_bwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(mega2_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         m2attr = true;
       }
-      if (fl_slab) {
-        FlSplitArgs fa;
-        fa.x = a.x; fa.w0a = c.w0a; fa.w0b = c.w0b; fa.s1 = w.s1; fa.B = B; fa.D = D; fa.H = H; fa.ns = NSF;
-        fa.span = a.want_spans ? w.spans + (size_t)a.span_slot * 3 * 2048 * 2 + 2 * 2048 * 2 : nullptr;
-        hipLaunchKernelGGL(fl_split, dim3((H2 / 32) * ((B + 63) / 64) * NSF), dim3(kSkThreads), 0, st, fa);
-        cx.check();
-        cx.mark("fl_split", 2.0 * B * (double)D * H2);
-        hipLaunchKernelGGL(mega2_fwd_bwd<1>, dim3((B + kPanel - 1) / kPanel * 4), dim3(kMT), (size_t)M2::total * sizeof(float), st, c);
-      } else {
-        hipLaunchKernelGGL(mega2_fwd_bwd<0>, dim3((B + kPanel - 1) / kPanel * 4), dim3(kMT), (size_t)M2::total * sizeof(float), st, c);
-      }
+      hipLaunchKernelGGL(mega2_fwd_bwd, dim3((B + kPanel - 1) / kPanel * 4), dim3(kMT), (size_t)M2::total * sizeof(float), st, c);
     } else {
       hipLaunchKernelGGL(fn, dim3((B + kPanel - 1) / kPanel * c.Q), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
     }
     cx.check();
     // algorithmic MFMA FLOPs of the launch: forward chain + decoder layer (lambda and its data gradient) + backward chain
     double macs = (double)H * 2 * Lz + (double)Lz * H + 2.0 * H * D + (double)H * Lz + 2.0 * Lz * H;
-    if (fl && !fl_slab) macs += (double)D * H2;        // the first layer rides in the launch
+    if (fl) macs += (double)D * H2;        // the first layer rides in the launch
     if (gm) macs += (double)H * K + (double)K * H + (double)K * 2 * Lz + (double)(H + 2 * Lz) * K + (double)K * H;
     if (m2) { cx.mark("mega2_fwd_bwd", 2.0 * B * macs); goto mega_done; }
     cx.mark("mega_fwd_bwd", 2.0 * B * macs);
@@ -1023,14 +976,14 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
   const bool dw_upd = a.adam_p && a.adam_p == a.params;     // single device: the optimizer runs in the same launch
   // (every model of the mega schedule whose gradients are all matrix products: the learned mixture prior's variables of
   //  VAE_GMP come as per-panel partials and keep the split-K launch + finalize_adam)
-  if (fl && (!gmp || !getenv("GMVAE_NO_DWADAM_GMP")) && (dw_upd || a.dp_images) && a.step_dev && !getenv("GMVAE_NO_DWADAM")) {
+  if (fl && (dw_upd || a.dp_images) && a.step_dev) {
     ImgPlan pl;
     plan_images(d, model, L, w, ml, a.params, pl);
     if (pl.map_ok) {
       static DwArgs da;                          // (host-side scratch: 3 KB, too large for comfort on the stack next to Launch)
       memset(&da, 0, sizeof(da));
       da.B = B;
-      da.u8x3 = getenv("GMVAE_NO_DW_U8X3") ? 0 : 1;
+      da.u8x3 = 1;
       da.dbg = getenv("GMVAE_STAMPS") ? w.gstamps + 3 * 2048 * 8 : nullptr;
       da.lr_t = m2_ran ? reinterpret_cast<const float*>(w.sync + 2) : nullptr;
       da.ln_b1 = (float)log((double)a.beta1); da.ln_b2 = (float)log((double)a.beta2);
@@ -1059,7 +1012,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         da.ntens++;
       };
       const int K4 = (int)pad4(K);
-      const int mu = env_cfg("GMVAE_DW_MU", 2);
+      const int mu = 2;
       // (32-row tiles for the fp32 problems: more, lighter workgroups -- 240 <= 256 CUs at the default sizes -- and the
       //  decoder output layer's longer epilogue, two operand images, no longer ends the launch)
       if (gm) {
@@ -1090,7 +1043,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
             }
         }
         for (int t = 0; t < nt; ++t) used[t] = false;
-        const bool xcd = nt > 0 && !getenv("GMVAE_DW_NO_XCD");
+        const bool xcd = nt > 0;
         int next_any = 0;
         for (int b = 0; b < da.total_tiles && b < kDwMaxTiles; ++b) {
           int pick = -1;
@@ -1115,12 +1068,6 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       fa.err_word = w.sync + 1;
       fa.img[0] = w.img_m; fa.img[1] = w.dimg; fa.img[2] = w.img2f; fa.img[3] = w.img2b; fa.img[4] = w.dimg2;
       fa.span = (a.want_spans && w.spans) ? w.spans + (size_t)a.span_slot * 3 * 2048 * 2 + 2048 * 2 : nullptr;
-      if (a.next_x && a.next_pix && a.next_idx && dw_upd) {
-        fa.bin_pix = a.next_pix; fa.bin_idx = a.next_idx; fa.bin_x = a.next_x; fa.bin_rows_src = a.next_rows_src;
-        fa.bin_B = B; fa.bin_D = D; fa.bin_seed = a.bin_seed; fa.bin_row0 = d.row0;
-        const uint64_t quads = (uint64_t)B * (D >> 2);
-        fa.bin_blocks = (int)((quads + (uint64_t)kBinQuadsPerThread * 256 - 1) / ((uint64_t)kBinQuadsPerThread * 256));
-      }
       if (gmp) {                                 // the prior variables: per-panel partials of mega_fwd_bwd
         const int KLp = (int)pad4((uint64_t)K * Lz);
         fa.gmp_part = w.gmp_part; fa.gmp_n = (B + kPanel - 1) / kPanel; fa.gmp_len = 2 * KLp + (int)pad4(K); fa.gmp_off = (long long)L.loc;
@@ -1130,7 +1077,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       }
       // the padding words of the flat gradient buffer are never written by the tiles: the buffer is all-reduced / read whole
       if (da.total_tiles > kDwMaxTiles) return GMVAE_E_DIMS;
-      hipLaunchKernelGGL(dw_adam, dim3(da.total_tiles + 1 + fa.bin_blocks + da.gmp_blocks), dim3(kDwThreads), 0, st, da);
+      hipLaunchKernelGGL(dw_adam, dim3(da.total_tiles + 1 + da.gmp_blocks), dim3(kDwThreads), 0, st, da);
       cx.check();
       double fl_ = 0;
       for (int i = 0; i < da.ntens; ++i) fl_ += 2.0 * da.t[i].M * da.t[i].N * B;
@@ -1142,10 +1089,8 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
   // of two 64-row staging rounds; the fp32 problems take 2 NS splits of ONE round each: their workgroups, the
   // launch's critical path, are latency chains, and the single-buffered tile configuration leaves room for all
   // of them on the chip at once (3 per CU).
-  const int NS2 = (2 * NS <= NS_MAX && B / (2 * NS) >= 64 && !getenv("GMVAE_DW_UNIFORM")) ? 2 * NS : NS;
-  int NSX = NS;                  // splits of the uint8-activation problems
-  if (getenv("GMVAE_DW_XSPLITS") && atoi(getenv("GMVAE_DW_XSPLITS")) >= 1 && atoi(getenv("GMVAE_DW_XSPLITS")) <= NS2)
-    NSX = atoi(getenv("GMVAE_DW_XSPLITS"));
+  const int NS2 = (2 * NS <= NS_MAX && B / (2 * NS) >= 64) ? 2 * NS : NS;
+  const int NSX = NS;            // splits of the uint8-activation problems
   SlabX sx;
   memset(&sx, 0, sizeof(sx));
   {
@@ -1169,7 +1114,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     }
     g.add(p_tn(w.z, false, Lz, 1, w.dbuf[0], H, Lz, H, B, sl + Dn.w[0], sl + Dn.b[0], NS2, PP, nullptr));         // dWd0
     if (NS2 == NSX) sx.n = 0;
-    launch_group(cx, g, "bwd_dw_all", env_cfg("GMVAE_DW_CFG", B >= 512 ? (NS2 != NS ? 3 : 1) : 0),
+    launch_group(cx, g, "bwd_dw_all", B >= 512 ? (NS2 != NS ? 3 : 1) : 0,
                  (getenv("GMVAE_STAMPS") || a.want_spans) ? w.gstamps + 2048 * 8 : nullptr);
   }
   return finish_fused(cx, a, L, w, tail, NS2, B, &sx);
@@ -1241,7 +1186,7 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
     }
     ax.ntasks = nt;
     ax.nblocks = ax.noise_blocks + nt;
-    launch_group(cx, g, "fwd_x_first_layers_splitk+aux", env_cfg("GMVAE_P1_CFG", 0));
+    launch_group(cx, g, "fwd_x_first_layers_splitk+aux", 0);
   }
   const int NS = dw_splits(B);
   const long long PP = (long long)L.P_pad;
@@ -1346,7 +1291,7 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   const GmvaeDims& d = *a.d;
   const int B = d.B, K = d.K, Lz = d.L, D = d.D, H = d.hidden[0];
   hipStream_t st = cx.st;
-  static SkArgs s;                               // (host-side scratch, ~1 KB)
+  SkArgs s;                                      // (a stack local: two host threads may step at once; passed by value to the kernels)
   memset(&s, 0, sizeof(s));
   const bool vae = a.model != GMVAE_MODEL_GMVAE, gmp = a.model == GMVAE_MODEL_VAE_GMP;
   // (VAE: the one encoder stands in for both of the GMVAE's: SkArgs::model)
@@ -1386,11 +1331,7 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   const int nrt = (B + 15) / 16;
   const double fB = 2.0 * B;
   s.dbg = g_sk_dbg;                                // diagnostic: tools/skstamps.py (null unless gmvae_debug_sk_stamps(NULL) ran)
-  const int empty_mode = getenv("GMVAE_SK_EMPTY") ? atoi(getenv("GMVAE_SK_EMPTY")) : 0;     // (diagnostic, tools/micro)
   auto launch = [&](auto kern, int grid, int threads, size_t sh, const char* name, double fl) {
-    if (empty_mode == 2) hipLaunchKernelGGL(sk_gemm<SK_EMPTY>, dim3(grid), dim3(kSkThreads), 0, st, s);      // same grids, no work
-    else if (empty_mode == 3) { int tiny[2] = {1, 2}; (void)tiny; hipLaunchKernelGGL(sk_tiny, dim3(grid), dim3(256), 0, st, (float*)nullptr, 1); }
-    else
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), sh, st, s);
     cx.check();
     cx.mark(name, fl);
@@ -1406,35 +1347,17 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   launch(sk_gemm<SK_F3>, ((Lz + 15) / 16) * nrt, kSkThreads, 0, "sk_q_head_z", fB * H * 2 * Lz);
   if (gmp) launch_mixture_logprob(cx, w, a.params, L, B, Lz, K);
   launch(sk_gemm<SK_F4>, (H / 64) * nrt, kSkThreads, 0, "sk_dec_hidden", fB * Lz * H);
-  if (empty_mode == 1) launch(sk_gemm<SK_EMPTY>, (H / 64) * nrt, kSkThreads, 0, "sk_empty", 0.0);     // (diagnostic)
   launch(sk_gemm<SK_F5>, (D / 16) * nrt, kSkThreads, 0, "sk_dec_bernoulli", fB * H * D);
-  // The W launch can run in three parts: a weight's update may start once (a) its two operands are final and (b) every
-  // launch of this step that READS the weight is through -- the decoder's weights after B2, encoder_gmm's second layer after
-  // B3 -- on a side stream beside the rest of the backward pass (fork / join with events: parallel branches of the hipGraph),
-  // which takes 45 % of the optimizer's traffic off the critical path.  MEASURED AND OFF: on this stack a fork / join pair
-  // inside a graph costs far more than it hides (94.3 vs 60.8 us per step, A/B on one box); GMVAE_SK_FORK=1 enables it.
-  static hipStream_t side = nullptr;
-  static hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join = nullptr;
-  static const bool want_fork = getenv("GMVAE_SK_FORK") != nullptr;
-  bool fork = want_fork && !cx.prof;
-  if (fork && !side) {
-    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ev_fork[1], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
-      side = nullptr;
-      (void)hipGetLastError();
-    }
-  }
-  if (!side) fork = false;
-  auto launch_dw = [&](hipStream_t on, int part, bool tail) {     // part 0: decoder weights, 1: encoder_gmm layer 1, 2: the rest (+ everything not forked)
-    s.ntens = 0; s.total_tiles = 0; s.has_tail = tail ? 1 : 0;
-    if (part == 0 || (part == 2 && !fork)) {
-      add(s.hd, false, H, s.g, D, H, D, Dn.w[1], (long long)Dn.b[1]);                                    // dWd1 (+ dbd1)
-      add(s.z, false, Lz, s.dhd, H, Lz, H, Dn.w[0], (long long)Dn.b[0]);                                 // dWd0
-    }
-    if (part == 1 || (part == 2 && !fork)) add(s.hg, false, H, s.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1]);      // dWg1
-    if (part == 2 && vae) {
+  // (Measured and removed in round 4: the W launch in three parts on a forked graph branch beside B3 / B4 -- a fork / join
+  //  pair inside a hipGraph cost far more than it hid on this stack: 94.3 vs 60.8 us per step, profiles/round3_notes.md.)
+  auto launch_dw = [&]() {
+    s.ntens = 0; s.total_tiles = 0; s.has_tail = 1;
+    add(s.hd, false, H, s.g, D, H, D, Dn.w[1], (long long)Dn.b[1]);                                      // dWd1 (+ dbd1)
+    add(s.z, false, Lz, s.dhd, H, Lz, H, Dn.w[0], (long long)Dn.b[0]);                                   // dWd0
+    add(s.hg, false, H, s.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1]);                            // dWg1
+    if (vae) {
       add(a.x, true, D, s.dhg, H, D, H, E.w[0], (long long)E.b[0]);                                      // dWe0 (+ dbe0)
-    } else if (part == 2) {
+    } else {
       add(a.x, true, D, s.dhy, H, D, H, E.w[0], (long long)E.b[0]);                                      // dWy0 (+ dby0)
       add(a.x, true, D, s.dhg, H, D, H, G.w[0], (long long)G.b[0]);                                      // dWg0[x] (+ dbg0)
       add(s.y, false, s.K4, s.dhg, H, K, H, G.w[0] + (uint64_t)D * H, -1);                               // dWg0[y]
@@ -1443,10 +1366,10 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
     }
     double fw = 0;
     for (int i = 0; i < s.ntens; ++i) fw += 2.0 * s.t[i].M * s.t[i].N * B;
-    const int gmp_wgs = (s.gmp_part && tail) ? (s.gmp_len + kSkThreads - 1) / kSkThreads : 0;      // (sk_dw derives the same count)
-    hipLaunchKernelGGL(sk_dw, dim3((s.total_tiles + kSkWaves - 1) / kSkWaves + (tail ? 1 : 0) + gmp_wgs), dim3(kSkThreads), 0, on, s);
+    const int gmp_wgs = s.gmp_part ? (s.gmp_len + kSkThreads - 1) / kSkThreads : 0;      // (sk_dw derives the same count)
+    hipLaunchKernelGGL(sk_dw, dim3((s.total_tiles + kSkWaves - 1) / kSkWaves + 1 + gmp_wgs), dim3(kSkThreads), 0, st, s);
     cx.check();
-    cx.mark(part == 0 ? "sk_dw_decoder" : part == 1 ? "sk_dw_enc_gmm1" : (s.ap ? "sk_dw_adam" : "sk_dw"), fw);
+    cx.mark(s.ap ? "sk_dw_adam" : "sk_dw", fw);
   };
   launch(sk_gemm<SK_B1>, (H / 16) * nrt, kSkThreads, 0, "sk_bwd_dhd", fB * D * H);
   launch(sk_gemm<SK_B2>, ((Lz + 15) / 16) * nrt, kSkThreads, 0, "sk_bwd_dz_heads", fB * H * Lz);
@@ -1458,21 +1381,9 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
                        a.params + L.rawscale, a.params + L.mixlog, w.gmp_part, B, Lz, K, (int)pad4((uint64_t)K * Lz));
     rowk(cx, "gmp_param_bwd");
   }
-  if (fork) {
-    hipEventRecord(ev_fork[0], st);
-    hipStreamWaitEvent(side, ev_fork[0], 0);
-    launch_dw(side, 0, false);
-  }
   launch(sk_gemm<SK_B3>, (H / 32) * nrt, kSkThreads, 0, "sk_bwd_dhg", fB * 2 * Lz * H);
-  if (fork) {
-    hipEventRecord(ev_fork[1], st);
-    hipStreamWaitEvent(side, ev_fork[1], 0);
-    launch_dw(side, 1, false);
-    hipEventRecord(ev_join, side);
-  }
   if (!vae) launch(H <= 512 ? sk_ybwd<2> : sk_ybwd<4>, B, 256, 0, "sk_y_path_bwd", fB * ((double)(H + 2 * Lz) * K + K * H));
-  if (fork) hipStreamWaitEvent(st, ev_join, 0);                  // join: the step ends when all three W parts have
-  launch_dw(st, 2, true);
+  launch_dw();
   return cx.err;
 }
 
@@ -1489,7 +1400,6 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   const float c = d.raw_sigma_bias, smin = d.sigma_min;
   hipStream_t st = cx.st;
   const bool planes = planes_ok(d, L) && w.hd3 != nullptr;
-  const int pform = planes_form();
 
   // ---- noise (fast mode): Philox for eps and u -- its own launch in the general schedule, auxiliary
   // workgroups of the first GEMM launch in the fused one
@@ -1503,15 +1413,8 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   if (a.backward && skinny_ok(d, model)) return run_step_skinny(cx, a, L, w, eps, u, ge, gu);
   if (fused_ok(d, model) && !a.z_out && !a.y_out && !a.logits_out)
     return run_step_fused(cx, a, L, w, eps, u, ge, gu);
-  // (general schedule: the Philox fill rides as auxiliary workgroups of the first GEMM launch below; GMVAE_NOISE_LAUNCH=1
-  //  keeps it a launch of its own)
-  const bool noise_aux = (ge || gu) && !getenv("GMVAE_NOISE_LAUNCH");
-  if ((ge || gu) && !noise_aux) {
-    const uint64_t q = noise_items(ge, gu, (uint64_t)R, Lz, K);
-    hipLaunchKernelGGL(noise_fill, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, ge, gu, (uint64_t)R, Lz, K,
-                       (uint64_t)d.row0 * S, a.seed, a.step, a.step_dev);
-    rowk(cx, "noise_fill");
-  }
+  // (general schedule: the Philox fill rides as auxiliary workgroups of the first GEMM launch below)
+  const bool noise_aux = ge || gu;
 
   // ================================ forward ================================
   const NetL& E = gm ? L.ency : L.enc;
@@ -1578,9 +1481,9 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     if (i < Dn.nl - 1) {
       Problem ph = p_nn(in, false, Dn.dim[i], P + Dn.w[i], Dn.dim[i + 1], R, Dn.dim[i + 1], Dn.dim[i], w.hd[i + 1],
                         Dn.dim[i + 1], P + Dn.b[i], true);
-      if (planes && i == Dn.nl - 2 && !getenv("GMVAE_PLANES_NO_FUSED_SPLIT")) {
+      if (planes && i == Dn.nl - 2) {
         // the top layer's input activation leaves this launch's epilogue as planes too (no split launch over R x H)
-        ph.C3 = w.hd3; ph.c3_stride = (long long)R * Dn.dim[i + 1]; ph.c3_b16 = pform == 2;
+        ph.C3 = w.hd3; ph.c3_stride = (long long)R * Dn.dim[i + 1];
         hd3_fused = true;
       }
       g.add(ph);
@@ -1596,14 +1499,13 @@ static int run_step(Ctx& cx, const StepArgs& a) {
         // both operands as planes of 16-bit pieces (the weight's are shared with the data gradient below), (sigmoid - x)
         // leaves as planes only: its two consumers are plane GEMMs
         const long long nh = (long long)R * Dn.dim[i], nw = (long long)Dn.dim[i] * D;
-        const int b16 = pform == 2;
-        if (!hd3_fused) launch_split(st, pform, in, nullptr, Dn.dim[i], nh, w.hd3);
-        launch_split(st, pform, P + Dn.w[i], nullptr, D, nw, w.w3);
+        if (!hd3_fused) launch_split(st, in, nullptr, Dn.dim[i], nh, w.hd3);
+        launch_split(st, P + Dn.w[i], nullptr, D, nw, w.w3);
         rowk(cx, "split_planes");
         p.seg[0].a.ptr = w.hd3; p.seg[0].b.ptr = w.w3;
-        p.planes = pform; p.a_pstride = nh; p.b_pstride = nw;
+        p.planes = 1; p.a_pstride = nh; p.b_pstride = nw;
         p.C = nullptr;
-        p.C3 = a.backward ? w.g3 : nullptr; p.c3_stride = (long long)R * D; p.c3_b16 = b16;
+        p.C3 = a.backward ? w.g3 : nullptr; p.c3_stride = (long long)R * D;
       }
       g.add(p);
       const int bn = cfg_bn(launch_group(cx, g, "fwd_dec_bernoulli"));
@@ -1634,11 +1536,11 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   // S > 1: weight gradients whose contraction runs over the B batch rows (the encoder of x, and the x rows of enc_gmm's
   // first layer after sum_over_s) need only num_splits(B) slabs: finalize_grads then reads 2 instead of 16 slabs for the
   // two largest tensors of the config-5 sizes, and their launches write as many fewer
-  const int NSB = (S > 1 && !getenv("GMVAE_NSB_OFF")) ? (num_splits(B) < NS ? num_splits(B) : NS) : NS;
+  const int NSB = S > 1 ? (num_splits(B) < NS ? num_splits(B) : NS) : NS;
   // Weight gradients with few outputs and a contraction over all R rows (decoder layer 0, the layers of enc_gmm after the
   // first, the prior, the y rows of enc_gmm's first layer) take MORE splits than NS -- up to 64 -- at large R: as 64 tiles of
   // 50 rounds each such launch was a 125 us latency chain at the config-5 sizes.  (The slab buffer is sized for it: carve.)
-  const int NSS = (num_splits_small(R) > NS && !getenv("GMVAE_NSS_OFF")) ? num_splits_small(R) : NS;
+  const int NSS = num_splits_small(R) > NS ? num_splits_small(R) : NS;
   SlabX sxb;
   memset(&sxb, 0, sizeof(sxb));
   auto brange = [&](uint64_t b, uint64_t n, int ns) {
@@ -1664,14 +1566,14 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     if (top && planes) {
       const long long nh = (long long)R * Dn.dim[i], nw = (long long)Dn.dim[i] * D, ng = (long long)R * D;
       if (rwS) {           // IWAE: the row weights ride on the activation's pieces (they cannot scale pieces inside the loop)
-        launch_split(st, pform, act, rwS, Dn.dim[i], nh, w.hd3);
+        launch_split(st, act, rwS, Dn.dim[i], nh, w.hd3);
         rowk(cx, "split_planes_rw");
       }
       Problem pw3 = pw;
       pw3.seg[0].a.ptr = w.hd3; pw3.seg[0].b.ptr = w.g3;
-      pw3.planes = pform; pw3.a_pstride = nh; pw3.b_pstride = ng;      // (seg[0].kscale = rwS now only weighs the column sums)
+      pw3.planes = 1; pw3.a_pstride = nh; pw3.b_pstride = ng;      // (seg[0].kscale = rwS now only weighs the column sums)
       p.seg[0].a.ptr = w.g3; p.seg[0].b.ptr = w.w3;
-      p.planes = pform; p.a_pstride = ng; p.b_pstride = nw;
+      p.planes = 1; p.a_pstride = ng; p.b_pstride = nw;
       g.add(pw3);
     } else {
       g.add(pw);
@@ -1854,16 +1756,13 @@ int gmvae_step(const GmvaeDims* dims, int model, const uint8_t* x, const float* 
 /* internal: gmvae_step with the end-of-step Adam fused in (single device; used by the train graph) */
 static int step_with_adam(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
                           float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float b1,
-                          float b2, float eps_, hipStream_t st, bool imgs_ready = false, const uint8_t* next_pix = nullptr,
-                          const int32_t* next_idx = nullptr, uint8_t* next_x = nullptr, uint64_t next_rows_src = 0,
-                          uint64_t bin_seed = 0, float* tail_log = nullptr) {
+                          float b2, float eps_, hipStream_t st, bool imgs_ready = false, float* tail_log = nullptr) {
   Ctx cx;
   cx.st = st;
   StepArgs a = {dims, model, x, nullptr, nullptr, params, grads, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
                 seed, 0, step_dev, true};
   a.adam_p = params; a.adam_m = m; a.adam_v = v; a.lr = lr; a.beta1 = b1; a.beta2 = b2; a.epsilon = eps_;
   a.imgs_ready = imgs_ready;
-  a.next_pix = next_pix; a.next_idx = next_idx; a.next_x = next_x; a.next_rows_src = next_rows_src; a.bin_seed = bin_seed;
   a.tail_log = tail_log;
   return run_step(cx, a);
 }
@@ -2006,10 +1905,9 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
     if (na % 8 || nb % 8) return GMVAE_E_DIMS;
     if (na > cap_a) { if (pa) hipFree(pa); if (hipMalloc(&pa, 3 * na * 2) != hipSuccess) return GMVAE_E_ALIGN; cap_a = na; }
     if (nb > cap_b) { if (pb) hipFree(pb); if (hipMalloc(&pb, 3 * nb * 2) != hipSuccess) return GMVAE_E_ALIGN; cap_b = nb; }
-    const int pform = planes_form();
-    if (cfg == 4) {
-      launch_split(cx.st, pform, static_cast<const float*>(A), nullptr, trans == 2 ? M : K, (long long)na, pa);
-      launch_split(cx.st, pform, W, nullptr, trans == 1 ? K : N, (long long)nb, pb);
+      if (cfg == 4) {
+      launch_split(cx.st, static_cast<const float*>(A), nullptr, trans == 2 ? M : K, (long long)na, pa);
+      launch_split(cx.st, W, nullptr, trans == 1 ? K : N, (long long)nb, pb);
     }
     Problem p;
     const float* fa = reinterpret_cast<const float*>(pa);
@@ -2017,7 +1915,7 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
     if (trans == 0) p = p_nn(fa, false, K, fb, N, M, N, K, C, N, bias, relu != 0);
     else if (trans == 1) p = p_nt(fa, K, fb, K, M, N, K, C, N, nullptr, 0);
     else p = p_tn(fa, false, M, 1, fb, N, M, N, K, C, bias ? C + (size_t)M * N : nullptr, splitk, (long long)(M + 1) * N, nullptr);
-    p.planes = pform | (env_cfg("GMVAE_PLANES_DBG", 0) << 4);     // (timing experiments: 2 = no global loads, 4 = no LDS stores in the loop)
+    p.planes = 1;
     p.a_pstride = (long long)na; p.b_pstride = (long long)nb;
     g.add(p);
     launch_group(cx, g, "gemm_test_planes", 2);
@@ -2159,13 +2057,11 @@ int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, floa
       if (!strncmp(pr->name[i], "mega", 4)) first_last(hsp, 2, 1, lo, hi);
       else if (!strncmp(pr->name[i], "bwd_dw_all", 10)) first_last(hsp + nsp, 8, 4, lo, hi);
       else if (!strncmp(pr->name[i], "finalize_adam", 13) || !strncmp(pr->name[i], "dw_adam", 7)) first_last(hsp + 2048 * 2, 2, 1, lo, hi);
-      else if (!strncmp(pr->name[i], "fl_split", 8)) first_last(hsp + 2 * 2048 * 2, 2, 1, lo, hi);
       if (hi > lo) { acc[i] += (double)(hi - lo) * 0.01; start[i] = lo; }       // 100 MHz ticks -> microseconds
     }
     {  // the next step's first stamped launch closes the last launch's share (steady state: the same launch sequence)
       unsigned long long lo = ~0ull, hi = 0;
       if (pr->n > 0 && !strncmp(pr->name[0], "mega", 4)) first_last(hsp + slot, 2, 1, lo, hi);
-      else if (pr->n > 0 && !strncmp(pr->name[0], "fl_split", 8)) first_last(hsp + slot + 2 * 2048 * 2, 2, 1, lo, hi);
       start[pr->n] = hi > lo ? lo : 0;
     }
     for (int i = 0; i < pr->n; ++i)
@@ -2272,10 +2168,10 @@ static int train_graph_create(const GmvaeDims* dims, int model, const uint8_t* p
   int rc = 0;
   he = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
   if (he != hipSuccess) rc = (int)he;
-  // the launch's batches: one kernel in front of the steps (kernels.hpp binarize_batches); GMVAE_BIN_PER_STEP=1 keeps the
-  // per-step forms (a launch per batch, or extra workgroups of the optimizer launch in the mega schedule)
-  const bool bin_all = pixels && !getenv("GMVAE_BIN_PER_STEP");
-  if (rc == 0 && bin_all) {
+  // the launch's batches: ONE kernel in front of the steps (kernels.hpp binarize_batches); the uniforms are keyed by
+  // (seed, the consuming step's index, global quad), none of which depends on the training state.  (Round 4 removed the
+  // per-step forms -- a launch per batch, or extra workgroups of the optimizer launch -- measured 3-4 us per step slower.)
+  if (rc == 0 && pixels) {
     const uint64_t q = (uint64_t)n_steps * dims->B * (uint64_t)(dims->D >> 2);
     (void)hipGetLastError();
     hipLaunchKernelGGL(binarize_batches, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, cs, pixels, idx, n_rows, dims->B, dims->D,
@@ -2283,33 +2179,11 @@ static int train_graph_create(const GmvaeDims* dims, int model, const uint8_t* p
     rc = (int)hipGetLastError();
   }
   if (rc == 0) {
-    for (int s = 0; s < n_steps && rc == 0; ++s) {
-      uint8_t* xs = x + s * xstride;
-      // The input pipeline's step: this batch's rows, binarised with the step's own uniforms.  In the mega schedule
-      // only the first batch of a launch is a launch of its own; batch s + 1 is drawn by extra workgroups of step s's
-      // finalize_adam launch (same values: the uniforms are keyed by the consuming step's index).
-      const uint64_t bseed = seed ^ 0x62696e6172697a65ull;
-      const bool ride = pixels && !bin_all && mega_ok(*dims, model) && !getenv("GMVAE_NO_BIN_RIDE");
-      if (pixels && !bin_all && (!ride || s == 0))
-        rc = gmvae_binarize(pixels, n_rows, idx + (size_t)s * dims->B, 0, dims->B, dims->D, bseed, 0, step_dev, xs,
-                            dims->row0, cs);
-      if (rc) break;
-      if (fused_ok(*dims, model) || mega_ok(*dims, model) || !getenv("GMVAE_GENERAL_UNFUSED")) {
-        // (the general schedule too: its last launch, finalize_grads, applies TF-Adam and logs the tail)
-        // every step after the first finds its weight images written by the step before it (same graph, nothing in between)
-        const bool nxt = ride && s + 1 < n_steps;
-        rc = step_with_adam(dims, model, xs, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, cs, s > 0,
-                            nxt ? pixels : nullptr, nxt ? idx + (size_t)(s + 1) * dims->B : nullptr, nxt ? xs + xstride : nullptr,
-                            n_rows, bseed, tail_log ? tail_log + (size_t)s * GMVAE_TAIL : nullptr);
-      } else {
-        rc = gmvae_step(dims, model, xs, nullptr, nullptr, params, grads, workspace, seed, 0, step_dev, cs);
-        if (rc == 0)
-          rc = adam_tf_step(params, m, v, grads, L.P_pad, lr, beta1, beta2, epsilon, 0, step_dev, 1.f,
-                            grads + L.P_pad + 4, grads + L.P_pad, cs);
-        if (rc == 0 && tail_log)
-          hipMemcpyAsync(tail_log + (size_t)s * GMVAE_TAIL, grads + L.P_pad, GMVAE_TAIL * sizeof(float), hipMemcpyDeviceToDevice, cs);
-      }
-    }
+    // every schedule ends with a launch that applies TF-Adam and logs the tail; every step after the first finds its
+    // weight images written by the step before it (same graph, nothing in between)
+    for (int s = 0; s < n_steps && rc == 0; ++s)
+      rc = step_with_adam(dims, model, x + s * xstride, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, cs,
+                          s > 0, tail_log ? tail_log + (size_t)s * GMVAE_TAIL : nullptr);
     he = hipStreamEndCapture(cs, &tg->graph);
     if (rc == 0 && he != hipSuccess) rc = (int)he;
   }
@@ -2370,6 +2244,16 @@ int gmvae_debug_sk_stamps(unsigned long long* host_out) {
   return (int)hipMemcpy(host_out, g_sk_dbg, (size_t)10 * 256 * 8 * 8, hipMemcpyDeviceToHost);
 }
 
+/* disarm: later steps and captures no longer stamp; frees the buffer.  The caller must first destroy every train graph
+ * captured while the buffer was armed (their kernel arguments hold its address). */
+int gmvae_debug_sk_stamps_free(void) {
+  if (!g_sk_dbg) return 0;
+  hipDeviceSynchronize();
+  const hipError_t e = hipFree(g_sk_dbg);
+  g_sk_dbg = nullptr;
+  return (int)e;
+}
+
 /* debugging aid: resident workgroups per CU as the runtime computes them */
 int gmvae_step_schedule(const GmvaeDims* dims, int model, char* out48) {
   if (int e = check_dims(dims, model)) return e;
@@ -2423,6 +2307,13 @@ int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, u
       *byte_offset = (uint64_t)(reinterpret_cast<char*>(t.p) - base);
       return 0;
     }
+  if (name[0] == 'h' && (name[1] == 'e' || name[1] == 'g' || name[1] == 'd') && name[2] >= '1' && name[2] <= '9' && !name[3]) {
+    const int i = name[2] - '0';                   // "he<i>" / "hg<i>" / "hd<i>": the kept input activation of layer i
+    float* const* const tabh = name[1] == 'e' ? w.he : (name[1] == 'g' ? w.hg : w.hd);
+    if (i > MAXH || !tabh[i]) return GMVAE_E_NET;
+    *byte_offset = (uint64_t)(reinterpret_cast<char*>(tabh[i]) - base);
+    return 0;
+  }
   return GMVAE_E_NET;
 }
 
@@ -2494,7 +2385,7 @@ static int dp_step_impl(const GmvaeDims* dims, int model, const uint8_t* x, floa
   if (in_graph && mega) {
     ml = mega_lay(dims->hidden[0], dims->L, dims->K, dims->D, model);
     plan_images(*dims, model, L, w, ml, params, pl);
-    scatter = pl.map_ok && ml.fl_ok && !getenv("GMVAE_NO_FL");
+    scatter = pl.map_ok && ml.fl_ok && !getenv("GMVAE_NO_FL") && !sched_safe(*dims);
   }
   Ctx cx;
   cx.st = st;

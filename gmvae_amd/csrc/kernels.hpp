@@ -719,14 +719,7 @@ struct FinalArgs {
   unsigned long long* span;   // measurement: [block][2] wall-clock (100 MHz) at a block's first and last instruction
   // VAE_GMP: the prior variables' gradients are per-workgroup partials of mega_fwd_bwd, not split-K slabs
   const float* gmp_part; int gmp_n, gmp_len; long long gmp_off;
-  // input pipeline inside the train graph: bin_blocks extra workgroups (after the tail block) binarise the NEXT step's
-  // batch -- this launch is a latency chain on 2/3 of the CUs, the Philox work hides in it
-  int bin_blocks, bin_B, bin_D;
-  const unsigned char* bin_pix;
-  const int32_t* bin_idx;
-  unsigned char* bin_x;
-  unsigned long long bin_rows_src, bin_seed, bin_row0;   // bin_row0: global index of the batch's first row (Philox counter)
-  // "quad" blocks (after the binarisation blocks): ONE tensor [q_rows][q_cols] whose image stores the 4 values of 4
+  // "quad" blocks (after the tail block): ONE tensor [q_rows][q_cols] whose image stores the 4 values of 4
   // consecutive ROWS together (img_dst kind 4: the decoder output layer's forward operand) is updated by threads that
   // own (4 rows, 1 column) each: their parameter / moment / slab accesses are 4-byte but lane-contiguous, and the
   // image leaves as ONE 16-byte store per thread, consecutive lanes writing consecutive units.  (Scattered from the
@@ -768,19 +761,12 @@ __device__ __forceinline__ void finalize_tail_block(const FinalArgs& a, float (*
     if (a.epoch_word) *a.epoch_word += 1u;
   }
 }
-// block `bb` of the next step's batch binarisation (input pipeline inside the train graph)
-__device__ __forceinline__ void finalize_bin_block(const FinalArgs& a, const int bb) {
-  const unsigned long long step = a.step_dev[1] + 1ull;
-  for (uint64_t q0 = ((uint64_t)bb * kBinQuadsPerThread) * 256 + threadIdx.x; q0 < ((uint64_t)(bb + 1) * kBinQuadsPerThread) * 256;
-       q0 += blockDim.x)
-    binarize_quad(q0, a.bin_pix, a.bin_idx, 0, a.bin_rows_src, a.bin_B, a.bin_D, a.bin_seed, step, a.bin_x, a.bin_row0);
-}
 __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
 #define GMVAE_FIN_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
   if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x] = wall_clock64();
-  const int nb = gridDim.x - 1 - a.bin_blocks - a.quad_blocks;
-  if ((int)blockIdx.x > nb + a.bin_blocks) {     // quad blocks: (4 rows, 1 column) of the q_ tensor per thread
-    const int gq = ((int)blockIdx.x - nb - a.bin_blocks - 1) * 256 + (int)threadIdx.x;
+  const int nb = gridDim.x - 1 - a.quad_blocks;
+  if ((int)blockIdx.x > nb) {                    // quad blocks: (4 rows, 1 column) of the q_ tensor per thread
+    const int gq = ((int)blockIdx.x - nb - 1) * 256 + (int)threadIdx.x;
     if (gq >= (a.q_rows >> 2) * a.q_cols) { GMVAE_FIN_END(); return; }
     const int rq = gq / a.q_cols, c = gq - rq * a.q_cols;
     const long long i0 = (long long)a.q_begin + (long long)(4 * rq) * a.q_cols + c;
@@ -820,11 +806,6 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) im2[img_dst(a.q2_kind, a.q2_base, a.q2_ld, a.q2_chunk, 4 * rq + j, c)] = pa[j];
     }
-    GMVAE_FIN_END();
-    return;
-  }
-  if ((int)blockIdx.x > nb) {                    // the next step's batch: its uniforms are keyed by that step's index
-    finalize_bin_block(a, (int)blockIdx.x - nb - 1);
     GMVAE_FIN_END();
     return;
   }

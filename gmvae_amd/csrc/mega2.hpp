@@ -117,10 +117,6 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // (st4o -- a launch output as a 16-byte write-through store -- lives in mega.hpp)
 
-// SLAB = 1 (round 3): the first layer ran as a launch of its own (skinny.hpp fl_split) and left NS slabs of the
-// pre-activations; the panel's workgroups sum their rows in slab order (identical bits in all four) instead of pulling a
-// quarter of W0 each and exchanging partial tiles through granules.
-template <int SLAB>
 __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int H = M2::H, L = M2::L, K = M2::K, D = M2::D, L2 = M2::L2, K2 = M2::K2;
@@ -151,36 +147,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   // ======================================================================= FL: first layer over this quarter's columns
   // (the staging of mega_fwd_bwd's specialised instance: 49 bursts of 4 weight rows per tensor in two sub-chunks)
   float flt[4] = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (SLAB) {
-    const unsigned long long step = a.step_dev[0];
-    constexpr int qer = L / 4, qur = (K + 3) / 4, qe = kPanel * qer, qu = kPanel * qur;
-    dma_copy_m(img, a.img2f, M2::imgF, wave, lane);             // the forward operand image: nothing overlays it here
-    float sv[4][4];
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)                              // (NS = 4 slabs at D = 784; the host checks)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        sv[s2][r] = a.s1[((long long)s2 * B + min(r0 + lk * 4 + r, B - 1)) * H2f + wave * 16 + ln];
-    if (tid < qe + qu) {                           // this panel's rows of the Philox streams (= gmvae_noise_fill's)
-      const bool is_u = tid >= qe;
-      const int li = is_u ? tid - qe : tid;
-      const int qpr = is_u ? qur : qer;
-      const int row = li / qpr, quad = li - row * qpr;
-      float nz[4];
-      noise_vals(a.row0 + (unsigned long long)(r0 + row), (unsigned)quad, is_u, a.seed, step, nz);
-      if (!is_u) {
-        st4(P_eps + tid * 4, make_float4(nz[0], nz[1], nz[2], nz[3]));
-      } else {
-        const int k0u = quad * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (k0u + j < K) P_u[row * 16 + k0u + j] = nz[j];
-      }
-    }
-    if (bid == (int)gridDim.x - 1 && tid == 0) a.step_dev[1] = step;       // the copy dw_adam reads
-#pragma unroll
-    for (int r = 0; r < 4; ++r) flt[r] = ((sv[0][r] + sv[1][r]) + sv[2][r]) + sv[3][r];
-  } else {
+  {
     constexpr int KQ = M2::fl_kq, kq4 = KQ / 4;
     float* const Wst = sm;
     float* const A_x = sm + M2::fl_A;

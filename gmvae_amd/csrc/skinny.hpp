@@ -75,7 +75,7 @@ struct SkArgs {
 };
 #define SK_STAMP(slot, i) if (a.dbg && threadIdx.x == 0 && blockIdx.x < 256) a.dbg[((size_t)(slot) * 256 + blockIdx.x) * 8 + (i)] = wall_clock64()
 
-enum { SK_F1 = 0, SK_F3, SK_F4, SK_F5, SK_B1, SK_B2, SK_B3, SK_EMPTY };
+enum { SK_F1 = 0, SK_F3, SK_F4, SK_F5, SK_B1, SK_B2, SK_B3 };
 
 // ---- contraction pieces: one wave's share (k-groups kg = kg_lo + wave, + 8, ... < kg_hi; a k-group = 16 contraction steps).
 // The wave's groups run in batches of 4, 2, 1 (compile-time sizes): every load of a batch is in flight before its first MFMA,
@@ -196,14 +196,11 @@ __device__ __forceinline__ float sk_row16_sum(float v) {
   return v;
 }
 
-__global__ void sk_tiny(float* p, int n) { if (n < 0) p[0] = 1.f; }       // (diagnostic: a launch with 12 bytes of arguments)
-
 // One matrix-product launch of the schedule.  Grid: column tiles x row tiles (x ns1 slabs for F1); a workgroup = one
 // 16-row output tile; tiles are NN4 (16 x 64, strided columns), pairs (F3) or plain 16-column tiles (NT forms).
 template <int ST>
 __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
   __shared__ __attribute__((aligned(16))) float red[kSkWaves * 16 * 64];      // [wave][4 t + r][lane]
-  if constexpr (ST == SK_EMPTY) { if (a.B < 0) red[0] = 0.f; return; }       // (diagnostic: the cost of a launch that does nothing)
   constexpr int SLOT = ST == SK_F1 ? 0 : ST == SK_F3 ? 2 : ST == SK_F4 ? 3 : ST == SK_F5 ? 4 : ST == SK_B1 ? 5 : ST == SK_B2 ? 6 : 7;
   SK_STAMP(SLOT, 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -910,92 +907,6 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
   }
   }
   SK_STAMP(9, 3);
-}
-
-// ---- the first layer of the LARGE-batch fused schedule as a launch of its own (round 3) ------------------------------------
-// h_pre[b][0 .. 2H) = x[b] [Wy0 | Wg0[:D]]  (scripts/gmvae.py:238,246 first Linear of encoder_y / encoder_gmm) as NS slabs
-// over the contraction; mega2_fwd_bwd's panels sum them in slab order.  Inside mega2_fwd_bwd (round 2) each panel's four
-// workgroups pulled a quarter of W0 each -- 100 KB per workgroup, 25.6 MB of L2 -> LDS per launch at the ~12 B/clk/CU an all-CU
-// burst gets -- and met through 8-byte granules (2.4 us, 10 MB of write-through traffic).  Here a workgroup owns
-// [64 rows] x [32 columns] x [1/NS of the contraction]: 25 KB of W0 and 12.5 KB of x per workgroup, register-direct
-// operands (skinny.hpp's k labelling: 4 bytes of x = four consecutive k), 8 waves split the k-groups and meet in LDS in
-// wave order.  A kernel boundary (1.6 us) now costs less than the exchange it replaces.
-struct FlSplitArgs {
-  const unsigned char* x;
-  const float *w0a, *w0b;      // Wy0 [D][H], Wg0 [D + K][H] (its first D rows)
-  float* s1;                   // [ns][B][2H]
-  int B, D, H, ns;
-  unsigned long long* span;    // measurement: [block][2] wall-clock (100 MHz) or null
-};
-__global__ __launch_bounds__(kSkThreads) void fl_split(const FlSplitArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[kSkWaves * 32 * 64];     // [wave][8 tiles x 4 regs][lane]: 64 KB
-  if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x] = wall_clock64();
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ln = lane & 15, lk = lane >> 4;
-  const int B = a.B, D = a.D, H = a.H, H2 = 2 * H;
-  const int nct = H2 / 32, nrb = (B + 63) / 64;
-  const int bid = blockIdx.x;
-  const int ct = bid % nct, rb = (bid / nct) % nrb, ks = bid / (nct * nrb);
-  const int c0 = ct * 32;
-  const float* const W = (c0 < H ? a.w0a + c0 : a.w0b + (c0 - H)) + 2 * ln;      // this lane's two columns
-  long long arow[4];
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) arow[rt] = (long long)min(rb * 64 + 16 * rt + ln, B - 1) * D;
-  const int kgs = D / 16;
-  const int kg_lo = (int)((long long)kgs * ks / a.ns), kg_hi = (int)((long long)kgs * (ks + 1) / a.ns);
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) { acc[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  sk_groups(kg_lo, kg_hi, wave, [&](auto ng, const int kgb) {
-    constexpr int NG = decltype(ng)::value;
-    unsigned aw[NG][4];
-    float2 bv[NG][4];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int k = 16 * (kgb + g * kSkWaves) + 4 * lk;
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) aw[g][rt] = *reinterpret_cast<const unsigned*>(a.x + arow[rt] + k);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bv[g][q] = *reinterpret_cast<const float2*>(W + (long long)(k + q) * H);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-          const float av = (float)((aw[g][rt] >> (8 * q)) & 0xffu);
-          acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[g][q].x, acc[rt][0], 0, 0, 0);
-          acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[g][q].y, acc[rt][1], 0, 0, 0);
-        }
-  });
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[(wave * 32 + (rt * 2 + t) * 4 + r) * 64 + lane] = acc[rt][t][r];
-  __syncthreads();
-  // thread (lane slot el, j): row tile j >> 1, accumulator registers 2 (j & 1), + 1: two rows x two columns
-  const int el = tid & 63, j = tid >> 6, rt = j >> 1, rp = 2 * (j & 1);
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int r = rp + rr;
-    float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-    for (int w = 0; w < kSkWaves; ++w) {
-      v0 += red[(w * 32 + (rt * 2 + 0) * 4 + r) * 64 + el];
-      v1 += red[(w * 32 + (rt * 2 + 1) * 4 + r) * 64 + el];
-    }
-    const int row = rb * 64 + 16 * rt + 4 * (el >> 4) + r;
-    if (row < B) {
-      float* dst = a.s1 + ((long long)ks * B + row) * H2 + c0 + 2 * (el & 15);
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst),
-                         ((unsigned long long)__float_as_uint(v1) << 32) | __float_as_uint(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 }  // namespace gmvae

@@ -65,6 +65,7 @@ class Engine:
                 raise ValueError(f"gen_bias_init must be a scalar or a vector of data_size = {self.D} values, got {gb.numel()}")
         self.hp = dict(sigma_min=sigma_min, raw_sigma_bias=raw_sigma_bias, temperature=temperature,
                        gen_bias_init=float(gen_bias_init))
+        self.safe_schedule = False              # use_safe_schedule(): the schedules without mutual waits (per engine)
         d0 = self.dims(1)
         self.P, self.P_real = L.param_count(d0, self.model)
         self.layout = L.param_layout(d0, self.model)
@@ -79,14 +80,14 @@ class Engine:
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
         self._graph_gen = 0                     # bumped by drop_graphs: replay closures of dropped graphs raise
-        self.safe_schedule = False              # use_safe_schedule(): the schedules without mutual waits
         self.init_parameters(random_seed)
 
     # ------------------------------------------------------------ parameters
     def dims(self, B: int, S: Optional[int] = None, row0: Optional[int] = None):
         """GmvaeDims for a local batch of B rows; row0 = global index of its first row (default rank * B)."""
         return L.make_dims(B, self.D, self.Lz, self.K, self.hidden, S=self.S if S is None else S,
-                           row0=self.rank * B if row0 is None else int(row0), gen_bias_vec=self.gen_bias_vec, **self.hp)
+                           row0=self.rank * B if row0 is None else int(row0), gen_bias_vec=self.gen_bias_vec,
+                           sched_flags=L.SCHED_SAFE if self.safe_schedule else 0, **self.hp)
 
     def sync_replicas(self, src: int = 0):
         """Data parallel: every rank takes rank `src`'s parameters, Adam moments, step counter and noise seed (the
@@ -180,9 +181,14 @@ class Engine:
     def _workspace(self, B: int, S: Optional[int] = None, row0: Optional[int] = None):
         key = (B, self.S if S is None else S)
         d = self.dims(B, S, row0)
+        # the size is re-queried on every call: the library sizes the layout from the dims alone, but its few remaining
+        # test / tuning switches (GMVAE_NSPLIT_SMALL) enter the slab count -- a cached allocation must never be too small
+        n = L.workspace_bytes(d, self.model) // 4 + 64
+        if key in self._ws and self._ws[key].numel() < n:
+            self.drop_graphs(clear_handoff_errors=False)      # captured graphs hold pointers into the old allocation
+            del self._ws[key]
         if key not in self._ws:
-            n = L.workspace_bytes(d, self.model)
-            self._ws[key] = torch.zeros(n // 4 + 64, dtype=torch.float32, device=self.device)
+            self._ws[key] = torch.zeros(n, dtype=torch.float32, device=self.device)
         return d, self._ws[key]
 
     @staticmethod
@@ -513,13 +519,10 @@ class Engine:
                 w.fill_(1)
 
     def use_safe_schedule(self):
-        """Switch this process to the schedules WITHOUT mutual waits between workgroups (first layer as its own launch,
-        one workgroup per panel: GMVAE_NO_FL=1, GMVAE_MEGA_Q=1), destroy the captured graphs and clear the error words.
-        Slower (4 launches per step instead of 2), never stalling: what run_train and bench.py degrade to when a hand-off
-        of the fused schedule timed out."""
-        import os
-        os.environ["GMVAE_NO_FL"] = "1"
-        os.environ["GMVAE_MEGA_Q"] = "1"
+        """Switch THIS ENGINE to the schedules WITHOUT mutual waits between workgroups (first layer as its own launch, one
+        workgroup per panel: GmvaeDims.sched_flags = GMVAE_SCHED_SAFE on every call from now on -- no process-wide state),
+        destroy the captured graphs and clear the error words.  Slower (4 launches per step instead of 2), never stalling:
+        what run_train and bench.py degrade to when a hand-off of the fused schedule timed out."""
         self.safe_schedule = True
         self.drop_graphs(clear_handoff_errors=True)
 
@@ -620,6 +623,8 @@ class Engine:
             starts.append(r[:, 0].min())
             ends.append(r[:, 3].max())
         n = len(present)
+        self.drop_graphs(clear_handoff_errors=False)              # the stamped graphs hold the buffer's address: destroy them,
+        L.check(L.lib.gmvae_debug_sk_stamps_free(), "gmvae_debug_sk_stamps_free")      # then disarm (later steps do not stamp)
         if n < 8 or not all(starts[i + 1] > starts[i] for i in range(n - 1)):
             return None                                            # (stamps of different steps: a launch was mid-flight)
         out = []

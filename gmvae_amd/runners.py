@@ -239,12 +239,20 @@ def run_train(config):
         vals = (tails[:, 0] / tails[:, 4]).tolist()
         base = eng.global_step - len(vals)
         fault = getattr(config, "fault_hook", None)         # (tests: called with the engine after every summary block)
-        poisoned = bool(eng.handoff_timeouts()) or not all(np.isfinite(vals))
+        timed_out = bool(eng.handoff_timeouts())            # the explicit flag of a hand-off that gave up waiting
+        nonfinite = not all(np.isfinite(vals))
         if world > 1:                                       # every rank takes the same branch (the tails are all-reduced,
-            flag = torch.tensor([int(poisoned)], device=eng.device)      # the error word is per device)
+            flag = torch.tensor([int(timed_out)], device=eng.device)     # the error word is per device)
             parallel.all_reduce_flat(flag, op=parallel.dist.ReduceOp.MAX)
-            poisoned = bool(flag.item())
-        if poisoned:
+            timed_out = bool(flag.item())
+        if nonfinite and not timed_out:
+            # no hand-off gave up: the loss itself left the finite range (divergence, bad input).  Changing the schedule
+            # would re-run the same arithmetic; stop here with the last good checkpoint, like a failed sess.run.
+            bad = [base + i + 1 for i, v in enumerate(vals) if not np.isfinite(v)]
+            raise RuntimeError(f"non-finite training loss at step(s) {bad[:8]} with no hand-off timeout on any rank: "
+                               f"training diverged (or the inputs are not finite); the last good checkpoint was kept")
+        good = [(base + i + 1, v) for i, v in enumerate(vals) if np.isfinite(v)]      # (true step index, loss)
+        if timed_out:
             # A hand-off of the fused schedule timed out: something else holds part of the chip (a co-tenant, a
             # partitioned device).  The poisoned steps carry NaN losses and the optimizer SKIPPED them (params, m, v
             # untouched), so the model is intact.  Like MonitoredTrainingSession recovering from a failed step
@@ -252,7 +260,7 @@ def run_train(config):
             if eng.safe_schedule:
                 raise RuntimeError(f"training step poisoned between steps {base + 1} and {eng.global_step} although the "
                                    f"schedule without mutual waits is in use (hand-off timeouts: {eng.handoff_timeouts()}; "
-                                   f"losses finite: {bool(np.all(np.isfinite(vals)))}); the last good checkpoint was kept")
+                                   f"losses finite: {not nonfinite}); the last good checkpoint was kept")
             bad = [i for i, v in enumerate(vals) if not np.isfinite(v)]
             rewind = bool(bad) and bad == list(range(bad[0], len(vals)))      # the poisoned steps are the block's tail:
             if rewind:                                                        # run them again (new batches, same noise keys)
@@ -261,11 +269,11 @@ def run_train(config):
             if rank == 0:
                 print(f"[run_train] hand-off timeout: {len(bad)} step(s) of {base + 1}..{base + len(vals)} skipped by the "
                       f"optimizer; continuing from step {eng.global_step} on the schedule without mutual waits", flush=True)
-            eng.use_safe_schedule()
+            eng.use_safe_schedule()                         # (a field of THIS engine's dims: no process-wide state)
             run_train.degraded = True
-            vals = [v for v in vals if np.isfinite(v)]
-        for i, v in enumerate(vals):                        # EarlyStoppingHook sees every step's (all-reduced) loss
-            stop = hook.after_run(base + i + 1, v) or stop
+        for step_i, v in good:                              # EarlyStoppingHook sees every applied step's (all-reduced) loss
+            stop = hook.after_run(step_i, v) or stop        # under its TRUE step index (skipped steps leave gaps)
+        vals = [v for _, v in good]
         if fault is not None:
             fault(eng)
         if not vals:

@@ -39,7 +39,7 @@ extern "C" {
 
 #define GMVAE_MAX_HIDDEN 8
 #define GMVAE_TAIL 8          /* floats appended to the gradient buffer */
-#define GMVAE_ABI_VERSION 3
+#define GMVAE_ABI_VERSION 4
 
 enum { GMVAE_MODEL_VAE = 0, GMVAE_MODEL_VAE_GMP = 1, GMVAE_MODEL_GMVAE = 2 };
 
@@ -80,8 +80,14 @@ typedef struct GmvaeDims {
    * output layer's epilogue; steps with a vector run the schedules whose decoder layer is a grouped-GEMM launch. */
   const float* gen_bias_vec;
   int32_t gen_bias_len;
-  int32_t reserved_;
+  /* ABI v4 -- schedule flags (the v3 `reserved_` word; 0 = the default schedules).  GMVAE_SCHED_SAFE: only schedules in which
+   * no workgroup waits for another workgroup of its own launch (one workgroup per 16-row panel, the first layer as a launch
+   * of its own): slower (4 launches per step instead of 2), never stalling when something else holds part of the device.  A
+   * caller sets it after a hand-off timeout (the workspace's error word) -- per call, not per process.  It changes neither
+   * sizes, layouts nor the workspace. */
+  int32_t sched_flags;
 } GmvaeDims;
+enum { GMVAE_SCHED_SAFE = 1 };
 
 /* One tensor of the flat parameter buffer.  Names are the reference's TF
  * variable names (scripts/base.py:53,60 '<name>_fcnet/linear_<i>/{w,b}';
@@ -273,17 +279,22 @@ int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, in
                           float beta2, float epsilon, void* comm, float* tail_log, void** graph_out);
 
 /* Debugging aid: byte offset inside the workspace of a named intermediate ("hy1","hg1","hd1","y",
- * "logits","qp","pp","z","g","dqp","dpp","dlogits","dbuf0".."dbuf2","s1","s4", ...). */
+ * "logits","qp","pp","z","g","dqp","dpp","dlogits","dbuf0".."dbuf2","s1","s4", ...; "he<i>" / "hg<i>" / "hd<i>", i >= 1:
+ * the kept input activation of layer i of the encoder (encoder_y for GMVAE) / encoder_gmm / decoder -- the parity
+ * tests read the ReLU masks of a step from them). */
 int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, uint64_t* byte_offset);
 
 /* Debugging aid: device wall-clock stamps of the skinny schedule's launches ([10 launches][256 blocks][8] uint64 at
  * 100 MHz).  host_out == NULL arms it (allocates the buffer; steps enqueued or captured afterwards stamp into it);
  * otherwise the buffer is copied to host_out.  tools/skstamps.py. */
 int gmvae_debug_sk_stamps(unsigned long long* host_out);
+/* Disarms it and frees the buffer.  Destroy every train graph captured while it was armed FIRST (their kernel arguments
+ * hold the buffer's address). */
+int gmvae_debug_sk_stamps_free(void);
 
 /* Which schedule a TRAINING step of these sizes takes, as text (<= 47 chars + NUL into out48): "mega2", "mega", "skinny",
  * "fused" or "general", with "+planes" appended where the top decoder layer's GEMMs run as bf16 piece products on pre-split
- * operands (gemm.hpp plane_rounds).  Host-side, reads the same environment switches as the step.  bench.py prices its
+ * operands (gemm.hpp plane_rounds3).  Host-side, reads the same environment switches as the step.  bench.py prices its
  * roofline line with it. */
 int gmvae_step_schedule(const GmvaeDims* dims, int model, char* out48);
 

@@ -132,22 +132,33 @@ def _log_softmax(a):
     return s - np.log(np.exp(s).sum(axis=-1, keepdims=True))
 
 
-def _mlp_fwd(p, name, n_layers, x):
+def _mlp_fwd(p, name, n_layers, x, pres=None):
     """snt.nets.MLP, activate_final=False, relu hidden (base.py:47-60).
-    Returns output and the list of layer inputs [h_0 .. h_n]."""
+    Returns output and the list of layer inputs [h_0 .. h_n]; `pres` (a list,
+    optional) receives (pre-activation, sum_k |input_k| |w_kj| + |b_j|) of every
+    hidden layer -- what the trajectory tests need to tell a pre-activation
+    that is zero to within fp32 rounding from one that is not."""
     hs = [x]
     h = x
     for i in range(n_layers):
-        h = h @ p[f"{name}_fcnet/linear_{i}/w"] + p[f"{name}_fcnet/linear_{i}/b"]
+        w, b = p[f"{name}_fcnet/linear_{i}/w"], p[f"{name}_fcnet/linear_{i}/b"]
+        a = h
+        h = a @ w + b
         if i < n_layers - 1:
+            if pres is not None:
+                pres.append((h, np.abs(a) @ np.abs(w) + np.abs(b)))
             h = np.maximum(h, 0)
             hs.append(h)
     return h, hs
 
 
-def _mlp_bwd(p, g, name, n_layers, hs, dout, need_dx=True):
+def _mlp_bwd(p, g, name, n_layers, hs, dout, need_dx=True, masks=None):
     """Closed-form backward of _mlp_fwd.  hs[i] is the input
-    of layer i; hs[i>0] is post-ReLU so the mask is hs[i] > 0."""
+    of layer i; hs[i>0] is post-ReLU so the mask is hs[i] > 0 -- unless
+    `masks[i]` (bool, same shape) names the subgradient to take: at a
+    pre-activation of exactly zero TF's ReluGrad takes 0, but an fp32 and an
+    fp64 evaluation of a pre-activation that is zero to within rounding can
+    land on different sides; the trajectory tests pass the device's choice."""
     d = dout
     for i in reversed(range(n_layers)):
         g[f"{name}_fcnet/linear_{i}/w"] = hs[i].T @ d
@@ -155,7 +166,8 @@ def _mlp_bwd(p, g, name, n_layers, hs, dout, need_dx=True):
         if i > 0 or need_dx:
             d = d @ p[f"{name}_fcnet/linear_{i}/w"].T
             if i > 0:
-                d = d * (hs[i] > 0)
+                mk = masks[i] if (masks is not None and i < len(masks) and masks[i] is not None) else (hs[i] > 0)
+                d = d * mk
     return d
 
 
@@ -192,7 +204,8 @@ def forward(model: int, d: Dims, p: Dict[str, np.ndarray], x: np.ndarray,
     if model == MODEL_GMVAE:
         T = dtype(d.temperature)
         u = np.asarray(u, dtype).reshape(R, K)
-        logits, hs_y = _mlp_fwd(p, "encoder_y", nl, xf)            # gmvae.py:238
+        pre_y, pre_g = [], []
+        logits, hs_y = _mlp_fwd(p, "encoder_y", nl, xf, pre_y)     # gmvae.py:238
         g = -np.log(-np.log(u))                                    # A9 Gumbel
         a = (np.repeat(logits, S, axis=0) + g) / T
         y = np.exp(_log_softmax(a))                                # gmvae.py:240
@@ -201,12 +214,15 @@ def forward(model: int, d: Dims, p: Dict[str, np.ndarray], x: np.ndarray,
         nent_b = (pi * lnpi).sum(axis=1)                           # gmvae.py:262, utils.py:165-170
         pp = y @ p["prior_gmm_fcnet/linear_0/w"] + p["prior_gmm_fcnet/linear_0/b"]  # gmvae.py:243
         mu_p, sig_p, raw_p = _normal_head(pp, L, c, smin)
-        qp, hs_g = _mlp_fwd(p, "encoder_gmm", nl, np.concatenate([xr, y], axis=1))  # gmvae.py:246, base.py:66
+        qp, hs_g = _mlp_fwd(p, "encoder_gmm", nl, np.concatenate([xr, y], axis=1), pre_g)  # gmvae.py:246, base.py:66
+        C["pre"] = {"encoder_y": pre_y, "encoder_gmm": pre_g}
         C.update(logits=logits, hs_y=hs_y, y=y, pi=pi, lnpi=lnpi, nent_b=nent_b, pp=pp,
                  mu_p=mu_p, sig_p=sig_p, raw_p=raw_p, hs_g=hs_g, gumbel=g)
         enc_name = "encoder_gmm"
     else:
-        qp, hs_e = _mlp_fwd(p, "encoder", nl, xf)                  # vae.py:170
+        pre_e = []
+        qp, hs_e = _mlp_fwd(p, "encoder", nl, xf, pre_e)           # vae.py:170
+        C["pre"] = {"encoder": pre_e}
         if S > 1:
             qp = np.repeat(qp, S, axis=0)
         C.update(hs_e=hs_e)
@@ -230,7 +246,9 @@ def forward(model: int, d: Dims, p: Dict[str, np.ndarray], x: np.ndarray,
         logp = (m + np.log(np.exp(comp - m).sum(axis=1, keepdims=True)))[:, 0]
         C.update(resp=np.exp(comp - logp[:, None]), gmp_t=t, gmp_s=s, lnw=lnw)
 
-    lam, hs_d = _mlp_fwd(p, "decoder", nl, z)                      # gmvae.py:251 / vae.py:174
+    pre_d = []
+    lam, hs_d = _mlp_fwd(p, "decoder", nl, z, pre_d)               # gmvae.py:251 / vae.py:174
+    C["pre"]["decoder"] = pre_d
     lam = lam + np.asarray(d.gen_bias_init, dtype)                 # base.py:135 (scalar or [D] vector, broadcast over rows)
     logpx = (xr * lam - softplus(lam)).sum(axis=1)                 # A8, gmvae.py:254
 
@@ -255,7 +273,10 @@ def forward(model: int, d: Dims, p: Dict[str, np.ndarray], x: np.ndarray,
 # backward (SURVEY.md 8(a) A12 closed form; checked against fp64 autograd in
 # tests/test_oracle.py)
 # --------------------------------------------------------------------------
-def loss_and_grads(model: int, d: Dims, p, x, eps, u=None, dtype=np.float64):
+def loss_and_grads(model: int, d: Dims, p, x, eps, u=None, dtype=np.float64, relu_masks=None):
+    """relu_masks: optional {net name: [None, mask of hidden layer 1, ...]} -- the ReLU subgradients to take instead of
+    (activation > 0); see _mlp_bwd.  The forward pass is unaffected."""
+    rm = relu_masks or {}
     p = {k: np.asarray(v, dtype) for k, v in p.items()}
     C = forward(model, d, p, x, eps, u, dtype)
     B, R, S, L, K = C["B"], C["R"], d.S, d.L, d.K
@@ -266,7 +287,7 @@ def loss_and_grads(model: int, d: Dims, p, x, eps, u=None, dtype=np.float64):
     z, mu_q, sig_q, eps_ = C["z"], C["mu_q"], C["sig_q"], C["eps"]
 
     dlam = w * (sigmoid(C["lam"]) - C["xr"])
-    dz_dec = _mlp_bwd(p, g, "decoder", nl, C["hs_d"], dlam)
+    dz_dec = _mlp_bwd(p, g, "decoder", nl, C["hs_d"], dlam, masks=rm.get("decoder"))
 
     if model == MODEL_GMVAE:
         t = (z - C["mu_p"]) / C["sig_p"]
@@ -294,17 +315,17 @@ def loss_and_grads(model: int, d: Dims, p, x, eps, u=None, dtype=np.float64):
         dpp = np.concatenate([dmu_p, draw_p], axis=1)
         g["prior_gmm_fcnet/linear_0/w"] = C["y"].T @ dpp
         g["prior_gmm_fcnet/linear_0/b"] = dpp.sum(axis=0)
-        dxy = _mlp_bwd(p, g, "encoder_gmm", nl, C["hs_g"], dqp)    # [R, D+K]
+        dxy = _mlp_bwd(p, g, "encoder_gmm", nl, C["hs_g"], dqp, masks=rm.get("encoder_gmm"))    # [R, D+K]
         dy = dxy[:, d.D:] + dpp @ p["prior_gmm_fcnet/linear_0/w"].T
         y = C["y"]
         da = y * (dy - (y * dy).sum(axis=1, keepdims=True))
         dl = (da / dtype(d.temperature)).reshape(B, S, K).sum(axis=1)
         pi, lnpi = C["pi"], C["lnpi"]
         dl = dl + (pi * (lnpi - C["nent_b"][:, None])) / B
-        _mlp_bwd(p, g, "encoder_y", nl, C["hs_y"], dl, need_dx=False)
+        _mlp_bwd(p, g, "encoder_y", nl, C["hs_y"], dl, need_dx=False, masks=rm.get("encoder_y"))
     else:
         dq_b = dqp.reshape(B, S, 2 * L).sum(axis=1) if S > 1 else dqp
-        _mlp_bwd(p, g, "encoder", nl, C["hs_e"], dq_b, need_dx=False)
+        _mlp_bwd(p, g, "encoder", nl, C["hs_e"], dq_b, need_dx=False, masks=rm.get("encoder"))
     C["dlam"], C["dqp"] = dlam, dqp
     return C, g
 
@@ -328,10 +349,10 @@ def adam_tf_step(theta, m, v, grad, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, dtyp
     return theta.astype(dt), m.astype(dt), v.astype(dt)
 
 
-def train_step(model, d, flat, m, v, t, x, eps, u=None, lr=1e-3, dtype=np.float32):
+def train_step(model, d, flat, m, v, t, x, eps, u=None, lr=1e-3, dtype=np.float32, relu_masks=None):
     """One full reference step on the flat buffer: fwd + bwd + TF-Adam."""
     p = unpack(model, d, flat)
-    C, g = loss_and_grads(model, d, p, x, eps, u, dtype)
+    C, g = loss_and_grads(model, d, p, x, eps, u, dtype, relu_masks=relu_masks)
     gflat = pack(model, d, g, dtype)
     flat, m, v = adam_tf_step(flat.astype(dtype), m, v, gflat, t, lr=lr, dtype=dtype)
     return flat, m, v, C, gflat

@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol(L):
     for sym in declared:
         assert hasattr(raw, sym), f"{sym} declared in include/gmvae_hip.h but not exported"
     assert declared == set(L.EXPORTS)
-    assert L.lib.gmvae_abi_version() == 3
+    assert L.lib.gmvae_abi_version() == 4
 
 
 @pytest.mark.parametrize("name,d", [
@@ -128,3 +128,34 @@ def test_step_schedule_names(L, monkeypatch):
     assert L.step_schedule(L.make_dims(40, 784, 16, 10, [64, 64]), G) == "general"
     monkeypatch.setenv("GMVAE_NO_PLANES", "1")
     assert L.step_schedule(L.make_dims(512, 3072, 64, 64, [512], S=50), G) == "general"
+
+
+def test_workspace_layout_does_not_depend_on_schedule_switches(L, monkeypatch):
+    """carve() sizes every buffer from the dims alone (the *_shape predicates): a workspace allocated under one set of
+    GMVAE_NO_* schedule switches must fit -- and lay out identically -- under any other (a workspace sized with
+    GMVAE_NO_SKINNY=1 and used without it ran past its end)."""
+    cases = [("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,)), 64), ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,)), 1024),
+             ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(512,)), 256), ("vae", O.Dims(D=784, L=2, K=1, hidden=(64,)), 100)]
+    names = [b"hy1", b"hd1", b"g", b"dz", b"dqp", b"slabs", b"z"]
+
+    def probe(cd, mid):
+        out = [L.workspace_bytes(cd, mid)]
+        for nm in names:
+            off = C.c_uint64()
+            out.append(off.value if L.lib.gmvae_workspace_offset(C.byref(cd), mid, nm, C.byref(off)) == 0 else None)
+        return out
+
+    for name, d, B in cases:
+        mid = O.MODEL_NAMES[name]
+        cd = L.make_dims(B, d.D, d.L, d.K, d.hidden)
+        for k in ("GMVAE_NO_SKINNY", "GMVAE_SKINNY_MAXB", "GMVAE_NO_MEGA", "GMVAE_NO_MEGA2", "GMVAE_NO_FUSED", "GMVAE_NO_PLANES",
+                  "GMVAE_NO_FL", "GMVAE_MEGA_Q"):
+            monkeypatch.delenv(k, raising=False)
+        base = probe(cd, mid)
+        for k, v in (("GMVAE_NO_SKINNY", "1"), ("GMVAE_SKINNY_MAXB", "8"), ("GMVAE_NO_MEGA", "1"), ("GMVAE_NO_MEGA2", "1"),
+                     ("GMVAE_NO_FUSED", "1"), ("GMVAE_NO_PLANES", "1"), ("GMVAE_NO_FL", "1"), ("GMVAE_MEGA_Q", "1")):
+            monkeypatch.setenv(k, v)
+            assert probe(cd, mid) == base, (name, k)
+            monkeypatch.delenv(k)
+        cd.sched_flags = L.SCHED_SAFE
+        assert probe(cd, mid) == base, (name, "sched_flags")

@@ -78,36 +78,6 @@ def test_gemm_tn_splitk_bias_row(H, cfg, M, N, K, u8, ns):
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=3e-5 * math.sqrt(K))
 
 
-@pytest.mark.parametrize("terms", ["6", "9"])
-@pytest.mark.parametrize("trans,M,N,K", [(0, 300, 200, 150), (1, 257, 130, 96), (2, 140, 256, 1000)])
-def test_gemm_split3_bf16_piece_products(H, monkeypatch, terms, trans, M, N, K):
-    """The opt-in split3 path of the 128x128 configuration (GMVAE_SPLIT3): fp32 x fp32 as exact bf16 piece products
-    (6 of the 9, or all 9) with fp32 accumulation, for every operand orientation (NN / NT / TN with the bias-gradient
-    column sums): fp32-GEMM accuracy against fp64."""
-    monkeypatch.setenv("GMVAE_SPLIT3", terms)
-    L = _L()
-    rng = np.random.default_rng(M + N + K)
-    if trans == 0:
-        A, W = rng.normal(size=(M, K)).astype(np.float32), rng.normal(size=(K, N)).astype(np.float32)
-        ref = A.astype(np.float64) @ W.astype(np.float64)
-        shape = (M, N)
-    elif trans == 1:
-        A, W = rng.normal(size=(M, K)).astype(np.float32), rng.normal(size=(N, K)).astype(np.float32)
-        ref = A.astype(np.float64) @ W.astype(np.float64).T
-        shape = (M, N)
-    else:
-        A, W = rng.normal(size=(K, M)).astype(np.float32), rng.normal(size=(K, N)).astype(np.float32)
-        ref = np.concatenate([A.astype(np.float64).T @ W, W.astype(np.float64).sum(0, keepdims=True)], 0)
-        shape = (2, M + 1, N)
-    Ad, Wd = H.dev(A), H.dev(W)
-    Cd = torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
-    L.check(L.lib.gmvae_gemm_test(L.ptr(Ad), 0, L.ptr(Wd), L.ptr(Wd) if trans == 2 else None, L.ptr(Cd), M, N, K, trans, 0, 2,
-                                  2 if trans == 2 else 1, L.current_stream()), "gemm_test")
-    got = Cd.cpu().numpy().astype(np.float64)
-    got = got.sum(axis=0) if trans == 2 else got
-    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=3e-5 * math.sqrt(K))
-
-
 @pytest.mark.parametrize("trans,M,N,K,ns", [(0, 256, 384, 160, 1), (1, 384, 128, 96, 1), (2, 128, 256, 1024, 2),
                                             (2, 256, 128, 320, 3), (0, 128, 128, 32, 1),
                                             # >= 512 tiles: the XCD-aware tile orders (all tn of a tm / all tm of a (split, tn)
@@ -148,14 +118,11 @@ def test_gemm_big_rounds_instance(H, monkeypatch, trans, M, N, K, ns):
 @pytest.mark.parametrize("trans,M,N,K,ns", [(0, 256, 384, 160, 1), (1, 384, 128, 96, 1), (2, 128, 256, 1024, 2),
                                             (2, 256, 128, 320, 3), (0, 128, 128, 32, 1), (1, 128 * 131, 512, 64, 1),
                                             (2, 512, 128 * 43, 96, 3), (0, 128 * 67, 128 * 16, 64, 1)])
-@pytest.mark.parametrize("form", ["2", "1"])
-def test_gemm_plane_rounds_instance(H, monkeypatch, form, trans, M, N, K, ns):
-    """Operands split ONCE into three planes of 16-bit pieces (gemm.hpp split_planes / split_planes_b16) and multiplied as six
-    exact bf16 piece products with fp32 accumulation (`cfg` 4 of gmvae_gemm_test) -- form 2: planes blocked by 16, LDS-DMA ring
-    (plane_rounds3, the default); form 1: row-major planes staged through registers (plane_rounds) -- every operand orientation
-    (NN / NT / TN with split-K and the bias-gradient column sums) to fp32-GEMM accuracy against fp64, and no further from it
-    than the fp32 MFMA instance is."""
-    monkeypatch.setenv("GMVAE_PLANES_FORM", form)
+def test_gemm_plane_rounds_instance(H, trans, M, N, K, ns):
+    """Operands split ONCE into three planes of 16-bit pieces (gemm.hpp split_planes_b16: planes blocked by 16) and multiplied
+    as six exact bf16 piece products with fp32 accumulation through the LDS-DMA ring of plane_rounds3 (`cfg` 4 of
+    gmvae_gemm_test) -- every operand orientation (NN / NT / TN with split-K and the bias-gradient column sums) to fp32-GEMM
+    accuracy against fp64, and no further from it than the fp32 MFMA instance is."""
     L = _L()
     rng = np.random.default_rng(M + 3 * N + 7 * K + trans)
     if trans == 0:
@@ -317,15 +284,13 @@ def test_big_round_gemm_inside_the_step_iwae(H, monkeypatch, model):
 
 
 @pytest.mark.parametrize("model,S,hidden", [(O.MODEL_GMVAE, 4, (128,)), (O.MODEL_VAE, 1, (64, 128)), (O.MODEL_VAE_GMP, 2, (128,))])
-@pytest.mark.parametrize("form", ["2", "1"])
-def test_plane_gemms_inside_the_step(H, monkeypatch, form, model, S, hidden):
-    """The top decoder layer's three GEMMs on pre-split operands (gemm.hpp plane_rounds; by default from 4096 rows, forced
-    here at R = B*S = 128 / 256 rows, H = 128, D = 256): the hidden activation and the weight split by split_planes,
+def test_plane_gemms_inside_the_step(H, monkeypatch, model, S, hidden):
+    """The top decoder layer's three GEMMs on pre-split operands (gemm.hpp plane_rounds3; by default from 4096 rows, forced
+    here at R = B*S = 128 / 256 rows, H = 128, D = 256): the hidden activation and the weight split by split_planes_b16,
     (sigmoid - x) written as planes by the Bernoulli epilogue, the IWAE row weights riding on the activation's pieces and
     weighing the bias gradient's column sums -- against the oracle at the step's gates, NOT bit-identical to the fp32 MFMA
     instance (evidence that the path ran) and as close to it as fp32 rounding."""
     monkeypatch.setenv("GMVAE_PLANES_MINROWS", "128")
-    monkeypatch.setenv("GMVAE_PLANES_FORM", form)
     d = O.Dims(D=256, L=64, K=10, hidden=hidden, S=S)
     rng = np.random.default_rng(6)
     p = O.init_params(model, d, rng)
@@ -341,6 +306,27 @@ def test_plane_gemms_inside_the_step(H, monkeypatch, form, model, S, hidden):
     g_f32, _ = H.hip_step(model, d, flat, x, eps, u)
     assert not np.array_equal(g_pl, g_f32)
     np.testing.assert_allclose(g_pl, g_f32, rtol=0, atol=2e-5 * np.abs(g_f32).max())
+
+
+def test_plane_gemms_at_config5_dims_under_natural_gating(H, monkeypatch):
+    """BASELINE configs[4]'s dimensions (D = 3072, K = 64, H = 512, S = 50) with NO GMVAE_PLANES_* switch set, at the smallest
+    batch that passes every gate of planes_ok by itself: R = B * S must be >= 4096 AND a multiple of 128 (whole 128-row
+    tiles), i.e. B a multiple of 64 -- B = 128, R = 6,400 sample rows.  The step then runs "general+planes" exactly as the
+    25,600-row shard of the benchmark does -- logits + Bernoulli epilogue, the data gradient and the 6-of-9-piece weight
+    gradient over a 6,400-long contraction with 16 split-K slabs, the IWAE row weights on the activation's pieces -- and every
+    loss term and every gradient tensor is compared with the fp64 oracle at the step's gates (NumPy needs ~20 s there)."""
+    for k in ("GMVAE_PLANES_MINROWS", "GMVAE_NO_PLANES", "GMVAE_NSPLIT_SMALL", "GMVAE_FORCE_CFG", "GMVAE_NO_BIG"):
+        monkeypatch.delenv(k, raising=False)
+    d = O.Dims(D=3072, L=64, K=64, hidden=(512,), S=50)
+    B = 128
+    assert _L().step_schedule(H.dims_of(d, B), O.MODEL_GMVAE) == "general+planes"
+    rng = np.random.default_rng(11)
+    p = O.init_params(O.MODEL_GMVAE, d, rng)
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    x, eps, u = O.make_inputs(d, B)
+    H.compare_step(O.MODEL_GMVAE, d, p, x, eps, u)
 
 
 def _random_plane_cases(n, seed):

@@ -369,3 +369,51 @@ def test_two_ranks_on_one_gpu_run_gmvae_train(tmp_path):
     assert torch.isfinite(a["params"]).all() and 0 < a["loss"] < 500      # from D ln 2 - ln K = 541
     assert os.path.exists(os.path.join(tmp_path, "log", "gmvae", "h64_n1_z64", "model.pt"))
     assert "Step 40" in outs[0]
+
+
+@pytest.mark.gpu
+def test_bench_world2_branch_on_one_gpu_prints_a_marked_line(tmp_path):
+    """bench.py's `world > 1` branch executed for real: two fresh child ranks on the one GPU of the box,
+    `torch.distributed` over gloo (RCCL refuses two ranks on one device), started before anything touches the GPU.  This is
+    a FALLBACK path by bench.py's own definition, so the JSON line must be printed anyway -- n_gpus 2, replicas
+    bit-identical, "fallback": true with the reason and config.all_reduce naming the path that was timed -- and, without
+    --allow-fallback, the exit code must be non-zero AFTER the line is out."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        port = _free_port()
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r),
+                       GMVAE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                                           "--batch", "512", "--safe-schedule", "--no-cpu-baseline", "--no-iwae-bound"] + extra,
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = []
+        try:
+            for p in procs:
+                outs.append(p.communicate(timeout=420))
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                               # exactly the PIDs started here
+        return procs, outs
+
+    procs, outs = run(["--allow-fallback"])
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} exited {p.returncode}:\n{se[-3000:]}"
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]      # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 20 and j["config"]["global_batch"] == 1024 and j["value"] > 0
+    assert j["config"]["replicas_identical"] is True and j["config"]["safe_schedule"] is True
+    assert j["fallback"] is True and j["fallback_reasons"] and j["config"]["all_reduce"] == "torch.distributed"
+    assert j["config"]["dist_backend"] == "gloo" and j["scaling"] == "weak" and np.isfinite(j["final_loss"])
+    # without --allow-fallback: the same line, then a non-zero exit code on every rank
+    procs, outs = run([])
+    assert all(p.returncode == 3 for p in procs), [p.returncode for p in procs]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["fallback"] is True

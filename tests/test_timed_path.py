@@ -32,18 +32,63 @@ def _noise(L, rows, Lz, K, row_base, seed, step, want_u):
     return eps.cpu().numpy(), (u.cpu().numpy() if want_u else None)
 
 
-def _oracle_trajectory(L, model, d, flat0, xs, seed, step0=0, row_base=0):
-    """n oracle steps (fp64) on the noise of device steps step0 .. step0+n-1; returns (flat, C_last, g_last, g_first)."""
+NETS = {O.MODEL_GMVAE: (("encoder_y", "he", False), ("encoder_gmm", "hg", True), ("decoder", "hd", True)),
+        O.MODEL_VAE: (("encoder", "he", False), ("decoder", "hd", True)),
+        O.MODEL_VAE_GMP: (("encoder", "he", False), ("decoder", "hd", True))}
+PRE_TOL = 2e-4         # a ReLU may take the other side than in fp64 only where |pre-activation| <= PRE_TOL * sum_k |a_k| |w_kj|
+FLIPS = []             # (case, step, net, |pre| / sum |a||w|) of every unit where the device's ReLU mask differs from fp64's
+
+
+def _device_masks(e, model, d, B):
+    """The ReLU masks of the device's LAST step: (kept activation > 0) of every hidden layer, read from the engine's
+    workspace (gmvae_workspace_offset "he<i>" / "hg<i>" / "hd<i>"; rows = B for the encoder of x, B*S otherwise)."""
+    from gmvae_amd import _lib as L
+    cd = e.dims(B)
+    ws = e._ws[(B, e.S)]
+    out = {}
+    for net, tag, per_sample in NETS[model]:
+        ms = [None]
+        for i, h in enumerate(d.hidden, start=1):
+            off = C.c_uint64()
+            L.check(L.lib.gmvae_workspace_offset(C.byref(cd), model, f"{tag}{i}".encode(), C.byref(off)), f"offset {tag}{i}")
+            rows = B * d.S if per_sample else B
+            ms.append(ws[off.value // 4: off.value // 4 + rows * h].view(rows, h).cpu().numpy() > 0)
+        out[net] = ms
+    return out
+
+
+def _oracle_trajectory(L, model, d, flat0, xs, seed, step0=0, row_base=0, masks_of_step=None, tag=""):
+    """n oracle steps (fp64) on the noise of device steps step0 .. step0+n-1; returns (flat, C_last, g_last, [g_t]).
+
+    masks_of_step(t) -> the device's ReLU masks of step t (see _device_masks).  ReLU has no derivative at 0 and an fp32
+    pre-activation that is zero to within rounding can land on the other side than the fp64 one: there -- and ONLY
+    there: every unit where the device's mask differs from the oracle's own must have |pre| <= PRE_TOL * sum |a||w| in
+    fp64 -- the oracle takes the device's subgradient, so that every parameter seed runs inside the same gates instead of a
+    seed being picked that happens to have no such unit."""
     flat = flat0.astype(np.float64)
     m, v = np.zeros_like(flat), np.zeros_like(flat)
-    g_first = None
+    gs = []
     for t in range(xs.shape[0]):
         B = xs[t].shape[0]
         eps, u = _noise(L, B * d.S, d.L, d.K, row_base * d.S, seed, step0 + t, model == O.MODEL_GMVAE)
-        flat, m, v, Cc, g = O.train_step(model, d, flat, m, v, step0 + t + 1, xs[t], eps, u, lr=LR, dtype=np.float64)
-        if g_first is None:
-            g_first = g
-    return flat, Cc, g, g_first
+        masks = None
+        if masks_of_step is not None:
+            masks = masks_of_step(t)
+            Cc = O.forward(model, d, O.unpack(model, d, flat), xs[t], eps, u, np.float64)
+            for net, ms in masks.items():
+                for i in range(1, len(ms)):
+                    pre, mag = Cc["pre"][net][i - 1]
+                    diff = ms[i] != (pre > 0)
+                    if diff.any():
+                        ratio = np.abs(pre[diff]) / np.maximum(mag[diff], 1e-30)
+                        FLIPS.extend((tag, step0 + t, net, float(r)) for r in ratio)
+                        assert ratio.max() <= PRE_TOL, (f"{tag} step {step0 + t} {net} layer {i}: the device's ReLU mask differs from "
+                                                        f"fp64's at a pre-activation that is NOT numerically zero "
+                                                        f"(|pre| / sum|a||w| = {ratio.max():.2e})")
+        flat, m, v, Cc, g = O.train_step(model, d, flat, m, v, step0 + t + 1, xs[t], eps, u, lr=LR, dtype=np.float64,
+                                         relu_masks=masks)
+        gs.append(g)
+    return flat, Cc, g, gs
 
 
 def _compare_last_step(model, d, eng, B, Cc, g):
@@ -63,70 +108,117 @@ def _compare_last_step(model, d, eng, B, Cc, g):
         assert err <= 1e-4, f"{name}: last-step gradient rel-to-max err {err:.2e}"
 
 
-def _compare_params(model, d, eng, flat_ref, g_first, n):
-    """Parameters after n device TF-Adam steps vs the fp64 oracle.  Adam divides by sqrt(v): where a gradient element
-    is far below its tensor's scale (|g| < 1e-3 max|g|, where the 1e-4-of-max gradient gate is no relative statement)
-    the update direction is rounding noise in ANY fp32 implementation, the reference's included, and only the bound
-    of n * lr per step holds; everywhere else the parameters must agree to 5e-5 (lr = 1e-3: 5 % of one step)."""
+PARAM_STATS = []       # (case, n, share of elements whose tolerance is below lr / 10, worst diff / tolerance)
+
+
+def _compare_params(model, d, eng, flat_ref, gs, n, tag=""):
+    """Parameters after n device TF-Adam steps vs the fp64 oracle, element by element, with a tolerance that follows from
+    Adam itself.  A step moves an element by alpha * m / (sqrt(v) + eps) = O(lr) * sign-like ratio: a gradient error delta
+    changes that by about lr * c * |delta| / |g| (c of order 1-3: d/dg of m / sqrt(v)), saturating at ~2.5 lr when |g| is
+    itself rounding noise -- in ANY fp32 implementation, the reference's included.  With the device's gradient error taken
+    as 3e-6 of the tensor's largest gradient (30x below the 1e-4 gate of _compare_last_step: its typical measured value):
+        tol_i = 3e-5 + lr * sum_t min(2.5, 3 * 3e-6 * max|g_t| / |g_t,i|)
+    i.e. 3e-5 (3 % of one step) for an element whose gradient is within 1e-3 of its tensor's largest, ~ lr only for those
+    below 1e-5 of it.  The share of elements that are constrained to better than a tenth of one step is asserted too, so
+    that the graded bound cannot silently become 'anything goes'."""
     got = eng.params.detach().cpu().numpy().astype(np.float64)
     diff = np.abs(got - flat_ref)
     assert np.isfinite(got).all() and diff.max() <= 2.5 * n * LR
-    lay, _, _ = O.param_layout(model, d)
-    n_well = 0
+    lay, P, _ = O.param_layout(model, d)
+    tol = np.full(P, 3e-5)
+    for g in gs:
+        for name, shape, off in lay:
+            k = int(np.prod(shape))
+            ga = np.abs(g[off:off + k])
+            tol[off:off + k] += LR * np.minimum(2.5, 9e-6 * max(ga.max(), 1e-30) / np.maximum(ga, 1e-300))
+    real = np.zeros(P, bool)
+    for name, shape, off in lay:
+        real[off:off + int(np.prod(shape))] = True
+    worst = float((diff[real] / tol[real]).max())
+    tight = float((tol[real] <= LR / 10).mean())
+    PARAM_STATS.append((tag, n, tight, worst))
     for name, shape, off in lay:
         k = int(np.prod(shape))
-        g1 = np.abs(g_first[off:off + k])
-        well = g1 > 1e-3 * max(g1.max(), 1e-12)
-        n_well += int(well.sum())
-        if well.any():
-            assert diff[off:off + k][well].max() <= 5e-5, f"{name}: max |dtheta| {diff[off:off + k][well].max():.2e}"
-    assert n_well > 0.5 * sum(int(np.prod(s)) for _, s, _ in lay)
+        r = diff[off:off + k] / tol[off:off + k]
+        assert r.max() <= 1.0, f"{tag} {name}: |dtheta| {diff[off:off + k][r.argmax()]:.2e} at tolerance {tol[off:off + k][r.argmax()]:.2e}"
+    assert tight >= 0.9, f"{tag}: only {tight:.1%} of the parameters are constrained to a tenth of one step"
 
 
 CASES = [
-    # model, D, L, K, hidden, B, n_steps, note
-    ("gmvae", 784, 64, 10, (64,), 1024, 4),      # BASELINE configs[2]: Q = 4, steps 2..n in-launch first layer (FLT = 1)
-    ("gmvae", 784, 64, 10, (64,), 1000, 3),      # ragged last panel
-    ("gmvae", 784, 64, 10, (64,), 2048, 3),      # Q = 2
-    ("gmvae", 784, 64, 10, (64,), 8192, 3),      # Q = 1: the unsharded configs[3] batch on one GPU
-    ("vae", 784, 2, 1, (64,), 100, 4),           # BASELINE configs[0]
-    ("vae_gmp", 784, 64, 10, (64,), 256, 4),     # BASELINE configs[1]
-    ("gmvae", 784, 16, 10, (64,), 96, 3),        # generic mega instance (not the specialised sizes)
-    ("gmvae", 784, 128, 10, (512,), 64, 5, 12),  # bin/run_train.sh sizes, 5 steps.  Seed 12: of the 20 parameter seeds 11..30
-                                                 # (tools/seed_search.py) 17 run 5 steps inside every gate; at 11, 14 and 23 ONE of
-                                                 # the 64 x 512 pre-activations sits within fp32 rounding of zero at some step and
-                                                 # its ReLU takes the other side than in fp64 (one gradient column off by ~1e-3 of
-                                                 # max; the graph and eager device steps agree bit for bit): a property of
-                                                 # comparing ANY fp32 trajectory with an fp64 one, not of the kernels
-    ("vae", 784, 8, 1, (96, 96), 48, 3),         # two hidden layers: general schedule, VAE
-    ("vae", 784, 128, 1, (512,), 64, 4, 12),     # the VAE at bin/run_train.sh's sizes: skinny schedule, eight launches
-    ("vae", 784, 32, 1, (256,), 200, 3, 12),     # skinny VAE, ragged row tiles, in-kernel eps rows over several extra workgroups
-    ("gmvae", 784, 8, 10, (256,), 64, 4, 12),    # skinny, the reference's default latent size (a ragged tile of latent dimensions)
-    ("vae_gmp", 784, 64, 10, (512,), 256, 4, 12),  # skinny VAE_GMP (BASELINE configs[1] at H = 512): the prior's variables updated in the tail
+    # model, D, L, K, hidden, B, n_steps, parameter seeds
+    ("gmvae", 784, 64, 10, (64,), 1024, 4, (11, 12)),     # BASELINE configs[2]: Q = 4, steps 2..n in-launch first layer
+    ("gmvae", 784, 64, 10, (64,), 1000, 3, (11,)),        # ragged last panel
+    ("gmvae", 784, 64, 10, (64,), 2048, 3, (11,)),        # Q = 2
+    ("gmvae", 784, 64, 10, (64,), 8192, 3, (11,)),        # Q = 1: the unsharded configs[3] batch on one GPU
+    ("vae", 784, 2, 1, (64,), 100, 4, (11, 12, 13)),      # BASELINE configs[0]
+    ("vae_gmp", 784, 64, 10, (64,), 256, 4, (11, 12, 13)),  # BASELINE configs[1]
+    ("gmvae", 784, 16, 10, (64,), 96, 3, (11,)),          # generic mega instance (not the specialised sizes)
+    # bin/run_train.sh sizes, 5 steps, EVERY parameter seed 11..30 (round 3 ran seed 12 only: at 11, 14 and 23 one of the
+    # 64 x 512 pre-activations sits within fp32 rounding of zero at some step and its ReLU takes the other side than in
+    # fp64; the oracle now follows the device's subgradient at such units and only there, see _oracle_trajectory)
+    ("gmvae", 784, 128, 10, (512,), 64, 5, tuple(range(11, 31))),
+    ("vae", 784, 8, 1, (96, 96), 48, 3, (11, 12)),        # two hidden layers: general schedule, VAE
+    ("vae", 784, 128, 1, (512,), 64, 4, (11, 12, 13, 14)),     # the VAE at bin/run_train.sh's sizes: skinny schedule, eight launches
+    ("vae", 784, 32, 1, (256,), 200, 3, (11, 12)),        # skinny VAE, ragged row tiles, in-kernel eps rows over several extra workgroups
+    ("gmvae", 784, 8, 10, (256,), 64, 4, (11, 12, 13, 14)),    # skinny, the reference's default latent size (a ragged tile of latent dimensions)
+    ("vae_gmp", 784, 64, 10, (512,), 256, 4, (11, 12, 13, 14)),  # skinny VAE_GMP (BASELINE configs[1] at H = 512)
+    ("gmvae", 784, 64, 10, (512,), 1024, 3, (11, 12)),    # BASELINE configs[2] at H = 512
 ]
 
 
-def trajectory_case(model, D, Lz, K, hidden, B, n, seed=11):
+def trajectory_case(model, D, Lz, K, hidden, B, n, seed=11, engine_kw=None):
+    """An n-step train graph against n oracle steps.  A second engine with the same seed steps the same batches through n
+    launches of a ONE-step graph (the same kernels: the two must agree bit for bit) and hands the oracle the ReLU masks of
+    every step."""
     from gmvae_amd import _lib as L
     from gmvae_amd.engine import Engine
     mid = O.MODEL_NAMES[model]
     d = O.Dims(D=D, L=Lz, K=K, hidden=hidden)
-    e = Engine(model, D, Lz, K, list(hidden), random_seed=seed)
+    kw = engine_kw or {}
+    e = Engine(model, D, Lz, K, list(hidden), random_seed=seed, **kw)
     flat0 = e.params.detach().cpu().numpy()
     xs = (np.random.default_rng(B).random((n, B, D)) < 0.87).astype(np.uint8)
+    xd = torch.from_numpy(xs).cuda()
     sx, replay = e.capture_train_step(B, lr=LR, n_steps=n)
-    sx.copy_(torch.from_numpy(xs).cuda())
+    sx.copy_(xd if n > 1 else xd[0])
     replay()
     torch.cuda.synchronize()
     assert e.handoff_timeouts() == 0 and e.global_step == n and int(e.step_dev[0].item()) == n
-    flat_ref, Cc, g, g1 = _oracle_trajectory(L, mid, d, flat0, xs, e.noise_seed)
+    e1 = Engine(model, D, Lz, K, list(hidden), random_seed=seed, **kw)
+    sx1, replay1 = e1.capture_train_step(B, lr=LR, n_steps=1)
+    masks = []
+    for t in range(n):
+        sx1.copy_(xd[t])
+        replay1()
+        torch.cuda.synchronize()
+        masks.append(_device_masks(e1, mid, d, B))
+    assert torch.equal(e1.params, e.params), "n launches of a 1-step graph and one launch of an n-step graph must agree bit for bit"
+    tag = f"{model}-L{Lz}-H{'x'.join(map(str, hidden))}-B{B}-seed{seed}"
+    flat_ref, Cc, g, gs = _oracle_trajectory(L, mid, d, flat0, xs, e.noise_seed, masks_of_step=lambda t: masks[t], tag=tag)
     _compare_last_step(mid, d, e, B, Cc, g)
-    _compare_params(mid, d, e, flat_ref, g1, n)
+    _compare_params(mid, d, e, flat_ref, gs, n, tag)
 
 
-@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-L{c[2]}-B{c[5]}" for c in CASES])
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-L{c[2]}-H{c[4][0]}-B{c[5]}-n{c[6]}" for c in CASES])
 def test_train_graph_matches_oracle_trajectory(case):
-    trajectory_case(*case)
+    *shape, seeds = case
+    for seed in seeds:
+        trajectory_case(*shape, seed=seed)
+
+
+def test_trajectory_margins_report():
+    """Not a gate: prints what the trajectory comparators measured (run after the cases above in file order) -- the units
+    where the device's ReLU took the other side than fp64 (with how close to zero the fp64 pre-activation was) and the
+    worst parameter difference relative to its Adam-derived tolerance."""
+    if FLIPS:
+        by = {}
+        for tag, step, net, r in FLIPS:
+            by.setdefault(tag, []).append(r)
+        print(f"\n[trajectory] ReLU units taken from the device: {len(FLIPS)} in {len(by)} trajectories; "
+              f"largest |pre| / sum|a||w| {max(r for *_, r in FLIPS):.2e} (gate {PRE_TOL:.0e})")
+    if PARAM_STATS:
+        print(f"[trajectory] parameters: worst |dtheta| / tolerance {max(w for *_, w in PARAM_STATS):.2f}; "
+              f"share constrained to lr / 10: min {min(t for _, _, t, _ in PARAM_STATS):.1%}")
 
 
 def test_second_graph_launch_continues_the_trajectory():
@@ -144,9 +236,9 @@ def test_second_graph_launch_continues_the_trajectory():
     replay()
     replay()
     torch.cuda.synchronize()
-    flat_ref, Cc, g, g1 = _oracle_trajectory(L, O.MODEL_GMVAE, d, flat0, np.concatenate([xs, xs]), e.noise_seed)
+    flat_ref, Cc, g, gs = _oracle_trajectory(L, O.MODEL_GMVAE, d, flat0, np.concatenate([xs, xs]), e.noise_seed)
     _compare_last_step(O.MODEL_GMVAE, d, e, B, Cc, g)
-    _compare_params(O.MODEL_GMVAE, d, e, flat_ref, g1, 2 * n)
+    _compare_params(O.MODEL_GMVAE, d, e, flat_ref, gs, 2 * n, "two-launches")
 
 
 def test_dp_graph_world1_matches_oracle_trajectory():
@@ -168,9 +260,9 @@ def test_dp_graph_world1_matches_oracle_trajectory():
     replay()
     torch.cuda.synchronize()
     assert e.handoff_timeouts() == 0
-    flat_ref, Cc, g, g1 = _oracle_trajectory(L, O.MODEL_GMVAE, d, flat0, xs, e.noise_seed, row_base=3 * B)
+    flat_ref, Cc, g, gs = _oracle_trajectory(L, O.MODEL_GMVAE, d, flat0, xs, e.noise_seed, row_base=3 * B)
     _compare_last_step(O.MODEL_GMVAE, d, e, B, Cc, g)
-    _compare_params(O.MODEL_GMVAE, d, e, flat_ref, g1, n)
+    _compare_params(O.MODEL_GMVAE, d, e, flat_ref, gs, n, "dp-world1")
 
 
 EAGER = [
@@ -234,9 +326,9 @@ def test_pipeline_graph_matches_oracle_from_raw_pixels():
     bseed = e.noise_seed ^ Engine.BINARIZE_SEED_XOR
     xs = np.stack([O.binarize(pix, rows[t], bseed, t) for t in range(n)])
     assert np.array_equal(replay.batches.cpu().numpy(), xs)
-    flat_ref, Cc, g, g1 = _oracle_trajectory(L, O.MODEL_GMVAE, d, flat0, xs, e.noise_seed)
+    flat_ref, Cc, g, gs = _oracle_trajectory(L, O.MODEL_GMVAE, d, flat0, xs, e.noise_seed)
     _compare_last_step(O.MODEL_GMVAE, d, e, B, Cc, g)
-    _compare_params(O.MODEL_GMVAE, d, e, flat_ref, g1, n)
+    _compare_params(O.MODEL_GMVAE, d, e, flat_ref, gs, n, "pipeline")
 
 
 def test_config5_shard_full_size_properties(monkeypatch):
@@ -297,11 +389,3 @@ def test_config5_shard_full_size_properties(monkeypatch):
         n = int(np.prod(shape))
         ref = g[name].ravel()
         assert np.abs(small[off:off + n] / 8 - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6), name
-
-
-def test_first_layer_as_its_own_launch_matches_oracle(monkeypatch):
-    """GMVAE_FLSPLIT=1: the first layer as a launch of its own (csrc/skinny.hpp fl_split) feeding mega2_fwd_bwd<SLAB> from four
-    slabs -- measured slower than the in-launch form and off by default, kept correct: same trajectory gates."""
-    monkeypatch.setenv("GMVAE_FLSPLIT", "1")
-    trajectory_case("gmvae", 784, 64, 10, (64,), 1024, 4)
-    trajectory_case("gmvae", 784, 64, 10, (64,), 1000, 3)
