@@ -934,16 +934,20 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     // the reference's default sizes (run_gmvae.py: latent 64, hidden 64, K 10; MNIST D 784) run a specialised instance
     typedef void (*MegaFn)(const MegaArgs);
     const bool spec = H == 64 && Lz == 64 && K == 10 && D == 784 && (gm || gmp);
-    const MegaFn fns[6] = {mega_fwd_bwd<0, 0, 0, 0, -1, 0>,      mega_fwd_bwd<0, 0, 0, 0, -1, 1>,
+    // BASELINE configs[0] (scripts/vae.py defaults at latent_size 2 on MNIST): the plain VAE's instance (round 4; it ran the
+    // generic one before: ~1100 instructions of index set-up and ~100 spilled scalars per launch)
+    const bool spec_vae = model == GMVAE_MODEL_VAE && H == 64 && Lz == 2 && K == 1 && D == 784;
+    const MegaFn fns[8] = {mega_fwd_bwd<0, 0, 0, 0, -1, 0>,      mega_fwd_bwd<0, 0, 0, 0, -1, 1>,
                            mega_fwd_bwd<64, 64, 10, 784, 2, 0>, mega_fwd_bwd<64, 64, 10, 784, 2, 1>,
-                           mega_fwd_bwd<64, 64, 10, 784, 1, 0>, mega_fwd_bwd<64, 64, 10, 784, 1, 1>};
-    const MegaFn fn = fns[(spec ? (gm ? 2 : 4) : 0) + (fl ? 1 : 0)];
+                           mega_fwd_bwd<64, 64, 10, 784, 1, 0>, mega_fwd_bwd<64, 64, 10, 784, 1, 1>,
+                           mega_fwd_bwd<64, 2, 1, 784, 0, 0>,   mega_fwd_bwd<64, 2, 1, 784, 0, 1>};
+    const MegaFn fn = fns[(spec ? (gm ? 2 : 4) : (spec_vae ? 6 : 0)) + (fl ? 1 : 0)];
     if (getenv("GMVAE_TRACE"))
       fprintf(stderr, "[gmvae] mega_fwd_bwd: model %d B %d first_layer_inside %d workgroups_per_panel %d specialised %d\n", model, B,
-              (int)fl, Qm, (int)spec);
+              (int)fl, Qm, (int)(spec || spec_vae));
     static bool mattr = false;
     if (!mattr) {
-      for (int i = 0; i < 6; ++i)
+      for (int i = 0; i < 8; ++i)
         hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       mattr = true;
     }
