@@ -320,7 +320,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
         take(2ull * ((B + 15) / 16) * (kMegaQMax - 1) * (kPanel * d.hidden[0] + kPanel)));
     w.sync = reinterpret_cast<unsigned*>(take(64));
     if (ml.fl_ok)
-      w.xfl = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * 4 * kPanel * 2 * d.hidden[0]));
+      w.xfl = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16 + 1) * 4 * kPanel * 2 * d.hidden[0]));      // (+ 1: mega2 pairs panels)
     w.gstamps = reinterpret_cast<unsigned long long*>(take(2ull * 4 * 2048 * 8));
     w.spans = reinterpret_cast<unsigned long long*>(take(2ull * 2 * 3 * 2048 * 2));
     if (model == GMVAE_MODEL_GMVAE && d.hidden[0] == M2::H && d.L == M2::L && d.K == M2::K && d.D == M2::D && d.B <= 1024) {
@@ -962,7 +962,8 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         hipFuncSetAttribute(reinterpret_cast<const void*>(mega2_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         m2attr = true;
       }
-      hipLaunchKernelGGL(mega2_fwd_bwd, dim3((B + kPanel - 1) / kPanel * 4), dim3(kMT), (size_t)M2::total * sizeof(float), st, c);
+      // (an even number of panels: the first layer works on pairs of them, mega2.hpp)
+      hipLaunchKernelGGL(mega2_fwd_bwd, dim3((((B + kPanel - 1) / kPanel + 1) & ~1) * 4), dim3(kMT), (size_t)M2::total * sizeof(float), st, c);
     } else {
       hipLaunchKernelGGL(fn, dim3((B + kPanel - 1) / kPanel * c.Q), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
     }

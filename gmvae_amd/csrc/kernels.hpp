@@ -675,8 +675,20 @@ __global__ void adam_tf(float* __restrict__ p, float* __restrict__ m, float* __r
 //   kind 2: contraction index = r (forward: out = in * W):     img[base + ((r >> 2) * ld + c) * 4 + (r & 3)]
 //   kind 3: contraction index = c (backward: din = dout * W^T): img[base + ((c >> 2) * ld + r) * 4 + (c & 3)]
 //   kinds 4 / 5 / 6: the decoder output layer [H][D] (4: forward, 5: data gradient, 6: its bias), 16-column tiles
-//   dealt round-robin to the panel's 4 workgroups: tile t = c >> 4 belongs to workgroup q = t & 3 as its local tile
-//   t >> 2; lc = ((c >> 6) << 4) | (c & 15) is the column inside that workgroup's part (`chunk` floats per part).
+//   dealt to the panel's 4 workgroups by m2_dec_part: tile t = c >> 4 belongs to workgroup q as its local tile lt;
+//   lc = 16 lt + (c & 15) is the column inside that workgroup's part (`chunk` floats per part).
+// Which workgroup of a panel owns decoder column tile t, and as which local tile (D = 784: 49 tiles).  The three producer
+// quarters (1..3) take 14 / 14 / 13 tiles round-robin, the lead quarter (0) the last 8: ONE tile per wave.  The lead is
+// the launch's critical path (it also stores the panel's activations and runs the backward chain), and its hand-off poll
+// can only succeed ~1 us after the producers publish: with 13 / 12 / 12 / 12 tiles it finished its decoder stage 1.6 us
+// AFTER them (tools/handoff_clock.py); two-deep waves cost the producers nothing extra up to 16 tiles.
+constexpr int kM2LeadTiles = 8, kM2ProdTiles = 14, kM2Tiles = 49;
+__host__ __device__ inline void m2_dec_part(const int t, int& q, int& lt) {
+  if (t < kM2Tiles - kM2LeadTiles) { q = 1 + t % 3; lt = t / 3; }
+  else { q = 0; lt = t - (kM2Tiles - kM2LeadTiles); }
+}
+__host__ __device__ inline int m2_dec_tile(const int q, const int lt) { return q == 0 ? kM2Tiles - kM2LeadTiles + lt : 3 * lt + (q - 1); }
+__host__ __device__ inline int m2_dec_ntiles(const int q) { return q == 0 ? kM2LeadTiles : (q == 3 ? kM2ProdTiles - 1 : kM2ProdTiles); }
 __host__ __device__ inline int img_dst(const int kind, const int base, const int ld, const int chunk, const int r, const int c) {
   switch (kind) {
     case 0: return base + r * ld + c;
@@ -684,10 +696,12 @@ __host__ __device__ inline int img_dst(const int kind, const int base, const int
     case 2: return base + (((r >> 2) * ld + c) << 2) + (r & 3);
     case 3: return base + (((c >> 2) * ld + r) << 2) + (c & 3);
     default: {
-      const int q = (c >> 4) & 3, lc = ((c >> 6) << 4) | (c & 15);
-      if (kind == 4) return base + q * chunk + (((r >> 2) * ld + lc) << 2) + (r & 3);    // [H/4][ld = 208][4]
-      if (kind == 5) return base + q * chunk + (((lc >> 2) * ld + r) << 2) + (lc & 3);   // [208/4][ld = H][4]
-      return base + q * chunk + lc;                                                       // bias [208]
+      int q, lt;
+      m2_dec_part(c >> 4, q, lt);
+      const int lc = (lt << 4) | (c & 15);
+      if (kind == 4) return base + q * chunk + (((r >> 2) * ld + lc) << 2) + (r & 3);    // [H/4][ld = DC][4]
+      if (kind == 5) return base + q * chunk + (((lc >> 2) * ld + r) << 2) + (lc & 3);   // [DC/4][ld = H][4]
+      return base + q * chunk + lc;                                                       // bias [DC]
     }
   }
 }

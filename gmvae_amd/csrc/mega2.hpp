@@ -16,9 +16,12 @@
 //     g = sigmoid(lambda) - x and -- the accumulator being exactly the B operand of the data gradient's contraction
 //     over those columns -- dhd1 += g Wd1^T follow without a barrier or an LDS round trip.
 //
-// Grid and hand-offs are mega_fwd_bwd's: 4 workgroups per panel (first-layer columns split four ways, partials exchanged
-// through tagged 8-byte granules; the decoder's column tiles dealt round-robin; quarters 1..3 publish their dhd1 and
-// row-sum partials and leave, quarter 0 runs the backward chain).
+// Grid and hand-offs are mega_fwd_bwd's: 4 workgroups per panel (the decoder's column tiles dealt round-robin; quarters
+// 1..3 publish their dhd1 and row-sum partials and leave, quarter 0 runs the backward chain).  The FIRST LAYER (round 4) is
+// split over the EIGHT workgroups of two neighbouring panels: workgroup (panel 2s + h, quarter q) multiplies the 32 rows of
+// both panels by rows [196 q, 196 q + 196) of ONE of the two first-layer weight tensors (h = 0: encoder_y's, 1: encoder_gmm's
+// x rows) -- 50 KB of weights per workgroup instead of 100 (its wait for them was 6.3 k of the stage's 17 k cycles) for the
+// same 392 matrix instructions and the same exchange (2048 granules out, 16 per lane in).
 #pragma once
 #include "mega.hpp"
 
@@ -27,7 +30,7 @@ namespace gmvae {
 struct M2 {
   static constexpr int H = 64, L = 64, K = 10, KP = 16, L2 = 128, D = 784, K2 = 12;
   static constexpr int NT = D / 16;               // 49 decoder column tiles
-  static constexpr int DC = 208;                  // columns of one workgroup's part, padded to 13 tiles
+  static constexpr int DC = 16 * kM2ProdTiles;    // columns of one workgroup's part: 14 tiles (kernels.hpp m2_dec_part)
   // ---- forward operand image (floats): biases, then [contraction / 4][outputs][4] weights
   static constexpr int b_y0 = 0, b_y1 = 64, b_g0 = 80, b_p = 144, b_g1 = 272, b_d0 = 400;
   static constexpr int Wy1f = 512;                // [16][16][4]   logits = hy * Wy1      (contraction h, 16 >= K outputs)
@@ -78,9 +81,13 @@ struct M2 {
   static constexpr int P_dl = P_dhg + 16 * ld64;  // [16][20]
   static_assert(P_dl + 16 * ldk <= P_dhd, "backward panels must fit the dred region");
   static_assert(total * 4 <= 160 * 1024, "LDS budget");
-  // the in-launch first layer's staging (mega.hpp FL: [2][196][64] weights + [16][226] x image) overlays [0, ...)
-  static constexpr int fl_kq = 196, fl_A = 25088;
-  static_assert(fl_A + 16 * kFlLda <= red, "first-layer staging must end below the scratch that is live during it");
+  // the in-launch first layer's staging ([196][64] weights + [32][226] x image) lies BEHIND the forward operand image (over
+  // the panels, which nothing uses yet): the image's DMA is then issued at the kernel's start, beside the weight bursts,
+  // instead of after the exchange's publish -- where its 66 KB sat in front of every wave's polls (vmcnt retires in order:
+  // the exchange took 2.4 us, the time of that DMA, for a hand-off whose latency is ~1 us)
+  static constexpr int fl_kq = 196, fl_W = imgF, fl_A = fl_W + fl_kq * 64;
+  static_assert(fl_A + 32 * kFlLda <= total, "first-layer staging must fit");
+  static constexpr int imgF_pieces = (imgF + 2047) / 2048;      // 1 KB LDS-DMA pieces per wave (the last ones clamped: uniform counts)
 };
 
 // one 16-output tile `nt` of  out[row][n] = sum_k in[row][k] W[k][n]:  W as a [K/4][NPAD][4] operand image, `in` a
@@ -112,6 +119,28 @@ __device__ __forceinline__ f32x4 m2_tile(const float* __restrict__ Wimg, const i
 __device__ __forceinline__ void granule_publish(unsigned long long* p, const unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Two granules {value, epoch} {value, epoch} of one lane as ONE 16-byte write-through store / sc1 load (round 4: the sweeps
+// of the two hand-offs were bound by the CU's vector-memory ISSUE -- 128 and 96 eight-byte wave-loads per sweep at ~16
+// cycles each, 1.3 us per sweep whatever had been published when; each 8-byte half is still its own flag, cdna_hip_programming
+// G16 R2).  The loads are inline asm: g2_wait() makes their registers the outputs of the wait, so no use can move above it.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void granule2_publish(unsigned long long* p, const unsigned epoch, const float v0, const float v1) {
+  const u32x4_t t = {__float_as_uint(v0), epoch, __float_as_uint(v1), epoch};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ u32x4_t granule2_load(const unsigned long long* p) {
+  u32x4_t r;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void g2_wait(u32x4_t (&v)[N]) {
+  static_assert(N == 6 || N == 8, "operand lists below");
+  if constexpr (N == 8)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5])::"memory");
+}
 __device__ __forceinline__ float4 f4(const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -123,13 +152,15 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   constexpr int Q = 4, H2f = 2 * H;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, lk = lane >> 4;
-  const int B = a.B, nP = (B + kPanel - 1) / kPanel;
+  // (the grid covers an EVEN number of panels: the first layer works on pairs of them; with an odd count the last pair's
+  //  second panel is a phantom whose four workgroups take their part in the first layer and leave)
+  const int B = a.B, nP = ((B + kPanel - 1) / kPanel + 1) & ~1;
   const int bid = blockIdx.x;
   // producers (quarters 1..3) take the LOWER block ids: a consumer can then never keep its producers off the chip
   const int q = bid < nP * (Q - 1) ? 1 + bid / nP : 0;
   const int pnl = bid < nP * (Q - 1) ? bid % nP : bid - nP * (Q - 1);
   const int r0 = pnl * kPanel;
-  const int nrow = min(kPanel, B - r0);
+  const int nrow = min(kPanel, B - r0);            // (<= 0: a phantom panel)
   const bool lead = q == 0;
   if (a.span && tid == 0) a.span[2 * bid] = wall_clock64();
 #define M2_SPAN_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
@@ -142,51 +173,68 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   float* P_dhd = sm + M2::P_dhd;
   GMVAE_STAMP(0);
   // diagnostics (tools/handoff_clock.py, GMVAE_STAMPS=5): device wall clock around the two in-launch hand-offs
-#define M2_WC(i) if (a.dbg && a.fine >= 5 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8 + (i)] = wall_clock64()
+#define M2_WC(i) if (a.dbg && a.fine == 5 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8 + (i)] = wall_clock64()
+  // GMVAE_STAMPS=6 (tools/flstamps.py): shader-clock stamps inside the first-layer stage
+#define M2_FC(i) if (a.dbg && a.fine == 6 && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime()
 
   // ======================================================================= FL: first layer over this quarter's columns
   // (the staging of mega_fwd_bwd's specialised instance: 49 bursts of 4 weight rows per tensor in two sub-chunks)
   float flt[4] = {0.f, 0.f, 0.f, 0.f};
   {
     constexpr int KQ = M2::fl_kq, kq4 = KQ / 4;
-    float* const Wst = sm;
+    float* const Wst = sm + M2::fl_W;
     float* const A_x = sm + M2::fl_A;
     const int k0 = q * KQ;
+    const int sp = pnl >> 1, hh = pnl & 1;         // the pair of panels; this workgroup's weight tensor (and its own row tile)
+    const int rs0 = sp * 2 * kPanel;               // first of the pair's 32 rows
+    const float* const W0 = (hh ? a.w0b : a.w0a) + (long long)k0 * H;
     const unsigned epoch_fl = epoch0;
     const unsigned long long step = a.step_dev[0];
     constexpr int qer = L / 4, qur = (K + 3) / 4, qe = kPanel * qer, qu = kPanel * qur;
     float nz[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    unsigned xw[2];
+    unsigned xw[4];
     const int row_ = lane >> 4, piece = lane & 15;
     const int src = row_ * 64 + ((piece ^ ((row_ & 1) << 2)) << 2);
-    auto burst = [&](const int first, const int b, const int per) {
-      const int t = b / per, idx = first + b % per;
-      __builtin_amdgcn_global_load_lds((t ? a.w0b : a.w0a) + (long long)k0 * H + (idx << 8) + src, Wst + t * KQ * H + (idx << 8), 16, 0, 0);
-    };
+    // 49 bursts of 4 weight rows (1 KB each) in two sub-chunks of 24 and 25; always 3 + 4 per wave (clamped duplicates)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) burst(0, wave + 8 * j, 24);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {               // always two loads per thread (clamped): uniform vmcnt accounting
-      const int i = min(tid + it * kMT, kPanel * kq4 - 1);
-      const int row = i / kq4, k4 = (i - row * kq4) * 4;
-      const unsigned wv = *reinterpret_cast<const unsigned*>(a.x + (long long)min(r0 + row, B - 1) * D + k0 + k4);
-      xw[it] = row < nrow ? wv : 0u;
+    for (int j = 0; j < 3; ++j) {
+      const int idx = wave + 8 * j;
+      __builtin_amdgcn_global_load_lds(W0 + (idx << 8) + src, Wst + (idx << 8), 16, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 7; ++j) burst(24, min(wave + 8 * j, 49), 25);
-    if (tid < qe + qu) {                           // this panel's rows of the Philox streams (= gmvae_noise_fill's)
+    for (int it = 0; it < 4; ++it) {               // always four loads per thread (clamped): uniform vmcnt accounting
+      const int i = min(tid + it * kMT, 2 * kPanel * kq4 - 1);
+      const int row = i / kq4, k4 = (i - row * kq4) * 4;
+      const unsigned wv = *reinterpret_cast<const unsigned*>(a.x + (long long)min(rs0 + row, B - 1) * D + k0 + k4);
+      xw[it] = rs0 + row < B ? wv : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = 24 + min(wave + 8 * j, 24);
+      __builtin_amdgcn_global_load_lds(W0 + (idx << 8) + src, Wst + (idx << 8), 16, 0, 0);
+    }
+    // the forward operand image: M2::imgF_pieces pieces per wave, behind the weight bursts in every wave's queue
+#pragma unroll
+    for (int j = 0; j < M2::imgF_pieces; ++j) {
+      const int c = min(wave * 256 + j * 2048, M2::imgF - 256);
+      __builtin_amdgcn_global_load_lds(a.img2f + c + lane * 4, img + c, 16, 0, 0);
+    }
+    M2_FC(0);
+    if (tid < qe + qu && nrow > 0) {               // this panel's rows of the Philox streams (= gmvae_noise_fill's)
       const bool is_u = tid >= qe;
       const int li = is_u ? tid - qe : tid;
       const int qpr = is_u ? qur : qer;
       const int row = li / qpr, quad = li - row * qpr;
       noise_vals(a.row0 + (unsigned long long)(r0 + row), (unsigned)quad, is_u, a.seed, step, nz);
     }
-    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                      // the first half and the x bytes are in
+    static_assert(M2::imgF_pieces == 9, "the counted waits below assume 9 image pieces per wave");
+    asm volatile("s_waitcnt vmcnt(13)" ::: "memory");                     // the first half and the x bytes are in
+    M2_FC(1);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < 4; ++it) {
       const int i = tid + it * kMT;
-      if (i < kPanel * kq4) {
+      if (i < 2 * kPanel * kq4) {
         const int row = i / kq4, k4 = (i - row * kq4) * 4;
         const unsigned w = xw[it];
         float2* const dst = reinterpret_cast<float2*>(A_x + row * kFlLda + k4);
@@ -195,23 +243,33 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       }
     }
     __syncthreads();
-    const int tl = wave & 3;
+    M2_FC(2);
+    const int tl = wave & 3, rt = wave >> 2;        // this wave's 16 columns of the tensor, its row tile (= panel of the pair)
     const int swz = ((tl * 16 + ln) ^ ((lk & 1) << 4)) - (tl * 16 + ln);
-    const float* const Wt = (wave < 4 ? Wst : Wst + KQ * H) + swz;
-    acc = tile_ksteps<1, kFlLda>(A_x, Wt, H, 1, tl, 0, 24, 24, lane, acc);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float* const Wt = Wst + swz;
+    const float* const At = A_x + rt * kPanel * kFlLda;
+    acc = tile_ksteps<1, kFlLda>(At, Wt, H, 1, tl, 0, 24, 24, lane, acc);
+    M2_FC(3);
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                      // the second half (the image may still be landing)
     __syncthreads();
-    acc = tile_ksteps<1, kFlLda>(A_x, Wt, H, 1, tl, 24, 49, 49, lane, acc);
-    constexpr int ngr = kPanel * H2f;
+    M2_FC(4);
+    acc = tile_ksteps<1, kFlLda>(At, Wt, H, 1, tl, 24, 49, 49, lane, acc);
+    constexpr int ngr = 2 * kPanel * H;            // granules one workgroup publishes: [32 rows][64 columns]
     {
-      unsigned long long* xo = a.xfl + ((long long)pnl * 4 + q) * ngr;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        granule_publish(xo + (wave * 4 + r) * 64 + lane, ((unsigned long long)epoch_fl << 32) | __float_as_uint(acc[r]));
+      unsigned long long* xo = a.xfl + (((long long)sp * 4 + q) * 2 + hh) * ngr;
+      // granule (wave, lane, r) at ((2 wave + r / 2) 64 + lane) 2 + r % 2: a wave's two stores are 1 KB each, contiguous
+      granule2_publish(xo + ((wave * 2 + 0) * 64 + lane) * 2, epoch_fl, acc[0], acc[1]);
+      granule2_publish(xo + ((wave * 2 + 1) * 64 + lane) * 2, epoch_fl, acc[2], acc[3]);
+    }
+    M2_FC(5);
+    if (bid == 0 && tid == 0) a.step_dev[1] = step;       // the copy dw_adam reads (block 0 is never a phantom)
+    if (nrow <= 0) {                               // a phantom panel's workgroup: its share of the pair's first layer is out
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (no LDS-DMA piece may still be landing when the LDS is handed on)
+      M2_SPAN_END();
+      return;
     }
     M2_WC(5);
-    __syncthreads();                               // the staging area is dead: the operand image may land on it
-    dma_copy_m(img, a.img2f, M2::imgF, wave, lane);
+    __syncthreads();                               // the staging area is dead: the panels it overlays may be written
     if (tid < qe) {
       st4(P_eps + tid * 4, make_float4(nz[0], nz[1], nz[2], nz[3]));
     } else if (tid < qe + qu) {
@@ -220,53 +278,49 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       for (int j = 0; j < 4; ++j)
         if (k0u + j < K) P_u[row * 16 + k0u + j] = nz[j];
     }
-    if (bid == (int)gridDim.x - 1 && tid == 0) a.step_dev[1] = step;       // the copy finalize_adam reads
     {
       // the four quarters' partials (this workgroup's own included): all 16 granules of a lane in ONE sweep, re-read
       // until every tag carries this step's epoch; summed in quarter order, so every workgroup of the panel gets the same bits
-      const unsigned long long* const xp0 = a.xfl + (long long)pnl * 4 * ngr + (wave * 4) * 64 + lane;
-      unsigned long long gv[4][4];
+      // output (row lk * 4 + r of THIS panel = row tile hh of the pair, column wave * 16 + ln of the 128): tensor wave >> 2,
+      // its column tile wave & 3 -- from each of the four quarters' workgroups that hold that tensor
+      const unsigned long long* const xp0 = a.xfl + ((long long)sp * 4 * 2 + (wave >> 2)) * ngr + (((hh * 4 + (wave & 3)) * 2) * 64 + lane) * 2;
+      u32x4_t gv[8];                               // [quarter pq][pair]: {value r = 2 pair, epoch, value r = 2 pair + 1, epoch}
       unsigned spins = 0;
       for (;;) {
-        const unsigned long long* const xp = xp0;
-        // all 16 loads are in flight before the first tag is looked at (left to itself the compiler waits for the
-        // first twelve before it issues the rest: a second memory round trip per sweep)
+        // all 8 loads are in flight before the first tag is looked at
 #pragma unroll
-        for (int pq = 0; pq < 4; ++pq)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            gv[pq][r] = __hip_atomic_load(xp + (long long)pq * ngr + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int pq = 0; pq < 4; ++pq) {
+          gv[2 * pq] = granule2_load(xp0 + (long long)pq * 2 * ngr);
+          gv[2 * pq + 1] = granule2_load(xp0 + (long long)pq * 2 * ngr + 128);
+        }
+        g2_wait(gv);
         bool ok = true;
 #pragma unroll
-        for (int pq = 0; pq < 4; ++pq)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ok = ok && (unsigned)(gv[pq][r] >> 32) == epoch_fl;
+        for (int i = 0; i < 8; ++i) ok = ok && gv[i][1] == epoch_fl && gv[i][3] == epoch_fl;
         if (__all(ok)) break;
         if (++spins > spin_limit) {
           if (lane == 0) atomicExch(a.err_word, 1u);
 #pragma unroll
-          for (int pq = 0; pq < 4; ++pq)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gv[pq][r] = 0x7fc00000ull;
+          for (int i = 0; i < 8; ++i) { gv[i][0] = 0x7fc00000u; gv[i][2] = 0x7fc00000u; }
           break;
         }
         __builtin_amdgcn_s_sleep(2);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        flt[r] = __uint_as_float((unsigned)gv[0][r]);
-        flt[r] += __uint_as_float((unsigned)gv[1][r]);
-        flt[r] += __uint_as_float((unsigned)gv[2][r]);
-        flt[r] += __uint_as_float((unsigned)gv[3][r]);
+      for (int r = 0; r < 4; ++r) {                // summed in quarter order: every workgroup of the panel gets the same bits
+        flt[r] = __uint_as_float(gv[0 + (r >> 1)][2 * (r & 1)]);
+        flt[r] += __uint_as_float(gv[2 + (r >> 1)][2 * (r & 1)]);
+        flt[r] += __uint_as_float(gv[4 + (r >> 1)][2 * (r & 1)]);
+        flt[r] += __uint_as_float(gv[6 + (r >> 1)][2 * (r & 1)]);
       }
       if (a.dbg && a.fine >= 5 && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + 14] = spins;
     }
   }
   M2_WC(6);
+  M2_FC(6);
   // ---- decoder operands of this wave's column tiles, straight into registers (used ~10 stages from here)
   // local tile lt = wave, wave + 8 of this workgroup's part; global tile t = 4 lt + q
-  const int ntq = (M2::NT - q + 3) >> 2;           // 13 tiles for quarter 0, 12 for the others
+  const int ntq = m2_dec_ntiles(q);                // 8 tiles for the lead (one per wave), 14 / 14 / 13 for the producers
   const bool two = wave + 8 < ntq;                 // (wave-uniform) this wave has a second tile
   float4 wf[2][4], wb[2][4], bias4[2];
   unsigned xb[2] = {0u, 0u};
@@ -283,7 +337,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) wb[it][ht] = ld4(dbq + (((lt * 4 + lk) * 64 + ht * 16 + ln) << 2));
         bias4[it] = ld4(bq + lt * 16 + 4 * lk);
-        const int c0 = (4 * lt + q) * 16;
+        const int c0 = m2_dec_tile(q, lt) * 16;
         xb[it] = *reinterpret_cast<const unsigned*>(a.x + (long long)min(r0 + ln, B - 1) * D + c0 + 4 * lk);
       }
     }
@@ -293,6 +347,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   if (two) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   __syncthreads();
+  M2_FC(7);
   {                                                // bias + ReLU straight from the (row-major oriented) accumulator
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -471,7 +526,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
         // quarter 0 keeps g in registers until its hand-off polls are through: vmcnt retires in order, so a poll's
         // data would otherwise wait for the acknowledgement of these stores (measured: 1.8 us per sweep)
         if (lead) gkeep[it] = make_float4(g[0], g[1], g[2], g[3]);
-        else if (ok) st4o(a.g + (long long)(r0 + ln) * D + (4 * lt + q) * 16 + 4 * lk, make_float4(g[0], g[1], g[2], g[3]));
+        else if (ok) st4o(a.g + (long long)(r0 + ln) * D + m2_dec_tile(q, lt) * 16 + 4 * lk, make_float4(g[0], g[1], g[2], g[3]));
         // dhd1 += g Wd1^T over this tile's 16 columns: the accumulator layout IS the B operand
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
@@ -513,11 +568,9 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   if (!lead) {
     // ------------------------------------------------------------- producer: publish the partials and leave
     unsigned long long* xo = a.xchg + ((long long)pnl * (Q - 1) + (q - 1)) * ngr;
-    if (tid < 256) {
-      const float dv[4] = {dsum.x, dsum.y, dsum.z, dsum.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        granule_publish(xo + 4 * tid + j, ((unsigned long long)epoch << 32) | __float_as_uint(dv[j]));
+    if (tid < 256) {                               // granule (thread t, j) at ((2 (t / 64) + j / 2) 64 + t % 64) 2 + j % 2
+      granule2_publish(xo + ((wave * 2 + 0) * 64 + lane) * 2, epoch, dsum.x, dsum.y);
+      granule2_publish(xo + ((wave * 2 + 1) * 64 + lane) * 2, epoch, dsum.z, dsum.w);
     } else if (tid < 256 + kPanel) {
       granule_publish(xo + kPanel * H + (tid - 256), ((unsigned long long)epoch << 32) | __float_as_uint(rsn));
     }
@@ -534,53 +587,64 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   {
     const unsigned long long* xi = a.xchg + (long long)pnl * (Q - 1) * ngr;
     const bool wd = tid < 256, wn = tid >= 256 && tid < 256 + kPanel;
-    // all three producers' granules are requested in ONE sweep (a sweep is a memory round trip)
-    unsigned long long v[Q - 1][5];
+    // all three producers' granules are requested in ONE sweep (a sweep is a memory round trip): waves 0..3 their threads'
+    // four dhd1 granules per producer as two 16-byte loads, wave 4 (lanes 0..15) the row-sum granules; waves 5..7 own
+    // nothing and stay out of the CU's memory queue (wave-uniform branches: the loads of a wave are still issued together)
     unsigned spins = 0;
-    // Branch-free sweep: every lane requests four granules of each producer (its own four dhd1 granules, or -- lanes
-    // 256..271 -- its row-sum granule; the others re-read granule 0 and ignore it), so that all twelve loads of a lane
-    // are in flight together.  (With the loads under `if (owner)` the compiler waited inside every branch: up to six
-    // dependent memory round trips per sweep, 1.3-1.8 us.)
-    const int gbase = wd ? 4 * tid : (wn ? kPanel * H + (tid - 256) : 0);
-    const int gstep = wd ? 1 : 0;
-    for (;;) {
-      const unsigned long long* const xs = xi + gbase;
+    if (wave < 4) {
+      u32x4_t v[6];
+      const unsigned long long* const xs = xi + ((wave * 2) * 64 + lane) * 2;
+      for (;;) {
 #pragma unroll
-      for (int pq = 0; pq < Q - 1; ++pq)
+        for (int pq = 0; pq < Q - 1; ++pq) {
+          v[2 * pq] = granule2_load(xs + (long long)pq * ngr);
+          v[2 * pq + 1] = granule2_load(xs + (long long)pq * ngr + 128);
+        }
+        g2_wait(v);
+        bool ok = true;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          v[pq][j] = __hip_atomic_load(xs + (long long)pq * ngr + j * gstep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_sched_barrier(0);
-      bool ok = true;
+        for (int i = 0; i < 6; ++i) ok = ok && v[i][1] == epoch && v[i][3] == epoch;
+        if (__all(ok)) break;
+        if (++spins > spin_limit) {                          // a producer never ran; flag and go on
+          if (lane == 0) atomicExch(a.err_word, 1u);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) { v[i][0] = 0x7fc00000u; v[i][2] = 0x7fc00000u; }      // NaN: the step's loss and gradients say so loudly
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
 #pragma unroll
       for (int pq = 0; pq < Q - 1; ++pq) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ok = ok && ((unsigned)(v[pq][j] >> 32) == epoch || !(wd || wn));
-        v[pq][4] = v[pq][0];                       // (the row-sum lanes' granule)
+        dsum.x += __uint_as_float(v[2 * pq][0]); dsum.y += __uint_as_float(v[2 * pq][2]);
+        dsum.z += __uint_as_float(v[2 * pq + 1][0]); dsum.w += __uint_as_float(v[2 * pq + 1][2]);
       }
-      if (__all(ok)) break;
-      if (++spins > spin_limit) {                          // a producer never ran; flag and go on
-        if (lane == 0) atomicExch(a.err_word, 1u);
+    } else if (wave == 4) {
+      unsigned long long v[Q - 1];
+      const unsigned long long* const xs = xi + kPanel * H + min(lane, kPanel - 1);
+      for (;;) {
 #pragma unroll
-        for (int pq = 0; pq < Q - 1; ++pq)
+        for (int pq = 0; pq < Q - 1; ++pq) v[pq] = __hip_atomic_load(xs + (long long)pq * ngr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_sched_barrier(0);
+        bool ok = true;
 #pragma unroll
-          for (int j = 0; j < 5; ++j) v[pq][j] = 0x7fc00000ull;   // NaN: the step's loss and gradients say so loudly
-        break;
+        for (int pq = 0; pq < Q - 1; ++pq) ok = ok && (unsigned)(v[pq] >> 32) == epoch;
+        if (__all(ok)) break;
+        if (++spins > spin_limit) {
+          if (lane == 0) atomicExch(a.err_word, 1u);
+#pragma unroll
+          for (int pq = 0; pq < Q - 1; ++pq) v[pq] = 0x7fc00000ull;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
       }
-      __builtin_amdgcn_s_sleep(4);
-    }
 #pragma unroll
-    for (int pq = 0; pq < Q - 1; ++pq) {
-      if (wd) {
-        dsum.x += __uint_as_float((unsigned)v[pq][0]); dsum.y += __uint_as_float((unsigned)v[pq][1]);
-        dsum.z += __uint_as_float((unsigned)v[pq][2]); dsum.w += __uint_as_float((unsigned)v[pq][3]);
-      }
-      if (wn) rsn += __uint_as_float((unsigned)v[pq][4]);
+      for (int pq = 0; pq < Q - 1; ++pq)
+        if (wn) rsn += __uint_as_float((unsigned)v[pq]);
     }
     if (a.dbg && a.fine >= 5 && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + 15] = spins;       // sweeps that failed
     if (ln < nrow) {                               // now the decoder tiles' g = sigmoid(lambda) - x
-      st4o(a.g + (long long)(r0 + ln) * D + (4 * wave + q) * 16 + 4 * lk, gkeep[0]);
-      if (two) st4o(a.g + (long long)(r0 + ln) * D + (4 * (wave + 8) + q) * 16 + 4 * lk, gkeep[1]);
+      st4o(a.g + (long long)(r0 + ln) * D + m2_dec_tile(0, wave) * 16 + 4 * lk, gkeep[0]);
+      if (two) st4o(a.g + (long long)(r0 + ln) * D + m2_dec_tile(0, wave + 8) * 16 + 4 * lk, gkeep[1]);
     }
     M2_WC(2);
     if (wd) {                                      // masked top gradient (+ saved for dWd0)
@@ -600,7 +664,11 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
     }
   }
   M2_WC(3);
-  dma_wait();                                      // the backward image
+  // the backward image has landed: the hand-off polls of waves 0..4 returned data, and vmcnt retires in order -- their
+  // pieces of the image were issued long before; waves 5..7 wait for everything but their one g store just issued.  (An
+  // s_waitcnt vmcnt(0) here also waited for the write-through acknowledgement of the g stores: ~1 us in front of the
+  // backward chain.)
+  if (wave > 4) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   __syncthreads();
   M2_WC(4);
   GMVAE_STAMP(6);
