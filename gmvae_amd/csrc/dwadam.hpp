@@ -68,7 +68,7 @@ template <bool U8, int MU, class Mid>
 __device__ __forceinline__ void dw_contract(const void* __restrict__ Ap, const float* __restrict__ dY, const int lda, const int ldy,
                                             const int M, const int N, const int m0, const int n0, const int b_lo, const int b_hi,
                                             const int ln, const int lk, f32x4 (&acc)[4], float& cs, Mid mid) {
-  static_assert(MU == 4 || MU == 2, "2 or 4 strided 16-row tiles per workgroup tile");
+  static_assert(MU == 4 || MU == 2 || MU == 1, "1, 2 or 4 strided 16-row tiles per workgroup tile");
   const int ma = m0 + MU * ln;                   // this lane's MU fan-in rows (one per strided tile)
   const bool a_ok = ma < M, n_ok = n0 + ln < N;  // (M is a multiple of 4 or the source rows are padded to one)
   const int mac = min(ma, ((M + 3) & ~3) - MU), nc = min(n0 + ln, N - 1);
@@ -76,7 +76,8 @@ __device__ __forceinline__ void dw_contract(const void* __restrict__ Ap, const f
   const float* const A32 = static_cast<const float*>(Ap);
   constexpr int KB = 32;
   typedef typename std::conditional<MU == 4, typename std::conditional<U8, unsigned, float4>::type,
-                                    typename std::conditional<U8, unsigned short, float2>::type>::type AT;
+                                    typename std::conditional<MU == 2, typename std::conditional<U8, unsigned short, float2>::type,
+                                                              typename std::conditional<U8, unsigned char, float>::type>::type>::type AT;
   auto mfma4 = [&](const AT& avs, const float bq) {
     float aq[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (U8) {
@@ -85,8 +86,10 @@ __device__ __forceinline__ void dw_contract(const void* __restrict__ Ap, const f
       for (int t = 0; t < MU; ++t) aq[t] = (float)((w >> (8 * t)) & 0xff);
     } else if constexpr (MU == 4) {
       aq[0] = avs.x; aq[1] = avs.y; aq[2] = avs.z; aq[3] = avs.w;
-    } else {
+    } else if constexpr (MU == 2) {
       aq[0] = avs.x; aq[1] = avs.y;
+    } else {
+      aq[0] = avs;
     }
 #pragma unroll
     for (int t = 0; t < MU; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? aq[t] : 0.f, bq, acc[t], 0, 0, 0);
@@ -186,6 +189,9 @@ __device__ __forceinline__ void dw_contract_u8x3(const unsigned char* __restrict
   }
 }
 
+// (Round 4, measured and reverted: [16 x 16] tiles for the decoder output layer -- 196 instead of 98 -- end at 7.4 us instead
+//  of 9.6, but 338 workgroups need two per CU: at <= 128 registers the contraction's 64 in-flight operands spill (124 B of
+//  scratch per lane) and the launch takes 14.6 us; at one per CU the last 83 tiles start when the first ones end: 15.7 us.)
 __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
   __shared__ __attribute__((aligned(16))) float red[kDwWaves * 64 * 16];     // [wave][mt * 4 + r][lane]
   __shared__ float redcs[kDwWaves * 64];
@@ -288,8 +294,8 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
   if (T.a_u8 && b_hi - b_lo == 128 && a.u8x3)
     dw_contract_u8x3(static_cast<const unsigned char*>(T.A), T.dY, lda, ldy, M, N, m0, n0, b_lo, ln, lk, acc, cs);
   else if (T.a_u8) dw_contract<true, 4>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
-  else if (MUr == 4) dw_contract<false, 4>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
-  else dw_contract<false, 2>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+  else if (MUr == 2) dw_contract<false, 2>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+  else dw_contract<false, 1>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
   prologue();                                    // its loads fly while the partial tiles go to LDS and the waves meet
   DW_ST(2);
   // ---- the waves' partial tiles meet in LDS (fixed order: bit-reproducible)
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
     for (int w = 0; w < kDwWaves; ++w)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int o = 4 * eu + j, r = MUr == 4 ? eu : o >> 1, t = MUr == 4 ? j : o & 1;
+        const int o = 4 * eu + j, r = MUr == 4 ? eu : (MUr == 2 ? o >> 1 : o), t = MUr == 4 ? j : (MUr == 2 ? o & 1 : 0);
         g[j] += red[(w * 16 + 4 * t + r) * 64 + el];
       }
 #pragma unroll

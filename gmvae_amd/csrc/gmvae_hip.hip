@@ -1018,19 +1018,20 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       };
       const int K4 = (int)pad4(K);
       const int mu = 2;
+      constexpr int kDwd1Mu = 2;       // (the decoder output layer as [16 x 16] tiles: measured slower, dwadam.hpp)
       // (32-row tiles for the fp32 problems: more, lighter workgroups -- 240 <= 256 CUs at the default sizes -- and the
       //  decoder output layer's longer epilogue, two operand images, no longer ends the launch)
       if (gm) {
         add(a.x, true, D, w.dbuf[2], H, D, H, E.w[0], (long long)E.b[0]);                                 // dWy0 (+ dby0)
         add(a.x, true, D, w.dbuf[1], H, D, H, G.w[0], (long long)G.b[0]);                                 // dWg0[x] (+ dbg0)
-        add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1], mu);                            // dWd1 (+ dbd1)
+        add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1], kDwd1Mu);                            // dWd1 (+ dbd1)
         add(w.y, false, K4, w.dbuf[1], H, K, H, G.w[0] + (uint64_t)D * H, -1, mu);                        // dWg0[y]
         add(w.he[1], false, H, w.dlogits, K4, H, K, E.w[1], (long long)E.b[1], mu);                       // dWy1
         add(w.y, false, K4, w.dpp, 2 * Lz, K, 2 * Lz, L.prior.w[0], (long long)L.prior.b[0], mu);         // dWp
         add(w.hg[1], false, H, w.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1], mu);                  // dWg1
       } else {
         add(a.x, true, D, w.dbuf[1], H, D, H, E.w[0], (long long)E.b[0]);                                 // dWe0 (+ dbe0)
-        add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1], mu);                            // dWd1 (+ dbd1)
+        add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1], kDwd1Mu);                            // dWd1 (+ dbd1)
         add(w.he[1], false, H, w.dqp, 2 * Lz, H, 2 * Lz, E.w[1], (long long)E.b[1], mu);                  // dWe1
       }
       add(w.z, false, Lz, w.dbuf[0], H, Lz, H, Dn.w[0], (long long)Dn.b[0], mu);                          // dWd0

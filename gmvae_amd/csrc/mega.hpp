@@ -571,9 +571,18 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   asm volatile("" : "+v"(tidf_));
   const int tid = tidf_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 15, lk = lane >> 4;
   if (gmp) {                      // mixture constants: 1/s, log-softmax weights, per-component constant
-    for (int i = tid; i < K * L; i += kMT) {
-      const int k = i / L, l = i - k * L;
-      M_inv[k * ldM + l] = 1.f / fsoftplus(M_raw[k * ldM + l]);
+    // one WAVE per component: its lanes walk the latent dimensions, so 1/s and -sum log s of a component are one pass and
+    // one wave reduction (round 4: ten threads each walked their component's L dimensions serially -- 64 dependent LDS
+    // reads and logs, ~9 k cycles = 4 us at the head of every VAE_GMP launch, tools/stamps.py)
+    for (int k = wave; k < K; k += kMW) {
+      float ls = 0.f;
+      for (int l = lane; l < L; l += 64) {
+        const float iv = 1.f / fsoftplus(M_raw[k * ldM + l]);
+        M_inv[k * ldM + l] = iv;
+        ls += flog(iv);                            // = -log s
+      }
+      ls = wave_sum(ls);
+      if (lane == 0) M_c[k] = ls;                  // (finished below, once the mixture weights' normaliser is known)
     }
   }
   __syncthreads();
@@ -586,11 +595,9 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     se = wave_sum(se);
     const float lse = mx + flog(se);
     for (int k = tid; k < K; k += 64) {
-      float ls = 0.f;
-      for (int l = 0; l < L; ++l) ls += flog(M_inv[k * ldM + l]);          // = -sum log s
       const float lw = M_mix[k] - lse;
       M_w[k] = fexp(lw);
-      M_c[k] = lw + ls - 0.5f * kLog2Pi * (float)L;
+      M_c[k] = lw + M_c[k] - 0.5f * kLog2Pi * (float)L;
     }
   }
   GMVAE_STAMP(1);
@@ -717,19 +724,28 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   if (gmp) {
     // MixtureSameFamily.log_prob (vae.py:240-244,181): 32 lanes per row, lane = component (+32), each lane
     // walks l over the LDS-resident (loc, 1/s) image; K-way logsumexp by wavefront shuffles; responsibilities kept.
+    // (round 4: the 32 lanes of a row split the LATENT dimensions and every component's squared distance is a 32-lane
+    //  reduction -- with lane = component, K = 10 left 22 of 32 lanes idle behind L serial steps of three LDS reads each)
     const int row = tid >> 5, sub = tid & 31;
-    float comp[2];
+    float comp[2] = {-INFINITY, -INFINITY};
+    {
+      float zl[4];                                 // this lane's latent dimensions l = sub + 32 i (L <= 128)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = sub + 32 * j;
-      comp[j] = -INFINITY;
-      if (k < K) {
+      for (int i = 0; i < 4; ++i) zl[i] = sub + 32 * i < L ? P_z[row * L + sub + 32 * i] : 0.f;
+      for (int k = 0; k < K; ++k) {
         float acc = 0.f;
-        for (int l = 0; l < L; ++l) {
-          const float t = (P_z[row * L + l] - M_loc[k * ldM + l]) * M_inv[k * ldM + l];
-          acc += t * t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int l = sub + 32 * i;
+          if (l < L) {
+            const float t = (zl[i] - M_loc[k * ldM + l]) * M_inv[k * ldM + l];
+            acc += t * t;
+          }
         }
-        comp[j] = M_c[k] - 0.5f * acc;
+        acc = row32_sum(acc);
+        const float c = M_c[k] - 0.5f * acc;
+        if (k < 32) { if (sub == k) comp[0] = c; }           // lane k (mod 32) keeps component k, as the reductions below expect
+        else if (sub == k - 32) comp[1] = c;
       }
     }
     float mx = fmaxf(comp[0], comp[1]);
@@ -1028,18 +1044,23 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       const int k = i / L, l = i - k * L;
       const float iv = M_inv[k * ldM + l], lc = M_loc[k * ldM + l];
       float ga = 0.f, gb = 0.f;
-      for (int row = 0; row < nrow; ++row) {
-        const float wr = P_r[row * KP + k];
-        const float t = (P_z[row * L + l] - lc) * iv;
-        ga -= wr * t * iv;
-        gb += wr * (1.f - t * t) * iv;
+      float wr[kPanel], zz[kPanel];                // all 32 LDS reads in flight (a runtime row bound made them 16 dependent rounds)
+#pragma unroll
+      for (int row = 0; row < kPanel; ++row) { wr[row] = P_r[row * KP + k]; zz[row] = P_z[row * L + l]; }
+#pragma unroll
+      for (int row = 0; row < kPanel; ++row) {
+        const float w_ = row < nrow ? wr[row] : 0.f;
+        const float t = row < nrow ? (zz[row] - lc) * iv : 0.f;
+        ga -= w_ * t * iv;
+        gb += w_ * (1.f - t * t) * iv;
       }
       out[i] = ga;
       out[KLp + i] = gb * sigmoidf_(M_raw[k * ldM + l]);
     }
     for (int k = tid; k < K; k += kMT) {
       float ga = 0.f;
-      for (int row = 0; row < nrow; ++row) ga -= P_r[row * KP + k] - M_w[k];
+#pragma unroll
+      for (int row = 0; row < kPanel; ++row) ga -= row < nrow ? P_r[row * KP + k] - M_w[k] : 0.f;
       out[2 * KLp + k] = ga;
     }
   }

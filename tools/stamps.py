@@ -5,10 +5,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gmvae_amd import _lib as L
 from gmvae_amd.engine import Engine
-B = 1024
+# argv: [model B L K]  (default: the headline configuration)
+MODEL = sys.argv[1] if len(sys.argv) > 1 else "gmvae"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+LZ = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+KK = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 Q = int(os.environ.get("GMVAE_MEGA_Q", "4"))
-nP = B // 16
-e = Engine("gmvae", 784, 64, 10, [64], random_seed=0)
+nP = (B + 15) // 16
+if MODEL == "gmvae" and B <= 1024 and LZ == 64 and KK == 10:
+    nP = (nP + 1) & ~1                            # mega2_fwd_bwd's grid covers an even number of panels
+e = Engine(MODEL, 784, LZ, KK, [64], random_seed=0)
 x = torch.from_numpy((np.random.default_rng(0).random((B, 784)) < 0.87).astype(np.uint8)).cuda()
 G = int(os.environ.get("GRAPH_STEPS", "16"))
 sx, replay = e.capture_train_step(B, 1e-3, n_steps=G)          # the hipGraph the bench replays
