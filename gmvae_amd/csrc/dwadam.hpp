@@ -55,7 +55,6 @@ struct DwArgs {
   // (after the tail block) sum them in panel order, apply the update and write the variables' LDS-image copies
   int gmp_blocks, gmp_nmap;
   ImgMap gmp_map[3];
-  int tile_begin[kDwMaxT];
   DwTensor t[kDwMaxT];
   FinalArgs fa;                // p, m, v, grads, Adam constants, loss-tail inputs, counters, images
 };
@@ -240,14 +239,13 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, lk = lane >> 4;
-  const int tile = a.perm[bid];
-  int ti = 0;
-#pragma unroll
-  for (int i = 1; i < kDwMaxT; ++i)
-    if (i < a.ntens && tile >= a.tile_begin[i]) ti = i;
+  // perm[slot] = (tensor << 10) | tile inside the tensor: ONE kernel-argument load names the tensor (a search through
+  // tile_begin[] was a dependent round of scalar loads in front of every workgroup's first operand load)
+  const int pv_ = a.perm[bid];
+  const int ti = pv_ >> 10, tl = pv_ & 1023;
   const DwTensor& T = a.t[ti];
   const int M = T.M, N = T.N, lda = T.lda, ldy = T.ldy, B = a.B;
-  const int tl = tile - T.tile_begin, tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
+  const int tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
   const int MUr = T.mu;
   const int m0 = tm * 16 * MUr, n0 = tn * 16;
   // ---- epilogue owners (threads 0..255): unit (lane slot l, r) = dW[mb .. mb+3][n]
@@ -287,6 +285,7 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
   // ---- the contraction: this wave's share of the batch rows, 4 rows (k) per MFMA step
   const int rows_w = (((B + kDwWaves - 1) / kDwWaves) + 3) & ~3;
   const int b_lo = wave * rows_w, b_hi = min(B, b_lo + rows_w);
+  prologue();                                    // (variant B: requested BEFORE the contraction's operands)
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -296,7 +295,6 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
   else if (T.a_u8) dw_contract<true, 4>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
   else if (MUr == 2) dw_contract<false, 2>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
   else dw_contract<false, 1>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
-  prologue();                                    // its loads fly while the partial tiles go to LDS and the waves meet
   DW_ST(2);
   // ---- the waves' partial tiles meet in LDS (fixed order: bit-reproducible)
 #pragma unroll

@@ -997,7 +997,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         DwTensor& T = da.t[da.ntens];
         T.A = A; T.a_u8 = u8 ? 1 : 0; T.lda = lda; T.dY = dY; T.ldy = ldy; T.M = M; T.N = N; T.w_off = (int)w_off; T.b_off = (int)b_off;
         T.mu = u8 ? 4 : mu;
-        T.tiles_n = (N + 15) / 16; T.tile_begin = da.total_tiles; da.tile_begin[da.ntens] = da.total_tiles;
+        T.tiles_n = (N + 15) / 16; T.tile_begin = da.total_tiles;
         da.total_tiles += ((M + 16 * T.mu - 1) / (16 * T.mu)) * T.tiles_n;
         T.bk = T.k1 = T.k2 = -1;
         for (int i = 0; i < pl.nmap; ++i) {      // where the optimizer also has to leave the updated values (mega2's operand images)
@@ -1061,7 +1061,10 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
           } else {
             pick = b;
           }
-          da.perm[b] = (unsigned short)pick;
+          int pt = 0;                             // (tensor << 10) | tile inside the tensor (dwadam.hpp)
+          for (int i = 1; i < da.ntens; ++i)
+            if (pick >= da.t[i].tile_begin) pt = i;
+          da.perm[b] = (unsigned short)((pt << 10) | (pick - da.t[pt].tile_begin));
         }
         if (da.total_tiles > kDwMaxTiles) { /* cannot happen at these sizes; the launch below is guarded */ }
       }

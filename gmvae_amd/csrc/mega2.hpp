@@ -403,6 +403,8 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   __syncthreads();
   GMVAE_STAMP(2);
   // S3 prior head (8 tiles) and encoder_gmm hidden (4 tiles), contraction = y (one tile of 16)
+  // (Round 4, measured and reverted: the producers skipping the prior head and its half of S5 -- the launch got 0.5 us
+  //  LONGER: the lead, which cannot skip them, then reaches its hand-off later relative to the producers' publish.)
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     acc = m2_tile<1, 128>(img + M2::Wpf, wave, P_y, M2::ldk, 0, ln, lk, acc);
