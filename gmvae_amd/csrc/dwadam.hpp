@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (mb + j >= M) pp[j] = 0.f;              // rows past the tensor: the image's padding stays zero
-      if (T.k1 == 2 || T.k1 == 4)
+      if (T.k1 == 2 || T.k1 == 4 || T.k1 == 7)
         *reinterpret_cast<float4*>(fa.img[T.which1] + img_dst(T.k1, T.base1, T.ld1, T.chunk1, mb, en)) = make_float4(pp[0], pp[1], pp[2], pp[3]);
       else if (T.k1 >= 0) {
 #pragma unroll

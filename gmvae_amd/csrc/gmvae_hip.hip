@@ -22,6 +22,7 @@
 #include "chain.hpp"
 #include "mega.hpp"
 #include "mega2.hpp"
+#include "mega2v.hpp"
 #include "dwadam.hpp"
 #include "skinny.hpp"
 
@@ -191,6 +192,22 @@ static bool mega2_ok(const GmvaeDims& d, int model) {
   return model == GMVAE_MODEL_GMVAE && mega_ok(d, model) && d.hidden[0] == M2::H && d.L == M2::L && d.K == M2::K &&
          d.D == M2::D && d.B <= 1024;
 }
+// mega2v_fwd_bwd (mega2v.hpp): the same design for the VAE family at small batches, SEVEN workgroups per panel -- the plain
+// VAE at latent 2 (BASELINE configs[0]) and VAE_GMP at latent 64, K = 10 (configs[1]), hidden 64, D = 784
+static int mega2v_kind(const GmvaeDims& d, int model) {       // 0: not these sizes; 1: VAE L = 2; 2: VAE_GMP L = 64 K = 10
+  if (d.n_hidden != 1 || d.hidden[0] != 64 || d.D != 784 || d.S != 1 || d.gen_bias_vec) return 0;
+  if ((d.B + kPanel - 1) / kPanel * 7 > 256) return 0;
+  if (model == GMVAE_MODEL_VAE && d.L == 2) return 1;
+  if (model == GMVAE_MODEL_VAE_GMP && d.L == 64 && d.K == 10) return 2;
+  return 0;
+}
+typedef M2V<0, 2, 1> MV0;
+typedef M2V<1, 64, 10> MV1;
+static bool mega2v_ok(const GmvaeDims& d, int model) {
+  const char* e = getenv("GMVAE_NO_MEGA2");
+  if (e && atoi(e)) return false;
+  return mega_ok(d, model) && mega2v_kind(d, model) != 0 && !sched_safe(d) && !getenv("GMVAE_MEGA_Q");
+}
 // the skinny schedule (skinny.hpp): GMVAE, one WIDE hidden layer, a SMALL batch -- bin/run_train.sh's sizes
 constexpr int kSkMaxB = 4096;       // hard bound of the skinny schedule's batch (its buffers are carved up to here)
 static bool skinny_shape(const GmvaeDims& d, int model) {
@@ -316,8 +333,9 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     w.dimg = take((uint64_t)ml.nch * ml.chunk);
     if (!w.s1) w.s1 = take((uint64_t)fwd_splits(d.D) * B * 2 * d.hidden[0]);
     w.stamps = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16) * kMegaQMax * 16 * 2));   // one slot per workgroup
+    // (mega2v_fwd_bwd: six producers per panel)
     w.xchg = reinterpret_cast<unsigned long long*>(
-        take(2ull * ((B + 15) / 16) * (kMegaQMax - 1) * (kPanel * d.hidden[0] + kPanel)));
+        take(2ull * ((B + 15) / 16) * (mega2v_kind(d, model) ? 6 : kMegaQMax - 1) * (kPanel * d.hidden[0] + kPanel)));
     w.sync = reinterpret_cast<unsigned*>(take(64));
     if (ml.fl_ok)
       w.xfl = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16 + 1) * 4 * kPanel * 2 * d.hidden[0]));      // (+ 1: mega2 pairs panels)
@@ -327,6 +345,11 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
       w.img2f = take(M2::imgF);                  // (not gated by GMVAE_NO_MEGA2: the workspace layout must not depend on a switch)
       w.img2b = take(M2::imgB);
       w.dimg2 = take(M2::dimg);
+    }
+    if (const int vk = mega2v_kind(d, model)) {
+      w.img2f = take(vk == 1 ? MV0::imgF : MV1::imgF);
+      w.img2b = take(vk == 1 ? MV0::imgB : MV1::imgB);
+      w.dimg2 = take(vk == 1 ? MV0::dimg : MV1::dimg);
     }
   }
   if (skinny_shape(d, model)) {       // (sized by the dims alone: no switch, no batch bound below kSkMaxB)
@@ -759,6 +782,28 @@ static void plan_images(const GmvaeDims& d, int model, const Layout& L, const WS
     add_map(Dn.w[1], (long long)H * D, D, 5, M2::dB, 64, 4, M2::dBq);
     add_map(Dn.b[1], D, D, 6, M2::dbias, 0, 4, M2::dbq);
   }
+  if (mega2v_ok(d, model) && w.img2f) {
+    // mega2v_fwd_bwd's operand images (mega2v.hpp M2V): the same kinds; the decoder layer dealt to seven workgroups (7..9)
+    const int vk = mega2v_kind(d, model);
+    pl.nmap = 0; pl.map_ok = true;
+#define GMVAE_MV(f) (vk == 1 ? MV0::f : MV1::f)
+    add_map(E.b[0], H, H, 0, GMVAE_MV(b_e0), H, 2);
+    add_map(E.b[1], 2 * Lz, 2 * Lz, 0, GMVAE_MV(b_g1), 2 * Lz, 2);
+    add_map(Dn.b[0], H, H, 0, GMVAE_MV(b_d0), H, 2);
+    add_map(E.w[1], (long long)H * 2 * Lz, 2 * Lz, 2, GMVAE_MV(Wg1f), GMVAE_MV(L2P), 2);
+    add_map(E.w[1], (long long)H * 2 * Lz, 2 * Lz, 3, GMVAE_MV(Wg1b), 64, 3);
+    add_map(Dn.w[0], (long long)Lz * H, H, 2, GMVAE_MV(Wd0f), 64, 2);
+    add_map(Dn.w[0], (long long)Lz * H, H, 3, GMVAE_MV(Wd0b), GMVAE_MV(LP), 3);
+    add_map(Dn.w[1], (long long)H * D, D, 7, GMVAE_MV(dF), GMVAE_MV(DC), 4, GMVAE_MV(dFq));
+    add_map(Dn.w[1], (long long)H * D, D, 8, GMVAE_MV(dB), 64, 4, GMVAE_MV(dBq));
+    add_map(Dn.b[1], D, D, 9, GMVAE_MV(dbias), 0, 4, GMVAE_MV(dbq));
+    if (gmp) {
+      add_map(L.loc, (long long)K * Lz, Lz, 0, MV1::M_loc, MV1::ldM, 2);
+      add_map(L.rawscale, (long long)K * Lz, Lz, 0, MV1::M_raw, MV1::ldM, 2);
+      add_map(L.mixlog, K, K, 0, MV1::M_mix, K, 2);
+    }
+#undef GMVAE_MV
+  }
   pl.lo = 1 << 30; pl.hi = 0;
   for (int i = 0; i < pl.nmap; ++i) {
     pl.lo = pl.map[i].begin < pl.lo ? pl.map[i].begin : pl.lo;
@@ -867,8 +912,9 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
   }
-  const int Qm = mega_q(d);
-  bool fl = ml.fl_ok && Qm == 4 && (B + kPanel - 1) / kPanel * 4 <= n_cu &&
+  const int vk = (mega2v_ok(d, model) && w.img2f) ? mega2v_kind(d, model) : 0;
+  const int Qm = vk ? 7 : mega_q(d);
+  bool fl = ml.fl_ok && (Qm == 4 || vk) && (B + kPanel - 1) / kPanel * Qm <= n_cu &&
             (a.adam_p == a.params || a.dp_images) && a.step_dev && gen_eps && w.xfl && !getenv("GMVAE_NO_FL") && !sched_safe(d);
   if (fl && !a.imgs_ready) {
     // first step of a train graph / an eager step: the weight images straight from the parameters (kernels.hpp img_build),
@@ -952,7 +998,8 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       mattr = true;
     }
     const bool m2 = fl && mega2_ok(d, model) && w.img2f;
-    m2_ran = m2;
+    const bool m2v = fl && vk != 0;
+    m2_ran = m2 || m2v;
     if (m2) {
       c.img2f = w.img2f; c.img2b = w.img2b; c.dimg2 = w.dimg2;
       c.lr = a.lr; c.b1 = a.beta1; c.b2 = a.beta2;
@@ -964,6 +1011,19 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       }
       // (an even number of panels: the first layer works on pairs of them, mega2.hpp)
       hipLaunchKernelGGL(mega2_fwd_bwd, dim3((((B + kPanel - 1) / kPanel + 1) & ~1) * 4), dim3(kMT), (size_t)M2::total * sizeof(float), st, c);
+    } else if (m2v) {
+      c.img2f = w.img2f; c.img2b = w.img2b; c.dimg2 = w.dimg2;
+      c.lr = a.lr; c.b1 = a.beta1; c.b2 = a.beta2;
+      c.lr_t_out = (a.adam_p && a.adam_p == a.params && a.step_dev) ? reinterpret_cast<float*>(w.sync + 2) : nullptr;
+      static bool m2vattr = false;
+      if (!m2vattr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(mega2v_fwd_bwd<0, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(mega2v_fwd_bwd<1, 64, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        m2vattr = true;
+      }
+      const unsigned grid = (unsigned)((B + kPanel - 1) / kPanel * 7);
+      if (vk == 1) hipLaunchKernelGGL((mega2v_fwd_bwd<0, 2, 1>), dim3(grid), dim3(kMT), (size_t)MV0::total * sizeof(float), st, c);
+      else hipLaunchKernelGGL((mega2v_fwd_bwd<1, 64, 10>), dim3(grid), dim3(kMT), (size_t)MV1::total * sizeof(float), st, c);
     } else {
       hipLaunchKernelGGL(fn, dim3((B + kPanel - 1) / kPanel * c.Q), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
     }
@@ -973,6 +1033,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     if (fl) macs += (double)D * H2;        // the first layer rides in the launch
     if (gm) macs += (double)H * K + (double)K * H + (double)K * 2 * Lz + (double)(H + 2 * Lz) * K + (double)K * H;
     if (m2) { cx.mark("mega2_fwd_bwd", 2.0 * B * macs); goto mega_done; }
+    if (m2v) { cx.mark("mega2v_fwd_bwd", 2.0 * B * macs); goto mega_done; }
     cx.mark("mega_fwd_bwd", 2.0 * B * macs);
   mega_done:;
   }
@@ -1009,7 +1070,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
           if (b_off >= 0 && mp.begin == (int)b_off && mp.end == (int)(b_off + N)) { T.bk = mp.kind; T.bbase = mp.base; T.bchunk = mp.chunk; T.bwhich = mp.which; }
         }
         // the row-interleaved image (kinds 2 / 4) first: it leaves as one 16-byte store per thread
-        if (T.k2 == 2 || T.k2 == 4) {
+        if (T.k2 == 2 || T.k2 == 4 || T.k2 == 7) {
           const int k = T.k1, b_ = T.base1, l_ = T.ld1, c_ = T.chunk1, w_ = T.which1;
           T.k1 = T.k2; T.base1 = T.base2; T.ld1 = T.ld2; T.chunk1 = T.chunk2; T.which1 = T.which2;
           T.k2 = k; T.base2 = b_; T.ld2 = l_; T.chunk2 = c_; T.which2 = w_;
@@ -2271,7 +2332,7 @@ int gmvae_step_schedule(const GmvaeDims* dims, int model, char* out48) {
   Layout L;
   build_layout(d, model, L);
   const char* nm = "general";
-  if (mega_ok(d, model)) nm = mega2_ok(d, model) ? "mega2" : "mega";
+  if (mega_ok(d, model)) nm = mega2_ok(d, model) ? "mega2" : (mega2v_ok(d, model) ? "mega2v" : "mega");
   else if (skinny_ok(d, model)) nm = "skinny";
   else if (fused_ok(d, model)) nm = "fused";
   const bool gen = !strcmp(nm, "general");

@@ -677,6 +677,8 @@ __global__ void adam_tf(float* __restrict__ p, float* __restrict__ m, float* __r
 //   kinds 4 / 5 / 6: the decoder output layer [H][D] (4: forward, 5: data gradient, 6: its bias), 16-column tiles
 //   dealt to the panel's 4 workgroups by m2_dec_part: tile t = c >> 4 belongs to workgroup q as its local tile lt;
 //   lc = 16 lt + (c & 15) is the column inside that workgroup's part (`chunk` floats per part).
+//   kinds 7 / 8 / 9: the same three images for mega2v_fwd_bwd's SEVEN workgroups per panel (mega2v.hpp): tile t belongs to
+//   workgroup t % 7 as its local tile t / 7.
 // Which workgroup of a panel owns decoder column tile t, and as which local tile (D = 784: 49 tiles).  The three producer
 // quarters (1..3) take 14 / 14 / 13 tiles round-robin, the lead quarter (0) the last 8: ONE tile per wave.  The lead is
 // the launch's critical path (it also stores the panel's activations and runs the backward chain), and its hand-off poll
@@ -697,10 +699,11 @@ __host__ __device__ inline int img_dst(const int kind, const int base, const int
     case 3: return base + (((c >> 2) * ld + r) << 2) + (c & 3);
     default: {
       int q, lt;
-      m2_dec_part(c >> 4, q, lt);
+      if (kind >= 7) { q = (c >> 4) % 7; lt = (c >> 4) / 7; }
+      else m2_dec_part(c >> 4, q, lt);
       const int lc = (lt << 4) | (c & 15);
-      if (kind == 4) return base + q * chunk + (((r >> 2) * ld + lc) << 2) + (r & 3);    // [H/4][ld = DC][4]
-      if (kind == 5) return base + q * chunk + (((lc >> 2) * ld + r) << 2) + (lc & 3);   // [DC/4][ld = H][4]
+      if (kind == 4 || kind == 7) return base + q * chunk + (((r >> 2) * ld + lc) << 2) + (r & 3);    // [H/4][ld = DC][4]
+      if (kind == 5 || kind == 8) return base + q * chunk + (((lc >> 2) * ld + r) << 2) + (lc & 3);   // [DC/4][ld = H][4]
       return base + q * chunk + lc;                                                       // bias [DC]
     }
   }

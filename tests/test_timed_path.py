@@ -58,14 +58,15 @@ def _device_masks(e, model, d, B):
     return out
 
 
-def _oracle_trajectory(L, model, d, flat0, xs, seed, step0=0, row_base=0, masks_of_step=None, tag=""):
+def _oracle_trajectory(L, model, d, flat0, xs, seed, step0=0, row_base=0, masks_of_step=None, params_of_step=None, tag=""):
     """n oracle steps (fp64) on the noise of device steps step0 .. step0+n-1; returns (flat, C_last, g_last, [g_t]).
 
-    masks_of_step(t) -> the device's ReLU masks of step t (see _device_masks).  ReLU has no derivative at 0 and an fp32
-    pre-activation that is zero to within rounding can land on the other side than the fp64 one: there -- and ONLY
-    there: every unit where the device's mask differs from the oracle's own must have |pre| <= PRE_TOL * sum |a||w| in
-    fp64 -- the oracle takes the device's subgradient, so that every parameter seed runs inside the same gates instead of a
-    seed being picked that happens to have no such unit."""
+    masks_of_step(t) -> the device's ReLU masks of step t (see _device_masks); params_of_step(t) -> the device's parameters
+    BEFORE step t.  ReLU has no derivative at 0 and an fp32 pre-activation that is zero to within rounding can land on the
+    other side than the fp64 one: there -- and ONLY there: every unit where the device's mask differs from the fp64 mask AT
+    THE DEVICE'S OWN PARAMETERS must have |pre| <= PRE_TOL * sum |a||w| in fp64 (a kernel statement: the same parameters, the
+    same noise, only rounding apart) -- the oracle trajectory takes the device's subgradients, so that every parameter seed
+    runs inside the same gates instead of a seed being picked that happens to have no such unit."""
     flat = flat0.astype(np.float64)
     m, v = np.zeros_like(flat), np.zeros_like(flat)
     gs = []
@@ -75,7 +76,8 @@ def _oracle_trajectory(L, model, d, flat0, xs, seed, step0=0, row_base=0, masks_
         masks = None
         if masks_of_step is not None:
             masks = masks_of_step(t)
-            Cc = O.forward(model, d, O.unpack(model, d, flat), xs[t], eps, u, np.float64)
+            at = flat if params_of_step is None else params_of_step(t)
+            Cc = O.forward(model, d, O.unpack(model, d, at), xs[t], eps, u, np.float64)
             for net, ms in masks.items():
                 for i in range(1, len(ms)):
                     pre, mag = Cc["pre"][net][i - 1]
@@ -125,8 +127,8 @@ def _compare_last_step(model, d, eng, B, Cc, g, at_device=None, tag=""):
 
 GRAD_STATS = []        # (case, tensor, last-step gradient error at the device's parameters / the tensor's largest entry)
 import os
-GRAD_ERR = 1e-6        # assumed device gradient error in units of the tensor's largest gradient (measured: <= 1.2e-6, GRAD_STATS;
-                       # with 3e-7 assumed the worst parameter still sits at 0.15 of its tolerance)
+GRAD_ERR = 4e-6        # assumed device gradient error in units of the tensor's largest gradient: the worst one MEASURED at the
+                       # device's own parameters over all cases (3.7e-6, GRAD_STATS; gate 1e-4)
 PARAM_STATS = []       # (case, n, share of elements whose tolerance is below lr / 10, worst diff / tolerance)
 
 
@@ -135,10 +137,10 @@ def _compare_params(model, d, eng, flat_ref, gs, n, tag=""):
     Adam itself.  A step moves an element by alpha * m / (sqrt(v) + eps) = O(lr) * sign-like ratio: a gradient error delta
     changes that by about lr * c * |delta| / |g| (c of order 1-3: d/dg of m / sqrt(v)), saturating at ~2.5 lr when |g| is
     itself rounding noise -- in ANY fp32 implementation, the reference's included.  With the device's gradient error taken
-    as 1e-6 of the tensor's largest gradient (100x below the 1e-4 gate of _compare_last_step: its measured size, GRAD_STATS):
-        tol_i = 3e-5 + lr * sum_t min(2.5, 3 * 1e-6 * max|g_t| / |g_t,i|)
+    as 4e-6 of the tensor's largest gradient (25x below the 1e-4 gate of _compare_last_step: its measured size, GRAD_STATS):
+        tol_i = 3e-5 + lr * sum_t min(2.5, 3 * 4e-6 * max|g_t| / |g_t,i|)
     i.e. 3e-5 (3 % of one step) for an element whose gradient is within 1e-3 of its tensor's largest, ~ lr only for those
-    below 3e-6 of it.  The share of elements that are constrained to better than a tenth of one step is asserted too, so
+    below 1e-5 of it.  The share of elements that are constrained to better than a tenth of one step is asserted too, so
     that the graded bound cannot silently become 'anything goes'."""
     got = eng.params.detach().cpu().numpy().astype(np.float64)
     diff = np.abs(got - flat_ref)
@@ -207,17 +209,18 @@ def trajectory_case(model, D, Lz, K, hidden, B, n, seed=11, engine_kw=None):
     assert e.handoff_timeouts() == 0 and e.global_step == n and int(e.step_dev[0].item()) == n
     e1 = Engine(model, D, Lz, K, list(hidden), random_seed=seed, **kw)
     sx1, replay1 = e1.capture_train_step(B, lr=LR, n_steps=1)
-    masks, pre_last = [], None
+    masks, pre = [], []
     for t in range(n):
-        if t == n - 1:
-            pre_last = e1.params.detach().cpu().numpy().astype(np.float64)     # the device's parameters before the last step
+        pre.append(e1.params.detach().cpu().numpy().astype(np.float64))         # the device's parameters before step t
         sx1.copy_(xd[t])
         replay1()
         torch.cuda.synchronize()
         masks.append(_device_masks(e1, mid, d, B))
     assert torch.equal(e1.params, e.params), "n launches of a 1-step graph and one launch of an n-step graph must agree bit for bit"
     tag = f"{model}-L{Lz}-H{'x'.join(map(str, hidden))}-B{B}-seed{seed}"
-    flat_ref, Cc, g, gs = _oracle_trajectory(L, mid, d, flat0, xs, e.noise_seed, masks_of_step=lambda t: masks[t], tag=tag)
+    flat_ref, Cc, g, gs = _oracle_trajectory(L, mid, d, flat0, xs, e.noise_seed, masks_of_step=lambda t: masks[t],
+                                             params_of_step=lambda t: pre[t], tag=tag)
+    pre_last = pre[n - 1]
     eps, u = _noise(L, B * d.S, d.L, d.K, 0, e.noise_seed, n - 1, mid == O.MODEL_GMVAE)
     C2, g2 = O.loss_and_grads(mid, d, O.unpack(mid, d, pre_last), xs[n - 1], eps, u, np.float64, relu_masks=masks[n - 1])
     _compare_last_step(mid, d, e, B, Cc, g, at_device=(C2, O.pack(mid, d, g2, np.float64)), tag=tag)

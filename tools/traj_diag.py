@@ -19,13 +19,13 @@ for seed in map(int, sys.argv[8:]):
     e1 = Engine(model, D, Lz, K, [H], random_seed=seed)
     flat0 = e1.params.detach().cpu().numpy()
     sx1, replay1 = e1.capture_train_step(B, lr=T.LR, n_steps=1)
-    masks, pre = [], None
+    masks, pres = [], []
     for t in range(n):
-        if t == n - 1:
-            pre = e1.params.detach().cpu().numpy().astype(np.float64)
+        pres.append(e1.params.detach().cpu().numpy().astype(np.float64))
         sx1.copy_(xd[t]); replay1(); torch.cuda.synchronize()
         masks.append(T._device_masks(e1, mid, d, B))
-    flat_ref, Cc, g, gs = T._oracle_trajectory(L, mid, d, flat0, xs, e1.noise_seed, masks_of_step=lambda t: masks[t], tag=f"seed{seed}")
+    flat_ref, Cc, g, gs = T._oracle_trajectory(L, mid, d, flat0, xs, e1.noise_seed, masks_of_step=lambda t: masks[t], params_of_step=lambda t: pres[t], tag=f"seed{seed}")
+    pre = pres[n - 1]
     eps, u = T._noise(L, B, Lz, K, 0, e1.noise_seed, n - 1, mid == O.MODEL_GMVAE)
     C2, g2 = O.loss_and_grads(mid, d, O.unpack(mid, d, pre), xs[n - 1], eps, u, np.float64, relu_masks=masks[n - 1])
     g2 = O.pack(mid, d, g2, np.float64)
