@@ -118,11 +118,14 @@ def test_initializers_and_device_flags_are_checked_on_the_host(monkeypatch):
 def test_step_schedule_names(L, monkeypatch):
     """gmvae_step_schedule: which schedule a training step of given sizes takes (host-side; bench.py prices its roofline
     with it) -- the reference defaults, bin/run_train.sh's sizes, the config-5 shard, two hidden layers."""
-    for k in ("GMVAE_NO_MEGA", "GMVAE_NO_MEGA2", "GMVAE_NO_SKINNY", "GMVAE_NO_FUSED", "GMVAE_NO_PLANES", "GMVAE_PLANES_MINROWS"):
+    for k in ("GMVAE_NO_MEGA", "GMVAE_NO_MEGA2", "GMVAE_NO_SKINNY", "GMVAE_NO_FUSED", "GMVAE_NO_PLANES", "GMVAE_PLANES_MINROWS", "GMVAE_MEGA_Q"):
         monkeypatch.delenv(k, raising=False)
     G = L.MODEL_IDS["gmvae"]
     assert L.step_schedule(L.make_dims(1024, 784, 64, 10, [64]), G) == "mega2"
-    assert L.step_schedule(L.make_dims(256, 784, 64, 10, [64]), L.MODEL_IDS["vae_gmp"]) == "mega"
+    assert L.step_schedule(L.make_dims(256, 784, 64, 10, [64]), L.MODEL_IDS["vae_gmp"]) == "mega2v"      # BASELINE configs[1]
+    assert L.step_schedule(L.make_dims(100, 784, 2, 1, [64]), L.MODEL_IDS["vae"]) == "mega2v"           # BASELINE configs[0]
+    assert L.step_schedule(L.make_dims(1024, 784, 64, 10, [64]), L.MODEL_IDS["vae_gmp"]) == "mega"      # (7 workgroups per panel no longer fit)
+    assert L.step_schedule(L.make_dims(256, 784, 64, 10, [64], sched_flags=L.SCHED_SAFE), L.MODEL_IDS["vae_gmp"]) == "mega"
     assert L.step_schedule(L.make_dims(64, 784, 128, 10, [512]), G) == "skinny"
     assert L.step_schedule(L.make_dims(512, 3072, 64, 64, [512], S=50), G) == "general+planes"
     assert L.step_schedule(L.make_dims(40, 784, 16, 10, [64, 64]), G) == "general"
@@ -135,7 +138,8 @@ def test_workspace_layout_does_not_depend_on_schedule_switches(L, monkeypatch):
     GMVAE_NO_* schedule switches must fit -- and lay out identically -- under any other (a workspace sized with
     GMVAE_NO_SKINNY=1 and used without it ran past its end)."""
     cases = [("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,)), 64), ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,)), 1024),
-             ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(512,)), 256), ("vae", O.Dims(D=784, L=2, K=1, hidden=(64,)), 100)]
+             ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(512,)), 256), ("vae", O.Dims(D=784, L=2, K=1, hidden=(64,)), 100),
+             ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(64,)), 256)]
     names = [b"hy1", b"hd1", b"g", b"dz", b"dqp", b"slabs", b"z"]
 
     def probe(cd, mid):
