@@ -63,7 +63,10 @@ struct DwArgs {
 // B = 1024) are in flight before the first MFMA, and they are BRANCH-FREE (clamped address, value selected
 // afterwards): a load under `if (in range)` makes the compiler wait inside the branch, one memory round trip per load
 // (measured: 13 us for this loop).  The uint8 operand stays packed (one register per k-step) until its MFMAs.
-template <bool U8, int MU, class Mid>
+// KB: k-steps (of 4 batch rows) requested per batch of loads: 32 (a wave's 128 rows at B = 1024), or 8 for SMALL batches --
+// at B <= 256 a wave's share is <= 32 rows, and 32 clamped k-steps per lane were 56 wasted loads of 64 in front of the few
+// matrix instructions that count (BASELINE configs[0] / configs[1]: B = 100 / 256).
+template <bool U8, int MU, int KB = 32, class Mid>
 __device__ __forceinline__ void dw_contract(const void* __restrict__ Ap, const float* __restrict__ dY, const int lda, const int ldy,
                                             const int M, const int N, const int m0, const int n0, const int b_lo, const int b_hi,
                                             const int ln, const int lk, f32x4 (&acc)[4], float& cs, Mid mid) {
@@ -73,7 +76,6 @@ __device__ __forceinline__ void dw_contract(const void* __restrict__ Ap, const f
   const int mac = min(ma, ((M + 3) & ~3) - MU), nc = min(n0 + ln, N - 1);
   const unsigned char* const A8 = static_cast<const unsigned char*>(Ap);
   const float* const A32 = static_cast<const float*>(Ap);
-  constexpr int KB = 32;
   typedef typename std::conditional<MU == 4, typename std::conditional<U8, unsigned, float4>::type,
                                     typename std::conditional<MU == 2, typename std::conditional<U8, unsigned short, float2>::type,
                                                               typename std::conditional<U8, unsigned char, float>::type>::type>::type AT;
@@ -292,6 +294,11 @@ __global__ __launch_bounds__(kDwThreads) void dw_adam(const DwArgs a) {
   float cs = 0.f;
   if (T.a_u8 && b_hi - b_lo == 128 && a.u8x3)
     dw_contract_u8x3(static_cast<const unsigned char*>(T.A), T.dY, lda, ldy, M, N, m0, n0, b_lo, ln, lk, acc, cs);
+  else if (rows_w <= 32) {                       // small batch: 8 k-steps per batch of loads
+    if (T.a_u8) dw_contract<true, 4, 8>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+    else if (MUr == 2) dw_contract<false, 2, 8>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+    else dw_contract<false, 1, 8>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+  }
   else if (T.a_u8) dw_contract<true, 4>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
   else if (MUr == 2) dw_contract<false, 2>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
   else dw_contract<false, 1>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
