@@ -35,6 +35,7 @@ constexpr int NS_MAX = 16;
 constexpr int MAX_LEVELS = 96;
 constexpr int GMP_PARTS = 64;
 constexpr int kMegaQMax = 4;
+constexpr int kSkDwShares = 2;   // batch shares of the skinny schedule's two-launch W stage (sk_dwc: partial gradients in w.slabs)
 constexpr int kSkNs1 = 4;        // slabs of the skinny schedule's first layer (contraction split); <= skinny.hpp kSkNs1x
 
 // Workgroups that share one 16-row panel of mega_fwd_bwd (they split its decoder chunks): as many as keep the
@@ -369,6 +370,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     if (num_splits_small(R) > ns) ns = num_splits_small(R);       // (the extra slabs are only touched in the small tensors' ranges)
     if ((fused_shape(d, model) || mega_shape(d, model)) && dw_splits(d.B) > ns) ns = dw_splits(d.B);
     if (mega_shape(d, model) && 2 * dw_splits(d.B) <= NS_MAX && 2 * dw_splits(d.B) > ns) ns = 2 * dw_splits(d.B);
+    if (skinny_shape(d, model) && ns < kSkDwShares) ns = kSkDwShares;       // (sk_dwc's partial gradients)
     w.slabs = take((uint64_t)ns * L.P_pad);
   }
   w.cl_pred = reinterpret_cast<int32_t*>(take(B));
@@ -1373,7 +1375,17 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
     s.gmp_len = 2 * (int)pad4((uint64_t)K * Lz) + (int)pad4(K); s.gmp_off = (long long)L.loc;
   }
   s.B = B; s.D = D; s.H = H; s.L = Lz; s.K = K; s.K4 = (int)pad4(K);
-  s.ns1 = vae ? 1 : kSkNs1; s.nparts = D / 16;
+  // first-layer slabs: the contraction over D splits only while the unsplit launch would leave compute units idle (B = 64, H = 512:
+  // 64 workgroups -> 256 with 4 slabs); at B = 1024 the 1024 unsplit workgroups already fill the chip and each slab is a second
+  // pass over the staging and the slab sum
+  {
+    const int wgs1 = (2 * H / 64) * ((B + 15) / 16), ns1 = 256 / (wgs1 > 0 ? wgs1 : 1);
+    s.ns1 = vae ? 1 : (ns1 < 1 ? 1 : (ns1 > kSkNs1 ? kSkNs1 : ns1));
+  }
+  // the two D-wide layers (F5, B1) in 64-column tiles once 16-row x 64-column tiles alone give the chip its workgroups
+  const bool wide = ((D + 63) / 64) * ((B + 15) / 16) >= 256;
+  s.nparts = wide ? (D + 63) / 64 : D / 16;
+
   s.c = d.raw_sigma_bias; s.smin = d.sigma_min; s.invT = 1.f / d.temperature; s.gen_bias = d.gen_bias_init;
   s.gen_bias_vec = d.gen_bias_vec;
   s.x = a.x; s.P = a.params;
@@ -1391,14 +1403,29 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   s.ln_b1 = (float)log((double)a.beta1); s.ln_b2 = (float)log((double)a.beta2);
   s.tail = a.grads + L.P_pad; s.tail_log = a.tail_log;
   s.logpx = w.logpx; s.logq = w.logq; s.logp = w.logp; s.logw = w.logw;
+  // the W stage's form: up to 128 batch rows sk_dw (one-wave tiles); above, [64 x 64] tiles: one workgroup each (sk_dwb), or
+  // -- from 512 rows, with more tiles than CUs -- two batch shares each and the optimizer in a launch of its own (sk_dwc + sk_adam)
+  const bool dw_big = B > 128;
   auto add = [&](const void* A, bool u8, int lda, const float* dY, int ldy, int M, int N, uint64_t w_off, long long b_off) {
     SkTensor& T = s.t[s.ntens++];
     T.A = A; T.a_u8 = u8 ? 1 : 0; T.lda = lda; T.dY = dY; T.ldy = ldy; T.M = M; T.N = N; T.w_off = (int)w_off; T.b_off = (int)b_off;
     T.vec = (N % 4 == 0 && ldy % 4 == 0) ? 1 : 0;            // 16-byte optimizer accesses ([16 x 64] tiles) where rows allow
-    T.tiles_n = T.vec ? (N + 63) / 64 : (N + 15) / 16; T.tile_begin = s.total_tiles;
-    s.total_tiles += (T.vec ? (M + 15) / 16 : (M + 63) / 64) * T.tiles_n;
+    T.tile_begin = s.total_tiles;
+    if (dw_big) {                                            // sk_dwb / sk_dwc: [64 x 64] tiles
+      T.tiles_n = (N + 63) / 64;
+      s.total_tiles += ((M + 63) / 64) * T.tiles_n;
+    } else {
+      T.tiles_n = T.vec ? (N + 63) / 64 : (N + 15) / 16;
+      s.total_tiles += (T.vec ? (M + 15) / 16 : (M + 63) / 64) * T.tiles_n;
+    }
   };
   const int nrt = (B + 15) / 16;
+  // row tiles per workgroup of a matrix-product launch with nct column tiles: as many (4, 2, 1) as still leave 256 workgroups
+  auto rt_of = [&](int nct) {
+    int rt = 4;
+    while (rt > 1 && nct * ((nrt + rt - 1) / rt) < 256) rt >>= 1;
+    return rt;
+  };
   const double fB = 2.0 * B;
   s.dbg = g_sk_dbg;                                // diagnostic: tools/skstamps.py (null unless gmvae_debug_sk_stamps(NULL) ran)
   auto launch = [&](auto kern, int grid, int threads, size_t sh, const char* name, double fl) {
@@ -1406,18 +1433,24 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
     cx.check();
     cx.mark(name, fl);
   };
+  auto gemm = [&](auto stage, int nct, int slabs, int extra, const char* name, double fl) {
+    constexpr int ST = decltype(stage)::value;
+    const int rt = rt_of(nct * slabs), grid = nct * ((nrt + rt - 1) / rt) * slabs + extra;
+    launch(rt == 4 ? sk_gemm<ST, 4> : rt == 2 ? sk_gemm<ST, 2> : sk_gemm<ST, 1>, grid, kSkThreads, 0, name, fl);
+  };
   if (vae) {
     const int eps_blocks = gen_eps ? (int)(((long long)B * ((Lz + 3) / 4) + kSkThreads - 1) / kSkThreads) : 0;
-    launch(sk_gemm<SK_F1>, (H / 64) * nrt + eps_blocks, kSkThreads, 0, "sk_first_layer", fB * D * H);
+    gemm(std::integral_constant<int, SK_F1>{}, H / 64, 1, eps_blocks, "sk_first_layer", fB * D * H);
   } else {
-  launch(sk_gemm<SK_F1>, (2 * H / 64) * nrt * s.ns1, kSkThreads, 0, "sk_first_layers", fB * D * 2 * H);
+  gemm(std::integral_constant<int, SK_F1>{}, 2 * H / 64, s.ns1, 0, "sk_first_layers", fB * D * 2 * H);
   const int eps_blocks = gen_eps ? (int)(((long long)B * ((Lz + 3) / 4) + 255) / 256) : 0;       // extra workgroups: the eps rows
   launch(H <= 512 ? sk_ypath<2> : sk_ypath<4>, B + eps_blocks, 256, 0, "sk_y_path", fB * ((double)H * K + K * H + K * 2.0 * Lz));
   }
-  launch(sk_gemm<SK_F3>, ((Lz + 15) / 16) * nrt, kSkThreads, 0, "sk_q_head_z", fB * H * 2 * Lz);
+  gemm(std::integral_constant<int, SK_F3>{}, (Lz + 15) / 16, 1, 0, "sk_q_head_z", fB * H * 2 * Lz);
   if (gmp) launch_mixture_logprob(cx, w, a.params, L, B, Lz, K);
-  launch(sk_gemm<SK_F4>, (H / 64) * nrt, kSkThreads, 0, "sk_dec_hidden", fB * Lz * H);
-  launch(sk_gemm<SK_F5>, (D / 16) * nrt, kSkThreads, 0, "sk_dec_bernoulli", fB * H * D);
+  gemm(std::integral_constant<int, SK_F4>{}, H / 64, 1, 0, "sk_dec_hidden", fB * Lz * H);
+  if (wide) gemm(std::integral_constant<int, SK_F5W>{}, (D + 63) / 64, 1, 0, "sk_dec_bernoulli", fB * H * D);
+  else gemm(std::integral_constant<int, SK_F5>{}, D / 16, 1, 0, "sk_dec_bernoulli", fB * H * D);
   // (Measured and removed in round 4: the W launch in three parts on a forked graph branch beside B3 / B4 -- a fork / join
   //  pair inside a hipGraph cost far more than it hid on this stack: 94.3 vs 60.8 us per step, profiles/round3_notes.md.)
   auto launch_dw = [&]() {
@@ -1437,12 +1470,32 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
     double fw = 0;
     for (int i = 0; i < s.ntens; ++i) fw += 2.0 * s.t[i].M * s.t[i].N * B;
     const int gmp_wgs = s.gmp_part ? (s.gmp_len + kSkThreads - 1) / kSkThreads : 0;      // (sk_dw derives the same count)
-    hipLaunchKernelGGL(sk_dw, dim3((s.total_tiles + kSkWaves - 1) / kSkWaves + 1 + gmp_wgs), dim3(kSkThreads), 0, st, s);
+    if (dw_big && B >= 512 && s.total_tiles > 256) {
+      s.dwp = w.slabs; s.dwp_stride = (long long)L.P_pad; s.dw_ks = kSkDwShares;
+      s.nseg = 0;
+      int wgs = 0;
+      for (int i = 0; i < s.ntens; ++i)
+        for (int h = 0; h < 2; ++h) {
+          if (h == 1 && s.t[i].b_off < 0) continue;
+          s.seg_off[s.nseg] = h ? (long long)s.t[i].b_off : (long long)s.t[i].w_off;
+          s.seg_len[s.nseg] = h ? s.t[i].N : s.t[i].M * s.t[i].N;
+          s.seg_wg[s.nseg] = wgs;
+          wgs += (s.seg_len[s.nseg] + 1023) / 1024;
+          ++s.nseg;
+        }
+      s.seg_wg[s.nseg] = wgs;
+      const int gmp256 = s.gmp_part ? (s.gmp_len + kDwcThreads - 1) / kDwcThreads : 0;
+      hipLaunchKernelGGL(sk_dwc, dim3(8 * ((s.total_tiles * s.dw_ks + 7) / 8) + 1 + gmp256), dim3(kDwcThreads), 0, st, s);
+      cx.check();
+      hipLaunchKernelGGL(sk_adam, dim3(wgs), dim3(256), 0, st, s);
+    } else if (dw_big) hipLaunchKernelGGL(sk_dwb, dim3(8 * ((s.total_tiles + 7) / 8) + 1 + gmp_wgs), dim3(kSkThreads), 0, st, s);
+    else hipLaunchKernelGGL(sk_dw, dim3((s.total_tiles + kSkWaves - 1) / kSkWaves + 1 + gmp_wgs), dim3(kSkThreads), 0, st, s);
     cx.check();
     cx.mark(s.ap ? "sk_dw_adam" : "sk_dw", fw);
   };
-  launch(sk_gemm<SK_B1>, (H / 16) * nrt, kSkThreads, 0, "sk_bwd_dhd", fB * D * H);
-  launch(sk_gemm<SK_B2>, ((Lz + 15) / 16) * nrt, kSkThreads, 0, "sk_bwd_dz_heads", fB * H * Lz);
+  if (wide) gemm(std::integral_constant<int, SK_B1W>{}, H / 64, 1, 0, "sk_bwd_dhd", fB * D * H);
+  else gemm(std::integral_constant<int, SK_B1>{}, H / 16, 1, 0, "sk_bwd_dhd", fB * D * H);
+  gemm(std::integral_constant<int, SK_B2>{}, (Lz + 15) / 16, 1, 0, "sk_bwd_dz_heads", fB * H * Lz);
   if (gmp) {                                     // the mixture prior's share of dz and the q head's reverse; its variables' gradients
     hipLaunchKernelGGL(z_head_bwd, dim3(grid_for(B, 4)), dim3(256), 0, st, w.dz, w.qp, 1, (const float*)nullptr, eps, w.z, (const float*)nullptr,
                        w.resp, a.params + L.loc, a.params + L.rawscale, w.dqp, (float*)nullptr, B, Lz, K, (int)PRIOR_GMP, d.raw_sigma_bias, d.sigma_min);
@@ -1451,7 +1504,7 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
                        a.params + L.rawscale, a.params + L.mixlog, w.gmp_part, B, Lz, K, (int)pad4((uint64_t)K * Lz));
     rowk(cx, "gmp_param_bwd");
   }
-  launch(sk_gemm<SK_B3>, (H / 32) * nrt, kSkThreads, 0, "sk_bwd_dhg", fB * 2 * Lz * H);
+  gemm(std::integral_constant<int, SK_B3>{}, H / 32, 1, 0, "sk_bwd_dhg", fB * 2 * Lz * H);
   if (!vae) launch(H <= 512 ? sk_ybwd<2> : sk_ybwd<4>, B, 256, 0, "sk_y_path_bwd", fB * ((double)(H + 2 * Lz) * K + K * H));
   launch_dw();
   return cx.err;
@@ -2305,13 +2358,13 @@ int gmvae_train_graph_destroy(void* graph) {
 int gmvae_debug_sk_stamps(unsigned long long* host_out) {
   if (!host_out) {                                 // arm: allocate the buffer (outside any stream capture); later captures stamp into it
     if (!g_sk_dbg) {
-      if (hipMalloc(&g_sk_dbg, (size_t)10 * 256 * 8 * 8) != hipSuccess) return GMVAE_E_NULL;
-      hipMemset(g_sk_dbg, 0, (size_t)10 * 256 * 8 * 8);
+      if (hipMalloc(&g_sk_dbg, (size_t)10 * kSkDbgWgs * 8 * 8) != hipSuccess) return GMVAE_E_NULL;
+      hipMemset(g_sk_dbg, 0, (size_t)10 * kSkDbgWgs * 8 * 8);
     }
     return 0;
   }
   if (!g_sk_dbg) return GMVAE_E_NULL;
-  return (int)hipMemcpy(host_out, g_sk_dbg, (size_t)10 * 256 * 8 * 8, hipMemcpyDeviceToHost);
+  return (int)hipMemcpy(host_out, g_sk_dbg, (size_t)10 * kSkDbgWgs * 8 * 8, hipMemcpyDeviceToHost);
 }
 
 /* disarm: later steps and captures no longer stamp; frees the buffer.  The caller must first destroy every train graph

@@ -57,6 +57,12 @@ struct SkArgs {
   unsigned long long* step_dev;
   // W launch
   int ntens, total_tiles;
+  float* dwp;                  // W in two launches (sk_dwc + sk_adam): dw_ks partial gradients in the flat layout, dwp_stride floats apart
+  long long dwp_stride;
+  int dw_ks;
+  int nseg;                    // ... and the flat layout's segments the optimizer launch walks: workgroup seg_wg[i] starts segment i
+  int seg_wg[2 * kSkMaxT + 1], seg_len[2 * kSkMaxT];
+  long long seg_off[2 * kSkMaxT];
   int has_tail;                // W launch: its last workgroup is the loss tail (the launch that ends the step)
   SkTensor t[kSkMaxT];
   float *grads, *ap, *am, *av; // ap != null: TF-Adam in the epilogue
@@ -71,75 +77,150 @@ struct SkArgs {
   const float* gmp_part;
   int gmp_n, gmp_len;
   long long gmp_off;
-  unsigned long long* dbg;     // diagnostic (GMVAE_SK_STAMPS): [10 launches][256 blocks][8] device wall-clock stamps (100 MHz)
+  unsigned long long* dbg;     // diagnostic (GMVAE_SK_STAMPS): [10 launches][kSkDbgWgs blocks][8] device wall-clock stamps (100 MHz)
 };
-#define SK_STAMP(slot, i) if (a.dbg && threadIdx.x == 0 && blockIdx.x < 256) a.dbg[((size_t)(slot) * 256 + blockIdx.x) * 8 + (i)] = wall_clock64()
+constexpr int kSkDbgWgs = 1024;   // workgroups per launch that leave stamps
+#define SK_STAMP(slot, i) if (a.dbg && threadIdx.x == 0 && blockIdx.x < kSkDbgWgs) a.dbg[((size_t)(slot) * kSkDbgWgs + blockIdx.x) * 8 + (i)] = wall_clock64()
 
-enum { SK_F1 = 0, SK_F3, SK_F4, SK_F5, SK_B1, SK_B2, SK_B3 };
+// (F5W, B1W: the two D-wide layers in 64-column tiles, for batches that fill the chip without the narrow tiles' extra workgroups)
+enum { SK_F1 = 0, SK_F3, SK_F4, SK_F5, SK_B1, SK_B2, SK_B3, SK_F5W, SK_B1W };
 
 // ---- contraction pieces: one wave's share (k-groups kg = kg_lo + wave, + 8, ... < kg_hi; a k-group = 16 contraction steps).
-// The wave's groups run in batches of 4, 2, 1 (compile-time sizes): every load of a batch is in flight before its first MFMA,
-// and no matrix instruction is spent on an absent group (a layer with K = 128 has ONE group per wave).
-template <class F>
+// The wave's groups run in batches of 4, 2, 1 (compile-time sizes; MAXG bounds them): every load of a batch is in flight
+// before its first MFMA, and no matrix instruction is spent on an absent group (a layer with K = 128 has ONE group per wave).
+// RT: row tiles of 16 batch rows that share the wave's W fragments (1 at <= 128 rows; 2 or 4 where the batch fills the chip
+// anyway: a W fragment loaded once then feeds RT x as many MFMAs -- at B = 1024 the one-tile form ran at the L2's rate).
+template <int MAXG, class F>
 __device__ __forceinline__ void sk_groups(const int kg_lo, const int kg_hi, const int wave, F&& body) {
   const int kg = kg_lo + wave;
   const int n = kg < kg_hi ? (kg_hi - kg + kSkWaves - 1) / kSkWaves : 0;
   int done = 0;
-  for (; n - done >= 4; done += 4) body(std::integral_constant<int, 4>{}, kg + kSkWaves * done);
-  if (n - done >= 2) { body(std::integral_constant<int, 2>{}, kg + kSkWaves * done); done += 2; }
+  if constexpr (MAXG >= 4) {
+    for (; n - done >= 4; done += 4) body(std::integral_constant<int, 4>{}, kg + kSkWaves * done);
+    if (n - done >= 2) { body(std::integral_constant<int, 2>{}, kg + kSkWaves * done); done += 2; }
+  } else if constexpr (MAXG >= 2) {
+    for (; n - done >= 2; done += 2) body(std::integral_constant<int, 2>{}, kg + kSkWaves * done);
+  } else {
+    for (; done < n; ++done) body(std::integral_constant<int, 1>{}, kg + kSkWaves * done);
+  }
   if (n - done >= 1) body(std::integral_constant<int, 1>{}, kg + kSkWaves * done);
 }
+template <int RT> constexpr int sk_maxg() { return RT == 1 ? 4 : RT == 2 ? 2 : 1; }
+// RT > 1: one group per stage, two register sets: the next group's loads are in flight under this group's RT x as many MFMAs
+template <class Frag, class LD, class MM>
+__device__ __forceinline__ void sk_pipe(const int kg_lo, const int kg_hi, const int wave, LD&& ld, MM&& mm) {
+  const int kg = kg_lo + wave;
+  const int n = kg < kg_hi ? (kg_hi - kg + kSkWaves - 1) / kSkWaves : 0;
+  if (n == 0) return;
+  Frag fa, fb;
+  ld(fa, kg);
+  int i = 0;
+  for (; i + 2 <= n; i += 2) {
+    ld(fb, kg + kSkWaves * (i + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fa);
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + 2 < n) ld(fa, kg + kSkWaves * (i + 2));
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fb);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (i < n) mm(fa);
+}
+template <int RT, int NB> struct SkFrag { float4 av[RT]; float4 bv[NB]; };
 // NN, 4 strided column tiles: out[row][n0 + 4 i + t] for lane column i: W k-major [K][ldw], one 16-byte load of W per k
 // MK: the contraction extent kmax is no multiple of 16 (a multiple of 4): quads at k >= kmax are loaded from the last valid quad
 // (clamped address, branch-free) and their A values replaced by 0
-template <bool U8, bool MK = false>
-__device__ __forceinline__ void sk_nn4(const void* __restrict__ Ap, const long long arow, const float* __restrict__ W, const int ldw,
+template <bool U8, int RT, bool MK = false>
+__device__ __forceinline__ void sk_nn4(const void* __restrict__ Ap, const long long (&arow)[RT], const float* __restrict__ W, const int ldw,
                                        const int ncol, const int kg_lo, const int kg_hi, const int wave, const int lk,
-                                       f32x4 (&acc)[4], const int kmax = 0) {
-  sk_groups(kg_lo, kg_hi, wave, [&](auto ng, const int kgb) {
+                                       f32x4 (&acc)[RT][4], const int kmax = 0) {
+  if constexpr (RT > 1) {
+    sk_pipe<SkFrag<RT, 4>>(kg_lo, kg_hi, wave,
+      [&](SkFrag<RT, 4>& f, const int kgi) {
+        const int k0 = 16 * kgi + 4 * lk;
+        const int k = MK ? min(k0, kmax - 4) : k0;
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+          if constexpr (U8) f.av[j].x = __uint_as_float(*reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(Ap) + arow[j] + k));
+          else f.av[j] = *reinterpret_cast<const float4*>(static_cast<const float*>(Ap) + arow[j] + k);
+          if (MK && k0 >= kmax) f.av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.bv[q] = *reinterpret_cast<const float4*>(W + (long long)(k + q) * ldw + ncol);
+      },
+      [&](const SkFrag<RT, 4>& f) {
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+          float aq[4];
+          if constexpr (U8) {
+            const unsigned w = __float_as_uint(f.av[j].x);
+            aq[0] = (float)(w & 0xffu); aq[1] = (float)((w >> 8) & 0xffu); aq[2] = (float)((w >> 16) & 0xffu); aq[3] = (float)(w >> 24);
+          } else {
+            aq[0] = f.av[j].x; aq[1] = f.av[j].y; aq[2] = f.av[j].z; aq[3] = f.av[j].w;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[q].x, acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[q].y, acc[j][1], 0, 0, 0);
+            acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[q].z, acc[j][2], 0, 0, 0);
+            acc[j][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[q].w, acc[j][3], 0, 0, 0);
+          }
+        }
+      });
+    return;
+  }
+  sk_groups<sk_maxg<RT>()>(kg_lo, kg_hi, wave, [&](auto ng, const int kgb) {
     constexpr int NG = decltype(ng)::value;
-    float4 av[NG], bv[NG][4];
+    float4 av[NG][RT], bv[NG][4];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int k0 = 16 * (kgb + g * kSkWaves) + 4 * lk;
       const int k = MK ? min(k0, kmax - 4) : k0;
-      if constexpr (U8) {
-        const unsigned w = *reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(Ap) + arow + k);
-        av[g] = make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
-      } else {
-        av[g] = *reinterpret_cast<const float4*>(static_cast<const float*>(Ap) + arow + k);
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        if constexpr (U8) {
+          const unsigned w = *reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(Ap) + arow[j] + k);
+          av[g][j] = make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
+        } else {
+          av[g][j] = *reinterpret_cast<const float4*>(static_cast<const float*>(Ap) + arow[j] + k);
+        }
+        if (MK && k0 >= kmax) av[g][j] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (MK && k0 >= kmax) av[g] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int q = 0; q < 4; ++q) bv[g][q] = *reinterpret_cast<const float4*>(W + (long long)(k + q) * ldw + ncol);
     }
     __builtin_amdgcn_sched_barrier(0);             // every load of the batch is issued before its first MFMA
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const float aq[4] = {av[g].x, av[g].y, av[g].z, av[g].w};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q].x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q].y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q].z, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q].w, acc[3], 0, 0, 0);
+      for (int j = 0; j < RT; ++j) {
+        const float aq[4] = {av[g][j].x, av[g][j].y, av[g][j].z, av[g][j].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q].x, acc[j][0], 0, 0, 0);
+          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q].y, acc[j][1], 0, 0, 0);
+          acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q].z, acc[j][2], 0, 0, 0);
+          acc[j][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q].w, acc[j][3], 0, 0, 0);
+        }
       }
     }
   });
 }
 // NN, NU plain column tiles at columns col[t] (4-byte loads of W: the q head's (mu, raw) column pairs)
-template <int NU>
-__device__ __forceinline__ void sk_nnp(const float* __restrict__ A, const long long arow, const float* __restrict__ W, const int ldw,
+template <int NU, int RT>
+__device__ __forceinline__ void sk_nnp(const float* __restrict__ A, const long long (&arow)[RT], const float* __restrict__ W, const int ldw,
                                        const int (&col)[NU], const int kg_lo, const int kg_hi, const int wave, const int lk,
-                                       f32x4 (&acc)[4]) {
-  sk_groups(kg_lo, kg_hi, wave, [&](auto ng, const int kgb) {
+                                       f32x4 (&acc)[RT][4]) {
+  sk_groups<sk_maxg<RT>()>(kg_lo, kg_hi, wave, [&](auto ng, const int kgb) {
     constexpr int NG = decltype(ng)::value;
-    float4 av[NG];
+    float4 av[NG][RT];
     float bv[NG][4][NU];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int k = 16 * (kgb + g * kSkWaves) + 4 * lk;
-      av[g] = *reinterpret_cast<const float4*>(A + arow + k);
+#pragma unroll
+      for (int j = 0; j < RT; ++j) av[g][j] = *reinterpret_cast<const float4*>(A + arow[j] + k);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -148,28 +229,60 @@ __device__ __forceinline__ void sk_nnp(const float* __restrict__ A, const long l
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const float aq[4] = {av[g].x, av[g].y, av[g].z, av[g].w};
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int j = 0; j < RT; ++j) {
+        const float aq[4] = {av[g][j].x, av[g][j].y, av[g][j].z, av[g][j].w};
 #pragma unroll
-        for (int t = 0; t < NU; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q][t], acc[t], 0, 0, 0);
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t = 0; t < NU; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], bv[g][q][t], acc[j][t], 0, 0, 0);
+      }
     }
   });
 }
 // NT (data gradients): out[row][j] = sum_c A[row][c] W[j][c], W rows contraction-contiguous: 16-byte loads of both
-template <int NU, bool MK = false>
-__device__ __forceinline__ void sk_nt(const float* __restrict__ A, const long long arow, const float* __restrict__ W, const int ldw,
+template <int NU, int RT, bool MK = false>
+__device__ __forceinline__ void sk_nt(const float* __restrict__ A, const long long (&arow)[RT], const float* __restrict__ W, const int ldw,
                                       const int (&wrow)[NU], const int kg_lo, const int kg_hi, const int wave, const int lk,
-                                      f32x4 (&acc)[4], const int kmax = 0) {
-  sk_groups(kg_lo, kg_hi, wave, [&](auto ng, const int kgb) {
+                                      f32x4 (&acc)[RT][4], const int kmax = 0) {
+  if constexpr (RT > 1) {
+    sk_pipe<SkFrag<RT, NU>>(kg_lo, kg_hi, wave,
+      [&](SkFrag<RT, NU>& f, const int kgi) {
+        const int k0 = 16 * kgi + 4 * lk;
+        const int k = MK ? min(k0, kmax - 4) : k0;
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+          f.av[j] = *reinterpret_cast<const float4*>(A + arow[j] + k);
+          if (MK && k0 >= kmax) f.av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < NU; ++t) f.bv[t] = *reinterpret_cast<const float4*>(W + (long long)wrow[t] * ldw + k);
+      },
+      [&](const SkFrag<RT, NU>& f) {
+#pragma unroll
+        for (int j = 0; j < RT; ++j)
+#pragma unroll
+          for (int t = 0; t < NU; ++t) {
+            acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.av[j].x, f.bv[t].x, acc[j][t], 0, 0, 0);
+            acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.av[j].y, f.bv[t].y, acc[j][t], 0, 0, 0);
+            acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.av[j].z, f.bv[t].z, acc[j][t], 0, 0, 0);
+            acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.av[j].w, f.bv[t].w, acc[j][t], 0, 0, 0);
+          }
+      });
+    return;
+  }
+  sk_groups<sk_maxg<RT>()>(kg_lo, kg_hi, wave, [&](auto ng, const int kgb) {
     constexpr int NG = decltype(ng)::value;
-    float4 av[NG], bv[NG][NU];
+    float4 av[NG][RT], bv[NG][NU];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int k0 = 16 * (kgb + g * kSkWaves) + 4 * lk;
       const int k = MK ? min(k0, kmax - 4) : k0;
-      av[g] = *reinterpret_cast<const float4*>(A + arow + k);
-      if (MK && k0 >= kmax) av[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        av[g][j] = *reinterpret_cast<const float4*>(A + arow[j] + k);
+        if (MK && k0 >= kmax) av[g][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
 #pragma unroll
       for (int t = 0; t < NU; ++t) bv[g][t] = *reinterpret_cast<const float4*>(W + (long long)wrow[t] * ldw + k);
     }
@@ -177,12 +290,14 @@ __device__ __forceinline__ void sk_nt(const float* __restrict__ A, const long lo
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
 #pragma unroll
-      for (int t = 0; t < NU; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].x, bv[g][t].x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].y, bv[g][t].y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].z, bv[g][t].z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g].w, bv[g][t].w, acc[t], 0, 0, 0);
-      }
+      for (int j = 0; j < RT; ++j)
+#pragma unroll
+        for (int t = 0; t < NU; ++t) {
+          acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][j].x, bv[g][t].x, acc[j][t], 0, 0, 0);
+          acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][j].y, bv[g][t].y, acc[j][t], 0, 0, 0);
+          acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][j].z, bv[g][t].z, acc[j][t], 0, 0, 0);
+          acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][j].w, bv[g][t].w, acc[j][t], 0, 0, 0);
+        }
     }
   });
 }
@@ -196,21 +311,24 @@ __device__ __forceinline__ float sk_row16_sum(float v) {
   return v;
 }
 
-// One matrix-product launch of the schedule.  Grid: column tiles x row tiles (x ns1 slabs for F1); a workgroup = one
-// 16-row output tile; tiles are NN4 (16 x 64, strided columns), pairs (F3) or plain 16-column tiles (NT forms).
-template <int ST>
+// One matrix-product launch of the schedule.  Grid: column tiles x groups of RT row tiles (x ns1 slabs for F1); a workgroup =
+// RT 16-row output tiles of one column tile; tiles are NN4 (16 x 64, strided columns), pairs (F3) or plain 16-column tiles
+// (NT forms).  The 8 waves split the contraction; their partial tiles meet in LDS two row tiles at a time (RT = 1: the one),
+// thread (jl, er, el) of the meeting owning accumulator register er of lane slot el of row tile 2 c + jl and its epilogue.
+template <int ST, int RT>
 __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[kSkWaves * 16 * 64];      // [wave][4 t + r][lane]
-  constexpr int SLOT = ST == SK_F1 ? 0 : ST == SK_F3 ? 2 : ST == SK_F4 ? 3 : ST == SK_F5 ? 4 : ST == SK_B1 ? 5 : ST == SK_B2 ? 6 : 7;
+  constexpr int NU = (ST == SK_F1 || ST == SK_F4 || ST == SK_F5W || ST == SK_B1W) ? 4 : (ST == SK_F3 || ST == SK_B3) ? 2 : 1;
+  constexpr int CJ = RT == 1 ? 1 : 2, NC = RT / CJ;                            // row tiles per meeting, meetings
+  __shared__ __attribute__((aligned(16))) float red[kSkWaves * CJ * NU * 4 * 64];      // [wave][jl][4 t + r][lane]
+  constexpr int SLOT = ST == SK_F1 ? 0 : ST == SK_F3 ? 2 : ST == SK_F4 ? 3 : (ST == SK_F5 || ST == SK_F5W) ? 4 : (ST == SK_B1 || ST == SK_B1W) ? 5 : ST == SK_B2 ? 6 : 7;
   SK_STAMP(SLOT, 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, lk = lane >> 4;
   const int B = a.B, D = a.D, H = a.H, L = a.L;
-  const int nrt = (B + 15) >> 4;
-  constexpr int NU = (ST == SK_F1 || ST == SK_F4) ? 4 : (ST == SK_F3 || ST == SK_B3) ? 2 : 1;
+  const int nrt = (((B + 15) >> 4) + RT - 1) / RT;      // groups of RT row tiles
   const bool vae = a.model != 2;                 // (VAE and VAE_GMP: one encoder, no y path)
   const int nct = ST == SK_F1 ? (vae ? H : 2 * H) / 64 : ST == SK_F3 ? (L + 15) / 16 : ST == SK_F4 ? H / 64 : ST == SK_F5 ? D / 16
-                : ST == SK_B1 ? H / 16 : ST == SK_B2 ? (L + 15) / 16 : H / 32;
+                : ST == SK_B1 ? H / 16 : ST == SK_B2 ? (L + 15) / 16 : ST == SK_F5W ? (D + 63) / 64 : ST == SK_B1W ? H / 64 : H / 32;
   const int bid = blockIdx.x;
   if constexpr (ST == SK_F1) {
     if (bid >= nct * nrt * a.ns1) {               // VAE: extra workgroups draw the eps rows (the GMVAE's ride on F2)
@@ -230,19 +348,27 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     if (vae && bid == 0 && tid == 0 && a.step_dev) a.step_dev[1] = a.step_dev[0];     // the copy the W launch reads
   }
   const int ct = bid % nct, rt = (bid / nct) % nrt, ks = bid / (nct * nrt);
-  const int r0 = rt * 16;
-  const int rowc = min(r0 + ln, B - 1);           // this lane's activation row (clamped; rows >= B are masked at the stores)
+  const int r0 = rt * 16 * RT;
+  long long rowc[RT];                             // this lane's activation rows (clamped; rows >= B are masked at the stores)
+#pragma unroll
+  for (int j = 0; j < RT; ++j) rowc[j] = min(r0 + 16 * j + ln, B - 1);
   const float* const P = a.P;
   // ---- the epilogue's inputs (threads 0..255 own one accumulator register of one lane slot each: see below) are
   // requested FIRST: they do not depend on the contraction, and behind the waves' meeting in LDS they were a memory
   // round trip of their own (1.2 - 1.6 us of a 4 - 6 us launch, tools/skstamps.py)
   const int el = tid & 63, er = (tid >> 6) & 3;   // owner of accumulator register er of lane slot el
-  const int row = r0 + 4 * (el >> 4) + er, ec = el & 15;
-  const bool rok = row < B;
-  const long long rr = rok ? row : B - 1;
-  float pf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int jl = tid >> 8, ec = el & 15;          // ... of row tile 2 c + jl in meeting c
+  const bool owner = tid < 256 * CJ;
+  float pfa[NC][6];
   float4 pf4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (tid < 256) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    float (&pf)[6] = pfa[c];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pf[i] = 0.f;
+    const int row = r0 + 16 * (CJ * c + jl) + 4 * (el >> 4) + er;
+    const long long rr = row < B ? row : B - 1;
+  if (owner) {
     if constexpr (ST == SK_F1) {
       if (vae) pf4 = *reinterpret_cast<const float4*>(P + a.by0 + ct * 64 + 4 * ec);
     } else if constexpr (ST == SK_F3) {
@@ -255,8 +381,16 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
       const int n = ct * 16 + ec;
       pf[0] = P[a.bd1 + n] + (a.gen_bias_vec ? a.gen_bias_vec[n] : 0.f);
       pf[1] = (float)a.x[rr * D + n];
+    } else if constexpr (ST == SK_F5W) {
+      const int n = min(ct * 64 + 4 * ec, D - 4);  // (a ragged last tile of columns: clamped here, masked at the stores)
+      pf4 = *reinterpret_cast<const float4*>(P + a.bd1 + n);
+      if (a.gen_bias_vec) { const float4 q = *reinterpret_cast<const float4*>(a.gen_bias_vec + n); pf4.x += q.x; pf4.y += q.y; pf4.z += q.z; pf4.w += q.w; }
+      pf[0] = __uint_as_float(*reinterpret_cast<const unsigned*>(a.x + rr * D + n));       // 4 pixels
     } else if constexpr (ST == SK_B1) {
       pf[0] = a.hd[rr * H + ct * 16 + ec];
+    } else if constexpr (ST == SK_B1W) {
+      const float4 q = *reinterpret_cast<const float4*>(a.hd + rr * H + ct * 64 + 4 * ec);
+      pf[0] = q.x; pf[1] = q.y; pf[2] = q.z; pf[3] = q.w;
     } else if constexpr (ST == SK_B3) {
       pf[0] = a.hg[rr * H + ct * 32 + ec]; pf[1] = a.hg[rr * H + ct * 32 + 16 + ec];
     } else if constexpr (ST == SK_B2) {
@@ -265,49 +399,75 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
       if (!vae) { pf[2] = a.pp[rr * 2 * L + l]; pf[3] = a.pp[rr * 2 * L + L + l]; }
     }
   }
-  f32x4 acc[4];
+  }
+  f32x4 acc[RT][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < RT; ++j)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  long long arow[RT];
   if constexpr (ST == SK_F1) {
     const int c0 = ct * 64, kgs = D / 16;
     const int kg_lo = (int)((long long)kgs * ks / a.ns1), kg_hi = (int)((long long)kgs * (ks + 1) / a.ns1);
     const float* W = c0 < H ? P + a.Wy0 + c0 : P + a.Wg0 + (c0 - H);
-    sk_nn4<true>(a.x, (long long)rowc * D, W, H, 4 * ln, kg_lo, kg_hi, wave, lk, acc);
+    for (int j = 0; j < RT; ++j) arow[j] = rowc[j] * D;
+    sk_nn4<true, RT>(a.x, arow, W, H, 4 * ln, kg_lo, kg_hi, wave, lk, acc);
   } else if constexpr (ST == SK_F3) {
     const int lc = min(ct * 16 + ln, L - 1);
     const int col[2] = {lc, L + lc};
-    sk_nnp<2>(a.hg, (long long)rowc * H, P + a.Wg1, 2 * L, col, 0, H / 16, wave, lk, acc);
+    for (int j = 0; j < RT; ++j) arow[j] = rowc[j] * H;
+    sk_nnp<2, RT>(a.hg, arow, P + a.Wg1, 2 * L, col, 0, H / 16, wave, lk, acc);
   } else if constexpr (ST == SK_F4) {
-    if (L & 15) sk_nn4<false, true>(a.z, (long long)rowc * L, P + a.Wd0 + ct * 64, H, 4 * ln, 0, (L + 15) / 16, wave, lk, acc, L);
-    else sk_nn4<false>(a.z, (long long)rowc * L, P + a.Wd0 + ct * 64, H, 4 * ln, 0, L / 16, wave, lk, acc);
+    for (int j = 0; j < RT; ++j) arow[j] = rowc[j] * L;
+    if (L & 15) sk_nn4<false, RT, true>(a.z, arow, P + a.Wd0 + ct * 64, H, 4 * ln, 0, (L + 15) / 16, wave, lk, acc, L);
+    else sk_nn4<false, RT>(a.z, arow, P + a.Wd0 + ct * 64, H, 4 * ln, 0, L / 16, wave, lk, acc);
   } else if constexpr (ST == SK_F5) {             // 16-column tiles: D / 16 x row tiles workgroups (the widest layer on the most CUs)
     const int col[1] = {ct * 16 + ln};
-    sk_nnp<1>(a.hd, (long long)rowc * H, P + a.Wd1, D, col, 0, H / 16, wave, lk, acc);
+    for (int j = 0; j < RT; ++j) arow[j] = rowc[j] * H;
+    sk_nnp<1, RT>(a.hd, arow, P + a.Wd1, D, col, 0, H / 16, wave, lk, acc);
+  } else if constexpr (ST == SK_F5W) {            // 64-column tiles (strided, as F1): 4 x the MFMAs per W fragment
+    for (int j = 0; j < RT; ++j) arow[j] = rowc[j] * H;
+    sk_nn4<false, RT>(a.hd, arow, P + a.Wd1, D, min(ct * 64 + 4 * ln, D - 4), 0, H / 16, wave, lk, acc);
+  } else if constexpr (ST == SK_B1W) {            // 4 strided W rows per lane: out column ct 64 + 4 ln + t
+    const int wr[4] = {ct * 64 + 4 * ln, ct * 64 + 4 * ln + 1, ct * 64 + 4 * ln + 2, ct * 64 + 4 * ln + 3};
+    for (int j = 0; j < RT; ++j) arow[j] = rowc[j] * D;
+    sk_nt<4, RT>(a.g, arow, P + a.Wd1, D, wr, 0, D / 16, wave, lk, acc);
   } else if constexpr (ST == SK_B1) {             // dhd = g Wd1^T: out column j = hidden unit, W row j of Wd1 [H][D]
     const int wr[1] = {ct * 16 + ln};
-    sk_nt<1>(a.g, (long long)rowc * D, P + a.Wd1, D, wr, 0, D / 16, wave, lk, acc);
+    for (int j = 0; j < RT; ++j) arow[j] = rowc[j] * D;
+    sk_nt<1, RT>(a.g, arow, P + a.Wd1, D, wr, 0, D / 16, wave, lk, acc);
   } else if constexpr (ST == SK_B2) {             // dz = dhd Wd0^T: W row l of Wd0 [L][H]
     const int wr[1] = {min(ct * 16 + ln, L - 1)};
-    sk_nt<1>(a.dhd, (long long)rowc * H, P + a.Wd0, H, wr, 0, H / 16, wave, lk, acc);
+    for (int j = 0; j < RT; ++j) arow[j] = rowc[j] * H;
+    sk_nt<1, RT>(a.dhd, arow, P + a.Wd0, H, wr, 0, H / 16, wave, lk, acc);
   } else {                                        // B3: dhg = dqp Wg1^T: W row h of Wg1 [H][2L]
     const int wr[2] = {ct * 32 + ln, ct * 32 + 16 + ln};
-    if ((2 * L) & 15) sk_nt<2, true>(a.dqp, (long long)rowc * 2 * L, P + a.Wg1, 2 * L, wr, 0, (2 * L + 15) / 16, wave, lk, acc, 2 * L);
-    else sk_nt<2>(a.dqp, (long long)rowc * 2 * L, P + a.Wg1, 2 * L, wr, 0, (2 * L) / 16, wave, lk, acc);
+    for (int j = 0; j < RT; ++j) arow[j] = rowc[j] * 2 * L;
+    if ((2 * L) & 15) sk_nt<2, RT, true>(a.dqp, arow, P + a.Wg1, 2 * L, wr, 0, (2 * L + 15) / 16, wave, lk, acc, 2 * L);
+    else sk_nt<2, RT>(a.dqp, arow, P + a.Wg1, 2 * L, wr, 0, (2 * L) / 16, wave, lk, acc);
   }
   SK_STAMP(SLOT, 1);
-  // ---- the waves' partial tiles meet in LDS (fixed order)
+  // ---- the waves' partial tiles meet in LDS (fixed order), CJ row tiles at a time
 #pragma unroll
-  for (int t = 0; t < NU; ++t)
+  for (int c = 0; c < NC; ++c) {
+  if (c) __syncthreads();                         // (the previous meeting's readers are done)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * t + r) * 64 + lane] = acc[t][r];
+  for (int j = 0; j < CJ; ++j)
+#pragma unroll
+    for (int t = 0; t < NU; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wave * CJ + j) * NU * 4 + 4 * t + r) * 64 + lane] = acc[CJ * c + j][t][r];
   __syncthreads();
-  SK_STAMP(SLOT, 2);
-  if (tid >= 256) return;
+  if (c == 0) { SK_STAMP(SLOT, 2); }
+  if (!owner) continue;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int w = 0; w < kSkWaves; ++w)
 #pragma unroll
-    for (int t = 0; t < NU; ++t) v[t] += red[(w * 16 + 4 * t + er) * 64 + el];
+    for (int t = 0; t < NU; ++t) v[t] += red[((w * CJ + jl) * NU * 4 + 4 * t + er) * 64 + el];
+  const float (&pf)[6] = pfa[c];
+  const int row = r0 + 16 * (CJ * c + jl) + 4 * (el >> 4) + er;
+  const bool rok = row < B;
   // ---- epilogues
   if constexpr (ST == SK_F1) {
     if (vae) {                                    // the whole layer: hidden activation of the encoder (scripts/base.py:47-60,67)
@@ -355,6 +515,28 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     if (rok) st1o(a.g + (long long)row * D + ct * 16 + ec, (lam >= 0.f ? rcp : e * rcp) - xv);
     rs = sk_row16_sum(rs);
     if (ec == 0 && rok) st1o(a.part + (long long)row * a.nparts + ct, rs);
+  } else if constexpr (ST == SK_F5W) {
+    const int n = ct * 64 + 4 * ec;
+    const bool nok = n < D;
+    const unsigned xw = __float_as_uint(pf[0]);
+    const float bq[4] = {pf4.x, pf4.y, pf4.z, pf4.w};
+    float gq[4], rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float lam = v[t] + bq[t] + a.gen_bias;
+      const float xv = (float)((xw >> (8 * t)) & 0xffu);
+      const float e = __expf(-fabsf(lam));
+      const float rcp = __builtin_amdgcn_rcpf(1.f + e);
+      const float sp = fmaxf(lam, 0.f) - __logf(rcp);
+      rs += xv * lam - sp;
+      gq[t] = (lam >= 0.f ? rcp : e * rcp) - xv;
+    }
+    if (rok && nok) st4o(a.g + (long long)row * D + n, make_float4(gq[0], gq[1], gq[2], gq[3]));
+    rs = sk_row16_sum(nok ? rs : 0.f);
+    if (ec == 0 && rok) st1o(a.part + (long long)row * a.nparts + ct, rs);
+  } else if constexpr (ST == SK_B1W) {
+    if (rok) st4o(a.dhd + (long long)row * H + ct * 64 + 4 * ec,
+                  make_float4(pf[0] > 0.f ? v[0] : 0.f, pf[1] > 0.f ? v[1] : 0.f, pf[2] > 0.f ? v[2] : 0.f, pf[3] > 0.f ? v[3] : 0.f));
   } else if constexpr (ST == SK_B1) {
     if (rok) st1o(a.dhd + (long long)row * H + ct * 16 + ec, pf[0] > 0.f ? v[0] : 0.f);
   } else if constexpr (ST == SK_B3) {
@@ -389,6 +571,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
       st1o(a.dpp + (long long)row * 2 * L + L + l, (spp > a.smin) ? (1.f - t * t) * isp * (rawp >= 0.f ? rp : ep * rp) : 0.f);
       }
     }
+  }
   }
   SK_STAMP(SLOT, 3);
 }
@@ -725,6 +908,69 @@ __device__ __forceinline__ void sk_dw_tile_v(const SkArgs& a, const SkTensor& T,
   }
 }
 
+// VAE_GMP: the workgroups of a W launch that update the mixture prior's variables (idx: the workgroup's index among them)
+__device__ __forceinline__ void sk_gmp_update(const SkArgs& a, const int idx, const int tid, const int nthr = kSkThreads) {
+  const int B = a.B;
+  const int i = idx * nthr + tid;
+  // VAE_GMP: the mixture prior's variables (loc, raw scale, mixture logits: scripts/vae.py:233-238) have no matrix-product
+  // gradient: gmp_param_bwd left gmp_n partials in the flat layout's order; sum them in partial order, update
+  const int KL = a.K * a.L, KLp = (KL + 3) & ~3;
+  const bool valid = i < a.gmp_len && (i < KL || (i >= KLp && i < KLp + KL) || (i >= 2 * KLp && i < 2 * KLp + a.K));
+  if (!valid) return;                               // (alignment padding between the three tensors)
+  const float tf = (float)((a.step_dev ? a.step_dev[1] : a.step) + 1ull);
+  const float lr_t = a.ap ? a.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1)) : 0.f;
+  const long long o = a.gmp_off + i;
+  float pw = 0.f, pm = 0.f, pv = 0.f;
+  if (a.ap) { pw = a.ap[o]; pm = a.am[o]; pv = a.av[o]; }
+  float gsum = 0.f;
+  for (int g0 = 0; g0 < a.gmp_n; g0 += 16) {        // 16 partials in flight at a time (one by one: 16 dependent round trips each)
+    float pv16[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pv16[j] = a.gmp_part[(long long)min(g0 + j, a.gmp_n - 1) * a.gmp_len + i];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) gsum += g0 + j < a.gmp_n ? pv16[j] : 0.f;
+  }
+  a.grads[o] = gsum;
+  if (a.ap) {
+    adam_update(pw, pm, pv, gsum, 1.f / (float)B, lr_t, 1.f - a.b1, 1.f - a.b2, a.aeps);
+    a.ap[o] = pw; a.am[o] = pm; a.av[o] = pv;
+  }
+}
+
+// the loss tail of a W launch (one workgroup): per-row terms from the partials, batch sums, counters
+__device__ __forceinline__ void sk_loss_tail(const SkArgs& a, float (&red)[4][256], const int tid) {
+  const int B = a.B;
+  const unsigned long long dbg_c0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int nlt = (a.L + 15) / 16;
+  if (tid < 256) {
+    for (int b = tid; b < B; b += 256) {
+      float lpx = 0.f, lq = 0.f, lp = 0.f;
+      for (int i = 0; i < a.nparts; ++i) lpx += a.part[(long long)b * a.nparts + i];
+      for (int i = 0; i < nlt; ++i) { lq += a.lqp[(long long)i * B + b]; lp += a.lqp[(long long)(nlt + i) * B + b]; }
+      if (a.model == 1) lp = a.logp[b];               // (VAE_GMP: the mixture log-density, written by mixture_logprob_*)
+      const float ne = a.nent ? a.nent[b] : 0.f;      // (VAE: no entropy term)
+      const float lw = lpx + lp - lq - ne;
+      a.logpx[b] = lpx; a.logq[b] = lq; a.logp[b] = lp; a.logw[b] = lw;
+      a0 -= lw; a1 -= lpx; a2 += lq - lp; a3 += ne;
+    }
+    red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2; red[3][tid] = a3;
+  }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o)
+      for (int j = 0; j < 4; ++j) red[j][tid] += red[j][tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const unsigned long long dbg_c1 = __builtin_amdgcn_s_memtime(), dbg_r1 = __builtin_amdgcn_s_memrealtime();
+    const float tl[8] = {red[0][0], red[1][0], red[2][0], red[3][0], (float)B, 0.f, (float)(dbg_c1 - dbg_c0), (float)(dbg_r1 - dbg_r0)};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a.tail[j] = tl[j]; if (a.tail_log) a.tail_log[j] = tl[j]; }
+    if (a.step_dev) a.step_dev[0] = a.step_dev[1] + 1ull;
+  }
+}
+
 // W: every weight and bias gradient + TF-Adam (scripts/runners.py:181-183).  The contraction runs over the <= 128 batch
 // rows only, so a [64 x 16] tile of dW = A^T dY is ONE wave's work (16 MFMA steps of 4 rows per 64 rows, 4 strided 16-row
 // tiles as in dwadam.hpp) and a workgroup carries 8 tiles; nothing meets in LDS.  The optimizer runs on the accumulator
@@ -739,63 +985,12 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
   const int ntw = (int)gridDim.x - (a.has_tail ? 1 : 0) - gmp_wgs;      // tile workgroups; then the loss tail, if this launch carries it; then
                                                                         // (VAE_GMP) the workgroups that update the mixture prior's variables
   if ((int)blockIdx.x >= ntw + (a.has_tail ? 1 : 0)) {
-    const int i = ((int)blockIdx.x - ntw - (a.has_tail ? 1 : 0)) * kSkThreads + tid;
-    // VAE_GMP: the mixture prior's variables (loc, raw scale, mixture logits: scripts/vae.py:233-238) have no matrix-product
-    // gradient: gmp_param_bwd left gmp_n partials in the flat layout's order; sum them in partial order, update
-    const int KL = a.K * a.L, KLp = (KL + 3) & ~3;
-    const bool valid = i < a.gmp_len && (i < KL || (i >= KLp && i < KLp + KL) || (i >= 2 * KLp && i < 2 * KLp + a.K));
-    if (!valid) return;                               // (alignment padding between the three tensors)
-    const float tf = (float)((a.step_dev ? a.step_dev[1] : a.step) + 1ull);
-    const float lr_t = a.ap ? a.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1)) : 0.f;
-    const long long o = a.gmp_off + i;
-    float pw = 0.f, pm = 0.f, pv = 0.f;
-    if (a.ap) { pw = a.ap[o]; pm = a.am[o]; pv = a.av[o]; }
-    float gsum = 0.f;
-    for (int g0 = 0; g0 < a.gmp_n; g0 += 16) {        // 16 partials in flight at a time (one by one: 16 dependent round trips each)
-      float pv16[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) pv16[j] = a.gmp_part[(long long)min(g0 + j, a.gmp_n - 1) * a.gmp_len + i];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) gsum += g0 + j < a.gmp_n ? pv16[j] : 0.f;
-    }
-    a.grads[o] = gsum;
-    if (a.ap) {
-      adam_update(pw, pm, pv, gsum, 1.f / (float)B, lr_t, 1.f - a.b1, 1.f - a.b2, a.aeps);
-      a.ap[o] = pw; a.am[o] = pm; a.av[o] = pv;
-    }
+    sk_gmp_update(a, (int)blockIdx.x - ntw - (a.has_tail ? 1 : 0), tid);
     return;
   }
   SK_STAMP(9, 0);
   if ((int)blockIdx.x == ntw) {                   // ---- loss tail: per-row terms from the partials, batch sums, counters
-    const unsigned long long dbg_c0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const int nlt = (a.L + 15) / 16;
-    if (tid < 256) {
-      for (int b = tid; b < B; b += 256) {
-        float lpx = 0.f, lq = 0.f, lp = 0.f;
-        for (int i = 0; i < a.nparts; ++i) lpx += a.part[(long long)b * a.nparts + i];
-        for (int i = 0; i < nlt; ++i) { lq += a.lqp[(long long)i * B + b]; lp += a.lqp[(long long)(nlt + i) * B + b]; }
-        if (a.model == 1) lp = a.logp[b];               // (VAE_GMP: the mixture log-density, written by mixture_logprob_*)
-        const float ne = a.nent ? a.nent[b] : 0.f;      // (VAE: no entropy term)
-        const float lw = lpx + lp - lq - ne;
-        a.logpx[b] = lpx; a.logq[b] = lq; a.logp[b] = lp; a.logw[b] = lw;
-        a0 -= lw; a1 -= lpx; a2 += lq - lp; a3 += ne;
-      }
-      red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2; red[3][tid] = a3;
-    }
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o)
-        for (int j = 0; j < 4; ++j) red[j][tid] += red[j][tid + o];
-      __syncthreads();
-    }
-    if (tid == 0) {
-      const unsigned long long dbg_c1 = __builtin_amdgcn_s_memtime(), dbg_r1 = __builtin_amdgcn_s_memrealtime();
-      const float tl[8] = {red[0][0], red[1][0], red[2][0], red[3][0], (float)B, 0.f, (float)(dbg_c1 - dbg_c0), (float)(dbg_r1 - dbg_r0)};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { a.tail[j] = tl[j]; if (a.tail_log) a.tail_log[j] = tl[j]; }
-      if (a.step_dev) a.step_dev[0] = a.step_dev[1] + 1ull;
-    }
+    sk_loss_tail(a, red, tid);
     return;
   }
   // a workgroup's 8 waves take 8 CONSECUTIVE tiles (one row of tiles of a tensor: they share the A rows and write
@@ -907,6 +1102,405 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
   }
   }
   SK_STAMP(9, 3);
+}
+
+
+// W for batches above 128 rows: sk_dw's one-wave tiles re-read their operands per [16 x 64] tile -- at B = 1024, H = 512 that is
+// 450 MB through L2 for 2.9 GFLOP and the launch ran at the L2's rate (63 us).  Here a WORKGROUP owns a [64 x 64] tile of
+// dW = A^T dY: lane (ln, lk) loads 16 bytes of A (4 uint8 or 4 floats: rows m0 + 4 ln + tm) and 16 bytes of dY (columns
+// n0 + 4 ln + tn) per batch row and feeds 16 MFMAs from them; the 8 waves split the batch rows and their partial tiles meet
+// in LDS in wave order (two halves of 32 accumulator registers: 64 KB).  The optimizer runs on the summed tile, spread over
+// all 512 threads: thread (tml, r, lane) of half p owns dW[m0 + 16 lk + 4 r + 2 p + tml][n0 + 4 ln .. + 3], so p, m, v and the
+// gradient move in 16-byte accesses, 256 contiguous bytes per lane group (rows of N % 4 != 0: element by element).
+// Tiles are dealt so that the 8 workgroups an XCD receives in turn hold neighbouring tiles (shared operand columns in its L2).
+// (Measured and dropped: [32 x 64] tiles to balance 354 tiles over 256 CUs -- twice the workgroups, but only two of them fit a CU,
+// so the second half queued: 43 us against 46.  Where the tiles do not balance, the stage runs as sk_dwc + sk_adam below.)
+__global__ __launch_bounds__(kSkThreads) void sk_dwb(const SkArgs a) {
+  constexpr int TM = 4, NP = 2;                    // strided 16-row tiles; meetings (halves of 32 accumulator registers)
+  __shared__ __attribute__((aligned(16))) float part[kSkWaves * 8 * 64 * 4];      // [wave][tml * 4 + r][lane][tn]
+  __shared__ __attribute__((aligned(16))) float csl[kSkWaves * 16 * 4];           // column sums [wave][ln][tn]
+  __shared__ float red[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lk = lane >> 4;
+  const int B = a.B;
+  const int gmp_wgs = (a.gmp_part && a.has_tail) ? (a.gmp_len + kSkThreads - 1) / kSkThreads : 0;
+  const int ntw = (int)gridDim.x - (a.has_tail ? 1 : 0) - gmp_wgs;
+  if ((int)blockIdx.x >= ntw + (a.has_tail ? 1 : 0)) {
+    sk_gmp_update(a, (int)blockIdx.x - ntw - (a.has_tail ? 1 : 0), tid);
+    return;
+  }
+  SK_STAMP(9, 0);
+  if ((int)blockIdx.x == ntw) {
+    sk_loss_tail(a, red, tid);
+    return;
+  }
+  const int per = ntw >> 3;                        // (ntw = 8 ceil(total_tiles / 8))
+  const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (tile >= a.total_tiles) return;
+  int ti = 0;
+#pragma unroll
+  for (int i = 1; i < kSkMaxT; ++i)
+    if (i < a.ntens && tile >= a.t[i].tile_begin) ti = i;
+  const SkTensor& T = a.t[ti];
+  const int M = T.M, N = T.N, lda = T.lda, ldy = T.ldy;
+  const int tl = tile - T.tile_begin, tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
+  const int m0 = tm * 16 * TM, n0 = tn * 64;
+  const int mac = min(m0 + TM * ln, ((M + 3) & ~3) - TM);        // (operand rows hold pad4(M), pad4(N) elements; rows m >= M and
+  const int nc = min(n0 + 4 * ln, ((N + 3) & ~3) - 4);         //  columns n >= N of the tile are computed from clamped loads and never stored)
+  const bool n_ok = n0 + 4 * ln < N;
+  const int rows_p = (((B + kSkWaves - 1) / kSkWaves) + 3) & ~3;
+  const int b_lo = min(B, wave * rows_p), b_hi = min(B, b_lo + rows_p);
+  f32x4 acc[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned char* const A8 = static_cast<const unsigned char*>(T.A);
+  const float* const A32 = static_cast<const float*>(T.A);
+  for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
+    float av[4][TM];
+    float4 bv[4];
+    if (T.a_u8) {
+      unsigned aw[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int b = min(b0 + 4 * s + lk, b_hi - 1);
+        aw[s] = *reinterpret_cast<const unsigned*>(A8 + (long long)b * lda + mac);
+        bv[s] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[s][i] = (float)((aw[s] >> (8 * i)) & 0xffu);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int b = min(b0 + 4 * s + lk, b_hi - 1);
+        const float4 q = *reinterpret_cast<const float4*>(A32 + (long long)b * lda + mac);
+        av[s][0] = q.x; av[s][1] = q.y; av[s][2] = q.z; av[s][3] = q.w;
+        bv[s] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool on = b0 + 4 * s + lk < b_hi && n_ok;            // a zero B operand voids clamped batch rows and columns
+      const float bq[4] = {on ? bv[s].x : 0.f, on ? bv[s].y : 0.f, on ? bv[s].z : 0.f, on ? bv[s].w : 0.f};
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][i], bq[j], acc[i][j], 0, 0, 0);
+      cs.x += bq[0]; cs.y += bq[1]; cs.z += bq[2]; cs.w += bq[3];
+    }
+  }
+  SK_STAMP(9, 1);
+  // ---- the optimizer's operands of this thread's two rows (one per half), requested before the waves meet
+  const bool upd = a.ap != nullptr;
+  const bool vecn = (N & 3) == 0;
+  const int tml = wave >> 2, er = wave & 3;
+  const int n = n0 + 4 * ln;
+  float pp[NP][4], pm[NP][4], pv[NP][4];
+  long long ei[NP];
+  bool eok[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int m = m0 + TM * (4 * lk + er) + 2 * p + tml;       // MFMA row 4 lk + er of strided tile 2 p + tml
+    eok[p] = m < M && n < N;
+    ei[p] = (long long)T.w_off + (long long)min(m, M - 1) * N + min(n, vecn ? N - 4 : N - 1);
+    if (upd) {
+      if (vecn) {
+        const float4 q0 = *reinterpret_cast<const float4*>(a.ap + ei[p]), q1 = *reinterpret_cast<const float4*>(a.am + ei[p]),
+                     q2 = *reinterpret_cast<const float4*>(a.av + ei[p]);
+        pp[p][0] = q0.x; pp[p][1] = q0.y; pp[p][2] = q0.z; pp[p][3] = q0.w;
+        pm[p][0] = q1.x; pm[p][1] = q1.y; pm[p][2] = q1.z; pm[p][3] = q1.w;
+        pv[p][0] = q2.x; pv[p][1] = q2.y; pv[p][2] = q2.z; pv[p][3] = q2.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const long long i = ei[p] + min(j, N - 1 - min(n, N - 1));
+          pp[p][j] = a.ap[i]; pm[p][j] = a.am[i]; pv[p][j] = a.av[i];
+        }
+      }
+    }
+  }
+  float lr_t = 0.f;
+  if (upd) {
+    const float tf = (float)((a.step_dev ? a.step_dev[1] : a.step) + 1ull);
+    lr_t = a.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1));
+  }
+  const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, gs = 1.f / (float)B;
+  const bool bias = tm == 0 && T.b_off >= 0;
+  if (bias) {
+    cs.x += __shfl_xor(cs.x, 16, 64); cs.y += __shfl_xor(cs.y, 16, 64); cs.z += __shfl_xor(cs.z, 16, 64); cs.w += __shfl_xor(cs.w, 16, 64);
+    cs.x += __shfl_xor(cs.x, 32, 64); cs.y += __shfl_xor(cs.y, 32, 64); cs.z += __shfl_xor(cs.z, 32, 64); cs.w += __shfl_xor(cs.w, 32, 64);
+    if (lk == 0) *reinterpret_cast<float4*>(csl + (wave * 16 + ln) * 4) = cs;
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    if (p) __syncthreads();                        // (the first half's readers are done)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float4*>(part + (((wave * 8 + i * 4 + r) * 64) + lane) * 4) =
+            make_float4(acc[2 * p + i][0][r], acc[2 * p + i][1][r], acc[2 * p + i][2][r], acc[2 * p + i][3][r]);
+    __syncthreads();
+    if (p == 0) { SK_STAMP(9, 2); }
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < kSkWaves; ++w) {
+      const float4 q = *reinterpret_cast<const float4*>(part + (((w * 8 + tml * 4 + er) * 64) + lane) * 4);
+      g[0] += q.x; g[1] += q.y; g[2] += q.z; g[3] += q.w;
+    }
+    if (upd) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) adam_update(pp[p][j], pm[p][j], pv[p][j], g[j], gs, lr_t, omb1, omb2, a.aeps);
+    }
+    if (eok[p]) {
+      if (vecn) {
+        st4o(a.grads + ei[p], make_float4(g[0], g[1], g[2], g[3]));
+        if (upd) {
+          st4o(a.ap + ei[p], make_float4(pp[p][0], pp[p][1], pp[p][2], pp[p][3]));
+          st4o(a.am + ei[p], make_float4(pm[p][0], pm[p][1], pm[p][2], pm[p][3]));
+          st4o(a.av + ei[p], make_float4(pv[p][0], pv[p][1], pv[p][2], pv[p][3]));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < N) {
+            st1o(a.grads + ei[p] + j, g[j]);
+            if (upd) { st1o(a.ap + ei[p] + j, pp[p][j]); st1o(a.am + ei[p] + j, pm[p][j]); st1o(a.av + ei[p] + j, pv[p][j]); }
+          }
+      }
+    }
+    if (p == 0 && bias && tid < 16 && n0 + 4 * tid < N) {      // bias gradient: column sums of dY over the batch rows, in wave order
+      float c4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < kSkWaves; ++w) {
+        const float4 q = *reinterpret_cast<const float4*>(csl + (w * 16 + tid) * 4);
+        c4[0] += q.x; c4[1] += q.y; c4[2] += q.z; c4[3] += q.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nb = n0 + 4 * tid + j;
+        if (nb < N) {
+          const long long i = (long long)T.b_off + nb;
+          a.grads[i] = c4[j];
+          if (upd) {
+            float bp = a.ap[i], bm = a.am[i], bvv = a.av[i];
+            adam_update(bp, bm, bvv, c4[j], gs, lr_t, omb1, omb2, a.aeps);
+            a.ap[i] = bp; a.am[i] = bm; a.av[i] = bvv;
+          }
+        }
+      }
+    }
+  }
+  SK_STAMP(9, 3);
+}
+
+// W in two launches, for batches where one workgroup per tile cannot balance (H = 512: 354 [64 x 64] tiles on 256 CUs, and a CU
+// that carries two sets the launch's time).  sk_dwc: workgroups of 4 waves; workgroup (tile, share) contracts one of dw_ks
+// shares of the batch rows for a [64 x 64] tile (operand fragments and accumulators as sk_dwb), its 4 waves meet in LDS and the
+// summed partial tile -- and, on the first tile row, the partial column sums (bias gradient) -- goes to dwp[share] in the flat
+// layout.  sk_adam then adds the shares in share order and runs TF-Adam element by element.  The loss tail and the mixture
+// prior's workgroups ride on sk_dwc.
+constexpr int kDwcThreads = 256, kDwcWaves = 4;
+__global__ __launch_bounds__(kDwcThreads, 4) void sk_dwc(const SkArgs a) {
+  constexpr int TM = 4, NP = 2;
+  __shared__ __attribute__((aligned(16))) float part[kDwcWaves * 8 * 64 * 4];     // [wave][tml * 4 + r][lane][tn]: 32 KB
+  __shared__ __attribute__((aligned(16))) float csl[kDwcWaves * 16 * 4];
+  __shared__ float red[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lk = lane >> 4;
+  const int B = a.B;
+  const int gmp_wgs = (a.gmp_part && a.has_tail) ? (a.gmp_len + kDwcThreads - 1) / kDwcThreads : 0;
+  const int ntw = (int)gridDim.x - (a.has_tail ? 1 : 0) - gmp_wgs;
+  if ((int)blockIdx.x >= ntw + (a.has_tail ? 1 : 0)) {
+    sk_gmp_update(a, (int)blockIdx.x - ntw - (a.has_tail ? 1 : 0), tid, kDwcThreads);
+    return;
+  }
+  SK_STAMP(9, 0);
+  if ((int)blockIdx.x == ntw) {
+    sk_loss_tail(a, red, tid);
+    return;
+  }
+  const int per = ntw >> 3;                        // (ntw = 8 ceil(total_tiles dw_ks / 8))
+  const int unit = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  const int tile = unit / a.dw_ks, ks = unit - tile * a.dw_ks;
+  if (tile >= a.total_tiles) return;
+  int ti = 0;
+#pragma unroll
+  for (int i = 1; i < kSkMaxT; ++i)
+    if (i < a.ntens && tile >= a.t[i].tile_begin) ti = i;
+  const SkTensor& T = a.t[ti];
+  const int M = T.M, N = T.N, lda = T.lda, ldy = T.ldy;
+  const int tl = tile - T.tile_begin, tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
+  const int m0 = tm * 16 * TM, n0 = tn * 64;
+  const int mac = min(m0 + TM * ln, ((M + 3) & ~3) - TM);
+  const int nc = min(n0 + 4 * ln, ((N + 3) & ~3) - 4);
+  const bool n_ok = n0 + 4 * ln < N;
+  const int rows_s = (((B + a.dw_ks - 1) / a.dw_ks) + 3) & ~3;                    // this workgroup's share of the batch rows ...
+  const int s_lo = min(B, ks * rows_s), s_hi = min(B, s_lo + rows_s);
+  const int rows_p = (((s_hi - s_lo + kDwcWaves - 1) / kDwcWaves) + 3) & ~3;      // ... and this wave's share of that
+  const int b_lo = min(s_hi, s_lo + wave * rows_p), b_hi = min(s_hi, b_lo + rows_p);
+  f32x4 acc[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned char* const A8 = static_cast<const unsigned char*>(T.A);
+  const float* const A32 = static_cast<const float*>(T.A);
+  for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
+    float4 av[4], bv[4];
+    if (T.a_u8) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int b = min(b0 + 4 * s + lk, b_hi - 1);
+        av[s].x = __uint_as_float(*reinterpret_cast<const unsigned*>(A8 + (long long)b * lda + mac));
+        bv[s] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const unsigned w = __float_as_uint(av[s].x);
+        av[s] = make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int b = min(b0 + 4 * s + lk, b_hi - 1);
+        av[s] = *reinterpret_cast<const float4*>(A32 + (long long)b * lda + mac);
+        bv[s] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool on = b0 + 4 * s + lk < b_hi && n_ok;            // a zero B operand voids clamped batch rows and columns
+      const float bq[4] = {on ? bv[s].x : 0.f, on ? bv[s].y : 0.f, on ? bv[s].z : 0.f, on ? bv[s].w : 0.f};
+      const float aq[4] = {av[s].x, av[s].y, av[s].z, av[s].w};
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[i], bq[j], acc[i][j], 0, 0, 0);
+      cs.x += bq[0]; cs.y += bq[1]; cs.z += bq[2]; cs.w += bq[3];
+    }
+  }
+  SK_STAMP(9, 1);
+  float* const out = a.dwp + (long long)ks * a.dwp_stride;
+  const bool vecn = (N & 3) == 0;
+  const bool bias = tm == 0 && T.b_off >= 0;
+  if (bias) {
+    cs.x += __shfl_xor(cs.x, 16, 64); cs.y += __shfl_xor(cs.y, 16, 64); cs.z += __shfl_xor(cs.z, 16, 64); cs.w += __shfl_xor(cs.w, 16, 64);
+    cs.x += __shfl_xor(cs.x, 32, 64); cs.y += __shfl_xor(cs.y, 32, 64); cs.z += __shfl_xor(cs.z, 32, 64); cs.w += __shfl_xor(cs.w, 32, 64);
+    if (lk == 0) *reinterpret_cast<float4*>(csl + (wave * 16 + ln) * 4) = cs;
+  }
+  const int n = n0 + 4 * ln;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    if (p) __syncthreads();                        // (the first half's readers are done)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float4*>(part + (((wave * 8 + i * 4 + r) * 64) + lane) * 4) =
+            make_float4(acc[2 * p + i][0][r], acc[2 * p + i][1][r], acc[2 * p + i][2][r], acc[2 * p + i][3][r]);
+    __syncthreads();
+    if (p == 0) { SK_STAMP(9, 2); }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                  // this thread's two (strided tile, MFMA row) pairs of the half
+      const int q8 = wave * 2 + h, tml = q8 >> 2, er = q8 & 3;
+      float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < kDwcWaves; ++w) {
+        const float4 q = *reinterpret_cast<const float4*>(part + (((w * 8 + q8) * 64) + lane) * 4);
+        g[0] += q.x; g[1] += q.y; g[2] += q.z; g[3] += q.w;
+      }
+      const int m = m0 + TM * (4 * lk + er) + 2 * p + tml;
+      if (m < M && n < N) {
+        float* const o = out + (long long)T.w_off + (long long)m * N + n;
+        if (vecn) st4o(o, make_float4(g[0], g[1], g[2], g[3]));
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (n + j < N) st1o(o + j, g[j]);
+        }
+      }
+    }
+    if (p == 0 && bias && tid < 16 && n0 + 4 * tid < N) {      // the share's column sums of dY, in wave order
+      float c4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < kDwcWaves; ++w) {
+        const float4 q = *reinterpret_cast<const float4*>(csl + (w * 16 + tid) * 4);
+        c4[0] += q.x; c4[1] += q.y; c4[2] += q.z; c4[3] += q.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n0 + 4 * tid + j < N) st1o(out + (long long)T.b_off + n0 + 4 * tid + j, c4[j]);
+    }
+  }
+  SK_STAMP(9, 3);
+}
+
+// The optimizer launch behind sk_dwc: a workgroup walks 1024 consecutive elements of one segment (a weight or bias tensor's
+// range of the flat layout; 16-byte aligned starts): gradient = the dw_ks partials in share order, then TF-Adam
+// (scripts/runners.py:181-183; ApplyAdam form, kernels.hpp adam_update).
+__global__ __launch_bounds__(256) void sk_adam(const SkArgs a) {
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < 2 * kSkMaxT; ++i)
+    if (i < a.nseg && wg >= a.seg_wg[i]) si = i;
+  const long long e0 = (long long)(wg - a.seg_wg[si]) * 1024 + 4 * tid;
+  const int rem = (int)min((long long)4, (long long)a.seg_len[si] - e0);
+  if (rem <= 0) return;
+  const long long i0 = a.seg_off[si] + e0;
+  const bool upd = a.ap != nullptr;
+  float g[4] = {0.f, 0.f, 0.f, 0.f}, pp[4] = {0.f, 0.f, 0.f, 0.f}, pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (rem == 4) {
+    for (int k = 0; k < a.dw_ks; ++k) {
+      const float4 q = *reinterpret_cast<const float4*>(a.dwp + (long long)k * a.dwp_stride + i0);
+      g[0] += q.x; g[1] += q.y; g[2] += q.z; g[3] += q.w;
+    }
+    if (upd) {
+      const float4 q0 = *reinterpret_cast<const float4*>(a.ap + i0), q1 = *reinterpret_cast<const float4*>(a.am + i0),
+                   q2 = *reinterpret_cast<const float4*>(a.av + i0);
+      pp[0] = q0.x; pp[1] = q0.y; pp[2] = q0.z; pp[3] = q0.w;
+      pm[0] = q1.x; pm[1] = q1.y; pm[2] = q1.z; pm[3] = q1.w;
+      pv[0] = q2.x; pv[1] = q2.y; pv[2] = q2.z; pv[3] = q2.w;
+    }
+  } else {
+    for (int k = 0; k < a.dw_ks; ++k)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (j < rem) g[j] += a.dwp[(long long)k * a.dwp_stride + i0 + j];
+    if (upd) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (j < rem) { pp[j] = a.ap[i0 + j]; pm[j] = a.am[i0 + j]; pv[j] = a.av[i0 + j]; }
+    }
+  }
+  if (upd) {
+    const float tf = (float)((a.step_dev ? a.step_dev[1] : a.step) + 1ull);
+    const float lr_t = a.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1));
+    const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, gs = 1.f / (float)a.B;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) adam_update(pp[j], pm[j], pv[j], g[j], gs, lr_t, omb1, omb2, a.aeps);
+  }
+  if (rem == 4) {
+    st4o(a.grads + i0, make_float4(g[0], g[1], g[2], g[3]));
+    if (upd) {
+      st4o(a.ap + i0, make_float4(pp[0], pp[1], pp[2], pp[3]));
+      st4o(a.am + i0, make_float4(pm[0], pm[1], pm[2], pm[3]));
+      st4o(a.av + i0, make_float4(pv[0], pv[1], pv[2], pv[3]));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (j < rem) {
+        a.grads[i0 + j] = g[j];
+        if (upd) { a.ap[i0 + j] = pp[j]; a.am[i0 + j] = pm[j]; a.av[i0 + j] = pv[j]; }
+      }
+  }
 }
 
 }  // namespace gmvae

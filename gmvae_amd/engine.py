@@ -609,9 +609,9 @@ class Engine:
         for _ in range(launches):
             replay()
         torch.cuda.synchronize()
-        buf = np.zeros(10 * 256 * 8, np.uint64)
+        buf = np.zeros(10 * 1024 * 8, np.uint64)
         L.check(L.lib.gmvae_debug_sk_stamps(buf.ctypes.data_as(C.c_void_p)), "gmvae_debug_sk_stamps")
-        st = buf.reshape(10, 256, 8).astype(np.float64)
+        st = buf.reshape(10, 1024, 8).astype(np.float64)
         names = ["sk_first_layers", "sk_y_path", "sk_q_head_z", "sk_dec_hidden", "sk_dec_bernoulli", "sk_bwd_dhd", "sk_bwd_dz_heads",
                  "sk_bwd_dhg", "sk_y_path_bwd", "sk_dw_adam"]
         starts, ends, present = [], [], []

@@ -284,7 +284,7 @@ int gmvae_dp_graph_create(const GmvaeDims* dims, int model, const uint8_t* x, in
  * tests read the ReLU masks of a step from them). */
 int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, uint64_t* byte_offset);
 
-/* Debugging aid: device wall-clock stamps of the skinny schedule's launches ([10 launches][256 blocks][8] uint64 at
+/* Debugging aid: device wall-clock stamps of the skinny schedule's launches ([10 launches][1024 blocks][8] uint64 at
  * 100 MHz).  host_out == NULL arms it (allocates the buffer; steps enqueued or captured afterwards stamp into it);
  * otherwise the buffer is copied to host_out.  tools/skstamps.py. */
 int gmvae_debug_sk_stamps(unsigned long long* host_out);

@@ -7,15 +7,16 @@ import numpy as np, torch
 from gmvae_amd import _lib as L
 from gmvae_amd.engine import Engine
 L.check(L.lib.gmvae_debug_sk_stamps(None), "arm")
-e = Engine("gmvae", 784, 128, 10, [512], random_seed=0)
 B, G = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), 8
+Lz = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+e = Engine("gmvae", 784, Lz, 10, [512], random_seed=0)
 sx, replay = e.capture_train_step(B, 1e-3, n_steps=G)
 sx.copy_(torch.from_numpy((np.random.default_rng(0).random((G, B, 784)) < 0.87).astype(np.uint8)).cuda())
 for _ in range(300): replay()
 torch.cuda.synchronize()
-buf = np.zeros(10 * 256 * 8, np.uint64)
+buf = np.zeros(10 * 1024 * 8, np.uint64)
 L.check(L.lib.gmvae_debug_sk_stamps(buf.ctypes.data_as(C.c_void_p)), "stamps")
-st = buf.reshape(10, 256, 8).astype(np.float64)
+st = buf.reshape(10, 1024, 8).astype(np.float64)
 names = ["F1 first", "F2 ypath", "F3 qhead", "F4 dechid", "F5 decout", "B1 dhd", "B2 dz", "B3 dhg", "B4 ybwd", "W dw"]
 prev_end = None
 for i, nm in enumerate(names):
@@ -26,3 +27,9 @@ for i, nm in enumerate(names):
     ph = [np.median(r[:, j + 1] - r[:, j]) * 0.01 for j in range(3)]
     print(f"{nm:10s} blocks {len(r):3d} gap-before {gap:5.2f} us | span {(end - start) * 0.01:5.2f} | first-WG start spread {(r[:,0].max()-start)*0.01:4.2f} | per-WG medians: loads+mfma {ph[0]:5.2f}  lds/sync {ph[1]:5.2f}  epilogue {ph[2]:5.2f}")
     prev_end = end
+    if len(sys.argv) > 3 and (sys.argv[3] == "all" or nm.split()[0] in sys.argv[3].split(",")):
+        o = np.argsort(r[:, 0])
+        print("   start quantiles (us):", " ".join("%6.2f" % ((np.quantile(r[:, 0], q) - start) * 0.01) for q in (0, .25, .5, .75, .9, 1)),
+              "| end quantiles:", " ".join("%6.2f" % ((np.quantile(r[:, 3], q) - start) * 0.01) for q in (0, .25, .5, .75, .9, 1)))
+        for k in o[:: max(1, len(o) // 16)]:
+            print("   wg start %7.2f  contraction %6.2f  meet %6.2f  epilogue %6.2f  end %7.2f" % ((r[k, 0] - start) * 0.01, (r[k, 1] - r[k, 0]) * 0.01, (r[k, 2] - r[k, 1]) * 0.01, (r[k, 3] - r[k, 2]) * 0.01, (r[k, 3] - start) * 0.01))
