@@ -1438,13 +1438,16 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
     const int rt = rt_of(nct * slabs), grid = nct * ((nrt + rt - 1) / rt) * slabs + extra;
     launch(rt == 4 ? sk_gemm<ST, 4> : rt == 2 ? sk_gemm<ST, 2> : sk_gemm<ST, 1>, grid, kSkThreads, 0, name, fl);
   };
+  // rows per workgroup of the y path: one while the chip holds every row's workgroup at once (3 per CU), then 2, 4 (H <= 512)
+  const int yr = (H > 512 || B <= 768) ? 1 : (B <= 1536 ? 2 : 4);
   if (vae) {
     const int eps_blocks = gen_eps ? (int)(((long long)B * ((Lz + 3) / 4) + kSkThreads - 1) / kSkThreads) : 0;
     gemm(std::integral_constant<int, SK_F1>{}, H / 64, 1, eps_blocks, "sk_first_layer", fB * D * H);
   } else {
   gemm(std::integral_constant<int, SK_F1>{}, 2 * H / 64, s.ns1, 0, "sk_first_layers", fB * D * 2 * H);
   const int eps_blocks = gen_eps ? (int)(((long long)B * ((Lz + 3) / 4) + 255) / 256) : 0;       // extra workgroups: the eps rows
-  launch(H <= 512 ? sk_ypath<2> : sk_ypath<4>, B + eps_blocks, 256, 0, "sk_y_path", fB * ((double)H * K + K * H + K * 2.0 * Lz));
+  if (yr == 1) launch(H <= 512 ? sk_ypath<2> : sk_ypath<4>, B + eps_blocks, 256, 0, "sk_y_path", fB * ((double)H * K + K * H + K * 2.0 * Lz));
+  else launch(yr == 2 ? sk_ypath_r<2, 2> : sk_ypath_r<2, 4>, (B + yr - 1) / yr + eps_blocks, 256, 0, "sk_y_path", fB * ((double)H * K + K * H + K * 2.0 * Lz));
   }
   gemm(std::integral_constant<int, SK_F3>{}, (Lz + 15) / 16, 1, 0, "sk_q_head_z", fB * H * 2 * Lz);
   if (gmp) launch_mixture_logprob(cx, w, a.params, L, B, Lz, K);
@@ -1505,7 +1508,11 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
     rowk(cx, "gmp_param_bwd");
   }
   gemm(std::integral_constant<int, SK_B3>{}, H / 32, 1, 0, "sk_bwd_dhg", fB * 2 * Lz * H);
-  if (!vae) launch(H <= 512 ? sk_ybwd<2> : sk_ybwd<4>, B, 256, 0, "sk_y_path_bwd", fB * ((double)(H + 2 * Lz) * K + K * H));
+  if (!vae) {
+
+    if (yr == 1) launch(H <= 512 ? sk_ybwd<2> : sk_ybwd<4>, B, 256, 0, "sk_y_path_bwd", fB * ((double)(H + 2 * Lz) * K + K * H));
+    else launch(yr == 2 ? sk_ybwd_r<2, 2> : sk_ybwd_r<2, 4>, (B + yr - 1) / yr, 256, 0, "sk_y_path_bwd", fB * ((double)(H + 2 * Lz) * K + K * H));
+  }
   launch_dw();
   return cx.err;
 }

@@ -106,28 +106,39 @@ __device__ __forceinline__ void sk_groups(const int kg_lo, const int kg_hi, cons
   if (n - done >= 1) body(std::integral_constant<int, 1>{}, kg + kSkWaves * done);
 }
 template <int RT> constexpr int sk_maxg() { return RT == 1 ? 4 : RT == 2 ? 2 : 1; }
-// RT > 1: one group per stage, two register sets: the next group's loads are in flight under this group's RT x as many MFMAs
-template <class Frag, class LD, class MM>
+// RT > 1: one group per stage, two register sets: the next group's loads are in flight under this group's RT x as many MFMAs.
+// (Stages of two groups at RT = 2 measured neutral -- 160 VGPRs, one workgroup per CU -- and were dropped.)
+template <int RT, int NB, int NG_> struct SkFrag { static constexpr int NG = NG_; float4 av[NG_][RT]; float4 bv[NG_][NB]; };
+template <int RT, int NB, class LD, class MM>
 __device__ __forceinline__ void sk_pipe(const int kg_lo, const int kg_hi, const int wave, LD&& ld, MM&& mm) {
+  constexpr int NG = 1;
   const int kg = kg_lo + wave;
   const int n = kg < kg_hi ? (kg_hi - kg + kSkWaves - 1) / kSkWaves : 0;
-  if (n == 0) return;
-  Frag fa, fb;
-  ld(fa, kg);
-  int i = 0;
-  for (; i + 2 <= n; i += 2) {
-    ld(fb, kg + kSkWaves * (i + 1));
-    __builtin_amdgcn_sched_barrier(0);
-    mm(fa);
-    __builtin_amdgcn_sched_barrier(0);
-    if (i + 2 < n) ld(fa, kg + kSkWaves * (i + 2));
-    __builtin_amdgcn_sched_barrier(0);
-    mm(fb);
-    __builtin_amdgcn_sched_barrier(0);
+  const int ns = n / NG;
+  if (ns > 0) {
+    SkFrag<RT, NB, NG> fa, fb;
+    ld(fa, kg);
+    int i = 0;
+    for (; i + 2 <= ns; i += 2) {
+      ld(fb, kg + kSkWaves * NG * (i + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 2 < ns) ld(fa, kg + kSkWaves * NG * (i + 2));
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (i < ns) mm(fa);
   }
-  if (i < n) mm(fa);
+  if constexpr (NG > 1) {
+    for (int g = ns * NG; g < n; ++g) {
+      SkFrag<RT, NB, 1> f;
+      ld(f, kg + kSkWaves * g);
+      mm(f);
+    }
+  }
 }
-template <int RT, int NB> struct SkFrag { float4 av[RT]; float4 bv[NB]; };
 // NN, 4 strided column tiles: out[row][n0 + 4 i + t] for lane column i: W k-major [K][ldw], one 16-byte load of W per k
 // MK: the contraction extent kmax is no multiple of 16 (a multiple of 4): quads at k >= kmax are loaded from the last valid quad
 // (clamped address, branch-free) and their A values replaced by 0
@@ -136,37 +147,44 @@ __device__ __forceinline__ void sk_nn4(const void* __restrict__ Ap, const long l
                                        const int ncol, const int kg_lo, const int kg_hi, const int wave, const int lk,
                                        f32x4 (&acc)[RT][4], const int kmax = 0) {
   if constexpr (RT > 1) {
-    sk_pipe<SkFrag<RT, 4>>(kg_lo, kg_hi, wave,
-      [&](SkFrag<RT, 4>& f, const int kgi) {
-        const int k0 = 16 * kgi + 4 * lk;
-        const int k = MK ? min(k0, kmax - 4) : k0;
+    sk_pipe<RT, 4>(kg_lo, kg_hi, wave,
+      [&](auto& f, const int kgi) {
+        constexpr int NGf = std::remove_reference_t<decltype(f)>::NG;
 #pragma unroll
-        for (int j = 0; j < RT; ++j) {
-          if constexpr (U8) f.av[j].x = __uint_as_float(*reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(Ap) + arow[j] + k));
-          else f.av[j] = *reinterpret_cast<const float4*>(static_cast<const float*>(Ap) + arow[j] + k);
-          if (MK && k0 >= kmax) f.av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < NGf; ++g) {
+          const int k0 = 16 * (kgi + g * kSkWaves) + 4 * lk;
+          const int k = MK ? min(k0, kmax - 4) : k0;
+#pragma unroll
+          for (int j = 0; j < RT; ++j) {
+            if constexpr (U8) f.av[g][j].x = __uint_as_float(*reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(Ap) + arow[j] + k));
+            else f.av[g][j] = *reinterpret_cast<const float4*>(static_cast<const float*>(Ap) + arow[j] + k);
+            if (MK && k0 >= kmax) f.av[g][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) f.bv[g][q] = *reinterpret_cast<const float4*>(W + (long long)(k + q) * ldw + ncol);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) f.bv[q] = *reinterpret_cast<const float4*>(W + (long long)(k + q) * ldw + ncol);
       },
-      [&](const SkFrag<RT, 4>& f) {
+      [&](const auto& f) {
+        constexpr int NGf = std::remove_reference_t<decltype(f)>::NG;
 #pragma unroll
-        for (int j = 0; j < RT; ++j) {
-          float aq[4];
-          if constexpr (U8) {
-            const unsigned w = __float_as_uint(f.av[j].x);
-            aq[0] = (float)(w & 0xffu); aq[1] = (float)((w >> 8) & 0xffu); aq[2] = (float)((w >> 16) & 0xffu); aq[3] = (float)(w >> 24);
-          } else {
-            aq[0] = f.av[j].x; aq[1] = f.av[j].y; aq[2] = f.av[j].z; aq[3] = f.av[j].w;
-          }
+        for (int g = 0; g < NGf; ++g)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[q].x, acc[j][0], 0, 0, 0);
-            acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[q].y, acc[j][1], 0, 0, 0);
-            acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[q].z, acc[j][2], 0, 0, 0);
-            acc[j][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[q].w, acc[j][3], 0, 0, 0);
+          for (int j = 0; j < RT; ++j) {
+            float aq[4];
+            if constexpr (U8) {
+              const unsigned w = __float_as_uint(f.av[g][j].x);
+              aq[0] = (float)(w & 0xffu); aq[1] = (float)((w >> 8) & 0xffu); aq[2] = (float)((w >> 16) & 0xffu); aq[3] = (float)(w >> 24);
+            } else {
+              aq[0] = f.av[g][j].x; aq[1] = f.av[g][j].y; aq[2] = f.av[g][j].z; aq[3] = f.av[g][j].w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[g][q].x, acc[j][0], 0, 0, 0);
+              acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[g][q].y, acc[j][1], 0, 0, 0);
+              acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[g][q].z, acc[j][2], 0, 0, 0);
+              acc[j][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[g][q].w, acc[j][3], 0, 0, 0);
+            }
           }
-        }
       });
     return;
   }
@@ -246,28 +264,36 @@ __device__ __forceinline__ void sk_nt(const float* __restrict__ A, const long lo
                                       const int (&wrow)[NU], const int kg_lo, const int kg_hi, const int wave, const int lk,
                                       f32x4 (&acc)[RT][4], const int kmax = 0) {
   if constexpr (RT > 1) {
-    sk_pipe<SkFrag<RT, NU>>(kg_lo, kg_hi, wave,
-      [&](SkFrag<RT, NU>& f, const int kgi) {
-        const int k0 = 16 * kgi + 4 * lk;
-        const int k = MK ? min(k0, kmax - 4) : k0;
+    sk_pipe<RT, NU>(kg_lo, kg_hi, wave,
+      [&](auto& f, const int kgi) {
+        constexpr int NGf = std::remove_reference_t<decltype(f)>::NG;
 #pragma unroll
-        for (int j = 0; j < RT; ++j) {
-          f.av[j] = *reinterpret_cast<const float4*>(A + arow[j] + k);
-          if (MK && k0 >= kmax) f.av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int g = 0; g < NGf; ++g) {
+          const int k0 = 16 * (kgi + g * kSkWaves) + 4 * lk;
+          const int k = MK ? min(k0, kmax - 4) : k0;
 #pragma unroll
-        for (int t = 0; t < NU; ++t) f.bv[t] = *reinterpret_cast<const float4*>(W + (long long)wrow[t] * ldw + k);
-      },
-      [&](const SkFrag<RT, NU>& f) {
-#pragma unroll
-        for (int j = 0; j < RT; ++j)
-#pragma unroll
-          for (int t = 0; t < NU; ++t) {
-            acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.av[j].x, f.bv[t].x, acc[j][t], 0, 0, 0);
-            acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.av[j].y, f.bv[t].y, acc[j][t], 0, 0, 0);
-            acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.av[j].z, f.bv[t].z, acc[j][t], 0, 0, 0);
-            acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.av[j].w, f.bv[t].w, acc[j][t], 0, 0, 0);
+          for (int j = 0; j < RT; ++j) {
+            f.av[g][j] = *reinterpret_cast<const float4*>(A + arow[j] + k);
+            if (MK && k0 >= kmax) f.av[g][j] = make_float4(0.f, 0.f, 0.f, 0.f);
           }
+#pragma unroll
+          for (int t = 0; t < NU; ++t) f.bv[g][t] = *reinterpret_cast<const float4*>(W + (long long)wrow[t] * ldw + k);
+        }
+      },
+      [&](const auto& f) {
+        constexpr int NGf = std::remove_reference_t<decltype(f)>::NG;
+#pragma unroll
+        for (int g = 0; g < NGf; ++g)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)                // (contraction step outermost: consecutive MFMAs never share an accumulator)
+#pragma unroll
+            for (int j = 0; j < RT; ++j)
+#pragma unroll
+              for (int t = 0; t < NU; ++t) {
+                const float av = q == 0 ? f.av[g][j].x : q == 1 ? f.av[g][j].y : q == 2 ? f.av[g][j].z : f.av[g][j].w;
+                const float bv = q == 0 ? f.bv[g][t].x : q == 1 ? f.bv[g][t].y : q == 2 ? f.bv[g][t].z : f.bv[g][t].w;
+                acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j][t], 0, 0, 0);
+              }
       });
     return;
   }
@@ -802,6 +828,258 @@ __global__ __launch_bounds__(256) void sk_ybwd(const SkArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) v += dk[k] * wy[i][k];
     if (tid + 256 * i < H) st1o(a.dhy + (long long)row * H + tid + 256 * i, hv[i] > 0.f ? v : 0.f);
+  }
+  SK_STAMP(8, 3);
+}
+
+// ---- the y path at batches of more than 768 rows: R = 2 or 4 rows per workgroup.  One workgroup per row re-reads the three small
+// weight matrices' entries (~100 scalar loads per thread) for every row and at B = 1024 ran in two rounds of workgroups (F2
+// 15.5 us, B4 12.3 us of a 145 us step); here they are loaded once for R rows, the R x 16 block sums share one barrier, and the R
+// rows' softmax work runs side by side in wave 0's R DPP rows (lane 16 j + k: row j, component k).
+template <int R>
+__device__ __forceinline__ float sk_block_sum16r(const float (&p)[R][16], float* __restrict__ sh /* [R][16][16] */, const int tid) {
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float v = row16_sum(p[j][k]);
+      if ((tid & 15) == 15) sh[j * 256 + k * 16 + (tid >> 4)] = v;
+    }
+  __syncthreads();
+  float tot = 0.f;
+  if (tid < 16 * R) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += sh[(tid >> 4) * 256 + (tid & 15) * 16 + i];
+  }
+  return tot;                                      // thread 16 j + k: row j's k-th total
+}
+
+template <int NI, int R>
+__global__ __launch_bounds__(256) void sk_ypath_r(const SkArgs a) {
+  __shared__ float rsh[R * 256], ysh[R * 16], ush[R * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int B = a.B, H = a.H, L = a.L, K = a.K, H2 = 2 * H, L2 = 2 * L;
+  const int nwr = (B + R - 1) / R;                // workgroups that carry rows
+  if ((int)blockIdx.x >= nwr) {                   // extra workgroups: the eps rows (as sk_ypath)
+    const unsigned long long step = a.step_dev ? a.step_dev[0] : a.step;
+    const int qe = (L + 3) / 4;
+    const long long i = (long long)(blockIdx.x - nwr) * 256 + tid;
+    if (i < (long long)B * qe) {
+      const int r = (int)(i / qe), quad = (int)(i - (long long)r * qe);
+      float nz[4];
+      noise_vals(a.row0 + (unsigned long long)r, (unsigned)quad, false, a.seed, step, nz);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (quad * 4 + j < L) st1o(a.eps_w + (long long)r * L + quad * 4 + j, nz[j]);
+    }
+    return;
+  }
+  const int row0 = blockIdx.x * R;
+  const float* const P = a.P;
+  SK_STAMP(1, 0);
+  const unsigned long long step = a.step_dev ? a.step_dev[0] : a.step;
+  if (blockIdx.x == 0 && tid == 0 && a.step_dev) a.step_dev[1] = step;       // the copy the W launch reads
+  // ---- all loads: the weights once, the slabs of R rows
+  float sy[R][NI], sg[R][NI], by[NI], bg[NI], wy[NI][16], wg[NI][16], wp[2][16], bp[2];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = min(tid + 256 * i, H - 1);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const long long rj = min(row0 + j, B - 1);
+      float t = 0.f, g2 = 0.f;
+      for (int s2 = 0; s2 < a.ns1; ++s2) {          // (one slab at these batch sizes)
+        const long long o = ((long long)s2 * B + rj) * H2 + c;
+        t += a.s1[o]; g2 += a.s1[o + H];
+      }
+      sy[j][i] = t; sg[j][i] = g2;
+    }
+    by[i] = P[a.by0 + c];
+    bg[i] = P[a.bg0 + c];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int kc = min(k, K - 1);
+      wy[i][k] = P[a.Wy1 + (long long)c * K + kc];
+      wg[i][k] = P[a.Wg0 + (long long)(a.D + kc) * H + c];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int jc = min(tid + 256 * j, L2 - 1);
+    bp[j] = P[a.bp + jc];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wp[j][k] = P[a.Wp + (long long)min(k, K - 1) * L2 + jc];
+  }
+  const int sj = lane >> 4, sk = lane & 15;       // wave 0: lane 16 j + k works on (row j, component k)
+  const long long srow = min(row0 + sj, B - 1);
+  const float b1v = P[a.by1 + min(sk, K - 1)];
+  const float u_ext = a.gen_u ? 0.5f : a.u[srow * K + min(sk, K - 1)];
+  // ---- the rows' uniforms (wave 3)
+  const int nq = (K + 3) / 4;
+  if (a.gen_u && tid >= 192 && tid - 192 < R * nq) {
+    const int j = (tid - 192) / nq, quad = (tid - 192) - j * nq;
+    if (row0 + j < B) {
+      float nz[4];
+      noise_vals(a.row0 + (unsigned long long)(row0 + j), (unsigned)quad, true, a.seed, step, nz);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (quad * 4 + q < K) { st1o(a.u_w + (long long)(row0 + j) * K + quad * 4 + q, nz[q]); ush[j * 16 + quad * 4 + q] = nz[q]; }
+    }
+  }
+  float p[R][16], gx[R][NI];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p[j][k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const bool on = tid + 256 * i < H;
+      const float t = on ? fmaxf(sy[j][i] + by[i], 0.f) : 0.f;
+      gx[j][i] = sg[j][i] + bg[i];
+      if (on && row0 + j < B) st1o(a.hy + (long long)(row0 + j) * H + tid + 256 * i, t);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) p[j][k] += t * wy[i][k];
+    }
+  }
+  SK_STAMP(1, 1);
+  const float ptot = sk_block_sum16r<R>(p, rsh, tid);      // (its barrier also publishes ush)
+  SK_STAMP(1, 2);
+  if (wave == 0 && lane < 16 * R) {
+    const bool rv = row0 + sj < B;
+    const bool kv = sk < K;
+    const float lg = kv ? ptot + b1v : -INFINITY;
+    const float uu = kv && rv ? (a.gen_u ? ush[sj * 16 + sk] : u_ext) : 0.5f;
+    const float av = kv ? (lg - flog(-flog(uu))) * a.invT : -INFINITY;
+    const float mx = row16_max(av), m2 = row16_max(lg);
+    const float se = row16_sum(kv ? fexp(av - mx) : 0.f), s2 = row16_sum(kv ? fexp(lg - m2) : 0.f);
+    const float lse = mx + flog(se), l2 = m2 + flog(s2);
+    float yv = 0.f, ne = 0.f;
+    if (kv) {
+      yv = fexp(av - lse);
+      const float lp = lg - l2;
+      ne = fexp(lp) * lp;
+      if (rv) st1o(a.logits + srow * K + sk, lg);
+    }
+    ne = row16_sum(ne);
+    if (rv && sk < a.K4) st1o(a.y + srow * a.K4 + sk, yv);       // rows of pad4(K) floats, the padding zero
+    if (rv && sk == 0) st1o(a.nent + srow, ne);
+    ysh[sj * 16 + sk] = yv;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    if (row0 + j >= B) break;
+    float yk[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) yk[k] = ysh[j * 16 + k];      // (zero for k >= K)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float v = gx[j][i];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v += yk[k] * wg[i][k];
+      if (tid + 256 * i < H) st1o(a.hg + (long long)(row0 + j) * H + tid + 256 * i, fmaxf(v, 0.f));
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float v = bp[q];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v += yk[k] * wp[q][k];
+      if (tid + 256 * q < L2) st1o(a.pp + (long long)(row0 + j) * L2 + tid + 256 * q, v);
+    }
+  }
+  SK_STAMP(1, 3);
+}
+
+template <int NI, int R>
+__global__ __launch_bounds__(256) void sk_ybwd_r(const SkArgs a) {
+  __shared__ float rsh[R * 256], dls[R * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int B = a.B, H = a.H, L2 = 2 * a.L, K = a.K;
+  const int row0 = blockIdx.x * R;
+  const float* const P = a.P;
+  SK_STAMP(8, 0);
+  float dg[R][NI], hv[R][NI], wy[NI][16], wg[NI][16], wp[2][16], dp[R][2];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = min(tid + 256 * i, H - 1);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const long long rj = min(row0 + j, B - 1);
+      dg[j][i] = a.dhg[rj * H + c];
+      hv[j][i] = a.hy[rj * H + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int kc = min(k, K - 1);
+      wy[i][k] = P[a.Wy1 + (long long)c * K + kc];
+      wg[i][k] = P[a.Wg0 + (long long)(a.D + kc) * H + c];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int jc = min(tid + 256 * q, L2 - 1);
+#pragma unroll
+    for (int j = 0; j < R; ++j) dp[j][q] = a.dpp[(long long)min(row0 + j, B - 1) * L2 + jc];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wp[q][k] = P[a.Wp + (long long)min(k, K - 1) * L2 + jc];
+  }
+  const int sj = lane >> 4, sk = lane & 15;
+  const long long srow = min(row0 + sj, B - 1);
+  const float lg_ = a.logits[srow * K + min(sk, K - 1)];
+  const float yv_ = a.y[srow * a.K4 + min(sk, K - 1)];
+  const float ne = a.nent[srow];
+  float p[R][16];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p[j][k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float dv = tid + 256 * i < H ? dg[j][i] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) p[j][k] += dv * wg[i][k];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float dv = tid + 256 * q < L2 ? dp[j][q] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) p[j][k] += dv * wp[q][k];
+    }
+  }
+  SK_STAMP(8, 1);
+  const float dy = sk_block_sum16r<R>(p, rsh, tid);
+  SK_STAMP(8, 2);
+  if (wave == 0 && lane < 16 * R) {
+    const bool rv = row0 + sj < B;
+    const bool kv = sk < K;
+    const float lg = kv ? lg_ : -INFINITY;
+    const float yv = kv ? yv_ : 0.f;
+    const float m2 = row16_max(lg);
+    const float s2 = row16_sum(kv ? fexp(lg - m2) : 0.f);
+    const float l2 = m2 + flog(s2);
+    const float dot = row16_sum(kv ? yv * dy : 0.f);
+    float dl = 0.f;
+    if (kv) {
+      const float lp = lg - l2;
+      dl = yv * (dy - dot) * a.invT + fexp(lp) * (lp - ne);
+    }
+    if (rv && sk < a.K4) st1o(a.dlogits + srow * a.K4 + sk, dl);      // padding columns zero
+    dls[sj * 16 + sk] = dl;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    if (row0 + j >= B) break;
+    float dk[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dk[k] = dls[j * 16 + k];      // (zero for k >= K)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v += dk[k] * wy[i][k];
+      if (tid + 256 * i < H) st1o(a.dhy + (long long)(row0 + j) * H + tid + 256 * i, hv[j][i] > 0.f ? v : 0.f);
+    }
   }
   SK_STAMP(8, 3);
 }

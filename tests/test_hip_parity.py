@@ -570,6 +570,13 @@ SKINNY_CASES = [
     ("vae_gmp", O.Dims(D=784, L=128, K=10, hidden=(512,)), 64),
     ("vae_gmp", O.Dims(D=256, L=20, K=7, hidden=(128,), sigma_min=0.6, raw_sigma_bias=0.25), 45),
     ("vae_gmp", O.Dims(D=400, L=16, K=80, hidden=(64,)), 30),                                    # K > 64: the tiled mixture log-density
+    # above 128 rows: groups of 2 / 4 row tiles per workgroup, 64-column tiles for the D-wide layers, [64 x 64] W tiles (one launch,
+    # or two batch shares + the optimizer launch), two rows per workgroup on the y path -- ragged in rows, columns and shares
+    ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(512,)), 1000),                                   # BASELINE configs[2] at H = 512, ragged
+    ("gmvae", O.Dims(D=400, L=20, K=7, hidden=(512,), temperature=0.7), 900),                    # ragged 64-column tile, W in one launch
+    ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(1024,)), 520),                                  # H = 1024: W in two launches, ragged shares
+    ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(512,)), 530),
+    ("vae", O.Dims(D=784, L=16, K=1, hidden=(320,)), 700),
 ]
 
 
@@ -588,6 +595,19 @@ def _random_skinny_cases(n, seed):
 
 
 RANDOM_SKINNY_CASES = _random_skinny_cases(15, 20261005)
+
+
+def test_skinny_schedule_beyond_its_default_batch_bound(H, monkeypatch):
+    """GMVAE_SKINNY_MAXB raises the schedule's batch bound (tools/sk_sweep.py): at 1600 rows the y path carries four rows per
+    workgroup, and the last workgroup's rows are ragged."""
+    monkeypatch.setenv("GMVAE_SKINNY_MAXB", "4096")
+    name, d, B = "gmvae", O.Dims(D=256, L=32, K=10, hidden=(256,)), 1598
+    model = O.MODEL_NAMES[name]
+    assert _L().step_schedule(H.dims_of(d, B), model) == "skinny"
+    rng = np.random.default_rng(B)
+    p = O.init_params(model, d, rng)
+    x, eps, u = O.make_inputs(d, B, model)
+    H.compare_step(model, d, p, x, eps, u)
 
 
 @pytest.mark.parametrize("name,d,B", RANDOM_SKINNY_CASES, ids=[f"{n}-D{d.D}-L{d.L}-K{d.K}-H{d.hidden[0]}-B{B}" for n, d, B in RANDOM_SKINNY_CASES])

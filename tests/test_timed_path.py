@@ -32,11 +32,9 @@ def _noise(L, rows, Lz, K, row_base, seed, step, want_u):
     return eps.cpu().numpy(), (u.cpu().numpy() if want_u else None)
 
 
-NETS = {O.MODEL_GMVAE: (("encoder_y", "he", False), ("encoder_gmm", "hg", True), ("decoder", "hd", True)),
-        O.MODEL_VAE: (("encoder", "he", False), ("decoder", "hd", True)),
-        O.MODEL_VAE_GMP: (("encoder", "he", False), ("decoder", "hd", True))}
-PRE_TOL = 1e-5         # a ReLU may take the other side than in fp64 only where |pre-activation| <= PRE_TOL * sum_k |a_k| |w_kj|
-                       # (measured over all cases: 6 such units in 5 of 60 trajectories, the largest ratio 5.0e-7)
+from hip_util import NETS, PRE_TOL      # (the nets' workspace tags; a ReLU may take the other side than in fp64 only where
+                                        #  |pre-activation| <= PRE_TOL * sum_k |a_k| |w_kj|: measured over all cases, 6 such
+                                        #  units in 5 of 60 trajectories, the largest ratio 5.0e-7)
 FLIPS = []             # (case, step, net, |pre| / sum |a||w|) of every unit where the device's ReLU mask differs from fp64's
 
 
