@@ -449,10 +449,15 @@ def main():
         dur = (lambda l: l[3]) if have_tl else (lambda l: l[1])
         gemms = [l for l in levels if l[2] > 0]          # launches that do MFMA work (grouped GEMMs, mega kernel)
         dom = max(gemms, key=dur)
-        SK_KERNELS = {"sk_first_layers": "void gmvae::sk_gemm<0>", "sk_first_layer": "void gmvae::sk_gemm<0>", "sk_q_head_z": "void gmvae::sk_gemm<1>", "sk_dec_hidden": "void gmvae::sk_gemm<2>",
-                      "sk_dec_bernoulli": "void gmvae::sk_gemm<3>", "sk_bwd_dhd": "void gmvae::sk_gemm<4>", "sk_bwd_dz_heads": "void gmvae::sk_gemm<5>",
-                      "sk_bwd_dhg": "void gmvae::sk_gemm<6>", "sk_y_path": "void gmvae::sk_ypath<", "sk_y_path_bwd": "void gmvae::sk_ybwd<",
-                      "sk_dw_adam": "gmvae::sk_dw", "sk_dw": "gmvae::sk_dw"}
+        # skinny.hpp: sk_gemm<stage, row tiles per workgroup>; the D-wide layers have a 64-column form (stages 7, 8); the y path a
+        # rows-per-workgroup form; the W stage is sk_dw, sk_dwb, or sk_dwc + sk_adam (two launches: their times add)
+        SK_KERNELS = {"sk_first_layers": ["void gmvae::sk_gemm<0, "], "sk_first_layer": ["void gmvae::sk_gemm<0, "], "sk_q_head_z": ["void gmvae::sk_gemm<1, "],
+                      "sk_dec_hidden": ["void gmvae::sk_gemm<2, "], "sk_dec_bernoulli": ["void gmvae::sk_gemm<3, ", "void gmvae::sk_gemm<7, "],
+                      "sk_bwd_dhd": ["void gmvae::sk_gemm<4, ", "void gmvae::sk_gemm<8, "], "sk_bwd_dz_heads": ["void gmvae::sk_gemm<5, "],
+                      "sk_bwd_dhg": ["void gmvae::sk_gemm<6, "], "sk_y_path": ["void gmvae::sk_ypath<", "void gmvae::sk_ypath_r<"],
+                      "sk_y_path_bwd": ["void gmvae::sk_ybwd<", "void gmvae::sk_ybwd_r<"],
+                      "sk_dw_adam": ["gmvae::sk_dw", "gmvae::sk_dwb", "gmvae::sk_dwc", "gmvae::sk_adam"],
+                      "sk_dw": ["gmvae::sk_dw", "gmvae::sk_dwb", "gmvae::sk_dwc", "gmvae::sk_adam"]}
         step_flops = flops_per_step(a.model, d.D, d.L, d.K, hidden, d.S, B)
         # Bytes_alg(step) = B D (uint8 batch) + 9 * 4 P (read params; write grads; Adam reads p, m, v, g and
         # writes p, m, v); noise is generated in-kernel
@@ -491,9 +496,10 @@ def main():
             roof.update({"peak": pk, "frac": roof["achieved"] / pk, "frac_in_kernel_span": dom[2] / dom[1] * 1e-6 / pk,
                          "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product; fp32 accumulation",
                          "frac_of_f32_mfma_peak": roof["achieved"] / PEAK_F32_MFMA_TFLOPS})
-        if dom[0].startswith("sk_dw"):
-            # the skinny schedule's longest launch is the weight-gradient + TF-Adam launch: bound by HBM, not by the matrix
-            # pipes -- algorithmic bytes = 7 x 4 P (p, m, v in; p, m, v and the gradient out), SURVEY.md 8(d)'s optimizer term
+        if dom[0].startswith("sk_dw") and 28.0 * eng.P_real / (PEAK_HBM_GBS * 1e9) >= dom[2] / (PEAK_F32_MFMA_TFLOPS * 1e12):
+            # the skinny schedule's longest launch is the weight-gradient + TF-Adam launch: at small batches bound by HBM, not by
+            # the matrix pipes -- algorithmic bytes = 7 x 4 P (p, m, v in; p, m, v and the gradient out), SURVEY.md 8(d)'s
+            # optimizer term.  (From a few hundred rows its fp32 MFMA time exceeds that: the default "mfma" pricing stands.)
             w_bytes = 28.0 * eng.P_real
             roof.update({"bound": "hbm", "achieved": w_bytes / dur(dom) * 1e-3, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": w_bytes / dur(dom) * 1e-3 / PEAK_HBM_GBS, "bytes_per_launch": w_bytes,
@@ -520,13 +526,15 @@ def main():
                     return False
                 kn = kn[5:] if kn.startswith("void ") else kn
                 k = k[5:] if k.startswith("void ") else k
-                return k.startswith(kn) and (kn.endswith(">") or kn.endswith("<") or k[len(kn):len(kn) + 1] in ("(", "<", " "))
-            kname = ("gmvae::" + dom[0]) if dom[0].startswith(("mega", "dw_")) else SK_KERNELS.get(dom[0])
-            hit = [k for k in kern_us if is_kernel(k, kname)]
+                return k.startswith(kn) and (kn.endswith((">", "<", ", ")) or k[len(kn):len(kn) + 1] in ("(", "<", " "))
+            knames = ["gmvae::" + dom[0]] if dom[0].startswith(("mega", "dw_")) else SK_KERNELS.get(dom[0], [])
+            hit = [k for k in kern_us if any(is_kernel(k, kn) for kn in knames)]
             if hit:
-                roof["rocprof_usec_per_launch"] = kern_us[hit[0]]
-                roof["frac_rocprof"] = (roof["bytes_per_launch"] / kern_us[hit[0]] * 1e-3 / PEAK_HBM_GBS if roof["bound"] == "hbm"
-                                        else dom[2] / kern_us[hit[0]] * 1e-6 / roof["peak"])
+                us = sum(kern_us[k] for k in hit)       # (one kernel, or the W stage's two launches)
+                roof["rocprof_usec_per_launch"] = us
+                roof["rocprof_kernels"] = hit
+                roof["frac_rocprof"] = (roof["bytes_per_launch"] / us * 1e-3 / PEAK_HBM_GBS if roof["bound"] == "hbm"
+                                        else dom[2] / us * 1e-6 / roof["peak"])
             pl = [k for k in kern_us if k.startswith("void gmvae::gemm_grouped<gmvae::Cfg<128, 128, 32, 2, 2, 1, 2>, 0, 2>")]
             if not hit and pl and schedule.endswith("+planes") and dom[0] in ("fwd_dec_bernoulli", "bwd_dec_top"):
                 # the plane instance runs exactly two launches per step (logits + Bernoulli; weight and data gradient): the
@@ -541,10 +549,9 @@ def main():
                 roof["traffic_source"] = os.path.relpath(traf[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, separate passes)"
                 per = {}
                 for nm, _, _, _ in levels:
-                    kn = SK_KERNELS.get(nm, "gmvae::" + nm)
-                    k2 = [k for k in tj if is_kernel(k, kn)]
+                    k2 = [k for k in tj if any(is_kernel(k, kn) for kn in SK_KERNELS.get(nm, ["gmvae::" + nm]))]
                     if k2:
-                        per[nm] = tj[k2[0]]["hbm_bytes_per_launch"]
+                        per[nm] = sum(tj[k]["hbm_bytes_per_launch"] for k in k2)
                 if dom[0] in per:
                     roof["traffic"] = per[dom[0]]
                 if len(per) == len(levels):            # every launch of the step is in the PMC record: whole-step traffic

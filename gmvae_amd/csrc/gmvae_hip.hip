@@ -216,8 +216,9 @@ static bool skinny_shape(const GmvaeDims& d, int model) {
   // column-local: its log-density, its share of dz and its variables' gradients stay three row kernels: eleven launches)
   if (d.n_hidden != 1 || d.S != 1) return false;
   const int H = d.hidden[0];
-  // measured against the general schedule at H = 256 / 512, L = 128 (tools/sk_sweep.py, one box): 2.9x faster at B = 32..64,
-  // 2.2x at 256, 1.7x at 512, 1.2 - 1.4x at 1024; not measured beyond
+  // measured against the general schedule at H = 128 / 256 / 512, L = 128 (tools/sk_sweep.py, one box): 2.9x faster at B = 32..64,
+  // 2.4 - 2.6x at 256, 1.9 - 2.1x at 512, 1.8 - 1.9x at 1024, 1.5 - 1.6x at 2048, 1.2 - 1.4x at 4096 (round 4: the forms for
+  // more than 128 rows -- row-tile groups, 64-column tiles, [64 x 64] W tiles)
   // (L a multiple of 4: 16-byte loads along latent rows; a ragged last tile of 16 latent dimensions is masked)
   // (K <= 16: the y path's per-row softmax in 16 lanes -- GMVAE only; the mixture prior's K is the row kernels' business)
   return H % 64 == 0 && H <= 1024 && d.D % 16 == 0 && d.L % 4 == 0 && d.L >= 4 && d.L <= 256 &&
@@ -226,7 +227,7 @@ static bool skinny_shape(const GmvaeDims& d, int model) {
 static bool skinny_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_SKINNY");
   if (e && atoi(e)) return false;
-  int maxb = 1024;
+  int maxb = kSkMaxB;
   if (const char* mb = getenv("GMVAE_SKINNY_MAXB")) maxb = atoi(mb) < kSkMaxB ? atoi(mb) : kSkMaxB;     // (tools/sk_sweep.py)
   return skinny_shape(d, model) && d.B <= maxb;
 }

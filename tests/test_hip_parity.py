@@ -597,11 +597,12 @@ def _random_skinny_cases(n, seed):
 RANDOM_SKINNY_CASES = _random_skinny_cases(15, 20261005)
 
 
-def test_skinny_schedule_beyond_its_default_batch_bound(H, monkeypatch):
-    """GMVAE_SKINNY_MAXB raises the schedule's batch bound (tools/sk_sweep.py): at 1600 rows the y path carries four rows per
-    workgroup, and the last workgroup's rows are ragged."""
-    monkeypatch.setenv("GMVAE_SKINNY_MAXB", "4096")
+def test_skinny_schedule_four_rows_per_y_path_workgroup(H, monkeypatch):
+    """Above 1536 rows the y path carries four rows per workgroup; here the last workgroup's rows are ragged.  (The schedule's
+    batch bound is 4096 rows: beyond, the general schedule.)"""
+    monkeypatch.setenv("GMVAE_NO_MEGA", "1")
     name, d, B = "gmvae", O.Dims(D=256, L=32, K=10, hidden=(256,)), 1598
+    assert _L().step_schedule(H.dims_of(d, 4097), O.MODEL_NAMES[name]) == "general"
     model = O.MODEL_NAMES[name]
     assert _L().step_schedule(H.dims_of(d, B), model) == "skinny"
     rng = np.random.default_rng(B)

@@ -24,8 +24,8 @@ for _ in range(5):
 ms.sort()
 print(ms[len(ms) // 2] * 1e3)
 ''' % root
-for H in (512, 256):
-    for B in (32, 64, 128, 256, 512, 1024):
+for H in [int(h) for h in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("512", "256"))]:
+    for B in [int(b) for b in (sys.argv[2].split(",") if len(sys.argv) > 2 else "32,64,128,256,512,1024".split(","))]:
         row = []
         for env in ({"GMVAE_SKINNY_MAXB": "4096"}, {"GMVAE_NO_SKINNY": "1"}):
             p = subprocess.run([sys.executable, "-c", code, str(B), str(H)], env=dict(os.environ, **env), capture_output=True, text=True)
