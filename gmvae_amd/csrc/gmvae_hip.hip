@@ -1404,8 +1404,9 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   s.ln_b1 = (float)log((double)a.beta1); s.ln_b2 = (float)log((double)a.beta2);
   s.tail = a.grads + L.P_pad; s.tail_log = a.tail_log;
   s.logpx = w.logpx; s.logq = w.logq; s.logp = w.logp; s.logw = w.logw;
-  // the W stage's form: up to 128 batch rows sk_dw (one-wave tiles); above, [64 x 64] tiles: one workgroup each (sk_dwb), or
-  // -- from 512 rows, with more tiles than CUs -- two batch shares each and the optimizer in a launch of its own (sk_dwc + sk_adam)
+  // the W stage's form: up to 128 batch rows sk_dw (one-wave tiles); above, [64 x 64] tiles: one workgroup each (sk_dwb<1>: bf16
+  // pieces, one per CU at its 170 registers; more tiles than CUs: sk_dwb<0>, fp32 matrix instructions, two per CU) or -- more
+  // tiles than CUs and at least 512 rows -- two batch shares each and the optimizer in a launch of its own (sk_dwc + sk_adam)
   const bool dw_big = B > 128;
   auto add = [&](const void* A, bool u8, int lda, const float* dY, int ldy, int M, int N, uint64_t w_off, long long b_off) {
     SkTensor& T = s.t[s.ntens++];
@@ -1474,7 +1475,7 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
     double fw = 0;
     for (int i = 0; i < s.ntens; ++i) fw += 2.0 * s.t[i].M * s.t[i].N * B;
     const int gmp_wgs = s.gmp_part ? (s.gmp_len + kSkThreads - 1) / kSkThreads : 0;      // (sk_dw derives the same count)
-    if (dw_big && B >= 512 && s.total_tiles > 256) {
+    if (dw_big && s.total_tiles > 256 && B >= 512) {
       s.dwp = w.slabs; s.dwp_stride = (long long)L.P_pad; s.dw_ks = kSkDwShares;
       s.nseg = 0;
       int wgs = 0;
@@ -1492,7 +1493,7 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
       hipLaunchKernelGGL(sk_dwc, dim3(8 * ((s.total_tiles * s.dw_ks + 7) / 8) + 1 + gmp256), dim3(kDwcThreads), 0, st, s);
       cx.check();
       hipLaunchKernelGGL(sk_adam, dim3(wgs), dim3(256), 0, st, s);
-    } else if (dw_big) hipLaunchKernelGGL(sk_dwb, dim3(8 * ((s.total_tiles + 7) / 8) + 1 + gmp_wgs), dim3(kSkThreads), 0, st, s);
+    } else if (dw_big) hipLaunchKernelGGL(s.total_tiles > 256 ? sk_dwb<0> : sk_dwb<1>, dim3(8 * ((s.total_tiles + 7) / 8) + 1 + gmp_wgs), dim3(kSkThreads), 0, st, s);
     else hipLaunchKernelGGL(sk_dw, dim3((s.total_tiles + kSkWaves - 1) / kSkWaves + 1 + gmp_wgs), dim3(kSkThreads), 0, st, s);
     cx.check();
     cx.mark(s.ap ? "sk_dw_adam" : "sk_dw", fw);

@@ -108,36 +108,91 @@ __device__ __forceinline__ void sk_groups(const int kg_lo, const int kg_hi, cons
 template <int RT> constexpr int sk_maxg() { return RT == 1 ? 4 : RT == 2 ? 2 : 1; }
 // RT > 1: one group per stage, two register sets: the next group's loads are in flight under this group's RT x as many MFMAs.
 // (Stages of two groups at RT = 2 measured neutral -- 160 VGPRs, one workgroup per CU -- and were dropped.)
-template <int RT, int NB, int NG_> struct SkFrag { static constexpr int NG = NG_; float4 av[NG_][RT]; float4 bv[NG_][NB]; };
-template <int RT, int NB, class LD, class MM>
+template <int RT, int NB> struct SkFrag { float4 av[RT]; float4 bv[NB]; };
+template <class Frag, class LD, class MM>
 __device__ __forceinline__ void sk_pipe(const int kg_lo, const int kg_hi, const int wave, LD&& ld, MM&& mm) {
-  constexpr int NG = 1;
   const int kg = kg_lo + wave;
   const int n = kg < kg_hi ? (kg_hi - kg + kSkWaves - 1) / kSkWaves : 0;
-  const int ns = n / NG;
-  if (ns > 0) {
-    SkFrag<RT, NB, NG> fa, fb;
-    ld(fa, kg);
-    int i = 0;
-    for (; i + 2 <= ns; i += 2) {
-      ld(fb, kg + kSkWaves * NG * (i + 1));
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fa);
-      __builtin_amdgcn_sched_barrier(0);
-      if (i + 2 < ns) ld(fa, kg + kSkWaves * NG * (i + 2));
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fb);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (i < ns) mm(fa);
+  if (n == 0) return;
+  Frag fa, fb;
+  ld(fa, kg);
+  int i = 0;
+  for (; i + 2 <= n; i += 2) {
+    ld(fb, kg + kSkWaves * (i + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fa);
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + 2 < n) ld(fa, kg + kSkWaves * (i + 2));
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fb);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  if constexpr (NG > 1) {
-    for (int g = ns * NG; g < n; ++g) {
-      SkFrag<RT, NB, 1> f;
-      ld(f, kg + kSkWaves * g);
-      mm(f);
-    }
+  if (i < n) mm(fa);
+}
+// 8 fp32 values -> their three bf16 pieces (truncation splits with exact residuals: hi + mid + lo == v bit for bit, dwadam.hpp),
+// packed pairwise: elements 2 j, 2 j + 1 in word j of each piece's MFMA operand
+typedef unsigned sk_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 sk_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void sk_split8(const float (&v)[8], sk_u32x4& h, sk_u32x4& m, sk_u32x4& l) {
+#pragma unroll
+  for (int jp = 0; jp < 4; ++jp) {
+    const float v0 = v[2 * jp], v1 = v[2 * jp + 1];
+    h[jp] = pack_hi16(v1, v0);
+    const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u), r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
+    m[jp] = pack_hi16(r1, r0);
+    const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    l[jp] = pack_hi16(s1, s0);
   }
+}
+// F1 above 128 rows (RT > 1): the uint8 batch times an fp32 weight on the bf16 matrix cores, exact as dw_adam's uint8 problems
+// (dwadam.hpp): x is exact in bf16 and W = hi + mid + lo, so a group of 32 contraction steps is 3 v_mfma_f32_16x16x32_bf16 (16
+// cycles) per [16 x 16] block instead of 8 v_mfma_f32_16x16x4_f32 (32 cycles); the lane's 8 steps are x[row][32 g + 8 lk ..
+// + 7] (one 8-byte load) and W[32 g + 8 lk + e][4 strided columns] (8 16-byte loads, split into pieces beside the MFMAs).
+// kmax (a multiple of 16): the last group may be half empty -- its addresses are clamped and its A values zero.
+template <int RT> struct SkFragB { uint2 aw[RT]; float4 bv[8]; };
+template <int RT>
+__device__ __forceinline__ void sk_nn4_u8bf(const unsigned char* __restrict__ X, const long long (&arow)[RT], const float* __restrict__ W,
+                                            const int ldw, const int ncol, const int g_lo, const int g_hi, const int wave, const int lk,
+                                            const int kmax, f32x4 (&acc)[RT][4]) {
+  sk_pipe<SkFragB<RT>>(g_lo, g_hi, wave,
+    [&](SkFragB<RT>& f, const int gi) {
+      const int k0 = 32 * gi + 8 * lk;
+      const int k = min(k0, kmax - 8);
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        f.aw[j] = *reinterpret_cast<const uint2*>(X + arow[j] + k);
+        if (k0 >= kmax) f.aw[j] = make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f.bv[e] = *reinterpret_cast<const float4*>(W + (long long)(k + e) * ldw + ncol);
+    },
+    [&](const SkFragB<RT>& f) {
+      sk_bf16x8 A[RT];
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        sk_u32x4 w;
+        w[0] = pack_hi16((float)((f.aw[j].x >> 8) & 0xffu), (float)(f.aw[j].x & 0xffu));
+        w[1] = pack_hi16((float)(f.aw[j].x >> 24), (float)((f.aw[j].x >> 16) & 0xffu));
+        w[2] = pack_hi16((float)((f.aw[j].y >> 8) & 0xffu), (float)(f.aw[j].y & 0xffu));
+        w[3] = pack_hi16((float)(f.aw[j].y >> 24), (float)((f.aw[j].y >> 16) & 0xffu));
+        A[j] = __builtin_bit_cast(sk_bf16x8, w);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = t == 0 ? f.bv[e].x : t == 1 ? f.bv[e].y : t == 2 ? f.bv[e].z : f.bv[e].w;
+        sk_u32x4 h, m, l;
+        sk_split8(v, h, m, l);
+        const sk_bf16x8 Bh = __builtin_bit_cast(sk_bf16x8, h), Bm = __builtin_bit_cast(sk_bf16x8, m), Bl = __builtin_bit_cast(sk_bf16x8, l);
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+          acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j], Bl, acc[j][t], 0, 0, 0);      // smallest pieces first
+          acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j], Bm, acc[j][t], 0, 0, 0);
+          acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j], Bh, acc[j][t], 0, 0, 0);
+        }
+      }
+    });
 }
 // NN, 4 strided column tiles: out[row][n0 + 4 i + t] for lane column i: W k-major [K][ldw], one 16-byte load of W per k
 // MK: the contraction extent kmax is no multiple of 16 (a multiple of 4): quads at k >= kmax are loaded from the last valid quad
@@ -147,44 +202,37 @@ __device__ __forceinline__ void sk_nn4(const void* __restrict__ Ap, const long l
                                        const int ncol, const int kg_lo, const int kg_hi, const int wave, const int lk,
                                        f32x4 (&acc)[RT][4], const int kmax = 0) {
   if constexpr (RT > 1) {
-    sk_pipe<RT, 4>(kg_lo, kg_hi, wave,
-      [&](auto& f, const int kgi) {
-        constexpr int NGf = std::remove_reference_t<decltype(f)>::NG;
+    sk_pipe<SkFrag<RT, 4>>(kg_lo, kg_hi, wave,
+      [&](SkFrag<RT, 4>& f, const int kgi) {
+        const int k0 = 16 * kgi + 4 * lk;
+        const int k = MK ? min(k0, kmax - 4) : k0;
 #pragma unroll
-        for (int g = 0; g < NGf; ++g) {
-          const int k0 = 16 * (kgi + g * kSkWaves) + 4 * lk;
-          const int k = MK ? min(k0, kmax - 4) : k0;
-#pragma unroll
-          for (int j = 0; j < RT; ++j) {
-            if constexpr (U8) f.av[g][j].x = __uint_as_float(*reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(Ap) + arow[j] + k));
-            else f.av[g][j] = *reinterpret_cast<const float4*>(static_cast<const float*>(Ap) + arow[j] + k);
-            if (MK && k0 >= kmax) f.av[g][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) f.bv[g][q] = *reinterpret_cast<const float4*>(W + (long long)(k + q) * ldw + ncol);
+        for (int j = 0; j < RT; ++j) {
+          if constexpr (U8) f.av[j].x = __uint_as_float(*reinterpret_cast<const unsigned*>(static_cast<const unsigned char*>(Ap) + arow[j] + k));
+          else f.av[j] = *reinterpret_cast<const float4*>(static_cast<const float*>(Ap) + arow[j] + k);
+          if (MK && k0 >= kmax) f.av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.bv[q] = *reinterpret_cast<const float4*>(W + (long long)(k + q) * ldw + ncol);
       },
-      [&](const auto& f) {
-        constexpr int NGf = std::remove_reference_t<decltype(f)>::NG;
+      [&](const SkFrag<RT, 4>& f) {
 #pragma unroll
-        for (int g = 0; g < NGf; ++g)
-#pragma unroll
-          for (int j = 0; j < RT; ++j) {
-            float aq[4];
-            if constexpr (U8) {
-              const unsigned w = __float_as_uint(f.av[g][j].x);
-              aq[0] = (float)(w & 0xffu); aq[1] = (float)((w >> 8) & 0xffu); aq[2] = (float)((w >> 16) & 0xffu); aq[3] = (float)(w >> 24);
-            } else {
-              aq[0] = f.av[g][j].x; aq[1] = f.av[g][j].y; aq[2] = f.av[g][j].z; aq[3] = f.av[g][j].w;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[g][q].x, acc[j][0], 0, 0, 0);
-              acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[g][q].y, acc[j][1], 0, 0, 0);
-              acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[g][q].z, acc[j][2], 0, 0, 0);
-              acc[j][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[g][q].w, acc[j][3], 0, 0, 0);
-            }
+        for (int j = 0; j < RT; ++j) {
+          float aq[4];
+          if constexpr (U8) {
+            const unsigned w = __float_as_uint(f.av[j].x);
+            aq[0] = (float)(w & 0xffu); aq[1] = (float)((w >> 8) & 0xffu); aq[2] = (float)((w >> 16) & 0xffu); aq[3] = (float)(w >> 24);
+          } else {
+            aq[0] = f.av[j].x; aq[1] = f.av[j].y; aq[2] = f.av[j].z; aq[3] = f.av[j].w;
           }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[q].x, acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[q].y, acc[j][1], 0, 0, 0);
+            acc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[q].z, acc[j][2], 0, 0, 0);
+            acc[j][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q], f.bv[q].w, acc[j][3], 0, 0, 0);
+          }
+        }
       });
     return;
   }
@@ -264,36 +312,29 @@ __device__ __forceinline__ void sk_nt(const float* __restrict__ A, const long lo
                                       const int (&wrow)[NU], const int kg_lo, const int kg_hi, const int wave, const int lk,
                                       f32x4 (&acc)[RT][4], const int kmax = 0) {
   if constexpr (RT > 1) {
-    sk_pipe<RT, NU>(kg_lo, kg_hi, wave,
-      [&](auto& f, const int kgi) {
-        constexpr int NGf = std::remove_reference_t<decltype(f)>::NG;
+    sk_pipe<SkFrag<RT, NU>>(kg_lo, kg_hi, wave,
+      [&](SkFrag<RT, NU>& f, const int kgi) {
+        const int k0 = 16 * kgi + 4 * lk;
+        const int k = MK ? min(k0, kmax - 4) : k0;
 #pragma unroll
-        for (int g = 0; g < NGf; ++g) {
-          const int k0 = 16 * (kgi + g * kSkWaves) + 4 * lk;
-          const int k = MK ? min(k0, kmax - 4) : k0;
-#pragma unroll
-          for (int j = 0; j < RT; ++j) {
-            f.av[g][j] = *reinterpret_cast<const float4*>(A + arow[j] + k);
-            if (MK && k0 >= kmax) f.av[g][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-#pragma unroll
-          for (int t = 0; t < NU; ++t) f.bv[g][t] = *reinterpret_cast<const float4*>(W + (long long)wrow[t] * ldw + k);
+        for (int j = 0; j < RT; ++j) {
+          f.av[j] = *reinterpret_cast<const float4*>(A + arow[j] + k);
+          if (MK && k0 >= kmax) f.av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int t = 0; t < NU; ++t) f.bv[t] = *reinterpret_cast<const float4*>(W + (long long)wrow[t] * ldw + k);
       },
-      [&](const auto& f) {
-        constexpr int NGf = std::remove_reference_t<decltype(f)>::NG;
+      [&](const SkFrag<RT, NU>& f) {
 #pragma unroll
-        for (int g = 0; g < NGf; ++g)
+        for (int q = 0; q < 4; ++q)                  // (contraction step outermost: consecutive MFMAs never share an accumulator:
+#pragma unroll                                       //  40 cycles of dependent latency against 32 of issue)
+          for (int j = 0; j < RT; ++j)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)                // (contraction step outermost: consecutive MFMAs never share an accumulator)
-#pragma unroll
-            for (int j = 0; j < RT; ++j)
-#pragma unroll
-              for (int t = 0; t < NU; ++t) {
-                const float av = q == 0 ? f.av[g][j].x : q == 1 ? f.av[g][j].y : q == 2 ? f.av[g][j].z : f.av[g][j].w;
-                const float bv = q == 0 ? f.bv[g][t].x : q == 1 ? f.bv[g][t].y : q == 2 ? f.bv[g][t].z : f.bv[g][t].w;
-                acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j][t], 0, 0, 0);
-              }
+            for (int t = 0; t < NU; ++t) {
+              const float av = q == 0 ? f.av[j].x : q == 1 ? f.av[j].y : q == 2 ? f.av[j].z : f.av[j].w;
+              const float bv = q == 0 ? f.bv[t].x : q == 1 ? f.bv[t].y : q == 2 ? f.bv[t].z : f.bv[t].w;
+              acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j][t], 0, 0, 0);
+            }
       });
     return;
   }
@@ -437,7 +478,11 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     const int kg_lo = (int)((long long)kgs * ks / a.ns1), kg_hi = (int)((long long)kgs * (ks + 1) / a.ns1);
     const float* W = c0 < H ? P + a.Wy0 + c0 : P + a.Wg0 + (c0 - H);
     for (int j = 0; j < RT; ++j) arow[j] = rowc[j] * D;
-    sk_nn4<true, RT>(a.x, arow, W, H, 4 * ln, kg_lo, kg_hi, wave, lk, acc);
+    if constexpr (RT > 1) {                       // (no slabs where RT > 1: ns1 = 1)
+      sk_nn4_u8bf<RT>(a.x, arow, W, H, 4 * ln, 0, (D + 31) / 32, wave, lk, D, acc);
+    } else {
+      sk_nn4<true, RT>(a.x, arow, W, H, 4 * ln, kg_lo, kg_hi, wave, lk, acc);
+    }
   } else if constexpr (ST == SK_F3) {
     const int lc = min(ct * 16 + ln, L - 1);
     const int col[2] = {lc, L + lc};
@@ -1383,6 +1428,159 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
 }
 
 
+// The uint8 problems (dW = x^T dY: 57 % of the stage's products at H = 512) run on the bf16 matrix cores, exact, as dw_adam's
+// (dwadam.hpp dw_contract_u8x3): x is exact in bf16, dY = hi + mid + lo, so 3 v_mfma_f32_16x16x32_bf16 (16 cycles) per 32 batch
+// rows and [16 x 16] block replace 8 v_mfma_f32_16x16x4_f32 (32 cycles); contraction index (lane group h, element e) of an MFMA
+// is batch row b0 + 4 e + h -- the rows the lane's register-direct loads hold anyway.
+// One wave's share [b_lo, b_hi) of the batch rows of a [64 x 64] tile of dW = A^T dY into acc[strided row tile][strided column
+// tile] (+ the columns' sums of dY into cs where the tile carries the bias gradient): lane (ln, lk) loads 16 bytes of A (4 uint8
+// or 4 floats: rows m0 + 4 ln + i) and 16 bytes of dY (columns n0 + 4 ln + j) per batch row.
+__device__ __forceinline__ void sk_dw_contract64(const SkTensor& T, const int mac, const int nc, const int b_lo, const int b_hi,
+                                                 const int lk, const bool bias, f32x4 (&acc)[4][4], float4& cs) {
+  const int lda = T.lda, ldy = T.ldy;
+  const unsigned char* const A8 = static_cast<const unsigned char*>(T.A);
+  const float* const A32 = static_cast<const float*>(T.A);
+  if (T.a_u8) {
+    for (int b0 = b_lo; b0 < b_hi; b0 += 32) {
+      unsigned aw[8];
+      float4 bv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int b = min(b0 + 4 * e + lk, b_hi - 1);
+        aw[e] = *reinterpret_cast<const unsigned*>(A8 + (long long)b * lda + mac);
+        bv[e] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (b0 + 4 * e + lk >= b_hi) aw[e] = 0u;    // a zero A operand voids a clamped batch row
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (b0 + 4 * e + lk < b_hi) { cs.x += bv[e].x; cs.y += bv[e].y; cs.z += bv[e].z; cs.w += bv[e].w; }
+      }
+      sk_bf16x8 At[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        sk_u32x4 w;
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp)
+          w[jp] = pack_hi16((float)((aw[2 * jp + 1] >> (8 * i)) & 0xffu), (float)((aw[2 * jp] >> (8 * i)) & 0xffu));
+        At[i] = __builtin_bit_cast(sk_bf16x8, w);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v[8] = {j == 0 ? bv[0].x : j == 1 ? bv[0].y : j == 2 ? bv[0].z : bv[0].w, j == 0 ? bv[1].x : j == 1 ? bv[1].y : j == 2 ? bv[1].z : bv[1].w,
+                            j == 0 ? bv[2].x : j == 1 ? bv[2].y : j == 2 ? bv[2].z : bv[2].w, j == 0 ? bv[3].x : j == 1 ? bv[3].y : j == 2 ? bv[3].z : bv[3].w,
+                            j == 0 ? bv[4].x : j == 1 ? bv[4].y : j == 2 ? bv[4].z : bv[4].w, j == 0 ? bv[5].x : j == 1 ? bv[5].y : j == 2 ? bv[5].z : bv[5].w,
+                            j == 0 ? bv[6].x : j == 1 ? bv[6].y : j == 2 ? bv[6].z : bv[6].w, j == 0 ? bv[7].x : j == 1 ? bv[7].y : j == 2 ? bv[7].z : bv[7].w};
+        sk_u32x4 h, m, l;
+        sk_split8(v, h, m, l);
+        const sk_bf16x8 Bh = __builtin_bit_cast(sk_bf16x8, h), Bm = __builtin_bit_cast(sk_bf16x8, m), Bl = __builtin_bit_cast(sk_bf16x8, l);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(At[i], Bl, acc[i][j], 0, 0, 0);      // smallest pieces first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(At[i], Bm, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(At[i], Bh, acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    // fp32 x fp32: both operands as three bf16 pieces, 6 piece products per product (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi:
+    // the three dropped ones are <= 2^-23 of the product, below its own fp32 rounding -- the plane GEMMs' form, gemm.hpp), 96 MFMA
+    // cycles per 32 batch rows and [16 x 16] block instead of 256; the splits are VALU work beside the matrix pipe
+    for (int b0 = b_lo; b0 < b_hi; b0 += 32) {
+      float4 af[8], bv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int b = min(b0 + 4 * e + lk, b_hi - 1);
+        af[e] = *reinterpret_cast<const float4*>(A32 + (long long)b * lda + mac);
+        bv[e] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (b0 + 4 * e + lk >= b_hi) af[e] = make_float4(0.f, 0.f, 0.f, 0.f);      // a zero A operand voids a clamped batch row
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (b0 + 4 * e + lk < b_hi) { cs.x += bv[e].x; cs.y += bv[e].y; cs.z += bv[e].z; cs.w += bv[e].w; }
+      }
+      sk_bf16x8 Ah[4], Am[4], Al[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = i == 0 ? af[e].x : i == 1 ? af[e].y : i == 2 ? af[e].z : af[e].w;
+        sk_u32x4 h, m, l;
+        sk_split8(v, h, m, l);
+        Ah[i] = __builtin_bit_cast(sk_bf16x8, h); Am[i] = __builtin_bit_cast(sk_bf16x8, m); Al[i] = __builtin_bit_cast(sk_bf16x8, l);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = j == 0 ? bv[e].x : j == 1 ? bv[e].y : j == 2 ? bv[e].z : bv[e].w;
+        sk_u32x4 h, m, l;
+        sk_split8(v, h, m, l);
+        const sk_bf16x8 Bh = __builtin_bit_cast(sk_bf16x8, h), Bm = __builtin_bit_cast(sk_bf16x8, m), Bl = __builtin_bit_cast(sk_bf16x8, l);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[i], Bl, c, 0, 0, 0);      // smallest products first
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[i], Bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am[i], Bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[i], Bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am[i], Bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[i], Bh, c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+      }
+    }
+  }
+}
+
+// ... the same with fp32 matrix instructions (16 v_mfma_f32_16x16x4_f32 per batch row quad): 126 registers instead of 170, so TWO
+// 8-wave workgroups fit a CU -- the form for more tiles than CUs at batches too short to pay for a second launch (sk_dwb<0>)
+__device__ __forceinline__ void sk_dw_contract64_f32(const SkTensor& T, const int mac, const int nc, const int b_lo, const int b_hi,
+                                                     const int lk, f32x4 (&acc)[4][4], float4& cs) {
+  const int lda = T.lda, ldy = T.ldy;
+  const unsigned char* const A8 = static_cast<const unsigned char*>(T.A);
+  const float* const A32 = static_cast<const float*>(T.A);
+  for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
+    float4 av[4], bv[4];
+    if (T.a_u8) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int b = min(b0 + 4 * s + lk, b_hi - 1);
+        av[s].x = __uint_as_float(*reinterpret_cast<const unsigned*>(A8 + (long long)b * lda + mac));
+        bv[s] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const unsigned w = __float_as_uint(av[s].x);
+        av[s] = make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int b = min(b0 + 4 * s + lk, b_hi - 1);
+        av[s] = *reinterpret_cast<const float4*>(A32 + (long long)b * lda + mac);
+        bv[s] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool on = b0 + 4 * s + lk < b_hi;                    // a zero B operand voids a clamped batch row
+      const float bq[4] = {on ? bv[s].x : 0.f, on ? bv[s].y : 0.f, on ? bv[s].z : 0.f, on ? bv[s].w : 0.f};
+      const float aq[4] = {av[s].x, av[s].y, av[s].z, av[s].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[i], bq[j], acc[i][j], 0, 0, 0);
+      cs.x += bq[0]; cs.y += bq[1]; cs.z += bq[2]; cs.w += bq[3];
+    }
+  }
+}
+
 // W for batches above 128 rows: sk_dw's one-wave tiles re-read their operands per [16 x 64] tile -- at B = 1024, H = 512 that is
 // 450 MB through L2 for 2.9 GFLOP and the launch ran at the L2's rate (63 us).  Here a WORKGROUP owns a [64 x 64] tile of
 // dW = A^T dY: lane (ln, lk) loads 16 bytes of A (4 uint8 or 4 floats: rows m0 + 4 ln + tm) and 16 bytes of dY (columns
@@ -1393,6 +1591,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
 // Tiles are dealt so that the 8 workgroups an XCD receives in turn hold neighbouring tiles (shared operand columns in its L2).
 // (Measured and dropped: [32 x 64] tiles to balance 354 tiles over 256 CUs -- twice the workgroups, but only two of them fit a CU,
 // so the second half queued: 43 us against 46.  Where the tiles do not balance, the stage runs as sk_dwc + sk_adam below.)
+template <int BF>
 __global__ __launch_bounds__(kSkThreads) void sk_dwb(const SkArgs a) {
   constexpr int TM = 4, NP = 2;                    // strided 16-row tiles; meetings (halves of 32 accumulator registers)
   __shared__ __attribute__((aligned(16))) float part[kSkWaves * 8 * 64 * 4];      // [wave][tml * 4 + r][lane][tn]
@@ -1434,43 +1633,9 @@ __global__ __launch_bounds__(kSkThreads) void sk_dwb(const SkArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-  const unsigned char* const A8 = static_cast<const unsigned char*>(T.A);
-  const float* const A32 = static_cast<const float*>(T.A);
-  for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
-    float av[4][TM];
-    float4 bv[4];
-    if (T.a_u8) {
-      unsigned aw[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int b = min(b0 + 4 * s + lk, b_hi - 1);
-        aw[s] = *reinterpret_cast<const unsigned*>(A8 + (long long)b * lda + mac);
-        bv[s] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) av[s][i] = (float)((aw[s] >> (8 * i)) & 0xffu);
-    } else {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int b = min(b0 + 4 * s + lk, b_hi - 1);
-        const float4 q = *reinterpret_cast<const float4*>(A32 + (long long)b * lda + mac);
-        av[s][0] = q.x; av[s][1] = q.y; av[s][2] = q.z; av[s][3] = q.w;
-        bv[s] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bool on = b0 + 4 * s + lk < b_hi && n_ok;            // a zero B operand voids clamped batch rows and columns
-      const float bq[4] = {on ? bv[s].x : 0.f, on ? bv[s].y : 0.f, on ? bv[s].z : 0.f, on ? bv[s].w : 0.f};
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][i], bq[j], acc[i][j], 0, 0, 0);
-      cs.x += bq[0]; cs.y += bq[1]; cs.z += bq[2]; cs.w += bq[3];
-    }
-  }
+  const bool bias = tm == 0 && T.b_off >= 0;
+  if constexpr (BF) sk_dw_contract64(T, mac, nc, b_lo, b_hi, lk, bias, acc, cs);
+  else sk_dw_contract64_f32(T, mac, nc, b_lo, b_hi, lk, acc, cs);
   SK_STAMP(9, 1);
   // ---- the optimizer's operands of this thread's two rows (one per half), requested before the waves meet
   const bool upd = a.ap != nullptr;
@@ -1507,7 +1672,6 @@ __global__ __launch_bounds__(kSkThreads) void sk_dwb(const SkArgs a) {
     lr_t = a.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1));
   }
   const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, gs = 1.f / (float)B;
-  const bool bias = tm == 0 && T.b_off >= 0;
   if (bias) {
     cs.x += __shfl_xor(cs.x, 16, 64); cs.y += __shfl_xor(cs.y, 16, 64); cs.z += __shfl_xor(cs.z, 16, 64); cs.w += __shfl_xor(cs.w, 16, 64);
     cs.x += __shfl_xor(cs.x, 32, 64); cs.y += __shfl_xor(cs.y, 32, 64); cs.z += __shfl_xor(cs.z, 32, 64); cs.w += __shfl_xor(cs.w, 32, 64);
@@ -1583,7 +1747,7 @@ __global__ __launch_bounds__(kSkThreads) void sk_dwb(const SkArgs a) {
 // layout.  sk_adam then adds the shares in share order and runs TF-Adam element by element.  The loss tail and the mixture
 // prior's workgroups ride on sk_dwc.
 constexpr int kDwcThreads = 256, kDwcWaves = 4;
-__global__ __launch_bounds__(kDwcThreads, 4) void sk_dwc(const SkArgs a) {
+__global__ __launch_bounds__(kDwcThreads, 3) void sk_dwc(const SkArgs a) {
   constexpr int TM = 4, NP = 2;
   __shared__ __attribute__((aligned(16))) float part[kDwcWaves * 8 * 64 * 4];     // [wave][tml * 4 + r][lane][tn]: 32 KB
   __shared__ __attribute__((aligned(16))) float csl[kDwcWaves * 16 * 4];
@@ -1627,46 +1791,11 @@ __global__ __launch_bounds__(kDwcThreads, 4) void sk_dwc(const SkArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-  const unsigned char* const A8 = static_cast<const unsigned char*>(T.A);
-  const float* const A32 = static_cast<const float*>(T.A);
-  for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
-    float4 av[4], bv[4];
-    if (T.a_u8) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int b = min(b0 + 4 * s + lk, b_hi - 1);
-        av[s].x = __uint_as_float(*reinterpret_cast<const unsigned*>(A8 + (long long)b * lda + mac));
-        bv[s] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const unsigned w = __float_as_uint(av[s].x);
-        av[s] = make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
-      }
-    } else {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int b = min(b0 + 4 * s + lk, b_hi - 1);
-        av[s] = *reinterpret_cast<const float4*>(A32 + (long long)b * lda + mac);
-        bv[s] = *reinterpret_cast<const float4*>(T.dY + (long long)b * ldy + nc);
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bool on = b0 + 4 * s + lk < b_hi && n_ok;            // a zero B operand voids clamped batch rows and columns
-      const float bq[4] = {on ? bv[s].x : 0.f, on ? bv[s].y : 0.f, on ? bv[s].z : 0.f, on ? bv[s].w : 0.f};
-      const float aq[4] = {av[s].x, av[s].y, av[s].z, av[s].w};
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[i], bq[j], acc[i][j], 0, 0, 0);
-      cs.x += bq[0]; cs.y += bq[1]; cs.z += bq[2]; cs.w += bq[3];
-    }
-  }
+  const bool bias = tm == 0 && T.b_off >= 0;
+  sk_dw_contract64(T, mac, nc, b_lo, b_hi, lk, bias, acc, cs);
   SK_STAMP(9, 1);
   float* const out = a.dwp + (long long)ks * a.dwp_stride;
   const bool vecn = (N & 3) == 0;
-  const bool bias = tm == 0 && T.b_off >= 0;
   if (bias) {
     cs.x += __shfl_xor(cs.x, 16, 64); cs.y += __shfl_xor(cs.y, 16, 64); cs.z += __shfl_xor(cs.z, 16, 64); cs.w += __shfl_xor(cs.w, 16, 64);
     cs.x += __shfl_xor(cs.x, 32, 64); cs.y += __shfl_xor(cs.y, 32, 64); cs.z += __shfl_xor(cs.z, 32, 64); cs.w += __shfl_xor(cs.w, 32, 64);
