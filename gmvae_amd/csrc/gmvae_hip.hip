@@ -35,7 +35,6 @@ constexpr int NS_MAX = 16;
 constexpr int MAX_LEVELS = 96;
 constexpr int GMP_PARTS = 64;
 constexpr int kMegaQMax = 4;
-constexpr int kSkDwShares = 2;   // batch shares of the skinny schedule's two-launch W stage (sk_dwc: partial gradients in w.slabs)
 constexpr int kSkNs1 = 4;        // slabs of the skinny schedule's first layer (contraction split); <= skinny.hpp kSkNs1x
 
 // Workgroups that share one 16-row panel of mega_fwd_bwd (they split its decoder chunks): as many as keep the
@@ -133,6 +132,7 @@ struct WS {
   float* hd[MAXH + 2];   // decoder activations [R, dim[i]]
   float *gx, *logits, *y, *nent, *pp, *qp, *z, *logq, *logp, *logpx, *logw, *rw, *resp, *g, *part;
   float *dbuf[3], *dz, *dqp, *dpp, *dy, *dlogits, *dqb, *slabs, *gmp_part;
+  unsigned* sk_cnt;                  // skinny schedule, sk_dwc: arrived batch shares per weight-gradient tile
   float *sk_s1, *sk_lqp, *sk_part;   // skinny schedule: first-layer slabs [ns1][B][2H]; log q / log p partials [2][L/16][B]; logpx partials [B][D/16]
   float *gmp_inv, *gmp_cst;     // tiled mixture log-prob (any K, L): 1 / softplus(raw_scale_diag) [K][L], per-component constants [K]
   double* lw64;            // S > 1: log w per row in fp64 (kernels.hpp row_terms / iwae_rows)
@@ -357,6 +357,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
   if (skinny_shape(d, model)) {       // (sized by the dims alone: no switch, no batch bound below kSkMaxB)
     w.sk_s1 = take((uint64_t)kSkNs1 * B * 2 * d.hidden[0]);
     w.sk_lqp = take(2ull * ((Lz + 15) / 16) * B);
+    w.sk_cnt = reinterpret_cast<unsigned*>(take(kSkDwcMaxTiles));
     w.sk_part = take(B * ((D + 15) / 16));
   }
   w.dz = take(R * Lz);
@@ -1403,6 +1404,7 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   s.lr = a.lr; s.b1 = a.beta1; s.b2 = a.beta2; s.aeps = a.epsilon;
   s.ln_b1 = (float)log((double)a.beta1); s.ln_b2 = (float)log((double)a.beta2);
   s.tail = a.grads + L.P_pad; s.tail_log = a.tail_log;
+  s.dw_cnt = w.sk_cnt;
   s.logpx = w.logpx; s.logq = w.logq; s.logp = w.logp; s.logw = w.logw;
   // the W stage's form: up to 128 batch rows sk_dw (one-wave tiles); above, [64 x 64] tiles: one workgroup each (sk_dwb<1>: bf16
   // pieces, one per CU at its 170 registers; more tiles than CUs: sk_dwb<0>, fp32 matrix instructions, two per CU) or -- more
@@ -1423,9 +1425,9 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   };
   const int nrt = (B + 15) / 16;
   // row tiles per workgroup of a matrix-product launch with nct column tiles: as many (4, 2, 1) as still leave 256 workgroups
-  auto rt_of = [&](int nct) {
+  auto rt_of = [&](int nct, int min_wgs = 256) {
     int rt = 4;
-    while (rt > 1 && nct * ((nrt + rt - 1) / rt) < 256) rt >>= 1;
+    while (rt > 1 && nct * ((nrt + rt - 1) / rt) < min_wgs) rt >>= 1;
     return rt;
   };
   const double fB = 2.0 * B;
@@ -1437,7 +1439,8 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   };
   auto gemm = [&](auto stage, int nct, int slabs, int extra, const char* name, double fl) {
     constexpr int ST = decltype(stage)::value;
-    const int rt = rt_of(nct * slabs), grid = nct * ((nrt + rt - 1) / rt) * slabs + extra;
+    // (F5W: 13 column tiles at D = 784 -- four row tiles already from 192 workgroups: one round of them beats two of 416)
+    const int rt = rt_of(nct * slabs, ST == SK_F5W ? 192 : 256), grid = nct * ((nrt + rt - 1) / rt) * slabs + extra;
     launch(rt == 4 ? sk_gemm<ST, 4> : rt == 2 ? sk_gemm<ST, 2> : sk_gemm<ST, 1>, grid, kSkThreads, 0, name, fl);
   };
   // rows per workgroup of the y path: one while the chip holds every row's workgroup at once (3 per CU), then 2, 4 (H <= 512)
@@ -1475,24 +1478,10 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
     double fw = 0;
     for (int i = 0; i < s.ntens; ++i) fw += 2.0 * s.t[i].M * s.t[i].N * B;
     const int gmp_wgs = s.gmp_part ? (s.gmp_len + kSkThreads - 1) / kSkThreads : 0;      // (sk_dw derives the same count)
-    if (dw_big && s.total_tiles > 256 && B >= 512) {
+    if (dw_big && s.total_tiles > 256 && B >= 512 && s.total_tiles <= kSkDwcMaxTiles) {
       s.dwp = w.slabs; s.dwp_stride = (long long)L.P_pad; s.dw_ks = kSkDwShares;
-      s.nseg = 0;
-      int wgs = 0;
-      for (int i = 0; i < s.ntens; ++i)
-        for (int h = 0; h < 2; ++h) {
-          if (h == 1 && s.t[i].b_off < 0) continue;
-          s.seg_off[s.nseg] = h ? (long long)s.t[i].b_off : (long long)s.t[i].w_off;
-          s.seg_len[s.nseg] = h ? s.t[i].N : s.t[i].M * s.t[i].N;
-          s.seg_wg[s.nseg] = wgs;
-          wgs += (s.seg_len[s.nseg] + 1023) / 1024;
-          ++s.nseg;
-        }
-      s.seg_wg[s.nseg] = wgs;
       const int gmp256 = s.gmp_part ? (s.gmp_len + kDwcThreads - 1) / kDwcThreads : 0;
-      hipLaunchKernelGGL(sk_dwc, dim3(8 * ((s.total_tiles * s.dw_ks + 7) / 8) + 1 + gmp256), dim3(kDwcThreads), 0, st, s);
-      cx.check();
-      hipLaunchKernelGGL(sk_adam, dim3(wgs), dim3(256), 0, st, s);
+      hipLaunchKernelGGL(sk_dwc, dim3(16 * ((s.total_tiles * s.dw_ks + 15) / 16) + 1 + gmp256), dim3(kDwcThreads), 0, st, s);
     } else if (dw_big) hipLaunchKernelGGL(s.total_tiles > 256 ? sk_dwb<0> : sk_dwb<1>, dim3(8 * ((s.total_tiles + 7) / 8) + 1 + gmp_wgs), dim3(kSkThreads), 0, st, s);
     else hipLaunchKernelGGL(sk_dw, dim3((s.total_tiles + kSkWaves - 1) / kSkWaves + 1 + gmp_wgs), dim3(kSkThreads), 0, st, s);
     cx.check();

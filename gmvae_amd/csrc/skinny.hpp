@@ -57,12 +57,10 @@ struct SkArgs {
   unsigned long long* step_dev;
   // W launch
   int ntens, total_tiles;
-  float* dwp;                  // W in two launches (sk_dwc + sk_adam): dw_ks partial gradients in the flat layout, dwp_stride floats apart
-  long long dwp_stride;
+  float* dwp;                  // sk_dwc: dw_ks partial gradients (one per batch share) in the flat layout, dwp_stride floats apart,
+  long long dwp_stride;        //   and a counter of arrived shares per tile (zeroed by the step's first launch)
   int dw_ks;
-  int nseg;                    // ... and the flat layout's segments the optimizer launch walks: workgroup seg_wg[i] starts segment i
-  int seg_wg[2 * kSkMaxT + 1], seg_len[2 * kSkMaxT];
-  long long seg_off[2 * kSkMaxT];
+  unsigned* dw_cnt;
   int has_tail;                // W launch: its last workgroup is the loss tail (the launch that ends the step)
   SkTensor t[kSkMaxT];
   float *grads, *ap, *am, *av; // ap != null: TF-Adam in the epilogue
@@ -79,6 +77,8 @@ struct SkArgs {
   long long gmp_off;
   unsigned long long* dbg;     // diagnostic (GMVAE_SK_STAMPS): [10 launches][kSkDbgWgs blocks][8] device wall-clock stamps (100 MHz)
 };
+constexpr int kSkDwShares = 2;         // batch shares of a tile in sk_dwc (their partial gradients: w.slabs)
+constexpr int kSkDwcMaxTiles = 4096;   // sk_dwc's per-tile arrival counters (H = 1024, D = 3072: 3 x 768 + small tensors)
 constexpr int kSkDbgWgs = 1024;   // workgroups per launch that leave stamps
 #define SK_STAMP(slot, i) if (a.dbg && threadIdx.x == 0 && blockIdx.x < kSkDbgWgs) a.dbg[((size_t)(slot) * kSkDbgWgs + blockIdx.x) * 8 + (i)] = wall_clock64()
 
@@ -109,11 +109,20 @@ template <int RT> constexpr int sk_maxg() { return RT == 1 ? 4 : RT == 2 ? 2 : 1
 // RT > 1: one group per stage, two register sets: the next group's loads are in flight under this group's RT x as many MFMAs.
 // (Stages of two groups at RT = 2 measured neutral -- 160 VGPRs, one workgroup per CU -- and were dropped.)
 template <int RT, int NB> struct SkFrag { float4 av[RT]; float4 bv[NB]; };
-template <class Frag, class LD, class MM>
+template <class Frag, bool PIPE = true, class LD, class MM>
 __device__ __forceinline__ void sk_pipe(const int kg_lo, const int kg_hi, const int wave, LD&& ld, MM&& mm) {
   const int kg = kg_lo + wave;
   const int n = kg < kg_hi ? (kg_hi - kg + kSkWaves - 1) / kSkWaves : 0;
   if (n == 0) return;
+  if constexpr (!PIPE) {                          // one register set (the 6-product forms at RT = 4: two would spill)
+    for (int i = 0; i < n; ++i) {
+      Frag f;
+      ld(f, kg + kSkWaves * i);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(f);
+    }
+    return;
+  }
   Frag fa, fb;
   ld(fa, kg);
   int i = 0;
@@ -191,6 +200,96 @@ __device__ __forceinline__ void sk_nn4_u8bf(const unsigned char* __restrict__ X,
           acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j], Bm, acc[j][t], 0, 0, 0);
           acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j], Bh, acc[j][t], 0, 0, 0);
         }
+      }
+    });
+}
+// fp32 x fp32 on the bf16 matrix cores for the two D-wide layers above 128 rows: both operands as three pieces, 6 piece products
+// per product (the three dropped ones <= 2^-23 of it: gemm.hpp's plane form), 6 x 16 MFMA cycles per group of 32 contraction steps
+// and [16 x 16] block instead of 8 x 32; the splits run on the vector pipe beside the other waves' MFMAs.
+__device__ __forceinline__ void sk_mma6(const sk_bf16x8 (&A)[3], const sk_bf16x8 (&B)[3], f32x4& c) {      // pieces [0] hi, [1] mid, [2] lo
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[2], c, 0, 0, 0);      // smallest products first
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], B[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[0], c, 0, 0, 0);
+}
+__device__ __forceinline__ void sk_pieces(const float (&v)[8], sk_bf16x8 (&P)[3]) {
+  sk_u32x4 h, m, l;
+  sk_split8(v, h, m, l);
+  P[0] = __builtin_bit_cast(sk_bf16x8, h); P[1] = __builtin_bit_cast(sk_bf16x8, m); P[2] = __builtin_bit_cast(sk_bf16x8, l);
+}
+// NN: A rows k-contiguous (two 16-byte loads per 8 steps), W k-major, 4 strided column tiles (eight 16-byte loads)
+template <int RT> struct SkFragN6 { float4 av[RT][2]; float4 bv[8]; };
+template <int RT>
+__device__ __forceinline__ void sk_nn4_bf6(const float* __restrict__ A, const long long (&arow)[RT], const float* __restrict__ W, const int ldw,
+                                           const int ncol, const int g_hi, const int wave, const int lk, f32x4 (&acc)[RT][4]) {
+  sk_pipe<SkFragN6<RT>, (RT < 4)>(0, g_hi, wave,
+    [&](SkFragN6<RT>& f, const int gi) {
+      const int k = 32 * gi + 8 * lk;
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        f.av[j][0] = *reinterpret_cast<const float4*>(A + arow[j] + k);
+        f.av[j][1] = *reinterpret_cast<const float4*>(A + arow[j] + k + 4);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f.bv[e] = *reinterpret_cast<const float4*>(W + (long long)(k + e) * ldw + ncol);
+    },
+    [&](const SkFragN6<RT>& f) {
+      sk_bf16x8 Ap[RT][3];
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const float v[8] = {f.av[j][0].x, f.av[j][0].y, f.av[j][0].z, f.av[j][0].w, f.av[j][1].x, f.av[j][1].y, f.av[j][1].z, f.av[j][1].w};
+        sk_pieces(v, Ap[j]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = t == 0 ? f.bv[e].x : t == 1 ? f.bv[e].y : t == 2 ? f.bv[e].z : f.bv[e].w;
+        sk_bf16x8 Bp[3];
+        sk_pieces(v, Bp);
+#pragma unroll
+        for (int j = 0; j < RT; ++j) sk_mma6(Ap[j], Bp, acc[j][t]);
+      }
+    });
+}
+// NT: both operands contraction-contiguous (two 16-byte loads per 8 steps each)
+template <int RT, int NU> struct SkFragT6 { float4 av[RT][2]; float4 bv[NU][2]; };
+template <int RT, int NU>
+__device__ __forceinline__ void sk_nt_bf6(const float* __restrict__ A, const long long (&arow)[RT], const float* __restrict__ W, const int ldw,
+                                          const int (&wrow)[NU], const int g_hi, const int wave, const int lk, const int kmax,
+                                          f32x4 (&acc)[RT][4]) {
+  sk_pipe<SkFragT6<RT, NU>, (RT < 4)>(0, g_hi, wave,
+    [&](SkFragT6<RT, NU>& f, const int gi) {
+      const int k0 = 32 * gi + 8 * lk;
+      const int k = min(k0, kmax - 8);            // (kmax a multiple of 16: the last group may be half empty: clamped, A zero)
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        f.av[j][0] = *reinterpret_cast<const float4*>(A + arow[j] + k);
+        f.av[j][1] = *reinterpret_cast<const float4*>(A + arow[j] + k + 4);
+        if (k0 >= kmax) { f.av[j][0] = make_float4(0.f, 0.f, 0.f, 0.f); f.av[j][1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      }
+#pragma unroll
+      for (int t = 0; t < NU; ++t) {
+        f.bv[t][0] = *reinterpret_cast<const float4*>(W + (long long)wrow[t] * ldw + k);
+        f.bv[t][1] = *reinterpret_cast<const float4*>(W + (long long)wrow[t] * ldw + k + 4);
+      }
+    },
+    [&](const SkFragT6<RT, NU>& f) {
+      sk_bf16x8 Ap[RT][3];
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const float v[8] = {f.av[j][0].x, f.av[j][0].y, f.av[j][0].z, f.av[j][0].w, f.av[j][1].x, f.av[j][1].y, f.av[j][1].z, f.av[j][1].w};
+        sk_pieces(v, Ap[j]);
+      }
+#pragma unroll
+      for (int t = 0; t < NU; ++t) {
+        const float v[8] = {f.bv[t][0].x, f.bv[t][0].y, f.bv[t][0].z, f.bv[t][0].w, f.bv[t][1].x, f.bv[t][1].y, f.bv[t][1].z, f.bv[t][1].w};
+        sk_bf16x8 Bp[3];
+        sk_pieces(v, Bp);
+#pragma unroll
+        for (int j = 0; j < RT; ++j) sk_mma6(Ap[j], Bp, acc[j][t]);
       }
     });
 }
@@ -413,6 +512,8 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
       return;
     }
     if (vae && bid == 0 && tid == 0 && a.step_dev) a.step_dev[1] = a.step_dev[0];     // the copy the W launch reads
+    if (bid == 0 && a.dw_cnt)                     // sk_dwc's arrival counters (nine launches ahead of their use)
+      for (int i = tid; i < kSkDwcMaxTiles; i += kSkThreads) a.dw_cnt[i] = 0u;
   }
   const int ct = bid % nct, rt = (bid / nct) % nrt, ks = bid / (nct * nrt);
   const int r0 = rt * 16 * RT;
@@ -498,11 +599,19 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     sk_nnp<1, RT>(a.hd, arow, P + a.Wd1, D, col, 0, H / 16, wave, lk, acc);
   } else if constexpr (ST == SK_F5W) {            // 64-column tiles (strided, as F1): 4 x the MFMAs per W fragment
     for (int j = 0; j < RT; ++j) arow[j] = rowc[j] * H;
-    sk_nn4<false, RT>(a.hd, arow, P + a.Wd1, D, min(ct * 64 + 4 * ln, D - 4), 0, H / 16, wave, lk, acc);
+    if constexpr (RT > 1) {                       // (H % 64 = 0: whole groups of 32)
+      sk_nn4_bf6<RT>(a.hd, arow, P + a.Wd1, D, min(ct * 64 + 4 * ln, D - 4), H / 32, wave, lk, acc);
+    } else {
+      sk_nn4<false, RT>(a.hd, arow, P + a.Wd1, D, min(ct * 64 + 4 * ln, D - 4), 0, H / 16, wave, lk, acc);
+    }
   } else if constexpr (ST == SK_B1W) {            // 4 strided W rows per lane: out column ct 64 + 4 ln + t
     const int wr[4] = {ct * 64 + 4 * ln, ct * 64 + 4 * ln + 1, ct * 64 + 4 * ln + 2, ct * 64 + 4 * ln + 3};
     for (int j = 0; j < RT; ++j) arow[j] = rowc[j] * D;
-    sk_nt<4, RT>(a.g, arow, P + a.Wd1, D, wr, 0, D / 16, wave, lk, acc);
+    if constexpr (RT > 1) {
+      sk_nt_bf6<RT, 4>(a.g, arow, P + a.Wd1, D, wr, (D + 31) / 32, wave, lk, D, acc);
+    } else {
+      sk_nt<4, RT>(a.g, arow, P + a.Wd1, D, wr, 0, D / 16, wave, lk, acc);
+    }
   } else if constexpr (ST == SK_B1) {             // dhd = g Wd1^T: out column j = hidden unit, W row j of Wd1 [H][D]
     const int wr[1] = {ct * 16 + ln};
     for (int j = 0; j < RT; ++j) arow[j] = rowc[j] * D;
@@ -1740,12 +1849,14 @@ __global__ __launch_bounds__(kSkThreads) void sk_dwb(const SkArgs a) {
   SK_STAMP(9, 3);
 }
 
-// W in two launches, for batches where one workgroup per tile cannot balance (H = 512: 354 [64 x 64] tiles on 256 CUs, and a CU
-// that carries two sets the launch's time).  sk_dwc: workgroups of 4 waves; workgroup (tile, share) contracts one of dw_ks
-// shares of the batch rows for a [64 x 64] tile (operand fragments and accumulators as sk_dwb), its 4 waves meet in LDS and the
-// summed partial tile -- and, on the first tile row, the partial column sums (bias gradient) -- goes to dwp[share] in the flat
-// layout.  sk_adam then adds the shares in share order and runs TF-Adam element by element.  The loss tail and the mixture
-// prior's workgroups ride on sk_dwc.
+// W where one workgroup per tile cannot balance (H = 512: 354 [64 x 64] tiles on 256 CUs, and a CU that carries two sets the
+// launch's time): workgroups of 4 waves; workgroup (tile, share) contracts one of dw_ks shares of the batch rows for a [64 x 64]
+// tile (operand fragments and accumulators as sk_dwb), its 4 waves meet in LDS and the summed partial tile -- and, on the first
+// tile row, the partial column sums (bias gradient) -- goes to dwp[share] in the flat layout (write-through).  The workgroup then
+// counts itself in (agent-scope atomic add behind a fence and a barrier); the one that arrives LAST for its tile adds the shares
+// in share order -- all of them read back from memory, so the sum does not depend on who was last -- and runs TF-Adam on the
+// tile: no second launch.  (As sk_dwc + an element-wise optimizer launch the stage took 32 us at B = 1024, H = 512: the second
+// launch moved 50 MB behind a 1.7 us boundary.)  The loss tail and the mixture prior's workgroups ride along.
 constexpr int kDwcThreads = 256, kDwcWaves = 4;
 __global__ __launch_bounds__(kDwcThreads, 3) void sk_dwc(const SkArgs a) {
   constexpr int TM = 4, NP = 2;
@@ -1766,7 +1877,8 @@ __global__ __launch_bounds__(kDwcThreads, 3) void sk_dwc(const SkArgs a) {
     sk_loss_tail(a, red, tid);
     return;
   }
-  const int per = ntw >> 3;                        // (ntw = 8 ceil(total_tiles dw_ks / 8))
+  __shared__ int lastf;
+  const int per = ntw >> 3;                        // (ntw = 16 ceil(total_tiles dw_ks / 16): a tile's shares on ONE XCD)
   const int unit = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
   const int tile = unit / a.dw_ks, ks = unit - tile * a.dw_ks;
   if (tile >= a.total_tiles) return;
@@ -1845,69 +1957,112 @@ __global__ __launch_bounds__(kDwcThreads, 3) void sk_dwc(const SkArgs a) {
         if (n0 + 4 * tid + j < N) st1o(out + (long long)T.b_off + n0 + 4 * tid + j, c4[j]);
     }
   }
-  SK_STAMP(9, 3);
-}
-
-// The optimizer launch behind sk_dwc: a workgroup walks 1024 consecutive elements of one segment (a weight or bias tensor's
-// range of the flat layout; 16-byte aligned starts): gradient = the dw_ks partials in share order, then TF-Adam
-// (scripts/runners.py:181-183; ApplyAdam form, kernels.hpp adam_update).
-__global__ __launch_bounds__(256) void sk_adam(const SkArgs a) {
-  const int wg = blockIdx.x, tid = threadIdx.x;
-  int si = 0;
-#pragma unroll
-  for (int i = 1; i < 2 * kSkMaxT; ++i)
-    if (i < a.nseg && wg >= a.seg_wg[i]) si = i;
-  const long long e0 = (long long)(wg - a.seg_wg[si]) * 1024 + 4 * tid;
-  const int rem = (int)min((long long)4, (long long)a.seg_len[si] - e0);
-  if (rem <= 0) return;
-  const long long i0 = a.seg_off[si] + e0;
+  // ---- count this share in; the last one of the tile finishes it.  No fence (an agent-scope fence writes the L2 back: with two
+  // per workgroup the launch took 133 us): the partials left as sc1 write-through stores, every wave waits for its own
+  // (vmcnt(0)), ONE lane adds behind the barrier, and the finisher reads with sc1 loads (MI355X_MICROARCH.md, hand-off table row 1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) lastf = __hip_atomic_fetch_add(a.dw_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.dw_ks - 1) ? 1 : 0;
+  __syncthreads();
+  if (!lastf) { SK_STAMP(9, 3); return; }
   const bool upd = a.ap != nullptr;
-  float g[4] = {0.f, 0.f, 0.f, 0.f}, pp[4] = {0.f, 0.f, 0.f, 0.f}, pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (rem == 4) {
-    for (int k = 0; k < a.dw_ks; ++k) {
-      const float4 q = *reinterpret_cast<const float4*>(a.dwp + (long long)k * a.dwp_stride + i0);
-      g[0] += q.x; g[1] += q.y; g[2] += q.z; g[3] += q.w;
-    }
-    if (upd) {
-      const float4 q0 = *reinterpret_cast<const float4*>(a.ap + i0), q1 = *reinterpret_cast<const float4*>(a.am + i0),
-                   q2 = *reinterpret_cast<const float4*>(a.av + i0);
-      pp[0] = q0.x; pp[1] = q0.y; pp[2] = q0.z; pp[3] = q0.w;
-      pm[0] = q1.x; pm[1] = q1.y; pm[2] = q1.z; pm[3] = q1.w;
-      pv[0] = q2.x; pv[1] = q2.y; pv[2] = q2.z; pv[3] = q2.w;
-    }
-  } else {
-    for (int k = 0; k < a.dw_ks; ++k)
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (j < rem) g[j] += a.dwp[(long long)k * a.dwp_stride + i0 + j];
-    if (upd) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (j < rem) { pp[j] = a.ap[i0 + j]; pm[j] = a.am[i0 + j]; pv[j] = a.av[i0 + j]; }
-    }
-  }
+  float lr_t = 0.f;
   if (upd) {
     const float tf = (float)((a.step_dev ? a.step_dev[1] : a.step) + 1ull);
-    const float lr_t = a.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1));
-    const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, gs = 1.f / (float)a.B;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) adam_update(pp[j], pm[j], pv[j], g[j], gs, lr_t, omb1, omb2, a.aeps);
+    lr_t = a.lr * sqrtf(-expm1f(tf * a.ln_b2)) / (-expm1f(tf * a.ln_b1));
   }
-  if (rem == 4) {
-    st4o(a.grads + i0, make_float4(g[0], g[1], g[2], g[3]));
+  const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, gs = 1.f / (float)B;
+  long long ei[4];
+  bool eok[4];
+  float g[4][4], pp[4][4], pm[4][4], pv[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {                    // this thread's four rows of the tile (the ones it stored above)
+    const int p = q >> 1, q8 = wave * 2 + (q & 1), tml = q8 >> 2, er = q8 & 3;
+    const int m = m0 + TM * (4 * lk + er) + 2 * p + tml;
+    eok[q] = m < M && n < N;
+    ei[q] = (long long)T.w_off + (long long)min(m, M - 1) * N + min(n, vecn ? N - 4 : N - 1);
     if (upd) {
-      st4o(a.ap + i0, make_float4(pp[0], pp[1], pp[2], pp[3]));
-      st4o(a.am + i0, make_float4(pm[0], pm[1], pm[2], pm[3]));
-      st4o(a.av + i0, make_float4(pv[0], pv[1], pv[2], pv[3]));
-    }
-  } else {
+      if (vecn) {
+        const float4 q0 = *reinterpret_cast<const float4*>(a.ap + ei[q]), q1 = *reinterpret_cast<const float4*>(a.am + ei[q]),
+                     q2 = *reinterpret_cast<const float4*>(a.av + ei[q]);
+        pp[q][0] = q0.x; pp[q][1] = q0.y; pp[q][2] = q0.z; pp[q][3] = q0.w;
+        pm[q][0] = q1.x; pm[q][1] = q1.y; pm[q][2] = q1.z; pm[q][3] = q1.w;
+        pv[q][0] = q2.x; pv[q][1] = q2.y; pv[q][2] = q2.z; pv[q][3] = q2.w;
+      } else {
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-      if (j < rem) {
-        a.grads[i0 + j] = g[j];
-        if (upd) { a.ap[i0 + j] = pp[j]; a.am[i0 + j] = pm[j]; a.av[i0 + j] = pv[j]; }
+        for (int j = 0; j < 4; ++j) {
+          const long long i = ei[q] + min(j, N - 1 - min(n, N - 1));
+          pp[q][j] = a.ap[i]; pm[q][j] = a.am[i]; pv[q][j] = a.av[i];
+        }
       }
+    }
   }
+  // the shares' partials: every load in flight before the first sum (agent-coherent loads: the other share came from another CU)
+  if (vecn) {
+    u32x4_t sv[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < kSkDwShares; ++k)
+        sv[2 * q + k] = granule2_load(reinterpret_cast<const unsigned long long*>(a.dwp + (long long)k * a.dwp_stride + ei[q]));
+    g2_wait<8>(sv);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[q][j] = __uint_as_float(sv[2 * q][j]) + __uint_as_float(sv[2 * q + 1][j]);
+  } else {
+    float t[4][4][kSkDwShares];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < kSkDwShares; ++k)
+          t[q][j][k] = __hip_atomic_load(a.dwp + (long long)k * a.dwp_stride + ei[q] + min(j, N - 1 - min(n, N - 1)), __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[q][j] = t[q][j][0] + t[q][j][1];
+  }
+  static_assert(kSkDwShares == 2, "the sums above add two shares");
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (upd) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) adam_update(pp[q][j], pm[q][j], pv[q][j], g[q][j], gs, lr_t, omb1, omb2, a.aeps);
+    }
+    if (eok[q]) {
+      if (vecn) {
+        st4o(a.grads + ei[q], make_float4(g[q][0], g[q][1], g[q][2], g[q][3]));
+        if (upd) {
+          st4o(a.ap + ei[q], make_float4(pp[q][0], pp[q][1], pp[q][2], pp[q][3]));
+          st4o(a.am + ei[q], make_float4(pm[q][0], pm[q][1], pm[q][2], pm[q][3]));
+          st4o(a.av + ei[q], make_float4(pv[q][0], pv[q][1], pv[q][2], pv[q][3]));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < N) {
+            st1o(a.grads + ei[q] + j, g[q][j]);
+            if (upd) { st1o(a.ap + ei[q] + j, pp[q][j]); st1o(a.am + ei[q] + j, pm[q][j]); st1o(a.av + ei[q] + j, pv[q][j]); }
+          }
+      }
+    }
+  }
+  if (bias && tid < 64 && n0 + tid < N) {          // the bias gradient: the shares' column sums, in share order
+    const long long i = (long long)T.b_off + n0 + tid;
+    const float c0 = __hip_atomic_load(a.dwp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                c1 = __hip_atomic_load(a.dwp + a.dwp_stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float c = c0 + c1;
+    a.grads[i] = c;
+    if (upd) {
+      float bp = a.ap[i], bm = a.am[i], bvv = a.av[i];
+      adam_update(bp, bm, bvv, c, gs, lr_t, omb1, omb2, a.aeps);
+      a.ap[i] = bp; a.am[i] = bm; a.av[i] = bvv;
+    }
+  }
+  SK_STAMP(9, 3);
 }
 
 }  // namespace gmvae
