@@ -774,6 +774,19 @@ __device__ __forceinline__ float sk_block_sum16(const float (&p)[16], float* __r
   return tot;
 }
 
+// the K <= 16 entries of one row of a [.][K] matrix (surplus entries: copies of valid ones, they meet zeros) as 8-byte loads -- 8
+// wave-instructions of 20 lines at K = 10 instead of 16: lane c reads row c, so every load of the row-major matrix touches a
+// cache line per 3 lanes whatever its width.  (Rows of an odd K are only 4-byte aligned: the copy below compiles to the same
+// global_load_dwordx2, which this target's unaligned access mode serves; no branch on K around the loads.)
+__device__ __forceinline__ void sk_row16(const float* __restrict__ rowp, const int K, float (&w)[16]) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    float2 v;
+    __builtin_memcpy(&v, rowp + min(2 * q, (K - 1) & ~1), sizeof(v));      // (odd K: the last pair's second element is the next row's first)
+    w[2 * q] = v.x; w[2 * q + 1] = v.y;
+  }
+}
+
 // F2: the y path, one workgroup (256 threads) per batch row: this row's Philox noise; hy = relu(sum of the first-layer
 // slabs + b) and the x part of encoder_gmm's first layer; logits = hy Wy1 + b; RelaxedOneHotCategorical.sample and the
 // entropy term (scripts/gmvae.py:238-240,262-263, as kernels.hpp y_head_fwd); hg = relu(gx + y Wg0[D:] + b); the prior
@@ -821,9 +834,9 @@ __global__ __launch_bounds__(256) void sk_ypath(const SkArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int kc = min(k, K - 1);                 // (branch-free; surplus entries meet zeros below)
-      wy[i][k] = P[a.Wy1 + (long long)c * K + kc];
       wg[i][k] = P[a.Wg0 + (long long)(a.D + kc) * H + c];
     }
+    sk_row16(P + a.Wy1 + (long long)c * K, K, wy[i]);
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -924,9 +937,9 @@ __global__ __launch_bounds__(256) void sk_ybwd(const SkArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int kc = min(k, K - 1);
-      wy[i][k] = P[a.Wy1 + (long long)c * K + kc];
       wg[i][k] = P[a.Wg0 + (long long)(a.D + kc) * H + c];
     }
+    sk_row16(P + a.Wy1 + (long long)c * K, K, wy[i]);
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -1053,9 +1066,9 @@ __global__ __launch_bounds__(256) void sk_ypath_r(const SkArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int kc = min(k, K - 1);
-      wy[i][k] = P[a.Wy1 + (long long)c * K + kc];
       wg[i][k] = P[a.Wg0 + (long long)(a.D + kc) * H + c];
     }
+    sk_row16(P + a.Wy1 + (long long)c * K, K, wy[i]);
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -1165,9 +1178,9 @@ __global__ __launch_bounds__(256) void sk_ybwd_r(const SkArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int kc = min(k, K - 1);
-      wy[i][k] = P[a.Wy1 + (long long)c * K + kc];
       wg[i][k] = P[a.Wg0 + (long long)(a.D + kc) * H + c];
     }
+    sk_row16(P + a.Wy1 + (long long)c * K, K, wy[i]);
   }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -1426,8 +1439,9 @@ __global__ __launch_bounds__(kSkThreads) void sk_dw(const SkArgs a) {
     return;
   }
   // a workgroup's 8 waves take 8 CONSECUTIVE tiles (one row of tiles of a tensor: they share the A rows and write
-  // neighbouring rows of p, m, v).  Measured alternatives, both slower: tiles dealt round-robin over 256 workgroups (no
-  // shared lines: 70 vs 60 us per step), consecutive tiles walking down a column of tiles (62)
+  // neighbouring rows of p, m, v).  Measured alternatives, all slower: tiles dealt round-robin over 256 workgroups (no
+  // shared lines: 70 vs 60 us per step), consecutive tiles walking down a column of tiles (62), 4 / 5 / 6 waves per workgroup
+  // to spread the 1412 tiles of the bin/run_train.sh sizes over more than 177 CUs (63.6 / 70.1 / 61.2 against 60.7: round 4)
   for (int tile = blockIdx.x * kSkWaves + wave; tile < a.total_tiles; tile += ntw * kSkWaves) {
   int ti = 0;
 #pragma unroll
