@@ -450,14 +450,14 @@ def main():
         gemms = [l for l in levels if l[2] > 0]          # launches that do MFMA work (grouped GEMMs, mega kernel)
         dom = max(gemms, key=dur)
         # skinny.hpp: sk_gemm<stage, row tiles per workgroup>; the D-wide layers have a 64-column form (stages 7, 8); the y path a
-        # rows-per-workgroup form; the W stage is sk_dw, sk_dwb, or sk_dwc + sk_adam (two launches: their times add)
+        # rows-per-workgroup form; the W stage is sk_dw, sk_dwb<.> or sk_dwc
         SK_KERNELS = {"sk_first_layers": ["void gmvae::sk_gemm<0, "], "sk_first_layer": ["void gmvae::sk_gemm<0, "], "sk_q_head_z": ["void gmvae::sk_gemm<1, "],
                       "sk_dec_hidden": ["void gmvae::sk_gemm<2, "], "sk_dec_bernoulli": ["void gmvae::sk_gemm<3, ", "void gmvae::sk_gemm<7, "],
                       "sk_bwd_dhd": ["void gmvae::sk_gemm<4, ", "void gmvae::sk_gemm<8, "], "sk_bwd_dz_heads": ["void gmvae::sk_gemm<5, "],
                       "sk_bwd_dhg": ["void gmvae::sk_gemm<6, "], "sk_y_path": ["void gmvae::sk_ypath<", "void gmvae::sk_ypath_r<"],
                       "sk_y_path_bwd": ["void gmvae::sk_ybwd<", "void gmvae::sk_ybwd_r<"],
-                      "sk_dw_adam": ["gmvae::sk_dw", "gmvae::sk_dwb", "gmvae::sk_dwc", "gmvae::sk_adam"],
-                      "sk_dw": ["gmvae::sk_dw", "gmvae::sk_dwb", "gmvae::sk_dwc", "gmvae::sk_adam"]}
+                      "sk_dw_adam": ["gmvae::sk_dw", "void gmvae::sk_dwb<", "gmvae::sk_dwc"],
+                      "sk_dw": ["gmvae::sk_dw", "void gmvae::sk_dwb<", "gmvae::sk_dwc"]}
         step_flops = flops_per_step(a.model, d.D, d.L, d.K, hidden, d.S, B)
         # Bytes_alg(step) = B D (uint8 batch) + 9 * 4 P (read params; write grads; Adam reads p, m, v, g and
         # writes p, m, v); noise is generated in-kernel
@@ -530,7 +530,7 @@ def main():
             knames = ["gmvae::" + dom[0]] if dom[0].startswith(("mega", "dw_")) else SK_KERNELS.get(dom[0], [])
             hit = [k for k in kern_us if any(is_kernel(k, kn) for kn in knames)]
             if hit:
-                us = sum(kern_us[k] for k in hit)       # (one kernel, or the W stage's two launches)
+                us = sum(kern_us[k] for k in hit)
                 roof["rocprof_usec_per_launch"] = us
                 roof["rocprof_kernels"] = hit
                 roof["frac_rocprof"] = (roof["bytes_per_launch"] / us * 1e-3 / PEAK_HBM_GBS if roof["bound"] == "hbm"
