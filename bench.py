@@ -456,6 +456,7 @@ def main():
                       "sk_bwd_dhd": ["void gmvae::sk_gemm<4, ", "void gmvae::sk_gemm<8, "], "sk_bwd_dz_heads": ["void gmvae::sk_gemm<5, "],
                       "sk_bwd_dhg": ["void gmvae::sk_gemm<6, "], "sk_y_path": ["void gmvae::sk_ypath<", "void gmvae::sk_ypath_r<"],
                       "sk_y_path_bwd": ["void gmvae::sk_ybwd<", "void gmvae::sk_ybwd_r<"],
+                      "sk_gmp_bwd": ["gmvae::sk_gmp_bwd"],
                       "sk_dw_adam": ["gmvae::sk_dw", "void gmvae::sk_dwb<", "gmvae::sk_dwc"],
                       "sk_dw": ["gmvae::sk_dw", "void gmvae::sk_dwb<", "gmvae::sk_dwc"]}
         step_flops = flops_per_step(a.model, d.D, d.L, d.K, hidden, d.S, B)

@@ -1372,7 +1372,8 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   const NetL &E = vae ? L.enc : L.ency, &G = vae ? L.enc : L.encg, &Dn = L.dec;
   s.model = a.model;
   if (gmp) {
-    s.dz = w.dz; s.gmp_part = w.gmp_part;
+    s.dz = w.dz; s.gmp_part = w.gmp_part; s.resp = w.resp;
+    s.gmp_raw = (long long)L.rawscale; s.gmp_mix = (long long)L.mixlog;
     s.gmp_n = B / 4 < 16 ? 16 : (B / 4 > GMP_PARTS ? GMP_PARTS : B / 4);       // strips of ~4 rows (gmp_param_bwd walks a strip serially), 16 .. GMP_PARTS
     s.gmp_len = 2 * (int)pad4((uint64_t)K * Lz) + (int)pad4(K); s.gmp_off = (long long)L.loc;
   }
@@ -1455,7 +1456,10 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   else launch(yr == 2 ? sk_ypath_r<2, 2> : sk_ypath_r<2, 4>, (B + yr - 1) / yr + eps_blocks, 256, 0, "sk_y_path", fB * ((double)H * K + K * H + K * 2.0 * Lz));
   }
   gemm(std::integral_constant<int, SK_F3>{}, (Lz + 15) / 16, 1, 0, "sk_q_head_z", fB * H * 2 * Lz);
-  if (gmp) launch_mixture_logprob(cx, w, a.params, L, B, Lz, K);
+  // (VAE_GMP: the mixture log-density rides on sk_gmp_bwd behind B2 where its LDS form fits; else the row kernel here)
+  const size_t gmp_sh = (size_t)(2 * K * (Lz | 1) + 128 + 64 * kGmpStripRows) * sizeof(float);
+  const bool gmp_fused = gmp && K <= 64 && gmp_sh <= 64 * 1024 && (B + s.gmp_n - 1) / (s.gmp_n > 0 ? s.gmp_n : 1) <= kGmpStripRows;
+  if (gmp && !gmp_fused) launch_mixture_logprob(cx, w, a.params, L, B, Lz, K);
   gemm(std::integral_constant<int, SK_F4>{}, H / 64, 1, 0, "sk_dec_hidden", fB * Lz * H);
   if (wide) gemm(std::integral_constant<int, SK_F5W>{}, (D + 63) / 64, 1, 0, "sk_dec_bernoulli", fB * H * D);
   else gemm(std::integral_constant<int, SK_F5>{}, D / 16, 1, 0, "sk_dec_bernoulli", fB * H * D);
@@ -1491,12 +1495,18 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   else gemm(std::integral_constant<int, SK_B1>{}, H / 16, 1, 0, "sk_bwd_dhd", fB * D * H);
   gemm(std::integral_constant<int, SK_B2>{}, (Lz + 15) / 16, 1, 0, "sk_bwd_dz_heads", fB * H * Lz);
   if (gmp) {                                     // the mixture prior's share of dz and the q head's reverse; its variables' gradients
-    hipLaunchKernelGGL(z_head_bwd, dim3(grid_for(B, 4)), dim3(256), 0, st, w.dz, w.qp, 1, (const float*)nullptr, eps, w.z, (const float*)nullptr,
-                       w.resp, a.params + L.loc, a.params + L.rawscale, w.dqp, (float*)nullptr, B, Lz, K, (int)PRIOR_GMP, d.raw_sigma_bias, d.sigma_min);
-    rowk(cx, "z_head_bwd");
-    hipLaunchKernelGGL(gmp_param_bwd, dim3(s.gmp_n), dim3(256), 0, st, w.z, w.resp, (const float*)nullptr, a.params + L.loc,
-                       a.params + L.rawscale, a.params + L.mixlog, w.gmp_part, B, Lz, K, (int)pad4((uint64_t)K * Lz));
-    rowk(cx, "gmp_param_bwd");
+    if (gmp_fused) {                             // one launch, (loc, 1 / s) staged in LDS (skinny.hpp sk_gmp_bwd)
+      const int nz = (B + 3) / 4;
+      hipLaunchKernelGGL(sk_gmp_bwd, dim3(nz + s.gmp_n), dim3(256), gmp_sh, st, s, nz);
+      rowk(cx, "sk_gmp_bwd");
+    } else {                                     // any K, L: the general schedule's row kernels
+      hipLaunchKernelGGL(z_head_bwd, dim3(grid_for(B, 4)), dim3(256), 0, st, w.dz, w.qp, 1, (const float*)nullptr, eps, w.z, (const float*)nullptr,
+                         w.resp, a.params + L.loc, a.params + L.rawscale, w.dqp, (float*)nullptr, B, Lz, K, (int)PRIOR_GMP, d.raw_sigma_bias, d.sigma_min);
+      rowk(cx, "z_head_bwd");
+      hipLaunchKernelGGL(gmp_param_bwd, dim3(s.gmp_n), dim3(256), 0, st, w.z, w.resp, (const float*)nullptr, a.params + L.loc,
+                         a.params + L.rawscale, a.params + L.mixlog, w.gmp_part, B, Lz, K, (int)pad4((uint64_t)K * Lz));
+      rowk(cx, "gmp_param_bwd");
+    }
   }
   gemm(std::integral_constant<int, SK_B3>{}, H / 32, 1, 0, "sk_bwd_dhg", fB * 2 * Lz * H);
   if (!vae) {

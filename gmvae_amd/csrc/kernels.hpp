@@ -196,7 +196,16 @@ __global__ void mixture_logprob_lse(const float* __restrict__ z, const float* __
     s_inv[k * LD + l] = 1.f / s;
   }
   __syncthreads();
-  if (wave == 0) {                      // per-component constants + log_softmax of the mixture logits
+  // per-component constants: sum_l -log s_kl, a wave per component with the lanes over l (one lane per component walking the L
+  // logarithms serially was 1 us of this launch at K = 10, L = 64) ...
+  for (int k = wave; k < K; k += nw) {
+    float ls = 0.f;
+    for (int l = lane; l < L; l += 64) ls += logf(s_inv[k * LD + l]);   // = -log s
+    ls = wave_sum(ls);
+    if (lane == 0) s_c[k] = ls;
+  }
+  __syncthreads();
+  if (wave == 0) {                      // ... + log_softmax of the mixture logits
     float mx = -INFINITY;
     for (int k = lane; k < K; k += 64) mx = fmaxf(mx, mixlog[k]);
     mx = wave_max(mx);
@@ -204,11 +213,7 @@ __global__ void mixture_logprob_lse(const float* __restrict__ z, const float* __
     for (int k = lane; k < K; k += 64) se += expf(mixlog[k] - mx);
     se = wave_sum(se);
     const float lse = mx + logf(se);
-    for (int k = lane; k < K; k += 64) {
-      float ls = 0.f;
-      for (int l = 0; l < L; ++l) ls += logf(s_inv[k * LD + l]);   // = -log s
-      s_c[k] = mixlog[k] - lse + ls - 0.5f * kLog2Pi * (float)L;
-    }
+    for (int k = lane; k < K; k += 64) s_c[k] = mixlog[k] - lse + s_c[k] - 0.5f * kLog2Pi * (float)L;
   }
   __syncthreads();
   const int rpw = 64 / Kp;              // rows handled by one wave at a time

@@ -57,6 +57,8 @@ struct SkArgs {
   unsigned long long* step_dev;
   // W launch
   int ntens, total_tiles;
+  const float* resp;           // VAE_GMP: the mixture prior's responsibilities [B][K] (mixture_logprob_*), and where its variables
+  long long gmp_raw, gmp_mix;  //   lie in the flat layout (loc at gmp_off)
   float* dwp;                  // sk_dwc: dw_ks partial gradients (one per batch share) in the flat layout, dwp_stride floats apart,
   long long dwp_stride;        //   and a counter of arrived shares per tile (zeroed by the step's first launch)
   int dw_ks;
@@ -2077,6 +2079,163 @@ __global__ __launch_bounds__(kDwcThreads, 3) void sk_dwc(const SkArgs a) {
     }
   }
   SK_STAMP(9, 3);
+}
+
+// VAE_GMP behind B2, ONE launch for everything the learned mixture prior adds to the step (scripts/vae.py:231-244, consumed at
+// vae.py:181): log p(z) and the responsibilities (kernels.hpp mixture_logprob_lse), the prior's share of dz with the
+// q head's reverse (z_head_bwd at PRIOR_GMP, S = 1) and the partial gradients of the prior's variables per strip of rows
+// (gmp_param_bwd).  As three launches of the general schedule's row kernels -- written for 10^4 - 10^5 rows: softplus(raw_scale)
+// per (row, component, dim), one lane walking a component's L terms -- they were 24 us of an 80 us step at B = 256.  Here every
+// workgroup stages (loc, 1 / s) and the components' constants once in LDS; a row's K component terms are K wave sums over the
+// latent dims (lane = dim), its logsumexp one more; the responsibilities never leave LDS.  Workgroups [0, nz): 4 rows each (a
+// wave per row) -> logp, dqp; [nz, nz + gmp_n): strip i of the rows -> partial i in the flat layout's order [loc KLp | raw_scale
+// KLp | mixture_logits pad4(K)], summed in strip order by the W launch.  K <= 64, 2 K (L | 1) floats of LDS (else the row kernels).
+constexpr int kGmpStripRows = 64;                  // rows of a strip whose responsibilities LDS holds (B <= 4096 / 64 strips)
+__global__ __launch_bounds__(256) void sk_gmp_bwd(const SkArgs a, const int nz) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int B = a.B, L = a.L, K = a.K, LD = L | 1, KL = K * L;
+  float* const s_loc = sm;                         // [K][LD]
+  float* const s_is = sm + K * LD;                 // [K][LD]: 1 / s
+  float* const s_c = s_is + K * LD;                // [64]: log_softmax(mixture_logits)_k - sum_l log s_kl - L/2 log 2 pi
+  float* const s_w = s_c + 64;                     // [64]: softmax(mixture_logits)
+  float* const s_r = s_w + 64;                     // responsibilities [kGmpStripRows or 4][64]
+  const float* const P = a.P;
+  SK_STAMP(8, 0);
+  // (every global load of the prologue in flight before the first use: the variables were written by the previous step's last
+  //  launch, one memory round trip is ~2 us)
+  const float ml = (wave == 0 && lane < K) ? P[a.gmp_mix + lane] : -INFINITY;
+  for (int i0 = 0; i0 < KL; i0 += 1024) {
+    float lc[4], rw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = min(i0 + tid + 256 * j, KL - 1);
+      lc[j] = P[a.gmp_off + i]; rw[j] = P[a.gmp_raw + i];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = i0 + tid + 256 * j;
+      if (i < KL) {
+        const int k = i / L, l = i - k * L;
+        s_loc[k * LD + l] = lc[j];
+        s_is[k * LD + l] = 1.f / softplusf_(rw[j]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = wave; k < K; k += 4) {
+    float ls = 0.f;
+    for (int l = lane; l < L; l += 64) ls += logf(s_is[k * LD + l]);       // = -log s
+    ls = row16_sum(ls); ls += __shfl_xor(ls, 16, 64); ls += __shfl_xor(ls, 32, 64);
+    if (lane == 0) s_c[k] = ls;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float mx = wave_max(ml);
+    const float em = lane < K ? expf(ml - mx) : 0.f;
+    const float se = wave_sum(em);
+    if (lane < K) { s_c[lane] = ml - (mx + logf(se)) + s_c[lane] - 0.5f * kLog2Pi * (float)L; s_w[lane] = em / se; }
+  }
+  __syncthreads();
+  SK_STAMP(8, 1);
+  // row r's responsibilities into rs[0..K) (and log p(z) returned in every lane): lane = latent dim (+ 64 q; L <= 256).  The K
+  // sums over the dims run 16 components at a time -- DPP row sums, then two shuffles across the wave's four rows, 16 independent
+  // chains (one wave_sum of six dependent shuffles per component made a row 2.5 us)
+  auto wsum = [](float v) { v = row16_sum(v); v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); };
+  auto wmax = [](float v) { v = row16_max(v); v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); };
+  auto row_resp = [&](const int r, float* __restrict__ rs) {
+    float zr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) zr[q] = a.z[(long long)r * L + min(lane + 64 * q, L - 1)];
+    float comp = -INFINITY;                        // lane k ends with component k's term
+    for (int k0 = 0; k0 < K; k0 += 16) {
+      float p[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = min(k0 + j, K - 1);
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int l = min(lane + 64 * q, L - 1);
+          const float t = (zr[q] - s_loc[k * LD + l]) * s_is[k * LD + l];
+          acc += lane + 64 * q < L ? t * t : 0.f;
+        }
+        p[j] = acc;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) p[j] = wsum(p[j]);
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (lane == k0 + j && lane < K) comp = s_c[lane] - 0.5f * p[j];
+    }
+    const float mx = wmax(comp);
+    const float se = wsum(lane < K ? expf(comp - mx) : 0.f);
+    const float lse = mx + logf(se);
+    if (lane < K) rs[lane] = expf(comp - lse);
+    return lse;
+  };
+  if ((int)blockIdx.x < nz) {
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= B) return;
+    float* const rs = s_r + wave * 64;
+    const float lse = row_resp(r, rs);
+    if (lane == 0) st1o(a.logp + r, lse);
+    SK_STAMP(8, 2);
+    __builtin_amdgcn_wave_barrier();
+    for (int l = lane; l < L; l += 64) {
+      const long long o = (long long)r * L + l;
+      const float zz = a.z[o], dzv = a.dz[o], ev = a.eps[o];
+      const float rawq = a.qp[(long long)r * 2 * L + L + l] + a.c;
+      float pterm = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float is = s_is[k * LD + l];
+        pterm += rs[k] * (zz - s_loc[k * LD + l]) * is * is;
+      }
+      const float spq = softplusf_(rawq), sg = fmaxf(spq, a.smin);
+      const float dmu = dzv + pterm;
+      const float dsg = dmu * ev - 1.f / sg;
+      st1o(a.dqp + (long long)r * 2 * L + l, dmu);
+      st1o(a.dqp + (long long)r * 2 * L + L + l, (spq > a.smin) ? dsg * sigmoidf_(rawq) : 0.f);
+    }
+    SK_STAMP(8, 3);
+    return;
+  }
+  const int strip = blockIdx.x - nz;
+  const int KLp = (KL + 3) & ~3;
+  const int rows_per = (B + a.gmp_n - 1) / a.gmp_n;      // (<= kGmpStripRows: the host's strip count)
+  const int rb = strip * rows_per, re = min(B, rb + rows_per);
+  for (int r = rb + wave; r < re; r += 4) row_resp(r, s_r + (r - rb) * 64);
+  __syncthreads();
+  SK_STAMP(8, 2);
+  float* const out = const_cast<float*>(a.gmp_part) + (long long)strip * a.gmp_len;      // (SkArgs keeps it const: the W launch only reads it)
+  for (int i = tid; i < KL; i += 256) {
+    const int k = i / L, l = i - k * L;
+    const float is = s_is[k * LD + l], lc = s_loc[k * LD + l];
+    const float rawv = P[a.gmp_raw + i];
+    float ga = 0.f, gb = 0.f;
+    for (int r0 = rb; r0 < re; r0 += 4) {          // four rows' loads in flight (a row at a time: a round trip per row)
+      float zv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) zv[j] = a.z[(long long)min(r0 + j, re - 1) * L + l];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (r0 + j < re) {
+          const float wr = s_r[(r0 + j - rb) * 64 + k];
+          const float t = (zv[j] - lc) * is;
+          ga -= wr * t * is;
+          gb += wr * (1.f - t * t) * is;
+        }
+    }
+    st1o(out + i, ga);
+    st1o(out + KLp + i, gb * sigmoidf_(rawv));
+  }
+  if (tid < K) {
+    const float wk = s_w[tid];
+    float ga = 0.f;
+    for (int r = rb; r < re; ++r) ga -= s_r[(r - rb) * 64 + tid] - wk;
+    st1o(out + 2 * KLp + tid, ga);
+  }
+  SK_STAMP(8, 3);
 }
 
 }  // namespace gmvae

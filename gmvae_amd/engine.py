@@ -614,8 +614,12 @@ class Engine:
         st = buf.reshape(10, 1024, 8).astype(np.float64)
         names = ["sk_first_layers", "sk_y_path", "sk_q_head_z", "sk_dec_hidden", "sk_dec_bernoulli", "sk_bwd_dhd", "sk_bwd_dz_heads",
                  "sk_bwd_dhg", "sk_y_path_bwd", "sk_dw_adam"]
+        order = list(range(10))
+        if self.model == L.MODEL_IDS["vae_gmp"]:                   # the mixture prior's launch stamps the (free) slot of the y
+            names[8] = "sk_gmp_bwd"                                #  path's reverse and runs behind B2
+            order = [0, 1, 2, 3, 4, 5, 6, 8, 7, 9]
         starts, ends, present = [], [], []
-        for i in range(10):
+        for i in order:
             r = st[i][st[i][:, 0] > 0]
             if not len(r):
                 continue                                           # (the VAE has no y path: slots 1 and 8 stay empty)

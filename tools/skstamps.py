@@ -9,7 +9,8 @@ from gmvae_amd.engine import Engine
 L.check(L.lib.gmvae_debug_sk_stamps(None), "arm")
 B, G = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), 8
 Lz = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-e = Engine("gmvae", 784, Lz, 10, [512], random_seed=0)
+model = sys.argv[4] if len(sys.argv) > 4 else "gmvae"
+e = Engine(model, 784, Lz, 10, [512], random_seed=0)
 sx, replay = e.capture_train_step(B, 1e-3, n_steps=G)
 sx.copy_(torch.from_numpy((np.random.default_rng(0).random((G, B, 784)) < 0.87).astype(np.uint8)).cuda())
 for _ in range(300): replay()
@@ -17,9 +18,11 @@ torch.cuda.synchronize()
 buf = np.zeros(10 * 1024 * 8, np.uint64)
 L.check(L.lib.gmvae_debug_sk_stamps(buf.ctypes.data_as(C.c_void_p)), "stamps")
 st = buf.reshape(10, 1024, 8).astype(np.float64)
-names = ["F1 first", "F2 ypath", "F3 qhead", "F4 dechid", "F5 decout", "B1 dhd", "B2 dz", "B3 dhg", "B4 ybwd", "W dw"]
+names = ["F1 first", "F2 ypath", "F3 qhead", "F4 dechid", "F5 decout", "B1 dhd", "B2 dz", "B3 dhg", "B4 ybwd" if model == "gmvae" else "GMP prior", "W dw"]
+order = list(range(10)) if model == "gmvae" else [0, 1, 2, 3, 4, 5, 6, 8, 7, 9]      # (VAE_GMP: sk_gmp_bwd stamps slot 8 and runs behind B2)
 prev_end = None
-for i, nm in enumerate(names):
+for i in order:
+    nm = names[i]
     r = st[i][st[i][:, 0] > 0]
     if not len(r): continue
     start, end = r[:, 0].min(), r[:, 3].max()
