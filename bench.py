@@ -505,6 +505,11 @@ def main():
             roof.update({"bound": "hbm", "achieved": w_bytes / dur(dom) * 1e-3, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": w_bytes / dur(dom) * 1e-3 / PEAK_HBM_GBS, "bytes_per_launch": w_bytes,
                          "frac_in_kernel_span": w_bytes / dom[1] * 1e-3 / PEAK_HBM_GBS})
+        if schedule == "skinny" and B > 128 and roof["bound"] == "mfma":
+            # above 128 rows the skinny schedule's large products run as exact bf16 piece products (skinny.hpp: the uint8
+            # operand's 3 per fp32 product, fp32 x fp32 6): `frac` stays fp32-EQUIVALENT FLOP/s over the fp32 MFMA peak
+            roof["peak_note"] = ("fp32-equivalent FLOP/s against the fp32 MFMA peak; the launch multiplies exact bf16 pieces "
+                                 "(3 piece products per product with the uint8 operand, 6 for fp32 x fp32) on the bf16 pipes")
         # Committed evidence of the same command (tools/profile_round.sh -> profiles/roundN_*): rocprofv3 --kernel-trace
         # --stats average per kernel, and HBM-side bytes per launch from separate --pmc passes (FETCH_SIZE x2 on gfx950 +
         # WRITE_SIZE; rocprofv3 --pmc cannot run inside this process).  Keyed by workload; the newest round present wins.
