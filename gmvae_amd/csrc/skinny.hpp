@@ -116,7 +116,8 @@ __device__ __forceinline__ void sk_pipe(const int kg_lo, const int kg_hi, const 
   const int kg = kg_lo + wave;
   const int n = kg < kg_hi ? (kg_hi - kg + kSkWaves - 1) / kSkWaves : 0;
   if (n == 0) return;
-  if constexpr (!PIPE) {                          // one register set (the 6-product forms at RT = 4: two would spill)
+  if constexpr (!PIPE) {                          // one register set: the 6-product forms (two sets: 188 registers at RT = 2 and
+                                                  // measured 0.5 us slower there, spills at RT = 4)
     for (int i = 0; i < n; ++i) {
       Frag f;
       ld(f, kg + kSkWaves * i);
@@ -226,7 +227,7 @@ template <int RT> struct SkFragN6 { float4 av[RT][2]; float4 bv[8]; };
 template <int RT>
 __device__ __forceinline__ void sk_nn4_bf6(const float* __restrict__ A, const long long (&arow)[RT], const float* __restrict__ W, const int ldw,
                                            const int ncol, const int g_hi, const int wave, const int lk, f32x4 (&acc)[RT][4]) {
-  sk_pipe<SkFragN6<RT>, (RT < 4)>(0, g_hi, wave,
+  sk_pipe<SkFragN6<RT>, false>(0, g_hi, wave,
     [&](SkFragN6<RT>& f, const int gi) {
       const int k = 32 * gi + 8 * lk;
 #pragma unroll
@@ -262,7 +263,7 @@ template <int RT, int NU>
 __device__ __forceinline__ void sk_nt_bf6(const float* __restrict__ A, const long long (&arow)[RT], const float* __restrict__ W, const int ldw,
                                           const int (&wrow)[NU], const int g_hi, const int wave, const int lk, const int kmax,
                                           f32x4 (&acc)[RT][4]) {
-  sk_pipe<SkFragT6<RT, NU>, (RT < 4)>(0, g_hi, wave,
+  sk_pipe<SkFragT6<RT, NU>, false>(0, g_hi, wave,
     [&](SkFragT6<RT, NU>& f, const int gi) {
       const int k0 = 32 * gi + 8 * lk;
       const int k = min(k0, kmax - 8);            // (kmax a multiple of 16: the last group may be half empty: clamped, A zero)
