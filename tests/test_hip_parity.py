@@ -597,6 +597,43 @@ def _random_skinny_cases(n, seed):
 RANDOM_SKINNY_CASES = _random_skinny_cases(15, 20261005)
 
 
+def _random_large_skinny_cases(n, seed):
+    """Seeded random shapes for the schedule's forms ABOVE 128 rows: row-tile groups (ragged last group), 64-column tiles with a
+    ragged last tile (D no multiple of 64), the y path's 1 / 2 / 4 rows per workgroup, all three weight-gradient forms (one
+    workgroup per tile with bf16 pieces or fp32 instructions; batch shares with a last-arriver optimizer), the mixture prior's
+    one-launch form with ragged strips."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        model = ["gmvae", "vae_gmp", "vae"][i % 3]
+        d = O.Dims(D=int(rng.choice([208, 400, 784, 1008])), L=int(rng.choice([8, 20, 32, 64, 128])),
+                   K=1 if model == "vae" else int(rng.choice([3, 7, 10, 16])), hidden=(int(rng.choice([128, 256, 320, 512, 768])),),
+                   temperature=float(rng.choice([1.0, 0.7])), sigma_min=float(rng.choice([0.0, 0.0, 0.5])))
+        out.append((model, d, int(rng.choice([130, 257, 333, 520, 777, 1025, 1290, 1700, 2100]))))
+    return out
+
+
+# (the seed is the first after 20261006 whose 12 shapes take EVERY form: three batch-share launches -- one of them VAE_GMP --, one
+#  fp32 one-workgroup-per-tile launch, 1 / 2 / 4 rows per y-path workgroup; a coverage choice, made before any shape was run)
+RANDOM_LARGE_SKINNY_CASES = _random_large_skinny_cases(12, 20261026)
+
+
+@pytest.mark.parametrize("name,d,B", RANDOM_LARGE_SKINNY_CASES,
+                         ids=[f"{n}-D{d.D}-L{d.L}-K{d.K}-H{d.hidden[0]}-B{B}" for n, d, B in RANDOM_LARGE_SKINNY_CASES])
+def test_skinny_schedule_above_128_rows_on_random_shapes(H, monkeypatch, name, d, B):
+    monkeypatch.setenv("GMVAE_NO_MEGA", "1")
+    monkeypatch.setenv("GMVAE_NO_FUSED", "1")
+    model = O.MODEL_NAMES[name]
+    assert _L().step_schedule(H.dims_of(d, B), model) == "skinny"
+    rng = np.random.default_rng(B * 13 + d.D + d.L)
+    p = O.init_params(model, d, rng)
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    x, eps, u = O.make_inputs(d, B, model)
+    H.compare_step(model, d, p, x, eps, u)
+
+
 def test_skinny_schedule_four_rows_per_y_path_workgroup(H, monkeypatch):
     """Above 1536 rows the y path carries four rows per workgroup; here the last workgroup's rows are ragged.  (The schedule's
     batch bound is 4096 rows: beyond, the general schedule.)"""
