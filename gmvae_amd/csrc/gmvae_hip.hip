@@ -1409,7 +1409,7 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   s.logpx = w.logpx; s.logq = w.logq; s.logp = w.logp; s.logw = w.logw;
   // the W stage's form: up to 128 batch rows sk_dw (one-wave tiles); above, [64 x 64] tiles: one workgroup each (sk_dwb<1>: bf16
   // pieces, one per CU at its 170 registers; more tiles than CUs: sk_dwb<0>, fp32 matrix instructions, two per CU) or -- more
-  // tiles than CUs and at least 512 rows -- two batch shares each and the optimizer in a launch of its own (sk_dwc + sk_adam)
+  // tiles than CUs and at least 512 rows -- two batch shares each, the last-arriving share running the optimizer (sk_dwc)
   const bool dw_big = B > 128;
   auto add = [&](const void* A, bool u8, int lda, const float* dY, int ldy, int M, int N, uint64_t w_off, long long b_off) {
     SkTensor& T = s.t[s.ntens++];

@@ -1665,7 +1665,7 @@ __device__ __forceinline__ void sk_dw_contract64(const SkTensor& T, const int ma
 }
 
 // ... the same with fp32 matrix instructions (16 v_mfma_f32_16x16x4_f32 per batch row quad): 126 registers instead of 170, so TWO
-// 8-wave workgroups fit a CU -- the form for more tiles than CUs at batches too short to pay for a second launch (sk_dwb<0>)
+// 8-wave workgroups fit a CU -- the form for more tiles than CUs at batches too short for batch shares (sk_dwb<0>)
 __device__ __forceinline__ void sk_dw_contract64_f32(const SkTensor& T, const int mac, const int nc, const int b_lo, const int b_hi,
                                                      const int lk, f32x4 (&acc)[4][4], float4& cs) {
   const int lda = T.lda, ldy = T.ldy;
@@ -1716,7 +1716,7 @@ __device__ __forceinline__ void sk_dw_contract64_f32(const SkTensor& T, const in
 // gradient move in 16-byte accesses, 256 contiguous bytes per lane group (rows of N % 4 != 0: element by element).
 // Tiles are dealt so that the 8 workgroups an XCD receives in turn hold neighbouring tiles (shared operand columns in its L2).
 // (Measured and dropped: [32 x 64] tiles to balance 354 tiles over 256 CUs -- twice the workgroups, but only two of them fit a CU,
-// so the second half queued: 43 us against 46.  Where the tiles do not balance, the stage runs as sk_dwc + sk_adam below.)
+// so the second half queued: 43 us against 46.  Where the tiles do not balance, the stage runs as sk_dwc below.)
 template <int BF>
 __global__ __launch_bounds__(kSkThreads) void sk_dwb(const SkArgs a) {
   constexpr int TM = 4, NP = 2;                    // strided 16-row tiles; meetings (halves of 32 accumulator registers)
