@@ -1745,12 +1745,11 @@ __global__ __launch_bounds__(kSkThreads) void sk_dwb(const SkArgs a) {
   for (int i = 1; i < kSkMaxT; ++i)
     if (i < a.ntens && tile >= a.t[i].tile_begin) ti = i;
   const SkTensor& T = a.t[ti];
-  const int M = T.M, N = T.N, lda = T.lda, ldy = T.ldy;
+  const int M = T.M, N = T.N;
   const int tl = tile - T.tile_begin, tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
   const int m0 = tm * 16 * TM, n0 = tn * 64;
   const int mac = min(m0 + TM * ln, ((M + 3) & ~3) - TM);        // (operand rows hold pad4(M), pad4(N) elements; rows m >= M and
   const int nc = min(n0 + 4 * ln, ((N + 3) & ~3) - 4);         //  columns n >= N of the tile are computed from clamped loads and never stored)
-  const bool n_ok = n0 + 4 * ln < N;
   const int rows_p = (((B + kSkWaves - 1) / kSkWaves) + 3) & ~3;
   const int b_lo = min(B, wave * rows_p), b_hi = min(B, b_lo + rows_p);
   f32x4 acc[TM][4];
@@ -1904,12 +1903,11 @@ __global__ __launch_bounds__(kDwcThreads, 3) void sk_dwc(const SkArgs a) {
   for (int i = 1; i < kSkMaxT; ++i)
     if (i < a.ntens && tile >= a.t[i].tile_begin) ti = i;
   const SkTensor& T = a.t[ti];
-  const int M = T.M, N = T.N, lda = T.lda, ldy = T.ldy;
+  const int M = T.M, N = T.N;
   const int tl = tile - T.tile_begin, tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
   const int m0 = tm * 16 * TM, n0 = tn * 64;
   const int mac = min(m0 + TM * ln, ((M + 3) & ~3) - TM);
   const int nc = min(n0 + 4 * ln, ((N + 3) & ~3) - 4);
-  const bool n_ok = n0 + 4 * ln < N;
   const int rows_s = (((B + a.dw_ks - 1) / a.dw_ks) + 3) & ~3;                    // this workgroup's share of the batch rows ...
   const int s_lo = min(B, ks * rows_s), s_hi = min(B, s_lo + rows_s);
   const int rows_p = (((s_hi - s_lo + kDwcWaves - 1) / kDwcWaves) + 3) & ~3;      // ... and this wave's share of that
