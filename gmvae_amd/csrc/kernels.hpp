@@ -50,6 +50,16 @@ __global__ void y_head_fwd(const float* __restrict__ logits, const float* __rest
   for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < R; r += gridDim.x * wpb) {
     const int b = r / S;
     const float* lg = logits + (long long)b * K;
+    if (K <= 64) {
+      // one pass: the perturbed logit is computed ONCE and kept (the three passes below re-evaluate -log(-log u) -- two
+      // precise logarithms -- per pass: at the config-5 sizes, 1.6 M elements, that arithmetic was the kernel's 17 us)
+      const bool kv = lane < K;
+      const float a = kv ? (lg[lane] + -logf(-logf(u[(long long)r * K + lane]))) * invT : -INFINITY;
+      const float mx = wave_max(a);
+      const float se = wave_sum(kv ? expf(a - mx) : 0.f);
+      const float lse = mx + logf(se);
+      if (kv) y[(long long)r * K + lane] = expf(a - lse);
+    } else {
     float mx = -INFINITY;
     for (int k = lane; k < K; k += 64) {
       const float g = -logf(-logf(u[(long long)r * K + k]));
@@ -66,6 +76,7 @@ __global__ void y_head_fwd(const float* __restrict__ logits, const float* __rest
     for (int k = lane; k < K; k += 64) {
       const float g = -logf(-logf(u[(long long)r * K + k]));
       y[(long long)r * K + k] = expf((lg[k] + g) * invT - lse);
+    }
     }
     if (r == b * S) {       // once per x: entropy of q(y|x)
       float m2 = -INFINITY;
