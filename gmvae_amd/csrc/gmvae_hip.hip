@@ -1549,6 +1549,30 @@ static int run_step(Ctx& cx, const StepArgs& a) {
 
   // ================================ forward ================================
   const NetL& E = gm ? L.ency : L.enc;
+  const int flx_h0 = E.dim[1], flx_h1 = gm ? L.encg.dim[1] : 0;
+  if (D % 16 == 0 && flx_h0 % 64 == 0 && flx_h1 % 64 == 0 && E.nl > 1) {
+    // first layers over the uint8 batch as exact bf16 piece products (skinny.hpp first_layers_u8bf); the Philox fill in a
+    // launch of its own
+    FlxArgs f;
+    f.x = a.x; f.W0 = P + E.w[0]; f.b0 = P + E.b[0]; f.out0 = w.he[1]; f.H0 = flx_h0; f.relu0 = 1;
+    f.W1 = gm ? P + L.encg.w[0] : nullptr; f.out1 = gm ? w.gx : nullptr; f.H1 = flx_h1;
+    f.B = B; f.D = D;
+    const int nct = (flx_h0 + flx_h1) / 64, nrt = (B + 15) / 16;
+    int rt = 4;
+    while (rt > 1 && nct * ((nrt + rt - 1) / rt) < 256) rt >>= 1;
+    const int grid = nct * ((nrt + rt - 1) / rt);
+    if (rt == 4) hipLaunchKernelGGL(first_layers_u8bf<4>, dim3(grid), dim3(kSkThreads), 0, st, f);
+    else if (rt == 2) hipLaunchKernelGGL(first_layers_u8bf<2>, dim3(grid), dim3(kSkThreads), 0, st, f);
+    else hipLaunchKernelGGL(first_layers_u8bf<1>, dim3(grid), dim3(kSkThreads), 0, st, f);
+    cx.check();
+    cx.mark("fwd_x_first_layers", 2.0 * B * D * (flx_h0 + flx_h1));
+    if (noise_aux) {
+      const uint64_t q = noise_items(ge, gu, (uint64_t)R, Lz, K);
+      hipLaunchKernelGGL(noise_fill, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, ge, gu, (uint64_t)R, Lz, K,
+                         (uint64_t)d.row0 * S, (uint64_t)a.seed, (uint64_t)a.step, reinterpret_cast<const uint64_t*>(a.step_dev));
+      rowk(cx, "noise_fill");
+    }
+  } else
   {  // first layers over the uint8 batch: enc_y layer 0 and the x-part of enc_gmm layer 0
     Group g;
     float* out = (E.nl == 1) ? (gm ? w.logits : w.qp) : w.he[1];

@@ -2237,4 +2237,69 @@ __global__ __launch_bounds__(256) void sk_gmp_bwd(const SkArgs a, const int nz) 
   SK_STAMP(8, 3);
 }
 
+// ---- the general schedule's first layers over the uint8 batch (enc layer 0: bias (+ ReLU); GMVAE: and the x part of enc_gmm layer 0,
+// raw) in the form F1 takes above 128 rows: RT row tiles x 64 strided columns per workgroup, the contraction split over 8 waves as
+// 3 exact bf16 piece products on the matrix cores (sk_nn4_u8bf), partial tiles meeting in LDS in wave order.  The grouped fp32 GEMM
+// ran these at 46 TFLOP/s (config-5 shard: [512 x 3072] x [3072 x 1024] in 70 us).  D % 16 = 0, widths % 64 = 0.
+struct FlxArgs {
+  const unsigned char* x;
+  const float *W0, *b0, *W1;   // [D][H0] (+ bias [H0]); [D][H1] or null
+  float *out0, *out1;          // [B][H0], [B][H1]
+  int H0, H1, relu0, B, D;
+};
+template <int RT>
+__global__ __launch_bounds__(kSkThreads) void first_layers_u8bf(const FlxArgs a) {
+  constexpr int CJ = RT == 1 ? 1 : 2, NC = RT / CJ;
+  __shared__ __attribute__((aligned(16))) float red[kSkWaves * CJ * 16 * 64];      // [wave][jl][4 t + r][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lk = lane >> 4;
+  const int B = a.B, D = a.D;
+  const int nct = (a.H0 + a.H1) / 64;
+  const int ct = blockIdx.x % nct, rt = blockIdx.x / nct;
+  const bool second = ct * 64 >= a.H0;
+  const int c0 = second ? ct * 64 - a.H0 : ct * 64, ldw = second ? a.H1 : a.H0;
+  const float* const W = (second ? a.W1 : a.W0) + c0;
+  const int r0 = rt * 16 * RT;
+  long long arow[RT];
+#pragma unroll
+  for (int j = 0; j < RT; ++j) arow[j] = (long long)min(r0 + 16 * j + ln, B - 1) * D;
+  const int el = tid & 63, er = (tid >> 6) & 3, jl = tid >> 8, ec = el & 15;
+  const bool owner = tid < 256 * CJ;
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (owner && !second && a.b0) bias = *reinterpret_cast<const float4*>(a.b0 + c0 + 4 * ec);
+  f32x4 acc[RT][4];
+#pragma unroll
+  for (int j = 0; j < RT; ++j)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  sk_nn4_u8bf<RT>(a.x, arow, W, ldw, 4 * ln, 0, (D + 31) / 32, wave, lk, D, acc);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    if (c) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * CJ + j) * 16 + 4 * t + r) * 64 + lane] = acc[CJ * c + j][t][r];
+    __syncthreads();
+    if (!owner) continue;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < kSkWaves; ++w)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] += red[((w * CJ + jl) * 16 + 4 * t + er) * 64 + el];
+    const int row = r0 + 16 * (CJ * c + jl) + 4 * (el >> 4) + er;
+    if (row < B) {
+      if (second) {
+        *reinterpret_cast<float4*>(a.out1 + (long long)row * a.H1 + c0 + 4 * ec) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        float4 o = make_float4(v[0] + bias.x, v[1] + bias.y, v[2] + bias.z, v[3] + bias.w);
+        if (a.relu0) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        *reinterpret_cast<float4*>(a.out0 + (long long)row * a.H0 + c0 + 4 * ec) = o;
+      }
+    }
+  }
+}
+
 }  // namespace gmvae
