@@ -1547,6 +1547,32 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   // (general schedule: the Philox fill rides as auxiliary workgroups of the first GEMM launch below)
   const bool noise_aux = ge || gu;
 
+  // row-panel layers over thousands of rows as register-direct bf16 piece products (skinny.hpp rows_nn_bf6): K % 32 = 0, widths
+  // % 64 = 0, R >= 2048 -- else the grouped GEMM
+  auto rows_ok = [&](int Kd, int N0, int N1) { return R >= 2048 && Kd % 32 == 0 && N0 % 64 == 0 && N1 % 64 == 0; };
+  auto launch_rows = [&](RowsArgs& ra, const char* name) {
+    const int nct = (ra.p[0].N + (ra.np > 1 ? ra.p[1].N : 0)) / 64;
+    int rt = 4;
+    // (row tiles per wave: as many as leave 1024 units -- every wave splits its W fragments itself, so fewer, fatter units
+    //  win while the chip stays full: fwd_enc_gmm at the config-5 sizes 43.1 us with 3200 units, 37.1 with 1600, 48.3 with 800)
+    while (rt > 1 && (long long)((R + 16 * rt - 1) / (16 * rt)) * nct < 1024) rt >>= 1;
+    const long long units = (long long)((R + 16 * rt - 1) / (16 * rt)) * nct;
+    const dim3 grid((unsigned)((units + kSkWaves - 1) / kSkWaves));
+    if (rt == 4) hipLaunchKernelGGL(rows_nn_bf6<4>, grid, dim3(kSkThreads), 0, st, ra);
+    else if (rt == 2) hipLaunchKernelGGL(rows_nn_bf6<2>, grid, dim3(kSkThreads), 0, st, ra);
+    else hipLaunchKernelGGL(rows_nn_bf6<1>, grid, dim3(kSkThreads), 0, st, ra);
+    cx.check();
+    double fl = 0;
+    for (int i = 0; i < ra.np; ++i) fl += 2.0 * R * ra.K * ra.p[i].N;
+    cx.mark(name, fl);
+  };
+  auto rows_prob = [&](const float* W, const float* bias, float* out, int N, bool relu) {
+    RowsProb q;
+    memset(&q, 0, sizeof(q));
+    q.W = W; q.bias = bias; q.out = out; q.N = N; q.relu = relu ? 1 : 0; q.add_div = 1;
+    return q;
+  };
+
   // ================================ forward ================================
   const NetL& E = gm ? L.ency : L.enc;
   const int flx_h0 = E.dim[1], flx_h1 = gm ? L.encg.dim[1] : 0;
@@ -1605,7 +1631,15 @@ static int run_step(Ctx& cx, const StepArgs& a) {
                        1.f / d.temperature);
     rowk(cx, "y_head_fwd");
     const NetL& G = L.encg;
-    {
+    if (rows_ok(K, G.dim[1], 2 * Lz)) {
+      RowsArgs ra;
+      memset(&ra, 0, sizeof(ra));
+      ra.A = w.y; ra.R = R; ra.K = K; ra.np = 2;
+      ra.p[0] = rows_prob(P + G.w[0] + (uint64_t)D * G.dim[1], P + G.b[0], (G.nl == 1) ? w.qp : w.hg[1], G.dim[1], G.nl > 1);
+      ra.p[0].addsrc = w.gx; ra.p[0].ld_add = G.dim[1]; ra.p[0].add_div = S;
+      ra.p[1] = rows_prob(P + L.prior.w[0], P + L.prior.b[0], w.pp, 2 * Lz, false);
+      launch_rows(ra, "fwd_y_layers");
+    } else {
       Group g;
       Problem p = p_nn(w.y, false, K, P + G.w[0] + (uint64_t)D * G.dim[1], G.dim[1], R, G.dim[1], K,
                        (G.nl == 1) ? w.qp : w.hg[1], G.dim[1], P + G.b[0], G.nl > 1);
@@ -1615,9 +1649,18 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       launch_group(cx, g, "fwd_y_layers");
     }
     for (int i = 1; i < G.nl; ++i) {
+      float* const out = (i == G.nl - 1) ? w.qp : w.hg[i + 1];
+      if (rows_ok(G.dim[i], G.dim[i + 1], 64)) {
+        RowsArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.A = w.hg[i]; ra.R = R; ra.K = G.dim[i]; ra.np = 1;
+        ra.p[0] = rows_prob(P + G.w[i], P + G.b[i], out, G.dim[i + 1], i < G.nl - 1);
+        launch_rows(ra, "fwd_enc_gmm");
+        continue;
+      }
       Group g;
-      g.add(p_nn(w.hg[i], false, G.dim[i], P + G.w[i], G.dim[i + 1], R, G.dim[i + 1], G.dim[i],
-                 (i == G.nl - 1) ? w.qp : w.hg[i + 1], G.dim[i + 1], P + G.b[i], i < G.nl - 1));
+      g.add(p_nn(w.hg[i], false, G.dim[i], P + G.w[i], G.dim[i + 1], R, G.dim[i + 1], G.dim[i], out, G.dim[i + 1],
+                 P + G.b[i], i < G.nl - 1));
       launch_group(cx, g, "fwd_enc_gmm");
     }
   }
@@ -1633,7 +1676,17 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   for (int i = 0; i < Dn.nl; ++i) {
     Group g;
     const float* in = (i == 0) ? w.z : w.hd[i];
-    if (i < Dn.nl - 1) {
+    if (i < Dn.nl - 1 && rows_ok(Dn.dim[i], Dn.dim[i + 1], 64)) {
+      RowsArgs ra;
+      memset(&ra, 0, sizeof(ra));
+      ra.A = in; ra.R = R; ra.K = Dn.dim[i]; ra.np = 1;
+      ra.p[0] = rows_prob(P + Dn.w[i], P + Dn.b[i], w.hd[i + 1], Dn.dim[i + 1], true);
+      if (planes && i == Dn.nl - 2) {              // the top layer's input activation also as planes (no split launch over R x H)
+        ra.p[0].C3 = w.hd3; ra.p[0].c3_stride = (long long)R * Dn.dim[i + 1];
+        hd3_fused = true;
+      }
+      launch_rows(ra, "fwd_dec");
+    } else if (i < Dn.nl - 1) {
       Problem ph = p_nn(in, false, Dn.dim[i], P + Dn.w[i], Dn.dim[i + 1], R, Dn.dim[i + 1], Dn.dim[i], w.hd[i + 1],
                         Dn.dim[i + 1], P + Dn.b[i], true);
       if (planes && i == Dn.nl - 2) {

@@ -2302,4 +2302,102 @@ __global__ __launch_bounds__(kSkThreads) void first_layers_u8bf(const FlxArgs a)
   }
 }
 
+// ---- the general schedule's row-panel layers at thousands of rows (IWAE: R = B S): out[R][N] = act(A[R][K] W[K][N] + bias (+ the
+// row group's addend)), K and N in the dozens to hundreds.  The grouped GEMM's LDS tiles ran these at 35 - 65 fp32 TFLOP/s and a
+// quarter of the HBM rate their [R x 512] outputs need (config-5 shard: fwd_y_layers 48, fwd_enc_gmm 53, fwd_dec 49 us).  Here
+// a WAVE owns RT row tiles x 64 strided columns for the whole contraction -- operands register-direct, both split into bf16 pieces
+// beside the MFMAs (6 piece products per product, sk_mma6) -- so nothing meets in LDS and every store is 16 bytes of one row;
+// units (row group, column tile) are dealt to waves in order, up to two problems of the same A side by side (the prior net beside
+// encoder_gmm's y part).  An output may also leave as plane_rounds3's bf16 planes (gemm.hpp C3: the next layer's operand).
+// K % 32 = 0, N % 64 = 0.
+struct RowsProb {
+  const float *W, *bias, *addsrc;   // [K][N]; [N] or null; [R / add_div][ld_add] or null
+  float* out;                       // [R][N]
+  unsigned short* C3;               // or null
+  long long c3_stride;
+  int N, relu, ld_add, add_div;
+};
+struct RowsArgs {
+  const float* A;                   // [R][K]
+  int R, K, np;
+  RowsProb p[2];
+};
+template <int RT>
+__global__ __launch_bounds__(kSkThreads) void rows_nn_bf6(const RowsArgs a) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int ln = lane & 15, lk = lane >> 4;
+  const int R = a.R, K = a.K;
+  const int nct0 = a.p[0].N >> 6, nct = nct0 + (a.np > 1 ? a.p[1].N >> 6 : 0);
+  const int unit = blockIdx.x * kSkWaves + wave;
+  const int rg = unit / nct, ct = unit - rg * nct;
+  const int r0 = rg * 16 * RT;
+  if (r0 >= R) return;
+  const RowsProb& P = ct < nct0 ? a.p[0] : a.p[1];
+  const int c0 = (ct < nct0 ? ct : ct - nct0) * 64;
+  const int N = P.N;
+  const float* const W = P.W + c0 + 4 * ln;
+  long long arow[RT];
+#pragma unroll
+  for (int j = 0; j < RT; ++j) arow[j] = (long long)min(r0 + 16 * j + ln, R - 1) * K;
+  f32x4 acc[RT][4];
+#pragma unroll
+  for (int j = 0; j < RT; ++j)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 8 * lk; k0 < K; k0 += 32) {
+    float4 av[RT][2], bv[8];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+      av[j][0] = *reinterpret_cast<const float4*>(a.A + arow[j] + k0);
+      av[j][1] = *reinterpret_cast<const float4*>(a.A + arow[j] + k0 + 4);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = *reinterpret_cast<const float4*>(W + (long long)(k0 + e) * N);
+    __builtin_amdgcn_sched_barrier(0);
+    sk_bf16x8 Ap[RT][3];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+      const float v[8] = {av[j][0].x, av[j][0].y, av[j][0].z, av[j][0].w, av[j][1].x, av[j][1].y, av[j][1].z, av[j][1].w};
+      sk_pieces(v, Ap[j]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = t == 0 ? bv[e].x : t == 1 ? bv[e].y : t == 2 ? bv[e].z : bv[e].w;
+      sk_bf16x8 Bp[3];
+      sk_pieces(v, Bp);
+#pragma unroll
+      for (int j = 0; j < RT; ++j) sk_mma6(Ap[j], Bp, acc[j][t]);
+    }
+  }
+  // ---- epilogue: accumulator [j][t][r] = out[r0 + 16 j + 4 lk + r][c0 + 4 ln + t]
+  const int nb = c0 + 4 * ln;
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (P.bias) bias = *reinterpret_cast<const float4*>(P.bias + nb);
+#pragma unroll
+  for (int j = 0; j < RT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + 16 * j + 4 * lk + r;
+      if (row >= R) continue;
+      float v[4] = {acc[j][0][r] + bias.x, acc[j][1][r] + bias.y, acc[j][2][r] + bias.z, acc[j][3][r] + bias.w};
+      if (P.addsrc) {
+        const float4 q = *reinterpret_cast<const float4*>(P.addsrc + (long long)(row / P.add_div) * P.ld_add + nb);
+        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+      }
+      if (P.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      *reinterpret_cast<float4*>(P.out + (long long)row * N + nb) = make_float4(v[0], v[1], v[2], v[3]);
+      if (P.C3) {
+        unsigned hi[2], mi[2], lo[2];
+        split_pair(v[0], v[1], hi[0], mi[0], lo[0]);
+        split_pair(v[2], v[3], hi[1], mi[1], lo[1]);
+        unsigned short* const d3 = P.C3 + ((long long)(nb >> 4) * R + row) * 16 + (nb & 15);
+        *reinterpret_cast<uint2*>(d3) = make_uint2(hi[0], hi[1]);
+        *reinterpret_cast<uint2*>(d3 + P.c3_stride) = make_uint2(mi[0], mi[1]);
+        *reinterpret_cast<uint2*>(d3 + 2 * P.c3_stride) = make_uint2(lo[0], lo[1]);
+      }
+    }
+}
+
 }  // namespace gmvae
