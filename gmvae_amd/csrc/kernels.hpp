@@ -431,7 +431,31 @@ __global__ void gmp_param_bwd(const float* __restrict__ z, const float* __restri
 }
 
 // sum over the S samples of a row group: out[b,:] = sum_s in[b*S+s,:]
+// (N % 4 = 0: a thread sums 4 columns with 16-byte loads, 10 samples' loads in flight -- 52 MB at the config-5 sizes moved at
+//  2.6 TB/s with one 4-byte load per thread and sample in flight; same order of additions per column)
 __global__ void sum_over_s(const float* __restrict__ in, float* __restrict__ out, int B, int S, int N) {
+  if ((N & 3) == 0) {
+    const int N4 = N >> 2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * N4) return;
+    const int b = (int)(i / N4), n = 4 * (int)(i - (long long)b * N4);
+    const float* p = in + (long long)b * S * N + n;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 10 <= S; s += 10) {
+      float4 v[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) v[j] = *reinterpret_cast<const float4*>(p + (long long)(s + j) * N);
+#pragma unroll
+      for (int j = 0; j < 10; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+    }
+    for (; s < S; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (long long)s * N);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (long long)b * N + n) = a;
+    return;
+  }
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)B * N) return;
   const int b = i / N, n = i % N;
