@@ -199,7 +199,21 @@ STEP_CASES = [
     ("gmvae", O.Dims(D=784, L=6, K=10, hidden=(64,)), 41),
     ("vae_gmp", O.Dims(D=400, L=10, K=7, hidden=(32,)), 23),
     ("vae", O.Dims(D=784, L=2, K=1, hidden=(64,)), 1024),
+    # the general schedule at thousands of rows WITHOUT the plane GEMMs: the first layers over the uint8 batch as bf16 piece
+    # products (first_layers_u8bf) and the forward row-panel layers -- the y part + prior net side by side, encoder_gmm's and the
+    # decoder's hidden layers -- as register-direct piece products (rows_nn_bf6: R >= 2048, K % 32 = 0, widths % 64 = 0); ragged
+    # last row tiles; IWAE rows (R = B S) in the second case
+    ("gmvae", O.Dims(D=256, L=32, K=32, hidden=(128, 64)), 2090),
+    ("gmvae", O.Dims(D=208, L=64, K=64, hidden=(64, 128), S=3), 700),
+    ("vae", O.Dims(D=256, L=32, K=1, hidden=(128, 128)), 2100),
 ]
+
+
+def test_large_row_cases_take_the_general_schedule(H):
+    """The three STEP_CASES meant for the general schedule's row-panel kernels really take that schedule."""
+    for name, d, B in STEP_CASES[-3:]:
+        assert _L().step_schedule(H.dims_of(d, B), O.MODEL_NAMES[name]) == "general", (name, d, B)
+        assert B * d.S >= 2048
 
 
 @pytest.mark.parametrize("name,d,B", STEP_CASES, ids=[f"{n}-D{d.D}-L{d.L}-K{d.K}-H{'x'.join(map(str, d.hidden))}-S{d.S}-B{B}"
