@@ -66,11 +66,53 @@ struct DwArgs {
 // KB: k-steps (of 4 batch rows) requested per batch of loads: 32 (a wave's 128 rows at B = 1024), or 8 for SMALL batches --
 // at B <= 256 a wave's share is <= 32 rows, and 32 clamped k-steps per lane were 56 wasted loads of 64 in front of the few
 // matrix instructions that count (BASELINE configs[0] / configs[1]: B = 100 / 256).
-template <bool U8, int MU, int KB = 32, class Mid>
+// SC = true (mega3_step, mega3.hpp): the fp32 operands were written by OTHER workgroups of the SAME launch (write-through, behind
+// a flag): they are read with agent-scope (sc1) loads, which another XCD's L2 cannot serve stale.  The uint8 batch is never
+// written by a launch that reads it: plain loads.
+#ifndef GMVAE_SC_IMPL
+#define GMVAE_SC_IMPL 0      // 0: relaxed agent-scope atomic loads; 1 (diagnostic, WRONG results): plain loads; 2: sc1 global loads in asm-free form
+#endif
+template <bool SC>
+__device__ __forceinline__ float ldg_f(const float* p) {
+#if GMVAE_SC_IMPL == 1
+  return *p;
+#elif GMVAE_SC_IMPL == 2
+  if constexpr (SC) return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else return *p;
+#else
+  if constexpr (SC) return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else return *p;
+#endif
+}
+template <bool SC, class T>
+__device__ __forceinline__ T ldg_a(const void* p) {
+#if GMVAE_SC_IMPL == 1
+  return *reinterpret_cast<const T*>(p);
+#elif GMVAE_SC_IMPL == 2
+  if constexpr (!SC) return *reinterpret_cast<const T*>(p);
+  else if constexpr (sizeof(T) == 4)
+    return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else {                                           // an 8-byte operand as two 4-byte agent-scope loads
+    const unsigned lo = __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned hi = __hip_atomic_load(reinterpret_cast<const unsigned*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+  }
+#else
+  if constexpr (!SC) return *reinterpret_cast<const T*>(p);
+  else if constexpr (sizeof(T) == 4)
+    return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else {
+    static_assert(sizeof(T) == 8, "agent-scope operand loads are 4 or 8 bytes");
+    return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+#endif
+}
+template <bool U8, int MU, int KB = 32, bool SC = false, class Mid>
 __device__ __forceinline__ void dw_contract(const void* __restrict__ Ap, const float* __restrict__ dY, const int lda, const int ldy,
                                             const int M, const int N, const int m0, const int n0, const int b_lo, const int b_hi,
                                             const int ln, const int lk, f32x4 (&acc)[4], float& cs, Mid mid) {
   static_assert(MU == 4 || MU == 2 || MU == 1, "1, 2 or 4 strided 16-row tiles per workgroup tile");
+  static_assert(!SC || U8 || MU <= 2, "agent-scope fp32 operand loads: at most 8 bytes");
   const int ma = m0 + MU * ln;                   // this lane's MU fan-in rows (one per strided tile)
   const bool a_ok = ma < M, n_ok = n0 + ln < N;  // (M is a multiple of 4 or the source rows are padded to one)
   const int mac = min(ma, ((M + 3) & ~3) - MU), nc = min(n0 + ln, N - 1);
@@ -107,8 +149,8 @@ __device__ __forceinline__ void dw_contract(const void* __restrict__ Ap, const f
 #pragma unroll
     for (int s = 0; s < KB; ++s) {
       if constexpr (U8) av[s] = *reinterpret_cast<const AT*>(a8 + (long long)(4 * s) * lda);
-      else av[s] = *reinterpret_cast<const AT*>(a32 + (long long)(4 * s) * lda);
-      bvv[s] = dy[(long long)(4 * s) * ldy];
+      else av[s] = ldg_a<SC, AT>(a32 + (long long)(4 * s) * lda);
+      bvv[s] = ldg_f<SC>(dy + (long long)(4 * s) * ldy);
     }
 #pragma unroll
     for (int s = 0; s < KB; ++s) mfma4(av[s], n_ok ? bvv[s] : 0.f);
@@ -121,8 +163,8 @@ __device__ __forceinline__ void dw_contract(const void* __restrict__ Ap, const f
     for (int s = 0; s < KB; ++s) {
       const int bc = min(b0 + 4 * s + lk, b_hi - 1);
       if constexpr (U8) av[s] = *reinterpret_cast<const AT*>(A8 + (long long)bc * lda + mac);
-      else av[s] = *reinterpret_cast<const AT*>(A32 + (long long)bc * lda + mac);
-      bvv[s] = dY[(long long)bc * ldy + nc];
+      else av[s] = ldg_a<SC, AT>(A32 + (long long)bc * lda + mac);
+      bvv[s] = ldg_f<SC>(dY + (long long)bc * ldy + nc);
     }
 #pragma unroll
     for (int s = 0; s < KB; ++s) mfma4(av[s], (b0 + 4 * s + lk < b_hi && n_ok) ? bvv[s] : 0.f);   // a zero B operand also voids the clamped A values
@@ -160,6 +202,58 @@ __device__ __forceinline__ void dw_contract_u8x3(const unsigned char* __restrict
     av[s] = *reinterpret_cast<const unsigned*>(a8 + (long long)(4 * s) * lda);
     bvv[s] = dy[(long long)(4 * s) * ldy];
   }
+#pragma unroll
+  for (int blk = 0; blk < KB / 8; ++blk) {
+    u32x4 bh, bm, bl;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      const float v0 = n_ok ? bvv[8 * blk + 2 * jp] : 0.f, v1 = n_ok ? bvv[8 * blk + 2 * jp + 1] : 0.f;
+      cs += v0; cs += v1;
+      bh[jp] = pack_hi16(v1, v0);
+      const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u), r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
+      bm[jp] = pack_hi16(r1, r0);
+      const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+      bl[jp] = pack_hi16(s1, s0);
+    }
+    const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bm = __builtin_bit_cast(bf16x8, bm), Bl = __builtin_bit_cast(bf16x8, bl);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      u32x4 aw;
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+        const float f0 = (float)((av[8 * blk + 2 * jp] >> (8 * t)) & 0xffu), f1 = (float)((av[8 * blk + 2 * jp + 1] >> (8 * t)) & 0xffu);
+        aw[jp] = a_ok ? pack_hi16(f1, f0) : 0u;
+      }
+      const bf16x8 At = __builtin_bit_cast(bf16x8, aw);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(At, Bl, acc[t], 0, 0, 0);      // smallest pieces first
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(At, Bm, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(At, Bh, acc[t], 0, 0, 0);
+    }
+  }
+}
+
+// The same contraction in two parts, for mega3_step (mega3.hpp): the uint8 operand (the batch: final before the launch) is
+// requested while the workgroup still waits for the pre-activation gradients; those follow with agent-scope loads.
+__device__ __forceinline__ void dw_u8x3_load_a(const unsigned char* __restrict__ A8, const int lda, const int M, const int m0,
+                                               const int b_lo, const int ln, const int lk, unsigned (&av)[32]) {
+  const int mac = min(m0 + 4 * ln, ((M + 3) & ~3) - 4);
+  const unsigned char* const a8 = A8 + (long long)(b_lo + lk) * lda + mac;
+#pragma unroll
+  for (int s = 0; s < 32; ++s) av[s] = *reinterpret_cast<const unsigned*>(a8 + (long long)(4 * s) * lda);
+}
+template <bool SC>
+__device__ __forceinline__ void dw_u8x3_rest(const unsigned (&av)[32], const float* __restrict__ dY, const int ldy, const int M, const int N,
+                                             const int m0, const int n0, const int b_lo, const int ln, const int lk, f32x4 (&acc)[4],
+                                             float& cs) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const bool a_ok = m0 + 4 * ln < M, n_ok = n0 + ln < N;
+  const int nc = min(n0 + ln, N - 1);
+  constexpr int KB = 32;
+  float bvv[KB];
+  const float* const dy = dY + (long long)(b_lo + lk) * ldy + nc;
+#pragma unroll
+  for (int s = 0; s < KB; ++s) bvv[s] = ldg_f<SC>(dy + (long long)(4 * s) * ldy);
 #pragma unroll
   for (int blk = 0; blk < KB / 8; ++blk) {
     u32x4 bh, bm, bl;

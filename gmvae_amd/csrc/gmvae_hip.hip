@@ -24,6 +24,7 @@
 #include "mega2.hpp"
 #include "mega2v.hpp"
 #include "dwadam.hpp"
+#include "mega3.hpp"
 #include "skinny.hpp"
 
 using namespace gmvae;
@@ -338,7 +339,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     // (mega2v_fwd_bwd: six producers per panel)
     w.xchg = reinterpret_cast<unsigned long long*>(
         take(2ull * ((B + 15) / 16) * (mega2v_kind(d, model) ? 6 : kMegaQMax - 1) * (kPanel * d.hidden[0] + kPanel)));
-    w.sync = reinterpret_cast<unsigned*>(take(64));
+    w.sync = reinterpret_cast<unsigned*>(take(256));          // [0] epoch, [1] timeout flag, [2] alpha_t; [64, 128): mega3_step's per-panel flags
     if (ml.fl_ok)
       w.xfl = reinterpret_cast<unsigned long long*>(take(2ull * ((B + 15) / 16 + 1) * 4 * kPanel * 2 * d.hidden[0]));      // (+ 1: mega2 pairs panels)
     w.gstamps = reinterpret_cast<unsigned long long*>(take(2ull * 4 * 2048 * 8));
@@ -910,15 +911,21 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
   // The first launch (first layer as split-K partials + noise + weight images) is skipped when the previous step
   // of the same graph left the images behind (finalize_adam) and the launch below can run the first layer itself:
   // a panel's 4 workgroups must all be resident for their exchange, i.e. one workgroup per CU.
-  static int n_cu = 0;
-  if (!n_cu) {
+  int n_cu = 0;
+  {                                             // (per device: a process may hold engines on several)
+    static int cu_of[64];
     int dev = 0;
     hipGetDevice(&dev);
-    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (dev < 0 || dev >= 64) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    else {
+      if (!cu_of[dev]) hipDeviceGetAttribute(&cu_of[dev], hipDeviceAttributeMultiprocessorCount, dev);
+      n_cu = cu_of[dev];
+    }
   }
   const int vk = (mega2v_ok(d, model) && w.img2f) ? mega2v_kind(d, model) : 0;
   const int Qm = vk ? 7 : mega_q(d);
-  bool fl = ml.fl_ok && (Qm == 4 || vk) && (B + kPanel - 1) / kPanel * Qm <= n_cu &&
+  const int np_grid = (!vk && mega2_ok(d, model)) ? (((B + kPanel - 1) / kPanel + 1) & ~1) : (B + kPanel - 1) / kPanel;   // (mega2 pairs panels)
+  bool fl = ml.fl_ok && (Qm == 4 || vk) && np_grid * Qm <= n_cu &&
             (a.adam_p == a.params || a.dp_images) && a.step_dev && gen_eps && w.xfl && !getenv("GMVAE_NO_FL") && !sched_safe(d);
   if (fl && !a.imgs_ready) {
     // first step of a train graph / an eager step: the weight images straight from the parameters (kernels.hpp img_build),
@@ -962,6 +969,12 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     launch_group(cx, g, "fwd_x_first_layers_splitk+aux", 0, getenv("GMVAE_STAMPS") ? w.gstamps : nullptr);
   }
   bool m2_ran = false;
+  // mega3_step (mega3.hpp): at mega2_fwd_bwd's sizes the weight-gradient tiles + TF-Adam run in the SAME launch -- its
+  // arguments are kept until the tile list below is built
+  MegaArgs c3;
+  bool fuse_pending = false;
+  double m2_flops = 0;
+  const bool dw_upd_ = a.adam_p && a.adam_p == a.params;
   {  // the whole per-row forward + backward in one launch
     MegaArgs c;
     memset(&c, 0, sizeof(c));
@@ -1013,8 +1026,11 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         hipFuncSetAttribute(reinterpret_cast<const void*>(mega2_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         m2attr = true;
       }
+      fuse_pending = (dw_upd_ || a.dp_images) && a.step_dev && !getenv("GMVAE_NO_FUSE");
+      c3 = c;
       // (an even number of panels: the first layer works on pairs of them, mega2.hpp)
-      hipLaunchKernelGGL(mega2_fwd_bwd, dim3((((B + kPanel - 1) / kPanel + 1) & ~1) * 4), dim3(kMT), (size_t)M2::total * sizeof(float), st, c);
+      if (!fuse_pending)
+        hipLaunchKernelGGL(mega2_fwd_bwd, dim3((((B + kPanel - 1) / kPanel + 1) & ~1) * 4), dim3(kMT), (size_t)M2::total * sizeof(float), st, c);
     } else if (m2v) {
       c.img2f = w.img2f; c.img2b = w.img2b; c.dimg2 = w.dimg2;
       c.lr = a.lr; c.b1 = a.beta1; c.b2 = a.beta2;
@@ -1036,7 +1052,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     double macs = (double)H * 2 * Lz + (double)Lz * H + 2.0 * H * D + (double)H * Lz + 2.0 * Lz * H;
     if (fl) macs += (double)D * H2;        // the first layer rides in the launch
     if (gm) macs += (double)H * K + (double)K * H + (double)K * 2 * Lz + (double)(H + 2 * Lz) * K + (double)K * H;
-    if (m2) { cx.mark("mega2_fwd_bwd", 2.0 * B * macs); goto mega_done; }
+    if (m2) { m2_flops = 2.0 * B * macs; if (!fuse_pending) cx.mark("mega2_fwd_bwd", m2_flops); goto mega_done; }
     if (m2v) { cx.mark("mega2v_fwd_bwd", 2.0 * B * macs); goto mega_done; }
     cx.mark("mega_fwd_bwd", 2.0 * B * macs);
   mega_done:;
@@ -1050,7 +1066,8 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     ImgPlan pl;
     plan_images(d, model, L, w, ml, a.params, pl);
     if (pl.map_ok) {
-      static DwArgs da;                          // (host-side scratch: 3 KB, too large for comfort on the stack next to Launch)
+      std::vector<DwArgs> da_store(1);           // (4 KB of host scratch per call: engines may step from several host threads)
+      DwArgs& da = da_store[0];
       memset(&da, 0, sizeof(da));
       da.B = B;
       da.u8x3 = 1;
@@ -1101,7 +1118,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       }
       add(w.z, false, Lz, w.dbuf[0], H, Lz, H, Dn.w[0], (long long)Dn.b[0], mu);                          // dWd0
       {  // XCD-aware order: slot b runs on XCD b % 8 (observed round-robin placement; speed only)
-        static int cls[kDwMaxTiles];             // the XCD a tile would like: the one that shares its larger operand
+        std::vector<int> cls(kDwMaxTiles);       // the XCD a tile would like: the one that shares its larger operand
         bool used[kDwMaxTiles];
         const int nt = da.total_tiles <= kDwMaxTiles ? da.total_tiles : 0;
         for (int i = 0; i < da.ntens; ++i) {
@@ -1151,13 +1168,101 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       }
       // the padding words of the flat gradient buffer are never written by the tiles: the buffer is all-reduced / read whole
       if (da.total_tiles > kDwMaxTiles) return GMVAE_E_DIMS;
-      hipLaunchKernelGGL(dw_adam, dim3(da.total_tiles + 1 + da.gmp_blocks), dim3(kDwThreads), 0, st, da);
-      cx.check();
       double fl_ = 0;
       for (int i = 0; i < da.ntens; ++i) fl_ += 2.0 * da.t[i].M * da.t[i].N * B;
+      const unsigned m2_grid = (unsigned)((((B + kPanel - 1) / kPanel + 1) & ~1) * 4);
+      if (fuse_pending && da.ntens <= kM3MaxT && !gmp) {
+        std::vector<M3Args> m3_store(1);
+        M3Args& m3 = m3_store[0];
+        memset(&m3, 0, sizeof(m3));
+        m3.m = c3;
+        m3.m.lr_t_out = nullptr;
+        m3.ntens = da.ntens;
+        m3.flags = w.sync + 64;
+        m3.dbg = getenv("GMVAE_M3_STAMPS") ? w.gstamps + 3 * 2048 * 8 : nullptr;
+        {
+          // The slot list (mega3.hpp): workgroup `rank` takes slots rank, rank + workers, ...  Producers (ranks below 3 panels)
+          // are done first, so they get the tiles of phases A and B in that order; the leads' ranks start at 3 panels, where
+          // the tiles of phase C (they need the END of the backward chain) and the loss tail begin.  Inside a group, slot b
+          // (XCD b % 8 under round-robin placement) prefers a tile of its operand class (speed only).
+          const int nPr = (B + kPanel - 1) / kPanel;
+          auto phase_of = [&](const DwTensor& T) {
+            if (T.dY == w.g || T.dY == w.dbuf[0]) return kM3PhA;                          // dWd1 (g, hd1), dWd0 (dhd1, z)
+            if (T.dY == w.dbuf[2] || T.dY == w.dlogits) return kM3PhC;                    // dWy0 / dWe0 (dhy1), dWy1 (dlogits)
+            return kM3PhB;                                                                // dqp, dpp, dhg1
+          };
+          std::vector<int> tile_cls(da.total_tiles), tile_ph(da.total_tiles), tile_pt(da.total_tiles);
+          for (int i = 0; i < da.ntens; ++i) {
+            const DwTensor& T = da.t[i];
+            m3.tphase[i] = (unsigned char)phase_of(T);
+            const int tiles_m = ((T.M + 16 * T.mu - 1) / (16 * T.mu));
+            for (int tm = 0; tm < tiles_m; ++tm)
+              for (int tn = 0; tn < T.tiles_n; ++tn) {
+                const int t = T.tile_begin + tm * T.tiles_n + tn;
+                tile_cls[t] = (tiles_m >= T.tiles_n ? tm : tn) & 7;
+                tile_ph[t] = m3.tphase[i];
+                tile_pt[t] = (i << 10) | (t - T.tile_begin);
+              }
+          }
+          std::vector<char> used(da.total_tiles, 0);
+          int slot = 0;
+          auto deal = [&](const int ph) {                     // the phase's tiles into consecutive slots
+            int left = 0;
+            for (int t = 0; t < da.total_tiles; ++t) left += tile_ph[t] == ph;
+            for (; left > 0; --left, ++slot) {
+              int pick = -1, any = -1;
+              for (int t = 0; t < da.total_tiles && pick < 0; ++t)
+                if (!used[t] && tile_ph[t] == ph) {
+                  if (any < 0) any = t;
+                  if (tile_cls[t] == (slot & 7)) pick = t;
+                }
+              if (pick < 0) pick = any;
+              used[pick] = 1;
+              if (slot < kM3MaxSlots) m3.perm[slot] = (unsigned short)tile_pt[pick];
+            }
+          };
+          deal(kM3PhA);
+          deal(kM3PhB);
+          for (; slot < 3 * nPr && slot < kM3MaxSlots; ++slot) m3.perm[slot] = kM3None;
+          deal(kM3PhC);
+          if (slot < kM3MaxSlots) m3.perm[slot] = kM3Tail;
+          m3.total_slots = ++slot;
+        }
+        for (int i = 0; i < da.ntens; ++i) m3.t[i] = da.t[i];
+        M3Fin& f3 = m3.fa;
+        f3.grads = fa.grads; f3.p = fa.p; f3.m = fa.m; f3.v = fa.v; f3.lr = fa.lr; f3.b1 = fa.b1; f3.b2 = fa.b2; f3.eps = fa.eps;
+        f3.do_adam = fa.do_adam; f3.count = fa.count; f3.logw = fa.logw; f3.logpx = fa.logpx; f3.logq = fa.logq; f3.logp = fa.logp;
+        f3.nent = fa.nent; f3.tail = fa.tail; f3.B = fa.B; f3.tail_log = fa.tail_log; f3.epoch_word = fa.epoch_word;
+        for (int i = 0; i < kImgBufs; ++i) f3.img[i] = fa.img[i];
+        static bool m3attr = false;
+        if (!m3attr) {
+          hipFuncSetAttribute(reinterpret_cast<const void*>(mega3_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          m3attr = true;
+        }
+        if (m3.total_slots <= kM3MaxSlots) {
+          hipLaunchKernelGGL(mega3_step, dim3(m2_grid), dim3(kMT), (size_t)M2::total * sizeof(float), st, m3);
+          cx.check();
+          cx.mark(dw_upd ? "mega3_step" : "mega3_grads", m2_flops + fl_);
+          return cx.err;
+        }
+      }
+      if (fuse_pending) {                        // (cannot happen at mega2's sizes: the tile list fits) the two-launch form
+        hipLaunchKernelGGL(mega2_fwd_bwd, dim3(m2_grid), dim3(kMT), (size_t)M2::total * sizeof(float), st, c3);
+        cx.check();
+        cx.mark("mega2_fwd_bwd", m2_flops);
+        fuse_pending = false;
+      }
+      hipLaunchKernelGGL(dw_adam, dim3(da.total_tiles + 1 + da.gmp_blocks), dim3(kDwThreads), 0, st, da);
+      cx.check();
       cx.mark(dw_upd ? "dw_adam" : "dw_grads", fl_);
       return cx.err;
     }
+  }
+  if (fuse_pending) {                            // the tile list could not be built: mega2_fwd_bwd as a launch of its own
+    hipLaunchKernelGGL(mega2_fwd_bwd, dim3((unsigned)((((B + kPanel - 1) / kPanel + 1) & ~1) * 4)), dim3(kMT), (size_t)M2::total * sizeof(float), st, c3);
+    cx.check();
+    cx.mark("mega2_fwd_bwd", m2_flops);
+    fuse_pending = false;
   }
   // Every weight gradient in one grouped launch.  The uint8-activation problems (bf16 matrix cores) take NS splits
   // of two 64-row staging rounds; the fp32 problems take 2 NS splits of ONE round each: their workgroups, the

@@ -145,9 +145,17 @@ __device__ __forceinline__ float4 f4(const f32x4 v) { return make_float4(v[0], v
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // (st4o -- a launch output as a 16-byte write-through store -- lives in mega.hpp)
+// a 4-byte launch output, write-through: mega3_step's workers on other XCDs read it in the SAME launch (behind the lead's flag)
+__device__ __forceinline__ void st1o(float* p, const float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
-__global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+// The launch's body.  FUSE = 0: the whole of mega2_fwd_bwd (below).  FUSE = 1: the per-row part of mega3_step (mega3.hpp), whose
+// workgroups go on to the weight-gradient tiles: the body then leaves alpha_t and the closing span stamp to the caller.  Returns
+// what the workgroup was: 0 a phantom panel's (its share of the pair's first layer is out), 1 a producer (partials published),
+// 2 the panel's lead (backward chain done, every output stored write-through).
+template <int FUSE>
+__device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, unsigned* const m3_flags = nullptr) {
   constexpr int H = M2::H, L = M2::L, K = M2::K, D = M2::D, L2 = M2::L2, K2 = M2::K2;
   constexpr int Q = 4, H2f = 2 * H;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   const int nrow = min(kPanel, B - r0);            // (<= 0: a phantom panel)
   const bool lead = q == 0;
   if (a.span && tid == 0) a.span[2 * bid] = wall_clock64();
-#define M2_SPAN_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
+#define M2_SPAN_END() if (!FUSE && a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
   const unsigned spin_limit = *a.err_word ? 0u : (1u << 19);       // bounded spins (see mega.hpp)
   const unsigned epoch0 = *a.epoch_word;           // tag of this step's hand-offs
   float* const img = sm + M2::IMG;
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
     if (nrow <= 0) {                               // a phantom panel's workgroup: its share of the pair's first layer is out
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (no LDS-DMA piece may still be landing when the LDS is handed on)
       M2_SPAN_END();
-      return;
+      return 0;
     }
     M2_WC(5);
     __syncthreads();                               // the staging area is dead: the panels it overlays may be written
@@ -394,11 +402,11 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       yv = fexp(av - lse);
       const float lp = lg - l2;
       ne = fexp(lp) * lp;
-      if (ok && lead) a.y[(long long)(r0 + row) * K2 + k] = yv;            // rows of pad4(K) floats
+      if (ok && lead) st1o(a.y + (long long)(r0 + row) * K2 + k, yv);            // rows of pad4(K) floats
     }
     P_y[row * M2::ldk + k] = yv;                                            // columns K..15 are zero
     ne = row16_sum(ne);
-    if (k == 0) { nllp[3 * kPanel + row] = ne; if (ok && lead) a.nent[r0 + row] = ne; }
+    if (k == 0) { nllp[3 * kPanel + row] = ne; if (ok && lead) st1o(a.nent + r0 + row, ne); }
   }
   __syncthreads();
   GMVAE_STAMP(2);
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
     aq = row32_sum(aq); ap = row32_sum(ap);
     if (sub == 0) {
       nllp[row] = aq; nllp[kPanel + row] = ap;
-      if (ok && lead) { a.logq[r0 + row] = aq; a.logp[r0 + row] = ap; }
+      if (ok && lead) { st1o(a.logq + r0 + row, aq); st1o(a.logp + r0 + row, ap); }
     }
   }
   __syncthreads();
@@ -577,12 +585,12 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       granule_publish(xo + kPanel * H + (tid - 256), ((unsigned long long)epoch << 32) | __float_as_uint(rsn));
     }
     M2_WC(1);
-    if (bid == 0 && tid == 0 && a.lr_t_out) {      // (a producer: off the launch's critical path)
+    if (!FUSE && bid == 0 && tid == 0 && a.lr_t_out) {      // (a producer: off the launch's critical path)
       const double t = (double)(a.step_dev[0] + 1ull);
       *a.lr_t_out = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, t)) / (1.0 - pow((double)a.b1, t)));
     }
     M2_SPAN_END();
-    return;
+    return 1;
   }
   // ======================================================================= B: backward chain (quarter 0)
   M2_WC(1);
@@ -660,8 +668,8 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
     if (wn) {
       const int row = tid - 256;
       if (row < nrow) {
-        a.logpx[r0 + row] = rsn;
-        a.logw[r0 + row] = rsn + nllp[kPanel + row] - nllp[row] - nllp[3 * kPanel + row];
+        st1o(a.logpx + r0 + row, rsn);
+        st1o(a.logw + r0 + row, rsn + nllp[kPanel + row] - nllp[row] - nllp[3 * kPanel + row]);
       }
     }
   }
@@ -732,7 +740,19 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
       if (ok) st4o(a.dhg1 + (long long)(r0 + ln) * H + c0, d);
     }
   }
+  // mega3_step, flag A (this lead's g, dhd1 -- and hd1, z before them -- are in memory): vmcnt retires in order, so once at
+  // most the stores issued AFTER them are outstanding (dqp, dpp; waves 0..3 also dhg1) they are acknowledged; they were
+  // issued two stages ago, so this wait is nearly free -- a vmcnt(0) here would also wait for the stores just issued
+  // (a ragged panel's waves skip stores whose rows do not exist: no counting there)
+  if constexpr (FUSE) {
+    if (nrow < kPanel || a.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (diagnostic stamps are stores too)
+    else if (wave < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  }
   __syncthreads();
+  if constexpr (FUSE) {
+    if (tid == 0) __hip_atomic_store(m3_flags + 3 * 64 + pnl, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // B4 dy = dhg * Wg0[D:]^T + dpp * Wp^T: one tile; the 4 + 8 contraction tiles are spread over the 8 waves
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -763,11 +783,19 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
     if (kv) {
       const float lp = lg - l2;
       dl = yv * (dy - dot) * a.invT + fexp(lp) * (lp - ne);
-      a.dlogits[(long long)(r0 + row) * K2 + k] = dl;
+      st1o(a.dlogits + (long long)(r0 + row) * K2 + k, dl);
     }
     P_dl[row * M2::ldk + k] = dl;
   }
+  // mega3_step, flag B (dqp, dpp, dhg1 -- and hg1, y before them): the only later store is waves 0..3's dlogits
+  if constexpr (FUSE) {
+    if (wave < 4 && nrow == kPanel && !a.dbg) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
+  if constexpr (FUSE) {
+    if (tid == 0) __hip_atomic_store(m3_flags + 4 * 64 + pnl, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // B6 dhy1 = (dlogits * Wy1^T) [hy1 > 0]: 4 tiles, contraction = k (one tile)
   if (wave < 4) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -781,6 +809,12 @@ __global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
   GMVAE_STAMP(7);
   M2_SPAN_END();
 #undef M2_SPAN_END
+  return 2;
+}
+
+__global__ __launch_bounds__(kMT) void mega2_fwd_bwd(const MegaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  mega2_body<0>(a, sm);
 }
 
 }  // namespace gmvae

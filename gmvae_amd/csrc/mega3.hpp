@@ -1,0 +1,318 @@
+// mega3_step: the WHOLE steady-state training step of the GMVAE at the reference's default sizes in ONE launch
+// (scripts/runners.py:231-232 is one sess.run: forward, gradients, apply_gradients) -- mega2_fwd_bwd's per-row part
+// (mega2.hpp: first layer, forward chain, decoder layer, backward chain) followed, IN THE SAME WORKGROUPS, by dw_adam's
+// weight-gradient tiles with TF-Adam in their epilogue (dwadam.hpp; scripts/runners.py:181-183).
+//
+// Why: as two launches the step paid two kernel boundaries (~2 us each: dispatch + end-of-kernel write-back), dw_adam's cold
+// start (kernel arguments, first loads: 1-3 us) and left the 192 producer workgroups of mega2_fwd_bwd idle for the ~6 us the
+// 64 leads spend on the hand-off and the backward chain.  Here a workgroup that is done with its per-row role becomes a
+// WORKER: it takes tile slots rank, rank + workers, ... of the step's tile list (240 tiles + the loss tail at B = 1024: one
+// slot per workgroup), requests what does not depend on this launch (the tile's parameters and Adam moments, the uint8 batch
+// operand) and then waits for the leads.
+//
+// Hand-off.  Everything a workgroup leaves for the tiles is stored write-through (st4o / st1o: sc1).  When the stores of a
+// PHASE are acknowledged by the memory side (s_waitcnt on the in-order vmcnt counter, in every wave, then a workgroup barrier),
+// ONE thread stores this step's epoch into the phase's flag of the panel (4 bytes, write-through):
+//   producers (rows 0..2 of the flag table)  their decoder tiles' g                       -- after the publish of their partials
+//   A (row 3)  the lead's g, dhd1 (hd1, z before them)                                      -- before the barrier behind B3
+//   B (row 4)  dqp, dpp, dhg1 (hg1, y before them)                                          -- before the barrier behind B5
+//   C (row 5)  dlogits, dhy1 (hy1 and the per-row loss terms before them)                   -- at the lead's end
+// A and B wait only until the stores issued AFTER the phase's last one are the only ones outstanding (mega2.hpp): those
+// were issued two stages earlier, so the lead -- the launch's critical path -- does not stall for them.  A worker polls the
+// flags of its tile's phase (agent-scope loads, wave 0) until every panel's carries the epoch, then reads the operands.  The
+// flags are epoch tags, not counters: nothing resets them, and a stale flag can never equal the current epoch.  Polls are
+// bounded (a timeout sets the error word: the step is not applied and the host falls back to the safe schedule, exactly as
+// for the granule hand-offs).
+//
+// Operand loads behind a flag are PLAIN loads, served by the XCD's L2.  (Measured, tools/m3stamps.py: agent-scope sc1 loads
+// of the operands -- 30 MB per step that no L2 may serve -- ran the fp32 tiles' contraction at the fabric's rate, 15 us against
+// 4; an agent-scope acquire fence, buffer_inv sc1, in every worker cost 7 us and emptied the L2s.)  Why plain loads cannot
+// see stale bytes here -- the hardware contract this kernel relies on, the same one every pair of dependent launches relies on:
+//   1. the launch starts with the L2s invalidated (the dispatch's acquire), so a line of a hand-off buffer enters an L2 only by
+//      a load or a store of THIS launch;
+//   2. no workgroup loads from a hand-off buffer before it has seen the flags of the buffer's phase, and by then every byte of
+//      the buffer is in memory (stores acknowledged before the flag);
+//   3. buffers of different phases share no 128-byte line (the workspace carves 256-byte units), and a panel's rows of one
+//      buffer are written by that panel's workgroups only;
+//   4. a write-through store of part of a line does not fetch the rest of the line into the writer's L2 (byte-masked write
+//      allocation), so the writer's L2 holds no stale copy of bytes other workgroups write later.
+// The per-row loss terms (two panels share a line) and the flags are read with agent-scope loads.
+//
+// What may be overwritten when: the optimizer epilogue rewrites parameters and operand images that THIS launch read -- but
+// every such read (first-layer weights, the three operand images) was waited for before the reader's hand-off, i.e. happens
+// before the last lead's flag, and no update happens before a worker has seen all flags.
+#pragma once
+#include "dwadam.hpp"
+#include "mega2.hpp"
+
+namespace gmvae {
+
+constexpr int kM3MaxSlots = 320;
+constexpr int kM3MaxT = 8;
+constexpr unsigned short kM3Tail = 0xffffu, kM3None = 0xfffeu;
+constexpr int kM3FlagRows = 6, kM3FlagLd = 64;       // rows 0..2: producers q - 1; 3: A; 4: B; 5: C
+constexpr int kM3PhA = 0, kM3PhB = 1, kM3PhC = 2;
+
+struct M3Fin {                 // what the tiles' optimizer epilogue and the loss tail need (FinalArgs without slabs / maps)
+  float *grads, *p, *m, *v;
+  float lr, b1, b2, eps;
+  int do_adam;                 // 0: gradients only (data parallel: the all-reduce and adam_tf_img follow)
+  float count;
+  const float *logw, *logpx, *logq, *logp, *nent;
+  float* tail;
+  int B;
+  float* tail_log;
+  float* img[kImgBufs];
+  unsigned* epoch_word;        // bumped by the tail slot for the next step's hand-offs (null: a later launch does it)
+};
+
+struct M3Args {
+  MegaArgs m;
+  int ntens, total_slots;
+  unsigned* flags;             // [kM3FlagRows][kM3FlagLd] per-panel epoch tags
+  unsigned long long* dbg;     // diagnostic: [workgroup][8] wall-clock stamps of the worker phase (tools/m3stamps.py) or null
+  unsigned char tphase[kM3MaxT];      // the phase whose flags a tensor's tiles wait for
+  unsigned short perm[kM3MaxSlots];   // slot -> (tensor << 10) | tile inside the tensor; kM3Tail: the loss tail; kM3None
+  DwTensor t[kM3MaxT];
+  M3Fin fa;
+};
+static_assert(sizeof(M3Args) <= 4096, "kernel arguments");
+
+__device__ __forceinline__ float ld_sc(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// the loss tail (kernels.hpp finalize_tail_block) over per-row terms the leads of THIS launch stored: agent-scope loads
+__device__ __forceinline__ void m3_tail(const M3Fin& a, unsigned long long* step_dev, const unsigned long long step, float* red) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int t = threadIdx.x;
+  if (t < 256) {
+    for (int b = t; b < a.B; b += 256) {
+      a0 -= ld_sc(a.logw + b);
+      a1 -= ld_sc(a.logpx + b);
+      a2 += ld_sc(a.logq + b) - ld_sc(a.logp + b);
+      a3 += a.nent ? ld_sc(a.nent + b) : 0.f;
+    }
+    red[t] = a0; red[256 + t] = a1; red[512 + t] = a2; red[768 + t] = a3;
+  }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o)
+      for (int j = 0; j < 4; ++j) red[j * 256 + t] += red[j * 256 + t + o];
+    __syncthreads();
+  }
+  if (t == 0) {
+    a.tail[0] = red[0]; a.tail[1] = red[256]; a.tail[2] = red[512]; a.tail[3] = red[768];
+    a.tail[4] = (float)a.B; a.tail[5] = 0.f; a.tail[6] = 0.f; a.tail[7] = 0.f;
+    if (a.tail_log) {
+      a.tail_log[0] = red[0]; a.tail_log[1] = red[256]; a.tail_log[2] = red[512]; a.tail_log[3] = red[768];
+      a.tail_log[4] = (float)a.B; a.tail_log[5] = 0.f; a.tail_log[6] = 0.f; a.tail_log[7] = 0.f;
+    }
+    // every workgroup read the counter and the epoch at its start, long before any lead's last flag
+    if (step_dev) { step_dev[1] = step; step_dev[0] = step + 1ull; }
+    if (a.epoch_word) *a.epoch_word += 1u;
+  }
+}
+
+__global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const MegaArgs& a = aa.m;
+  const M3Fin& fa = aa.fa;
+  // what the worker phase needs of the launch's start state (read before anything can have changed it)
+  const unsigned epoch = *a.epoch_word;
+  const unsigned long long step = a.step_dev[0];
+  const unsigned spin_limit = *a.err_word ? 0u : (1u << 19);
+  if (aa.dbg && threadIdx.x == 0) aa.dbg[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
+  const int role = mega2_body<1>(a, sm, aa.flags);
+#define M3_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
+#define M3_ST(i) if (aa.dbg && threadIdx.x == 0) aa.dbg[(size_t)blockIdx.x * 8 + (i)] = wall_clock64()
+  if (role == 0) { M3_END(); return; }
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lk = lane >> 4;
+  const int B = a.B, nPr = (B + kPanel - 1) / kPanel, nP = (nPr + 1) & ~1;
+  const int bid = blockIdx.x;
+  const int q = bid < nP * 3 ? 1 + bid / nP : 0;
+  const int pnl = bid < nP * 3 ? bid % nP : bid - nP * 3;
+  M3_ST(0);
+  // the role's last stores (a producer's g tiles; the lead's dlogits, dhy1) are acknowledged: its flag goes out
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();             // (also: the per-row role's LDS is dead in every wave)
+  if (tid == 0)
+    __hip_atomic_store(aa.flags + (role == 2 ? 5 : q - 1) * kM3FlagLd + pnl, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int rank = (q == 0 ? 3 * nPr : (q - 1) * nPr) + pnl, nW = 4 * nPr;
+  float* const red = sm;                         // [wave][mt * 4 + r][lane]
+  float* const redcs = sm + kDwWaves * 64 * 16;  // [wave][lane]
+  // alpha_t = lr sqrt(1 - b2^t) / (1 - b1^t) (fp64, adam_tf's form): computed while the workgroup would only wait
+  float lr_t = 0.f;
+  const bool upd = fa.do_adam != 0;
+  if (upd) {
+    const double t = (double)(step + 1ull);
+    lr_t = (float)((double)fa.lr * sqrt(1.0 - pow((double)fa.b2, t)) / (1.0 - pow((double)fa.b1, t)));
+  }
+  const float omb1 = 1.f - fa.b1, omb2 = 1.f - fa.b2, gs = 1.f / fa.count;
+  unsigned seen = 0;                             // (uniform) phases whose flags this workgroup has seen
+  bool poisoned = false;
+  auto wait_phase = [&](const int ph) {
+    if (seen & (1u << ph)) return;
+    if (wave == 0) {
+      // phase A: the three producers' rows and the lead's row 3 (4 loads per lane in flight); B: row 4; C: row 5
+      const unsigned* const f0 = aa.flags + min(lane, nPr - 1);
+      unsigned spins = 0;
+      for (;;) {
+        bool ok;
+        if (ph == kM3PhA) {
+          const unsigned f_0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned f_1 = __hip_atomic_load(f0 + kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned f_2 = __hip_atomic_load(f0 + 2 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned f_3 = __hip_atomic_load(f0 + 3 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = f_0 == epoch && f_1 == epoch && f_2 == epoch && f_3 == epoch;
+        } else {
+          ok = __hip_atomic_load(f0 + (ph == kM3PhB ? 4 : 5) * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+        }
+        if (__all(ok)) break;
+        if (++spins > spin_limit) {
+          if (lane == 0) atomicExch(a.err_word, 1u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();
+    poisoned = __hip_atomic_load(a.err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    seen |= 1u << ph;
+  };
+  for (int slot = rank; slot < aa.total_slots; slot += nW) {
+    const int pv_ = aa.perm[slot];
+    if (pv_ == kM3None) continue;
+    if (pv_ == kM3Tail) {
+      wait_phase(kM3PhC);
+      M3_ST(2);
+      m3_tail(fa, a.step_dev, step, red);
+      M3_ST(5);
+      if (aa.dbg && tid == 0) aa.dbg[(size_t)blockIdx.x * 8 + 6] = 99ull;
+      __syncthreads();
+      continue;
+    }
+    const int ti = pv_ >> 10, tl = pv_ & 1023;
+    const DwTensor& T = aa.t[ti];
+    const int ph = aa.tphase[ti];
+    const int M = T.M, N = T.N, lda = T.lda, ldy = T.ldy;
+    const int tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
+    const int MUr = T.mu;
+    const int m0 = tm * 16 * MUr, n0 = tn * 16;
+    // ---- epilogue owners (dwadam.hpp): unit (lane slot el, eu) = dW[mb .. mb+3][en]
+    const int el = tid & 63, eu = (tid >> 6) & 3;
+    const int mb = m0 + 4 * MUr * (el >> 4) + 4 * eu, en = n0 + (el & 15);
+    const bool eown = tid < 64 * MUr && mb < M && en < N;
+    const bool bown = tm == 0 && T.b_off >= 0 && tid >= 256 && tid < 272 && n0 + (tid - 256) < N;
+    float pp[4] = {0.f, 0.f, 0.f, 0.f}, pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f};
+    float bp = 0.f, bm = 0.f, bv = 0.f;
+    // the optimizer's operands: the previous launch wrote them -- requested before the wait
+    if (upd) {
+      if (eown) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int mm = min(mb + j, M - 1);
+          const long long i = (long long)T.w_off + (long long)mm * N + en;
+          pp[j] = fa.p[i]; pm[j] = fa.m[i]; pv[j] = fa.v[i];
+        }
+      }
+      if (bown) { const int i = T.b_off + n0 + tid - 256; bp = fa.p[i]; bm = fa.m[i]; bv = fa.v[i]; }
+    }
+    const int rows_w = (((B + kDwWaves - 1) / kDwWaves) + 3) & ~3;
+    const int b_lo = wave * rows_w, b_hi = min(B, b_lo + rows_w);
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float cs = 0.f;
+    M3_ST(1);
+    if (T.a_u8 && b_hi - b_lo == 128) {
+      unsigned av[32];
+      dw_u8x3_load_a(static_cast<const unsigned char*>(T.A), lda, M, m0, b_lo, ln, lk, av);     // the batch: final before the launch
+      wait_phase(ph);
+      M3_ST(2);
+      dw_u8x3_rest<false>(av, T.dY, ldy, M, N, m0, n0, b_lo, ln, lk, acc, cs);
+    } else {
+      wait_phase(ph);
+      M3_ST(2);
+      if (rows_w <= 32) {                          // small batch: 8 k-steps per batch of loads
+        if (T.a_u8) dw_contract<true, 4, 8>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+        else if (MUr == 2) dw_contract<false, 2, 8>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+        else dw_contract<false, 1, 8>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+      }
+      else if (T.a_u8) dw_contract<true, 4>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+      else if (MUr == 2) dw_contract<false, 2>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+      else dw_contract<false, 1>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+    }
+    M3_ST(3);
+    // ---- the waves' partial tiles meet in LDS (fixed order: bit-reproducible)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * t + r) * 64 + lane] = acc[t][r];
+    redcs[wave * 64 + lane] = cs;
+    __syncthreads();
+    M3_ST(4);
+    if (eown) {
+      float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < kDwWaves; ++w)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int o = 4 * eu + j, r = MUr == 4 ? eu : (MUr == 2 ? o >> 1 : o), t = MUr == 4 ? j : (MUr == 2 ? o & 1 : 0);
+          g[j] += red[(w * 16 + 4 * t + r) * 64 + el];
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (mb + j < M) {
+          const long long i = (long long)T.w_off + (long long)(mb + j) * N + en;
+          fa.grads[i] = g[j];
+          if (upd && !poisoned) {
+            adam_update(pp[j], pm[j], pv[j], g[j], gs, lr_t, omb1, omb2, fa.eps);
+            fa.p[i] = pp[j]; fa.m[i] = pm[j]; fa.v[i] = pv[j];
+          }
+        }
+      }
+      if (upd && !poisoned) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (mb + j >= M) pp[j] = 0.f;              // rows past the tensor: the image's padding stays zero
+        if (T.k1 == 2 || T.k1 == 4 || T.k1 == 7)
+          *reinterpret_cast<float4*>(fa.img[T.which1] + img_dst(T.k1, T.base1, T.ld1, T.chunk1, mb, en)) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        else if (T.k1 >= 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (mb + j < M) fa.img[T.which1][img_dst(T.k1, T.base1, T.ld1, T.chunk1, mb + j, en)] = pp[j];
+        }
+        if (T.k2 >= 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (mb + j < M) fa.img[T.which2][img_dst(T.k2, T.base2, T.ld2, T.chunk2, mb + j, en)] = pp[j];
+        }
+      }
+    }
+    if (bown) {                                    // bias gradient = column sum of dY over the batch
+      const int c = tid - 256;
+      float g = 0.f;
+#pragma unroll
+      for (int w = 0; w < kDwWaves; ++w)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g += redcs[w * 64 + k * 16 + c];
+      const int i = T.b_off + n0 + c;
+      fa.grads[i] = g;
+      if (upd && !poisoned) {
+        adam_update(bp, bm, bv, g, gs, lr_t, omb1, omb2, fa.eps);
+        fa.p[i] = bp; fa.m[i] = bm; fa.v[i] = bv;
+        if (T.bk >= 0) fa.img[T.bwhich][img_dst(T.bk, T.bbase, 0, T.bchunk, 0, n0 + c)] = bp;
+      }
+    }
+    M3_ST(5);
+    if (aa.dbg && tid == 0) aa.dbg[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)ti;
+    __syncthreads();                               // the meeting area is free for the next slot
+  }
+  M3_END();
+#undef M3_END
+#undef M3_ST
+}
+
+}  // namespace gmvae

@@ -473,7 +473,7 @@ __device__ __forceinline__ void sk_nt(const float* __restrict__ A, const long lo
 
 // launch outputs leave write-through (mega2.hpp st4o): nothing waits dirty in L2 for the end-of-kernel write-back, which
 // at ten short launches per step is most of a step (measured: tools/micro/launch_floor.hip, profiles/round3_notes.md)
-__device__ __forceinline__ void st1o(float* p, const float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (st1o -- a 4-byte launch output, write-through -- lives in mega2.hpp)
 
 __device__ __forceinline__ float sk_row16_sum(float v) {
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);

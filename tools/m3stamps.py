@@ -1,0 +1,36 @@
+"""Wall-clock stamps (100 MHz) of mega3_step's workgroups (GMVAE_STAMPS=1): the per-row role's end, then the worker phase by
+tensor -- operands requested, all leads' flags seen, contraction done, partial tiles met in LDS, optimizer epilogue done."""
+import sys, os, ctypes as C
+os.environ.setdefault("GMVAE_M3_STAMPS", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gmvae_amd import _lib as L
+from gmvae_amd.engine import Engine
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+e = Engine("gmvae", 784, 64, 10, [64], random_seed=0)
+x = torch.from_numpy((np.random.default_rng(0).random((B, 784)) < 0.87).astype(np.uint8)).cuda()
+G = 16
+sx, replay = e.capture_train_step(B, 1e-3, n_steps=G)
+sx.copy_(x.unsqueeze(0).expand(G, -1, -1))
+for _ in range(200): replay()
+torch.cuda.synchronize()
+d, ws = e._workspace(B)
+off = C.c_uint64(); L.check(L.lib.gmvae_workspace_offset(C.byref(d), e.model, b"gstamps", C.byref(off)), "off")
+raw = ws.view(torch.int64)[off.value // 8 + 3 * 2048 * 8: off.value // 8 + 4 * 2048 * 8].cpu().numpy().reshape(2048, 8).astype(np.float64)
+raw = raw[raw[:, 7] > 0]
+t0 = raw[:, 7].min()
+nP = ((B + 15) // 16 + 1) & ~1
+lead = np.arange(len(raw)) >= 3 * nP
+us = lambda a: a * 0.01
+print("workgroups", len(raw), "timeouts", e.handoff_timeouts(), "launch span %.2f us" % us(raw[:, 5].max() - t0))
+print("per-row role ends: producers median %.2f max %.2f | leads median %.2f max %.2f" % (
+    us(np.median(raw[~lead, 0] - t0)), us((raw[~lead, 0] - t0).max()), us(np.median(raw[lead, 0] - t0)), us((raw[lead, 0] - t0).max())))
+names = ["dWy0", "dWg0x", "dWd1", "dWg0y", "dWy1", "dWp", "dWg1", "dWd0"]
+for who, sel in (("producers", ~lead), ("leads", lead)):
+    for ti in list(range(8)) + [99]:
+        r = raw[sel & (raw[:, 6] == ti) & (raw[:, 5] > 0)]
+        if not len(r): continue
+        med = lambda a: np.median(a) * 0.01
+        nm = "tail" if ti == 99 else names[ti]
+        print(f"{who:9s} {nm:6s} n={len(r):3d} role end {med(r[:,0]-t0):5.2f} | requested {med(r[:,1]-t0):5.2f} | flags seen {med(r[:,2]-t0):5.2f} (max {us((r[:,2]-t0).max()):5.2f})"
+              f" | contraction +{med(r[:,3]-r[:,2]):5.2f} | meet +{med(r[:,4]-r[:,3]):5.2f} | epilogue +{med(r[:,5]-r[:,4]):5.2f} | end {med(r[:,5]-t0):5.2f} (max {us((r[:,5]-t0).max()):5.2f})")
