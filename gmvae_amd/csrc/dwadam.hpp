@@ -284,6 +284,47 @@ __device__ __forceinline__ void dw_u8x3_rest(const unsigned (&av)[32], const flo
   }
 }
 
+// The fp32 contraction of a wave's 128 rows in two parts (mega3_step): the A operand (a forward activation, final long before
+// the pre-activation gradients) is requested first; the dY values and the matrix instructions follow behind the tile's flag.
+template <int MU>
+struct DwA32 { typedef typename std::conditional<MU == 2, float2, float>::type T; };
+template <int MU>
+__device__ __forceinline__ void dw_f32_load_a(const float* __restrict__ A32, const int lda, const int M, const int m0, const int b_lo,
+                                              const int ln, const int lk, typename DwA32<MU>::T (&av)[32]) {
+  static_assert(MU == 2 || MU == 1, "32- or 16-row tiles");
+  const int mac = min(m0 + MU * ln, ((M + 3) & ~3) - MU);
+  const float* const a32 = A32 + (long long)(b_lo + lk) * lda + mac;
+#pragma unroll
+  for (int s = 0; s < 32; ++s) av[s] = *reinterpret_cast<const typename DwA32<MU>::T*>(a32 + (long long)(4 * s) * lda);
+}
+// (SC: the dY values with agent-scope loads -- for columns whose lines an earlier phase may have pulled into this XCD's L2
+//  before their last bytes were written: the g columns of the lead's decoder tile, mega3.hpp)
+template <int MU, bool SC = false>
+__device__ __forceinline__ void dw_f32_rest(const typename DwA32<MU>::T (&av)[32], const float* __restrict__ dY, const int ldy, const int M,
+                                            const int N, const int m0, const int n0, const int b_lo, const int ln, const int lk,
+                                            f32x4 (&acc)[4], float& cs) {
+  const bool a_ok = m0 + MU * ln < M, n_ok = n0 + ln < N;
+  const int nc = min(n0 + ln, N - 1);
+  float bvv[32];
+  const float* const dy = dY + (long long)(b_lo + lk) * ldy + nc;
+#pragma unroll
+  for (int s = 0; s < 32; ++s) bvv[s] = SC ? ldg_f<true>(dy + (long long)(4 * s) * ldy) : dy[(long long)(4 * s) * ldy];
+  // all 32 loads in flight before the first matrix instruction (with the A operand resident the scheduler otherwise sinks each
+  // load in front of its use to save registers: 32 dependent round trips, 8.5 us measured)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    const float bq = n_ok ? bvv[s] : 0.f;
+    if constexpr (MU == 2) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? av[s].x : 0.f, bq, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? av[s].y : 0.f, bq, acc[1], 0, 0, 0);
+    } else {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ok ? av[s] : 0.f, bq, acc[0], 0, 0, 0);
+    }
+    cs += bq;
+  }
+}
+
 // (Round 4, measured and reverted: [16 x 16] tiles for the decoder output layer -- 196 instead of 98 -- end at 7.4 us instead
 //  of 9.6, but 338 workgroups need two per CU: at <= 128 registers the contraction's 64 in-flight operands spill (124 B of
 //  scratch per lane) and the launch takes 14.6 us; at one per CU the last 83 tiles start when the first ones end: 15.7 us.)

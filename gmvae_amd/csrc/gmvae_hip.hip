@@ -1179,40 +1179,39 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         m3.m.lr_t_out = nullptr;
         m3.ntens = da.ntens;
         m3.flags = w.sync + 64;
+        m3.lr_next = w.sync + 4;
         m3.dbg = getenv("GMVAE_M3_STAMPS") ? w.gstamps + 3 * 2048 * 8 : nullptr;
         {
-          // The slot list (mega3.hpp): workgroup `rank` takes slots rank, rank + workers, ...  Producers (ranks below 3 panels)
-          // are done first, so they get the tiles of phases A and B in that order; the leads' ranks start at 3 panels, where
-          // the tiles of phase C (they need the END of the backward chain) and the loss tail begin.  Inside a group, slot b
-          // (XCD b % 8 under round-robin placement) prefers a tile of its operand class (speed only).
-          const int nPr = (B + kPanel - 1) / kPanel;
-          auto phase_of = [&](const DwTensor& T) {
-            if (T.dY == w.g || T.dY == w.dbuf[0]) return kM3PhA;                          // dWd1 (g, hd1), dWd0 (dhd1, z)
-            if (T.dY == w.dbuf[2] || T.dY == w.dlogits) return kM3PhC;                    // dWy0 / dWe0 (dhy1), dWy1 (dlogits)
-            return kM3PhB;                                                                // dqp, dpp, dhg1
-          };
-          std::vector<int> tile_cls(da.total_tiles), tile_ph(da.total_tiles), tile_pt(da.total_tiles);
+          // The slot list (mega3.hpp): workgroup `rank` takes slots rank, rank + workers, ...; the producers hold the ranks below
+          // 3 panels and are done first.  Phase P first -- the decoder output layer's gradient over the producers' column tiles:
+          // its tiles wait for the producers' flags only and run under the leads' backward chain --, then phase F: the fp32
+          // tiles (longer), the uint8-batch tiles, the loss tail.  At B = 1024: P on producers 0..95, F on producers 96..191 and
+          // on the leads.  Inside a group, slot b (XCD b % 8 under round-robin placement) prefers a tile of its operand class.
+          const int nt = da.total_tiles;
+          std::vector<int> tile_cls(nt), tile_grp(nt), tile_pt(nt);
           for (int i = 0; i < da.ntens; ++i) {
             const DwTensor& T = da.t[i];
-            m3.tphase[i] = (unsigned char)phase_of(T);
             const int tiles_m = ((T.M + 16 * T.mu - 1) / (16 * T.mu));
             for (int tm = 0; tm < tiles_m; ++tm)
               for (int tn = 0; tn < T.tiles_n; ++tn) {
                 const int t = T.tile_begin + tm * T.tiles_n + tn;
+                int q_ = 1, lt_ = 0;
+                if (T.dY == w.g) m2_dec_part(tn, q_, lt_);                                 // whose g columns: a producer's or the lead's
+                const bool phP = T.dY == w.g && q_ != 0;
                 tile_cls[t] = (tiles_m >= T.tiles_n ? tm : tn) & 7;
-                tile_ph[t] = m3.tphase[i];
-                tile_pt[t] = (i << 10) | (t - T.tile_begin);
+                tile_grp[t] = phP ? 0 : (T.a_u8 ? 2 : 1);
+                tile_pt[t] = (i << 10) | (t - T.tile_begin) | (phP ? 0 : kM3PhaseF);
               }
           }
-          std::vector<char> used(da.total_tiles, 0);
+          std::vector<char> used(nt, 0);
           int slot = 0;
-          auto deal = [&](const int ph) {                     // the phase's tiles into consecutive slots
+          for (int grp = 0; grp < 3; ++grp) {
             int left = 0;
-            for (int t = 0; t < da.total_tiles; ++t) left += tile_ph[t] == ph;
+            for (int t = 0; t < nt; ++t) left += tile_grp[t] == grp;
             for (; left > 0; --left, ++slot) {
               int pick = -1, any = -1;
-              for (int t = 0; t < da.total_tiles && pick < 0; ++t)
-                if (!used[t] && tile_ph[t] == ph) {
+              for (int t = 0; t < nt && pick < 0; ++t)
+                if (!used[t] && tile_grp[t] == grp) {
                   if (any < 0) any = t;
                   if (tile_cls[t] == (slot & 7)) pick = t;
                 }
@@ -1220,11 +1219,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
               used[pick] = 1;
               if (slot < kM3MaxSlots) m3.perm[slot] = (unsigned short)tile_pt[pick];
             }
-          };
-          deal(kM3PhA);
-          deal(kM3PhB);
-          for (; slot < 3 * nPr && slot < kM3MaxSlots; ++slot) m3.perm[slot] = kM3None;
-          deal(kM3PhC);
+          }
           if (slot < kM3MaxSlots) m3.perm[slot] = kM3Tail;
           m3.total_slots = ++slot;
         }

@@ -724,13 +724,20 @@ __global__ void adam_tf(float* __restrict__ p, float* __restrict__ m, float* __r
 // the launch's critical path (it also stores the panel's activations and runs the backward chain), and its hand-off poll
 // can only succeed ~1 us after the producers publish: with 13 / 12 / 12 / 12 tiles it finished its decoder stage 1.6 us
 // AFTER them (tools/handoff_clock.py); two-deep waves cost the producers nothing extra up to 16 tiles.
-constexpr int kM2LeadTiles = 8, kM2ProdTiles = 14, kM2Tiles = 49;
+// (M2_LEAD_TILES = 1, mega3_step: the producers own 16 tiles each -- still two per wave -- and the lead ONE, so that the
+//  decoder layer's weight gradient depends on the producers alone and its tiles can start while the leads run the backward
+//  chain; mega3.hpp)
+#ifndef M2_LEAD_TILES
+#define M2_LEAD_TILES 1
+#endif
+constexpr int kM2Tiles = 49, kM2LeadTiles = M2_LEAD_TILES, kM2ProdTiles = (kM2Tiles - kM2LeadTiles + 2) / 3;
+static_assert(kM2LeadTiles >= 1 && kM2LeadTiles <= 8 && kM2ProdTiles <= 16, "one tile per lead wave, at most two per producer wave");
 __host__ __device__ inline void m2_dec_part(const int t, int& q, int& lt) {
   if (t < kM2Tiles - kM2LeadTiles) { q = 1 + t % 3; lt = t / 3; }
   else { q = 0; lt = t - (kM2Tiles - kM2LeadTiles); }
 }
 __host__ __device__ inline int m2_dec_tile(const int q, const int lt) { return q == 0 ? kM2Tiles - kM2LeadTiles + lt : 3 * lt + (q - 1); }
-__host__ __device__ inline int m2_dec_ntiles(const int q) { return q == 0 ? kM2LeadTiles : (q == 3 ? kM2ProdTiles - 1 : kM2ProdTiles); }
+__host__ __device__ inline int m2_dec_ntiles(const int q) { return q == 0 ? kM2LeadTiles : (kM2Tiles - kM2LeadTiles - (q - 1) + 2) / 3; }
 __host__ __device__ inline int img_dst(const int kind, const int base, const int ld, const int chunk, const int r, const int c) {
   switch (kind) {
     case 0: return base + r * ld + c;

@@ -133,6 +133,17 @@ __device__ __forceinline__ u32x4_t granule2_load(const unsigned long long* p) {
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
   return r;
 }
+// The same load served by the XCD's L2 (sc0: only the CU's own cache is bypassed).  A write-through store updates the writer's
+// L2 on its way to memory, so a reader ON THE SAME XCD sees it an L2 round trip later instead of a trip through the fabric;
+// a reader on another XCD would spin on its own L2's stale copy -- hence M2_L2_SWEEPS failed sweeps at most, then sc1.
+#ifndef M2_L2_SWEEPS
+#define M2_L2_SWEEPS 0
+#endif
+__device__ __forceinline__ u32x4_t granule2_load_l2(const unsigned long long* p) {
+  u32x4_t r;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
 template <int N>
 __device__ __forceinline__ void g2_wait(u32x4_t (&v)[N]) {
   static_assert(N == 6 || N == 8, "operand lists below");
@@ -170,6 +181,9 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
   const int r0 = pnl * kPanel;
   const int nrow = min(kPanel, B - r0);            // (<= 0: a phantom panel)
   const bool lead = q == 0;
+  // who stores the panel's forward activations (kept for the weight gradients; every quarter holds the same bits): the lead,
+  // or -- mega3_step -- quarter 1, whose end-of-role flag then covers them and who is off the launch's critical path
+  const bool act = FUSE ? q == 1 : lead;
   if (a.span && tid == 0) a.span[2 * bid] = wall_clock64();
 #define M2_SPAN_END() if (!FUSE && a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
   const unsigned spin_limit = *a.err_word ? 0u : (1u << 19);       // bounded spins (see mega.hpp)
@@ -296,10 +310,18 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
       unsigned spins = 0;
       for (;;) {
         // all 8 loads are in flight before the first tag is looked at
+        if (M2_L2_SWEEPS > 0 && spins < M2_L2_SWEEPS && (wave >> 2) == hh) {        // (wave-uniform) this panel's own quarters: same XCD
 #pragma unroll
-        for (int pq = 0; pq < 4; ++pq) {
-          gv[2 * pq] = granule2_load(xp0 + (long long)pq * 2 * ngr);
-          gv[2 * pq + 1] = granule2_load(xp0 + (long long)pq * 2 * ngr + 128);
+          for (int pq = 0; pq < 4; ++pq) {
+            gv[2 * pq] = granule2_load_l2(xp0 + (long long)pq * 2 * ngr);
+            gv[2 * pq + 1] = granule2_load_l2(xp0 + (long long)pq * 2 * ngr + 128);
+          }
+        } else {
+#pragma unroll
+          for (int pq = 0; pq < 4; ++pq) {
+            gv[2 * pq] = granule2_load(xp0 + (long long)pq * 2 * ngr);
+            gv[2 * pq + 1] = granule2_load(xp0 + (long long)pq * 2 * ngr + 128);
+          }
         }
         g2_wait(gv);
         bool ok = true;
@@ -321,7 +343,10 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
         flt[r] += __uint_as_float(gv[4 + (r >> 1)][2 * (r & 1)]);
         flt[r] += __uint_as_float(gv[6 + (r >> 1)][2 * (r & 1)]);
       }
-      if (a.dbg && a.fine >= 5 && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + 14] = spins;
+      if (a.dbg && a.fine >= 5 && tid == 0) {
+        a.dbg[(size_t)blockIdx.x * 16 + 14] = spins;
+        a.dbg[(size_t)blockIdx.x * 16 + 0] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // HW_REG_XCC_ID: the XCD this workgroup runs on
+      }
     }
   }
   M2_WC(6);
@@ -330,6 +355,7 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
   // local tile lt = wave, wave + 8 of this workgroup's part; global tile t = 4 lt + q
   const int ntq = m2_dec_ntiles(q);                // 8 tiles for the lead (one per wave), 14 / 14 / 13 for the producers
   const bool two = wave + 8 < ntq;                 // (wave-uniform) this wave has a second tile
+  const bool one = wave < ntq;                     //               ... a first one (the lead may own fewer tiles than waves)
   float4 wf[2][4], wb[2][4], bias4[2];
   unsigned xb[2] = {0u, 0u};
   {
@@ -338,7 +364,7 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
     const float* const bq = a.dimg2 + M2::dbias + q * M2::dbq;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      if (it == 0 || two) {
+      if (it == 0 ? one : two) {
         const int lt = wave + 8 * it;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) wf[it][kt] = ld4(dfq + (((kt * 4 + lk) * M2::DC + lt * 16 + ln) << 2));
@@ -353,7 +379,8 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
   // vmcnt retires in order: everything OLDER than these 10 (20) register loads -- the whole operand image -- has landed
   // once at most that many are outstanding; the loads themselves stay in flight across the next stages.
   if (two) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (one) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   M2_FC(7);
   {                                                // bias + ReLU straight from the (row-major oriented) accumulator
@@ -370,7 +397,7 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
   }
   __syncthreads();
   GMVAE_STAMP(1);
-  if (lead && tid < 256) {                         // hy1 (kept for dWy1) leaves as 16-byte write-through stores
+  if (act && tid < 256) {                          // hy1 (kept for dWy1) leaves as 16-byte write-through stores
     const int row = tid >> 4, c = (tid & 15) << 2;
     if (row < nrow) st4o(a.hy1 + (long long)(r0 + row) * H + c, ld4(P_h1 + row * M2::ld128 + c));
   }
@@ -402,7 +429,7 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
       yv = fexp(av - lse);
       const float lp = lg - l2;
       ne = fexp(lp) * lp;
-      if (ok && lead) st1o(a.y + (long long)(r0 + row) * K2 + k, yv);            // rows of pad4(K) floats
+      if (ok && act) st1o(a.y + (long long)(r0 + row) * K2 + k, yv);            // rows of pad4(K) floats
     }
     P_y[row * M2::ldk + k] = yv;                                            // columns K..15 are zero
     ne = row16_sum(ne);
@@ -426,7 +453,7 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
       const float4 h = make_float4(fmaxf(ac2[0] + gx.x + bg.x, 0.f), fmaxf(ac2[1] + gx.y + bg.y, 0.f),
                                    fmaxf(ac2[2] + gx.z + bg.z, 0.f), fmaxf(ac2[3] + gx.w + bg.w, 0.f));
       st4(P_hg + ln * M2::ld64 + c0, h);
-      if (lead && ln < nrow) st4o(a.hg1 + (long long)(r0 + ln) * H + c0, h);
+      if (act && ln < nrow) st4o(a.hg1 + (long long)(r0 + ln) * H + c0, h);
     }
   }
   __syncthreads();
@@ -478,7 +505,7 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
     }
   }
   __syncthreads();
-  if (lead && tid >= 256) {                        // z (kept for dWd0): waves 4..7, which have no tile in S6
+  if (act && tid >= 256) {                         // z (kept for dWd0): waves 4..7, which have no tile in S6
     const int t2 = tid - 256, row = t2 >> 4, c = (t2 & 15) << 2;
     if (row < nrow) st4o(a.z + (long long)(r0 + row) * L + c, ld4(P_z + row * M2::ld64 + c));
   }
@@ -490,7 +517,7 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
     const float4 bb = ld4(img + M2::b_d0 + c0);
     const float4 h = make_float4(fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f), fmaxf(acc[2] + bb.z, 0.f), fmaxf(acc[3] + bb.w, 0.f));
     st4(P_hd + ln * M2::ld64 + c0, h);
-    if (lead && ln < nrow) st4o(a.hd1 + (long long)(r0 + ln) * H + c0, h);
+    if (act && ln < nrow) st4o(a.hd1 + (long long)(r0 + ln) * H + c0, h);
   }
   __syncthreads();                                 // the forward image is dead
   GMVAE_STAMP(4);
@@ -605,10 +632,18 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
       u32x4_t v[6];
       const unsigned long long* const xs = xi + ((wave * 2) * 64 + lane) * 2;
       for (;;) {
+        if (M2_L2_SWEEPS > 0 && spins < M2_L2_SWEEPS) {
 #pragma unroll
-        for (int pq = 0; pq < Q - 1; ++pq) {
-          v[2 * pq] = granule2_load(xs + (long long)pq * ngr);
-          v[2 * pq + 1] = granule2_load(xs + (long long)pq * ngr + 128);
+          for (int pq = 0; pq < Q - 1; ++pq) {
+            v[2 * pq] = granule2_load_l2(xs + (long long)pq * ngr);
+            v[2 * pq + 1] = granule2_load_l2(xs + (long long)pq * ngr + 128);
+          }
+        } else {
+#pragma unroll
+          for (int pq = 0; pq < Q - 1; ++pq) {
+            v[2 * pq] = granule2_load(xs + (long long)pq * ngr);
+            v[2 * pq + 1] = granule2_load(xs + (long long)pq * ngr + 128);
+          }
         }
         g2_wait(v);
         bool ok = true;
@@ -633,7 +668,9 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
       const unsigned long long* const xs = xi + kPanel * H + min(lane, kPanel - 1);
       for (;;) {
 #pragma unroll
-        for (int pq = 0; pq < Q - 1; ++pq) v[pq] = __hip_atomic_load(xs + (long long)pq * ngr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int pq = 0; pq < Q - 1; ++pq)
+          v[pq] = (M2_L2_SWEEPS > 0 && spins < M2_L2_SWEEPS) ? __hip_atomic_load(xs + (long long)pq * ngr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                                             : __hip_atomic_load(xs + (long long)pq * ngr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_sched_barrier(0);
         bool ok = true;
 #pragma unroll
@@ -652,7 +689,7 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
         if (wn) rsn += __uint_as_float((unsigned)v[pq]);
     }
     if (a.dbg && a.fine >= 5 && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + 15] = spins;       // sweeps that failed
-    if (ln < nrow) {                               // now the decoder tiles' g = sigmoid(lambda) - x
+    if (ln < nrow && one) {                        // now the decoder tiles' g = sigmoid(lambda) - x
       st4o(a.g + (long long)(r0 + ln) * D + m2_dec_tile(0, wave) * 16 + 4 * lk, gkeep[0]);
       if (two) st4o(a.g + (long long)(r0 + ln) * D + m2_dec_tile(0, wave + 8) * 16 + 4 * lk, gkeep[1]);
     }
@@ -678,7 +715,7 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
   // pieces of the image were issued long before; waves 5..7 wait for everything but their one g store just issued.  (An
   // s_waitcnt vmcnt(0) here also waited for the write-through acknowledgement of the g stores: ~1 us in front of the
   // backward chain.)
-  if (wave > 4) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  if (wave > 4) { if (one) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   __syncthreads();
   M2_WC(4);
   GMVAE_STAMP(6);
@@ -740,19 +777,7 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
       if (ok) st4o(a.dhg1 + (long long)(r0 + ln) * H + c0, d);
     }
   }
-  // mega3_step, flag A (this lead's g, dhd1 -- and hd1, z before them -- are in memory): vmcnt retires in order, so once at
-  // most the stores issued AFTER them are outstanding (dqp, dpp; waves 0..3 also dhg1) they are acknowledged; they were
-  // issued two stages ago, so this wait is nearly free -- a vmcnt(0) here would also wait for the stores just issued
-  // (a ragged panel's waves skip stores whose rows do not exist: no counting there)
-  if constexpr (FUSE) {
-    if (nrow < kPanel || a.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (diagnostic stamps are stores too)
-    else if (wave < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  }
   __syncthreads();
-  if constexpr (FUSE) {
-    if (tid == 0) __hip_atomic_store(m3_flags + 3 * 64 + pnl, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   // B4 dy = dhg * Wg0[D:]^T + dpp * Wp^T: one tile; the 4 + 8 contraction tiles are spread over the 8 waves
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -787,15 +812,7 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
     }
     P_dl[row * M2::ldk + k] = dl;
   }
-  // mega3_step, flag B (dqp, dpp, dhg1 -- and hg1, y before them): the only later store is waves 0..3's dlogits
-  if constexpr (FUSE) {
-    if (wave < 4 && nrow == kPanel && !a.dbg) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
   __syncthreads();
-  if constexpr (FUSE) {
-    if (tid == 0) __hip_atomic_store(m3_flags + 4 * 64 + pnl, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   // B6 dhy1 = (dlogits * Wy1^T) [hy1 > 0]: 4 tiles, contraction = k (one tile)
   if (wave < 4) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};

@@ -10,19 +10,21 @@
 // slot per workgroup), requests what does not depend on this launch (the tile's parameters and Adam moments, the uint8 batch
 // operand) and then waits for the leads.
 //
-// Hand-off.  Everything a workgroup leaves for the tiles is stored write-through (st4o / st1o: sc1).  When the stores of a
-// PHASE are acknowledged by the memory side (s_waitcnt on the in-order vmcnt counter, in every wave, then a workgroup barrier),
-// ONE thread stores this step's epoch into the phase's flag of the panel (4 bytes, write-through):
-//   producers (rows 0..2 of the flag table)  their decoder tiles' g                       -- after the publish of their partials
-//   A (row 3)  the lead's g, dhd1 (hd1, z before them)                                      -- before the barrier behind B3
-//   B (row 4)  dqp, dpp, dhg1 (hg1, y before them)                                          -- before the barrier behind B5
-//   C (row 5)  dlogits, dhy1 (hy1 and the per-row loss terms before them)                   -- at the lead's end
-// A and B wait only until the stores issued AFTER the phase's last one are the only ones outstanding (mega2.hpp): those
-// were issued two stages earlier, so the lead -- the launch's critical path -- does not stall for them.  A worker polls the
-// flags of its tile's phase (agent-scope loads, wave 0) until every panel's carries the epoch, then reads the operands.  The
-// flags are epoch tags, not counters: nothing resets them, and a stale flag can never equal the current epoch.  Polls are
-// bounded (a timeout sets the error word: the step is not applied and the host falls back to the safe schedule, exactly as
-// for the granule hand-offs).
+// Hand-off.  Everything a workgroup leaves for the tiles is stored write-through (st4o / st1o: sc1).  A workgroup ends its
+// per-row role with: s_waitcnt vmcnt(0) in every wave (its stores are acknowledged by the memory side: 0.3-1.1 us measured) ->
+// workgroup barrier -> ONE thread stores this step's epoch into the workgroup's flag (4 bytes, write-through):
+//   rows 0..2 of the flag table: the producers (quarters 1..3) -- their decoder tiles' g; quarter 1 also stores the panel's
+//                                forward activations (hy1, y, hg1, z, hd1: every quarter holds the same bits)
+//   row 3:                       the lead -- g of its one decoder tile, dhd1, dqp, dpp, dhg1, dlogits, dhy1, per-row loss terms
+// Tiles come in two phases: P needs the producers' flags only -- the decoder output layer's weight gradient (hd1^T g: 98
+// tiles, the step's longest) over the 48 column tiles the producers own (kernels.hpp M2_LEAD_TILES = 1) -- and runs while the
+// leads are still in their hand-off and backward chain; F needs the leads' flags too.  A worker polls the flag rows of its
+// tile's phase (agent-scope loads, wave 0) until every panel's carry the epoch.  The flags are epoch tags, not counters:
+// nothing resets them, and a stale flag can never equal the current epoch.  Polls are bounded (a timeout sets the error word:
+// the step is not applied and the host falls back to the safe schedule, exactly as for the granule hand-offs).
+// (Measured and dropped, profiles/round5_notes.md: flags in the middle of the backward chain -- behind counted vmcnt waits
+// they cost the leads 0.6-0.9 us and arrive no earlier than the final flag + 1 us; polls every 0.1 us by 190 workgroups slowed
+// the slowest lead by 1.5 us.)
 //
 // Operand loads behind a flag are PLAIN loads, served by the XCD's L2.  (Measured, tools/m3stamps.py: agent-scope sc1 loads
 // of the operands -- 30 MB per step that no L2 may serve -- ran the fp32 tiles' contraction at the fabric's rate, 15 us against
@@ -32,8 +34,9 @@
 //      a load or a store of THIS launch;
 //   2. no workgroup loads from a hand-off buffer before it has seen the flags of the buffer's phase, and by then every byte of
 //      the buffer is in memory (stores acknowledged before the flag);
-//   3. buffers of different phases share no 128-byte line (the workspace carves 256-byte units), and a panel's rows of one
-//      buffer are written by that panel's workgroups only;
+//   3. buffers of different phases share no 128-byte line (the workspace carves 256-byte units); a panel's rows of one buffer
+//      are written by that panel's workgroups only, and those run on ONE XCD when the panel count is a multiple of 8 (workgroups
+//      are dealt round-robin over the XCDs; tools/handoff_clock.py prints HW_REG_XCC_ID per workgroup: 64 of 64 panels);
 //   4. a write-through store of part of a line does not fetch the rest of the line into the writer's L2 (byte-masked write
 //      allocation), so the writer's L2 holds no stale copy of bytes other workgroups write later.
 // The per-row loss terms (two panels share a line) and the flags are read with agent-scope loads.
@@ -49,9 +52,8 @@ namespace gmvae {
 
 constexpr int kM3MaxSlots = 320;
 constexpr int kM3MaxT = 8;
-constexpr unsigned short kM3Tail = 0xffffu, kM3None = 0xfffeu;
-constexpr int kM3FlagRows = 6, kM3FlagLd = 64;       // rows 0..2: producers q - 1; 3: A; 4: B; 5: C
-constexpr int kM3PhA = 0, kM3PhB = 1, kM3PhC = 2;
+constexpr unsigned short kM3Tail = 0xffffu, kM3None = 0xfffeu, kM3PhaseF = 0x8000u;
+constexpr int kM3FlagLd = 64;                        // rows 0..2: producers q - 1; row 3: the leads
 
 struct M3Fin {                 // what the tiles' optimizer epilogue and the loss tail need (FinalArgs without slabs / maps)
   float *grads, *p, *m, *v;
@@ -69,10 +71,10 @@ struct M3Fin {                 // what the tiles' optimizer epilogue and the los
 struct M3Args {
   MegaArgs m;
   int ntens, total_slots;
-  unsigned* flags;             // [kM3FlagRows][kM3FlagLd] per-panel epoch tags
+  unsigned* flags;             // [4][kM3FlagLd] per-workgroup epoch tags
+  unsigned* lr_next;           // [2]: {alpha_t bits, the Adam step t it is for}: left by the previous step's tail slot
   unsigned long long* dbg;     // diagnostic: [workgroup][8] wall-clock stamps of the worker phase (tools/m3stamps.py) or null
-  unsigned char tphase[kM3MaxT];      // the phase whose flags a tensor's tiles wait for
-  unsigned short perm[kM3MaxSlots];   // slot -> (tensor << 10) | tile inside the tensor; kM3Tail: the loss tail; kM3None
+  unsigned short perm[kM3MaxSlots];   // slot -> (tensor << 10) | tile inside the tensor (| kM3PhaseF); kM3Tail: the loss tail
   DwTensor t[kM3MaxT];
   M3Fin fa;
 };
@@ -81,9 +83,14 @@ static_assert(sizeof(M3Args) <= 4096, "kernel arguments");
 __device__ __forceinline__ float ld_sc(const float* p) {
   return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// alpha_t = lr sqrt(1 - b2^t) / (1 - b1^t) (fp64, adam_tf's form)
+__device__ __forceinline__ float m3_alpha(const M3Fin& a, const unsigned long long t) {
+  return (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, (double)t)) / (1.0 - pow((double)a.b1, (double)t)));
+}
 
 // the loss tail (kernels.hpp finalize_tail_block) over per-row terms the leads of THIS launch stored: agent-scope loads
-__device__ __forceinline__ void m3_tail(const M3Fin& a, unsigned long long* step_dev, const unsigned long long step, float* red) {
+__device__ __forceinline__ void m3_tail(const M3Fin& a, unsigned long long* step_dev, const unsigned long long step, unsigned* lr_next,
+                                        float* red) {
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   const int t = threadIdx.x;
   if (t < 256) {
@@ -94,6 +101,10 @@ __device__ __forceinline__ void m3_tail(const M3Fin& a, unsigned long long* step
       a3 += a.nent ? ld_sc(a.nent + b) : 0.f;
     }
     red[t] = a0; red[256 + t] = a1; red[512 + t] = a2; red[768 + t] = a3;
+  }
+  if (t == 256 && a.do_adam) {                   // the NEXT step's alpha_t, tagged with that step's index
+    lr_next[0] = __float_as_uint(m3_alpha(a, step + 2ull));
+    lr_next[1] = (unsigned)(step + 2ull);        // (Adam's t of that step: never 0, the workspace's initial value)
   }
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -108,7 +119,7 @@ __device__ __forceinline__ void m3_tail(const M3Fin& a, unsigned long long* step
       a.tail_log[0] = red[0]; a.tail_log[1] = red[256]; a.tail_log[2] = red[512]; a.tail_log[3] = red[768];
       a.tail_log[4] = (float)a.B; a.tail_log[5] = 0.f; a.tail_log[6] = 0.f; a.tail_log[7] = 0.f;
     }
-    // every workgroup read the counter and the epoch at its start, long before any lead's last flag
+    // every workgroup read the counter and the epoch at its start, long before any lead's flag
     if (step_dev) { step_dev[1] = step; step_dev[0] = step + 1ull; }
     if (a.epoch_word) *a.epoch_word += 1u;
   }
@@ -122,10 +133,12 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
   const unsigned epoch = *a.epoch_word;
   const unsigned long long step = a.step_dev[0];
   const unsigned spin_limit = *a.err_word ? 0u : (1u << 19);
+  const unsigned lr_bits = aa.lr_next[0], lr_tag = aa.lr_next[1];
   if (aa.dbg && threadIdx.x == 0) aa.dbg[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
-  const int role = mega2_body<1>(a, sm, aa.flags);
+  const int role = mega2_body<1>(a, sm);
 #define M3_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
 #define M3_ST(i) if (aa.dbg && threadIdx.x == 0) aa.dbg[(size_t)blockIdx.x * 8 + (i)] = wall_clock64()
+#define M3_ST2(i) if (aa.dbg && threadIdx.x == 0) aa.dbg[(size_t)(blockIdx.x + 256) * 8 + (i)] = wall_clock64()
   if (role == 0) { M3_END(); return; }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, lk = lane >> 4;
@@ -134,68 +147,70 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
   const int q = bid < nP * 3 ? 1 + bid / nP : 0;
   const int pnl = bid < nP * 3 ? bid % nP : bid - nP * 3;
   M3_ST(0);
-  // the role's last stores (a producer's g tiles; the lead's dlogits, dhy1) are acknowledged: its flag goes out
+  // the role's stores are acknowledged: the workgroup's flag goes out
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  M3_ST2(0);
   __syncthreads();             // (also: the per-row role's LDS is dead in every wave)
+  M3_ST2(1);
   if (tid == 0)
-    __hip_atomic_store(aa.flags + (role == 2 ? 5 : q - 1) * kM3FlagLd + pnl, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(aa.flags + (role == 2 ? 3 : q - 1) * kM3FlagLd + pnl, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int rank = (q == 0 ? 3 * nPr : (q - 1) * nPr) + pnl, nW = 4 * nPr;
   float* const red = sm;                         // [wave][mt * 4 + r][lane]
   float* const redcs = sm + kDwWaves * 64 * 16;  // [wave][lane]
-  // alpha_t = lr sqrt(1 - b2^t) / (1 - b1^t) (fp64, adam_tf's form): computed while the workgroup would only wait
-  float lr_t = 0.f;
   const bool upd = fa.do_adam != 0;
-  if (upd) {
-    const double t = (double)(step + 1ull);
-    lr_t = (float)((double)fa.lr * sqrt(1.0 - pow((double)fa.b2, t)) / (1.0 - pow((double)fa.b1, t)));
-  }
+  // alpha_t: the previous step's tail slot left it (tagged with this step's index); the first step of a launch computes it
+  float lr_t = __uint_as_float(lr_bits);
+  if (upd && lr_tag != (unsigned)(step + 1ull)) lr_t = m3_alpha(fa, step + 1ull);
+  M3_ST2(2);
   const float omb1 = 1.f - fa.b1, omb2 = 1.f - fa.b2, gs = 1.f / fa.count;
-  unsigned seen = 0;                             // (uniform) phases whose flags this workgroup has seen
+  unsigned seen = 0;                             // (uniform) bit 0: the producers' flags seen; bit 1: the leads'
   bool poisoned = false;
-  auto wait_phase = [&](const int ph) {
-    if (seen & (1u << ph)) return;
+  // wait for the producers' rows (leads = false) or for all four rows
+  auto wait_flags = [&](const bool leads) {
+    const unsigned want = leads ? 3u : 1u;
+    if ((seen & want) == want) return;
     if (wave == 0) {
-      // phase A: the three producers' rows and the lead's row 3 (4 loads per lane in flight); B: row 4; C: row 5
       const unsigned* const f0 = aa.flags + min(lane, nPr - 1);
+      const bool np = !(seen & 1u);                // (uniform) the producers' rows are still to be seen
       unsigned spins = 0;
       for (;;) {
-        bool ok;
-        if (ph == kM3PhA) {
+        bool ok = true;
+        if (np) {
           const unsigned f_0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const unsigned f_1 = __hip_atomic_load(f0 + kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const unsigned f_2 = __hip_atomic_load(f0 + 2 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned f_3 = __hip_atomic_load(f0 + 3 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = f_0 == epoch && f_1 == epoch && f_2 == epoch && f_3 == epoch;
-        } else {
-          ok = __hip_atomic_load(f0 + (ph == kM3PhB ? 4 : 5) * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+          ok = f_0 == epoch && f_1 == epoch && f_2 == epoch;
         }
+        if (leads) ok = ok && __hip_atomic_load(f0 + 3 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
         if (__all(ok)) break;
         if (++spins > spin_limit) {
           if (lane == 0) atomicExch(a.err_word, 1u);
           break;
         }
-        __builtin_amdgcn_s_sleep(4);
+        if (aa.dbg && lane == 0) aa.dbg[(size_t)(blockIdx.x + 256) * 8 + 4] = wall_clock64();     // the last failed poll
+        __builtin_amdgcn_s_sleep(8);
       }
     }
+    if (aa.dbg && tid == 0) { aa.dbg[(size_t)(blockIdx.x + 256) * 8 + 3] = wall_clock64(); aa.dbg[(size_t)(blockIdx.x + 256) * 8 + 5] = (unsigned long long)leads; }
     __syncthreads();
     poisoned = __hip_atomic_load(a.err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-    seen |= 1u << ph;
+    seen |= want;
   };
   for (int slot = rank; slot < aa.total_slots; slot += nW) {
     const int pv_ = aa.perm[slot];
     if (pv_ == kM3None) continue;
     if (pv_ == kM3Tail) {
-      wait_phase(kM3PhC);
+      wait_flags(true);
       M3_ST(2);
-      m3_tail(fa, a.step_dev, step, red);
+      m3_tail(fa, a.step_dev, step, aa.lr_next, red);
       M3_ST(5);
       if (aa.dbg && tid == 0) aa.dbg[(size_t)blockIdx.x * 8 + 6] = 99ull;
       __syncthreads();
       continue;
     }
-    const int ti = pv_ >> 10, tl = pv_ & 1023;
+    const bool phF = (pv_ & kM3PhaseF) != 0;
+    const int ti = (pv_ & 0x7fff) >> 10, tl = pv_ & 1023;
     const DwTensor& T = aa.t[ti];
-    const int ph = aa.tphase[ti];
     const int M = T.M, N = T.N, lda = T.lda, ldy = T.ldy;
     const int tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
     const int MUr = T.mu;
@@ -207,7 +222,7 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
     const bool bown = tm == 0 && T.b_off >= 0 && tid >= 256 && tid < 272 && n0 + (tid - 256) < N;
     float pp[4] = {0.f, 0.f, 0.f, 0.f}, pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f};
     float bp = 0.f, bm = 0.f, bv = 0.f;
-    // the optimizer's operands: the previous launch wrote them -- requested before the wait
+    // the optimizer's operands: the previous launch wrote them -- requested before any wait
     if (upd) {
       if (eown) {
 #pragma unroll
@@ -221,26 +236,48 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
     }
     const int rows_w = (((B + kDwWaves - 1) / kDwWaves) + 3) & ~3;
     const int b_lo = wave * rows_w, b_hi = min(B, b_lo + rows_w);
+    const bool full = b_hi - b_lo == 128;          // (uniform: B = 1024) the register-resident forms
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float cs = 0.f;
     M3_ST(1);
-    if (T.a_u8 && b_hi - b_lo == 128) {
+    if (T.a_u8 && full) {
       unsigned av[32];
       dw_u8x3_load_a(static_cast<const unsigned char*>(T.A), lda, M, m0, b_lo, ln, lk, av);     // the batch: final before the launch
-      wait_phase(ph);
+      wait_flags(phF);
       M3_ST(2);
       dw_u8x3_rest<false>(av, T.dY, ldy, M, N, m0, n0, b_lo, ln, lk, acc, cs);
+    } else if (!T.a_u8 && full && phF && MUr <= 2) {
+      // a forward activation times a pre-activation gradient: the activation (quarter 1 stored it) behind the producers'
+      // flags, the gradient behind the leads'
+      wait_flags(false);
+      if (MUr == 2) {
+        float2 av[32];
+        dw_f32_load_a<2>(static_cast<const float*>(T.A), lda, M, m0, b_lo, ln, lk, av);
+        wait_flags(true);
+        M3_ST(2);
+        // (the lead's g columns share 128-byte lines with producers' columns that phase P has already read: not from L2)
+        if (T.dY == a.g) dw_f32_rest<2, true>(av, T.dY, ldy, M, N, m0, n0, b_lo, ln, lk, acc, cs);
+        else dw_f32_rest<2>(av, T.dY, ldy, M, N, m0, n0, b_lo, ln, lk, acc, cs);
+      } else {
+        float av[32];
+        dw_f32_load_a<1>(static_cast<const float*>(T.A), lda, M, m0, b_lo, ln, lk, av);
+        wait_flags(true);
+        M3_ST(2);
+        dw_f32_rest<1>(av, T.dY, ldy, M, N, m0, n0, b_lo, ln, lk, acc, cs);
+      }
     } else {
-      wait_phase(ph);
+      wait_flags(phF);
       M3_ST(2);
       if (rows_w <= 32) {                          // small batch: 8 k-steps per batch of loads
         if (T.a_u8) dw_contract<true, 4, 8>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+        else if (MUr == 2 && phF && T.dY == a.g) dw_contract<false, 2, 8, true>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
         else if (MUr == 2) dw_contract<false, 2, 8>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
         else dw_contract<false, 1, 8>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
       }
       else if (T.a_u8) dw_contract<true, 4>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
+      else if (MUr == 2 && phF && T.dY == a.g) dw_contract<false, 2, 32, true>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);   // (the lead's g columns: not from L2, see above)
       else if (MUr == 2) dw_contract<false, 2>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
       else dw_contract<false, 1>(T.A, T.dY, lda, ldy, M, N, m0, n0, b_lo, b_hi, ln, lk, acc, cs, 0);
     }
@@ -313,6 +350,7 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
   M3_END();
 #undef M3_END
 #undef M3_ST
+#undef M3_ST2
 }
 
 }  // namespace gmvae

@@ -34,3 +34,8 @@ print("  consumer: D end -> poll start", us(cons[:, 1] - cons[:, 0]), "| poll", 
 print("  panel's last producer publish -> consumer polls done", us(cons[:, 2] - lastp))
 print("  failed sweeps (thread 0): D hand-off, consumers: median", np.median(raw[nP * 3:, 15]), "max", raw[nP * 3:, 15].max(),
       "| first-layer exchange, all workgroups: median", np.median(raw[:, 14]), "max", raw[:, 14].max())
+xcc = raw[:, 0].astype(int)
+print('XCC ids of workgroups 0..31:', xcc[:32].tolist(), '| leads 192..207:', xcc[192:208].tolist())
+bid = np.arange(nP * Q)
+print("XCD of a workgroup == blockIdx % 8 for", int((xcc == bid % 8).sum()), "of", len(bid), "workgroups; a panel's four workgroups on one XCD in",
+      int(sum(len(set(xcc[[q * nP + p for q in range(3)] + [3 * nP + p]])) == 1 for p in range(nP))), "of", nP, "panels")

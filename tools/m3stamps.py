@@ -16,7 +16,9 @@ for _ in range(200): replay()
 torch.cuda.synchronize()
 d, ws = e._workspace(B)
 off = C.c_uint64(); L.check(L.lib.gmvae_workspace_offset(C.byref(d), e.model, b"gstamps", C.byref(off)), "off")
-raw = ws.view(torch.int64)[off.value // 8 + 3 * 2048 * 8: off.value // 8 + 4 * 2048 * 8].cpu().numpy().reshape(2048, 8).astype(np.float64)
+raw_all = ws.view(torch.int64)[off.value // 8 + 3 * 2048 * 8: off.value // 8 + 4 * 2048 * 8].cpu().numpy().reshape(2048, 8).astype(np.float64)
+raw, ext = raw_all[:256], raw_all[256:512]
+ext = ext[raw[:, 7] > 0]
 raw = raw[raw[:, 7] > 0]
 t0 = raw[:, 7].min()
 nP = ((B + 15) // 16 + 1) & ~1
@@ -34,3 +36,14 @@ for who, sel in (("producers", ~lead), ("leads", lead)):
         nm = "tail" if ti == 99 else names[ti]
         print(f"{who:9s} {nm:6s} n={len(r):3d} role end {med(r[:,0]-t0):5.2f} | requested {med(r[:,1]-t0):5.2f} | flags seen {med(r[:,2]-t0):5.2f} (max {us((r[:,2]-t0).max()):5.2f})"
               f" | contraction +{med(r[:,3]-r[:,2]):5.2f} | meet +{med(r[:,4]-r[:,3]):5.2f} | epilogue +{med(r[:,5]-r[:,4]):5.2f} | end {med(r[:,5]-t0):5.2f} (max {us((r[:,5]-t0).max()):5.2f})")
+
+q = lambda a: "median %.2f (min %.2f max %.2f)" % (np.median(a) * 0.01, a.min() * 0.01, a.max() * 0.01)
+for who, sel in (("producers", ~lead), ("leads", lead)):
+    print(f"{who}: role end -> stores acknowledged {q(ext[sel, 0] - raw[sel, 0])} | -> barrier passed {q(ext[sel, 1] - ext[sel, 0])} | alpha_t {q(ext[sel, 2] - ext[sel, 1])}")
+print("leads' role ends sorted (us):", np.round(np.sort(raw[lead, 0] - t0) * 0.01, 2).tolist())
+lf = ext[lead, 1].max()
+pf = ext[~lead, 1].max()
+for ph, nm in ((0, "producers' flags"), (1, "leads' flags")):
+    sel = ext[:, 5] == ph
+    ref = lf if ph else pf
+    if sel.any(): print(f"last wait was for the {nm}: n={int(sel.sum())} seen {q(ext[sel, 3] - t0)}; after the LAST such flag's store {q(ext[sel, 3] - ref)}")
