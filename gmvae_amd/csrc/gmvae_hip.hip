@@ -1026,7 +1026,10 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         hipFuncSetAttribute(reinterpret_cast<const void*>(mega2_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         m2attr = true;
       }
-      fuse_pending = (dw_upd_ || a.dp_images) && a.step_dev && !getenv("GMVAE_NO_FUSE");
+      // (B = 1024: 256 workgroups for the 241 tile slots and the register-resident contraction forms; measured at smaller
+      //  batches -- fewer workgroups than slots -- the one-launch form loses: B = 512 43.2 against 33.8 us, profiles/round5_notes.md.
+      //  GMVAE_FUSE=1 forces it for any batch: tools/fuse_check.py)
+      fuse_pending = (dw_upd_ || a.dp_images) && a.step_dev && !getenv("GMVAE_NO_FUSE") && (B == 1024 || getenv("GMVAE_FUSE"));
       c3 = c;
       // (an even number of panels: the first layer works on pairs of them, mega2.hpp)
       if (!fuse_pending)

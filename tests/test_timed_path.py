@@ -417,3 +417,35 @@ def test_config5_shard_full_size_properties(monkeypatch):
         n = int(np.prod(shape))
         ref = g[name].ravel()
         assert np.abs(small[off:off + n] / 8 - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6), name
+
+
+@pytest.mark.parametrize("B", [1024, 1000, 256])
+def test_one_launch_step_equals_two_launch_step_bit_for_bit(B, monkeypatch):
+    """mega3_step (csrc/mega3.hpp: the per-row part and the weight-gradient tiles + TF-Adam of scripts/runners.py:181-183,231-232
+    in ONE launch, handed over through per-workgroup flags inside the launch) against mega2_fwd_bwd -> dw_adam on the same
+    batches: the tiles run the same arithmetic in the same order, so parameters and both Adam moments after 48 steps must agree
+    BIT FOR BIT -- a tile that read an operand before it was final, or an update that overtook a reader, shows up here.
+    (B = 1024 takes the one-launch form by itself; GMVAE_FUSE=1 forces it for the ragged and the small batch.)"""
+    from gmvae_amd.engine import Engine
+    from gmvae_amd import _lib as L
+    G, n = 16, 48
+    rng = np.random.default_rng(B)
+    xs = torch.from_numpy((rng.random((G, B, 784)) < 0.87).astype(np.uint8)).cuda()
+    res = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("GMVAE_NO_FUSE", raising=False); monkeypatch.setenv("GMVAE_FUSE", "1")
+        else:
+            monkeypatch.setenv("GMVAE_NO_FUSE", "1"); monkeypatch.delenv("GMVAE_FUSE", raising=False)
+        e = Engine("gmvae", 784, 64, 10, [64], random_seed=5)
+        sx, replay = e.capture_train_step(B, LR, n_steps=G)
+        sx.copy_(xs)
+        for _ in range(n // G):
+            replay()
+        torch.cuda.synchronize()
+        names = [nm for nm, _, _, _ in e.profile_train_levels(xs[0], lr=LR, iters=2)]
+        assert e.handoff_timeouts() == 0 and int(e.step_dev[0].item()) >= n
+        res.append((e.params.detach().clone(), e.m.clone(), e.v.clone(), names))
+    assert res[0][3] == ["mega3_step"] and res[1][3] == ["mega2_fwd_bwd", "dw_adam"], (res[0][3], res[1][3])
+    for a_, b_ in zip(res[0][:3], res[1][:3]):
+        assert torch.isfinite(a_).all() and torch.equal(a_, b_)

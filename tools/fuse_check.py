@@ -14,8 +14,8 @@ for B in sizes:
     xs = torch.from_numpy((rng.random((G, B, 784)) < 0.87).astype(np.uint8)).cuda()
     res = []
     for fused in (True, False):
-        if fused: os.environ.pop("GMVAE_NO_FUSE", None)
-        else: os.environ["GMVAE_NO_FUSE"] = "1"
+        if fused: os.environ.pop("GMVAE_NO_FUSE", None); os.environ["GMVAE_FUSE"] = "1"
+        else: os.environ["GMVAE_NO_FUSE"] = "1"; os.environ.pop("GMVAE_FUSE", None)
         e = Engine("gmvae", 784, 64, 10, [64], random_seed=5)
         sx, replay = e.capture_train_step(B, 1e-3, n_steps=G)
         sx.copy_(xs)
@@ -25,7 +25,7 @@ for B in sizes:
             losses.append(e.last_tail_log().clone() if hasattr(e, "last_tail_log") else None)
         torch.cuda.synchronize()
         res.append((e.params.detach().clone(), e.m.clone(), e.v.clone(), e.handoff_timeouts(), e.step_schedule(B) if hasattr(e, "step_schedule") else ""))
-    os.environ.pop("GMVAE_NO_FUSE", None)
+    os.environ.pop("GMVAE_NO_FUSE", None); os.environ.pop("GMVAE_FUSE", None)
     same = all(torch.equal(a, b) for a, b in zip(res[0][:3], res[1][:3]))
     d = (res[0][0] - res[1][0]).abs().max().item()
     print(f"B={B:5d} steps={steps // G * G}: fused == two-launch bit for bit: {same} (max |dtheta| {d:.3e}) timeouts {res[0][3]} / {res[1][3]} finite {bool(torch.isfinite(res[0][0]).all())}", flush=True)

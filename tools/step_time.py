@@ -11,6 +11,7 @@ cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "configs2"]
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
 G = int(os.environ.get("GRAPH_STEPS", "40"))
 B, D = cfg["batch"], cfg["data_dim"]
+if len(sys.argv) > 3: B = int(sys.argv[3])
 e = Engine(cfg["model"], D, cfg["latent"], cfg["components"] if cfg["model"] != "vae" else 1, [cfg["hidden"]] * cfg["layers"],
            n_samples=cfg["n_samples"], random_seed=0)
 rng = np.random.default_rng(0)
