@@ -38,14 +38,21 @@ CONFIGS = {
     # H = 512 (bin/run_train.sh:6) is the "realistic point" of configs[1] / configs[2]
     "configs1_h512": dict(model="vae_gmp", batch=256, latent=64, components=10, hidden=512, layers=1, data_dim=784, n_samples=1),
     "configs2_h512": dict(model="gmvae", batch=1024, latent=64, components=10, hidden=512, layers=1, data_dim=784, n_samples=1),
+    # one rank's step of BASELINE configs[3] (1024 rows per GPU) on the DATA-PARALLEL path with a one-rank RCCL communicator:
+    # gradients -> RCCL all-reduce node inside the hipGraph (an identity copy here) -> TF-Adam scaled by 1/count.  What the
+    # path costs before a byte crosses xGMI; `--gpus N` runs the same path with N ranks.
+    "configs3_dp1": dict(model="gmvae", batch=1024, latent=64, components=10, hidden=64, layers=1, data_dim=784, n_samples=1,
+                         dp_world1=True),
 }
 
 
 def workload_name(a, n_gpus):
     key = dict(model=a.model, batch=a.batch, latent=a.latent, components=a.components if a.model != "vae" else 1,
                hidden=a.hidden, layers=a.layers, data_dim=a.data_dim, n_samples=a.n_samples)
+    if getattr(a, "dp_world1", False) and n_gpus == 1:
+        return "one rank of BASELINE configs[3] on the data-parallel path (one-rank RCCL communicator)"
     for name, c in CONFIGS.items():
-        if c == key:
+        if {k: v for k, v in c.items() if k != "dp_world1"} == key:
             if name == "configs2":
                 return "BASELINE configs[2]" if n_gpus == 1 else f"BASELINE configs[3] shape: 1024 rows per GPU x {n_gpus}"
             return {"configs0": "BASELINE configs[0]", "configs1": "BASELINE configs[1]",
@@ -99,6 +106,8 @@ def parse():
     ap.add_argument("--levels", action="store_true", help="also print the per-launch table to stderr")
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
                     help="a named workload (BASELINE.json configs / SURVEY.md 8(d)); the default line is configs2")
+    ap.add_argument("--dp-world1", action="store_true",
+                    help="N = 1 on the data-parallel path: RCCL all-reduce node (one-rank communicator) inside the hipGraph")
     a = ap.parse_args()
     if a.config:
         for k, v in CONFIGS[a.config].items():
@@ -199,6 +208,7 @@ def main():
         else:
             dist.init_process_group(backend)
     n_gpus = world
+    dp = world > 1 or bool(a.dp_world1)              # the data-parallel path (also with ONE rank: --config configs3_dp1)
 
     def dev_all_reduce(t, op):                      # small control tensors: on the device over RCCL, through the host over gloo
         if backend == "nccl":
@@ -280,7 +290,7 @@ def main():
 
     if world > 1 and backend != "nccl":
         fallback(f"GMVAE_DIST_BACKEND={backend}: the all-reduce is staged through the host between two eager halves of the step")
-    elif world > 1:
+    elif dp:
         try:
             eng.enable_rccl()           # RCCL communicator inside libgmvae_hip.so: step + all-reduce + Adam in one graph
         except Exception as e:
@@ -294,7 +304,7 @@ def main():
     multi_fn = None
     if use_graph:
         try:
-            static_x, replay = eng.capture_train_step(B, lr=1e-3, all_reduce=world > 1)
+            static_x, replay = eng.capture_train_step(B, lr=1e-3, all_reduce=dp)
             static_x.copy_(x)
             step_fn = replay
             if a.pipeline and world == 1:
@@ -303,7 +313,7 @@ def main():
                 multi_fn = eng.capture_train_pipeline(ds, B, lr=1e-3, n_steps=G)
                 step_fn = eng.capture_train_pipeline(ds, B, lr=1e-3, n_steps=1)
             elif G > 1:
-                xs, multi_fn = eng.capture_train_step(B, lr=1e-3, all_reduce=world > 1, n_steps=G)
+                xs, multi_fn = eng.capture_train_step(B, lr=1e-3, all_reduce=dp, n_steps=G)
                 rng = np.random.default_rng(4321 + rank)
                 xs.copy_(torch.from_numpy((rng.random((G, B, d.D)) < 0.87).astype(np.uint8)))
         except Exception as e:                      # e.g. RCCL inside capture unsupported
@@ -314,7 +324,7 @@ def main():
             fallback(f"the RCCL all-reduce was not captured inside the hipGraph (data-parallel mode: {getattr(eng, 'dp_mode', None)})")
     if not use_graph:
         def step_fn():
-            eng.train_step(x, lr=1e-3, all_reduce=world > 1)
+            eng.train_step(x, lr=1e-3, all_reduce=dp)
 
     def run_steps(k):                               # exactly k training steps
         if multi_fn is not None:
@@ -357,11 +367,11 @@ def main():
         eng.use_safe_schedule()
         eng.init_parameters(0)                       # poisoned steps were skipped by the optimizer, but start clean anyway
         eng.sync_replicas()
-        static_x, step_fn = eng.capture_train_step(B, lr=1e-3, all_reduce=world > 1)
+        static_x, step_fn = eng.capture_train_step(B, lr=1e-3, all_reduce=dp)
         static_x.copy_(x)
         multi_fn = None
         if G > 1:
-            xs, multi_fn = eng.capture_train_step(B, lr=1e-3, all_reduce=world > 1, n_steps=G)
+            xs, multi_fn = eng.capture_train_step(B, lr=1e-3, all_reduce=dp, n_steps=G)
             xs.copy_(torch.from_numpy((np.random.default_rng(4321 + rank).random((G, B, d.D)) < 0.87).astype(np.uint8)))
         run_steps(2 * G)
         torch.cuda.synchronize()
@@ -416,6 +426,14 @@ def main():
         lo, hi = dev_all_reduce(cs.clone(), dist.ReduceOp.MIN), dev_all_reduce(cs.clone(), dist.ReduceOp.MAX)
         replicas_identical = bool((lo == hi).item())
     value = n_gpus * B * d.S * a.steps / dt
+    # the data-parallel step's timeline (device wall clock inside the launches on both sides of the RCCL node; COLLECTIVE:
+    # every rank replays the same three-step graph 10 times)
+    dp_tl = None
+    if dp and use_graph and getattr(eng, "dp_mode", None) == "rccl-in-hipgraph":
+        try:
+            dp_tl = eng.profile_dp_step(x, lr=1e-3, iters=10)
+        except Exception as e:
+            dp_tl = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         t_step_us = dt / a.steps * 1e6
@@ -427,7 +445,15 @@ def main():
         # so that the committed rocprofv3 average of the same kernel (profiles/) must agree with it.  Other schedules /
         # N > 1: hipEvents around eager launches.
         levels = None
-        if world == 1:
+        if dp_tl and "error" not in dp_tl:
+            # the DP step's launches with their shares of its timeline (they add up to the step): gradient launch(es), the
+            # all-reduce window (RCCL node + the launch boundaries around it), the Adam launch up to the next step's start
+            fl_step = flops_per_step(a.model, d.D, d.L, d.K, hidden, d.S, B)
+            gname = "+".join(dp_tl["grad_launches"]) or "gradients"
+            levels = [(gname, dp_tl["grad_span"], fl_step, dp_tl["grad_span"]),
+                      ("rccl_all_reduce", dp_tl["allreduce_window"], 0.0, dp_tl["allreduce_window"]),
+                      ("adam_tf_img", dp_tl["adam_span"], 0.0, dp_tl["adam_span"] + dp_tl["gap_to_next_step"])]
+        if levels is None and world == 1:
             try:
                 levels = eng.profile_train_levels(x, lr=1e-3, iters=30)
             except Exception:
@@ -519,7 +545,9 @@ def main():
             tag = {"BASELINE configs[2]": "bench", "per-GPU shard of BASELINE configs[4]": "config5_shard",
                    "bin/run_train.sh sizes": "run_train_sizes", "BASELINE configs[1]": "configs1",
                    "BASELINE configs[0]": "configs0", "BASELINE configs[1] at hidden 512": "configs1_h512",
-                   "BASELINE configs[2] at hidden 512": "configs2_h512"}.get(workload_name(a, n_gpus)) if world == 1 else None
+                   "BASELINE configs[2] at hidden 512": "configs2_h512",
+                   "one rank of BASELINE configs[3] on the data-parallel path (one-rank RCCL communicator)": "configs3_dp1",
+                   }.get(workload_name(a, n_gpus)) if world == 1 else None
             stats = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_{tag}_kernel_stats.csv"))) if tag else []
             kern_us = {}
             if stats:
@@ -533,7 +561,7 @@ def main():
                 kn = kn[5:] if kn.startswith("void ") else kn
                 k = k[5:] if k.startswith("void ") else k
                 return k.startswith(kn) and (kn.endswith((">", "<", ", ")) or k[len(kn):len(kn) + 1] in ("(", "<", " "))
-            knames = ["gmvae::" + dom[0]] if dom[0].startswith(("mega", "dw_")) else SK_KERNELS.get(dom[0], [])
+            knames = (["gmvae::mega3_step"] if dom[0].startswith("mega3") else ["gmvae::" + dom[0]]) if dom[0].startswith(("mega", "dw_")) else SK_KERNELS.get(dom[0], [])
             hit = [k for k in kern_us if any(is_kernel(k, kn) for kn in knames)]
             if hit:
                 us = sum(kern_us[k] for k in hit)
@@ -555,7 +583,7 @@ def main():
                 roof["traffic_source"] = os.path.relpath(traf[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, separate passes)"
                 per = {}
                 for nm, _, _, _ in levels:
-                    k2 = [k for k in tj if any(is_kernel(k, kn) for kn in SK_KERNELS.get(nm, ["gmvae::" + nm]))]
+                    k2 = [k for k in tj if any(is_kernel(k, kn) for kn in SK_KERNELS.get(nm, ["gmvae::mega3_step" if nm.startswith("mega3") else "gmvae::" + nm]))]
                     if k2:
                         per[nm] = sum(tj[k]["hbm_bytes_per_launch"] for k in k2)
                 if dom[0] in per:
@@ -598,6 +626,7 @@ def main():
                        "all_reduce": getattr(eng, "dp_mode", None) if use_graph or world == 1 else "torch.distributed (eager)",
                        "dist_backend": backend if world > 1 else None, "replicas_identical": replicas_identical},
             "fallback": bool(fallbacks), "fallback_reasons": fallbacks or None,
+            "dp_timeline_usec": dp_tl, "allreduce_usec": (dp_tl or {}).get("allreduce_window"), "rccl_nranks": world if dp else None,
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "final_loss": final_tail[0] / max(final_tail[4], 1.0),
         }

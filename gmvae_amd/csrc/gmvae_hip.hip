@@ -892,6 +892,59 @@ static int finish_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, floa
   return cx.err;
 }
 
+// The weight tensors of the single-hidden-layer step as dw_adam / mega3_step / adam_tiles tile them (dwadam.hpp DwTensor): operand
+// pointers, flat parameter offsets, where the optimizer also leaves the updated values (the operand images of plan_images)
+static void dw_tensors(const GmvaeDims& d, const int model, const Layout& L, const WS& w, const uint8_t* x, const ImgPlan& pl, DwArgs& da) {
+  const bool gm = model == GMVAE_MODEL_GMVAE;
+  const int B = d.B, K = d.K, Lz = d.L, D = d.D, H = d.hidden[0];
+  (void)B;
+  const NetL &E = gm ? L.ency : L.enc, &G = L.encg, &Dn = L.dec;
+  struct { const uint8_t* x; } a = {x};
+  auto add = [&](const void* A, bool u8, int lda, const float* dY, int ldy, int M, int N, uint64_t w_off, long long b_off,
+                 int mu = 4) {
+    DwTensor& T = da.t[da.ntens];
+    T.A = A; T.a_u8 = u8 ? 1 : 0; T.lda = lda; T.dY = dY; T.ldy = ldy; T.M = M; T.N = N; T.w_off = (int)w_off; T.b_off = (int)b_off;
+    T.mu = u8 ? 4 : mu;
+    T.tiles_n = (N + 15) / 16; T.tile_begin = da.total_tiles;
+    da.total_tiles += ((M + 16 * T.mu - 1) / (16 * T.mu)) * T.tiles_n;
+    T.bk = T.k1 = T.k2 = -1;
+    for (int i = 0; i < pl.nmap; ++i) {      // where the optimizer also has to leave the updated values (mega2's operand images)
+      const ImgMap& mp = pl.map[i];
+      if (mp.begin == (int)w_off && mp.end == (int)(w_off + (uint64_t)M * N)) {
+        if (T.k1 < 0) { T.k1 = mp.kind; T.base1 = mp.base; T.ld1 = mp.ld; T.chunk1 = mp.chunk; T.which1 = mp.which; }
+        else { T.k2 = mp.kind; T.base2 = mp.base; T.ld2 = mp.ld; T.chunk2 = mp.chunk; T.which2 = mp.which; }
+      }
+      if (b_off >= 0 && mp.begin == (int)b_off && mp.end == (int)(b_off + N)) { T.bk = mp.kind; T.bbase = mp.base; T.bchunk = mp.chunk; T.bwhich = mp.which; }
+    }
+    // the row-interleaved image (kinds 2 / 4) first: it leaves as one 16-byte store per thread
+    if (T.k2 == 2 || T.k2 == 4 || T.k2 == 7) {
+      const int k = T.k1, b_ = T.base1, l_ = T.ld1, c_ = T.chunk1, w_ = T.which1;
+      T.k1 = T.k2; T.base1 = T.base2; T.ld1 = T.ld2; T.chunk1 = T.chunk2; T.which1 = T.which2;
+      T.k2 = k; T.base2 = b_; T.ld2 = l_; T.chunk2 = c_; T.which2 = w_;
+    }
+    da.ntens++;
+  };
+  const int K4 = (int)pad4(K);
+  const int mu = 2;
+  constexpr int kDwd1Mu = 2;       // (the decoder output layer as [16 x 16] tiles: measured slower, dwadam.hpp)
+  // (32-row tiles for the fp32 problems: more, lighter workgroups -- 240 <= 256 CUs at the default sizes -- and the
+  //  decoder output layer's longer epilogue, two operand images, no longer ends the launch)
+  if (gm) {
+    add(a.x, true, D, w.dbuf[2], H, D, H, E.w[0], (long long)E.b[0]);                                 // dWy0 (+ dby0)
+    add(a.x, true, D, w.dbuf[1], H, D, H, G.w[0], (long long)G.b[0]);                                 // dWg0[x] (+ dbg0)
+    add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1], kDwd1Mu);                            // dWd1 (+ dbd1)
+    add(w.y, false, K4, w.dbuf[1], H, K, H, G.w[0] + (uint64_t)D * H, -1, mu);                        // dWg0[y]
+    add(w.he[1], false, H, w.dlogits, K4, H, K, E.w[1], (long long)E.b[1], mu);                       // dWy1
+    add(w.y, false, K4, w.dpp, 2 * Lz, K, 2 * Lz, L.prior.w[0], (long long)L.prior.b[0], mu);         // dWp
+    add(w.hg[1], false, H, w.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1], mu);                  // dWg1
+  } else {
+    add(a.x, true, D, w.dbuf[1], H, D, H, E.w[0], (long long)E.b[0]);                                 // dWe0 (+ dbe0)
+    add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1], kDwd1Mu);                            // dWd1 (+ dbd1)
+    add(w.he[1], false, H, w.dqp, 2 * Lz, H, 2 * Lz, E.w[1], (long long)E.b[1], mu);                  // dWe1
+  }
+  add(w.z, false, Lz, w.dbuf[0], H, Lz, H, Dn.w[0], (long long)Dn.b[0], mu);                          // dWd0
+}
+
 // ---- the mega schedule (all three models): first-layer split-K GEMM (+ aux) -> mega_fwd_bwd -> all dW -> finish
 static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, const float* eps, const float* u,
                          float* gen_eps, float* gen_u) {
@@ -1077,49 +1130,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       da.dbg = getenv("GMVAE_STAMPS") ? w.gstamps + 3 * 2048 * 8 : nullptr;
       da.lr_t = m2_ran ? reinterpret_cast<const float*>(w.sync + 2) : nullptr;
       da.ln_b1 = (float)log((double)a.beta1); da.ln_b2 = (float)log((double)a.beta2);
-      auto add = [&](const void* A, bool u8, int lda, const float* dY, int ldy, int M, int N, uint64_t w_off, long long b_off,
-                     int mu = 4) {
-        DwTensor& T = da.t[da.ntens];
-        T.A = A; T.a_u8 = u8 ? 1 : 0; T.lda = lda; T.dY = dY; T.ldy = ldy; T.M = M; T.N = N; T.w_off = (int)w_off; T.b_off = (int)b_off;
-        T.mu = u8 ? 4 : mu;
-        T.tiles_n = (N + 15) / 16; T.tile_begin = da.total_tiles;
-        da.total_tiles += ((M + 16 * T.mu - 1) / (16 * T.mu)) * T.tiles_n;
-        T.bk = T.k1 = T.k2 = -1;
-        for (int i = 0; i < pl.nmap; ++i) {      // where the optimizer also has to leave the updated values (mega2's operand images)
-          const ImgMap& mp = pl.map[i];
-          if (mp.begin == (int)w_off && mp.end == (int)(w_off + (uint64_t)M * N)) {
-            if (T.k1 < 0) { T.k1 = mp.kind; T.base1 = mp.base; T.ld1 = mp.ld; T.chunk1 = mp.chunk; T.which1 = mp.which; }
-            else { T.k2 = mp.kind; T.base2 = mp.base; T.ld2 = mp.ld; T.chunk2 = mp.chunk; T.which2 = mp.which; }
-          }
-          if (b_off >= 0 && mp.begin == (int)b_off && mp.end == (int)(b_off + N)) { T.bk = mp.kind; T.bbase = mp.base; T.bchunk = mp.chunk; T.bwhich = mp.which; }
-        }
-        // the row-interleaved image (kinds 2 / 4) first: it leaves as one 16-byte store per thread
-        if (T.k2 == 2 || T.k2 == 4 || T.k2 == 7) {
-          const int k = T.k1, b_ = T.base1, l_ = T.ld1, c_ = T.chunk1, w_ = T.which1;
-          T.k1 = T.k2; T.base1 = T.base2; T.ld1 = T.ld2; T.chunk1 = T.chunk2; T.which1 = T.which2;
-          T.k2 = k; T.base2 = b_; T.ld2 = l_; T.chunk2 = c_; T.which2 = w_;
-        }
-        da.ntens++;
-      };
-      const int K4 = (int)pad4(K);
-      const int mu = 2;
-      constexpr int kDwd1Mu = 2;       // (the decoder output layer as [16 x 16] tiles: measured slower, dwadam.hpp)
-      // (32-row tiles for the fp32 problems: more, lighter workgroups -- 240 <= 256 CUs at the default sizes -- and the
-      //  decoder output layer's longer epilogue, two operand images, no longer ends the launch)
-      if (gm) {
-        add(a.x, true, D, w.dbuf[2], H, D, H, E.w[0], (long long)E.b[0]);                                 // dWy0 (+ dby0)
-        add(a.x, true, D, w.dbuf[1], H, D, H, G.w[0], (long long)G.b[0]);                                 // dWg0[x] (+ dbg0)
-        add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1], kDwd1Mu);                            // dWd1 (+ dbd1)
-        add(w.y, false, K4, w.dbuf[1], H, K, H, G.w[0] + (uint64_t)D * H, -1, mu);                        // dWg0[y]
-        add(w.he[1], false, H, w.dlogits, K4, H, K, E.w[1], (long long)E.b[1], mu);                       // dWy1
-        add(w.y, false, K4, w.dpp, 2 * Lz, K, 2 * Lz, L.prior.w[0], (long long)L.prior.b[0], mu);         // dWp
-        add(w.hg[1], false, H, w.dqp, 2 * Lz, H, 2 * Lz, G.w[1], (long long)G.b[1], mu);                  // dWg1
-      } else {
-        add(a.x, true, D, w.dbuf[1], H, D, H, E.w[0], (long long)E.b[0]);                                 // dWe0 (+ dbe0)
-        add(w.hd[1], false, H, w.g, D, H, D, Dn.w[1], (long long)Dn.b[1], kDwd1Mu);                            // dWd1 (+ dbd1)
-        add(w.he[1], false, H, w.dqp, 2 * Lz, H, 2 * Lz, E.w[1], (long long)E.b[1], mu);                  // dWe1
-      }
-      add(w.z, false, Lz, w.dbuf[0], H, Lz, H, Dn.w[0], (long long)Dn.b[0], mu);                          // dWd0
+      dw_tensors(d, model, L, w, a.x, pl, da);
       {  // XCD-aware order: slot b runs on XCD b % 8 (observed round-robin placement; speed only)
         std::vector<int> cls(kDwMaxTiles);       // the XCD a tile would like: the one that shares its larger operand
         bool used[kDwMaxTiles];
@@ -2681,7 +2692,8 @@ int gmvae_comm_destroy(void* comm) {
  * previous step of the same graph did so, and this step may run its first layer inside mega_fwd_bwd. */
 static int dp_step_impl(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v, float* grads,
                         void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1, float beta2,
-                        float epsilon, void* comm, hipStream_t st, bool in_graph, bool imgs_ready, float* tail_log = nullptr) {
+                        float epsilon, void* comm, hipStream_t st, bool in_graph, bool imgs_ready, float* tail_log = nullptr,
+                        int span_slot = -1, Prof* prof = nullptr) {
   if (int e = check_dims(dims, model)) return e;
   if (!x || !params || !m || !v || !grads || !workspace || !comm || !g_rccl.h || !step_dev) return GMVAE_E_NULL;
   if (!aligned16(params) || !aligned16(grads) || !aligned16(workspace)) return GMVAE_E_ALIGN;
@@ -2704,6 +2716,8 @@ static int dp_step_impl(const GmvaeDims* dims, int model, const uint8_t* x, floa
                 seed, 0, step_dev, true};
   a.dp_images = scatter;
   a.imgs_ready = scatter && imgs_ready;
+  if (span_slot >= 0) { a.want_spans = true; a.span_slot = span_slot; }
+  cx.prof = prof;
   int rc = run_step(cx, a);
   if (rc) return rc;
   const int nrc = g_rccl.AllReduce(grads, grads, (size_t)L.P_pad + GMVAE_TAIL, /*ncclFloat*/ 7, /*ncclSum*/ 0, comm, st);
@@ -2713,11 +2727,40 @@ static int dp_step_impl(const GmvaeDims* dims, int model, const uint8_t* x, floa
     return adam_tf_step(params, m, v, grads, L.P_pad, lr, beta1, beta2, epsilon, 0, step_dev, 1.f, grads + L.P_pad + 4,
                         grads + L.P_pad, st);
   }
+  if (mega2_ok(*dims, model) && w.img2f && !getenv("GMVAE_NO_ADAM_TILES")) {
+    // at mega2's sizes every parameter is a tile of one of the step's weight tensors: the optimizer in tile shape (mega3.hpp)
+    std::vector<DwArgs> da_store(1);
+    DwArgs& da = da_store[0];
+    memset(&da, 0, sizeof(da));
+    dw_tensors(*dims, model, L, w, x, pl, da);
+    if (da.ntens <= kM3MaxT && da.total_tiles <= kM3MaxSlots) {
+      std::vector<AdamTilesArgs> at_store(1);
+      AdamTilesArgs& at = at_store[0];
+      memset(&at, 0, sizeof(at));
+      at.ntens = da.ntens; at.total_tiles = da.total_tiles;
+      for (int i = 0; i < da.ntens; ++i) {
+        at.t[i] = da.t[i];
+        const int nt_i = (i + 1 < da.ntens ? da.t[i + 1].tile_begin : da.total_tiles) - da.t[i].tile_begin;
+        for (int t = 0; t < nt_i; ++t) at.perm[da.t[i].tile_begin + t] = (unsigned short)((i << 10) | t);
+      }
+      at.grads = grads; at.p = params; at.m = m; at.v = v; at.lr = lr; at.b1 = beta1; at.b2 = beta2; at.eps = epsilon;
+      at.t_dev = reinterpret_cast<const unsigned long long*>(step_dev);
+      at.gscale_dev = grads + L.P_pad + 4; at.loss_sum_dev = grads + L.P_pad; at.tail_log = tail_log;
+      at.img[0] = w.img_m; at.img[1] = w.dimg; at.img[2] = w.img2f; at.img[3] = w.img2b; at.img[4] = w.dimg2;
+      at.epoch_word = w.sync; at.lr_dev = w.sync + 4;
+      if (span_slot >= 0 && w.spans) at.span = w.spans + (size_t)span_slot * 3 * 2048 * 2 + 2 * 2048 * 2;
+      (void)hipGetLastError();
+      hipLaunchKernelGGL(adam_tiles, dim3((unsigned)da.total_tiles), dim3(256), 0, st, at);
+      return (int)hipGetLastError();
+    }
+  }
   ImgScatter sc;
   memset(&sc, 0, sizeof(sc));
   sc.nmap = pl.nmap; sc.lo = pl.lo; sc.hi = pl.hi; sc.epoch_word = w.sync;
   sc.img[0] = w.img_m; sc.img[1] = w.dimg; sc.img[2] = w.img2f; sc.img[3] = w.img2b; sc.img[4] = w.dimg2;
   for (int i = 0; i < pl.nmap; ++i) { sc.map[i] = pl.map[i]; sc.mbegin[i] = pl.map[i].begin; sc.mend[i] = pl.map[i].end; }
+  if (span_slot >= 0 && w.spans) sc.span = w.spans + (size_t)span_slot * 3 * 2048 * 2 + 2 * 2048 * 2;     // (the third kernel's region of the slot)
+  sc.lr_dev = w.sync + 4;
   (void)hipGetLastError();
   hipLaunchKernelGGL(adam_tf_img, dim3((unsigned)((L.P_pad / 4 + 255) / 256)), dim3(256), 0, st, params, m, v, grads,
                      (long long)L.P_pad, lr, beta1, beta2, epsilon, step_dev, grads + L.P_pad + 4, grads + L.P_pad, tail_log, sc);
@@ -2729,6 +2772,90 @@ int gmvae_dp_step(const GmvaeDims* dims, int model, const uint8_t* x, float* par
                   float beta2, float epsilon, void* comm, void* stream) {
   return dp_step_impl(dims, model, x, params, m, v, grads, workspace, seed, step_dev, lr, beta1, beta2, epsilon, comm,
                       static_cast<hipStream_t>(stream), false, false);
+}
+
+/* measurement hook (bench.py --config configs3_dp1, and every rank of bench.py --gpus N): the data-parallel step's timeline.
+ * Three consecutive steps in ONE captured graph (RCCL node included), replayed `iters` times; the launches of steps 2 and 3
+ * stamp the device wall clock (100 MHz, one clock for the device).  out[0] in-kernel span of the gradient launch(es) of a
+ * step (first workgroup start -> last workgroup end); out[1] = that end -> first block start of the Adam launch: the
+ * all-reduce window (the RCCL node and the two launch boundaries around it); out[2] span of the Adam launch; out[3] its end ->
+ * the NEXT step's first workgroup start; out[4] the step: first workgroup start -> the next step's.  Microseconds, means.
+ * COLLECTIVE: every rank of the communicator must call it with the same `iters`. */
+int gmvae_dp_profile(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v, float* grads,
+                     void* workspace, uint64_t seed, uint64_t* step_dev, float lr, void* comm, int iters, float* out,
+                     int max_levels, int* n_levels, char* names, void* stream) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!x || !params || !m || !v || !grads || !workspace || !step_dev || !comm || !out) return GMVAE_E_NULL;
+  if (iters < 1) return GMVAE_E_DIMS;
+  if (!mega_ok(*dims, model)) return GMVAE_E_DIMS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Layout L;
+  build_layout(*dims, model, L);
+  WS w;
+  carve(*dims, model, L, workspace, w);
+  if (!w.spans) return GMVAE_E_DIMS;
+  hipStream_t cs = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  Prof* pr = new Prof();
+  pr->events = false;
+  int rc = 0;
+  if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { delete pr; return (int)hipGetLastError(); }
+  rc = g_rccl.AllReduce(grads, grads, (size_t)L.P_pad + GMVAE_TAIL, 7, 0, comm, cs) ? 1000 : 0;      // (channel set-up outside capture)
+  hipStreamSynchronize(cs);
+  if (rc == 0 && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = (int)hipGetLastError();
+  if (rc == 0) {
+    for (int it = 0; it < 3 && rc == 0; ++it) {
+      if (it < 2) pr->n = 0;
+      pr->active = it == 1;
+      rc = dp_step_impl(dims, model, x, params, m, v, grads, workspace, seed, step_dev, lr, 0.9f, 0.999f, 1e-8f, comm, cs, true,
+                        it > 0, nullptr, it == 0 ? -1 : it - 1, pr);
+    }
+    const hipError_t he = hipStreamEndCapture(cs, &graph);
+    if (rc == 0 && he != hipSuccess) rc = (int)he;
+  }
+  if (rc == 0 && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = (int)hipGetLastError();
+  const size_t nsp = 2 * 3 * 2048 * 2, slot = 3 * 2048 * 2;
+  unsigned long long* hsp = new unsigned long long[nsp];
+  double acc[5] = {0, 0, 0, 0, 0};
+  int good = 0;
+  for (int it = 0; it < iters && rc == 0; ++it) {
+    hipMemsetAsync(w.spans, 0, nsp * 8, st);
+    if (hipGraphLaunch(exec, st) != hipSuccess) { rc = (int)hipGetLastError(); break; }
+    hipStreamSynchronize(st);
+    hipMemcpy(hsp, w.spans, nsp * 8, hipMemcpyDeviceToHost);
+    unsigned long long lo[2] = {~0ull, ~0ull}, hi[2] = {0, 0};
+    for (int sl = 0; sl < 2; ++sl)
+      for (int k = 0; k < 2; ++k)                 // the per-row launch and (two-launch form) the weight-gradient launch
+        for (int b = 0; b < 2048; ++b) {
+          const unsigned long long s0 = hsp[sl * slot + (size_t)k * 2048 * 2 + 2 * b], s1 = hsp[sl * slot + (size_t)k * 2048 * 2 + 2 * b + 1];
+          if (!s0 || !s1) continue;
+          lo[sl] = s0 < lo[sl] ? s0 : lo[sl];
+          hi[sl] = s1 > hi[sl] ? s1 : hi[sl];
+        }
+    const unsigned long long a0r = hsp[2 * 2048 * 2], a1 = hsp[2 * 2048 * 2 + 1];
+    if (!a0r || !a1 || hi[0] <= lo[0] || lo[1] == ~0ull) continue;
+    const unsigned long long a0 = (1ull << 62) - a0r;
+    acc[0] += (double)(hi[0] - lo[0]) * 0.01;
+    acc[1] += (double)(a0 - hi[0]) * 0.01;
+    acc[2] += (double)(a1 - a0) * 0.01;
+    acc[3] += (double)(lo[1] - a1) * 0.01;
+    acc[4] += (double)(lo[1] - lo[0]) * 0.01;
+    ++good;
+  }
+  delete[] hsp;
+  for (int i = 0; i < 5; ++i) out[i] = good ? (float)(acc[i] / good) : 0.f;
+  if (n_levels && names) {
+    const int n = pr->n < max_levels ? pr->n : max_levels;
+    *n_levels = n;
+    for (int i = 0; i < n; ++i) memcpy(names + (size_t)i * 48, pr->name[i], 48);
+  }
+  if (exec) hipGraphExecDestroy(exec);
+  if (graph) hipGraphDestroy(graph);
+  if (cs) hipStreamDestroy(cs);
+  delete pr;
+  (void)hipGetLastError();
+  return rc ? rc : (good ? 0 : GMVAE_E_DIMS);
 }
 
 /* the same step captured once into a hipGraph (RCCL kernels included); replay with gmvae_train_graph_launch */

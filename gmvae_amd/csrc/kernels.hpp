@@ -986,10 +986,15 @@ __global__ __launch_bounds__(256) void finalize_adam(const FinalArgs a) {
 
 // TF-Adam after the data-parallel all-reduce, with finalize_adam's image scatter: the updated parameters also go to
 // their positions in the next step's weight images (so that step can run its first layer inside mega_fwd_bwd).
+__host__ __device__ inline unsigned alpha_key(const float b1, const float b2) {      // tag of a cached alpha_t: the moments' rates
+  return __builtin_bit_cast(unsigned, b1) * 2654435761u ^ __builtin_bit_cast(unsigned, b2);
+}
 struct ImgScatter {
   int nmap, lo, hi;
   float* img[kImgBufs];
   unsigned* epoch_word;
+  const unsigned* lr_dev;     // {alpha_t bits, the Adam step t it is for, lr bits, alpha_key} left by mega3_step's tail slot (mega3.hpp), or null
+  unsigned long long* span;   // measurement (gmvae_dp_profile): [0] = 2^62 - the earliest block start, [1] = the latest block end (100 MHz wall clock), or null
   int mbegin[kMaxImgMap], mend[kMaxImgMap];
   ImgMap map[kMaxImgMap];
 };
@@ -997,12 +1002,20 @@ __global__ __launch_bounds__(256) void adam_tf_img(float* __restrict__ p, float*
                                                    const float* __restrict__ g, long long P, float lr, float b1, float b2,
                                                    float eps, const uint64_t* t_dev, const float* gscale_dev,
                                                    const float* loss_sum_dev, float* tail_log, const ImgScatter sc) {
+  if (sc.span && threadIdx.x == 0) atomicMax(sc.span, (1ull << 62) - wall_clock64());
+  struct SpanEnd {                               // (every exit path of the block stamps its end)
+    unsigned long long* p;
+    __device__ ~SpanEnd() { if (p && threadIdx.x == 0) atomicMax(p + 1, wall_clock64()); }
+  } span_end{sc.span};
   if (blockIdx.x == 0 && threadIdx.x == 0 && sc.epoch_word) *sc.epoch_word += 1u;
   if (blockIdx.x == 0 && threadIdx.x < 8 && tail_log && loss_sum_dev) tail_log[threadIdx.x] = loss_sum_dev[threadIdx.x];   // the all-reduced tail
   if (loss_sum_dev && !__builtin_isfinite(*loss_sum_dev)) return;   // poisoned step: keep params, m, v and the images
   const unsigned long long t = *t_dev;
   const float gscale = 1.f / *gscale_dev;
-  const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+  float lr_t;
+  if (sc.lr_dev && sc.lr_dev[1] == (unsigned)t && sc.lr_dev[2] == __float_as_uint(lr) && sc.lr_dev[3] == alpha_key(b1, b2))
+    lr_t = __uint_as_float(sc.lr_dev[0]);                      // (the same fp64 form, computed once by mega3_step's tail slot)
+  else lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
   const float omb1 = 1.f - b1, omb2 = 1.f - b2;
   const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= P) return;                                        // P is the padded parameter count: a multiple of 4

@@ -72,7 +72,7 @@ struct M3Args {
   MegaArgs m;
   int ntens, total_slots;
   unsigned* flags;             // [4][kM3FlagLd] per-workgroup epoch tags
-  unsigned* lr_next;           // [2]: {alpha_t bits, the Adam step t it is for}: left by the previous step's tail slot
+  unsigned* lr_next;           // [4]: {alpha_t bits, the Adam step t it is for, lr bits, alpha_key(b1, b2)}: left by the previous step's tail slot
   unsigned long long* dbg;     // diagnostic: [workgroup][8] wall-clock stamps of the worker phase (tools/m3stamps.py) or null
   unsigned short perm[kM3MaxSlots];   // slot -> (tensor << 10) | tile inside the tensor (| kM3PhaseF); kM3Tail: the loss tail
   DwTensor t[kM3MaxT];
@@ -102,9 +102,14 @@ __device__ __forceinline__ void m3_tail(const M3Fin& a, unsigned long long* step
     }
     red[t] = a0; red[256 + t] = a1; red[512 + t] = a2; red[768 + t] = a3;
   }
-  if (t == 256 && a.do_adam) {                   // the NEXT step's alpha_t, tagged with that step's index
-    lr_next[0] = __float_as_uint(m3_alpha(a, step + 2ull));
-    lr_next[1] = (unsigned)(step + 2ull);        // (Adam's t of that step: never 0, the workspace's initial value)
+  if (t == 256) {
+    // alpha_t for whoever applies the next update, tagged with its Adam step t (never 0, the workspace's initial value): the
+    // NEXT step's tiles (single device), or -- gradients only -- THIS step's adam_tf_img behind the all-reduce
+    const unsigned long long tt = a.do_adam ? step + 2ull : step + 1ull;
+    lr_next[0] = __float_as_uint(m3_alpha(a, tt));
+    lr_next[1] = (unsigned)tt;
+    lr_next[2] = __float_as_uint(a.lr);          // (a step counter may be rewound and the rate changed: the tag names both)
+    lr_next[3] = alpha_key(a.b1, a.b2);
   }
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -133,7 +138,9 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
   const unsigned epoch = *a.epoch_word;
   const unsigned long long step = a.step_dev[0];
   const unsigned spin_limit = *a.err_word ? 0u : (1u << 19);
-  const unsigned lr_bits = aa.lr_next[0], lr_tag = aa.lr_next[1];
+  const unsigned lr_bits = aa.lr_next[0];
+  const bool lr_hit = aa.lr_next[1] == (unsigned)(a.step_dev[0] + 1ull) && aa.lr_next[2] == __float_as_uint(aa.fa.lr) &&
+                      aa.lr_next[3] == alpha_key(aa.fa.b1, aa.fa.b2);
   if (aa.dbg && threadIdx.x == 0) aa.dbg[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
   const int role = mega2_body<1>(a, sm);
 #define M3_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
   const bool upd = fa.do_adam != 0;
   // alpha_t: the previous step's tail slot left it (tagged with this step's index); the first step of a launch computes it
   float lr_t = __uint_as_float(lr_bits);
-  if (upd && lr_tag != (unsigned)(step + 1ull)) lr_t = m3_alpha(fa, step + 1ull);
+  if (upd && !lr_hit) lr_t = m3_alpha(fa, step + 1ull);
   M3_ST2(2);
   const float omb1 = 1.f - fa.b1, omb2 = 1.f - fa.b2, gs = 1.f / fa.count;
   unsigned seen = 0;                             // (uniform) bit 0: the producers' flags seen; bit 1: the leads'
@@ -351,6 +358,101 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
 #undef M3_END
 #undef M3_ST
 #undef M3_ST2
+}
+
+// adam_tiles: the data-parallel step's optimizer launch behind the all-reduce (scripts/runners.py:183 apply_gradients, scaled by
+// the all-reduced row count) in the TILE shape of mega3_step's epilogue: a workgroup owns one [16 MU x 16] tile of a weight
+// tensor (+ its bias columns on the first tile row); gradients, parameters and moments move as lane-contiguous accesses and
+// the updated values leave for the next step's operand images as 16-byte units -- the generic adam_tf_img (kernels.hpp) walks
+// the flat buffer and scatters element by element through a 15-entry map: 7.5 us in-kernel against this launch's ~3.
+// Same update statement (adam_update), same alpha_t, same scale: bit-identical parameters.
+struct AdamTilesArgs {
+  int ntens, total_tiles;
+  unsigned short perm[kM3MaxSlots];
+  DwTensor t[kM3MaxT];
+  float *grads, *p, *m, *v;
+  float lr, b1, b2, eps;
+  const unsigned long long* t_dev;     // Adam's t of this step (the gradient launch's tail slot already advanced the counter)
+  const float* gscale_dev;             // the all-reduced row count
+  const float* loss_sum_dev;           // the all-reduced loss sum: non-finite = a poisoned step on some rank, nothing is applied
+  float* tail_log;
+  float* img[kImgBufs];
+  unsigned* epoch_word;
+  const unsigned* lr_dev;
+  unsigned long long* span;
+};
+static_assert(sizeof(AdamTilesArgs) <= 4096, "kernel arguments");
+
+__global__ __launch_bounds__(256) void adam_tiles(const AdamTilesArgs a) {
+  if (a.span && threadIdx.x == 0) atomicMax(a.span, (1ull << 62) - wall_clock64());
+  struct SpanEnd {
+    unsigned long long* p;
+    __device__ ~SpanEnd() { if (p && threadIdx.x == 0) atomicMax(p + 1, wall_clock64()); }
+  } span_end{a.span};
+  const int tid = threadIdx.x, bid = blockIdx.x;
+  if (bid == 0 && tid == 0 && a.epoch_word) *a.epoch_word += 1u;
+  if (bid == 0 && tid < 8 && a.tail_log) a.tail_log[tid] = a.loss_sum_dev[tid];       // the all-reduced tail
+  if (bid >= a.total_tiles) return;
+  const int pv_ = a.perm[bid];
+  const int ti = (pv_ & 0x7fff) >> 10, tl = pv_ & 1023;
+  const DwTensor& T = a.t[ti];
+  const int M = T.M, N = T.N, MUr = T.mu;
+  const int tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
+  const int m0 = tm * 16 * MUr, n0 = tn * 16;
+  const int el = tid & 63, eu = (tid >> 6) & 3;
+  const int mb = m0 + 4 * MUr * (el >> 4) + 4 * eu, en = n0 + (el & 15);
+  const bool eown = tid < 64 * MUr && mb < M && en < N;
+  // (the bias columns: threads 240..255 -- free at every tile height)
+  const bool bown = tm == 0 && T.b_off >= 0 && tid >= 240 && n0 + (tid - 240) < N;
+  float pp[4] = {0.f, 0.f, 0.f, 0.f}, pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
+  float bp = 0.f, bm = 0.f, bv = 0.f, bg = 0.f;
+  if (eown) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int mm = min(mb + j, M - 1);
+      const long long i = (long long)T.w_off + (long long)mm * N + en;
+      pp[j] = a.p[i]; pm[j] = a.m[i]; pv[j] = a.v[i]; g[j] = a.grads[i];
+    }
+  }
+  if (bown) { const int i = T.b_off + n0 + tid - 240; bp = a.p[i]; bm = a.m[i]; bv = a.v[i]; bg = a.grads[i]; }
+  if (!__builtin_isfinite(*a.loss_sum_dev)) return;            // poisoned step: keep params, m, v and the images
+  const unsigned long long t = *a.t_dev;
+  const float gs = 1.f / *a.gscale_dev;
+  float lr_t;
+  if (a.lr_dev && a.lr_dev[1] == (unsigned)t && a.lr_dev[2] == __float_as_uint(a.lr) && a.lr_dev[3] == alpha_key(a.b1, a.b2))
+    lr_t = __uint_as_float(a.lr_dev[0]);
+  else lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, (double)t)) / (1.0 - pow((double)a.b1, (double)t)));
+  const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2;
+  if (eown) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (mb + j < M) {
+        const long long i = (long long)T.w_off + (long long)(mb + j) * N + en;
+        adam_update(pp[j], pm[j], pv[j], g[j], gs, lr_t, omb1, omb2, a.eps);
+        a.p[i] = pp[j]; a.m[i] = pm[j]; a.v[i] = pv[j];
+      } else {
+        pp[j] = 0.f;                               // rows past the tensor: the image's padding stays zero
+      }
+    }
+    if (T.k1 == 2 || T.k1 == 4 || T.k1 == 7)
+      *reinterpret_cast<float4*>(a.img[T.which1] + img_dst(T.k1, T.base1, T.ld1, T.chunk1, mb, en)) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    else if (T.k1 >= 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (mb + j < M) a.img[T.which1][img_dst(T.k1, T.base1, T.ld1, T.chunk1, mb + j, en)] = pp[j];
+    }
+    if (T.k2 >= 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (mb + j < M) a.img[T.which2][img_dst(T.k2, T.base2, T.ld2, T.chunk2, mb + j, en)] = pp[j];
+    }
+  }
+  if (bown) {
+    const int c = tid - 240, i = T.b_off + n0 + c;
+    adam_update(bp, bm, bv, bg, gs, lr_t, omb1, omb2, a.eps);
+    a.p[i] = bp; a.m[i] = bm; a.v[i] = bv;
+    if (T.bk >= 0) a.img[T.bwhich][img_dst(T.bk, T.bbase, 0, T.bchunk, 0, n0 + c)] = bp;
+  }
 }
 
 }  // namespace gmvae

@@ -575,6 +575,25 @@ class Engine:
             out.append((nm, float(usec[i]), float(flops[i]), float(usec_tl[i])))
         return out
 
+    def profile_dp_step(self, x, lr: float = 1e-3, iters: int = 10):
+        """gmvae_dp_profile: the data-parallel step's timeline with this engine's RCCL communicator (enable_rccl first; a
+        one-rank communicator is allowed).  COLLECTIVE: every rank calls it with the same `iters`.  Returns a dict of
+        microseconds: grad_span, allreduce_window, adam_span, gap_to_next_step, step; and the gradient launches' names."""
+        if not getattr(self, "_comm", None):
+            raise L.GmvaeError("profile_dp_step needs enable_rccl()")
+        x = self._prep_x(x)
+        d, ws = self._workspace(x.shape[0])
+        out = (C.c_float * 8)()
+        n = C.c_int(0)
+        names = C.create_string_buffer(16 * 48)
+        rc = L.lib.gmvae_dp_profile(C.byref(d), self.model, L.ptr(x), L.ptr(self.params), L.ptr(self.m), L.ptr(self.v),
+                                    L.ptr(self.grads), L.ptr(ws), self.noise_seed, L.ptr(self.step_dev), lr, self._comm, iters,
+                                    out, 16, C.byref(n), names, L.current_stream())
+        L.check(rc, "gmvae_dp_profile")
+        self.global_step = int(self.step_dev[0].item())
+        return {"grad_span": out[0], "allreduce_window": out[1], "adam_span": out[2], "gap_to_next_step": out[3], "step": out[4],
+                "grad_launches": [names.raw[i * 48:(i + 1) * 48].split(b"\0")[0].decode() for i in range(n.value)]}
+
     def profile_levels(self, x, iters: int = 20):
         """Per-launch timing of the step with hipEvents (gmvae_step_profile)."""
         x = self._prep_x(x)

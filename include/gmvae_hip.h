@@ -225,6 +225,15 @@ int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, floa
                         float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, int iters,
                         int max_levels, int* n_levels, char* names, float* usec, float* usec_timeline, double* flops,
                         void* stream);
+/* The data-parallel step's timeline (scripts/runners.py:231-232 has no counterpart: the reference is single-device; SURVEY.md
+ * 8(e)): three consecutive steps of gmvae_dp_graph_create's graph (RCCL all-reduce node included) in ONE graph, replayed
+ * `iters` times; the launches of steps 2 and 3 stamp the device wall clock.  out[5], microseconds, means: [0] in-kernel span of
+ * a step's gradient launch(es); [1] their last workgroup's end -> first block of the Adam launch (the all-reduce window: the
+ * RCCL node and the launch boundaries around it); [2] span of the Adam launch; [3] its end -> the next step's first workgroup;
+ * [4] the step.  names / n_levels (may be NULL): the gradient launches' names.  COLLECTIVE over `comm`: same iters on every rank. */
+int gmvae_dp_profile(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v, float* grads,
+                     void* workspace, uint64_t seed, uint64_t* step_dev, float lr, void* comm, int iters, float* out,
+                     int max_levels, int* n_levels, char* names, void* stream);
 int gmvae_step_profile(const GmvaeDims* dims, int model, const uint8_t* x, const float* eps, const float* u,
                        const float* params, float* grads, void* workspace, uint64_t seed, int iters,
                        int max_levels, int* n_levels, char* names, float* usec, double* flops, void* stream);
