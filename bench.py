@@ -41,6 +41,10 @@ CONFIGS = {
     # one rank's step of BASELINE configs[3] (1024 rows per GPU) on the DATA-PARALLEL path with a one-rank RCCL communicator:
     # gradients -> RCCL all-reduce node inside the hipGraph (an identity copy here) -> TF-Adam scaled by 1/count.  What the
     # path costs before a byte crosses xGMI; `--gpus N` runs the same path with N ranks.
+    # the forward-only evaluation of BASELINE.json's metric: the -log p(x) importance-weighted bound at S = 50 samples per row
+    # on configs[2]'s model and batch (scripts/runners.py:324-333 reuses the model's loss for evaluation): 51,200 sample rows
+    "eval_iwae": dict(model="gmvae", batch=1024, latent=64, components=10, hidden=64, layers=1, data_dim=784, n_samples=50,
+                      eval_only=True),
     "configs3_dp1": dict(model="gmvae", batch=1024, latent=64, components=10, hidden=64, layers=1, data_dim=784, n_samples=1,
                          dp_world1=True),
 }
@@ -52,7 +56,7 @@ def workload_name(a, n_gpus):
     if getattr(a, "dp_world1", False) and n_gpus == 1:
         return "one rank of BASELINE configs[3] on the data-parallel path (one-rank RCCL communicator)"
     for name, c in CONFIGS.items():
-        if {k: v for k, v in c.items() if k != "dp_world1"} == key:
+        if {k: v for k, v in c.items() if k not in ("dp_world1", "eval_only")} == key and not c.get("eval_only"):
             if name == "configs2":
                 return "BASELINE configs[2]" if n_gpus == 1 else f"BASELINE configs[3] shape: 1024 rows per GPU x {n_gpus}"
             return {"configs0": "BASELINE configs[0]", "configs1": "BASELINE configs[1]",
@@ -182,8 +186,118 @@ def cpu_parity(model: str, dims: dict, flat0, x_np, eps_np, u_np):
     return float(-C64["loss"])
 
 
+def flops_forward(model: str, D: int, L: int, K: int, hidden, S: int, B: int) -> float:
+    """2 * forward MACs of one evaluation: the layers over x once per batch row, everything else per sample row."""
+    def mac(n_in, n_out):
+        dims = [n_in] + list(hidden) + [n_out]
+        return sum(p * q for p, q in zip(dims[:-1], dims[1:]))
+    h0 = hidden[0]
+    if model == "gmvae":
+        per_row = mac(D, K) + D * h0                         # encoder_y, and encoder_gmm's x rows of its first layer
+        per_sample = K * 2 * L + (mac(D + K, 2 * L) - D * h0) + mac(L, D)
+    else:
+        per_row, per_sample = mac(D, 2 * L), mac(L, D)
+    return 2.0 * B * (per_row + S * per_sample)
+
+
+def main_eval(a):
+    """--config eval_iwae: throughput of the forward-only -log p(x) bound (gmvae_forward, S importance samples per row, in-kernel
+    Philox noise) -- ONE JSON line with the same keys as the training line; a "step" is one evaluation pass over the batch."""
+    import torch
+    from gmvae_amd.engine import Engine
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if a.gpus != 1:
+        raise SystemExit("bench.py --config eval_iwae: evaluation batches are independent -- run one process per GPU (replicas only)")
+    torch.cuda.set_device(0)
+    hidden = [a.hidden] * a.layers
+    K = a.components if a.model != "vae" else 1
+    S, B, D, Lz = a.n_samples, a.batch, a.data_dim, a.latent
+    dims = dict(D=D, L=Lz, K=K, hidden=tuple(hidden), S=S)
+    eng = Engine(a.model, D, Lz, K, hidden, n_samples=S, random_seed=0)
+    x_np = (np.random.default_rng(1234).random((B, D)) < 0.87).astype(np.uint8)
+    x = torch.from_numpy(x_np).cuda()
+    flat0 = eng.params.detach().cpu().numpy()
+    # ---- parity: the bound on a seeded batch of <= 256 rows, HIP forward vs the fp64 oracle on identical (x, eps, u)
+    tiny = float(np.finfo(np.float32).tiny)
+    B_iw = max(8, min(256, B, int(2e7 // (D * S))))
+    rn = np.random.default_rng(4242)
+    eps_iw = rn.standard_normal((B_iw * S, Lz)).astype(np.float32)
+    u_iw = None
+    if a.model == "gmvae":
+        u_iw = np.clip(rn.uniform(tiny, 1.0, (B_iw * S, K)).astype(np.float32), tiny, np.nextafter(np.float32(1), np.float32(0)))
+    fw = eng.forward(x[:B_iw], torch.from_numpy(eps_iw), None if u_iw is None else torch.from_numpy(u_iw), n_samples=S)
+    torch.cuda.synchronize()
+    t_iw = fw["tail"].cpu().numpy().astype(np.float64)
+    iw_hip = float(t_iw[0] / t_iw[4])
+    iw_cpu = -cpu_parity(a.model, dims, flat0, x_np[:B_iw], eps_iw, u_iw)
+    parity = {"neg_log_px_bound_hip": iw_hip, "neg_log_px_bound_cpu_fp64": iw_cpu, "n_samples": S, "rows": B_iw,
+              "rel_err": float(abs(iw_hip - iw_cpu) / abs(iw_cpu))}
+    # ---- timing: W + K passes of ONE captured forward replayed back to back (HIP events on the launch stream)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.75:                 # (DVFS: the host-side oracle above let the clocks drop)
+        eng.profile_forward(x, n_samples=S, iters=20)
+    eng.profile_forward(x, n_samples=S, iters=max(1, a.warmup))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    levels, us_total, tail = eng.profile_forward(x, n_samples=S, iters=a.steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0                           # (includes the per-launch pass: not the figure of merit)
+    dt_ms = us_total * 1e-3
+    value = B * S / (us_total * 1e-6)
+    fl_alg = flops_forward(a.model, D, Lz, K, hidden, S, B)
+    gem = [l for l in levels if l[2] > 0]
+    dom = max(gem, key=lambda l: l[1])
+    from gmvae_amd import _lib as LIB
+    roof = {"bound": "mfma", "kernel": dom[0] if dom[0].startswith(("mega", "sk_", "dw_", "rows_", "first_")) else f"gemm_grouped<{dom[0]}>",
+            "achieved": dom[2] / dom[1] * 1e-6, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom[2] / dom[1] * 1e-6 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "usec_per_launch": dom[1], "flops_per_launch": dom[2],
+            "timing": "per launch: hipEvents around eager launches (mean); the pass: one captured forward replayed back to back",
+            "step_flops_alg": fl_alg, "step_tflops_alg": fl_alg / us_total * 1e-6,
+            "step_frac_of_mfma_peak": fl_alg / us_total * 1e-6 / PEAK_F32_MFMA_TFLOPS,
+            "step_flops_executed": sum(l[2] for l in levels), "launches_per_step": len(levels),
+            "sum_launch_usec": sum(l[1] for l in levels),
+            "levels": [[nm, round(us, 2), round(f / max(us, 1e-9) * 1e-6, 2)] for nm, us, f in levels],
+            "levels_columns": ["launch", "usec (events, eager)", "TFLOP/s"],
+            "schedule": LIB.step_schedule(eng.dims(B, S), eng.model) + " (forward only)"}
+    try:
+        import csv, glob
+        stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_eval_iwae_kernel_stats.csv")))
+        if stats:
+            roof["rocprof_source"] = os.path.relpath(stats[-1], ROOT)
+    except Exception:
+        pass
+    cpu = None
+    if not a.no_cpu_baseline:
+        import oracle as O
+        d_o = O.Dims(**dims)
+        mid = O.MODEL_NAMES[a.model]
+        pr32 = O.unpack(mid, d_o, flat0.astype(np.float32))
+        nb = B_iw
+        n_done, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < a.cpu_seconds or n_done == 0:
+            O.forward(mid, d_o, pr32, x_np[:nb], eps_iw, u_iw, np.float32)
+            n_done += 1
+        el = time.perf_counter() - t1
+        cpu = {"value": nb * S * n_done / el, "unit": "ELBO-samples/sec", "cores": "default BLAS threads", "kind": "port",
+               "sample": f"{n_done} forward passes of the fp32 NumPy/BLAS oracle over {nb} rows x {S} samples in {el:.1f} s"}
+    out = {"metric": "ELBO-samples/sec", "value": value, "unit": "samples/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": dt_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{a.model} forward-only -log p(x) IWAE bound (gmvae_forward, in-kernel Philox noise), D={D} K={K} "
+                                  f"L={Lz} hidden={hidden} S={S} samples per row, batch {B} = {B * S} sample rows "
+                                  f"(BASELINE.json metric's bound on configs[2]'s model)",
+                      "global_batch": B, "parallelism": "dp1", "hipgraph": True},
+           "host_wall_seconds_of_the_profile_call": wall,
+           "neg_log_px_bound_of_the_timed_batch": float(tail[0].item() / max(tail[4].item(), 1.0)),
+           "roofline": roof, "cpu_baseline": cpu, "parity": {"iwae_bound": parity}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
+    if getattr(a, "eval_only", False):
+        return main_eval(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -532,10 +646,31 @@ def main():
                          "frac": w_bytes / dur(dom) * 1e-3 / PEAK_HBM_GBS, "bytes_per_launch": w_bytes,
                          "frac_in_kernel_span": w_bytes / dom[1] * 1e-3 / PEAK_HBM_GBS})
         if schedule == "skinny" and B > 128 and roof["bound"] == "mfma":
-            # above 128 rows the skinny schedule's large products run as exact bf16 piece products (skinny.hpp: the uint8
-            # operand's 3 per fp32 product, fp32 x fp32 6): `frac` stays fp32-EQUIVALENT FLOP/s over the fp32 MFMA peak
-            roof["peak_note"] = ("fp32-equivalent FLOP/s against the fp32 MFMA peak; the launch multiplies exact bf16 pieces "
-                                 "(3 piece products per product with the uint8 operand, 6 for fp32 x fp32) on the bf16 pipes")
+            # Above 128 rows the skinny schedule's large products run as exact bf16 piece products on the bf16 pipes (skinny.hpp:
+            # 3 piece products per product with the uint8 operand, 6 for fp32 x fp32): such a launch is priced against the peak
+            # of the instruction it issues -- dense bf16 peak / (piece products per product, FLOP-weighted over the launch's
+            # tensors) in fp32-equivalent FLOP/s, as the plane launches above -- with the fp32-MFMA fraction carried beside it.
+            h0 = hidden[0]
+            pieces = None
+            if dom[0] in ("sk_first_layers", "sk_first_layer"):
+                pieces, why = 3.0, "the uint8 batch is exact in bf16: 3 piece products per product"
+            elif dom[0] in ("sk_dec_bernoulli", "sk_bwd_dhd") and -(-d.D // 64) * -(-B // 16) >= 256:
+                pieces, why = 6.0, "fp32 x fp32: 6 piece products per product (64-column form)"
+            elif dom[0].startswith("sk_dw"):
+                gmv = a.model == "gmvae"
+                f_u8 = 2.0 * B * d.D * h0 * (2 if gmv else 1)                     # x^T dY: encoder(_y) and, GMVAE, encoder_gmm's x rows
+                f_all = dom[2]
+                pieces = (3.0 * f_u8 + 6.0 * max(f_all - f_u8, 0.0)) / max(f_all, 1.0)
+                why = (f"FLOP-weighted over the launch's tensors: {f_u8 / f_all:.2f} of its FLOPs with the uint8 operand (3 piece "
+                       f"products per product), the rest fp32 x fp32 (6)")
+            if pieces:
+                pk = PEAK_BF16_MFMA_TFLOPS / pieces
+                roof.update({"frac_of_f32_mfma_peak": roof["frac"], "peak": pk, "frac": roof["achieved"] / pk,
+                             "frac_in_kernel_span": dom[2] / dom[1] * 1e-6 / pk, "piece_products_per_product": pieces,
+                             "peak_note": f"dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {pieces:.2f} piece products per "
+                                          f"fp32 product ({why}); fp32 accumulation; frac_of_f32_mfma_peak = the same FLOP/s over 157.3"})
+            else:
+                roof["peak_note"] = "this launch multiplies on the fp32 matrix instruction: fp32 MFMA peak"
         # Committed evidence of the same command (tools/profile_round.sh -> profiles/roundN_*): rocprofv3 --kernel-trace
         # --stats average per kernel, and HBM-side bytes per launch from separate --pmc passes (FETCH_SIZE x2 on gfx950 +
         # WRITE_SIZE; rocprofv3 --pmc cannot run inside this process).  Keyed by workload; the newest round present wins.

@@ -75,6 +75,7 @@ def _load():
         "gmvae_step_schedule": ([dp, i32, vp], i32),
         "gmvae_debug_sk_stamps": ([vp], i32),
         "gmvae_debug_sk_stamps_free": ([], i32),
+        "gmvae_forward_profile": ([dp, i32, vp, vp, vp, vp, u64, i32, i32, C.POINTER(i32), vp, vp, vp, vp, vp], i32),
         "gmvae_dp_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, vp, i32, vp, i32, C.POINTER(i32), vp, vp], i32),
         "gmvae_train_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, i32, i32, C.POINTER(i32), vp, vp, vp, vp, vp], i32),
         "gmvae_step_profile": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, i32, i32, C.POINTER(i32), vp, vp, vp, vp], i32),

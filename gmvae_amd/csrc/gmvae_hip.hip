@@ -2296,6 +2296,81 @@ int gmvae_step_profile(const GmvaeDims* dims, int model, const uint8_t* x, const
   return rc;
 }
 
+/* measurement hook (bench.py --config eval_iwae): the FORWARD-ONLY evaluation (gmvae_forward with in-kernel Philox noise: the
+ * -log p(x) importance-weighted bound of scripts/runners.py:324-333 at dims->S samples).  Pass 1: `iters` eager forwards with
+ * hipEvents around every launch -> names, mean microseconds and algorithmic FLOPs per launch.  Pass 2: ONE forward captured
+ * into a hipGraph and replayed `iters` times back to back -> *usec_total = mean microseconds per forward (events around the
+ * whole train of replays). */
+int gmvae_forward_profile(const GmvaeDims* dims, int model, const uint8_t* x, const float* params, float* tail, void* workspace,
+                          uint64_t seed, int iters, int max_levels, int* n_levels, char* names, float* usec, double* flops,
+                          float* usec_total, void* stream) {
+  if (int e = check_dims(dims, model)) return e;
+  if (!x || !params || !tail || !workspace || !n_levels || !names || !usec || !flops || !usec_total) return GMVAE_E_NULL;
+  if (iters < 1) return GMVAE_E_DIMS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Prof* pr = new Prof();
+  for (int i = 0; i <= MAX_LEVELS; ++i) hipEventCreate(&pr->ev[i]);
+  double acc[MAX_LEVELS] = {0};
+  int rc = 0;
+  for (int it = 0; it < iters && rc == 0; ++it) {
+    Ctx cx;
+    cx.st = st;
+    cx.prof = pr;
+    pr->n = 0;
+    pr->active = true;
+    hipEventRecord(pr->ev[0], st);
+    StepArgs a = {dims, model, x, nullptr, nullptr, params, nullptr, tail, nullptr, nullptr, nullptr, nullptr, workspace, seed,
+                  (uint64_t)it, nullptr, false};
+    rc = run_step(cx, a);
+    hipStreamSynchronize(st);
+    for (int i = 0; i < pr->n; ++i) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, pr->ev[i], pr->ev[i + 1]);
+      acc[i] += ms * 1000.0;
+    }
+  }
+  const int n = pr->n < max_levels ? pr->n : max_levels;
+  *n_levels = n;
+  for (int i = 0; i < n; ++i) {
+    memcpy(names + (size_t)i * 48, pr->name[i], 48);
+    usec[i] = (float)(acc[i] / iters);
+    flops[i] = pr->flops[i];
+  }
+  *usec_total = 0.f;
+  if (rc == 0) {                                 // pass 2: the same launches back to back
+    hipStream_t cs = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      Ctx cx;
+      cx.st = cs;
+      StepArgs a = {dims, model, x, nullptr, nullptr, params, nullptr, tail, nullptr, nullptr, nullptr, nullptr, workspace, seed,
+                    0, nullptr, false};
+      const int r2 = run_step(cx, a);
+      ok = hipStreamEndCapture(cs, &graph) == hipSuccess && r2 == 0 && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    }
+    if (ok) {
+      for (int w_ = 0; w_ < 3; ++w_) hipGraphLaunch(exec, st);
+      hipEventRecord(pr->ev[0], st);
+      for (int it = 0; it < iters; ++it) hipGraphLaunch(exec, st);
+      hipEventRecord(pr->ev[1], st);
+      hipStreamSynchronize(st);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, pr->ev[0], pr->ev[1]);
+      *usec_total = ms * 1000.f / (float)iters;
+    }
+    if (exec) hipGraphExecDestroy(exec);
+    if (graph) hipGraphDestroy(graph);
+    if (cs) hipStreamDestroy(cs);
+    (void)hipGetLastError();
+  }
+  for (int i = 0; i <= MAX_LEVELS; ++i) hipEventDestroy(pr->ev[i]);
+  delete pr;
+  return rc;
+}
+
 int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
                         float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, int iters,
                         int max_levels, int* n_levels, char* names, float* usec, float* usec_timeline, double* flops,

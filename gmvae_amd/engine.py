@@ -575,6 +575,25 @@ class Engine:
             out.append((nm, float(usec[i]), float(flops[i]), float(usec_tl[i])))
         return out
 
+    def profile_forward(self, x, n_samples: Optional[int] = None, iters: int = 20):
+        """gmvae_forward_profile: the forward-only evaluation (in-kernel Philox noise) at n_samples importance samples.
+        Returns ([(launch, usec, flops)], usec per forward of a replayed hipGraph)."""
+        x = self._prep_x(x)
+        S = self.S if n_samples is None else int(n_samples)
+        d, ws = self._workspace(x.shape[0], S)
+        tail = torch.empty(L.TAIL, dtype=torch.float32, device=self.device)
+        n = C.c_int(0)
+        names = C.create_string_buffer(96 * 48)
+        usec = (C.c_float * 96)()
+        flops = (C.c_double * 96)()
+        total = C.c_float(0)
+        rc = L.lib.gmvae_forward_profile(C.byref(d), self.model, L.ptr(x), L.ptr(self.params), L.ptr(tail), L.ptr(ws),
+                                         self.noise_seed, iters, 96, C.byref(n), names, usec, flops, C.byref(total),
+                                         L.current_stream())
+        L.check(rc, "gmvae_forward_profile")
+        lev = [(names.raw[i * 48:(i + 1) * 48].split(b"\0")[0].decode(), usec[i], flops[i]) for i in range(n.value)]
+        return lev, total.value, tail
+
     def profile_dp_step(self, x, lr: float = 1e-3, iters: int = 10):
         """gmvae_dp_profile: the data-parallel step's timeline with this engine's RCCL communicator (enable_rccl first; a
         one-rank communicator is allowed).  COLLECTIVE: every rank calls it with the same `iters`.  Returns a dict of

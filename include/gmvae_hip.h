@@ -234,6 +234,12 @@ int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, floa
 int gmvae_dp_profile(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v, float* grads,
                      void* workspace, uint64_t seed, uint64_t* step_dev, float lr, void* comm, int iters, float* out,
                      int max_levels, int* n_levels, char* names, void* stream);
+/* The forward-only evaluation (gmvae_forward with in-kernel Philox noise; scripts/runners.py:324-333 reuses the model's loss
+ * for the -log p(x) bound) timed: per launch with hipEvents (names / usec / flops as gmvae_step_profile), and *usec_total =
+ * microseconds per forward when ONE captured forward is replayed `iters` times back to back. */
+int gmvae_forward_profile(const GmvaeDims* dims, int model, const uint8_t* x, const float* params, float* tail, void* workspace,
+                          uint64_t seed, int iters, int max_levels, int* n_levels, char* names, float* usec, double* flops,
+                          float* usec_total, void* stream);
 int gmvae_step_profile(const GmvaeDims* dims, int model, const uint8_t* x, const float* eps, const float* u,
                        const float* params, float* grads, void* workspace, uint64_t seed, int iters,
                        int max_levels, int* n_levels, char* names, float* usec, double* flops, void* stream);
