@@ -43,9 +43,19 @@ constexpr int kSkNs1 = 4;        // slabs of the skinny schedule's first layer (
 // GmvaeDims::sched_flags & GMVAE_SCHED_SAFE: the schedules in which no workgroup waits for another of its own launch
 // (one workgroup per panel, the first layer as a launch of its own) -- what a caller degrades to after a hand-off timeout
 static bool sched_safe(const GmvaeDims& d) { return (d.sched_flags & GMVAE_SCHED_SAFE) != 0; }
+// compute units of the CURRENT device (cached per device id; 256 on an unpartitioned MI355X): the hand-offs inside a launch
+// need every workgroup of the grid resident at once, one per CU
+static int device_cus() {
+  static int cu_of[64];
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev < 0 || dev >= 64) { hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }
+  if (!cu_of[dev]) { hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); cu_of[dev] = n > 0 ? n : 256; }
+  return cu_of[dev];
+}
 static int mega_q(const GmvaeDims& d) {
-  const int panels = (d.B + 15) / 16;
-  int q = panels * 4 <= 256 ? 4 : panels * 2 <= 256 ? 2 : 1;
+  const int panels = (d.B + 15) / 16, cus = device_cus();
+  int q = panels * 4 <= cus ? 4 : panels * 2 <= cus ? 2 : 1;
   const char* e = getenv("GMVAE_MEGA_Q");          // (tests / diagnostics)
   if (e && atoi(e) >= 1 && atoi(e) <= kMegaQMax) q = atoi(e);
   if (sched_safe(d)) q = 1;
@@ -208,7 +218,8 @@ typedef M2V<1, 64, 10> MV1;
 static bool mega2v_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_MEGA2");
   if (e && atoi(e)) return false;
-  return mega_ok(d, model) && mega2v_kind(d, model) != 0 && !sched_safe(d) && !getenv("GMVAE_MEGA_Q");
+  return mega_ok(d, model) && mega2v_kind(d, model) != 0 && (d.B + kPanel - 1) / kPanel * 7 <= device_cus() && !sched_safe(d) &&
+         !getenv("GMVAE_MEGA_Q");
 }
 // the skinny schedule (skinny.hpp): GMVAE, one WIDE hidden layer, a SMALL batch -- bin/run_train.sh's sizes
 constexpr int kSkMaxB = 4096;       // hard bound of the skinny schedule's batch (its buffers are carved up to here)
@@ -964,17 +975,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
   // The first launch (first layer as split-K partials + noise + weight images) is skipped when the previous step
   // of the same graph left the images behind (finalize_adam) and the launch below can run the first layer itself:
   // a panel's 4 workgroups must all be resident for their exchange, i.e. one workgroup per CU.
-  int n_cu = 0;
-  {                                             // (per device: a process may hold engines on several)
-    static int cu_of[64];
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    else {
-      if (!cu_of[dev]) hipDeviceGetAttribute(&cu_of[dev], hipDeviceAttributeMultiprocessorCount, dev);
-      n_cu = cu_of[dev];
-    }
-  }
+  const int n_cu = device_cus();
   const int vk = (mega2v_ok(d, model) && w.img2f) ? mega2v_kind(d, model) : 0;
   const int Qm = vk ? 7 : mega_q(d);
   const int np_grid = (!vk && mega2_ok(d, model)) ? (((B + kPanel - 1) / kPanel + 1) & ~1) : (B + kPanel - 1) / kPanel;   // (mega2 pairs panels)

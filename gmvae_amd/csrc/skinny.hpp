@@ -474,6 +474,8 @@ __device__ __forceinline__ void sk_nt(const float* __restrict__ A, const long lo
 // launch outputs leave write-through (mega2.hpp st4o): nothing waits dirty in L2 for the end-of-kernel write-back, which
 // at ten short launches per step is most of a step (measured: tools/micro/launch_floor.hip, profiles/round3_notes.md)
 // (st1o -- a 4-byte launch output, write-through -- lives in mega2.hpp)
+// ReLU that keeps a NaN (fmaxf(NaN, 0) is 0: a non-finite pre-activation would vanish from the loss the runner watches)
+__device__ __forceinline__ float relu_nan(const float v) { return !(v <= 0.f) ? v : 0.f; }
 
 __device__ __forceinline__ float sk_row16_sum(float v) {
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
@@ -1975,6 +1977,16 @@ __global__ __launch_bounds__(kDwcThreads, 3) void sk_dwc(const SkArgs a) {
   // ---- count this share in; the last one of the tile finishes it.  No fence (an agent-scope fence writes the L2 back: with two
   // per workgroup the launch took 133 us): the partials left as sc1 write-through stores, every wave waits for its own
   // (vmcnt(0)), ONE lane adds behind the barrier, and the finisher reads with sc1 loads (MI355X_MICROARCH.md, hand-off table row 1)
+  // The hardware contract this rests on (the same one as mega2.hpp's granules and mega3.hpp's flags; not a C++ release/acquire
+  // pair -- an acq_rel add at agent scope IS the two fences measured above):
+  //   * st4o / st1o are sc1 WRITE-THROUGH stores (asserted below: with -DM2_WT=0 they would sit dirty in this XCD's L2 and the
+  //     finisher on another XCD would read stale partials), and vmcnt counts such a store until the memory side has
+  //     acknowledged it -- so after s_waitcnt vmcnt(0) in every wave and the barrier, the share's partials are in memory;
+  //   * the counter add is performed at the memory side (agent scope: sc1), after that barrier in program order of the ONE lane
+  //     that issues it: the share that reads dw_ks - 1 finds every other share's add, hence its stores, complete;
+  //   * the finisher's sc1 loads are served from memory, never from another XCD's (or its own, older) L2 line.
+  // Nothing assumes which XCD a workgroup runs on.
+  static_assert(M2_WT == 1, "sk_dwc's last-arriver hand-off needs the partial tiles stored write-through (sc1)");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) lastf = __hip_atomic_fetch_add(a.dw_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.dw_ks - 1) ? 1 : 0;
@@ -2295,7 +2307,7 @@ __global__ __launch_bounds__(kSkThreads) void first_layers_u8bf(const FlxArgs a)
         *reinterpret_cast<float4*>(a.out1 + (long long)row * a.H1 + c0 + 4 * ec) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
         float4 o = make_float4(v[0] + bias.x, v[1] + bias.y, v[2] + bias.z, v[3] + bias.w);
-        if (a.relu0) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        if (a.relu0) o = make_float4(relu_nan(o.x), relu_nan(o.y), relu_nan(o.z), relu_nan(o.w));
         *reinterpret_cast<float4*>(a.out0 + (long long)row * a.H0 + c0 + 4 * ec) = o;
       }
     }
@@ -2386,7 +2398,7 @@ __global__ __launch_bounds__(kSkThreads) void rows_nn_bf6(const RowsArgs a) {
         const float4 q = *reinterpret_cast<const float4*>(P.addsrc + (long long)(row / P.add_div) * P.ld_add + nb);
         v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
       }
-      if (P.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      if (P.relu) { v[0] = relu_nan(v[0]); v[1] = relu_nan(v[1]); v[2] = relu_nan(v[2]); v[3] = relu_nan(v[3]); }
       *reinterpret_cast<float4*>(P.out + (long long)row * N + nb) = make_float4(v[0], v[1], v[2], v[3]);
       if (P.C3) {
         unsigned hi[2], mi[2], lo[2];

@@ -248,9 +248,14 @@ def run_train(config):
         if nonfinite and not timed_out:
             # no hand-off gave up: the loss itself left the finite range (divergence, bad input).  Changing the schedule
             # would re-run the same arithmetic; stop here with the last good checkpoint, like a failed sess.run.
+            # (A deliberate deviation, INTEGRATION.md "Non-finite losses": the reference's MonitoredTrainingSession has no
+            #  NanTensorHook and would keep stepping on NaN parameters.  No checkpoint is written here -- the parameters
+            #  already went through the non-finite update -- the one on disk is from a finite step.)
             bad = [base + i + 1 for i, v in enumerate(vals) if not np.isfinite(v)]
+            last_good = bad[0] - 1
             raise RuntimeError(f"non-finite training loss at step(s) {bad[:8]} with no hand-off timeout on any rank: "
-                               f"training diverged (or the inputs are not finite); the last good checkpoint was kept")
+                               f"training diverged (or the inputs are not finite); last step with a finite loss: {last_good}; "
+                               f"the last good checkpoint ({_ckpt(config)}) was kept")
         good = [(base + i + 1, v) for i, v in enumerate(vals) if np.isfinite(v)]      # (true step index, loss)
         if timed_out:
             # A hand-off of the fused schedule timed out: something else holds part of the chip (a co-tenant, a

@@ -36,6 +36,8 @@ from hip_util import NETS, PRE_TOL      # (the nets' workspace tags; a ReLU may 
                                         #  |pre-activation| <= PRE_TOL * sum_k |a_k| |w_kj|: measured over all cases, 6 such
                                         #  units in 5 of 60 trajectories, the largest ratio 5.0e-7)
 FLIPS = []             # (case, step, net, |pre| / sum |a||w|) of every unit where the device's ReLU mask differs from fp64's
+DRIFT_FLIPS = []       # (case, step, net, units, largest |pre| / sum|a||w|): units the ORACLE's own parameters put on the other side
+                       # (not numerically zero anywhere: the oracle keeps its own mask there)
 
 
 def _device_masks(e, model, d, B):
@@ -60,7 +62,7 @@ def _oracle_trajectory(L, model, d, flat0, xs, seed, step0=0, row_base=0, masks_
     """n oracle steps (fp64) on the noise of device steps step0 .. step0+n-1; returns (flat, C_last, g_last, [g_t]).
 
     masks_of_step(t) -> the device's ReLU masks of step t (see _device_masks); params_of_step(t) -> the device's parameters
-    BEFORE step t.  ReLU has no derivative at 0 and an fp32 pre-activation that is zero to within rounding can land on the
+    BEFORE step t (None: the oracle's own).  ReLU has no derivative at 0 and an fp32 pre-activation that is zero to within rounding can land on the
     other side than the fp64 one: there -- and ONLY there: every unit where the device's mask differs from the fp64 mask AT
     THE DEVICE'S OWN PARAMETERS must have |pre| <= PRE_TOL * sum |a||w| in fp64 (a kernel statement: the same parameters, the
     same noise, only rounding apart) -- the oracle trajectory takes the device's subgradients, so that every parameter seed
@@ -73,10 +75,19 @@ def _oracle_trajectory(L, model, d, flat0, xs, seed, step0=0, row_base=0, masks_
         eps, u = _noise(L, B * d.S, d.L, d.K, row_base * d.S, seed, step0 + t, model == O.MODEL_GMVAE)
         masks = None
         if masks_of_step is not None:
-            masks = masks_of_step(t)
+            dev_masks = masks_of_step(t)
             at = flat if params_of_step is None else params_of_step(t)
             Cc = O.forward(model, d, O.unpack(model, d, at), xs[t], eps, u, np.float64)
-            for net, ms in masks.items():
+            # The oracle steps with the DEVICE's masks.  A kernel's mask error cannot hide behind that: at the device's own
+            # parameters every unit where its mask differs from fp64's is asserted numerically zero (above / below).  What the
+            # oracle's own parameters (different by the drift of t Adam steps) would have chosen is only RECORDED
+            # (DRIFT_FLIPS, printed by test_trajectory_margins_report): keeping the oracle's own mask there was tried
+            # (round 5) and fails for the reason tools/traj_diag.py documents -- one unit on the other side moves the KL
+            # term by 5e-4 (vae-L2-H64-B100-seed13), five times the term's gate, in ANY two correct fp32/fp64 trajectories.
+            Co = Cc if params_of_step is None else O.forward(model, d, O.unpack(model, d, flat), xs[t], eps, u, np.float64)
+            masks = {}
+            for net, ms in dev_masks.items():
+                out = [None]
                 for i in range(1, len(ms)):
                     pre, mag = Cc["pre"][net][i - 1]
                     diff = ms[i] != (pre > 0)
@@ -86,6 +97,16 @@ def _oracle_trajectory(L, model, d, flat0, xs, seed, step0=0, row_base=0, masks_
                         assert ratio.max() <= PRE_TOL, (f"{tag} step {step0 + t} {net} layer {i}: the device's ReLU mask differs from "
                                                         f"fp64's at a pre-activation that is NOT numerically zero "
                                                         f"(|pre| / sum|a||w| = {ratio.max():.2e})")
+                    pre_o, mag_o = Co["pre"][net][i - 1]
+                    own = pre_o > 0
+                    zero_o = np.abs(pre_o) <= PRE_TOL * np.maximum(mag_o, 1e-30)
+                    take = (ms[i] != own) & (diff | zero_o)
+                    drift = (ms[i] != own) & ~take                # the two trajectories' parameters put this unit on different sides
+                    if drift.any():
+                        DRIFT_FLIPS.append((tag, step0 + t, net, int(drift.sum()),
+                                            float((np.abs(pre_o[drift]) / np.maximum(mag_o[drift], 1e-30)).max())))
+                    out.append(ms[i])
+                masks[net] = out
         flat, m, v, Cc, g = O.train_step(model, d, flat, m, v, step0 + t + 1, xs[t], eps, u, lr=LR, dtype=np.float64,
                                          relu_masks=masks)
         gs.append(g)
@@ -125,43 +146,56 @@ def _compare_last_step(model, d, eng, B, Cc, g, at_device=None, tag=""):
 
 GRAD_STATS = []        # (case, tensor, last-step gradient error at the device's parameters / the tensor's largest entry)
 import os
-GRAD_ERR = 4e-6        # assumed device gradient error in units of the tensor's largest gradient: the worst one MEASURED at the
-                       # device's own parameters over all cases (3.7e-6, GRAD_STATS; gate 1e-4)
-PARAM_STATS = []       # (case, n, share of elements whose tolerance is below lr / 10, worst diff / tolerance)
+GRAD_ERR_GATE = 1e-5   # the device's gradient error at its own parameters (GRAD_STATS, in units of the tensor's largest gradient) must
+                       # stay below this for the Adam-derived parameter tolerance to mean anything (measured worst: 3.7e-6)
+GRAD_ERR_GRID = (1e-6, 2e-6, 3e-6, 4e-6, 5e-6, 6e-6, 8e-6, 1e-5)
+PARAM_STATS = []       # (case, n, {E: (worst |dtheta| / tolerance(E), share of elements constrained to lr / 10 at E, worst tensor)})
 
 
 def _compare_params(model, d, eng, flat_ref, gs, n, tag=""):
     """Parameters after n device TF-Adam steps vs the fp64 oracle, element by element, with a tolerance that follows from
     Adam itself.  A step moves an element by alpha * m / (sqrt(v) + eps) = O(lr) * sign-like ratio: a gradient error delta
     changes that by about lr * c * |delta| / |g| (c of order 1-3: d/dg of m / sqrt(v)), saturating at ~2.5 lr when |g| is
-    itself rounding noise -- in ANY fp32 implementation, the reference's included.  With the device's gradient error taken
-    as 4e-6 of the tensor's largest gradient (25x below the 1e-4 gate of _compare_last_step: its measured size, GRAD_STATS):
-        tol_i = 3e-5 + lr * sum_t min(2.5, 3 * 4e-6 * max|g_t| / |g_t,i|)
-    i.e. 3e-5 (3 % of one step) for an element whose gradient is within 1e-3 of its tensor's largest, ~ lr only for those
-    below 1e-5 of it.  The share of elements that are constrained to better than a tenth of one step is asserted too, so
-    that the graded bound cannot silently become 'anything goes'."""
+    itself rounding noise -- in ANY fp32 implementation, the reference's included.  With the device's gradient error E in
+    units of the tensor's largest gradient:
+        tol_i(E) = 3e-5 + lr * sum_t min(2.5, 3 * E * max|g_t| / |g_t,i|)
+    i.e. 3e-5 (3 % of one step) for an element whose gradient is near its tensor's largest, ~ lr only where the gradient is
+    itself rounding noise.  E is NOT a constant of this file: the comparison is evaluated on a grid of E and
+    test_trajectory_parameters_within_the_measured_gradient_error (below, after every case) gates each trajectory at the
+    grid value just above the gradient error this SESSION measured at the device's own parameters (max of GRAD_STATS,
+    asserted <= 1e-5).  Here: the loosest grid value (the assertion's bound itself), so that a gross error stops the case."""
     got = eng.params.detach().cpu().numpy().astype(np.float64)
     diff = np.abs(got - flat_ref)
     assert np.isfinite(got).all() and diff.max() <= 2.5 * n * LR
     lay, P, _ = O.param_layout(model, d)
-    tol = np.full(P, 3e-5)
+    real = np.zeros(P, bool)
+    for name, shape, off in lay:
+        real[off:off + int(np.prod(shape))] = True
+    ratios = []                                    # per step: max|g_t| / |g_t,i| (inf where the gradient is exactly zero)
     for g in gs:
+        r = np.full(P, np.inf)
         for name, shape, off in lay:
             k = int(np.prod(shape))
             ga = np.abs(g[off:off + k])
             # (an element whose gradient is EXACTLY zero -- every weight of a hidden unit whose ReLU is off for the whole batch
             #  -- is not updated by either side: no allowance)
-            tol[off:off + k] += np.where(ga > 0, LR * np.minimum(2.5, 3.0 * GRAD_ERR * max(ga.max(), 1e-30) / np.maximum(ga, 1e-300)), 0.0)
-    real = np.zeros(P, bool)
-    for name, shape, off in lay:
-        real[off:off + int(np.prod(shape))] = True
-    worst = float((diff[real] / tol[real]).max())
-    tight = float((tol[real] <= LR / 10).mean())
-    PARAM_STATS.append((tag, n, tight, worst))
-    for name, shape, off in lay:
-        k = int(np.prod(shape))
-        r = diff[off:off + k] / tol[off:off + k]
-        assert r.max() <= 1.0, f"{tag} {name}: |dtheta| {diff[off:off + k][r.argmax()]:.2e} at tolerance {tol[off:off + k][r.argmax()]:.2e}"
+            r[off:off + k] = np.where(ga > 0, max(ga.max(), 1e-30) / np.maximum(ga, 1e-300), np.nan)
+        ratios.append(r)
+    grid = {}
+    for E in GRAD_ERR_GRID:
+        tol = np.full(P, 3e-5)
+        for r in ratios:
+            tol += np.where(np.isnan(r), 0.0, LR * np.minimum(2.5, 3.0 * E * np.nan_to_num(r, nan=0.0)))
+        q = diff[real] / tol[real]
+        worst_name = ""
+        for name, shape, off in lay:
+            k = int(np.prod(shape))
+            if (diff[off:off + k] / tol[off:off + k]).max() >= q.max():
+                worst_name = name
+        grid[E] = (float(q.max()), float((tol[real] <= LR / 10).mean()), worst_name)
+    PARAM_STATS.append((tag, n, grid))
+    w, tight, nm = grid[GRAD_ERR_GRID[-1]]
+    assert w <= 1.0, f"{tag} {nm}: |dtheta| / tolerance {w:.2f} even at the assertion's own bound E = {GRAD_ERR_GRID[-1]:.0e}"
     assert tight >= 0.5, f"{tag}: only {tight:.1%} of the parameters are constrained to a tenth of one step"
 
 
@@ -184,6 +218,11 @@ CASES = [
     ("gmvae", 784, 8, 10, (256,), 64, 4, (11, 12, 13, 14)),    # skinny, the reference's default latent size (a ragged tile of latent dimensions)
     ("vae_gmp", 784, 64, 10, (512,), 256, 4, (11, 12, 13, 14)),  # skinny VAE_GMP (BASELINE configs[1] at H = 512)
     ("gmvae", 784, 64, 10, (512,), 1024, 3, (11, 12)),    # BASELINE configs[2] at H = 512
+    # TF-Adam through sk_dwc's last-arriver finisher (more [64 x 64] tiles than CUs at H = 1024, B >= 512: two batch shares per
+    # tile) for the other two models, and the mixture prior's update workgroups riding on that launch
+    ("vae", 784, 64, 1, (1024,), 512, 3, (11,)),
+    ("vae_gmp", 784, 64, 10, (1024,), 640, 3, (11,)),
+    ("vae_gmp", 784, 64, 10, (512,), 768, 3, (11,)),      # (sk_dwb<1>: one workgroup per tile, B > 512)
 ]
 
 
@@ -242,11 +281,23 @@ def test_trajectory_margins_report():
             by.setdefault(tag, []).append(r)
         print(f"\n[trajectory] ReLU units taken from the device: {len(FLIPS)} in {len(by)} trajectories; "
               f"largest |pre| / sum|a||w| {max(r for *_, r in FLIPS):.2e} (gate {PRE_TOL:.0e})")
+    if DRIFT_FLIPS:
+        print(f"[trajectory] units the oracle's own (drifted) parameters would put on the other side than the device's mask: "
+              f"{sum(n for *_, n, _ in DRIFT_FLIPS)} in {len(set(t for t, *_ in DRIFT_FLIPS))} trajectories; largest "
+              f"|pre| / sum|a||w| there {max(r for *_, r in DRIFT_FLIPS):.2e}")
     if GRAD_STATS:
         print(f"[trajectory] last-step gradients at the device's parameters: worst rel-to-max error {max(e for *_, e in GRAD_STATS):.2e} (gate 1e-4)")
-    if PARAM_STATS:
-        print(f"[trajectory] parameters: worst |dtheta| / tolerance {max(w for *_, w in PARAM_STATS):.2f}; "
-              f"share constrained to lr / 10: min {min(t for _, _, t, _ in PARAM_STATS):.1%}")
+    if PARAM_STATS and GRAD_STATS:
+        E = _session_grad_err()
+        print(f"[trajectory] parameters at the session's measured gradient error (grid value {E:.0e}): worst |dtheta| / tolerance "
+              f"{max(g[E][0] for *_, g in PARAM_STATS):.2f}; share constrained to lr / 10: min {min(g[E][1] for *_, g in PARAM_STATS):.1%}")
+
+
+def _session_grad_err():
+    """The grid value just above the worst gradient error measured in this session at the device's own parameters."""
+    ge = max(e for *_, e in GRAD_STATS)
+    assert ge <= GRAD_ERR_GATE, f"device gradient error {ge:.2e} at its own parameters exceeds {GRAD_ERR_GATE:.0e}"
+    return min(E for E in GRAD_ERR_GRID if E >= ge)
 
 
 def test_second_graph_launch_continues_the_trajectory():
@@ -449,3 +500,14 @@ def test_one_launch_step_equals_two_launch_step_bit_for_bit(B, monkeypatch):
     assert res[0][3] == ["mega3_step"] and res[1][3] == ["mega2_fwd_bwd", "dw_adam"], (res[0][3], res[1][3])
     for a_, b_ in zip(res[0][:3], res[1][:3]):
         assert torch.isfinite(a_).all() and torch.equal(a_, b_)
+
+
+def test_trajectory_parameters_within_the_measured_gradient_error():
+    """The gate of every trajectory's parameters (run after the cases above in file order): element-wise |dtheta| within the
+    Adam-derived tolerance at the gradient error THIS session measured (max over all cases of the last-step gradient error at
+    the device's own parameters -- not a pasted constant), and at least half of the elements constrained to a tenth of a step."""
+    if not PARAM_STATS or not GRAD_STATS:
+        pytest.skip("no trajectory case ran in this session")
+    E = _session_grad_err()
+    bad = [(tag, g[E]) for tag, _, g in PARAM_STATS if g[E][0] > 1.0 or g[E][1] < 0.5]
+    assert not bad, f"at the measured gradient error (grid {E:.0e}): {bad[:5]}"
