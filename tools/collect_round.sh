@@ -1,10 +1,10 @@
 #!/bin/bash
 # gpurun_out/prof_r<N> (scratch, written by tools/profile_round.sh on the GPU box) -> profiles/round<N>_* (tracked)
 set -e
-RN=${1:-4}
+RN=${1:-5}
 cd "$(dirname "$0")/.."
 S=gpurun_out/prof_r$RN
-for n in bench run_train_sizes config5_shard configs1 configs0 configs2_h512 configs1_h512; do
+for n in bench run_train_sizes config5_shard configs1 configs0 configs2_h512 configs1_h512 configs3_dp1 eval_iwae; do
   cp $S/$n/${n}_kernel_stats.csv profiles/round${RN}_${n}_kernel_stats.csv
   cp $S/$n.json profiles/round${RN}_${n}_under_rocprof.json
 done
