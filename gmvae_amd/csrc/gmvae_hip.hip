@@ -155,6 +155,7 @@ struct WS {
   unsigned long long* spans;    // measurement: [2 slots][3 kernels][2048 blocks][2] wall-clock stamps (mega_fwd_bwd, finalize_adam / dw_adam, fl_split)
   unsigned long long* gstamps;  // diagnostic stamps of the grouped-GEMM launches: [4 slots][2048 blocks][8]
   unsigned* sync;               // [0] = per-step epoch of the hand-off, [1] = hand-off timeout flag
+  unsigned* m3flags;            // mega3_step's per-workgroup epoch flags, replicated (mega3.hpp)
   float *img_f, *img_b;         // per-step LDS weight images of chain_fwd / chain_bwd (prepared by aux blocks)
   float *img_m, *dimg;          // mega kernel: small-weight image (odd leading dimensions) + decoder chunk images
   float *img2f, *img2b, *dimg2; // mega2 kernel: forward / backward operand images, decoder operand images
@@ -356,6 +357,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     w.gstamps = reinterpret_cast<unsigned long long*>(take(2ull * 4 * 2048 * 8));
     w.spans = reinterpret_cast<unsigned long long*>(take(2ull * 2 * 3 * 2048 * 2));
     if (model == GMVAE_MODEL_GMVAE && d.hidden[0] == M2::H && d.L == M2::L && d.K == M2::K && d.D == M2::D && d.B <= 1024) {
+      w.m3flags = reinterpret_cast<unsigned*>(take((uint64_t)kM3FlagReplicas * kM3FlagRepLd));      // mega3_step's flag replicas
       w.img2f = take(M2::imgF);                  // (not gated by GMVAE_NO_MEGA2: the workspace layout must not depend on a switch)
       w.img2b = take(M2::imgB);
       w.dimg2 = take(M2::dimg);
@@ -1193,7 +1195,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         m3.m = c3;
         m3.m.lr_t_out = nullptr;
         m3.ntens = da.ntens;
-        m3.flags = w.sync + 64;
+        m3.flags = w.m3flags;
         m3.lr_next = w.sync + 4;
         m3.dbg = getenv("GMVAE_M3_STAMPS") ? w.gstamps + 3 * 2048 * 8 : nullptr;
         {

@@ -54,6 +54,13 @@ constexpr int kM3MaxSlots = 320;
 constexpr int kM3MaxT = 8;
 constexpr unsigned short kM3Tail = 0xffffu, kM3None = 0xfffeu, kM3PhaseF = 0x8000u;
 constexpr int kM3FlagLd = 64;                        // rows 0..2: producers q - 1; row 3: the leads
+#ifndef M3_FLAG_REPLICAS
+#define M3_FLAG_REPLICAS 8
+#endif
+// Every flag is stored M3_FLAG_REPLICAS times, 4 KB apart (one wave-level store), and a worker polls replica rank % replicas:
+// ~200 workgroups polling the SAME two lines made them a hot spot of one memory channel (polls returned after 2-4 us instead of
+// 1.2, and the slowest lead -- whose stores cross the same channel -- lost 1-1.5 us; profiles/round5_notes.md)
+constexpr int kM3FlagReplicas = M3_FLAG_REPLICAS, kM3FlagRepLd = 1024;
 
 struct M3Fin {                 // what the tiles' optimizer epilogue and the loss tail need (FinalArgs without slabs / maps)
   float *grads, *p, *m, *v;
@@ -71,7 +78,7 @@ struct M3Fin {                 // what the tiles' optimizer epilogue and the los
 struct M3Args {
   MegaArgs m;
   int ntens, total_slots;
-  unsigned* flags;             // [4][kM3FlagLd] per-workgroup epoch tags
+  unsigned* flags;             // [kM3FlagReplicas][kM3FlagRepLd]: in each replica [4][kM3FlagLd] per-workgroup epoch tags
   unsigned* lr_next;           // [4]: {alpha_t bits, the Adam step t it is for, lr bits, alpha_key(b1, b2)}: left by the previous step's tail slot
   unsigned long long* dbg;     // diagnostic: [workgroup][8] wall-clock stamps of the worker phase (tools/m3stamps.py) or null
   unsigned short perm[kM3MaxSlots];   // slot -> (tensor << 10) | tile inside the tensor (| kM3PhaseF); kM3Tail: the loss tail
@@ -105,7 +112,12 @@ __device__ __forceinline__ void m3_tail(const M3Fin& a, unsigned long long* step
   if (t == 256) {
     // alpha_t for whoever applies the next update, tagged with its Adam step t (never 0, the workspace's initial value): the
     // NEXT step's tiles (single device), or -- gradients only -- THIS step's adam_tf_img behind the all-reduce
-    const unsigned long long tt = a.do_adam ? step + 2ull : step + 1ull;
+    unsigned long long tt = a.do_adam ? step + 2ull : step + 1ull;
+    // (opaque to the optimizer: the expression is invariant over the slot loop, and hoisted in front of it the two fp64 pow cost
+    //  EVERY workgroup 1.44 us before its first tile -- on the launch's critical path for the leads; tools/m3stamps.py)
+    unsigned tt_lo = (unsigned)tt;
+    asm volatile("" : "+v"(tt_lo));
+    tt = (tt & ~0xffffffffull) | tt_lo;
     lr_next[0] = __float_as_uint(m3_alpha(a, tt));
     lr_next[1] = (unsigned)tt;
     lr_next[2] = __float_as_uint(a.lr);          // (a step counter may be rewound and the rate changed: the tag names both)
@@ -159,8 +171,9 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
   M3_ST2(0);
   __syncthreads();             // (also: the per-row role's LDS is dead in every wave)
   M3_ST2(1);
-  if (tid == 0)
-    __hip_atomic_store(aa.flags + (role == 2 ? 3 : q - 1) * kM3FlagLd + pnl, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < kM3FlagReplicas)
+    __hip_atomic_store(aa.flags + tid * kM3FlagRepLd + (role == 2 ? 3 : q - 1) * kM3FlagLd + pnl, epoch, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
   const int rank = (q == 0 ? 3 * nPr : (q - 1) * nPr) + pnl, nW = 4 * nPr;
   float* const red = sm;                         // [wave][mt * 4 + r][lane]
   float* const redcs = sm + kDwWaves * 64 * 16;  // [wave][lane]
@@ -173,11 +186,27 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
   unsigned seen = 0;                             // (uniform) bit 0: the producers' flags seen; bit 1: the leads'
   bool poisoned = false;
   // wait for the producers' rows (leads = false) or for all four rows
-  auto wait_flags = [&](const bool leads) {
+  const unsigned* const f0 = aa.flags + (rank % kM3FlagReplicas) * kM3FlagRepLd + min(lane, nPr - 1);
+  const bool own = role == 2 && lane == pnl;       // a lead's own flag: it stored it itself (its visibility to itself is not waited for)
+  // An EARLY poll (wave 0): the flag loads go out BEFORE the tile's operand prefetch -- vmcnt retires in order, so a poll issued
+  // behind 44 cold prefetch loads returned with the last of them (a lead's first poll: 2.1 us instead of 1.2) -- and are looked at
+  // after the prefetch has been issued.  early_ok: all four rows carried the epoch (then wait_flags below does not poll again).
+  unsigned ef0 = 0, ef1 = 0, ef2 = 0, ef3 = 0;
+  auto early_issue = [&]() {
+    if (wave == 0 && seen != 3u) {
+      ef0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ef1 = __hip_atomic_load(f0 + kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ef2 = __hip_atomic_load(f0 + 2 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ef3 = __hip_atomic_load(f0 + 3 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto early_ok = [&]() -> bool {                  // (meaningful in wave 0 only)
+    return wave == 0 && seen != 3u && __all(ef0 == epoch && ef1 == epoch && ef2 == epoch && (ef3 == epoch || own));
+  };
+  auto wait_flags = [&](const bool leads, const bool pre = false) {
     const unsigned want = leads ? 3u : 1u;
     if ((seen & want) == want) return;
-    if (wave == 0) {
-      const unsigned* const f0 = aa.flags + min(lane, nPr - 1);
+    if (wave == 0 && !pre) {
       const bool np = !(seen & 1u);                // (uniform) the producers' rows are still to be seen
       unsigned spins = 0;
       for (;;) {
@@ -188,7 +217,7 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
           const unsigned f_2 = __hip_atomic_load(f0 + 2 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ok = f_0 == epoch && f_1 == epoch && f_2 == epoch;
         }
-        if (leads) ok = ok && __hip_atomic_load(f0 + 3 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+        if (leads) ok = ok && (own || __hip_atomic_load(f0 + 3 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch);
         if (__all(ok)) break;
         if (++spins > spin_limit) {
           if (lane == 0) atomicExch(a.err_word, 1u);
@@ -204,6 +233,7 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
     seen |= want;
   };
   for (int slot = rank; slot < aa.total_slots; slot += nW) {
+    M3_ST2(6);
     const int pv_ = aa.perm[slot];
     if (pv_ == kM3None) continue;
     if (pv_ == kM3Tail) {
@@ -219,6 +249,7 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
     const int ti = (pv_ & 0x7fff) >> 10, tl = pv_ & 1023;
     const DwTensor& T = aa.t[ti];
     const int M = T.M, N = T.N, lda = T.lda, ldy = T.ldy;
+    if (aa.dbg) { asm volatile("" ::"s"(M), "s"(N), "s"(lda), "s"(ldy)); M3_ST2(7); }
     const int tm = tl / T.tiles_n, tn = tl - tm * T.tiles_n;
     const int MUr = T.mu;
     const int m0 = tm * 16 * MUr, n0 = tn * 16;
@@ -229,6 +260,8 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
     const bool bown = tm == 0 && T.b_off >= 0 && tid >= 256 && tid < 272 && n0 + (tid - 256) < N;
     float pp[4] = {0.f, 0.f, 0.f, 0.f}, pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f};
     float bp = 0.f, bm = 0.f, bv = 0.f;
+    const bool early = phF && T.a_u8 != 0;         // (uniform) tiles whose whole prefetch needs no flag: poll first, prefetch, look
+    if (early) early_issue();
     // the optimizer's operands: the previous launch wrote them -- requested before any wait
     if (upd) {
       if (eown) {
@@ -243,16 +276,22 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
     }
     const int rows_w = (((B + kDwWaves - 1) / kDwWaves) + 3) & ~3;
     const int b_lo = wave * rows_w, b_hi = min(B, b_lo + rows_w);
-    const bool full = b_hi - b_lo == 128;          // (uniform: B = 1024) the register-resident forms
+    // The register-resident forms need 128 rows in EVERY wave: the choice must be workgroup-uniform, because the branches below
+    // wait a different number of times and every wait holds a workgroup barrier.  (b_hi - b_lo == 128 alone is true for waves
+    // 0..6 and false for wave 7 at B = 1000: wave 7 then passed ITS one barrier together with the others' first and read the
+    // gradients before the leads' flags were checked -- a rare one-ulp-scale difference tools/fuse_check.py caught once in five runs.)
+    // The uint8 tiles keep dw_adam's PER-WAVE choice (a wave with 128 rows multiplies bf16 pieces, a ragged last wave fp32:
+    // same bits as the two-launch form at any batch) -- both of their branches wait exactly once.
+    const bool full = B == 128 * kDwWaves, full_w = b_hi - b_lo == 128;
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float cs = 0.f;
     M3_ST(1);
-    if (T.a_u8 && full) {
+    if (T.a_u8 && full_w) {
       unsigned av[32];
       dw_u8x3_load_a(static_cast<const unsigned char*>(T.A), lda, M, m0, b_lo, ln, lk, av);     // the batch: final before the launch
-      wait_flags(phF);
+      wait_flags(phF, early && early_ok());
       M3_ST(2);
       dw_u8x3_rest<false>(av, T.dY, ldy, M, N, m0, n0, b_lo, ln, lk, acc, cs);
     } else if (!T.a_u8 && full && phF && MUr <= 2) {

@@ -40,6 +40,9 @@ for who, sel in (("producers", ~lead), ("leads", lead)):
 q = lambda a: "median %.2f (min %.2f max %.2f)" % (np.median(a) * 0.01, a.min() * 0.01, a.max() * 0.01)
 for who, sel in (("producers", ~lead), ("leads", lead)):
     print(f"{who}: role end -> stores acknowledged {q(ext[sel, 0] - raw[sel, 0])} | -> barrier passed {q(ext[sel, 1] - ext[sel, 0])} | alpha_t {q(ext[sel, 2] - ext[sel, 1])}")
+for who, sel in (("producers", ~lead), ("leads", lead)):
+    ok = sel & (ext[:, 6] > 0) & (ext[:, 7] > 0) & (raw[:, 1] > 0)
+    if ok.any(): print(f"{who}: alpha_t done -> slot loop entered {q(ext[ok, 6] - ext[ok, 2])} | -> tile descriptor read {q(ext[ok, 7] - ext[ok, 6])} | -> optimizer operands requested {q(raw[ok, 1] - ext[ok, 7])}")
 print("leads' role ends sorted (us):", np.round(np.sort(raw[lead, 0] - t0) * 0.01, 2).tolist())
 lf = ext[lead, 1].max()
 pf = ext[~lead, 1].max()
