@@ -363,6 +363,7 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
       w.dimg2 = take(M2::dimg);
     }
     if (const int vk = mega2v_kind(d, model)) {
+      w.m3flags = reinterpret_cast<unsigned*>(take((uint64_t)kM3FlagReplicas * kM3FlagRepLd));      // mega3v_step's flag replicas
       w.img2f = take(vk == 1 ? MV0::imgF : MV1::imgF);
       w.img2b = take(vk == 1 ? MV0::imgB : MV1::imgB);
       w.dimg2 = take(vk == 1 ? MV0::dimg : MV1::dimg);
@@ -1028,7 +1029,8 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
   // mega3_step (mega3.hpp): at mega2_fwd_bwd's sizes the weight-gradient tiles + TF-Adam run in the SAME launch -- its
   // arguments are kept until the tile list below is built
   MegaArgs c3;
-  bool fuse_pending = false;
+  bool fuse_pending = false, fusev_pending = false;
+  int vkind = 0;
   double m2_flops = 0;
   const bool dw_upd_ = a.adam_p && a.adam_p == a.params;
   {  // the whole per-row forward + backward in one launch
@@ -1101,7 +1103,12 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         m2vattr = true;
       }
       const unsigned grid = (unsigned)((B + kPanel - 1) / kPanel * 7);
-      if (vk == 1) hipLaunchKernelGGL((mega2v_fwd_bwd<0, 2, 1>), dim3(grid), dim3(kMT), (size_t)MV0::total * sizeof(float), st, c);
+      // (mega3v_step: the step as ONE launch where the optimizer runs on this device; the data-parallel graph keeps two launches)
+      fusev_pending = dw_upd_ && a.step_dev && !getenv("GMVAE_NO_FUSE") && grid <= 256;
+      vkind = vk;
+      c3 = c;
+      if (fusev_pending) { /* launched below, with the tile list */ }
+      else if (vk == 1) hipLaunchKernelGGL((mega2v_fwd_bwd<0, 2, 1>), dim3(grid), dim3(kMT), (size_t)MV0::total * sizeof(float), st, c);
       else hipLaunchKernelGGL((mega2v_fwd_bwd<1, 64, 10>), dim3(grid), dim3(kMT), (size_t)MV1::total * sizeof(float), st, c);
     } else {
       hipLaunchKernelGGL(fn, dim3((B + kPanel - 1) / kPanel * c.Q), dim3(kMT), (size_t)ml.total * sizeof(float), st, c);
@@ -1112,7 +1119,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     if (fl) macs += (double)D * H2;        // the first layer rides in the launch
     if (gm) macs += (double)H * K + (double)K * H + (double)K * 2 * Lz + (double)(H + 2 * Lz) * K + (double)K * H;
     if (m2) { m2_flops = 2.0 * B * macs; if (!fuse_pending) cx.mark("mega2_fwd_bwd", m2_flops); goto mega_done; }
-    if (m2v) { cx.mark("mega2v_fwd_bwd", 2.0 * B * macs); goto mega_done; }
+    if (m2v) { m2_flops = 2.0 * B * macs; if (!fusev_pending) cx.mark("mega2v_fwd_bwd", m2_flops); goto mega_done; }
     cx.mark("mega_fwd_bwd", 2.0 * B * macs);
   mega_done:;
   }
@@ -1188,7 +1195,8 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       double fl_ = 0;
       for (int i = 0; i < da.ntens; ++i) fl_ += 2.0 * da.t[i].M * da.t[i].N * B;
       const unsigned m2_grid = (unsigned)((((B + kPanel - 1) / kPanel + 1) & ~1) * 4);
-      if (fuse_pending && da.ntens <= kM3MaxT && !gmp) {
+      if ((fuse_pending || fusev_pending) && da.ntens <= kM3MaxT) {
+        const bool vfam = fusev_pending;           // the VAE family: mega3v_step (seven workgroups per panel + role-less workers)
         std::vector<M3Args> m3_store(1);
         M3Args& m3 = m3_store[0];
         memset(&m3, 0, sizeof(m3));
@@ -1198,12 +1206,17 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         m3.flags = w.m3flags;
         m3.lr_next = w.sync + 4;
         m3.dbg = getenv("GMVAE_M3_STAMPS") ? w.gstamps + 3 * 2048 * 8 : nullptr;
+        const int nPr = (B + kPanel - 1) / kPanel;
+        const unsigned grid3 = vfam ? 256u : m2_grid;
         {
-          // The slot list (mega3.hpp): workgroup `rank` takes slots rank, rank + workers, ...; the producers hold the ranks below
-          // 3 panels and are done first.  Phase P first -- the decoder output layer's gradient over the producers' column tiles:
-          // its tiles wait for the producers' flags only and run under the leads' backward chain --, then phase F: the fp32
-          // tiles (longer), the uint8-batch tiles, the loss tail.  At B = 1024: P on producers 0..95, F on producers 96..191 and
-          // on the leads.  Inside a group, slot b (XCD b % 8 under round-robin placement) prefers a tile of its operand class.
+          // The slot list (mega3.hpp): workgroup `rank` takes slots rank, rank + workers, ...  Phase P first -- the decoder
+          // output layer's gradient over the PRODUCERS' column tiles: it waits for the producers' flags only and runs under the
+          // leads' hand-off and backward chain --, then phase F: the fp32 tiles (longer), the uint8-batch tiles, the mixture
+          // prior's blocks, the loss tail.  GMVAE at B = 1024: ranks 0..191 are the producers (done first), 192..255 the leads:
+          // P on producers 0..95, F on producers 96..191 and on the leads.  VAE family: ranks below 6 panels are producers,
+          // the next `panels` ranks the leads -- they get NO slot --, the rest of the 256 workgroups have no per-row role and
+          // wait from the launch's start.  Inside a group, slot b (XCD b % 8 under round-robin placement) prefers a tile of
+          // its operand class (speed only).
           const int nt = da.total_tiles;
           std::vector<int> tile_cls(nt), tile_grp(nt), tile_pt(nt);
           for (int i = 0; i < da.ntens; ++i) {
@@ -1213,19 +1226,27 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
               for (int tn = 0; tn < T.tiles_n; ++tn) {
                 const int t = T.tile_begin + tm * T.tiles_n + tn;
                 int q_ = 1, lt_ = 0;
-                if (T.dY == w.g) m2_dec_part(tn, q_, lt_);                                 // whose g columns: a producer's or the lead's
+                if (T.dY == w.g) {                                                          // whose g columns: a producer's or the lead's
+                  if (vfam) q_ = tn % 7;                                                     // (mega2v.hpp: column tile 7 wave + quarter)
+                  else m2_dec_part(tn, q_, lt_);
+                }
                 const bool phP = T.dY == w.g && q_ != 0;
                 tile_cls[t] = (tiles_m >= T.tiles_n ? tm : tn) & 7;
                 tile_grp[t] = phP ? 0 : (T.a_u8 ? 2 : 1);
                 tile_pt[t] = (i << 10) | (t - T.tile_begin) | (phP ? 0 : kM3PhaseF);
               }
           }
+          const int lead_lo = vfam ? 6 * nPr : -1, lead_hi = vfam ? 7 * nPr : -1;          // ranks that take no slot
           std::vector<char> used(nt, 0);
           int slot = 0;
+          auto skip_leads = [&]() {
+            while (slot < kM3MaxSlots && (int)(slot % grid3) >= lead_lo && (int)(slot % grid3) < lead_hi) m3.perm[slot++] = kM3None;
+          };
           for (int grp = 0; grp < 3; ++grp) {
             int left = 0;
             for (int t = 0; t < nt; ++t) left += tile_grp[t] == grp;
             for (; left > 0; --left, ++slot) {
+              skip_leads();
               int pick = -1, any = -1;
               for (int t = 0; t < nt && pick < 0; ++t)
                 if (!used[t] && tile_grp[t] == grp) {
@@ -1237,6 +1258,11 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
               if (slot < kM3MaxSlots) m3.perm[slot] = (unsigned short)tile_pt[pick];
             }
           }
+          for (int gb = 0; gb < da.gmp_blocks; ++gb, ++slot) {
+            skip_leads();
+            if (slot < kM3MaxSlots) m3.perm[slot] = (unsigned short)(kM3Gmp + gb);
+          }
+          skip_leads();
           if (slot < kM3MaxSlots) m3.perm[slot] = kM3Tail;
           m3.total_slots = ++slot;
         }
@@ -1245,18 +1271,34 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         f3.grads = fa.grads; f3.p = fa.p; f3.m = fa.m; f3.v = fa.v; f3.lr = fa.lr; f3.b1 = fa.b1; f3.b2 = fa.b2; f3.eps = fa.eps;
         f3.do_adam = fa.do_adam; f3.count = fa.count; f3.logw = fa.logw; f3.logpx = fa.logpx; f3.logq = fa.logq; f3.logp = fa.logp;
         f3.nent = fa.nent; f3.tail = fa.tail; f3.B = fa.B; f3.tail_log = fa.tail_log; f3.epoch_word = fa.epoch_word;
+        f3.gmp_part = fa.gmp_part; f3.gmp_n = fa.gmp_n; f3.gmp_len = fa.gmp_len; f3.gmp_off = fa.gmp_off;
+        m3.gmp_nmap = da.gmp_nmap;
+        for (int i = 0; i < 3; ++i) m3.gmp_map[i] = da.gmp_map[i];
         for (int i = 0; i < kImgBufs; ++i) f3.img[i] = fa.img[i];
         static bool m3attr = false;
         if (!m3attr) {
           hipFuncSetAttribute(reinterpret_cast<const void*>(mega3_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          hipFuncSetAttribute(reinterpret_cast<const void*>(mega3v_step<0, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          hipFuncSetAttribute(reinterpret_cast<const void*>(mega3v_step<1, 64, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           m3attr = true;
         }
-        if (m3.total_slots <= kM3MaxSlots) {
-          hipLaunchKernelGGL(mega3_step, dim3(m2_grid), dim3(kMT), (size_t)M2::total * sizeof(float), st, m3);
+        // (the meeting area of a worker's tile: 34 KB at the bottom of the dynamic LDS, whatever the per-row part's map)
+        if (m3.total_slots <= kM3MaxSlots && (!gmp || da.gmp_blocks < 0xfe)) {
+          if (!vfam) hipLaunchKernelGGL(mega3_step, dim3(grid3), dim3(kMT), (size_t)M2::total * sizeof(float), st, m3);
+          else if (vkind == 1) hipLaunchKernelGGL((mega3v_step<0, 2, 1>), dim3(grid3), dim3(kMT), (size_t)MV0::total * sizeof(float), st, m3);
+          else hipLaunchKernelGGL((mega3v_step<1, 64, 10>), dim3(grid3), dim3(kMT), (size_t)MV1::total * sizeof(float), st, m3);
           cx.check();
-          cx.mark(dw_upd ? "mega3_step" : "mega3_grads", m2_flops + fl_);
+          cx.mark(vfam ? (dw_upd ? "mega3v_step" : "mega3v_grads") : (dw_upd ? "mega3_step" : "mega3_grads"), m2_flops + fl_);
           return cx.err;
         }
+      }
+      if (fusev_pending) {                       // the two-launch form after all
+        const unsigned gridv = (unsigned)((B + kPanel - 1) / kPanel * 7);
+        if (vkind == 1) hipLaunchKernelGGL((mega2v_fwd_bwd<0, 2, 1>), dim3(gridv), dim3(kMT), (size_t)MV0::total * sizeof(float), st, c3);
+        else hipLaunchKernelGGL((mega2v_fwd_bwd<1, 64, 10>), dim3(gridv), dim3(kMT), (size_t)MV1::total * sizeof(float), st, c3);
+        cx.check();
+        cx.mark("mega2v_fwd_bwd", m2_flops);
+        fusev_pending = false;
       }
       if (fuse_pending) {                        // (cannot happen at mega2's sizes: the tile list fits) the two-launch form
         hipLaunchKernelGGL(mega2_fwd_bwd, dim3(m2_grid), dim3(kMT), (size_t)M2::total * sizeof(float), st, c3);
@@ -1269,6 +1311,14 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       cx.mark(dw_upd ? "dw_adam" : "dw_grads", fl_);
       return cx.err;
     }
+  }
+  if (fusev_pending) {
+    const unsigned gridv = (unsigned)((B + kPanel - 1) / kPanel * 7);
+    if (vkind == 1) hipLaunchKernelGGL((mega2v_fwd_bwd<0, 2, 1>), dim3(gridv), dim3(kMT), (size_t)MV0::total * sizeof(float), st, c3);
+    else hipLaunchKernelGGL((mega2v_fwd_bwd<1, 64, 10>), dim3(gridv), dim3(kMT), (size_t)MV1::total * sizeof(float), st, c3);
+    cx.check();
+    cx.mark("mega2v_fwd_bwd", m2_flops);
+    fusev_pending = false;
   }
   if (fuse_pending) {                            // the tile list could not be built: mega2_fwd_bwd as a launch of its own
     hipLaunchKernelGGL(mega2_fwd_bwd, dim3((unsigned)((((B + kPanel - 1) / kPanel + 1) & ~1) * 4)), dim3(kMT), (size_t)M2::total * sizeof(float), st, c3);

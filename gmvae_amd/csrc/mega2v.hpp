@@ -82,9 +82,12 @@ __device__ __forceinline__ void g2_wait_n(u32x4_t (&v)[N]) {
                  "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11])::"memory");
 }
 
-template <int MODEL, int LT, int KT>
-__global__ __launch_bounds__(kMT) void mega2v_fwd_bwd(const MegaArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+// The launch's body.  FUSE = 0: the whole of mega2v_fwd_bwd (below).  FUSE = 1: the per-row part of mega3v_step (mega3.hpp), whose
+// workgroups go on to the weight-gradient tiles: every output another workgroup reads in the same launch leaves write-through,
+// quarter 1 (off the critical path) stores the panel's forward activations, alpha_t and the closing span stamp are the
+// caller's.  Returns 1 for a producer (partials published), 2 for the panel's lead (backward chain done).
+template <int MODEL, int LT, int KT, int FUSE>
+__device__ __forceinline__ int mega2v_body(const MegaArgs& a, float* const sm) {
   typedef M2V<MODEL, LT, KT> V;
   constexpr int H = V::H, L = V::L, K = V::K, D = V::D, L2 = V::L2, LP = V::LP, L2P = V::L2P, Q = V::Q, KQ = V::KQ;
   constexpr bool gmp = MODEL == 1;
@@ -98,8 +101,9 @@ __global__ __launch_bounds__(kMT) void mega2v_fwd_bwd(const MegaArgs a) {
   const int r0 = pnl * kPanel;
   const int nrow = min(kPanel, B - r0);
   const bool lead = q == 0;
+  const bool act = FUSE ? q == 1 : lead;           // who stores the forward activations (every quarter holds the same bits)
   if (a.span && tid == 0) a.span[2 * bid] = wall_clock64();
-#define M2V_SPAN_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
+#define M2V_SPAN_END() if (!FUSE && a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
   const unsigned spin_limit = *a.err_word ? 0u : (1u << 19);       // bounded spins (see mega.hpp)
   const unsigned epoch = *a.epoch_word;            // tag of this step's hand-offs
   float* const img = sm + V::IMG;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(kMT) void mega2v_fwd_bwd(const MegaArgs a) {
       M_c[lane] = lw + M_c[lane] - 0.5f * kLog2Pi * (float)L;
     }
   }
-  if (lead && tid < 256) {                         // he (kept for dWe1) leaves as 16-byte write-through stores
+  if (act && tid < 256) {                          // he (kept for dWe1) leaves as 16-byte write-through stores
     const int row = tid >> 4, c = (tid & 15) << 2;
     if (row < nrow) st4o(a.hy1 + (long long)(r0 + row) * H + c, ld4(P_h1 + row * V::ld64 + c));
   }
@@ -303,12 +307,12 @@ __global__ __launch_bounds__(kMT) void mega2v_fwd_bwd(const MegaArgs a) {
     if (sub == 0) {
       nllp[row] = aq;
       if (!gmp) nllp[kPanel + row] = ap;
-      if (ok && lead) { a.logq[r0 + row] = aq; if (!gmp) a.logp[r0 + row] = ap; }
+      if (ok && lead) { st1o(a.logq + r0 + row, aq); if (!gmp) st1o(a.logp + r0 + row, ap); }
     }
   }
   __syncthreads();
   GMVAE_STAMP(3);
-  if (lead && tid >= 256 && tid < 256 + kPanel * ((L + 3) / 4)) {     // z (kept for dWd0): waves 4.., which have no tile in S6
+  if (act && tid >= 256 && tid < 256 + kPanel * ((L + 3) / 4)) {      // z (kept for dWd0): waves 4.., which have no tile in S6
     const int t2 = tid - 256, row = t2 / ((L + 3) / 4), c = (t2 - row * ((L + 3) / 4)) << 2;
     if (row < nrow) {
       if constexpr ((L & 3) == 0) {
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(kMT) void mega2v_fwd_bwd(const MegaArgs a) {
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (c + j < L) a.z[(long long)(r0 + row) * L + c + j] = P_z[row * V::ldz + c + j];
+          if (c + j < L) st1o(a.z + (long long)(r0 + row) * L + c + j, P_z[row * V::ldz + c + j]);
       }
     }
   }
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(kMT) void mega2v_fwd_bwd(const MegaArgs a) {
     if (sub < 16) P_r[row * 16 + sub] = sub < K ? fexp(comp - lse) : 0.f;
     if (sub == 0) {
       nllp[kPanel + row] = lse;
-      if (lead && row < nrow) a.logp[r0 + row] = lse;
+      if (lead && row < nrow) st1o(a.logp + r0 + row, lse);
     }
   }
   // S6 decoder hidden: 4 tiles, contraction LP
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(kMT) void mega2v_fwd_bwd(const MegaArgs a) {
     const float4 bb = ld4(img + V::b_d0 + c0);
     const float4 h = make_float4(fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f), fmaxf(acc[2] + bb.z, 0.f), fmaxf(acc[3] + bb.w, 0.f));
     st4(P_hd + ln * V::ld64 + c0, h);
-    if (lead && ln < nrow) st4o(a.hd1 + (long long)(r0 + ln) * H + c0, h);
+    if (act && ln < nrow) st4o(a.hd1 + (long long)(r0 + ln) * H + c0, h);
   }
   __syncthreads();                                 // the forward weights are dead (the mixture prior's arrays lie behind them)
   GMVAE_STAMP(4);
@@ -446,12 +450,12 @@ __global__ __launch_bounds__(kMT) void mega2v_fwd_bwd(const MegaArgs a) {
     } else if (tid < 256 + kPanel) {
       granule_publish(xo + kPanel * H + (tid - 256), ((unsigned long long)epoch << 32) | __float_as_uint(rsn));
     }
-    if (bid == 0 && tid == 0 && a.lr_t_out) {      // (a producer: off the launch's critical path)
+    if (!FUSE && bid == 0 && tid == 0 && a.lr_t_out) {      // (a producer: off the launch's critical path)
       const double t = (double)(a.step_dev[0] + 1ull);
       *a.lr_t_out = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, t)) / (1.0 - pow((double)a.b1, t)));
     }
     M2V_SPAN_END();
-    return;
+    return 1;
   }
   // ======================================================================= B: backward chain (quarter 0)
   {
@@ -521,8 +525,8 @@ __global__ __launch_bounds__(kMT) void mega2v_fwd_bwd(const MegaArgs a) {
     if (wn) {
       const int row = tid - 256;
       if (row < nrow) {
-        a.logpx[r0 + row] = rsn;
-        a.logw[r0 + row] = rsn + nllp[kPanel + row] - nllp[row];
+        st1o(a.logpx + r0 + row, rsn);
+        st1o(a.logw + r0 + row, rsn + nllp[kPanel + row] - nllp[row]);
       }
     }
   }
@@ -576,7 +580,7 @@ __global__ __launch_bounds__(kMT) void mega2v_fwd_bwd(const MegaArgs a) {
       if (row < nrow && c < L2) st4o(a.dqp + (long long)(r0 + row) * L2 + c, ld4(P_dqp + row * V::ldq + c));
     } else {
       const int row = tid >> 5, c = tid & 31;
-      if (row < nrow && c < L2) a.dqp[(long long)(r0 + row) * L2 + c] = P_dqp[row * V::ldq + c];
+      if (row < nrow && c < L2) st1o(a.dqp + (long long)(r0 + row) * L2 + c, P_dqp[row * V::ldq + c]);
     }
   }
   // B3 dhe = (dqp * We1^T) [he > 0]: 4 tiles, contraction L2P (split in two over the wave halves where it is 128)
@@ -621,19 +625,26 @@ __global__ __launch_bounds__(kMT) void mega2v_fwd_bwd(const MegaArgs a) {
         ga -= w_ * t * iv;
         gb += w_ * (1.f - t * t) * iv;
       }
-      out[i] = ga;
-      out[KLp + i] = gb * sigmoidf_(M_raw[k * V::ldM + l]);
+      st1o(out + i, ga);
+      st1o(out + KLp + i, gb * sigmoidf_(M_raw[k * V::ldM + l]));
     }
     if (tid < K) {
       float ga = 0.f;
 #pragma unroll
       for (int row = 0; row < kPanel; ++row) ga -= row < nrow ? P_r[row * 16 + tid] - M_w[tid] : 0.f;
-      out[2 * KLp + tid] = ga;
+      st1o(out + 2 * KLp + tid, ga);
     }
   }
   GMVAE_STAMP(7);
   M2V_SPAN_END();
 #undef M2V_SPAN_END
+  return 2;
+}
+
+template <int MODEL, int LT, int KT>
+__global__ __launch_bounds__(kMT) void mega2v_fwd_bwd(const MegaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  mega2v_body<MODEL, LT, KT, 0>(a, sm);
 }
 
 }  // namespace gmvae

@@ -47,12 +47,13 @@
 #pragma once
 #include "dwadam.hpp"
 #include "mega2.hpp"
+#include "mega2v.hpp"
 
 namespace gmvae {
 
 constexpr int kM3MaxSlots = 320;
 constexpr int kM3MaxT = 8;
-constexpr unsigned short kM3Tail = 0xffffu, kM3None = 0xfffeu, kM3PhaseF = 0x8000u;
+constexpr unsigned short kM3Tail = 0xffffu, kM3None = 0xfffeu, kM3PhaseF = 0x8000u, kM3Gmp = 0xff00u;      // kM3Gmp + i: block i of the mixture prior's variables
 constexpr int kM3FlagLd = 64;                        // rows 0..2: producers q - 1; row 3: the leads
 #ifndef M3_FLAG_REPLICAS
 #define M3_FLAG_REPLICAS 8
@@ -73,6 +74,11 @@ struct M3Fin {                 // what the tiles' optimizer epilogue and the los
   float* tail_log;
   float* img[kImgBufs];
   unsigned* epoch_word;        // bumped by the tail slot for the next step's hand-offs (null: a later launch does it)
+  // VAE_GMP (mega3v_step): the learned mixture prior's variables have no matrix-product gradient -- the leads leave one partial
+  // per panel (gmp_part); "gmp" slots sum them in panel order, apply the update and write the variables' LDS-image copies
+  const float* gmp_part;
+  int gmp_n, gmp_len;
+  long long gmp_off;
 };
 
 struct M3Args {
@@ -84,6 +90,8 @@ struct M3Args {
   unsigned short perm[kM3MaxSlots];   // slot -> (tensor << 10) | tile inside the tensor (| kM3PhaseF); kM3Tail: the loss tail
   DwTensor t[kM3MaxT];
   M3Fin fa;
+  int gmp_nmap;
+  ImgMap gmp_map[3];
 };
 static_assert(sizeof(M3Args) <= 4096, "kernel arguments");
 
@@ -142,39 +150,33 @@ __device__ __forceinline__ void m3_tail(const M3Fin& a, unsigned long long* step
   }
 }
 
-__global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+// The worker phase of a one-launch step (mega3_step, mega3v_step): the calling workgroup -- `role` 1 a producer, 2 a lead, 3 a
+// workgroup that had no per-row role -- stores its flag (NQ producer rows of the flag table, then the leads' row), takes the
+// slots rank, rank + nW, ... of the tile list and runs them.
+template <int NQ>
+__device__ __forceinline__ void m3_worker_phase(const M3Args& aa, float* const sm, const int role, const int q, const int pnl,
+                                                const int rank, const int nW, const unsigned epoch, const unsigned long long step,
+                                                const unsigned spin_limit, const unsigned lr_bits, const bool lr_hit) {
   const MegaArgs& a = aa.m;
   const M3Fin& fa = aa.fa;
-  // what the worker phase needs of the launch's start state (read before anything can have changed it)
-  const unsigned epoch = *a.epoch_word;
-  const unsigned long long step = a.step_dev[0];
-  const unsigned spin_limit = *a.err_word ? 0u : (1u << 19);
-  const unsigned lr_bits = aa.lr_next[0];
-  const bool lr_hit = aa.lr_next[1] == (unsigned)(a.step_dev[0] + 1ull) && aa.lr_next[2] == __float_as_uint(aa.fa.lr) &&
-                      aa.lr_next[3] == alpha_key(aa.fa.b1, aa.fa.b2);
-  if (aa.dbg && threadIdx.x == 0) aa.dbg[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
-  const int role = mega2_body<1>(a, sm);
 #define M3_END() if (a.span && threadIdx.x == 0) a.span[2 * blockIdx.x + 1] = wall_clock64()
 #define M3_ST(i) if (aa.dbg && threadIdx.x == 0) aa.dbg[(size_t)blockIdx.x * 8 + (i)] = wall_clock64()
 #define M3_ST2(i) if (aa.dbg && threadIdx.x == 0) aa.dbg[(size_t)(blockIdx.x + 256) * 8 + (i)] = wall_clock64()
   if (role == 0) { M3_END(); return; }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, lk = lane >> 4;
-  const int B = a.B, nPr = (B + kPanel - 1) / kPanel, nP = (nPr + 1) & ~1;
-  const int bid = blockIdx.x;
-  const int q = bid < nP * 3 ? 1 + bid / nP : 0;
-  const int pnl = bid < nP * 3 ? bid % nP : bid - nP * 3;
+  const int B = a.B, nPr = (B + kPanel - 1) / kPanel;
   M3_ST(0);
-  // the role's stores are acknowledged: the workgroup's flag goes out
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  M3_ST2(0);
-  __syncthreads();             // (also: the per-row role's LDS is dead in every wave)
-  M3_ST2(1);
-  if (tid < kM3FlagReplicas)
-    __hip_atomic_store(aa.flags + tid * kM3FlagRepLd + (role == 2 ? 3 : q - 1) * kM3FlagLd + pnl, epoch, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  const int rank = (q == 0 ? 3 * nPr : (q - 1) * nPr) + pnl, nW = 4 * nPr;
+  if (role != 3) {
+    // the role's stores are acknowledged: the workgroup's flag goes out
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    M3_ST2(0);
+    __syncthreads();           // (also: the per-row role's LDS is dead in every wave)
+    M3_ST2(1);
+    if (tid < kM3FlagReplicas)
+      __hip_atomic_store(aa.flags + tid * kM3FlagRepLd + (role == 2 ? NQ : q - 1) * kM3FlagLd + pnl, epoch, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
   float* const red = sm;                         // [wave][mt * 4 + r][lane]
   float* const redcs = sm + kDwWaves * 64 * 16;  // [wave][lane]
   const bool upd = fa.do_adam != 0;
@@ -191,17 +193,20 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
   // An EARLY poll (wave 0): the flag loads go out BEFORE the tile's operand prefetch -- vmcnt retires in order, so a poll issued
   // behind 44 cold prefetch loads returned with the last of them (a lead's first poll: 2.1 us instead of 1.2) -- and are looked at
   // after the prefetch has been issued.  early_ok: all four rows carried the epoch (then wait_flags below does not poll again).
-  unsigned ef0 = 0, ef1 = 0, ef2 = 0, ef3 = 0;
+  unsigned ef[NQ + 1];
+#pragma unroll
+  for (int r = 0; r <= NQ; ++r) ef[r] = 0u;
   auto early_issue = [&]() {
     if (wave == 0 && seen != 3u) {
-      ef0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ef1 = __hip_atomic_load(f0 + kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ef2 = __hip_atomic_load(f0 + 2 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ef3 = __hip_atomic_load(f0 + 3 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int r = 0; r <= NQ; ++r) ef[r] = __hip_atomic_load(f0 + r * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
   auto early_ok = [&]() -> bool {                  // (meaningful in wave 0 only)
-    return wave == 0 && seen != 3u && __all(ef0 == epoch && ef1 == epoch && ef2 == epoch && (ef3 == epoch || own));
+    bool ok = ef[NQ] == epoch || own;
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) ok = ok && ef[r] == epoch;
+    return wave == 0 && seen != 3u && __all(ok);
   };
   auto wait_flags = [&](const bool leads, const bool pre = false) {
     const unsigned want = leads ? 3u : 1u;
@@ -211,13 +216,14 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
       unsigned spins = 0;
       for (;;) {
         bool ok = true;
-        if (np) {
-          const unsigned f_0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned f_1 = __hip_atomic_load(f0 + kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned f_2 = __hip_atomic_load(f0 + 2 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = f_0 == epoch && f_1 == epoch && f_2 == epoch;
+        if (np) {                                  // (all of the rows' loads in flight together)
+          unsigned fr[NQ];
+#pragma unroll
+          for (int r = 0; r < NQ; ++r) fr[r] = __hip_atomic_load(f0 + r * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int r = 0; r < NQ; ++r) ok = ok && fr[r] == epoch;
         }
-        if (leads) ok = ok && (own || __hip_atomic_load(f0 + 3 * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch);
+        if (leads) ok = ok && (own || __hip_atomic_load(f0 + NQ * kM3FlagLd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch);
         if (__all(ok)) break;
         if (++spins > spin_limit) {
           if (lane == 0) atomicExch(a.err_word, 1u);
@@ -243,6 +249,32 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
       M3_ST(5);
       if (aa.dbg && tid == 0) aa.dbg[(size_t)blockIdx.x * 8 + 6] = 99ull;
       __syncthreads();
+      continue;
+    }
+    if (pv_ >= kM3Gmp) {                           // the mixture prior's variables: partials -> gradient -> TF-Adam -> image
+      wait_flags(true);
+      const int e = (pv_ - kM3Gmp) * kMT + tid;
+      if (e < fa.gmp_len) {
+        const long long i = fa.gmp_off + e;
+        float g = 0.f;
+        for (int k = 0; k < fa.gmp_n; ++k) g += ld_sc(fa.gmp_part + (long long)k * fa.gmp_len + e);      // (panels share lines)
+        fa.grads[i] = g;
+        if (upd && !poisoned) {
+          float pp = fa.p[i], pm = fa.m[i], pv = fa.v[i];
+          adam_update(pp, pm, pv, g, gs, lr_t, omb1, omb2, fa.eps);
+          fa.p[i] = pp; fa.m[i] = pm; fa.v[i] = pv;
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (k < aa.gmp_nmap && i >= aa.gmp_map[k].begin && i < aa.gmp_map[k].end) {
+              const ImgMap& mp = aa.gmp_map[k];
+              const unsigned off = (unsigned)(i - mp.begin);
+              const int r = (int)(((unsigned long long)off * mp.magic) >> 32);
+              const int c = (int)off - r * mp.cols;
+              fa.img[mp.which][img_dst(mp.kind, mp.base, mp.ld, mp.chunk, r, c)] = pp;
+            }
+        }
+      }
+      if (aa.dbg && tid == 0) aa.dbg[(size_t)blockIdx.x * 8 + 6] = 98ull;
       continue;
     }
     const bool phF = (pv_ & kM3PhaseF) != 0;
@@ -397,6 +429,55 @@ __global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
 #undef M3_END
 #undef M3_ST
 #undef M3_ST2
+}
+
+
+__global__ __launch_bounds__(kMT) void mega3_step(const M3Args aa) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const MegaArgs& a = aa.m;
+  const M3Fin& fa = aa.fa;
+  // what the worker phase needs of the launch's start state (read before anything can have changed it)
+  const unsigned epoch = *a.epoch_word;
+  const unsigned long long step = a.step_dev[0];
+  const unsigned spin_limit = *a.err_word ? 0u : (1u << 19);
+  const unsigned lr_bits = aa.lr_next[0];
+  const bool lr_hit = aa.lr_next[1] == (unsigned)(a.step_dev[0] + 1ull) && aa.lr_next[2] == __float_as_uint(aa.fa.lr) &&
+                      aa.lr_next[3] == alpha_key(aa.fa.b1, aa.fa.b2);
+  if (aa.dbg && threadIdx.x == 0) aa.dbg[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
+  // (measured and dropped: pulling the worker phase's kernel-argument lines into the scalar cache here -- the dependent scalar
+  //  loads delay the first layer, the launch's critical path: 32.4 against 31.9 us)
+  const int role = mega2_body<1>(a, sm);
+  const int nPr_ = (a.B + kPanel - 1) / kPanel, nP_ = (nPr_ + 1) & ~1, bid_ = blockIdx.x;
+  const int q_ = bid_ < nP_ * 3 ? 1 + bid_ / nP_ : 0, pnl_ = bid_ < nP_ * 3 ? bid_ % nP_ : bid_ - nP_ * 3;
+  m3_worker_phase<3>(aa, sm, role, q_, pnl_, (q_ == 0 ? 3 * nPr_ : (q_ - 1) * nPr_) + pnl_, 4 * nPr_, epoch, step, spin_limit, lr_bits, lr_hit);
+}
+
+// mega3v_step: the same for the VAE family at small batches (mega2v.hpp: seven workgroups per panel; BASELINE configs[0] / [1]).
+// The per-row part needs only 49 / 112 of the chip's 256 CUs: the grid is padded with workgroups that have NO per-row role
+// and are workers from the launch's first cycle -- they request their tile's parameters, moments and batch operand at once and
+// poll; the leads take no tile at all.  Flag table: rows 0..5 the producers, row 6 the leads.
+template <int MODEL, int LT, int KT>
+__global__ __launch_bounds__(kMT) void mega3v_step(const M3Args aa) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const MegaArgs& a = aa.m;
+  const unsigned epoch = *a.epoch_word;
+  const unsigned long long step = a.step_dev[0];
+  const unsigned spin_limit = *a.err_word ? 0u : (1u << 19);
+  const unsigned lr_bits = aa.lr_next[0];
+  const bool lr_hit = aa.lr_next[1] == (unsigned)(a.step_dev[0] + 1ull) && aa.lr_next[2] == __float_as_uint(aa.fa.lr) &&
+                      aa.lr_next[3] == alpha_key(aa.fa.b1, aa.fa.b2);
+  if (aa.dbg && threadIdx.x == 0) aa.dbg[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
+  const int nP = (a.B + kPanel - 1) / kPanel, bid = blockIdx.x;
+  int role = 3, q = 0, pnl = 0, rank = bid;
+  if (bid < 7 * nP) {
+    role = mega2v_body<MODEL, LT, KT, 1>(a, sm);
+    q = bid < nP * 6 ? 1 + bid / nP : 0;
+    pnl = bid < nP * 6 ? bid % nP : bid - nP * 6;
+    rank = (q == 0 ? 6 * nP : (q - 1) * nP) + pnl;
+  } else if (a.span && threadIdx.x == 0) {
+    a.span[2 * bid] = wall_clock64();
+  }
+  m3_worker_phase<6>(aa, sm, role, q, pnl, rank, (int)gridDim.x, epoch, step, spin_limit, lr_bits, lr_hit);
 }
 
 // adam_tiles: the data-parallel step's optimizer launch behind the all-reduce (scripts/runners.py:183 apply_gradients, scaled by

@@ -502,6 +502,36 @@ def test_one_launch_step_equals_two_launch_step_bit_for_bit(B, monkeypatch):
         assert torch.isfinite(a_).all() and torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("model,Lz,K,B", [("vae", 2, 1, 100), ("vae_gmp", 64, 10, 256), ("vae_gmp", 64, 10, 333)])
+def test_one_launch_step_of_the_vae_family_equals_two_launch_step_bit_for_bit(model, Lz, K, B, monkeypatch):
+    """mega3v_step (csrc/mega3.hpp: mega2v_fwd_bwd's per-row part, the weight-gradient tiles + TF-Adam and -- VAE_GMP -- the mixture
+    prior's update blocks in ONE launch of 256 workgroups, most of them without a per-row role) against mega2v_fwd_bwd -> dw_adam
+    on the same batches (BASELINE configs[0] / configs[1] and a ragged batch): parameters and both Adam moments after 48 steps
+    must agree BIT FOR BIT (scripts/vae.py:153-188, scripts/runners.py:181-183,231-232)."""
+    from gmvae_amd.engine import Engine
+    G, n = 16, 48
+    rng = np.random.default_rng(B)
+    xs = torch.from_numpy((rng.random((G, B, 784)) < 0.87).astype(np.uint8)).cuda()
+    res = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("GMVAE_NO_FUSE", raising=False)
+        else:
+            monkeypatch.setenv("GMVAE_NO_FUSE", "1")
+        e = Engine(model, 784, Lz, K, [64], random_seed=5)
+        sx, replay = e.capture_train_step(B, LR, n_steps=G)
+        sx.copy_(xs)
+        for _ in range(n // G):
+            replay()
+        torch.cuda.synchronize()
+        names = [nm for nm, _, _, _ in e.profile_train_levels(xs[0], lr=LR, iters=2)]
+        assert e.handoff_timeouts() == 0 and int(e.step_dev[0].item()) >= n
+        res.append((e.params.detach().clone(), e.m.clone(), e.v.clone(), names))
+    assert res[0][3] == ["mega3v_step"] and res[1][3] == ["mega2v_fwd_bwd", "dw_adam"], (res[0][3], res[1][3])
+    for a_, b_ in zip(res[0][:3], res[1][:3]):
+        assert torch.isfinite(a_).all() and torch.equal(a_, b_)
+
+
 def test_trajectory_parameters_within_the_measured_gradient_error():
     """The gate of every trajectory's parameters (run after the cases above in file order): element-wise |dtheta| within the
     Adam-derived tolerance at the gradient error THIS session measured (max over all cases of the last-step gradient error at
