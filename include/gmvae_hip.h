@@ -39,7 +39,7 @@ extern "C" {
 
 #define GMVAE_MAX_HIDDEN 8
 #define GMVAE_TAIL 8          /* floats appended to the gradient buffer */
-#define GMVAE_ABI_VERSION 4
+#define GMVAE_ABI_VERSION 5   /* 5: + gmvae_dp_profile, gmvae_forward_profile (measurement hooks); no struct changed */
 
 enum { GMVAE_MODEL_VAE = 0, GMVAE_MODEL_VAE_GMP = 1, GMVAE_MODEL_GMVAE = 2 };
 
