@@ -1931,6 +1931,7 @@ __global__ __launch_bounds__(kDwcThreads, 3) void sk_dwc(const SkArgs a) {
     if (lk == 0) *reinterpret_cast<float4*>(csl + (wave * 16 + ln) * 4) = cs;
   }
   const int n = n0 + 4 * ln;
+  float gown[4][4];                                // this thread's four units of ITS share: the finisher does not read them back
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     if (p) __syncthreads();                        // (the first half's readers are done)
@@ -1952,6 +1953,8 @@ __global__ __launch_bounds__(kDwcThreads, 3) void sk_dwc(const SkArgs a) {
         g[0] += q.x; g[1] += q.y; g[2] += q.z; g[3] += q.w;
       }
       const int m = m0 + TM * (4 * lk + er) + 2 * p + tml;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gown[2 * p + h][j] = g[j];
       if (m < M && n < N) {
         float* const o = out + (long long)T.w_off + (long long)m * N + n;
         if (vecn) st4o(o, make_float4(g[0], g[1], g[2], g[3]));
@@ -2025,32 +2028,29 @@ __global__ __launch_bounds__(kDwcThreads, 3) void sk_dwc(const SkArgs a) {
     }
   }
   // the shares' partials: every load in flight before the first sum (agent-coherent loads: the other share came from another CU)
+  // (only the OTHER share is read back -- 11 MB of agent-scope loads at H = 512 instead of 22: such loads move at the fabric's
+  //  uncached rate, profiles/round5_notes.md; this share's sums are still in registers, and a + b == b + a bit for bit)
+  const long long oth = (long long)(1 - ks) * a.dwp_stride;
   if (vecn) {
-    u32x4_t sv[8];
+    u32x4_t sv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sv[q] = granule2_load(reinterpret_cast<const unsigned long long*>(a.dwp + oth + ei[q]));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3])::"memory");
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int k = 0; k < kSkDwShares; ++k)
-        sv[2 * q + k] = granule2_load(reinterpret_cast<const unsigned long long*>(a.dwp + (long long)k * a.dwp_stride + ei[q]));
-    g2_wait<8>(sv);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) g[q][j] = __uint_as_float(sv[2 * q][j]) + __uint_as_float(sv[2 * q + 1][j]);
+      for (int j = 0; j < 4; ++j) g[q][j] = ks == 0 ? gown[q][j] + __uint_as_float(sv[q][j]) : __uint_as_float(sv[q][j]) + gown[q][j];
   } else {
-    float t[4][4][kSkDwShares];
+    float t[4][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int k = 0; k < kSkDwShares; ++k)
-          t[q][j][k] = __hip_atomic_load(a.dwp + (long long)k * a.dwp_stride + ei[q] + min(j, N - 1 - min(n, N - 1)), __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
+        t[q][j] = __hip_atomic_load(a.dwp + oth + ei[q] + min(j, N - 1 - min(n, N - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[q][j] = t[q][j][0] + t[q][j][1];
+      for (int j = 0; j < 4; ++j) g[q][j] = ks == 0 ? gown[q][j] + t[q][j] : t[q][j] + gown[q][j];
   }
   static_assert(kSkDwShares == 2, "the sums above add two shares");
 #pragma unroll
