@@ -27,7 +27,8 @@ class GmvaeDims(C.Structure):
                 ("n_hidden", C.c_int32), ("hidden", C.c_int32 * MAX_HIDDEN),
                 ("sigma_min", C.c_float), ("raw_sigma_bias", C.c_float), ("temperature", C.c_float),
                 ("gen_bias_init", C.c_float), ("row0", C.c_uint64),
-                ("gen_bias_vec", C.c_void_p), ("gen_bias_len", C.c_int32), ("sched_flags", C.c_int32)]   # ABI v4
+                ("gen_bias_vec", C.c_void_p), ("gen_bias_len", C.c_int32), ("sched_flags", C.c_int32),    # ABI v4
+                ("hidden_act", C.c_int32)]                                                                  # ABI v6
 
 
 class GmvaeParamEntry(C.Structure):
@@ -101,8 +102,11 @@ def check(rc: int, what: str):
 SCHED_SAFE = 1        # GmvaeDims.sched_flags: only schedules without waits between the workgroups of a launch
 
 
+ACTS = {"relu": 0, "tanh": 1, "sigmoid": 2, "elu": 3}       # GMVAE_ACT_*: GmvaeDims.hidden_act
+
+
 def make_dims(B, D, L, K, hidden, S=1, sigma_min=0.0, raw_sigma_bias=0.5, temperature=1.0, gen_bias_init=0.0, row0=0,
-              gen_bias_vec=None, sched_flags=0):
+              gen_bias_vec=None, sched_flags=0, hidden_act="relu"):
     """gen_bias_vec: fp32 device tensor [D] (ConditionalBernoulli's vector bias_init, scripts/base.py:102-103) or None;
     the caller keeps it alive for as long as the dims are used."""
     hidden = list(hidden)
@@ -115,6 +119,7 @@ def make_dims(B, D, L, K, hidden, S=1, sigma_min=0.0, raw_sigma_bias=0.5, temper
     d.sigma_min, d.raw_sigma_bias = float(sigma_min), float(raw_sigma_bias)
     d.temperature, d.gen_bias_init = float(temperature), float(gen_bias_init)
     d.sched_flags = int(sched_flags)
+    d.hidden_act = ACTS[hidden_act] if isinstance(hidden_act, str) else int(hidden_act)
     d.row0 = int(row0)          # data parallel: global index of this device's first batch row (Philox counters only)
     if gen_bias_vec is not None:
         if gen_bias_vec.numel() != int(D) or not gen_bias_vec.is_cuda or not gen_bias_vec.is_contiguous():

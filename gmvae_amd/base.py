@@ -21,11 +21,22 @@ from . import _lib as L
 TINY = 1.1754943508222875e-38
 
 
-def _check_relu(fn):
-    if fn is None or fn in (torch.relu, F.relu, "relu") or getattr(fn, "__name__", "") == "relu":
-        return
-    raise NotImplementedError("the HIP kernels fuse ReLU (the reference default, scripts/vae.py:196); "
-                              f"hidden_activation_fn={fn!r} is not supported")
+def activation_name(fn) -> str:
+    """hidden_activation_fn (scripts/base.py:19,90,153: any callable; the factories pass ONE to every network, gmvae.py:282,
+    vae.py:196) -> the kind the kernels implement: relu (the reference's default tf.nn.relu), tanh, sigmoid, elu.  A name
+    or the torch / torch.nn.functional callable; anything else raises (an arbitrary Python callable cannot run in a kernel)."""
+    if fn is None:
+        return "relu"
+    table = {"relu": (torch.relu, F.relu), "tanh": (torch.tanh, F.tanh), "sigmoid": (torch.sigmoid, F.sigmoid), "elu": (F.elu,)}
+    for name, fns in table.items():
+        if fn == name or any(fn is f for f in fns) or getattr(fn, "__name__", "") == name:
+            return name
+    raise NotImplementedError(f"hidden_activation_fn={fn!r}: the HIP kernels implement relu (the reference default, "
+                              f"scripts/vae.py:196), tanh, sigmoid and elu")
+
+
+def _check_relu(fn):          # (kept name: validates, returns nothing)
+    activation_name(fn)
 
 
 # scripts/base.py:12 DEFAULT_INITIALIZERS = {'w': xavier, 'b': zeros}: what Engine.init_parameters draws.  A custom

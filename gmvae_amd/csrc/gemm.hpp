@@ -59,7 +59,8 @@ struct Problem {
   int tiles_m, tiles_n, splits, tile_begin;
   int epi;
   int ldc;
-  int relu;
+  int relu;                // activation of the epilogue: 0 none, 1 ReLU, 2 tanh, 3 sigmoid, 4 ELU (GMVAE_ACT_* + 1)
+  int mask_act;            // whose derivative `mask` (the KEPT activation) stands for: 0 / 1 ReLU (keep where mask > 0), 2.. as above
   int ld_add, add_div;
   int ld_mask;
   int ldx, x_div, nparts;
@@ -87,6 +88,20 @@ struct Problem {
   Segment seg[2];
 };
 
+// hidden_activation_fn in an epilogue (kind = GMVAE_ACT_* + 1; precise forms: these layers are not the ReLU fast paths) and
+// its derivative as a function of the KEPT activation h = f(pre): tanh' = 1 - h^2, sigmoid' = h (1 - h), elu' = h > 0 ? 1 : h + 1
+__device__ __forceinline__ float act_apply(const float x, const int kind) {
+  if (kind <= 1) return fmaxf(x, 0.f);
+  if (kind == 2) return tanhf(x);
+  if (kind == 3) return 1.f / (1.f + expf(-x));
+  return x > 0.f ? x : expm1f(x);
+}
+__device__ __forceinline__ float act_mask(const float x, const float h, const int kind) {
+  if (kind <= 1) return h > 0.f ? x : 0.f;
+  if (kind == 2) return x * (1.f - h * h);
+  if (kind == 3) return x * (h * (1.f - h));
+  return h > 0.f ? x : x * (h + 1.f);
+}
 struct Launch {
   // header: all a workgroup needs before it knows its problem, adjacent so that ONE scalar load fetches it (every
   // dependent round of kernel-argument loads costs ~0.3 us at a launch's cold start)
@@ -1059,6 +1074,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
     const float* mask = L.p[pi].mask;
     const float* rowscale = L.p[pi].rowscale;
     const int relu = L.p[pi].relu, ld_add = L.p[pi].ld_add, add_div = L.p[pi].add_div, ld_mask = L.p[pi].ld_mask;
+    const int mask_act = L.p[pi].mask_act;
     const long long soff = (long long)split * L.p[pi].split_stride;
     unsigned short* const C3s = L.p[pi].C3;        // (EPI_STORE with bias / ReLU: the activation also leaves as planes; never with splits)
     const long long c3ss = L.p[pi].c3_stride;
@@ -1116,8 +1132,8 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float x = v[j];
-            if (relu) x = fmaxf(x, 0.f);
-            x = kk[j] > 0.f ? x : 0.f;
+            if (relu) x = act_apply(x, relu);
+            x = mask ? act_mask(x, kk[j], mask_act) : x;
             v[j] = x * rs[q];
           }
           *reinterpret_cast<float4*>(Cout + soff + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1156,8 +1172,8 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
           if (bias2) x += bias2[n];
           if (addsrc) x += addsrc[(long long)(m / add_div) * ld_add + n];
           x += addconst;
-          if (relu) x = fmaxf(x, 0.f);
-          if (mask) x = mask[(long long)m * ld_mask + n] > 0.f ? x : 0.f;
+          if (relu) x = act_apply(x, relu);
+          if (mask) x = act_mask(x, mask[(long long)m * ld_mask + n], mask_act);
           v[j] = x * rs;
         }
         if (nb + 3 < N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {

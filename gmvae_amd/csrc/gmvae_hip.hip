@@ -112,6 +112,7 @@ static int check_dims(const GmvaeDims* d, int model) {
   if (d->gen_bias_vec ? d->gen_bias_len != d->D : d->gen_bias_len != 0) return GMVAE_E_DIMS;
   if (d->gen_bias_vec && (reinterpret_cast<uintptr_t>(d->gen_bias_vec) & 3)) return GMVAE_E_ALIGN;
   if ((long long)d->B * d->S > (1LL << 30)) return GMVAE_E_DIMS;
+  if (d->hidden_act < GMVAE_ACT_RELU || d->hidden_act > GMVAE_ACT_ELU) return GMVAE_E_DIMS;
   return 0;
 }
 
@@ -184,7 +185,7 @@ static int fwd_splits(int D) {
 // (the *_shape predicates read the dims only: carve() sizes the workspace with them, so that its layout never depends on an
 //  environment switch; the *_ok forms add the switches and choose the schedule)
 static bool mega_shape(const GmvaeDims& d, int model) {
-  if (d.n_hidden != 1 || d.S != 1 || d.D % 16) return false;
+  if (d.n_hidden != 1 || d.S != 1 || d.D % 16 || d.hidden_act != GMVAE_ACT_RELU) return false;
   if (d.gen_bias_vec) return false;            // the vector bias_init is applied by the grouped GEMM's epilogue (Problem::bias2)
   const int H = d.hidden[0];
   if (H % 16 || H > 64 || d.L % 2 || d.L > 128 || d.K > 64) return false;      // L even: k-steps of 4 over [mu | raw]
@@ -227,7 +228,7 @@ constexpr int kSkMaxB = 4096;       // hard bound of the skinny schedule's batch
 static bool skinny_shape(const GmvaeDims& d, int model) {
   // GMVAE; the VAE with the standard-normal prior (no y path: eight launches); VAE_GMP (the learned mixture prior is not
   // column-local: its log-density, its share of dz and its variables' gradients stay three row kernels: eleven launches)
-  if (d.n_hidden != 1 || d.S != 1) return false;
+  if (d.n_hidden != 1 || d.S != 1 || d.hidden_act != GMVAE_ACT_RELU) return false;
   const int H = d.hidden[0];
   // measured against the general schedule at H = 128 / 256 / 512, L = 128 (tools/sk_sweep.py, one box): 2.9x faster at B = 32..64,
   // 2.4 - 2.6x at 256, 1.9 - 2.1x at 512, 1.8 - 1.9x at 1024, 1.5 - 1.6x at 2048, 1.2 - 1.4x at 4096 (round 4: the forms for
@@ -245,7 +246,7 @@ static bool skinny_ok(const GmvaeDims& d, int model) {
   return skinny_shape(d, model) && d.B <= maxb;
 }
 static bool fused_shape(const GmvaeDims& d, int model) {
-  if (model != GMVAE_MODEL_GMVAE || d.n_hidden != 1 || d.S != 1) return false;
+  if (model != GMVAE_MODEL_GMVAE || d.n_hidden != 1 || d.S != 1 || d.hidden_act != GMVAE_ACT_RELU) return false;
   const int H = d.hidden[0];
   if (H % 16 || H > 64 || d.L % 8 || d.L > 128 || d.K > 64) return false;
   const int f = fwd_lay(H, d.L, d.K).total, b = bwd_lay(H, d.L, d.K).total;
@@ -281,6 +282,7 @@ static int num_splits_small(long long R) {
 static bool planes_ok(const GmvaeDims& d, const Layout& L) {
   const char* e = getenv("GMVAE_NO_PLANES");
   if (e && atoi(e)) return false;
+  if (d.hidden_act != GMVAE_ACT_RELU) return false;     // (the plane producers' epilogues are the ReLU ones)
   const long long R = (long long)d.B * d.S;
   const int Ht = L.dec.dim[L.dec.nl - 1];
   long long minr = 4096;
@@ -420,6 +422,9 @@ static Problem blank() {
   return p;
 }
 // C[M,N] = act(A[M,K] W[K,N] + bias)
+// hidden_activation_fn of the step being enqueued on this host thread (Problem::relu / mask_act kinds: GMVAE_ACT_* + 1);
+// set by run_step / gmvae_mlp_forward from GmvaeDims::hidden_act
+static thread_local int tl_hact = 1;
 static Problem p_nn(const void* A, bool u8, int lda, const float* W, int ldw, int M, int N, int K, float* C,
                     int ldc, const float* bias, bool relu) {
   Problem p = blank();
@@ -427,7 +432,7 @@ static Problem p_nn(const void* A, bool u8, int lda, const float* W, int ldw, in
   p.seg[0].a = opnd(A, lda, M, u8, true);
   p.seg[0].b = opnd(W, ldw, N, false, false);
   p.seg[0].K = K;
-  p.C = C; p.ldc = ldc; p.bias = bias; p.relu = relu;
+  p.C = C; p.ldc = ldc; p.bias = bias; p.relu = relu ? tl_hact : 0;
   return p;
 }
 // dX[M,N] = dY[M,K] W[N,K]^T  (W row-major [N rows, ldw])
@@ -438,7 +443,7 @@ static Problem p_nt(const float* dY, int ldy, const float* W, int ldw, int M, in
   p.seg[0].a = opnd(dY, ldy, M, false, true);
   p.seg[0].b = opnd(W, ldw, N, false, true);
   p.seg[0].K = K;
-  p.C = C; p.ldc = ldc; p.mask = mask; p.ld_mask = ld_mask;
+  p.C = C; p.ldc = ldc; p.mask = mask; p.ld_mask = ld_mask; p.mask_act = tl_hact;
   return p;
 }
 // dW[in,out] = Act[rows,in]^T dY[rows,out] (+ db = column sums of dY), split-K over rows into slabs
@@ -1707,16 +1712,18 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   float* gu = (gm && !u) ? w.u : nullptr;
   if (ge) eps = ge;
   if (gu) u = gu;
+  tl_hact = 1 + d.hidden_act;                  // (every Problem built below for this step: its epilogue's activation kind)
   if (a.backward && mega_ok(d, model)) return run_step_mega(cx, a, L, w, eps, u, ge, gu);
   if (a.backward && skinny_ok(d, model)) return run_step_skinny(cx, a, L, w, eps, u, ge, gu);
   if (fused_ok(d, model) && !a.z_out && !a.y_out && !a.logits_out)
     return run_step_fused(cx, a, L, w, eps, u, ge, gu);
   // (general schedule: the Philox fill rides as auxiliary workgroups of the first GEMM launch below)
   const bool noise_aux = ge || gu;
+  const bool relu_act = d.hidden_act == GMVAE_ACT_RELU;      // (tanh / sigmoid / ELU: the grouped GEMM's epilogues only)
 
   // row-panel layers over thousands of rows as register-direct bf16 piece products (skinny.hpp rows_nn_bf6): K % 32 = 0, widths
   // % 64 = 0, R >= 2048 -- else the grouped GEMM
-  auto rows_ok = [&](int Kd, int N0, int N1) { return R >= 2048 && Kd % 32 == 0 && N0 % 64 == 0 && N1 % 64 == 0; };
+  auto rows_ok = [&](int Kd, int N0, int N1) { return relu_act && R >= 2048 && Kd % 32 == 0 && N0 % 64 == 0 && N1 % 64 == 0; };
   auto launch_rows = [&](RowsArgs& ra, const char* name) {
     const int nct = (ra.p[0].N + (ra.np > 1 ? ra.p[1].N : 0)) / 64;
     int rt = 4;
@@ -1743,7 +1750,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   // ================================ forward ================================
   const NetL& E = gm ? L.ency : L.enc;
   const int flx_h0 = E.dim[1], flx_h1 = gm ? L.encg.dim[1] : 0;
-  if (D % 16 == 0 && flx_h0 % 64 == 0 && flx_h1 % 64 == 0 && E.nl > 1) {
+  if (relu_act && D % 16 == 0 && flx_h0 % 64 == 0 && flx_h1 % 64 == 0 && E.nl > 1) {
     // first layers over the uint8 batch as exact bf16 piece products (skinny.hpp first_layers_u8bf); the Philox fill in a
     // launch of its own
     FlxArgs f;
@@ -2220,6 +2227,7 @@ int gmvae_mlp_forward(const GmvaeDims* dims, int model, int net, const void* in,
   if (net == GMVAE_NET_ENCODER_GMM && !in2) return GMVAE_E_NULL;
   Ctx cx;
   cx.st = static_cast<hipStream_t>(stream);
+  tl_hact = 1 + d.hidden_act;
   float** hbuf = (net == GMVAE_NET_DECODER) ? w.hd : (net == GMVAE_NET_ENCODER_GMM ? w.hg : w.he);
   const float* P = params;
   for (int i = 0; i < N->nl; ++i) {
@@ -2287,6 +2295,7 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
     Problem p;
     const float* fa = reinterpret_cast<const float*>(pa);
     const float* fb = reinterpret_cast<const float*>(pb);
+    tl_hact = 1;
     if (trans == 0) p = p_nn(fa, false, K, fb, N, M, N, K, C, N, bias, relu != 0);
     else if (trans == 1) p = p_nt(fa, K, fb, K, M, N, K, C, N, nullptr, 0);
     else p = p_tn(fa, false, M, 1, fb, N, M, N, K, C, bias ? C + (size_t)M * N : nullptr, splitk, (long long)(M + 1) * N, nullptr);
@@ -2297,6 +2306,7 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
     return cx.err;
   }
   if (trans == 0) {
+    tl_hact = 1;
     g.add(p_nn(A, a_is_u8 != 0, K, W, N, M, N, K, C, N, bias, relu != 0));
   } else if (trans == 1) {
     g.add(p_nt(static_cast<const float*>(A), K, W, K, M, N, K, C, N, nullptr, 0));

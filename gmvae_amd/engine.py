@@ -40,7 +40,7 @@ class _ElboFn(torch.autograd.Function):
 class Engine:
     def __init__(self, model: str, data_size: int, latent_size: int, mixture_components: int,
                  hidden: Sequence[int], n_samples: int = 1, sigma_min: float = 0.0, raw_sigma_bias: float = 0.5,
-                 temperature: float = 1.0, gen_bias_init=0.0, random_seed: Optional[int] = None):
+                 temperature: float = 1.0, gen_bias_init=0.0, random_seed: Optional[int] = None, hidden_act: str = "relu"):
         """gen_bias_init: a scalar or a vector of data_size values (scripts/base.py:102-103: "a scalar or vector Tensor
         that is added to the output of the fully connected network", e.g. the logit of the training-set mean)."""
         self.device = L.require_gpu()
@@ -63,8 +63,11 @@ class Engine:
                 gen_bias_init = 0.0
             else:
                 raise ValueError(f"gen_bias_init must be a scalar or a vector of data_size = {self.D} values, got {gb.numel()}")
+        if hidden_act not in L.ACTS:
+            raise ValueError(f"hidden_act must be one of {sorted(L.ACTS)} (hidden_activation_fn, scripts/base.py:19), got {hidden_act!r}")
+        self.hidden_act = hidden_act
         self.hp = dict(sigma_min=sigma_min, raw_sigma_bias=raw_sigma_bias, temperature=temperature,
-                       gen_bias_init=float(gen_bias_init))
+                       gen_bias_init=float(gen_bias_init), hidden_act=hidden_act)
         self.safe_schedule = False              # use_safe_schedule(): the schedules without mutual waits (per engine)
         d0 = self.dims(1)
         self.P, self.P_real = L.param_count(d0, self.model)

@@ -129,10 +129,9 @@ def create_gmvae(data_size, latent_size, mixture_components=1, fcnet_hidden_size
     """Factory with the signature of scripts/gmvae.py:277-287 (+ n_samples)."""
     if fcnet_hidden_sizes is None:
         fcnet_hidden_sizes = [latent_size]                     # scripts/gmvae.py:316-317
-    base._check_relu(hidden_activation_fn)
     engine = Engine("gmvae", data_size, latent_size, mixture_components, fcnet_hidden_sizes, n_samples=n_samples,
                     sigma_min=sigma_min, raw_sigma_bias=raw_sigma_bias, temperature=temperature,
-                    gen_bias_init=gen_bias_init, random_seed=random_seed)
+                    gen_bias_init=gen_bias_init, random_seed=random_seed, hidden_act=base.activation_name(hidden_activation_fn))
     prior_gmm = base.ConditionalNormal(size=latent_size, hidden_layer_sizes=None,
                                        hidden_activation_fn=hidden_activation_fn, sigma_min=sigma_min,
                                        raw_sigma_bias=raw_sigma_bias, name="prior_gmm").bind(engine, L.NET_PRIOR_GMM)

@@ -101,11 +101,10 @@ def create_vae(data_size, latent_size, mixture_components=1, fcnet_hidden_sizes=
     IWAE extension of SURVEY.md A15; 1 == the reference)."""
     if fcnet_hidden_sizes is None:
         fcnet_hidden_sizes = [latent_size]                     # scripts/vae.py:228-229
-    base._check_relu(hidden_activation_fn)
     name = "vae_gmp" if mixture_components > 1 else "vae"
     engine = Engine(name, data_size, latent_size, mixture_components, fcnet_hidden_sizes, n_samples=n_samples,
                     sigma_min=sigma_min, raw_sigma_bias=raw_sigma_bias, gen_bias_init=gen_bias_init,
-                    random_seed=random_seed)
+                    random_seed=random_seed, hidden_act=base.activation_name(hidden_activation_fn))
     if mixture_components > 1:
         def prior():
             v = engine.views()

@@ -39,7 +39,7 @@ extern "C" {
 
 #define GMVAE_MAX_HIDDEN 8
 #define GMVAE_TAIL 8          /* floats appended to the gradient buffer */
-#define GMVAE_ABI_VERSION 5   /* 5: + gmvae_dp_profile, gmvae_forward_profile (measurement hooks); no struct changed */
+#define GMVAE_ABI_VERSION 6   /* 5: + gmvae_dp_profile, gmvae_forward_profile; 6: GmvaeDims.hidden_act appended */
 
 enum { GMVAE_MODEL_VAE = 0, GMVAE_MODEL_VAE_GMP = 1, GMVAE_MODEL_GMVAE = 2 };
 
@@ -86,8 +86,14 @@ typedef struct GmvaeDims {
    * caller sets it after a hand-off timeout (the workspace's error word) -- per call, not per process.  It changes neither
    * sizes, layouts nor the workspace. */
   int32_t sched_flags;
+  /* ABI v6 -- hidden_activation_fn of every conditional's MLP (scripts/base.py:19,90,153 take any callable; gmvae.py:282 and
+   * vae.py:196 pass ONE to all networks; default tf.nn.relu): GMVAE_ACT_*.  Steps with an activation other than ReLU run the
+   * general schedule (one grouped-GEMM launch per dependency level: the activation in the forward epilogue, its derivative --
+   * a function of the kept activation -- in the data-gradient epilogue). */
+  int32_t hidden_act;
 } GmvaeDims;
 enum { GMVAE_SCHED_SAFE = 1 };
+enum { GMVAE_ACT_RELU = 0, GMVAE_ACT_TANH = 1, GMVAE_ACT_SIGMOID = 2, GMVAE_ACT_ELU = 3 };
 
 /* One tensor of the flat parameter buffer.  Names are the reference's TF
  * variable names (scripts/base.py:53,60 '<name>_fcnet/linear_<i>/{w,b}';

@@ -46,6 +46,8 @@ class Dims:
     raw_sigma_bias: float = 0.5      # runners.py:85
     temperature: float = 1.0         # runners.py:86
     gen_bias_init: object = 0.0      # gmvae.py:285 / vae.py:199; scalar, or a vector [D] (base.py:102-103 "scalar or vector Tensor")
+    act: str = "relu"                # hidden_activation_fn of every conditional's MLP (base.py:19,90,153; gmvae.py:282, vae.py:196):
+                                     # "relu" (the reference's default: tf.nn.relu), "tanh", "sigmoid", "elu"
 
 
 # --------------------------------------------------------------------------
@@ -132,7 +134,36 @@ def _log_softmax(a):
     return s - np.log(np.exp(s).sum(axis=-1, keepdims=True))
 
 
-def _mlp_fwd(p, name, n_layers, x, pres=None):
+ACTS = ("relu", "tanh", "sigmoid", "elu")
+
+
+def _act(h, act):
+    """tf.nn.relu / tf.tanh / tf.sigmoid / tf.nn.elu (alpha = 1) on a pre-activation."""
+    if act == "relu":
+        return np.maximum(h, 0)
+    if act == "tanh":
+        return np.tanh(h)
+    if act == "sigmoid":
+        return sigmoid(h)
+    if act == "elu":
+        return np.where(h > 0, h, np.expm1(np.minimum(h, 0)))
+    raise ValueError(act)
+
+
+def _dact(a, act):
+    """f'(pre) as a function of the ACTIVATION a = f(pre) (what the backward pass keeps)."""
+    if act == "relu":
+        return (a > 0).astype(a.dtype)
+    if act == "tanh":
+        return 1 - a * a
+    if act == "sigmoid":
+        return a * (1 - a)
+    if act == "elu":
+        return np.where(a > 0, 1.0, a + 1.0).astype(a.dtype)
+    raise ValueError(act)
+
+
+def _mlp_fwd(p, name, n_layers, x, pres=None, act="relu"):
     """snt.nets.MLP, activate_final=False, relu hidden (base.py:47-60).
     Returns output and the list of layer inputs [h_0 .. h_n]; `pres` (a list,
     optional) receives (pre-activation, sum_k |input_k| |w_kj| + |b_j|) of every
@@ -147,12 +178,12 @@ def _mlp_fwd(p, name, n_layers, x, pres=None):
         if i < n_layers - 1:
             if pres is not None:
                 pres.append((h, np.abs(a) @ np.abs(w) + np.abs(b)))
-            h = np.maximum(h, 0)
+            h = _act(h, act)
             hs.append(h)
     return h, hs
 
 
-def _mlp_bwd(p, g, name, n_layers, hs, dout, need_dx=True, masks=None):
+def _mlp_bwd(p, g, name, n_layers, hs, dout, need_dx=True, masks=None, act="relu"):
     """Closed-form backward of _mlp_fwd.  hs[i] is the input
     of layer i; hs[i>0] is post-ReLU so the mask is hs[i] > 0 -- unless
     `masks[i]` (bool, same shape) names the subgradient to take: at a
@@ -166,8 +197,11 @@ def _mlp_bwd(p, g, name, n_layers, hs, dout, need_dx=True, masks=None):
         if i > 0 or need_dx:
             d = d @ p[f"{name}_fcnet/linear_{i}/w"].T
             if i > 0:
-                mk = masks[i] if (masks is not None and i < len(masks) and masks[i] is not None) else (hs[i] > 0)
-                d = d * mk
+                if masks is not None and i < len(masks) and masks[i] is not None:
+                    assert act == "relu", "subgradient masks are a ReLU matter"
+                    d = d * masks[i]
+                else:
+                    d = d * _dact(hs[i], act)
     return d
 
 
@@ -205,7 +239,7 @@ def forward(model: int, d: Dims, p: Dict[str, np.ndarray], x: np.ndarray,
         T = dtype(d.temperature)
         u = np.asarray(u, dtype).reshape(R, K)
         pre_y, pre_g = [], []
-        logits, hs_y = _mlp_fwd(p, "encoder_y", nl, xf, pre_y)     # gmvae.py:238
+        logits, hs_y = _mlp_fwd(p, "encoder_y", nl, xf, pre_y, act=d.act)     # gmvae.py:238
         g = -np.log(-np.log(u))                                    # A9 Gumbel
         a = (np.repeat(logits, S, axis=0) + g) / T
         y = np.exp(_log_softmax(a))                                # gmvae.py:240
@@ -214,14 +248,14 @@ def forward(model: int, d: Dims, p: Dict[str, np.ndarray], x: np.ndarray,
         nent_b = (pi * lnpi).sum(axis=1)                           # gmvae.py:262, utils.py:165-170
         pp = y @ p["prior_gmm_fcnet/linear_0/w"] + p["prior_gmm_fcnet/linear_0/b"]  # gmvae.py:243
         mu_p, sig_p, raw_p = _normal_head(pp, L, c, smin)
-        qp, hs_g = _mlp_fwd(p, "encoder_gmm", nl, np.concatenate([xr, y], axis=1), pre_g)  # gmvae.py:246, base.py:66
+        qp, hs_g = _mlp_fwd(p, "encoder_gmm", nl, np.concatenate([xr, y], axis=1), pre_g, act=d.act)  # gmvae.py:246, base.py:66
         C["pre"] = {"encoder_y": pre_y, "encoder_gmm": pre_g}
         C.update(logits=logits, hs_y=hs_y, y=y, pi=pi, lnpi=lnpi, nent_b=nent_b, pp=pp,
                  mu_p=mu_p, sig_p=sig_p, raw_p=raw_p, hs_g=hs_g, gumbel=g)
         enc_name = "encoder_gmm"
     else:
         pre_e = []
-        qp, hs_e = _mlp_fwd(p, "encoder", nl, xf, pre_e)           # vae.py:170
+        qp, hs_e = _mlp_fwd(p, "encoder", nl, xf, pre_e, act=d.act)           # vae.py:170
         C["pre"] = {"encoder": pre_e}
         if S > 1:
             qp = np.repeat(qp, S, axis=0)
@@ -247,7 +281,7 @@ def forward(model: int, d: Dims, p: Dict[str, np.ndarray], x: np.ndarray,
         C.update(resp=np.exp(comp - logp[:, None]), gmp_t=t, gmp_s=s, lnw=lnw)
 
     pre_d = []
-    lam, hs_d = _mlp_fwd(p, "decoder", nl, z, pre_d)               # gmvae.py:251 / vae.py:174
+    lam, hs_d = _mlp_fwd(p, "decoder", nl, z, pre_d, act=d.act)               # gmvae.py:251 / vae.py:174
     C["pre"]["decoder"] = pre_d
     lam = lam + np.asarray(d.gen_bias_init, dtype)                 # base.py:135 (scalar or [D] vector, broadcast over rows)
     logpx = (xr * lam - softplus(lam)).sum(axis=1)                 # A8, gmvae.py:254
@@ -287,7 +321,7 @@ def loss_and_grads(model: int, d: Dims, p, x, eps, u=None, dtype=np.float64, rel
     z, mu_q, sig_q, eps_ = C["z"], C["mu_q"], C["sig_q"], C["eps"]
 
     dlam = w * (sigmoid(C["lam"]) - C["xr"])
-    dz_dec = _mlp_bwd(p, g, "decoder", nl, C["hs_d"], dlam, masks=rm.get("decoder"))
+    dz_dec = _mlp_bwd(p, g, "decoder", nl, C["hs_d"], dlam, masks=rm.get("decoder"), act=d.act)
 
     if model == MODEL_GMVAE:
         t = (z - C["mu_p"]) / C["sig_p"]
@@ -315,17 +349,17 @@ def loss_and_grads(model: int, d: Dims, p, x, eps, u=None, dtype=np.float64, rel
         dpp = np.concatenate([dmu_p, draw_p], axis=1)
         g["prior_gmm_fcnet/linear_0/w"] = C["y"].T @ dpp
         g["prior_gmm_fcnet/linear_0/b"] = dpp.sum(axis=0)
-        dxy = _mlp_bwd(p, g, "encoder_gmm", nl, C["hs_g"], dqp, masks=rm.get("encoder_gmm"))    # [R, D+K]
+        dxy = _mlp_bwd(p, g, "encoder_gmm", nl, C["hs_g"], dqp, masks=rm.get("encoder_gmm"), act=d.act)    # [R, D+K]
         dy = dxy[:, d.D:] + dpp @ p["prior_gmm_fcnet/linear_0/w"].T
         y = C["y"]
         da = y * (dy - (y * dy).sum(axis=1, keepdims=True))
         dl = (da / dtype(d.temperature)).reshape(B, S, K).sum(axis=1)
         pi, lnpi = C["pi"], C["lnpi"]
         dl = dl + (pi * (lnpi - C["nent_b"][:, None])) / B
-        _mlp_bwd(p, g, "encoder_y", nl, C["hs_y"], dl, need_dx=False, masks=rm.get("encoder_y"))
+        _mlp_bwd(p, g, "encoder_y", nl, C["hs_y"], dl, need_dx=False, masks=rm.get("encoder_y"), act=d.act)
     else:
         dq_b = dqp.reshape(B, S, 2 * L).sum(axis=1) if S > 1 else dqp
-        _mlp_bwd(p, g, "encoder", nl, C["hs_e"], dq_b, need_dx=False, masks=rm.get("encoder"))
+        _mlp_bwd(p, g, "encoder", nl, C["hs_e"], dq_b, need_dx=False, masks=rm.get("encoder"), act=d.act)
     C["dlam"], C["dqp"] = dlam, dqp
     return C, g
 

@@ -12,7 +12,8 @@ def dims_of(d: O.Dims, B: int):
     gb = np.asarray(d.gen_bias_init, np.float32)
     vec = torch.from_numpy(gb.copy()).cuda() if gb.ndim else None        # vector bias_init (ABI v3)
     cd = L.make_dims(B, d.D, d.L, d.K, d.hidden, S=d.S, sigma_min=d.sigma_min, raw_sigma_bias=d.raw_sigma_bias,
-                     temperature=d.temperature, gen_bias_init=0.0 if gb.ndim else float(gb), gen_bias_vec=vec)
+                     temperature=d.temperature, gen_bias_init=0.0 if gb.ndim else float(gb), gen_bias_vec=vec,
+                     hidden_act=getattr(d, "act", "relu"))
     cd._keep_vec = vec                                                    # the struct holds a raw device pointer
     return cd
 
@@ -147,7 +148,7 @@ def compare_step(model, d, p, x, eps, u, loss_rtol=1e-4, grad_rtol=1e-4):
         return out
 
     errs = grad_errs(g)
-    if max(e for _, e in errs) > grad_rtol:
+    if max(e for _, e in errs) > grad_rtol and getattr(d, "act", "relu") == "relu":
         # a gradient outside its gate: the device's ReLU took another side than fp64 somewhere?  Legitimate only at units that are
         # numerically zero in fp64 (check_masks asserts it); the oracle then takes the device's subgradients and the gates apply
         who = [k for k, v in O.MODEL_NAMES.items() if v == model][0]

@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol(L):
     for sym in declared:
         assert hasattr(raw, sym), f"{sym} declared in include/gmvae_hip.h but not exported"
     assert declared == set(L.EXPORTS)
-    assert L.lib.gmvae_abi_version() == 5
+    assert L.lib.gmvae_abi_version() == 6
 
 
 @pytest.mark.parametrize("name,d", [
@@ -86,7 +86,7 @@ def test_dims_struct_matches_the_header(L):
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = re.findall(r"(\w+)(?:\[\w+\])?;", body)
     assert names == [f[0] for f in L.GmvaeDims._fields_]
-    assert C.sizeof(L.GmvaeDims) == 6 * 4 + 8 * 4 + 4 * 4 + 8 + 8 + 4 + 4
+    assert C.sizeof(L.GmvaeDims) == 6 * 4 + 8 * 4 + 4 * 4 + 8 + 8 + 4 + 4 + 4 + 4      # (v6: + hidden_act, + tail padding to 8)
 
 
 def test_initializers_and_device_flags_are_checked_on_the_host(monkeypatch):
@@ -100,8 +100,10 @@ def test_initializers_and_device_flags_are_checked_on_the_host(monkeypatch):
     for bad in ({"w": 3}, {"q": lambda s: 0}, "xavier", {}):
         with pytest.raises(TypeError):
             base.ConditionalCategorical(4, [8], initializers=bad)
+    for ok in (torch.relu, torch.tanh, torch.sigmoid, torch.nn.functional.elu, "elu", None):      # scripts/base.py:19: the kinds the kernels implement
+        base.ConditionalNormal(4, [8], hidden_activation_fn=ok)
     with pytest.raises(NotImplementedError):
-        base.ConditionalNormal(4, [8], hidden_activation_fn=torch.tanh)
+        base.ConditionalNormal(4, [8], hidden_activation_fn=torch.sin)
     monkeypatch.delenv("LOCAL_RANK", raising=False)
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
     sel = runners.select_device

@@ -207,6 +207,34 @@ STEP_CASES = [
     ("gmvae", O.Dims(D=208, L=64, K=64, hidden=(64, 128), S=3), 700),
     ("vae", O.Dims(D=256, L=32, K=1, hidden=(128, 128)), 2100),
 ]
+# hidden_activation_fn other than ReLU (scripts/base.py:19,90,153; gmvae.py:282, vae.py:196): tanh / sigmoid / ELU in the grouped
+# GEMM's epilogues (forward: the activation; data gradient: its derivative from the kept activation) -- all three models, two hidden
+# layers, IWAE rows, the reference's default sizes (which must leave the ReLU-only one-launch schedules), thousands of rows
+ACT_CASES = [
+    ("gmvae", O.Dims(D=300, L=16, K=10, hidden=(48, 32), act="tanh"), 50),
+    ("vae", O.Dims(D=784, L=8, K=1, hidden=(64,), S=3, act="sigmoid"), 40),
+    ("vae_gmp", O.Dims(D=200, L=24, K=12, hidden=(32,), act="elu"), 33),
+    ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,), act="elu"), 256),
+    ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,), act="tanh"), 64),
+    ("gmvae", O.Dims(D=256, L=32, K=32, hidden=(128, 64), act="sigmoid"), 2090),
+]
+
+
+@pytest.mark.parametrize("name,d,B", ACT_CASES, ids=[f"{n}-{d.act}-D{d.D}-L{d.L}-H{'x'.join(map(str, d.hidden))}-S{d.S}-B{B}" for n, d, B in ACT_CASES])
+def test_step_with_other_hidden_activations_matches_oracle(H, name, d, B):
+    model = O.MODEL_NAMES[name]
+    assert _L().step_schedule(H.dims_of(d, B), model) == "general"
+    rng = np.random.default_rng(B)
+    p = O.init_params(model, d, rng)
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    x, eps, u = O.make_inputs(d, B, model)
+    H.compare_step(model, d, p, x, eps, u)
+    # forward-only evaluation and one conditional's MLP on the same activation
+    Cc = O.forward(model, d, O.unpack(model, d, O.pack(model, d, p, np.float32).astype(np.float64)), x, eps, u, np.float64)
+    tail, rows = H.hip_forward(model, d, O.pack(model, d, p, np.float32), x, eps, u)[:2]
+    assert abs(tail[0] / B - Cc["loss"]) <= 1e-4 * abs(Cc["loss"])
 
 
 def test_large_row_cases_take_the_general_schedule(H):

@@ -95,6 +95,31 @@ def test_gmvae_modules_match_oracle():
     assert acc == pytest.approx(O.cluster_acc(_np(q_y.distribution.logits), labels.numpy(), 4), abs=1e-6)
 
 
+@pytest.mark.parametrize("fn,act", [(torch.tanh, "tanh"), (torch.sigmoid, "sigmoid"), (torch.nn.functional.elu, "elu")])
+def test_gmvae_with_another_hidden_activation_matches_oracle(fn, act):
+    """hidden_activation_fn (scripts/gmvae.py:282 passes ONE callable to every conditional's MLP; scripts/base.py:19,90,153):
+    the accessors (gmvae_mlp_forward) and run_model + backward on tanh / sigmoid / ELU against the oracle."""
+    import gmvae_amd
+    model = gmvae_amd.create_gmvae(200, 6, mixture_components=4, fcnet_hidden_sizes=[24, 16], sigma_min=0.0, raw_sigma_bias=0.5,
+                                   temperature=0.8, random_seed=2, hidden_activation_fn=fn)
+    d = O.Dims(D=200, L=6, K=4, hidden=(24, 16), temperature=0.8, act=act)
+    p = O.unpack(O.MODEL_GMVAE, d, _np(model.params))
+    x, eps, u = O.make_inputs(d, 10)
+    C, g = O.loss_and_grads(O.MODEL_GMVAE, d, p, x, eps, u, np.float64)
+    xt = torch.from_numpy(x).cuda()
+    q_y = model.encoder_y(xt)
+    np.testing.assert_allclose(_np(q_y.distribution.logits), C["logits"], rtol=1e-4, atol=1e-5)
+    y = q_y.sample(uniform=torch.from_numpy(u).cuda())
+    qz = model.encoder_gmm(xt, y)
+    np.testing.assert_allclose(_np(qz.scale_diag), C["sig_q"], rtol=1e-4, atol=1e-5)
+    loss = model.run_model(xt, xt, None, eps=torch.from_numpy(eps), u=torch.from_numpy(u))
+    assert loss.item() == pytest.approx(C["loss"], rel=1e-4)
+    loss.backward()
+    gref = O.pack(O.MODEL_GMVAE, d, g, np.float64)
+    got = _np(model._engine.params.grad).astype(np.float64)
+    assert np.abs(got - gref).max() <= 1e-4 * np.abs(gref).max()
+
+
 def _torch_draws(seed, u_shape=None, eps_shape=None):
     """The draws base.RelaxedOneHotCategorical.sample / MultivariateNormalDiag.sample make for `seed` (each call seeds
     a fresh device generator, as the reference passes the same `seed=self.random_seed` to every sampler)."""
@@ -318,7 +343,7 @@ def test_missing_engine_and_bad_activation_fail_loudly():
     import gmvae_amd
     from gmvae_amd import base
     with pytest.raises(NotImplementedError):
-        gmvae_amd.create_gmvae(64, 4, 3, hidden_activation_fn=torch.tanh)
+        gmvae_amd.create_gmvae(64, 4, 3, hidden_activation_fn=torch.sin)
     m = gmvae_amd.TrainableGMVAE(3, None, None, None, None)
     with pytest.raises(RuntimeError):
         m.run_model(torch.zeros(1, 1), torch.zeros(1, 1), None)

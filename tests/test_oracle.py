@@ -77,7 +77,7 @@ def torch_loss(model, d, P, x, eps, u):
         for i in range(nl if name != "prior_gmm" else 1):
             h = h @ P[f"{name}_fcnet/linear_{i}/w"] + P[f"{name}_fcnet/linear_{i}/b"]
             if i < nl - 1 and name != "prior_gmm":
-                h = torch.relu(h)
+                h = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, "elu": torch.nn.functional.elu}[d.act](h)
         return h
 
     def normal(out):
@@ -117,6 +117,10 @@ CASES = [
     ("vae", O.Dims(D=30, L=3, K=1, hidden=(6,), S=4), 3),
     ("vae_gmp", O.Dims(D=48, L=6, K=5, hidden=(12,)), 7),
     ("vae_gmp", O.Dims(D=36, L=4, K=3, hidden=(8, 8), S=2, gen_bias_init=0.3), 5),
+    # hidden_activation_fn other than the reference's default relu (scripts/base.py:19,90,153 accept any callable)
+    ("gmvae", O.Dims(D=40, L=4, K=3, hidden=(9, 7), act="tanh"), 5),
+    ("vae", O.Dims(D=48, L=2, K=1, hidden=(10,), S=2, act="sigmoid"), 6),
+    ("vae_gmp", O.Dims(D=48, L=6, K=5, hidden=(12,), act="elu"), 7),
 ]
 
 
