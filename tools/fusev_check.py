@@ -7,7 +7,9 @@ from gmvae_amd.engine import Engine
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 G = 16
 bad = 0
-for model, Lz, K, B in (("vae", 2, 1, 100), ("vae_gmp", 64, 10, 256), ("vae", 2, 1, 16), ("vae_gmp", 64, 10, 576), ("vae", 2, 1, 333)):
+CASES = [("vae", 2, 1, 100), ("vae_gmp", 64, 10, 256), ("vae", 2, 1, 16), ("vae_gmp", 64, 10, 576), ("vae", 2, 1, 333)]
+if len(sys.argv) > 2: CASES = CASES[:int(sys.argv[2])]
+for model, Lz, K, B in CASES:
     rng = np.random.default_rng(B)
     xs = torch.from_numpy((rng.random((G, B, 784)) < 0.87).astype(np.uint8)).cuda()
     res = []
