@@ -68,10 +68,17 @@ struct Problem {
   long long split_stride;  // floats between split-K slabs
   float* C;
   int xbf16;               // dW of a uint8 activation (A = x^T, k-major rows of bytes; B = dY fp32 rows): bf16 MFMA path
-  int xorder;              // tile order inside the launch (gemm_grouped: 0 split/tn/tm, 1 all tn of a tm on one XCD, 2 all tm of a (split, tn))
+  int xorder;              // tile order inside the launch (gemm_grouped: 0 split/tn/tm, 1 all tn of a tm on one XCD, 2 all tm of a (split, tn), 3 8 x 8 blocks, 4 all units of a split)
   int planes;              // operands of seg[0] are bf16 plane triples (hi, mid, lo as written by split_planes / the Bernoulli
                            // epilogue's C3): a.ptr / b.ptr name plane 0 (16-bit elements); plane_rounds3 below
+                           // planes == 2: f16 PAIRS (plane_rounds2 below): a s = p1 + 2^-11 p2 with the power-of-two scale s of
+                           // the tensor; the product is un-scaled by (*a_uns) (*b_uns) uns_c in front of the epilogue
   long long a_pstride, b_pstride;   // 16-bit elements between the planes of a / b
+  const float* a_uns;      // pairs: device words holding 1 / s of each operand (written by split_pairs_b16) or nullptr (= 1)
+  const float* b_uns;
+  float uns_c;             // pairs: constant part of the un-scaling (fixed-scale operands: (sigmoid - x) x 2^15)
+  float uns_cb;            // pairs: b's share of uns_c (the bias gradient's column sums are sums of b's pieces)
+  float c3_scale;          // != 0: C3 receives f16 pairs of (value x c3_scale) in two planes instead of bf16 triples in three
   unsigned short* C3;      // EPI_BERNOULLI: (sigmoid - x) written as planes [3][M][ldc] of 16-bit pieces (beside or instead of C);
                            // EPI_STORE with per-element options (bias / ReLU ...): the stored values also as planes (beside C)
   long long c3_stride;
@@ -517,6 +524,169 @@ __device__ __forceinline__ void plane_rounds3(unsigned short* __restrict__ img, 
 }
 
 
+// ---- f16 pairs: fp32 x fp32 products as THREE piece products ------------------------------------------------------
+// (round 5.)  The bf16 triples above make every product exact at six matrix instructions per 16 k.  Two f16 pieces carry 22
+// of the 24 significand bits: with s the tensor's power-of-two scale (its largest magnitude lands in [2^14, 2^15): exact),
+//     a s = p1 + 2^-11 p2 (1 + d),   p1 = f16(a s),   p2 = f16((a s - p1) 2^11),   |d| <= 2^-11
+// -- the residual a s - p1 is exact in fp32 and is stored SHIFTED by 2^11, so that it has p1's exponent range and never
+// lands among f16's subnormals: an element keeps 22 bits as long as |a| >= 2^-29 max|a| (p1 normal); below that it loses
+// them gradually (absolute error <= 2^-40 max|a|).  A product then is
+//     a b s t = p1 q1 + 2^-11 (p1 q2 + p2 q1) + O(2^-22 |a b s t|)
+// three v_mfma_f32_32x32x16_f16 per 16 k; the main term and the cross terms accumulate in fp32 registers of their own
+// (acc, accx) and meet once per tile: (acc + 2^-11 accx) / (s t).  Per product the relative error is <= 3 x 2^-22 (the two
+// dropped residuals and p2 q2) and unbiased; the fp32 accumulation over k that follows rounds at 2^-24 per ADD of the running
+// sum, which is what dominates the result in both forms.  Half the matrix instructions and two thirds of the operand bytes
+// of the triples: the config-5 GEMMs are bound by the L2 -> LDS stream of their pieces.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+// the scale of a tensor from the bits of its largest magnitude (uint order = float order for non-negative floats): 2^(14 - e)
+__device__ __forceinline__ float pair_scale(const unsigned amax_bits) {
+  int eb = (int)((amax_bits >> 23) & 0xffu);
+  if (eb == 0xff) eb = 127 + 14;                   // inf / NaN somewhere: scale 1 (they propagate through p1)
+  int sb = 127 + 14 - (eb - 127);
+  sb = sb < 2 ? 2 : (sb > 252 ? 252 : sb);         // (1 / s stays a normal float)
+  return __uint_as_float((unsigned)sb << 23);
+}
+// A tensor's largest magnitude (bits): every wave of the producing launch (or workgroup of amax_abs) leaves the maximum of
+// what it wrote in a word of its own -- no atomics (thousands of waves adding to ONE address with device-scope atomics
+// serialise at the memory side: a 13 M element reduction took 85 us that way; even a look-before-add cost the producer 15 us),
+// nothing to zero -- and amax_final below folds the words into one and derives the scale.
+__device__ __forceinline__ unsigned wave_umax(unsigned m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+  return m;
+}
+// two values (already scaled) -> their packed first and second pieces (element 0 in the low half)
+__device__ __forceinline__ void split_f16pair(const float v0, const float v1, unsigned& p1, unsigned& p2) {
+  const f32x2_t v = {v0, v1};
+  const f16x2_t h1 = __builtin_convertvector(v, f16x2_t);
+  const f32x2_t r = {(v0 - (float)h1.x) * 2048.f, (v1 - (float)h1.y) * 2048.f};
+  const f16x2_t h2 = __builtin_convertvector(r, f16x2_t);
+  p1 = __builtin_bit_cast(unsigned, h1);
+  p2 = __builtin_bit_cast(unsigned, h2);
+}
+__device__ __forceinline__ float f16lo(const unsigned w) { return (float)__builtin_bit_cast(f16x2_t, w).x; }
+__device__ __forceinline__ float f16hi(const unsigned w) { return (float)__builtin_bit_cast(f16x2_t, w).y; }
+
+// The loop: plane_rounds3's layout, staging and fragment reads with two planes per operand -- 16 KB per 16-deep round, a ring
+// of FOUR buffers (64 KB: round c + 4 is requested behind round c's barrier and waited for three rounds later), 12 matrix
+// instructions and 8 (k-contiguous) / 16 (transposing) fragment reads per wave and round.
+constexpr int kP2Op = 2 * 2048;                 // 16-bit elements per operand image: 2 planes of 128 x 16
+constexpr int kP2Buf = 2 * kP2Op;               // A | B
+constexpr int kP2Ring = 4;
+
+template <bool AMC, bool BMC>
+__device__ __forceinline__ void plane_rounds2(unsigned short* __restrict__ img, const unsigned short* __restrict__ A,
+                                              const uint32_t a_rows, const long long a_ps, const unsigned short* __restrict__ Bp,
+                                              const uint32_t b_rows, const long long b_ps, const float* __restrict__ kscale,
+                                              const bool do_cs, const int m0, const int n0, const int kb, const int NC16,
+                                              const int tid, const int lane, const int wave, const int wm0, const int wn0,
+                                              f32x16 (&acc)[2][2], f32x16 (&accx)[2][2], float (&cs8)[8]) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  uint32_t ea = p3_src<AMC>(wave, lane, a_rows, m0, kb), eb = p3_src<BMC>(wave, lane, b_rows, n0, kb);
+  const uint32_t a_round = AMC ? 256u : 16u * a_rows, b_round = BMC ? 256u : 16u * b_rows;
+  int fa0, fa1, fb0, fb1;
+  {
+    const int l31 = lane & 31, g16 = lane >> 4, i16 = lane & 15;
+    const int kc = (l31)*16 + 8 * ((lane >> 5) ^ ((l31 >> 3) & 1));
+    const int kr0 = 8 * (g16 >> 1) + (i16 >> 2), rot = 4 * (g16 & 1);
+    const int mc0 = (g16 & 1) * 256 + ((kr0 + rot) & 15) * 16 + 4 * (i16 & 3), mc1 = (g16 & 1) * 256 + ((kr0 + 4 + rot) & 15) * 16 + 4 * (i16 & 3);
+    fa0 = AMC ? (wm0 >> 4) * 256 + mc0 : wm0 * 16 + kc;
+    fa1 = AMC ? (wm0 >> 4) * 256 + mc1 : 0;
+    fb0 = BMC ? (wn0 >> 4) * 256 + mc0 : wn0 * 16 + kc;
+    fb1 = BMC ? (wn0 >> 4) * 256 + mc1 : 0;
+  }
+  const int cs_k = tid >> 4, cs_ch = tid & 15;
+  const int cs_off = (cs_ch >> 1) * 256 + ((cs_k + 4 * ((cs_ch >> 1) & 1)) & 15) * 16 + 8 * (cs_ch & 1);
+  int kk = kb + cs_k;
+#define GMVAE_P2_DMA(buf_)                                                                                 \
+  {                                                                                                        \
+    unsigned short* const d_ = img + (buf_) * kP2Buf + wave * 512;                                         \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                     \
+      __builtin_amdgcn_global_load_lds(A + pl * a_ps + ea, d_ + pl * 2048, 16, 0, 0);                      \
+      __builtin_amdgcn_global_load_lds(Bp + pl * b_ps + eb, d_ + kP2Op + pl * 2048, 16, 0, 0);             \
+    }                                                                                                      \
+    ea += a_round; eb += b_round;                                                                          \
+  }
+  // (order: what the next round multiplies first -- row block 0 of a, both column blocks of b -- is read first)
+#define GMVAE_P2_FRAGS(FA_, FB_, buf_)                                                                     \
+  {                                                                                                        \
+    const unsigned short* const ia_ = img + (buf_) * kP2Buf;                                               \
+    const unsigned short* const ib_ = ia_ + kP2Op;                                                         \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) FA_[0][pl] = __builtin_bit_cast(f16x8_t, p3_frag<AMC>(ia_ + pl * 2048, fa0, fa1));        \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) FB_[0][pl] = __builtin_bit_cast(f16x8_t, p3_frag<BMC>(ib_ + pl * 2048, fb0, fb1));        \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) FB_[1][pl] = __builtin_bit_cast(f16x8_t, p3_frag<BMC>(ib_ + pl * 2048 + 512, fb0, fb1));  \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) FA_[1][pl] = __builtin_bit_cast(f16x8_t, p3_frag<AMC>(ia_ + pl * 2048 + 512, fa0, fa1));  \
+  }
+  // row block i_ against both column blocks: six instructions, consecutive ones on different accumulators
+#define GMVAE_P2_TILES(FA_, FB_, i_)                                                                       \
+  {                                                                                                        \
+    f32x16 m0_ = acc[i_][0], m1_ = acc[i_][1], x0_ = accx[i_][0], x1_ = accx[i_][1];                       \
+    m0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA_[i_][0], FB_[0][0], m0_, 0, 0, 0);                     \
+    m1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA_[i_][0], FB_[1][0], m1_, 0, 0, 0);                     \
+    x0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA_[i_][0], FB_[0][1], x0_, 0, 0, 0);                     \
+    x1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA_[i_][0], FB_[1][1], x1_, 0, 0, 0);                     \
+    x0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA_[i_][1], FB_[0][0], x0_, 0, 0, 0);                     \
+    x1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA_[i_][1], FB_[1][0], x1_, 0, 0, 0);                     \
+    acc[i_][0] = m0_; acc[i_][1] = m1_; accx[i_][0] = x0_; accx[i_][1] = x1_;                              \
+  }
+  constexpr int kRd = (AMC && BMC) ? 4 : ((AMC || BMC) ? 3 : 2);       // LDS reads behind each of the first four of a round's last six
+#define GMVAE_P2_SG(n_) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, n_, 0);
+  // round c_ (fragments in CUR; buffer bc_ holds its images, bn_ the next round's); rounds c_ + 1 .. c_ + 3 are in flight
+  // when it waits for the next one, round c_ + 4 is requested behind the barrier into the buffer it has just finished
+#define GMVAE_P2_ROUND(CA_, CB_, NA_, NB_, c_, bc_, bn_)                                                   \
+  {                                                                                                        \
+    if (BMC && do_cs) {                                                                                    \
+      const unsigned short* const ib_ = img + (bc_) * kP2Buf + kP2Op + cs_off;                             \
+      const u32x4 h_ = *reinterpret_cast<const u32x4*>(ib_), l_ = *reinterpret_cast<const u32x4*>(ib_ + 2048);   \
+      const float sc = kscale ? kscale[kk] : 1.f;                                                          \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+        cs8[2 * q] += sc * (f16lo(h_[q]) + 0x1p-11f * f16lo(l_[q]));                                       \
+        cs8[2 * q + 1] += sc * (f16hi(h_[q]) + 0x1p-11f * f16hi(l_[q]));                                   \
+      }                                                                                                    \
+      kk += 16;                                                                                            \
+    }                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    GMVAE_P2_TILES(CA_, CB_, 0)                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if ((c_) + 3 < NC16) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");          \
+    else if ((c_) + 2 < NC16) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");     \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
+    if ((c_) + 4 < NC16) GMVAE_P2_DMA(bc_)                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    GMVAE_P2_FRAGS(NA_, NB_, bn_)                                                                          \
+    GMVAE_P2_TILES(CA_, CB_, 1)                                                                            \
+    GMVAE_P2_SG(kRd) GMVAE_P2_SG(kRd) GMVAE_P2_SG(kRd) GMVAE_P2_SG(kRd) GMVAE_P2_SG(0) GMVAE_P2_SG(0)      \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+  }
+  f16x8_t fa[2][2], fb[2][2], ga[2][2], gb[2][2];
+  GMVAE_P2_DMA(0)
+  GMVAE_P2_DMA(1)                                // (NC16 >= 2, even)
+  if (NC16 > 2) {
+    GMVAE_P2_DMA(2)
+    GMVAE_P2_DMA(3)
+    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");    // round 0 has landed, three rounds stay in flight
+  } else {
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+  }
+  GMVAE_P2_FRAGS(fa, fb, 0)
+  int bc = 0;
+#pragma unroll 1
+  for (int c = 0; c < NC16; c += 2) {
+    const int b1 = (bc + 1) & 3, b2 = (bc + 2) & 3;
+    GMVAE_P2_ROUND(fa, fb, ga, gb, c, bc, b1)
+    GMVAE_P2_ROUND(ga, gb, fa, fb, c + 1, b1, b2)
+    bc = b2;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (the caller reuses LDS)
+#undef GMVAE_P2_DMA
+#undef GMVAE_P2_FRAGS
+#undef GMVAE_P2_TILES
+#undef GMVAE_P2_ROUND
+#undef GMVAE_P2_SG
+}
+
+
 // ---- the 128x128x32 configuration's interior rounds ("big rounds") -----------------------------------------------
 // For tiles completely inside both fp32 operands and k ranges that are whole 32-deep rounds.  LDS image of an operand
 // round: [8 k-quads][128 mn] units of 16 bytes = the 4 consecutive k of one mn, unit index swizzled
@@ -759,14 +929,17 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
       const int tiles_m_ = L.p[pi].tiles_m;
       // (xorder 3, both operands large: groups of 8 column tiles of one tm, the groups of one block of 8 column tiles
       //  consecutive -- an XCD's 64 concurrent tiles are then 8 row blocks x 8 column blocks)
-      const int gs = xo == 1 ? tiles_n * splits : (xo == 2 ? tiles_m_ : 8 * splits);                 // tiles per group
-      const int ng = xo == 1 ? tiles_m_ : (xo == 2 ? tiles_n * splits : tiles_m_ * (tiles_n >> 3));  // groups
+      // (xorder 4, a split-K weight gradient: the group is ONE split -- all its tm x tn units on one XCD, which then needs
+      //  only that split's k slice of either operand)
+      const int gs = xo == 1 ? tiles_n * splits : (xo == 2 ? tiles_m_ : (xo == 4 ? tiles_m_ * tiles_n : 8 * splits));                 // tiles per group
+      const int ng = xo == 1 ? tiles_m_ : (xo == 2 ? tiles_n * splits : (xo == 4 ? splits : tiles_m_ * (tiles_n >> 3)));  // groups
       const int full = ng & ~7;                                             // groups dealt 8 at a time, one per XCD
       int grp, mem;
       if (t < full * gs) { const int j = t >> 3; grp = (j / gs) * 8 + (t & 7); mem = j % gs; }
       else { const int t2 = t - full * gs; grp = full + t2 / gs; mem = t2 % gs; }
       if (xo == 1) { tm = grp; split = mem % splits; tn = mem / splits; }
       else if (xo == 2) { tm = mem; split = grp % splits; tn = grp / splits; }
+      else if (xo == 4) { tm = mem % tiles_m_; tn = mem / tiles_m_; split = grp; }
       else { tm = grp % tiles_m_; split = mem % splits; tn = (grp / tiles_m_) * 8 + mem / splits; }
     }
   }
@@ -956,6 +1129,47 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
       if (sgi == 0) GMVAE_GSTAMP(1);
       continue;
     }
+    if constexpr (BIG == 3) {                     // every problem of the launch reads f16 pairs (host: planes_eligible, planes == 2)
+      static_assert(C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2, "plane rounds: 128x128x32");
+      __syncthreads();        // LDS is free
+      if (sgi == 0) GMVAE_GSTAMP(6);
+      const unsigned short* const Ah = static_cast<const unsigned short*>(a_ptr);
+      const unsigned short* const Bh = static_cast<const unsigned short*>(b_ptr);
+      const long long a_ps = L.p[pi].a_pstride, b_ps = L.p[pi].b_pstride;
+      static_assert(kP2Ring * kP2Buf * 2 <= C::LDS_FLOATS * 4, "plane_rounds2's ring must fit the kernel's LDS");
+      f32x16 accx[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accx[i][j][r] = 0.f;
+      {
+        const uint32_t a_rows = a_mc ? (uint32_t)K : (uint32_t)a_n, b_rows = b_mc ? (uint32_t)K : (uint32_t)b_n;
+#define GMVAE_PL2(AMC_, BMC_) \
+  plane_rounds2<AMC_, BMC_>(reinterpret_cast<unsigned short*>(lds), Ah, a_rows, a_ps, Bh, b_rows, b_ps, kscale, do_colsum, m0, n0, kb, \
+                            2 * NC, tid, lane, wave, wm0, wn0, acc, accx, cs8)
+        if (!b_mc) {
+          if (a_mc) GMVAE_PL2(true, false); else GMVAE_PL2(false, false);
+        } else {
+          if (a_mc) GMVAE_PL2(true, true); else GMVAE_PL2(false, true);
+        }
+#undef GMVAE_PL2
+      }
+      {
+        // main term + cross terms, and both operands' scales off: (acc + 2^-11 accx) / (s t)
+        const float ua = L.p[pi].a_uns ? *L.p[pi].a_uns : 1.f, ub = L.p[pi].b_uns ? *L.p[pi].b_uns : 1.f, uc = L.p[pi].uns_c;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = ((acc[i][j][r] + 0x1p-11f * accx[i][j][r]) * ua) * (ub * uc);
+      }
+      if (do_colsum) did_planes = true;
+      if (sgi == 0) GMVAE_GSTAMP(1);
+      continue;
+    }
     if constexpr (BIG == 1) {
       static_assert(C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2, "big rounds: 128x128x32");
       __syncthreads();        // LDS is free
@@ -1057,6 +1271,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
 #pragma unroll
       for (int g = 0; g < CSG; ++g) v += lds[C::CST + g * C::BN + tid];
     }
+    if constexpr (BIG == 3) v *= (L.p[pi].b_uns ? *L.p[pi].b_uns : 1.f) * L.p[pi].uns_cb;     // (the pieces carry b's scale)
     colsum_out[(long long)split * L.p[pi].split_stride + n0 + tid] = v;
   }
 
@@ -1202,6 +1417,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
     const int ldx = L.p[pi].ldx, x_div = L.p[pi].x_div, nparts = L.p[pi].nparts;
     unsigned short* const C3 = L.p[pi].C3;         // (only set for launches whose tiles are all interior: planes_eligible)
     const long long c3s = L.p[pi].c3_stride;
+    const float c3sc = L.p[pi].c3_scale;
     if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && (!Cout || al16(Cout)) && al16(bias) && (!bias2 || al16(bias2)) && (ldx & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(xp) & 3) == 0) {
       // interior tile: the bias quad once, the 4 target bytes of a pass as one word; every pass's target word AND staged
@@ -1245,7 +1461,14 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
           v[j] = (lam >= 0.f ? rcp : e * rcp) - xv;
         }
         if (Cout) *reinterpret_cast<float4*>(Cout + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
-        if (C3) {                                   // the three 16-bit pieces of (sigmoid - x), one plane each (plane_rounds3's operand)
+        if (C3 && c3sc != 0.f) {                    // f16 pairs of (sigmoid - x) x c3_scale (|.| <= 1: a fixed scale), two planes
+          unsigned q1[2], q2[2];
+          split_f16pair(v[0] * c3sc, v[1] * c3sc, q1[0], q2[0]);
+          split_f16pair(v[2] * c3sc, v[3] * c3sc, q1[1], q2[1]);
+          unsigned short* const d3 = C3 + ((long long)(nb >> 4) * M + (m0 + row)) * 16 + (nb & 15);
+          *reinterpret_cast<uint2*>(d3) = make_uint2(q1[0], q1[1]);
+          *reinterpret_cast<uint2*>(d3 + c3s) = make_uint2(q2[0], q2[1]);
+        } else if (C3) {                            // the three 16-bit pieces of (sigmoid - x), one plane each (plane_rounds3's operand)
           unsigned hi[2], mi[2], lo[2];
           split_pair(v[0], v[1], hi[0], mi[0], lo[0]);
           split_pair(v[2], v[3], hi[1], mi[1], lo[1]);
@@ -1344,6 +1567,83 @@ __global__ __launch_bounds__(256) void split_planes_b16(const float* __restrict_
     *reinterpret_cast<u32x4*>(dp) = u32x4{hi[0], hi[1], hi[2], hi[3]};
     *reinterpret_cast<u32x4*>(dp + pstride) = u32x4{mi[0], mi[1], mi[2], mi[3]};
     *reinterpret_cast<u32x4*>(dp + 2 * pstride) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+  }
+}
+
+// The same for f16 pairs (plane_rounds2): dst receives two planes of (value x rowscale x s), s = pair_scale(*amax_bits) -- the
+// power-of-two scale of the tensor, from the bits of its largest magnitude (amax_final below; of the UNWEIGHTED tensor: row
+// weights are <= 1).
+__global__ __launch_bounds__(256) void split_pairs_b16(const float* __restrict__ src, const float* __restrict__ rowscale,
+                                                        const int ld, const int rows, unsigned short* __restrict__ dst,
+                                                        const long long pstride, const unsigned* __restrict__ amax_bits) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const float s = pair_scale(*amax_bits);
+  const int npair = (ld + 31) >> 5, ngrp = rows >> 4, lane = threadIdx.x & 63;
+  const long long waves = (long long)ngrp * npair;
+  for (long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < waves; wv += (long long)gridDim.x * 4) {
+    const long long cp = wv / ngrp, rg = wv - cp * ngrp;
+    const long long r = rg * 16 + (lane >> 2);
+    const int c = (int)cp * 32 + 8 * (lane & 3);
+    if (c >= ld) continue;
+    const float* const sp = src + r * ld + c;
+    const float sc = (rowscale ? rowscale[r] : 1.f) * s;
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(sp), q1 = *reinterpret_cast<const f32x4*>(sp + 4);
+    const float v[8] = {q0.x * sc, q0.y * sc, q0.z * sc, q0.w * sc, q1.x * sc, q1.y * sc, q1.z * sc, q1.w * sc};
+    unsigned p1[4], p2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_f16pair(v[2 * j], v[2 * j + 1], p1[j], p2[j]);
+    unsigned short* const dp = dst + ((long long)(c >> 4) * rows + r) * 16 + (c & 15);
+    *reinterpret_cast<u32x4*>(dp) = u32x4{p1[0], p1[1], p1[2], p1[3]};
+    *reinterpret_cast<u32x4*>(dp + pstride) = u32x4{p2[0], p2[1], p2[2], p2[3]};
+  }
+}
+
+constexpr int kAmaxBlocks = 256;      // workgroups of an amax_abs launch
+// bits of the largest |src[i]| (n % 4 == 0, 16-byte aligned) of each workgroup's share into part[blockIdx.x]
+__global__ __launch_bounds__(256) void amax_abs(const float* __restrict__ src, const long long n4, unsigned* __restrict__ part) {
+  __shared__ unsigned wm[4];
+  unsigned m = 0;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * stride) {
+    f32x4 q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = i + j * stride < n4 ? reinterpret_cast<const f32x4*>(src)[i + j * stride] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned a = __float_as_uint(q[j].x) & 0x7fffffffu, b = __float_as_uint(q[j].y) & 0x7fffffffu;
+      const unsigned c = __float_as_uint(q[j].z) & 0x7fffffffu, d = __float_as_uint(q[j].w) & 0x7fffffffu;
+      const unsigned ab = a > b ? a : b, cd = c > d ? c : d, e = ab > cd ? ab : cd;
+      m = e > m ? e : m;
+    }
+  }
+  m = wave_umax(m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned a = wm[0] > wm[1] ? wm[0] : wm[1], b = wm[2] > wm[3] ? wm[2] : wm[3];
+    part[blockIdx.x] = a > b ? a : b;
+  }
+}
+
+// workgroup t folds tensor t's partial maxima into bits[t] and leaves 1 / pair_scale in uns[t] (t = 0, 1)
+struct AmaxFinalArgs {
+  const unsigned* part[2];
+  int n[2];
+  unsigned* bits;
+  float* uns;
+};
+__global__ __launch_bounds__(256) void amax_final(const AmaxFinalArgs a) {
+  __shared__ unsigned wm[4];
+  const int t = blockIdx.x;
+  unsigned m = 0;
+  for (int i = threadIdx.x; i < a.n[t]; i += 256) { const unsigned v = a.part[t][i]; m = v > m ? v : m; }
+  m = wave_umax(m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned x = wm[0] > wm[1] ? wm[0] : wm[1], y = wm[2] > wm[3] ? wm[2] : wm[3], mm = x > y ? x : y;
+    a.bits[t] = mm;
+    a.uns[t] = 1.f / pair_scale(mm);
   }
 }
 

@@ -160,6 +160,7 @@ struct WS {
   float *img_f, *img_b;         // per-step LDS weight images of chain_fwd / chain_bwd (prepared by aux blocks)
   float *img_m, *dimg;          // mega kernel: small-weight image (odd leading dimensions) + decoder chunk images
   float *img2f, *img2b, *dimg2; // mega2 kernel: forward / backward operand images, decoder operand images
+  float* pscale;
   unsigned short *hd3, *g3, *w3;   // general schedule, large top decoder layer: planes of 16-bit pieces (gemm.hpp plane_rounds) of its
                                    // input activation [3][R][H], of (sigmoid - x) [3][R][D] and of its weight [3][H][D]
   int32_t* cl_pred;
@@ -400,6 +401,9 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
       w.hd3 = reinterpret_cast<unsigned short*>(take((3 * R * Ht + 1) / 2));
       w.g3 = reinterpret_cast<unsigned short*>(take((3 * R * D + 1) / 2));
       w.w3 = reinterpret_cast<unsigned short*>(take((3 * Ht * D + 1) / 2));
+      // f16 pairs: [0], [1] bits of max |h|, max |W| of the step; [2], [3] 1 / scale of either; [16..] partial maxima: kAmaxBlocks
+      // words for W, then one per wave of the launch that produces h (rows_nn_bf6: a wave per 16 rows x 64 columns at least)
+      w.pscale = take(16 + kAmaxBlocks + ((R + 15) / 16) * ((Ht + 63) / 64));
     }
   }
   w.bytes = off;
@@ -508,7 +512,12 @@ static int tile_up(Launch& L) {
     // XCD-aware tile order (gemm.hpp): only where it matters -- many tiles and one operand much larger than the other
     p.xorder = 0;
     if (C::BM == 128 && (long long)p.tiles_m * p.tiles_n * p.splits >= 512) {
-      if (p.tiles_m >= 16 * p.tiles_n && p.tiles_n * p.splits <= 16) p.xorder = 1;
+      // (4: a split-K weight gradient with a multiple of 8 splits: ALL units of one split on one XCD -- the XCD then fetches only
+      //  its splits' k slices of BOTH operands; with order 2 every XCD fetched the whole A operand: at config 5 the activation
+      //  planes, 78 MB x 8)
+      static const bool x4 = !(getenv("GMVAE_NO_XORDER4") && atoi(getenv("GMVAE_NO_XORDER4")));
+      if (x4 && p.splits >= 8 && (p.splits & 7) == 0 && p.tiles_m * p.tiles_n >= 32 && p.tiles_m * p.tiles_n <= 512) p.xorder = 4;
+      else if (p.tiles_m >= 16 * p.tiles_n && p.tiles_n * p.splits <= 16) p.xorder = 1;
       else if (p.tiles_n >= 4 * p.tiles_m && p.tiles_m <= 16) p.xorder = 2;
       else if (p.tiles_m >= 64 && p.tiles_n >= 16 && (p.tiles_n & 7) == 0 && p.splits == 1) p.xorder = 3;
     }
@@ -542,6 +551,23 @@ static int grid_for(long long items, int per_block, int cap = 4096);
 // fp32 [rows][ld] (x rowscale[row]) -> three planes of 16-bit pieces in plane_rounds3's blocked-by-16 layout
 static void launch_split(hipStream_t st, const float* src, const float* rowscale, int ld, long long n, unsigned short* dst) {
   hipLaunchKernelGGL(split_planes_b16, dim3(grid_for(n / ld / 16 * ((ld + 31) / 32), 4, 16384)), dim3(256), 0, st, src, rowscale, ld, (int)(n / ld), dst, n);
+}
+
+// the f16-pair form (gemm.hpp plane_rounds2): per-workgroup partial maxima of a tensor (launch_amax; or left by the producing
+// launch's waves), folded into the bits of its largest magnitude and 1 / scale (launch_amax_final), then the split into two
+// planes scaled by the power of two that brings that magnitude into [2^14, 2^15)
+static void launch_amax(hipStream_t st, const float* src, long long n, unsigned* part) {
+  hipLaunchKernelGGL(amax_abs, dim3(kAmaxBlocks), dim3(256), 0, st, src, n / 4, part);
+}
+static void launch_amax_final(hipStream_t st, const unsigned* pa, int na, const unsigned* pb, int nb, unsigned* bits, float* uns) {
+  AmaxFinalArgs f;
+  f.part[0] = pa; f.n[0] = na; f.part[1] = pb; f.n[1] = nb; f.bits = bits; f.uns = uns;
+  hipLaunchKernelGGL(amax_final, dim3(2), dim3(256), 0, st, f);
+}
+static void launch_split_pairs(hipStream_t st, const float* src, const float* rowscale, int ld, long long n, unsigned short* dst,
+                               const unsigned* amax) {
+  hipLaunchKernelGGL(split_pairs_b16, dim3(grid_for(n / ld / 16 * ((ld + 31) / 32), 4, 16384)), dim3(256), 0, st, src, rowscale, ld,
+                     (int)(n / ld), dst, n, amax);
 }
 
 // every problem of the launch reads pre-split operands (gemm.hpp plane_rounds): interior 128 x 128 tiles, whole 32-deep
@@ -619,7 +645,8 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
   g.L.dbg = dbg;
   g.L.aux_nblocks = g.L.aux.nblocks;
   bool planes = g.L.p[0].planes != 0;
-  for (int i = 1; i < g.L.nprob; ++i) planes = planes && g.L.p[i].planes;
+  for (int i = 1; i < g.L.nprob; ++i) planes = planes && g.L.p[i].planes == g.L.p[0].planes;      // (one piece form per launch)
+  const bool pairs = planes && g.L.p[0].planes == 2;
   if (planes) {
     if (!planes_eligible(g.L)) { cx.err = cx.err ? cx.err : GMVAE_E_DIMS; return 2; }      // (the host only marks problems it checked)
     cfg = 2;
@@ -647,7 +674,8 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
   if (cfg == 2) {
     tiles = g.L.total_tiles = tile_up<CfgL>(g.L);
     const bool no_big = getenv("GMVAE_NO_BIG") != nullptr;      // diagnostic / A-B: the general loop
-    if (planes) hipLaunchKernelGGL((gemm_grouped<CfgL, 2>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
+    if (pairs) hipLaunchKernelGGL((gemm_grouped<CfgL, 3>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
+    else if (planes) hipLaunchKernelGGL((gemm_grouped<CfgL, 2>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
     else if (!no_big && big_eligible(g.L)) hipLaunchKernelGGL((gemm_grouped<CfgL, 1>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
     else hipLaunchKernelGGL(gemm_grouped<CfgL>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
   } else if (cfg == 3) {
@@ -1703,6 +1731,11 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   const float c = d.raw_sigma_bias, smin = d.sigma_min;
   hipStream_t st = cx.st;
   const bool planes = planes_ok(d, L) && w.hd3 != nullptr;
+  // the piece form of the plane GEMMs: f16 pairs (3 piece products, <= 3 x 2^-22 per product) unless GMVAE_PLANES_EXACT=1 asks for
+  // the bf16 triples (6 piece products, every product exact)
+  static const bool exact_env = getenv("GMVAE_PLANES_EXACT") && atoi(getenv("GMVAE_PLANES_EXACT"));
+  const bool pairs = planes && !exact_env;
+  constexpr float kGScale = 32768.f;            // (sigmoid - x) in [-1, 1]: a fixed scale for its pairs
 
   // ---- noise (fast mode): Philox for eps and u -- its own launch in the general schedule, auxiliary
   // workgroups of the first GEMM launch in the fused one
@@ -1724,6 +1757,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   // row-panel layers over thousands of rows as register-direct bf16 piece products (skinny.hpp rows_nn_bf6): K % 32 = 0, widths
   // % 64 = 0, R >= 2048 -- else the grouped GEMM
   auto rows_ok = [&](int Kd, int N0, int N1) { return relu_act && R >= 2048 && Kd % 32 == 0 && N0 % 64 == 0 && N1 % 64 == 0; };
+  int rows_units = 0;                            // waves with work of the last launch_rows (one partial maximum each: RowsProb::amax)
   auto launch_rows = [&](RowsArgs& ra, const char* name) {
     const int nct = (ra.p[0].N + (ra.np > 1 ? ra.p[1].N : 0)) / 64;
     int rt = 4;
@@ -1731,6 +1765,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     //  win while the chip stays full: fwd_enc_gmm at the config-5 sizes 43.1 us with 3200 units, 37.1 with 1600, 48.3 with 800)
     while (rt > 1 && (long long)((R + 16 * rt - 1) / (16 * rt)) * nct < 1024) rt >>= 1;
     const long long units = (long long)((R + 16 * rt - 1) / (16 * rt)) * nct;
+    rows_units = (int)units;
     const dim3 grid((unsigned)((units + kSkWaves - 1) / kSkWaves));
     if (rt == 4) hipLaunchKernelGGL(rows_nn_bf6<4>, grid, dim3(kSkThreads), 0, st, ra);
     else if (rt == 2) hipLaunchKernelGGL(rows_nn_bf6<2>, grid, dim3(kSkThreads), 0, st, ra);
@@ -1847,6 +1882,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   int nparts = 1;
   const NetL& Dn = L.dec;
   bool hd3_fused = false;
+  int hmax_n = 0;                                // partial maxima the launch producing the top layer's input left (f16 pairs)
   for (int i = 0; i < Dn.nl; ++i) {
     Group g;
     const float* in = (i == 0) ? w.z : w.hd[i];
@@ -1855,15 +1891,19 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       memset(&ra, 0, sizeof(ra));
       ra.A = in; ra.R = R; ra.K = Dn.dim[i]; ra.np = 1;
       ra.p[0] = rows_prob(P + Dn.w[i], P + Dn.b[i], w.hd[i + 1], Dn.dim[i + 1], true);
-      if (planes && i == Dn.nl - 2) {              // the top layer's input activation also as planes (no split launch over R x H)
+      if (planes && !pairs && i == Dn.nl - 2) {    // the top layer's input activation also as planes (no split launch over R x H)
         ra.p[0].C3 = w.hd3; ra.p[0].c3_stride = (long long)R * Dn.dim[i + 1];
         hd3_fused = true;
       }
+      if (pairs && i == Dn.nl - 2) {               // f16 pairs: the activation's largest magnitude rides on this launch (a word per wave)
+        ra.p[0].amax = reinterpret_cast<unsigned*>(w.pscale) + 16 + kAmaxBlocks;
+      }
       launch_rows(ra, "fwd_dec");
+      if (ra.p[0].amax) hmax_n = rows_units;
     } else if (i < Dn.nl - 1) {
       Problem ph = p_nn(in, false, Dn.dim[i], P + Dn.w[i], Dn.dim[i + 1], R, Dn.dim[i + 1], Dn.dim[i], w.hd[i + 1],
                         Dn.dim[i + 1], P + Dn.b[i], true);
-      if (planes && i == Dn.nl - 2) {
+      if (planes && !pairs && i == Dn.nl - 2) {
         // the top layer's input activation leaves this launch's epilogue as planes too (no split launch over R x H)
         ph.C3 = w.hd3; ph.c3_stride = (long long)R * Dn.dim[i + 1];
         hd3_fused = true;
@@ -1881,11 +1921,26 @@ static int run_step(Ctx& cx, const StepArgs& a) {
         // both operands as planes of 16-bit pieces (the weight's are shared with the data gradient below), (sigmoid - x)
         // leaves as planes only: its two consumers are plane GEMMs
         const long long nh = (long long)R * Dn.dim[i], nw = (long long)Dn.dim[i] * D;
-        if (!hd3_fused) launch_split(st, in, nullptr, Dn.dim[i], nh, w.hd3);
-        launch_split(st, P + Dn.w[i], nullptr, D, nw, w.w3);
+        if (pairs) {
+          // f16 pairs need the tensors' scales first: largest magnitudes (two small reductions), then the scaled splits
+          unsigned* const am = reinterpret_cast<unsigned*>(w.pscale);
+          unsigned* const hp = am + 16 + kAmaxBlocks;
+          if (!hmax_n) { launch_amax(st, in, nh, hp); hmax_n = kAmaxBlocks; }
+          launch_amax(st, P + Dn.w[i], nw, am + 16);
+          launch_amax_final(st, hp, hmax_n, am + 16, kAmaxBlocks, am, w.pscale + 2);
+          launch_split_pairs(st, in, nullptr, Dn.dim[i], nh, w.hd3, am);
+          launch_split_pairs(st, P + Dn.w[i], nullptr, D, nw, w.w3, am + 1);
+          p.planes = 2;
+          p.a_uns = w.pscale + 2; p.b_uns = w.pscale + 3; p.uns_c = 1.f; p.uns_cb = 1.f;
+          p.c3_scale = kGScale;
+        } else {
+          if (!hd3_fused) launch_split(st, in, nullptr, Dn.dim[i], nh, w.hd3);
+          launch_split(st, P + Dn.w[i], nullptr, D, nw, w.w3);
+          p.planes = 1;
+        }
         rowk(cx, "split_planes");
         p.seg[0].a.ptr = w.hd3; p.seg[0].b.ptr = w.w3;
-        p.planes = 1; p.a_pstride = nh; p.b_pstride = nw;
+        p.a_pstride = nh; p.b_pstride = nw;
         p.C = nullptr;
         p.C3 = a.backward ? w.g3 : nullptr; p.c3_stride = (long long)R * D;
       }
@@ -1948,14 +2003,20 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     if (top && planes) {
       const long long nh = (long long)R * Dn.dim[i], nw = (long long)Dn.dim[i] * D, ng = (long long)R * D;
       if (rwS) {           // IWAE: the row weights ride on the activation's pieces (they cannot scale pieces inside the loop)
-        launch_split(st, act, rwS, Dn.dim[i], nh, w.hd3);
+        // (pairs: under the scale of the unweighted activation -- the weights are <= 1)
+        if (pairs) launch_split_pairs(st, act, rwS, Dn.dim[i], nh, w.hd3, reinterpret_cast<unsigned*>(w.pscale));
+        else launch_split(st, act, rwS, Dn.dim[i], nh, w.hd3);
         rowk(cx, "split_planes_rw");
       }
       Problem pw3 = pw;
       pw3.seg[0].a.ptr = w.hd3; pw3.seg[0].b.ptr = w.g3;
-      pw3.planes = 1; pw3.a_pstride = nh; pw3.b_pstride = ng;      // (seg[0].kscale = rwS now only weighs the column sums)
+      pw3.planes = pairs ? 2 : 1; pw3.a_pstride = nh; pw3.b_pstride = ng;      // (seg[0].kscale = rwS now only weighs the column sums)
       p.seg[0].a.ptr = w.g3; p.seg[0].b.ptr = w.w3;
-      p.planes = 1; p.a_pstride = ng; p.b_pstride = nw;
+      p.planes = pairs ? 2 : 1; p.a_pstride = ng; p.b_pstride = nw;
+      if (pairs) {
+        pw3.a_uns = w.pscale + 2; pw3.uns_c = 1.f / kGScale; pw3.uns_cb = 1.f / kGScale;
+        p.b_uns = w.pscale + 3; p.uns_c = 1.f / kGScale; p.uns_cb = 1.f;
+      }
       g.add(pw3);
     } else {
       g.add(pw);
@@ -2278,6 +2339,39 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
   Ctx cx;
   cx.st = static_cast<hipStream_t>(stream);
   Group g;
+  if (cfg == 6 || cfg == 7) {
+    // the f16-pair instance: cfg 6 scales and splits both operands first, cfg 7 reuses the pairs of the previous cfg-6 call
+    static unsigned short *pa = nullptr, *pb = nullptr;
+    static float* sc = nullptr;                     // [0], [1] amax bits; [2], [3] 1 / scale; [16..], [16 + kAmaxBlocks..] partial maxima
+    static size_t cap_a = 0, cap_b = 0;
+    if (a_is_u8) return GMVAE_E_DIMS;
+    const size_t na = (size_t)M * K, nb = (size_t)N * K;
+    if (na % 8 || nb % 8) return GMVAE_E_DIMS;
+    if (!sc && hipMalloc(&sc, (16 + 2 * kAmaxBlocks) * 4) != hipSuccess) return GMVAE_E_ALIGN;
+    if (na > cap_a) { if (pa) hipFree(pa); if (hipMalloc(&pa, 2 * na * 2) != hipSuccess) return GMVAE_E_ALIGN; cap_a = na; }
+    if (nb > cap_b) { if (pb) hipFree(pb); if (hipMalloc(&pb, 2 * nb * 2) != hipSuccess) return GMVAE_E_ALIGN; cap_b = nb; }
+    if (cfg == 6) {
+      unsigned* const u = reinterpret_cast<unsigned*>(sc);
+      launch_amax(cx.st, static_cast<const float*>(A), (long long)na, u + 16);
+      launch_amax(cx.st, W, (long long)nb, u + 16 + kAmaxBlocks);
+      launch_amax_final(cx.st, u + 16, kAmaxBlocks, u + 16 + kAmaxBlocks, kAmaxBlocks, u, sc + 2);
+      launch_split_pairs(cx.st, static_cast<const float*>(A), nullptr, trans == 2 ? M : K, (long long)na, pa, u);
+      launch_split_pairs(cx.st, W, nullptr, trans == 1 ? K : N, (long long)nb, pb, u + 1);
+    }
+    Problem p;
+    const float* fa = reinterpret_cast<const float*>(pa);
+    const float* fb = reinterpret_cast<const float*>(pb);
+    tl_hact = 1;
+    if (trans == 0) p = p_nn(fa, false, K, fb, N, M, N, K, C, N, bias, relu != 0);
+    else if (trans == 1) p = p_nt(fa, K, fb, K, M, N, K, C, N, nullptr, 0);
+    else p = p_tn(fa, false, M, 1, fb, N, M, N, K, C, bias ? C + (size_t)M * N : nullptr, splitk, (long long)(M + 1) * N, nullptr);
+    p.planes = 2;
+    p.a_pstride = (long long)na; p.b_pstride = (long long)nb;
+    p.a_uns = sc + 2; p.b_uns = sc + 3; p.uns_c = 1.f; p.uns_cb = 1.f;
+    g.add(p);
+    launch_group(cx, g, "gemm_test_pairs", 2);
+    return cx.err;
+  }
   if (cfg == 4 || cfg == 5) {
     // the pre-split ("planes") instance: cfg 4 splits both operands into scratch planes first, cfg 5 reuses the planes of
     // the previous cfg-4 call (timing the GEMM alone).  M, N multiples of 128, K of 32 (TN: rows K of 32 x splitk).

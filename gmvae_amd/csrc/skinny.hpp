@@ -2328,6 +2328,7 @@ struct RowsProb {
   unsigned short* C3;               // or null
   long long c3_stride;
   int N, relu, ld_add, add_div;
+  unsigned* amax;                   // or null (np == 1 only): word [unit] receives the bits of the largest |out| that wave wrote (gemm.hpp amax_final)
 };
 struct RowsArgs {
   const float* A;                   // [R][K]
@@ -2387,6 +2388,7 @@ __global__ __launch_bounds__(kSkThreads) void rows_nn_bf6(const RowsArgs a) {
   const int nb = c0 + 4 * ln;
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
   if (P.bias) bias = *reinterpret_cast<const float4*>(P.bias + nb);
+  unsigned vmax = 0;
 #pragma unroll
   for (int j = 0; j < RT; ++j)
 #pragma unroll
@@ -2400,6 +2402,8 @@ __global__ __launch_bounds__(kSkThreads) void rows_nn_bf6(const RowsArgs a) {
       }
       if (P.relu) { v[0] = relu_nan(v[0]); v[1] = relu_nan(v[1]); v[2] = relu_nan(v[2]); v[3] = relu_nan(v[3]); }
       *reinterpret_cast<float4*>(P.out + (long long)row * N + nb) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const unsigned b = __float_as_uint(v[t]) & 0x7fffffffu; vmax = b > vmax ? b : vmax; }
       if (P.C3) {
         unsigned hi[2], mi[2], lo[2];
         split_pair(v[0], v[1], hi[0], mi[0], lo[0]);
@@ -2410,6 +2414,7 @@ __global__ __launch_bounds__(kSkThreads) void rows_nn_bf6(const RowsArgs a) {
         *reinterpret_cast<uint2*>(d3 + 2 * P.c3_stride) = make_uint2(lo[0], lo[1]);
       }
     }
+  if (P.amax) { vmax = wave_umax(vmax); if (lane == 0) P.amax[unit] = vmax; }
 }
 
 }  // namespace gmvae
