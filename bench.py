@@ -24,6 +24,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+PLANES_EXACT = os.environ.get("GMVAE_PLANES_EXACT", "0") not in ("", "0")       # the plane GEMMs' piece form (gmvae_hip.hip run_step)
+PLANE_PIECES = 6.0 if PLANES_EXACT else 3.0
+PLANES_DTYPE = ("f32 (products as 6 exact bf16 piece products, fp32 accumulation)" if PLANES_EXACT else
+                "f32 (products as 3 f16 piece products of scaled pairs: <= 3 x 2^-22 per product; fp32 accumulation)")
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 peak (v_mfma_f32_32x32x16_bf16)
 
 
@@ -631,11 +635,13 @@ def main():
         schedule = LIB.step_schedule(eng.dims(B), eng.model)
         roof["schedule"] = schedule
         if schedule.endswith("+planes") and dom[0] in ("fwd_dec_bernoulli", "bwd_dec_top"):
-            # the launch multiplies fp32 values as SIX bf16 piece products per product on pre-split operands (gemm.hpp
-            # plane_rounds): its matrix-pipe peak is the dense bf16 peak / 6 in fp32-equivalent FLOP/s
-            pk = PEAK_BF16_MFMA_TFLOPS / 6.0
+            # the launch multiplies fp32 values as piece products on pre-split operands (gemm.hpp plane_rounds2 / plane_rounds3):
+            # THREE v_mfma_f32_32x32x16_f16 per product on f16 pairs (SIX ..._bf16 on the exact bf16 triples under
+            # GMVAE_PLANES_EXACT=1); its matrix-pipe peak is the dense 16-bit peak / that count in fp32-equivalent FLOP/s
+            pk = PEAK_BF16_MFMA_TFLOPS / PLANE_PIECES
             roof.update({"peak": pk, "frac": roof["achieved"] / pk, "frac_in_kernel_span": dom[2] / dom[1] * 1e-6 / pk,
-                         "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product; fp32 accumulation",
+                         "piece_products_per_product": PLANE_PIECES,
+                         "peak_note": f"dense f16 / bf16 MFMA peak 2500 TFLOP/s / {PLANE_PIECES:.0f} piece products per fp32 product; fp32 accumulation",
                          "frac_of_f32_mfma_peak": roof["achieved"] / PEAK_F32_MFMA_TFLOPS})
         if dom[0].startswith("sk_dw") and 28.0 * eng.P_real / (PEAK_HBM_GBS * 1e9) >= dom[2] / (PEAK_F32_MFMA_TFLOPS * 1e12):
             # the skinny schedule's longest launch is the weight-gradient + TF-Adam launch: at small batches bound by HBM, not by
@@ -704,7 +710,8 @@ def main():
                 roof["rocprof_kernels"] = hit
                 roof["frac_rocprof"] = (roof["bytes_per_launch"] / us * 1e-3 / PEAK_HBM_GBS if roof["bound"] == "hbm"
                                         else dom[2] / us * 1e-6 / roof["peak"])
-            pl = [k for k in kern_us if k.startswith("void gmvae::gemm_grouped<gmvae::Cfg<128, 128, 32, 2, 2, 1, 2>, 0, 2>")]
+            pl = [k for k in kern_us if k.startswith("void gmvae::gemm_grouped<gmvae::Cfg<128, 128, 32, 2, 2, 1, 2>, 0, %d>" % (2 if PLANES_EXACT else 3))
+                  or k.startswith("void gmvae::gemm_grouped<gmvae::Cfg<128, 128, 32, 2, 2, 1, 2>, %d>" % (2 if PLANES_EXACT else 3))]
             if not hit and pl and schedule.endswith("+planes") and dom[0] in ("fwd_dec_bernoulli", "bwd_dec_top"):
                 # the plane instance runs exactly two launches per step (logits + Bernoulli; weight and data gradient): the
                 # committed average is over both, so the fraction is priced on both launches' FLOPs together
@@ -753,7 +760,7 @@ def main():
             "ms_per_step_median_of_repeats": region_ms[len(region_ms) // 2] if region_ms else None,
             "ms_per_step_repeats": [round(v, 5) for v in region_ms] if region_ms else None,
             "steps_per_graph_launch": unit, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if not (roof or {}).get("schedule", "").endswith("+planes") else "f32 (products as 6 bf16 piece products, fp32 accumulation)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if not (roof or {}).get("schedule", "").endswith("+planes") else PLANES_DTYPE, "data": "synthetic",
             "config": {"workload": f"{a.model} train step (noise+fwd+bwd+allreduce+TF-Adam), D={d.D} K={d.K} "
                                    f"L={d.L} hidden={hidden} S={d.S}, batch {B}/GPU x {n_gpus} GPU "
                                    f"({workload_name(a, n_gpus)})",

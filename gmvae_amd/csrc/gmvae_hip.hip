@@ -1733,8 +1733,8 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   const bool planes = planes_ok(d, L) && w.hd3 != nullptr;
   // the piece form of the plane GEMMs: f16 pairs (3 piece products, <= 3 x 2^-22 per product) unless GMVAE_PLANES_EXACT=1 asks for
   // the bf16 triples (6 piece products, every product exact)
-  static const bool exact_env = getenv("GMVAE_PLANES_EXACT") && atoi(getenv("GMVAE_PLANES_EXACT"));
-  const bool pairs = planes && !exact_env;
+  const char* const exact_env = getenv("GMVAE_PLANES_EXACT");
+  const bool pairs = planes && !(exact_env && atoi(exact_env));
   constexpr float kGScale = 32768.f;            // (sigmoid - x) in [-1, 1]: a fixed scale for its pairs
 
   // ---- noise (fast mode): Philox for eps and u -- its own launch in the general schedule, auxiliary

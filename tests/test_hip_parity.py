@@ -119,10 +119,11 @@ def test_gemm_big_rounds_instance(H, monkeypatch, trans, M, N, K, ns):
                                             (2, 256, 128, 320, 3), (0, 128, 128, 32, 1), (1, 128 * 131, 512, 64, 1),
                                             (2, 512, 128 * 43, 96, 3), (0, 128 * 67, 128 * 16, 64, 1)])
 def test_gemm_plane_rounds_instance(H, trans, M, N, K, ns):
-    """Operands split ONCE into three planes of 16-bit pieces (gemm.hpp split_planes_b16: planes blocked by 16) and multiplied
-    as six exact bf16 piece products with fp32 accumulation through the LDS-DMA ring of plane_rounds3 (`cfg` 4 of
-    gmvae_gemm_test) -- every operand orientation (NN / NT / TN with split-K and the bias-gradient column sums) to fp32-GEMM
-    accuracy against fp64, and no further from it than the fp32 MFMA instance is."""
+    """Operands split ONCE into planes of 16-bit pieces (blocked by 16) and multiplied as piece products with fp32 accumulation
+    through the LDS-DMA rings of gemm.hpp: f16 PAIRS under per-tensor power-of-two scales, three piece products per product
+    (plane_rounds2, `cfg` 6 of gmvae_gemm_test: amax_abs + amax_final + split_pairs_b16 first) and bf16 TRIPLES, six exact
+    piece products (plane_rounds3, `cfg` 4) -- every operand orientation (NN / NT / TN with split-K and the bias-gradient
+    column sums) to fp32-GEMM accuracy against fp64, and no further from it than the fp32 MFMA instance is."""
     L = _L()
     rng = np.random.default_rng(M + 3 * N + 7 * K + trans)
     if trans == 0:
@@ -139,7 +140,7 @@ def test_gemm_plane_rounds_instance(H, trans, M, N, K, ns):
         shape = (ns, M + 1, N)
     Ad, Wd = H.dev(A), H.dev(W)
     err = []
-    for cfg in (4, 2):
+    for cfg in (6, 4, 2):
         Cd = torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
         L.check(L.lib.gmvae_gemm_test(L.ptr(Ad), 0, L.ptr(Wd), L.ptr(Wd) if trans == 2 else None, L.ptr(Cd), M, N, K, trans, 0,
                                       cfg, ns, L.current_stream()), "gemm_test")
@@ -147,7 +148,59 @@ def test_gemm_plane_rounds_instance(H, trans, M, N, K, ns):
         got = got.sum(axis=0) if trans == 2 else got
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=3e-5 * math.sqrt(K))
         err.append(np.abs(got - ref).max())
-    assert err[0] <= 2.0 * err[1] + 1e-6, err
+    assert err[0] <= 2.0 * err[2] + 1e-6 and err[1] <= 2.0 * err[2] + 1e-6, err
+
+
+@pytest.mark.parametrize("trans", [0, 1, 2])
+@pytest.mark.parametrize("case", ["huge x tiny", "20 binades inside a tensor", "sparse rows", "one operand all zero", "a NaN", "subnormal maximum"])
+def test_gemm_pair_scales(H, trans, case):
+    """The f16 pairs' scaling (gemm.hpp pair_scale / split_pairs_b16): the power-of-two scale comes from the tensor's own
+    largest magnitude, so tensors of ANY magnitude multiply to fp32-GEMM accuracy (fp16's range never shows); inside one tensor
+    an element keeps its 22 bits down to 2^-29 of the largest (the shifted second piece has the first one's exponent) -- rows 10^6
+    times smaller than others still come out to 1e-5 of THEIR OWN scale; an all-zero operand gives exact zeros; a NaN
+    propagates to the outputs it touches and to no others."""
+    L = _L()
+    M, N, K, ns = 256, 128, 512, 2
+    rng = np.random.default_rng(trans + 17)
+    a_shape = (K, M) if trans == 2 else (M, K)
+    w_shape = (N, K) if trans == 1 else (K, N)
+    A, W = rng.normal(size=a_shape), rng.normal(size=w_shape)
+    row_scale = np.ones(M)
+    if case == "huge x tiny":
+        A *= 3e30; W *= 2e-34
+    elif case == "20 binades inside a tensor":
+        row_scale = 2.0 ** -rng.integers(0, 21, size=M)
+    elif case == "sparse rows":
+        row_scale = np.where(rng.random(M) < 0.5, 1.0, 1e-6)
+    elif case == "one operand all zero":
+        W[:] = 0.0
+    elif case == "subnormal maximum":
+        A *= 1e-41 / np.abs(A).max()
+    A = A * (row_scale[None, :] if trans == 2 else row_scale[:, None])
+    A, W = A.astype(np.float32), W.astype(np.float32)
+    if case == "a NaN":
+        if trans == 2: A[5, 7] = np.nan
+        else: A[7, 5] = np.nan
+    A64, W64 = A.astype(np.float64), W.astype(np.float64)
+    ref = A64 @ W64 if trans == 0 else (A64 @ W64.T if trans == 1 else A64.T @ W64)
+    shape = (ns, M + 1, N) if trans == 2 else (M, N)
+    Cd = torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
+    Ad, Wd = H.dev(A), H.dev(W)
+    L.check(L.lib.gmvae_gemm_test(L.ptr(Ad), 0, L.ptr(Wd), None, L.ptr(Cd), M, N, K, trans, 0, 6, ns, L.current_stream()), "gemm_test")
+    got = Cd.cpu().numpy().astype(np.float64)
+    got = got.sum(axis=0)[:M] if trans == 2 else got
+    if case == "a NaN":
+        assert np.isnan(got[7]).all() and not np.isnan(np.delete(got, 7, axis=0)).any()
+        got, ref = np.delete(got, 7, axis=0), np.delete(ref, 7, axis=0)
+    if case == "one operand all zero":
+        assert (got == 0).all()
+        return
+    # every output ROW against the scale of that row's own products (not the tensor's): sqrt(K) |a_row| |w| typical
+    row_mag = np.sqrt((A64 ** 2).sum(0 if trans == 2 else 1))
+    if case == "a NaN": row_mag = np.delete(row_mag, 7)
+    w_mag = np.sqrt((W64 ** 2).mean())
+    err = np.abs(got - ref).max(axis=1) / (row_mag * w_mag)
+    assert err.max() <= (1e-3 if case == "subnormal maximum" else 1e-5), (case, err.max())       # (fp32 denormal INPUTS carry few bits themselves)
 
 
 # ------------------------------------------------------------ full step
@@ -325,14 +378,18 @@ def test_big_round_gemm_inside_the_step_iwae(H, monkeypatch, model):
     np.testing.assert_allclose(g_big, g_gen, rtol=0, atol=2e-4 * np.abs(g_gen).max())
 
 
+@pytest.mark.parametrize("exact", [0, 1], ids=["f16 pairs", "bf16 triples"])
 @pytest.mark.parametrize("model,S,hidden", [(O.MODEL_GMVAE, 4, (128,)), (O.MODEL_VAE, 1, (64, 128)), (O.MODEL_VAE_GMP, 2, (128,))])
-def test_plane_gemms_inside_the_step(H, monkeypatch, model, S, hidden):
-    """The top decoder layer's three GEMMs on pre-split operands (gemm.hpp plane_rounds3; by default from 4096 rows, forced
-    here at R = B*S = 128 / 256 rows, H = 128, D = 256): the hidden activation and the weight split by split_planes_b16,
-    (sigmoid - x) written as planes by the Bernoulli epilogue, the IWAE row weights riding on the activation's pieces and
+def test_plane_gemms_inside_the_step(H, monkeypatch, model, S, hidden, exact):
+    """The top decoder layer's three GEMMs on pre-split operands (gemm.hpp plane_rounds2 / plane_rounds3; by default from 4096
+    rows, forced here at R = B*S = 128 / 256 rows, H = 128, D = 256), in both piece forms -- f16 pairs (the default: the
+    activation's largest magnitude from the producing launch or amax_abs, the weight's from amax_abs, amax_final,
+    split_pairs_b16; (sigmoid - x) written as pairs under a fixed scale by the Bernoulli epilogue) and bf16 triples
+    (GMVAE_PLANES_EXACT=1: split_planes_b16, three planes) -- the IWAE row weights riding on the activation's pieces and
     weighing the bias gradient's column sums -- against the oracle at the step's gates, NOT bit-identical to the fp32 MFMA
     instance (evidence that the path ran) and as close to it as fp32 rounding."""
     monkeypatch.setenv("GMVAE_PLANES_MINROWS", "128")
+    monkeypatch.setenv("GMVAE_PLANES_EXACT", str(exact))
     d = O.Dims(D=256, L=64, K=10, hidden=hidden, S=S)
     rng = np.random.default_rng(6)
     p = O.init_params(model, d, rng)
@@ -344,6 +401,9 @@ def test_plane_gemms_inside_the_step(H, monkeypatch, model, S, hidden):
     H.compare_step(model, d, p, x, eps, u)
     flat = O.pack(model, d, p, np.float32)
     g_pl, _ = H.hip_step(model, d, flat, x, eps, u)
+    monkeypatch.setenv("GMVAE_PLANES_EXACT", str(1 - exact))
+    g_other, _ = H.hip_step(model, d, flat, x, eps, u)
+    assert not np.array_equal(g_pl, g_other)                     # (the two piece forms are different arithmetic)
     monkeypatch.setenv("GMVAE_NO_PLANES", "1")
     g_f32, _ = H.hip_step(model, d, flat, x, eps, u)
     assert not np.array_equal(g_pl, g_f32)
