@@ -130,6 +130,7 @@ struct Launch {
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int NBUF_ = 2>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_, NBUF = NBUF_;
+  static constexpr int THREADS = 64 * WM * WN * WK;                  // 256; 512 for the 256 x 128 pair-plane instance (BIG = 3 only)
   static constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   static constexpr int LDA = BM + 1, LDB = BN + 1, LDC = BN + 4;
   static constexpr int NSA = BM * BK / 4 / kThreads, NSB = BN * BK / 4 / kThreads;
@@ -137,12 +138,14 @@ struct Cfg {
   static constexpr int CST = WK * BM * LDC;                          // floats, C staging
   static constexpr int XBF = (BM == 64 && BN == 64 && BK == 64) ? 4 * 64 * 96 / 2 : 0;     // the bf16 path's 4 images [64][96] x 2 B
   static constexpr int CSP = BM >= 128 ? 8 : 4;                      // column-sum partials per thread (plane_rounds3: 8)
-  static constexpr int LDS0 = OPS > CST + CSP * kThreads ? OPS : CST + CSP * kThreads;
-  static constexpr int LDS_FLOATS = LDS0 > XBF ? LDS0 : XBF;
+  static constexpr int LDS0 = OPS > CST + CSP * THREADS ? OPS : CST + CSP * THREADS;
+  static constexpr int LDS1 = LDS0 > XBF ? LDS0 : XBF;
+  static constexpr int P2R = (BM >= 128 && BN == 128) ? 4 * (BM * 16 + 2048) : 0;      // plane_rounds2's ring of 4 (floats: 2 planes x (BM + BN) x 16 k x 2 B per buffer)
+  static constexpr int LDS_FLOATS = LDS1 > P2R ? LDS1 : P2R;
   // waves per SIMD the register allocator must leave room for: the small configuration's launches carry more
   // workgroups than 2 per CU (tiles + auxiliary blocks), and a workgroup that starts late ends the launch late
   static constexpr int WAVES_EU = (BM * BN <= 32 * 32 || (NBUF == 1 && BM * BN <= 64 * 64)) ? 3 : (BM * BN >= 128 * 128 ? 2 : 1);
-  static_assert(WM * WN * WK == 4, "4 waves per workgroup");
+  static_assert(WM * WN * WK == 4 || (BM == 256 && WM * WN * WK == 8), "4 waves per workgroup (8 for 256 x 128)");
   static_assert(NSA >= 1 && NSB >= 1, "tile too small for 256 threads");
   static_assert((BK / WK) % 2 == 0, "k slice per wave must be even");
 };
@@ -151,6 +154,7 @@ typedef Cfg<64, 64, 64, 2, 2, 1> CfgM;
 typedef Cfg<64, 64, 64, 2, 2, 1, 1> CfgM1;  // single staging buffer (48 KB with the bf16 images): 3 workgroups per CU, for
                                             // launches whose tiles are one or two rounds long
 typedef Cfg<128, 128, 32, 2, 2, 1> CfgL;    // MFMA-bound: 64x64 per wave
+typedef Cfg<256, 128, 32, 4, 2, 1> CfgX;    // f16-pair planes only (gemm_grouped<CfgX, 3>): 8 waves of 64x64, one workgroup per CU
 // (Single-round variants -- BK = the whole k range of a split, one batch of loads -- were measured and dropped:
 // the staging phase of these launches scales with the bytes requested, not with the number of round trips.)
 
@@ -500,6 +504,13 @@ __device__ __forceinline__ void plane_rounds3(unsigned short* __restrict__ img, 
   bf16x8_t fa[2][3], fb[2][3], ga[2][3], gb[2][3];
   GMVAE_P3_DMA(0)
   GMVAE_P3_DMA(1)                                // (NC16 >= 2)
+  // (the accumulators start here, inside the orientation's own copy of the loop -- see plane_rounds2)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   if (NC16 > 2) {
     GMVAE_P3_DMA(2)
     asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");    // round 0 has landed, two rounds stay in flight
@@ -568,14 +579,26 @@ __device__ __forceinline__ void split_f16pair(const float v0, const float v1, un
 __device__ __forceinline__ float f16lo(const unsigned w) { return (float)__builtin_bit_cast(f16x2_t, w).x; }
 __device__ __forceinline__ float f16hi(const unsigned w) { return (float)__builtin_bit_cast(f16x2_t, w).y; }
 
-// The loop: plane_rounds3's layout, staging and fragment reads with two planes per operand -- 16 KB per 16-deep round, a ring
-// of FOUR buffers (64 KB: round c + 4 is requested behind round c's barrier and waited for three rounds later), 12 matrix
-// instructions and 8 (k-contiguous) / 16 (transposing) fragment reads per wave and round.
-constexpr int kP2Op = 2 * 2048;                 // 16-bit elements per operand image: 2 planes of 128 x 16
-constexpr int kP2Buf = 2 * kP2Op;               // A | B
+// The loop: plane_rounds3's layout, staging and fragment reads with two planes per operand, for workgroup tiles of BM x 128,
+// BM = 128 (4 waves, two workgroups per CU) or 256 (8 waves, one workgroup per CU: every wave still multiplies 64 x 64, but a
+// round's images are 24 KB for twice the products -- the loop is bound by the stream of pieces into LDS, measured below).  A ring
+// of FOUR buffers of (BM + 128) x 16 k x 2 planes x 2 B (16 / 24 KB): round c + 4 is requested behind round c's barrier and
+// waited for three rounds later (rings of 3 and 5 buffers ran the same / 2 % slower); per wave and round 12 matrix instructions,
+// 4 / 3 LDS-DMA instructions and 8 (k-contiguous) / 16 (transposing) fragment reads.
+// Timing experiments at BM = 128 (results discarded; 25600x512x3072 NT / 512x3072x25600 TN, us): whole loop 267 / 292; without
+// its matrix instructions 185 / 216; with neither those nor the fragment reads 194 / 218 -- the DMA stream alone, 12.9 TB/s
+// chip-wide, MI355X_MICROARCH.md's rate for an L2 / fabric mix like this one's; without the DMAs 147 / 168.  The two streams
+// overlap only in part (both slow down with the clock the matrix pipes throttle to: 2.05 GHz in the step), so fewer bytes per
+// product is what shortens the loop: the 256-row tile.
 constexpr int kP2Ring = 4;
+template <int BM> struct P2 {
+  static constexpr int PA = BM * 16;            // 16-bit elements per plane image of a (BM x 16 k); b's: 2048
+  static constexpr int OpA = 2 * PA, Buf = OpA + 4096;
+  static constexpr int NW = BM / 32;            // waves
+  static constexpr int DPW = NW == 4 ? 4 : 3;   // LDS-DMA instructions per wave and round
+};
 
-template <bool AMC, bool BMC>
+template <bool AMC, bool BMC, int BM>
 __device__ __forceinline__ void plane_rounds2(unsigned short* __restrict__ img, const unsigned short* __restrict__ A,
                                               const uint32_t a_rows, const long long a_ps, const unsigned short* __restrict__ Bp,
                                               const uint32_t b_rows, const long long b_ps, const float* __restrict__ kscale,
@@ -583,8 +606,13 @@ __device__ __forceinline__ void plane_rounds2(unsigned short* __restrict__ img, 
                                               const int tid, const int lane, const int wave, const int wm0, const int wn0,
                                               f32x16 (&acc)[2][2], f32x16 (&accx)[2][2], float (&cs8)[8]) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  uint32_t ea = p3_src<AMC>(wave, lane, a_rows, m0, kb), eb = p3_src<BMC>(wave, lane, b_rows, n0, kb);
+  typedef P2<BM> G;
+  // staging: this wave's pieces (1 KB each).  BM = 128: piece `wave` of both planes of a and of b.  BM = 256: piece `wave` of both
+  // planes of a (8 pieces per plane), and ONE of b's 8 pieces (plane wave >> 2, piece wave & 3)
+  uint32_t ea = p3_src<AMC>(wave, lane, a_rows, m0, kb), eb = p3_src<BMC>(wave & 3, lane, b_rows, n0, kb);
   const uint32_t a_round = AMC ? 256u : 16u * a_rows, b_round = BMC ? 256u : 16u * b_rows;
+  const unsigned short* const Bw = Bp + (G::NW == 8 ? (wave >> 2) * b_ps : 0);
+  const int b_dst = G::OpA + (G::NW == 8 ? (wave >> 2) * 2048 : 0) + (wave & 3) * 512;
   int fa0, fa1, fb0, fb1;
   {
     const int l31 = lane & 31, g16 = lane >> 4, i16 = lane & 15;
@@ -596,27 +624,29 @@ __device__ __forceinline__ void plane_rounds2(unsigned short* __restrict__ img, 
     fb0 = BMC ? (wn0 >> 4) * 256 + mc0 : wn0 * 16 + kc;
     fb1 = BMC ? (wn0 >> 4) * 256 + mc1 : 0;
   }
-  const int cs_k = tid >> 4, cs_ch = tid & 15;
+  // column sums (bias gradient; b mn-contiguous): thread (k = tid >> 4, 8 columns 8 (tid & 15)..) of the first 256 reads its chunk back
+  const bool cs_on = BMC && do_cs && tid < 256;
+  const int cs_k = (tid >> 4) & 15, cs_ch = tid & 15;
   const int cs_off = (cs_ch >> 1) * 256 + ((cs_k + 4 * ((cs_ch >> 1) & 1)) & 15) * 16 + 8 * (cs_ch & 1);
   int kk = kb + cs_k;
 #define GMVAE_P2_DMA(buf_)                                                                                 \
   {                                                                                                        \
-    unsigned short* const d_ = img + (buf_) * kP2Buf + wave * 512;                                         \
-    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                     \
-      __builtin_amdgcn_global_load_lds(A + pl * a_ps + ea, d_ + pl * 2048, 16, 0, 0);                      \
-      __builtin_amdgcn_global_load_lds(Bp + pl * b_ps + eb, d_ + kP2Op + pl * 2048, 16, 0, 0);             \
-    }                                                                                                      \
+    unsigned short* const d_ = img + (buf_) * G::Buf;                                                      \
+    __builtin_amdgcn_global_load_lds(A + ea, d_ + wave * 512, 16, 0, 0);                                   \
+    __builtin_amdgcn_global_load_lds(A + a_ps + ea, d_ + G::PA + wave * 512, 16, 0, 0);                    \
+    __builtin_amdgcn_global_load_lds(Bw + eb, d_ + b_dst, 16, 0, 0);                                       \
+    if (G::NW == 4) __builtin_amdgcn_global_load_lds(Bw + b_ps + eb, d_ + b_dst + 2048, 16, 0, 0);         \
     ea += a_round; eb += b_round;                                                                          \
   }
   // (order: what the next round multiplies first -- row block 0 of a, both column blocks of b -- is read first)
 #define GMVAE_P2_FRAGS(FA_, FB_, buf_)                                                                     \
   {                                                                                                        \
-    const unsigned short* const ia_ = img + (buf_) * kP2Buf;                                               \
-    const unsigned short* const ib_ = ia_ + kP2Op;                                                         \
-    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) FA_[0][pl] = __builtin_bit_cast(f16x8_t, p3_frag<AMC>(ia_ + pl * 2048, fa0, fa1));        \
-    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) FB_[0][pl] = __builtin_bit_cast(f16x8_t, p3_frag<BMC>(ib_ + pl * 2048, fb0, fb1));        \
-    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) FB_[1][pl] = __builtin_bit_cast(f16x8_t, p3_frag<BMC>(ib_ + pl * 2048 + 512, fb0, fb1));  \
-    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) FA_[1][pl] = __builtin_bit_cast(f16x8_t, p3_frag<AMC>(ia_ + pl * 2048 + 512, fa0, fa1));  \
+    const unsigned short* const ia_ = img + (buf_) * G::Buf;                                               \
+    const unsigned short* const ib_ = ia_ + G::OpA;                                                        \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) FA_[0][pl] = __builtin_bit_cast(f16x8_t, p3_frag<AMC>(ia_ + pl * G::PA, fa0, fa1));        \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) FB_[0][pl] = __builtin_bit_cast(f16x8_t, p3_frag<BMC>(ib_ + pl * 2048, fb0, fb1));         \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) FB_[1][pl] = __builtin_bit_cast(f16x8_t, p3_frag<BMC>(ib_ + pl * 2048 + 512, fb0, fb1));   \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) FA_[1][pl] = __builtin_bit_cast(f16x8_t, p3_frag<AMC>(ia_ + pl * G::PA + 512, fa0, fa1));  \
   }
   // row block i_ against both column blocks: six instructions, consecutive ones on different accumulators
 #define GMVAE_P2_TILES(FA_, FB_, i_)                                                                       \
@@ -636,8 +666,8 @@ __device__ __forceinline__ void plane_rounds2(unsigned short* __restrict__ img, 
   // when it waits for the next one, round c_ + 4 is requested behind the barrier into the buffer it has just finished
 #define GMVAE_P2_ROUND(CA_, CB_, NA_, NB_, c_, bc_, bn_)                                                   \
   {                                                                                                        \
-    if (BMC && do_cs) {                                                                                    \
-      const unsigned short* const ib_ = img + (bc_) * kP2Buf + kP2Op + cs_off;                             \
+    if (cs_on) {                                                                                           \
+      const unsigned short* const ib_ = img + (bc_) * G::Buf + G::OpA + cs_off;                            \
       const u32x4 h_ = *reinterpret_cast<const u32x4*>(ib_), l_ = *reinterpret_cast<const u32x4*>(ib_ + 2048);   \
       const float sc = kscale ? kscale[kk] : 1.f;                                                          \
       _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
@@ -649,8 +679,8 @@ __device__ __forceinline__ void plane_rounds2(unsigned short* __restrict__ img, 
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     GMVAE_P2_TILES(CA_, CB_, 0)                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
-    if ((c_) + 3 < NC16) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");          \
-    else if ((c_) + 2 < NC16) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");     \
+    if ((c_) + 3 < NC16) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * G::DPW) : "memory");      \
+    else if ((c_) + 2 < NC16) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G::DPW) : "memory");     \
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
     if ((c_) + 4 < NC16) GMVAE_P2_DMA(bc_)                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
@@ -662,12 +692,20 @@ __device__ __forceinline__ void plane_rounds2(unsigned short* __restrict__ img, 
   f16x8_t fa[2][2], fb[2][2], ga[2][2], gb[2][2];
   GMVAE_P2_DMA(0)
   GMVAE_P2_DMA(1)                                // (NC16 >= 2, even)
+  // both accumulator sets start HERE, inside the orientation's own copy of the loop: zeroed by the caller above the four-way
+  // branch, the compiler kept one set of zeros alive in 32 registers through every copy and spilled 46 registers inside the loop
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
   if (NC16 > 2) {
     GMVAE_P2_DMA(2)
     GMVAE_P2_DMA(3)
-    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");    // round 0 has landed, three rounds stay in flight
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * G::DPW) : "memory");    // round 0 has landed, three rounds stay in flight
   } else {
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G::DPW) : "memory");
   }
   GMVAE_P2_FRAGS(fa, fb, 0)
   int bc = 0;
@@ -705,8 +743,17 @@ __device__ __forceinline__ void big_rounds(float* __restrict__ lds, const float*
                                            const float* __restrict__ Bp, const uint32_t b_ld,
                                            const float* __restrict__ kscale, const int m0, const int n0, const int kb,
                                            const int NC, const int tid, const int lane, const int wm0, const int wn0,
-                                           f32x16 (&acc)[2][2], float4& cs4) {
+                                           f32x16 (&acc)[2][2], float4& cs4, const bool first) {
   const int h = lane >> 5, l31 = lane & 31;
+  // (a problem's first segment starts the accumulators here, inside the orientation's own copy of the loop -- see plane_rounds2)
+  if (first) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
   // the per-k scale and the column sums ride only beside an mn-contiguous b; both are wave-uniform run-time options (as
   // template parameters they made ten copies of this loop in one kernel)
   const bool KS = BMC && kscale != nullptr;
@@ -855,7 +902,7 @@ __device__ __forceinline__ void big_rounds(float* __restrict__ lds, const float*
 // checks: big_eligible); its only main loop is big_rounds -- a kernel of its own so that the general loop's loaders do
 // not share its register budget.  BIG = 2: every problem of the launch reads pre-split planes (plane_rounds3).
 template <class C, int BIG = 0>
-__global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Launch L) {
+__global__ __launch_bounds__(C::THREADS, C::WAVES_EU) void gemm_grouped(const Launch L) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   constexpr int kBK = C::BK;
   const int tid = threadIdx.x;
@@ -952,18 +999,20 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
   const int khalf = lane >> 5, l31 = lane & 31;
 
   f32x16 acc[C::TM][C::TN];
+  if constexpr (BIG <= 1) {       // (the plane instances start their accumulators inside their loops: one segment)
 #pragma unroll
-  for (int i = 0; i < C::TM; ++i)
+    for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-    for (int j = 0; j < C::TN; ++j)
+      for (int j = 0; j < C::TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
 
   // bias gradient of a dW problem: column sums of b over this tile's k range (first tile row only)
   float* const colsum_out = L.p[pi].colsum_out;
   const bool do_colsum = colsum_out != nullptr && tm == 0;
   float csum = 0.f;
-  constexpr int CSG = kThreads / C::BN;          // k groups of the column-sum threads
+  constexpr int CSG = C::THREADS / C::BN;        // k groups of the column-sum threads
   const int cs_n = tid % C::BN, cs_k = tid / C::BN;
   bool did_bf16 = false, did_big = false, did_planes = false;
   float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1130,24 +1179,18 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
       continue;
     }
     if constexpr (BIG == 3) {                     // every problem of the launch reads f16 pairs (host: planes_eligible, planes == 2)
-      static_assert(C::BM == 128 && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2, "plane rounds: 128x128x32");
+      static_assert((C::BM == 128 || C::BM == 256) && C::BN == 128 && C::BK == 32 && C::TM == 2 && C::TN == 2, "plane rounds: 128 / 256 x128x32");
       __syncthreads();        // LDS is free
       if (sgi == 0) GMVAE_GSTAMP(6);
       const unsigned short* const Ah = static_cast<const unsigned short*>(a_ptr);
       const unsigned short* const Bh = static_cast<const unsigned short*>(b_ptr);
       const long long a_ps = L.p[pi].a_pstride, b_ps = L.p[pi].b_pstride;
-      static_assert(kP2Ring * kP2Buf * 2 <= C::LDS_FLOATS * 4, "plane_rounds2's ring must fit the kernel's LDS");
-      f32x16 accx[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) accx[i][j][r] = 0.f;
+      static_assert(kP2Ring * P2<C::BM>::Buf * 2 <= C::LDS_FLOATS * 4, "plane_rounds2's ring must fit the kernel's LDS");
+      f32x16 accx[2][2];                          // (plane_rounds2 zeroes both sets: nseg == 1)
       {
         const uint32_t a_rows = a_mc ? (uint32_t)K : (uint32_t)a_n, b_rows = b_mc ? (uint32_t)K : (uint32_t)b_n;
 #define GMVAE_PL2(AMC_, BMC_) \
-  plane_rounds2<AMC_, BMC_>(reinterpret_cast<unsigned short*>(lds), Ah, a_rows, a_ps, Bh, b_rows, b_ps, kscale, do_colsum, m0, n0, kb, \
+  plane_rounds2<AMC_, BMC_, C::BM>(reinterpret_cast<unsigned short*>(lds), Ah, a_rows, a_ps, Bh, b_rows, b_ps, kscale, do_colsum, m0, n0, kb, \
                             2 * NC, tid, lane, wave, wm0, wn0, acc, accx, cs8)
         if (!b_mc) {
           if (a_mc) GMVAE_PL2(true, false); else GMVAE_PL2(false, false);
@@ -1177,7 +1220,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
       const float* const Af = static_cast<const float*>(a_ptr);
       const float* const Bf = static_cast<const float*>(b_ptr);
 #define GMVAE_BIG(AMC_, BMC_) \
-  big_rounds<AMC_, BMC_>(lds, Af, (uint32_t)a_ld, Bf, (uint32_t)b_ld, kscale, m0, n0, kb, NC, tid, lane, wm0, wn0, acc, cs4)
+  big_rounds<AMC_, BMC_>(lds, Af, (uint32_t)a_ld, Bf, (uint32_t)b_ld, kscale, m0, n0, kb, NC, tid, lane, wm0, wn0, acc, cs4, sgi == 0)
       if (!b_mc) {
         if (a_mc) GMVAE_BIG(true, false); else GMVAE_BIG(false, false);
       } else {
@@ -1188,6 +1231,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
       if (sgi == 0) GMVAE_GSTAMP(1);
       continue;
     }
+    if constexpr (BIG == 0) {       // (the instances above always `continue`: their kernels do not carry the general loop)
     __syncthreads();          // LDS is free (first segment: trivially; second: previous loop finished)
     if (sgi == 0) GMVAE_GSTAMP(6);
     GMVAE_GLOAD(0);
@@ -1222,6 +1266,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
       if (C::NBUF == 1 && c + 1 < NC) __syncthreads();     // everyone is done reading the only buffer
       if (c + 1 < NC) GMVAE_LSTORE(C::NBUF == 2 ? ((c + 1) & 1) : 0);
       __syncthreads();
+    }
     }
 #undef GMVAE_LOAD_A
 #undef GMVAE_FAST_A
@@ -1283,7 +1328,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
   const float* bias2 = L.p[pi].bias2;
   const float addconst = L.p[pi].addconst;
   constexpr int GPR = C::BN / 4;                 // groups per row (8, 16 or 32 consecutive lanes)
-  constexpr int PASSES = C::BM * GPR / kThreads;
+  constexpr int PASSES = C::BM * GPR / C::THREADS;
   if (epi == EPI_STORE) {
     const float* addsrc = L.p[pi].addsrc;
     const float* mask = L.p[pi].mask;
@@ -1301,7 +1346,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
       float* const dst0 = Cout + soff + (long long)m0 * ldc + n0;
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) {
-        const int gidx = tid + ps * kThreads;
+        const int gidx = tid + ps * C::THREADS;
         const int row = gidx / GPR, c4 = gidx % GPR;
         float4 v4 = *reinterpret_cast<const float4*>(lds + row * C::LDC + 4 * c4);
 #pragma unroll
@@ -1316,7 +1361,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
       // interior tile with options: 16-byte loads of every per-element option, ALL passes' loads in flight together (the
       // accumulators are staged, their registers are free): one pass at a time, each pass waits a full memory round trip --
       // ~20 % of a 16-round tile at the config-5 sizes, most of a 4-round one
-      constexpr int RPP = kThreads / GPR;        // rows per pass; the column group is the same in every pass
+      constexpr int RPP = C::THREADS / GPR;        // rows per pass; the column group is the same in every pass
       constexpr int PB = PASSES;          // every pass's loads in flight together: ONE memory round trip per tile
       const int c4 = tid % GPR, r0 = tid / GPR, nb = n0 + 4 * c4;
       float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1366,7 +1411,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
     } else
 #pragma unroll 1
     for (int ps = 0; ps < PASSES; ++ps) {
-      const int gidx = tid + ps * kThreads;
+      const int gidx = tid + ps * C::THREADS;
       const int row = gidx / GPR, c4 = gidx % GPR;
       float4 v4 = *reinterpret_cast<const float4*>(lds + row * C::LDC + 4 * c4);
 #pragma unroll
@@ -1424,7 +1469,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
       // accumulator quad are requested before the first is used (ONE memory and ONE LDS round trip per tile), and the row
       // sums meet through LDS at the end (a butterfly of 5 dependent cross-lane steps per pass was 80 LDS round trips per
       // tile, each several hundred cycles beside the co-resident workgroup's fragment reads: 22 us of a 77 us tile)
-      constexpr int RPP = kThreads / GPR;
+      constexpr int RPP = C::THREADS / GPR;
       const int c4 = tid % GPR, r0 = tid / GPR, nb = n0 + 4 * c4;
       float4 b4 = *reinterpret_cast<const float4*>(bias + nb);
       if (bias2) { const float4 c4v = *reinterpret_cast<const float4*>(bias2 + nb); b4.x += c4v.x; b4.y += c4v.y; b4.z += c4v.z; b4.w += c4v.w; }
@@ -1491,7 +1536,7 @@ __global__ __launch_bounds__(kThreads, C::WAVES_EU) void gemm_grouped(const Laun
     } else
 #pragma unroll 1
     for (int ps = 0; ps < PASSES; ++ps) {
-      const int gidx = tid + ps * kThreads;
+      const int gidx = tid + ps * C::THREADS;
       const int row = gidx / GPR, c4 = gidx % GPR;
       float4 v4 = *reinterpret_cast<const float4*>(lds + row * C::LDC + 4 * c4);
 #pragma unroll

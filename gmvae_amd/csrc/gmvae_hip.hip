@@ -511,7 +511,7 @@ static int tile_up(Launch& L) {
     p.tiles_n = (p.N + C::BN - 1) / C::BN;
     // XCD-aware tile order (gemm.hpp): only where it matters -- many tiles and one operand much larger than the other
     p.xorder = 0;
-    if (C::BM == 128 && (long long)p.tiles_m * p.tiles_n * p.splits >= 512) {
+    if (C::BM >= 128 && (long long)p.tiles_m * p.tiles_n * p.splits >= (C::BM == 256 ? 256 : 512)) {
       // (4: a split-K weight gradient with a multiple of 8 splits: ALL units of one split on one XCD -- the XCD then fetches only
       //  its splits' k slices of BOTH operands; with order 2 every XCD fetched the whole A operand: at config 5 the activation
       //  planes, 78 MB x 8)
@@ -674,7 +674,21 @@ static int launch_group(Ctx& cx, Group& g, const char* name, int cfg = -1, unsig
   if (cfg == 2) {
     tiles = g.L.total_tiles = tile_up<CfgL>(g.L);
     const bool no_big = getenv("GMVAE_NO_BIG") != nullptr;      // diagnostic / A-B: the general loop
-    if (pairs) hipLaunchKernelGGL((gemm_grouped<CfgL, 3>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
+    // f16 pairs: 256-row tiles (one 8-wave workgroup per CU, 0.75 of the LDS-DMA bytes per product) where every problem's rows
+    // allow and no tile ends in the Bernoulli epilogue -- with one workgroup per CU nothing multiplies while a tile's epilogue
+    // runs: config 5's backward launch (tiles of 100 - 192 rounds) 538 -> 513 us, its forward launch (32 rounds + the
+    // Bernoulli epilogue) 309 -> 347.  GMVAE_PAIRS_BM=128 / 256 forces either.
+    bool x256 = pairs, store_only = true;
+    for (int i = 0; i < g.L.nprob && x256; ++i) {
+      x256 = g.L.p[i].M % 256 == 0 && g.L.aux.nblocks == 0;
+      store_only = store_only && g.L.p[i].epi == EPI_STORE;
+    }
+    if (const char* e = getenv("GMVAE_PAIRS_BM")) x256 = x256 && atoi(e) == 256;
+    else x256 = x256 && store_only;
+    if (x256) {
+      tiles = g.L.total_tiles = tile_up<CfgX>(g.L);
+      hipLaunchKernelGGL((gemm_grouped<CfgX, 3>), dim3(tiles), dim3(CfgX::THREADS), 0, cx.st, g.L);
+    } else if (pairs) hipLaunchKernelGGL((gemm_grouped<CfgL, 3>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
     else if (planes) hipLaunchKernelGGL((gemm_grouped<CfgL, 2>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
     else if (!no_big && big_eligible(g.L)) hipLaunchKernelGGL((gemm_grouped<CfgL, 1>), dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
     else hipLaunchKernelGGL(gemm_grouped<CfgL>, dim3(tiles + g.L.aux.nblocks), dim3(kThreads), 0, cx.st, g.L);
