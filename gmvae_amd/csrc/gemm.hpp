@@ -19,6 +19,7 @@
 // valid address and the value is replaced by 0
 // with a select, so edge tiles and K tails run the same code as interior ones.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -1489,40 +1490,58 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_EU) void gemm_grouped(const La
         for (int w = 1; w < C::WK; ++w) vv[q] += *reinterpret_cast<const f32x4*>(lds + (w * C::BM + row) * C::LDC + 4 * c4);
       }
       if (dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); GMVAE_GSTAMP(6); }
+      // The passes, once per combination of outputs -- fp32 matrix or not, no planes / bf16 triples / f16 pairs -- with NO branch
+      // inside: as run-time (uniform) conditions inside the loop they cut every pass into basic blocks of its own, and the
+      // exp -> rcp -> log chain of a pass's 4 elements ran exposed, ~250 cycles per element (config 5: 12.5 us of a 31 us tile;
+      // the forward-only evaluation's whole launch is this epilogue).  As one block the 64 chains of a thread interleave.
+      const float bc[4] = {bb[0] + addconst, bb[1] + addconst, bb[2] + addconst, bb[3] + addconst};
+      auto passes = [&](auto mode_c, auto cout_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        constexpr bool CO = decltype(cout_c)::value;
 #pragma unroll
-      for (int q = 0; q < PASSES; ++q) {
-        if (q == PASSES / 2) { GMVAE_GSTAMP(7); }
-        const int row = r0 + RPP * q;
-        float v[4] = {vv[q].x, vv[q].y, vv[q].z, vv[q].w};
-        float rsum = 0.f;
+        for (int q = 0; q < PASSES; ++q) {
+          if (q == PASSES / 2) { GMVAE_GSTAMP(7); }
+          const int row = r0 + RPP * q;
+          float v[4] = {vv[q].x, vv[q].y, vv[q].z, vv[q].w};
+          float rsum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float lam = v[j] + bb[j] + addconst;
-          const float xv = (float)((xw[q] >> (8 * j)) & 0xffu);
-          const float e = __expf(-fabsf(lam));
-          const float rcp = __builtin_amdgcn_rcpf(1.f + e);
-          const float sp = fmaxf(lam, 0.f) - __logf(rcp);
-          rsum += xv * lam - sp;
-          v[j] = (lam >= 0.f ? rcp : e * rcp) - xv;
+          for (int j = 0; j < 4; ++j) {
+            // (the bare hardware forms: v_exp_f32 of an argument <= 0 and v_log_f32 of a value in [0.5, 1] need none of the
+            //  denormal-range fix-ups __expf / __logf wrap around them -- 10 of 38 vector instructions per element; e flushes to
+            //  0 below 2^-126: sigmoid and softplus are exact to 1e-38 there)
+            const float lam = v[j] + bc[j];
+            const float xv = (float)((xw[q] >> (8 * j)) & 0xffu);
+            const float e = __builtin_amdgcn_exp2f(fabsf(lam) * -1.44269504088896341f);
+            const float rcp = __builtin_amdgcn_rcpf(1.f + e);
+            const float sp = fmaf(__builtin_amdgcn_logf(rcp), -0.693147180559945309f, fmaxf(lam, 0.f));
+            rsum += xv * lam - sp;
+            v[j] = (lam >= 0.f ? rcp : e * rcp) - xv;
+          }
+          if constexpr (CO) *reinterpret_cast<float4*>(Cout + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
+          if constexpr (MODE == 2) {                  // f16 pairs of (sigmoid - x) x c3_scale (|.| <= 1: a fixed scale), two planes
+            unsigned q1[2], q2[2];
+            split_f16pair(v[0] * c3sc, v[1] * c3sc, q1[0], q2[0]);
+            split_f16pair(v[2] * c3sc, v[3] * c3sc, q1[1], q2[1]);
+            unsigned short* const d3 = C3 + ((long long)(nb >> 4) * M + (m0 + row)) * 16 + (nb & 15);
+            *reinterpret_cast<uint2*>(d3) = make_uint2(q1[0], q1[1]);
+            *reinterpret_cast<uint2*>(d3 + c3s) = make_uint2(q2[0], q2[1]);
+          } else if constexpr (MODE == 1) {           // the three 16-bit pieces of (sigmoid - x), one plane each (plane_rounds3's operand)
+            unsigned hi[2], mi[2], lo[2];
+            split_pair(v[0], v[1], hi[0], mi[0], lo[0]);
+            split_pair(v[2], v[3], hi[1], mi[1], lo[1]);
+            unsigned short* const d3 = C3 + ((long long)(nb >> 4) * M + (m0 + row)) * 16 + (nb & 15);
+            *reinterpret_cast<uint2*>(d3) = make_uint2(hi[0], hi[1]);
+            *reinterpret_cast<uint2*>(d3 + c3s) = make_uint2(mi[0], mi[1]);
+            *reinterpret_cast<uint2*>(d3 + 2 * c3s) = make_uint2(lo[0], lo[1]);
+          }
+          lds[row * C::LDC + 4 * c4] = rsum;          // (this thread's own, already consumed, slot of the staged tile)
         }
-        if (Cout) *reinterpret_cast<float4*>(Cout + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
-        if (C3 && c3sc != 0.f) {                    // f16 pairs of (sigmoid - x) x c3_scale (|.| <= 1: a fixed scale), two planes
-          unsigned q1[2], q2[2];
-          split_f16pair(v[0] * c3sc, v[1] * c3sc, q1[0], q2[0]);
-          split_f16pair(v[2] * c3sc, v[3] * c3sc, q1[1], q2[1]);
-          unsigned short* const d3 = C3 + ((long long)(nb >> 4) * M + (m0 + row)) * 16 + (nb & 15);
-          *reinterpret_cast<uint2*>(d3) = make_uint2(q1[0], q1[1]);
-          *reinterpret_cast<uint2*>(d3 + c3s) = make_uint2(q2[0], q2[1]);
-        } else if (C3) {                            // the three 16-bit pieces of (sigmoid - x), one plane each (plane_rounds3's operand)
-          unsigned hi[2], mi[2], lo[2];
-          split_pair(v[0], v[1], hi[0], mi[0], lo[0]);
-          split_pair(v[2], v[3], hi[1], mi[1], lo[1]);
-          unsigned short* const d3 = C3 + ((long long)(nb >> 4) * M + (m0 + row)) * 16 + (nb & 15);
-          *reinterpret_cast<uint2*>(d3) = make_uint2(hi[0], hi[1]);
-          *reinterpret_cast<uint2*>(d3 + c3s) = make_uint2(mi[0], mi[1]);
-          *reinterpret_cast<uint2*>(d3 + 2 * c3s) = make_uint2(lo[0], lo[1]);
-        }
-        lds[row * C::LDC + 4 * c4] = rsum;          // (this thread's own, already consumed, slot of the staged tile)
+      };
+      {
+        typedef std::integral_constant<int, 0> M0; typedef std::integral_constant<int, 1> M1; typedef std::integral_constant<int, 2> M2;
+        const int mode = !C3 ? 0 : (c3sc != 0.f ? 2 : 1);
+        if (Cout) { if (mode == 2) passes(M2{}, std::true_type{}); else if (mode == 1) passes(M1{}, std::true_type{}); else passes(M0{}, std::true_type{}); }
+        else { if (mode == 2) passes(M2{}, std::false_type{}); else if (mode == 1) passes(M1{}, std::false_type{}); else passes(M0{}, std::false_type{}); }
       }
       __syncthreads();
       if (tid < C::BM) {
