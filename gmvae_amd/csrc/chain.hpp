@@ -39,9 +39,7 @@ constexpr int kLDA = 17;        // leading dimension of [k][row] activation imag
 #define GMVAE_P256(n) (((n) + 255) & ~255)
 
 // fast transcendental forms (v_exp_f32 / v_log_f32 based, ~1e-6 relative): the ELBO tolerance is 1e-4
-__device__ __forceinline__ float flog(float x) { return __logf(x); }
-__device__ __forceinline__ float fexp(float x) { return __expf(x); }
-__device__ __forceinline__ float fsoftplus(float v) { return fmaxf(v, 0.f) + __logf(1.f + __expf(-fabsf(v))); }
+// (flog / fexp / fsoftplus: gemm.hpp)
 
 // Diagnostic stamps (cdna_hip_programming.md section 7): values leave the kernel only through `dbg`.
 #define GMVAE_STAMP(idx)                                                                   \

@@ -160,6 +160,14 @@ typedef Cfg<256, 128, 32, 4, 2, 1> CfgX;    // f16-pair planes only (gemm_groupe
 // the staging phase of these launches scales with the bytes requested, not with the number of round trips.)
 
 __device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// (the bare hardware forms, v_log_f32 / v_exp_f32 and one multiply: __logf / __expf wrap them in denormal-range fix-ups --
+//  compare, select, ldexp: ~5 more dependent instructions per call -- that none of these kernels' arguments need: logs are taken
+//  of normal numbers (uniforms >= 2^-24, sigmas >= sigma_min, sums >= 1, reciprocals in [0.5, 1]) and an exp whose result would
+//  be denormal (probabilities below 1e-38) may flush to 0)
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float fsoftplus(float v) { return fmaxf(v, 0.f) + flog(1.f + fexp(-fabsf(v))); }
+// (the general schedule's row kernels keep the denormal-safe forms: a sigma below 1e-38 is still a number there)
 __device__ __forceinline__ float sigmoidf_(float v) {
   float e = __expf(-fabsf(v));
   float r = 1.0f / (1.0f + e);
@@ -1576,9 +1584,9 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_EU) void gemm_grouped(const La
           // this launch at the config-5 sizes)
           const float lam = v[j] + bias[n] + (bias2 ? bias2[n] : 0.f) + addconst;
           const float xv = (float)xr[n];
-          const float e = __expf(-fabsf(lam));
+          const float e = fexp(-fabsf(lam));
           const float rcp = __builtin_amdgcn_rcpf(1.f + e);
-          const float sp = fmaxf(lam, 0.f) - __logf(rcp);
+          const float sp = fmaxf(lam, 0.f) - flog(rcp);
           rsum += (nb + j < N) ? xv * lam - sp : 0.f;
           v[j] = (lam >= 0.f ? rcp : e * rcp) - xv;
         }

@@ -833,9 +833,9 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
         const int row = lk * 4 + r;
         const bool ok = cok && row < nrow;
         const float lam = acc[r] + bias;
-        const float e = __expf(-fabsf(lam));
+        const float e = fexp(-fabsf(lam));
         const float rcp = __builtin_amdgcn_rcpf(1.f + e);          // 1/(1+e): sigmoid(|lam|)
-        const float sp = fmaxf(lam, 0.f) - __logf(rcp);             // softplus = max(lam,0) + log(1+e)
+        const float sp = fmaxf(lam, 0.f) - flog(rcp);             // softplus = max(lam,0) + log(1+e)
         const float sg = lam >= 0.f ? rcp : e * rcp;
         const float x_ = ok ? xv[r] : 0.f;
         rs[r] += ok ? x_ * lam - sp : 0.f;

@@ -552,9 +552,9 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float lam = acc[r] + bv[r] + a.gen_bias;
-          const float e = __expf(-fabsf(lam));
+          const float e = fexp(-fabsf(lam));                 // (bare v_exp_f32 / v_log_f32: chain.hpp)
           const float rcp = __builtin_amdgcn_rcpf(1.f + e);
-          const float sp = fmaxf(lam, 0.f) - __logf(rcp);
+          const float sp = fmaxf(lam, 0.f) - flog(rcp);
           const float sgm = lam >= 0.f ? rcp : e * rcp;
           const float x_ = ok ? (float)((xb[it] >> (8 * r)) & 0xffu) : 0.f;
           rs += ok ? x_ * lam - sp : 0.f;

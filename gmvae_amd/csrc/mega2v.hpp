@@ -400,9 +400,9 @@ __device__ __forceinline__ int mega2v_body(const MegaArgs& a, float* const sm) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float lam = acc[r] + bv[r] + a.gen_bias;
-      const float e = __expf(-fabsf(lam));
+      const float e = fexp(-fabsf(lam));
       const float rcp = __builtin_amdgcn_rcpf(1.f + e);
-      const float sp = fmaxf(lam, 0.f) - __logf(rcp);
+      const float sp = fmaxf(lam, 0.f) - flog(rcp);
       const float sgm = lam >= 0.f ? rcp : e * rcp;
       const float x_ = ok ? (float)((xb >> (8 * r)) & 0xffu) : 0.f;
       rs += ok ? x_ * lam - sp : 0.f;

@@ -693,9 +693,9 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     // logits = MLP(z) + bias_init (scripts/base.py:135); Independent(Bernoulli).log_prob (gmvae.py:254) and its gradient
     const float lam = v[0] + pf[0] + a.gen_bias;
     const float xv = pf[1];
-    const float e = __expf(-fabsf(lam));
+    const float e = fexp(-fabsf(lam));
     const float rcp = __builtin_amdgcn_rcpf(1.f + e);
-    const float sp = fmaxf(lam, 0.f) - __logf(rcp);
+    const float sp = fmaxf(lam, 0.f) - flog(rcp);
     float rs = xv * lam - sp;
     if (rok) st1o(a.g + (long long)row * D + ct * 16 + ec, (lam >= 0.f ? rcp : e * rcp) - xv);
     rs = sk_row16_sum(rs);
@@ -710,9 +710,9 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     for (int t = 0; t < 4; ++t) {
       const float lam = v[t] + bq[t] + a.gen_bias;
       const float xv = (float)((xw >> (8 * t)) & 0xffu);
-      const float e = __expf(-fabsf(lam));
+      const float e = fexp(-fabsf(lam));
       const float rcp = __builtin_amdgcn_rcpf(1.f + e);
-      const float sp = fmaxf(lam, 0.f) - __logf(rcp);
+      const float sp = fmaxf(lam, 0.f) - flog(rcp);
       rs += xv * lam - sp;
       gq[t] = (lam >= 0.f ? rcp : e * rcp) - xv;
     }
