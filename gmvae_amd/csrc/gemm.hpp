@@ -1472,23 +1472,27 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_EU) void gemm_grouped(const La
     unsigned short* const C3 = L.p[pi].C3;         // (only set for launches whose tiles are all interior: planes_eligible)
     const long long c3s = L.p[pi].c3_stride;
     const float c3sc = L.p[pi].c3_scale;
-    if (m0 + C::BM <= M && n0 + C::BN <= N && (ldc & 3) == 0 && (!Cout || al16(Cout)) && al16(bias) && (!bias2 || al16(bias2)) && (ldx & 3) == 0 &&
-        (reinterpret_cast<uintptr_t>(xp) & 3) == 0) {
+    if (m0 + C::BM <= M && (n0 + C::BN <= N || ((N & 3) == 0 && !C3)) && (ldc & 3) == 0 && (!Cout || al16(Cout)) && al16(bias) && (!bias2 || al16(bias2)) &&
+        (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & 3) == 0) {
+      // (also the LAST column tile of an N that is no multiple of the tile -- 784 = 6 x 128 + 16: a seventh of the tiles of every
+      //  Bernoulli launch at the reference's D --: column quads beyond N are predicated off instead of sending the whole tile
+      //  down the element-by-element path below)
       // interior tile: the bias quad once, the 4 target bytes of a pass as one word; every pass's target word AND staged
       // accumulator quad are requested before the first is used (ONE memory and ONE LDS round trip per tile), and the row
       // sums meet through LDS at the end (a butterfly of 5 dependent cross-lane steps per pass was 80 LDS round trips per
       // tile, each several hundred cycles beside the co-resident workgroup's fragment reads: 22 us of a 77 us tile)
       constexpr int RPP = C::THREADS / GPR;
       const int c4 = tid % GPR, r0 = tid / GPR, nb = n0 + 4 * c4;
-      float4 b4 = *reinterpret_cast<const float4*>(bias + nb);
-      if (bias2) { const float4 c4v = *reinterpret_cast<const float4*>(bias2 + nb); b4.x += c4v.x; b4.y += c4v.y; b4.z += c4v.z; b4.w += c4v.w; }
+      const bool nv = nb < N;                      // (this thread's column quad exists)
+      float4 b4 = nv ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias2 && nv) { const float4 c4v = *reinterpret_cast<const float4*>(bias2 + nb); b4.x += c4v.x; b4.y += c4v.y; b4.z += c4v.z; b4.w += c4v.w; }
       const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
       unsigned xw[PASSES];
       f32x4 vv[PASSES];
 #pragma unroll
       for (int q = 0; q < PASSES; ++q) {
         const int m = m0 + r0 + RPP * q;
-        xw[q] = *reinterpret_cast<const unsigned*>(xp + (long long)(m / x_div) * ldx + nb);
+        xw[q] = nv ? *reinterpret_cast<const unsigned*>(xp + (long long)(m / x_div) * ldx + nb) : 0u;
       }
 #pragma unroll
       for (int q = 0; q < PASSES; ++q) {
@@ -1525,7 +1529,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_EU) void gemm_grouped(const La
             rsum += xv * lam - sp;
             v[j] = (lam >= 0.f ? rcp : e * rcp) - xv;
           }
-          if constexpr (CO) *reinterpret_cast<float4*>(Cout + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
+          if constexpr (CO) { if (nv) *reinterpret_cast<float4*>(Cout + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]); }
           if constexpr (MODE == 2) {                  // f16 pairs of (sigmoid - x) x c3_scale (|.| <= 1: a fixed scale), two planes
             unsigned q1[2], q2[2];
             split_f16pair(v[0] * c3sc, v[1] * c3sc, q1[0], q2[0]);
@@ -1542,7 +1546,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_EU) void gemm_grouped(const La
             *reinterpret_cast<uint2*>(d3 + c3s) = make_uint2(mi[0], mi[1]);
             *reinterpret_cast<uint2*>(d3 + 2 * c3s) = make_uint2(lo[0], lo[1]);
           }
-          lds[row * C::LDC + 4 * c4] = rsum;          // (this thread's own, already consumed, slot of the staged tile)
+          lds[row * C::LDC + 4 * c4] = nv ? rsum : 0.f;          // (this thread's own, already consumed, slot of the staged tile)
         }
       };
       {
