@@ -160,6 +160,8 @@ typedef Cfg<256, 128, 32, 4, 2, 1> CfgX;    // f16-pair planes only (gemm_groupe
 // the staging phase of these launches scales with the bytes requested, not with the number of round trips.)
 
 __device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// ReLU that keeps a NaN (fmaxf would turn a diverged activation into 0 and hide it from the non-finite-loss check)
+__device__ __forceinline__ float relu_nan(const float v) { return !(v <= 0.f) ? v : 0.f; }
 // (the bare hardware forms, v_log_f32 / v_exp_f32 and one multiply: __logf / __expf wrap them in denormal-range fix-ups --
 //  compare, select, ldexp: ~5 more dependent instructions per call -- that none of these kernels' arguments need: logs are taken
 //  of normal numbers (uniforms >= 2^-24, sigmas >= sigma_min, sums >= 1, reciprocals in [0.5, 1]) and an exp whose result would

@@ -1862,6 +1862,24 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       ra.p[0].addsrc = w.gx; ra.p[0].ld_add = G.dim[1]; ra.p[0].add_div = S;
       ra.p[1] = rows_prob(P + L.prior.w[0], P + L.prior.b[0], w.pp, 2 * Lz, false);
       launch_rows(ra, "fwd_y_layers");
+    } else if (K <= kSmallKMax && G.dim[1] % 4 == 0 && Lz % 2 == 0 && G.dim[1] + 2 * Lz <= kSmallKCols && (relu_act || G.nl == 1) &&
+               (long long)R * (G.dim[1] + 2 * Lz) < (1ll << 32)) {
+      // the reference's K = 10: a 10-deep contraction is no GEMM (kernels.hpp rows_small_k)
+      SmallKArgs sa;
+      memset(&sa, 0, sizeof(sa));
+      sa.A = w.y; sa.R = R; sa.K = K; sa.np = 2;
+      sa.p[0].W = P + G.w[0] + (uint64_t)D * G.dim[1]; sa.p[0].bias = P + G.b[0]; sa.p[0].out = (G.nl == 1) ? w.qp : w.hg[1];
+      sa.p[0].N = G.dim[1]; sa.p[0].relu = G.nl > 1; sa.p[0].addsrc = w.gx; sa.p[0].ld_add = G.dim[1]; sa.p[0].add_div = S;
+      sa.p[1].W = P + L.prior.w[0]; sa.p[1].bias = P + L.prior.b[0]; sa.p[1].out = w.pp; sa.p[1].N = 2 * Lz; sa.p[1].add_div = 1;
+      // (a grid whose thread count is a multiple of the row's quads: a thread keeps its column quad and its weights in registers)
+      const int qn = (G.dim[1] + 2 * Lz) / 4;
+      // (about one wave of resident workgroups: each stages the weights once)
+      int nblk = grid_for((long long)R * qn, 256 * 4, 4 * device_cus());
+      nblk = nblk >= qn ? nblk / qn * qn : qn;
+      if (K == 10) hipLaunchKernelGGL(rows_small_k<10>, dim3(nblk), dim3(256), 0, st, sa);
+      else hipLaunchKernelGGL(rows_small_k<0>, dim3(nblk), dim3(256), 0, st, sa);
+      cx.check();
+      cx.mark("fwd_y_layers", 2.0 * R * K * (G.dim[1] + 2 * Lz));
     } else {
       Group g;
       Problem p = p_nn(w.y, false, K, P + G.w[0] + (uint64_t)D * G.dim[1], G.dim[1], R, G.dim[1], K,

@@ -37,6 +37,114 @@ __global__ void binarize_rows(const unsigned char* __restrict__ pixels, const in
   binarize_quad((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, pixels, idx, row0, n_rows_src, B, D, seed, step, x, out_row0);
 }
 
+// ------------------------------------------------ row-panel layers with a TINY contraction (K <= 16)
+// out[r][n] = act(bias[n] + addsrc[r / add_div][n] + sum_k A[r][k] W[k][n]) for up to two weight matrices sharing A -- the y rows
+// of enc_gmm's first layer and the conditional prior's layer at the reference's K = 10 mixture components (gmvae.py:246-252):
+// 10 multiply-adds per output.  As a grouped GEMM (K padded to a 32-deep round, a tile's load -> LDS -> MFMA -> epilogue trip
+// for 0.1 GFLOP) the launch took 50 us at 51,200 rows; here a thread owns 4 columns of a row, the weights sit in LDS and the
+// launch moves its 39 MB of outputs.
+struct SmallKProb {
+  const float *W, *bias, *addsrc;   // [K][N]; [N] or null; [R / add_div][ld_add] or null
+  float* out;                       // [R][N]
+  int N, relu, ld_add, add_div;
+};
+struct SmallKArgs {
+  const float* A;                   // [R][K]
+  int R, K, np;
+  SmallKProb p[2];
+};
+constexpr int kSmallKMax = 16, kSmallKCols = 512;
+// KC = the contraction length as a compile-time constant (the reference's 10: operands and weights of a trip in registers, no
+// branch in the multiply-adds) or 0: any K <= kSmallKMax, weights read from LDS inside the loop.  (A first form with K a run-time
+// bound on 16-fold unrolled register arrays took 224 registers + scratch and ran 29 us for 39 MB of outputs.)
+template <int KC>
+__global__ __launch_bounds__(256) void rows_small_k(const SmallKArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ws[kSmallKMax * kSmallKCols];
+  const int K = KC ? KC : a.K, N0 = a.p[0].N, NT = N0 + (a.np > 1 ? a.p[1].N : 0), q = NT >> 2;
+  {
+    // (16-byte pieces, every thread's loads in flight together: element by element a block spent 7 us on dependent loads
+    //  before its first row)
+    constexpr int NJ = kSmallKMax * kSmallKCols / 4 / 256;
+    float4 st[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int i = min((int)threadIdx.x + 256 * j, K * q - 1);      // (clamped: the store below is predicated)
+      const int k = i / q, n = (i - k * q) * 4;
+      const float* const src = n < N0 ? a.p[0].W + (long long)k * N0 + n : a.p[1].W + (long long)k * a.p[1].N + (n - N0);
+      st[j] = *reinterpret_cast<const float4*>(src);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int i = (int)threadIdx.x + 256 * j;
+      if (i < K * q) *reinterpret_cast<float4*>(Ws + 4 * i) = st[j];
+    }
+  }
+  __syncthreads();
+  // (32-bit index arithmetic: R * q < 2^31 is checked by the host; a thread walks rows with its column quad FIXED -- the grid's
+  //  stride is a multiple of q: no division inside the loop -- and every per-problem field is selected once, by value: a
+  //  per-lane choice between the two argument records would be served from a scratch copy)
+  const int items = a.R * q, stride = (int)gridDim.x * 256;
+  const int it = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (it >= items) return;
+  int r = it / q;
+  const int n = (it - r * q) * 4, dr = stride / q;
+  const bool first = n < N0;
+  const int nn = first ? n : n - N0, N = first ? N0 : a.p[1].N;
+  const float* const bias = first ? a.p[0].bias : a.p[1].bias;
+  const float* const addsrc = first ? a.p[0].addsrc : a.p[1].addsrc;
+  float* const out = first ? a.p[0].out : a.p[1].out;
+  const int relu = first ? a.p[0].relu : a.p[1].relu, ld_add = first ? a.p[0].ld_add : a.p[1].ld_add;
+  const int add_div = first ? a.p[0].add_div : a.p[1].add_div;
+  const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* const wcol = Ws + n;
+  if constexpr (KC > 0) {
+    float4 w4[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) w4[k] = *reinterpret_cast<const float4*>(wcol + k * NT);
+    // four rows per trip: their 4 x K operand loads (and the addend's) are in flight together
+    for (; r < a.R; r += 4 * dr) {
+      float y[4][KC];
+      float4 s4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ru = min(r + u * dr, a.R - 1);
+        const float* const ar = a.A + (long long)ru * KC;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) y[u][k] = ar[k];
+        s4[u] = addsrc ? *reinterpret_cast<const float4*>(addsrc + (long long)(ru / add_div) * ld_add + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r + u * dr >= a.R) break;
+        float4 acc = make_float4(b4.x + s4[u].x, b4.y + s4[u].y, b4.z + s4[u].z, b4.w + s4[u].w);
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+          acc.x = fmaf(y[u][k], w4[k].x, acc.x); acc.y = fmaf(y[u][k], w4[k].y, acc.y);
+          acc.z = fmaf(y[u][k], w4[k].z, acc.z); acc.w = fmaf(y[u][k], w4[k].w, acc.w);
+        }
+        if (relu) { acc.x = relu_nan(acc.x); acc.y = relu_nan(acc.y); acc.z = relu_nan(acc.z); acc.w = relu_nan(acc.w); }
+        *reinterpret_cast<float4*>(out + (long long)(r + u * dr) * N + nn) = acc;
+      }
+    }
+  } else {
+    for (; r < a.R; r += dr) {
+      float4 acc = b4;
+      if (addsrc) {
+        const float4 s4 = *reinterpret_cast<const float4*>(addsrc + (long long)(r / add_div) * ld_add + nn);
+        acc.x += s4.x; acc.y += s4.y; acc.z += s4.z; acc.w += s4.w;
+      }
+      const float* const ar = a.A + (long long)r * K;
+      for (int k = 0; k < K; ++k) {
+        const float y = ar[k];
+        const float4 w4 = *reinterpret_cast<const float4*>(wcol + k * NT);
+        acc.x = fmaf(y, w4.x, acc.x); acc.y = fmaf(y, w4.y, acc.y); acc.z = fmaf(y, w4.z, acc.z); acc.w = fmaf(y, w4.w, acc.w);
+      }
+      if (relu) { acc.x = relu_nan(acc.x); acc.y = relu_nan(acc.y); acc.z = relu_nan(acc.z); acc.w = relu_nan(acc.w); }
+      *reinterpret_cast<float4*>(out + (long long)r * N + nn) = acc;
+    }
+  }
+}
+
 // ------------------------------------------------ q(y|x): Gumbel-softmax head
 // RelaxedOneHotCategorical.sample (scripts/base.py:206-209, gmvae.py:240):
 //   g = -log(-log u); y = softmax((logits + g)/T)

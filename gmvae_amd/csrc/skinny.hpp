@@ -475,7 +475,7 @@ __device__ __forceinline__ void sk_nt(const float* __restrict__ A, const long lo
 // at ten short launches per step is most of a step (measured: tools/micro/launch_floor.hip, profiles/round3_notes.md)
 // (st1o -- a 4-byte launch output, write-through -- lives in mega2.hpp)
 // ReLU that keeps a NaN (fmaxf(NaN, 0) is 0: a non-finite pre-activation would vanish from the loss the runner watches)
-__device__ __forceinline__ float relu_nan(const float v) { return !(v <= 0.f) ? v : 0.f; }
+// (relu_nan: gemm.hpp)
 
 __device__ __forceinline__ float sk_row16_sum(float v) {
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
