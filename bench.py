@@ -712,7 +712,13 @@ def main():
                                         else dom[2] / us * 1e-6 / roof["peak"])
             pl = [k for k in kern_us if k.startswith("void gmvae::gemm_grouped<gmvae::Cfg<128, 128, 32, 2, 2, 1, 2>, 0, %d>" % (2 if PLANES_EXACT else 3))
                   or k.startswith("void gmvae::gemm_grouped<gmvae::Cfg<128, 128, 32, 2, 2, 1, 2>, %d>" % (2 if PLANES_EXACT else 3))]
-            if not hit and pl and schedule.endswith("+planes") and dom[0] in ("fwd_dec_bernoulli", "bwd_dec_top"):
+            px = [k for k in kern_us if k.startswith("void gmvae::gemm_grouped<gmvae::Cfg<256, 128, 32, 4, 2, 1, 2>, 3>")]
+            if not hit and px and not PLANES_EXACT and schedule.endswith("+planes") and dom[0] == "bwd_dec_top":
+                # f16 pairs: the backward launch (weight + data gradient) runs the 256 x 128 instance, a kernel of its own
+                roof["rocprof_usec_per_launch"] = kern_us[px[0]]
+                roof["rocprof_kernels"] = px
+                roof["frac_rocprof"] = dom[2] / kern_us[px[0]] * 1e-6 / roof["peak"]
+            elif not hit and pl and schedule.endswith("+planes") and dom[0] in ("fwd_dec_bernoulli", "bwd_dec_top"):
                 # the plane instance runs exactly two launches per step (logits + Bernoulli; weight and data gradient): the
                 # committed average is over both, so the fraction is priced on both launches' FLOPs together
                 both = [l for l in levels if l[0] in ("fwd_dec_bernoulli", "bwd_dec_top")]
