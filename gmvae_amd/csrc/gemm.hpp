@@ -80,6 +80,7 @@ struct Problem {
   float uns_c;             // pairs: constant part of the un-scaling (fixed-scale operands: (sigmoid - x) x 2^15)
   float uns_cb;            // pairs: b's share of uns_c (the bias gradient's column sums are sums of b's pieces)
   float c3_scale;          // != 0: C3 receives f16 pairs of (value x c3_scale) in two planes instead of bf16 triples in three
+  int n_padded;            // pairs: b's planes are zero-padded to a multiple of 128 columns (N itself need not be one)
   unsigned short* C3;      // EPI_BERNOULLI: (sigmoid - x) written as planes [3][M][ldc] of 16-bit pieces (beside or instead of C);
                            // EPI_STORE with per-element options (bias / ReLU ...): the stored values also as planes (beside C)
   long long c3_stride;
@@ -1653,18 +1654,22 @@ __global__ __launch_bounds__(256) void split_planes_b16(const float* __restrict_
 // weights are <= 1).
 __global__ __launch_bounds__(256) void split_pairs_b16(const float* __restrict__ src, const float* __restrict__ rowscale,
                                                         const int ld, const int rows, unsigned short* __restrict__ dst,
-                                                        const long long pstride, const unsigned* __restrict__ amax_bits) {
+                                                        const long long pstride, const unsigned* __restrict__ amax_bits,
+                                                        const int ldp) {
+  // (ldp >= ld: the planes hold ldp columns, the ones from ld on zero -- a GEMM whose N is no multiple of its tile reads whole
+  //  tiles of the weight's planes; ld % 8 == 0)
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const float s = pair_scale(*amax_bits);
-  const int npair = (ld + 31) >> 5, ngrp = rows >> 4, lane = threadIdx.x & 63;
+  const int npair = (ldp + 31) >> 5, ngrp = rows >> 4, lane = threadIdx.x & 63;
   const long long waves = (long long)ngrp * npair;
   for (long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < waves; wv += (long long)gridDim.x * 4) {
     const long long cp = wv / ngrp, rg = wv - cp * ngrp;
     const long long r = rg * 16 + (lane >> 2);
     const int c = (int)cp * 32 + 8 * (lane & 3);
-    if (c >= ld) continue;
-    const float* const sp = src + r * ld + c;
-    const float sc = (rowscale ? rowscale[r] : 1.f) * s;
+    if (c >= ldp) continue;
+    const bool in = c < ld;
+    const float* const sp = src + r * ld + (in ? c : 0);
+    const float sc = in ? (rowscale ? rowscale[r] : 1.f) * s : 0.f;
     const f32x4 q0 = *reinterpret_cast<const f32x4*>(sp), q1 = *reinterpret_cast<const f32x4*>(sp + 4);
     const float v[8] = {q0.x * sc, q0.y * sc, q0.z * sc, q0.w * sc, q1.x * sc, q1.y * sc, q1.z * sc, q1.w * sc};
     unsigned p1[4], p2[4];

@@ -161,6 +161,8 @@ struct WS {
   float *img_m, *dimg;          // mega kernel: small-weight image (odd leading dimensions) + decoder chunk images
   float *img2f, *img2b, *dimg2; // mega2 kernel: forward / backward operand images, decoder operand images
   float* pscale;
+  float* pscale_f;                 // forward-only pairs (fwd_pairs_ok): the same words for hd2f / w2f
+  unsigned short *hd2f, *w2f;      // ... the top decoder layer's input [R x Ht] and weight [Ht x pad128(D)] as f16 pairs
   unsigned short *hd3, *g3, *w3;   // general schedule, large top decoder layer: planes of 16-bit pieces (gemm.hpp plane_rounds) of its
                                    // input activation [3][R][H], of (sigmoid - x) [3][R][D] and of its weight [3][H][D]
   int32_t* cl_pred;
@@ -406,7 +408,34 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
       w.pscale = take(16 + kAmaxBlocks + ((R + 15) / 16) * ((Ht + 63) / 64));
     }
   }
+  {
+    // forward-only evaluation at thousands of rows (fwd_pairs_ok): the logits GEMM on f16 pairs whatever D (the weight's planes
+    // are zero-padded to whole 128-column tiles) and from a 32-wide hidden layer up
+    const uint64_t Ht = L.dec.dim[L.dec.nl - 1], Dp = (D + 127) / 128 * 128;
+    if (L.dec.nl >= 2 && R % 128 == 0 && Ht % 32 == 0 && D % 8 == 0 && R * Dp < (1ull << 32)) {
+      w.hd2f = reinterpret_cast<unsigned short*>(take(R * Ht));
+      w.w2f = reinterpret_cast<unsigned short*>(take(Ht * Dp));
+      w.pscale_f = take(16 + kAmaxBlocks + ((R + 15) / 16) * ((Ht + 63) / 64));
+    }
+  }
   w.bytes = off;
+}
+
+// forward-only steps (evaluation: S importance samples per row) whose logits GEMM is worth running on f16 pairs: the plane path
+// proper (planes_ok) needs D % 128 == 0 and a wide hidden layer because its BACKWARD GEMMs read (sigmoid - x) planes; forward
+// only, the one GEMM takes any D % 8 == 0 (weight planes zero-padded to the tile) and any hidden width % 32.  (eval_iwae:
+// 51200 x 784 x 64 -- as fp32 MFMA the launch is half matrix time, half Bernoulli epilogue.)
+static bool fwd_pairs_ok(const GmvaeDims& d, const Layout& L) {
+  const char* e = getenv("GMVAE_NO_PLANES");
+  if (e && atoi(e)) return false;
+  const char* x = getenv("GMVAE_PLANES_EXACT");
+  if (x && atoi(x)) return false;
+  if (d.hidden_act != GMVAE_ACT_RELU || L.dec.nl < 2) return false;
+  const long long R = (long long)d.B * d.S;
+  const int Ht = L.dec.dim[L.dec.nl - 1];
+  long long minr = 8192;
+  if (const char* m = getenv("GMVAE_PLANES_MINROWS")) minr = atoll(m);
+  return R >= minr && R % 128 == 0 && Ht % 32 == 0 && d.D % 8 == 0 && R * ((d.D + 127) / 128 * 128) < (1ll << 32);
 }
 
 // ----------------------------------------------------------- GEMM building
@@ -565,9 +594,11 @@ static void launch_amax_final(hipStream_t st, const unsigned* pa, int na, const 
   hipLaunchKernelGGL(amax_final, dim3(2), dim3(256), 0, st, f);
 }
 static void launch_split_pairs(hipStream_t st, const float* src, const float* rowscale, int ld, long long n, unsigned short* dst,
-                               const unsigned* amax) {
-  hipLaunchKernelGGL(split_pairs_b16, dim3(grid_for(n / ld / 16 * ((ld + 31) / 32), 4, 16384)), dim3(256), 0, st, src, rowscale, ld,
-                     (int)(n / ld), dst, n, amax);
+                               const unsigned* amax, int ldp = 0) {
+  if (ldp < ld) ldp = ld;                         // (ldp > ld: zero columns up to ldp; the plane stride follows)
+  const long long rows = n / ld;
+  hipLaunchKernelGGL(split_pairs_b16, dim3(grid_for(rows / 16 * ((ldp + 31) / 32), 4, 16384)), dim3(256), 0, st, src, rowscale, ld,
+                     (int)rows, dst, rows * ldp, amax, ldp);
 }
 
 // every problem of the launch reads pre-split operands (gemm.hpp plane_rounds): interior 128 x 128 tiles, whole 32-deep
@@ -575,7 +606,7 @@ static void launch_split_pairs(hipStream_t st, const float* src, const float* ro
 static bool planes_eligible(const Launch& L) {
   for (int i = 0; i < L.nprob; ++i) {
     const Problem& p = L.p[i];
-    if (!p.planes || p.xbf16 || p.nseg != 1 || p.M % 128 || p.N % 128) return false;
+    if (!p.planes || p.xbf16 || p.nseg != 1 || p.M % 128 || (p.N % 128 && !(p.planes == 2 && p.n_padded && p.N % 4 == 0))) return false;
     const Segment& sg = p.seg[0];
     if (sg.a.row_div != 1 || sg.b.row_div != 1 || sg.a.n_mn < p.M || sg.b.n_mn < p.N || sg.K % 32) return false;
     if (sg.a.ld % 16 || sg.b.ld % 16) return false;
@@ -1749,6 +1780,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   // the bf16 triples (6 piece products, every product exact)
   const char* const exact_env = getenv("GMVAE_PLANES_EXACT");
   const bool pairs = planes && !(exact_env && atoi(exact_env));
+  const bool fwdp = !planes && !a.backward && w.hd2f != nullptr && fwd_pairs_ok(d, L);      // forward only: the logits GEMM on pairs
   constexpr float kGScale = 32768.f;            // (sigmoid - x) in [-1, 1]: a fixed scale for its pairs
 
   // ---- noise (fast mode): Philox for eps and u -- its own launch in the general schedule, auxiliary
@@ -1927,8 +1959,8 @@ static int run_step(Ctx& cx, const StepArgs& a) {
         ra.p[0].C3 = w.hd3; ra.p[0].c3_stride = (long long)R * Dn.dim[i + 1];
         hd3_fused = true;
       }
-      if (pairs && i == Dn.nl - 2) {               // f16 pairs: the activation's largest magnitude rides on this launch (a word per wave)
-        ra.p[0].amax = reinterpret_cast<unsigned*>(w.pscale) + 16 + kAmaxBlocks;
+      if ((pairs || fwdp) && i == Dn.nl - 2) {     // f16 pairs: the activation's largest magnitude rides on this launch (a word per wave)
+        ra.p[0].amax = reinterpret_cast<unsigned*>(pairs ? w.pscale : w.pscale_f) + 16 + kAmaxBlocks;
       }
       launch_rows(ra, "fwd_dec");
       if (ra.p[0].amax) hmax_n = rows_units;
@@ -1949,7 +1981,25 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       p.addconst = d.gen_bias_init;
       p.bias2 = d.gen_bias_vec;
       p.x = a.x; p.ldx = D; p.x_div = S; p.part = w.part;
-      if (planes) {
+      if (fwdp) {
+        // forward only: both operands as f16 pairs, the weight's planes zero-padded to whole 128-column tiles
+        const int Dp = (D + 127) / 128 * 128;
+        const long long nh = (long long)R * Dn.dim[i], nw = (long long)Dn.dim[i] * D;
+        unsigned* const am = reinterpret_cast<unsigned*>(w.pscale_f);
+        unsigned* const hp = am + 16 + kAmaxBlocks;
+        if (!hmax_n) { launch_amax(st, in, nh, hp); hmax_n = kAmaxBlocks; }
+        launch_amax(st, P + Dn.w[i], nw, am + 16);
+        launch_amax_final(st, hp, hmax_n, am + 16, kAmaxBlocks, am, w.pscale_f + 2);
+        launch_split_pairs(st, in, nullptr, Dn.dim[i], nh, w.hd2f, am);
+        launch_split_pairs(st, P + Dn.w[i], nullptr, D, nw, w.w2f, am + 1, Dp);
+        rowk(cx, "split_planes");
+        p.planes = 2; p.n_padded = 1;
+        p.a_uns = w.pscale_f + 2; p.b_uns = w.pscale_f + 3; p.uns_c = 1.f; p.uns_cb = 1.f;
+        p.seg[0].a.ptr = w.hd2f; p.seg[0].b.ptr = w.w2f;
+        p.seg[0].b.ld = Dp; p.seg[0].b.n_mn = Dp;      // (the planes' own extents: padded)
+        p.a_pstride = nh; p.b_pstride = (long long)Dn.dim[i] * Dp;
+        p.C = nullptr;
+      } else if (planes) {
         // both operands as planes of 16-bit pieces (the weight's are shared with the data gradient below), (sigmoid - x)
         // leaves as planes only: its two consumers are plane GEMMs
         const long long nh = (long long)R * Dn.dim[i], nw = (long long)Dn.dim[i] * D;

@@ -533,6 +533,33 @@ def test_forward_outputs(H):
     assert tail[0] / 40 == pytest.approx(Cc["loss"], rel=1e-5)
 
 
+@pytest.mark.parametrize("name,D,hidden,S,B", [("gmvae", 784, (64,), 4, 64), ("gmvae", 200, (32, 96), 2, 128), ("vae_gmp", 784, (64,), 8, 32),
+                                               ("vae", 1000, (160,), 1, 256)])
+def test_forward_only_logits_gemm_on_pairs(H, monkeypatch, name, D, hidden, S, B):
+    """Forward-only evaluation (gmvae_forward, S importance samples per row) at thousands of rows runs its logits GEMM on f16
+    pairs whatever D (gmvae_hip.hip fwd_pairs_ok: the weight's planes are zero-padded to whole 128-column tiles, the last
+    column tile's missing quads are predicated off in the Bernoulli epilogue) -- forced here at R = B*S = 256 rows with
+    GMVAE_PLANES_MINROWS: D = 784 = 6 x 128 + 16, 200 and 1000 (no multiples of the tile), hidden widths of 64 / 96 / 160; every row's
+    log p(x|z), log w, z and the bound against the fp64 oracle, and NOT bit-identical to the fp32 MFMA path (evidence that the
+    pairs ran) while equal to it within fp32 rounding."""
+    model = O.MODEL_NAMES[name]
+    d = O.Dims(D=D, L=16, K=10 if name != "vae" else 1, hidden=hidden, S=S)
+    p = O.init_params(model, d, np.random.default_rng(D + S))
+    x, eps, u = O.make_inputs(d, B, model)
+    flat = O.pack(model, d, p, np.float32)
+    Cc = O.forward(model, d, O.unpack(model, d, flat.astype(np.float64)), x, eps, u)
+    monkeypatch.setenv("GMVAE_PLANES_MINROWS", "256")
+    tail, rows, z = H.hip_forward(model, d, flat, x, eps, u)[:3]
+    np.testing.assert_allclose(z, Cc["z"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rows[:, 0], Cc["logpx"], rtol=1e-5)
+    np.testing.assert_allclose(rows[:, 3], Cc["logw"], rtol=1e-5)
+    assert tail[0] / B == pytest.approx(Cc["loss"], rel=1e-5)
+    monkeypatch.setenv("GMVAE_NO_PLANES", "1")
+    rows_f32 = H.hip_forward(model, d, flat, x, eps, u)[1]
+    assert not np.array_equal(rows[:, 0], rows_f32[:, 0])
+    np.testing.assert_allclose(rows[:, 0], rows_f32[:, 0], rtol=2e-6)
+
+
 # ----------------------------------------------------------------- Adam
 def test_adam_tf_three_steps(H):
     """Against the oracle run in fp32 (TF's own arithmetic type) tightly, and in fp64 loosely."""
