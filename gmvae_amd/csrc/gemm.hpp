@@ -170,7 +170,26 @@ __device__ __forceinline__ float relu_nan(const float v) { return !(v <= 0.f) ? 
 __device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ __forceinline__ float fsoftplus(float v) { return fmaxf(v, 0.f) + flog(1.f + fexp(-fabsf(v))); }
-// (the general schedule's row kernels keep the denormal-safe forms: a sigma below 1e-38 is still a number there)
+// The general schedule's z heads (51,200 x 64 elements per evaluation pass: z_head_fwd was 33 us of libm softplus / log /
+// IEEE division, 17.5 us with these): the hardware forms where they are exact enough and the denormal-safe ones where they are
+// not, chosen per element -- softplus through the compensated log1p, log(1 + e) e / ((1 + e) - 1) (a few ulp for every e in
+// [0, 1]; the plain log(1 + e) of the fast paths is 2e-4 off at sigma = 2e-4), __expf instead of the bare exp where the bare
+// one would flush (|v| > 80), logf instead of the bare log below the normal range.
+__device__ __forceinline__ float softplus_r(const float v) {
+  const float av = fabsf(v);
+  const float e = av > 80.f ? __expf(-av) : fexp(-av);
+  const float u = 1.f + e, d = u - 1.f;
+  const float l1p = d == 0.f ? e : flog(u) * (e * __builtin_amdgcn_rcpf(d));
+  return fmaxf(v, 0.f) + l1p;
+}
+__device__ __forceinline__ float log_r(const float x) { return x < 1.1754944e-38f ? logf(x) : flog(x); }
+__device__ __forceinline__ float sigmoid_r(const float v) {
+  const float av = fabsf(v);
+  const float e = av > 80.f ? __expf(-av) : fexp(-av);
+  const float r = __builtin_amdgcn_rcpf(1.f + e);
+  return v >= 0.f ? r : e * r;
+}
+// (the other row kernels keep the denormal-safe libm forms: a sigma below 1e-38 is still a number there)
 __device__ __forceinline__ float sigmoidf_(float v) {
   float e = __expf(-fabsf(v));
   float r = 1.0f / (1.0f + e);

@@ -301,16 +301,16 @@ __global__ void z_head_fwd(const float* __restrict__ qp, int qp_div, const float
     float aq = 0.f, ap = 0.f;
     for (int l = lane; l < L; l += 64) {
       const float mu = q[l];
-      const float sg = fmaxf(softplusf_(q[L + l] + c), smin);
+      const float sg = fmaxf(softplus_r(q[L + l] + c), smin);
       const float zz = mu + sg * eps[(long long)r * L + l];
       z[(long long)r * L + l] = zz;
-      const float e = (zz - mu) / sg;                       // from z, not eps (A7)
-      aq += -0.5f * e * e - 0.5f * kLog2Pi - logf(sg);
+      const float e = (zz - mu) * __builtin_amdgcn_rcpf(sg);        // from z, not eps (A7)
+      aq += -0.5f * e * e - 0.5f * kLog2Pi - log_r(sg);
       if (prior == PRIOR_COND) {
         const float* p = pp + (long long)r * 2 * L;
-        const float sp = fmaxf(softplusf_(p[L + l] + c), smin);
-        const float t = (zz - p[l]) / sp;
-        ap += -0.5f * t * t - 0.5f * kLog2Pi - logf(sp);
+        const float sp = fmaxf(softplus_r(p[L + l] + c), smin);
+        const float t = (zz - p[l]) * __builtin_amdgcn_rcpf(sp);
+        ap += -0.5f * t * t - 0.5f * kLog2Pi - log_r(sp);
       } else if (prior == PRIOR_STD) {
         ap += -0.5f * zz * zz - 0.5f * kLog2Pi;
       }
@@ -504,19 +504,19 @@ __global__ void z_head_bwd(const float* __restrict__ dz, const float* __restrict
     const float* q = qp + (long long)(r / qp_div) * 2 * L;
     for (int l = lane; l < L; l += 64) {
       const float rawq = q[L + l] + c;
-      const float spq = softplusf_(rawq);
+      const float spq = softplus_r(rawq);
       const float sg = fmaxf(spq, smin);
       const float zz = z[(long long)r * L + l];
       float pterm;
       if (prior == PRIOR_COND) {
         const float* p = pp + (long long)r * 2 * L;
         const float rawp = p[L + l] + c;
-        const float spp = softplusf_(rawp);
-        const float sp = fmaxf(spp, smin);
-        const float t = (zz - p[l]) / sp;
-        pterm = t / sp;
+        const float spp = softplus_r(rawp);
+        const float sp = fmaxf(spp, smin), isp = __builtin_amdgcn_rcpf(sp);
+        const float t = (zz - p[l]) * isp;
+        pterm = t * isp;
         dpp[(long long)r * 2 * L + l] = -w * pterm;
-        dpp[(long long)r * 2 * L + L + l] = (spp > smin) ? w * (1.f - t * t) / sp * sigmoidf_(rawp) : 0.f;
+        dpp[(long long)r * 2 * L + L + l] = (spp > smin) ? w * (1.f - t * t) * isp * sigmoid_r(rawp) : 0.f;
       } else if (prior == PRIOR_STD) {
         pterm = zz;
       } else {
@@ -527,9 +527,9 @@ __global__ void z_head_bwd(const float* __restrict__ dz, const float* __restrict
         }
       }
       const float dmu = dz[(long long)r * L + l] + w * pterm;
-      const float dsg = dmu * eps[(long long)r * L + l] - w / sg;
+      const float dsg = dmu * eps[(long long)r * L + l] - w * __builtin_amdgcn_rcpf(sg);
       dqp[(long long)r * 2 * L + l] = dmu;
-      dqp[(long long)r * 2 * L + L + l] = (spq > smin) ? dsg * sigmoidf_(rawq) : 0.f;
+      dqp[(long long)r * 2 * L + L + l] = (spq > smin) ? dsg * sigmoid_r(rawq) : 0.f;
     }
   }
 }
