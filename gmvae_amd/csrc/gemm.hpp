@@ -169,6 +169,10 @@ __device__ __forceinline__ float relu_nan(const float v) { return !(v <= 0.f) ? 
 //  be denormal (probabilities below 1e-38) may flush to 0)
 __device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+// (softplus in the one-launch / skinny / chain paths is max(v, 0) - log(rcp(1 + e)): it rounds 1 + e first, so sigma carries a
+//  relative error of 6e-8 / sigma -- 6e-6 at sigma = 0.01, and nothing is left of a sigma below 6e-8.  The compensated form
+//  (softplus_r below: log(1 + e) e / ((1 + e) - 1), 2.4e-7 everywhere) was measured there and dropped: two more dependent
+//  quarter-rate instructions per latent on the per-row chain, configs[2] 31.17 -> 31.40 us.  The general schedule's z heads use it.)
 __device__ __forceinline__ float fsoftplus(float v) { return fmaxf(v, 0.f) + flog(1.f + fexp(-fabsf(v))); }
 // The general schedule's z heads (51,200 x 64 elements per evaluation pass: z_head_fwd was 33 us of libm softplus / log /
 // IEEE division, 17.5 us with these): the hardware forms where they are exact enough and the denormal-safe ones where they are
