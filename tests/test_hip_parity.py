@@ -560,6 +560,48 @@ def test_forward_only_logits_gemm_on_pairs(H, monkeypatch, name, D, hidden, S, B
     np.testing.assert_allclose(rows[:, 0], rows_f32[:, 0], rtol=2e-6)
 
 
+def _random_forward_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        model = ["gmvae", "vae", "vae_gmp"][i % 3]
+        S = int(rng.choice([1, 2, 4, 8]))
+        R = int(rng.choice([128, 256, 384]))
+        hidden = tuple([int(rng.choice([24, 64]))] * int(rng.integers(0, 2)) + [int(rng.choice([32, 64, 96, 160]))])
+        d = O.Dims(D=int(rng.choice([8, 104, 200, 784, 904])), L=int(rng.choice([2, 8, 20, 64])),
+                   K=1 if model == "vae" else int(rng.choice([1, 3, 10, 16, 17])), hidden=hidden, S=S)
+        out.append((model, d, R // S))
+    return out
+
+
+RANDOM_FORWARD_CASES = _random_forward_cases(12, 20261007)
+
+
+@pytest.mark.parametrize("name,d,B", RANDOM_FORWARD_CASES,
+                         ids=[f"{n}-D{d.D}-L{d.L}-K{d.K}-H{'x'.join(map(str, d.hidden))}-S{d.S}-B{B}" for n, d, B in RANDOM_FORWARD_CASES])
+def test_forward_only_on_random_shapes(H, monkeypatch, name, d, B):
+    """Forward-only passes on random shapes with the forward pairs forced from 128 rows: D below, at and beyond one 128-column
+    tile and no multiple of it, hidden widths of 32 - 160, mixture sizes on both sides of rows_small_k's K <= 16 (and of
+    y_head_fwd's four-rows-per-wave form), IWAE samples -- every row's log p(x|z), log w and z against the fp64 oracle."""
+    monkeypatch.setenv("GMVAE_PLANES_MINROWS", "128")
+    model = O.MODEL_NAMES[name]
+    rng = np.random.default_rng(B + d.D + d.K)
+    p = O.init_params(model, d, rng)
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    x, eps, u = O.make_inputs(d, B, model)
+    flat = O.pack(model, d, p, np.float32)
+    Cc = O.forward(model, d, O.unpack(model, d, flat.astype(np.float64)), x, eps, u)
+    tail, rows, z, y, lg = H.hip_forward(model, d, flat, x, eps, u)
+    np.testing.assert_allclose(z, Cc["z"], rtol=1e-4, atol=1e-5)
+    if model == O.MODEL_GMVAE:
+        np.testing.assert_allclose(y, Cc["y"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(rows[:, 0], Cc["logpx"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(rows[:, 3], Cc["logw"], rtol=1e-5, atol=1e-4)
+    assert tail[0] / B == pytest.approx(Cc["loss"], rel=1e-5)
+
+
 # ----------------------------------------------------------------- Adam
 def test_adam_tf_three_steps(H):
     """Against the oracle run in fp32 (TF's own arithmetic type) tightly, and in fp64 loosely."""
