@@ -1550,8 +1550,9 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_EU) void gemm_grouped(const La
             const float lam = v[j] + bc[j];
             const float xv = (float)((xw[q] >> (8 * j)) & 0xffu);
             const float e = __builtin_amdgcn_exp2f(fabsf(lam) * -1.44269504088896341f);
-            const float rcp = __builtin_amdgcn_rcpf(1.f + e);
-            const float sp = fmaf(__builtin_amdgcn_logf(rcp), -0.693147180559945309f, fmaxf(lam, 0.f));
+            const float ope = 1.f + e;
+            const float rcp = __builtin_amdgcn_rcpf(ope);       // (only the sigmoid needs it: a forward-only pass drops it)
+            const float sp = fmaf(__builtin_amdgcn_logf(ope), 0.693147180559945309f, fmaxf(lam, 0.f));
             rsum += xv * lam - sp;
             v[j] = (lam >= 0.f ? rcp : e * rcp) - xv;
           }
