@@ -405,7 +405,10 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
       w.w3 = reinterpret_cast<unsigned short*>(take((3 * Ht * D + 1) / 2));
       // f16 pairs: [0], [1] bits of max |h|, max |W| of the step; [2], [3] 1 / scale of either; [16..] partial maxima: kAmaxBlocks
       // words for W, then one per wave of the launch that produces h (rows_nn_bf6: a wave per 16 rows x 64 columns at least)
-      w.pscale = take(16 + kAmaxBlocks + ((R + 15) / 16) * ((Ht + 63) / 64));
+      {
+        const uint64_t units = ((R + 15) / 16) * ((Ht + 63) / 64);      // (or kAmaxBlocks partials when amax_abs reduces h)
+        w.pscale = take(16 + kAmaxBlocks + (units > (uint64_t)kAmaxBlocks ? units : (uint64_t)kAmaxBlocks));
+      }
     }
   }
   {
@@ -415,7 +418,8 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     if (L.dec.nl >= 2 && R % 128 == 0 && Ht % 32 == 0 && D % 8 == 0 && R * Dp < (1ull << 32)) {
       w.hd2f = reinterpret_cast<unsigned short*>(take(R * Ht));
       w.w2f = reinterpret_cast<unsigned short*>(take(Ht * Dp));
-      w.pscale_f = take(16 + kAmaxBlocks + ((R + 15) / 16) * ((Ht + 63) / 64));
+      const uint64_t units = ((R + 15) / 16) * ((Ht + 63) / 64);        // (or kAmaxBlocks partials when amax_abs reduces h)
+      w.pscale_f = take(16 + kAmaxBlocks + (units > (uint64_t)kAmaxBlocks ? units : (uint64_t)kAmaxBlocks));
     }
   }
   w.bytes = off;
