@@ -2035,12 +2035,18 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       nparts = (D + bn - 1) / bn;
     }
   }
-  hipLaunchKernelGGL(row_terms, dim3(grid_for(R, 256, 1 << 22)), dim3(256), 0, st, w.part, nparts, w.logq, w.logp,
-                     gm ? w.nent : (const float*)nullptr, S, w.logpx, w.logw, a.row_terms, R, S > 1 ? w.lw64 : (double*)nullptr);
-  rowk(cx, "row_terms");
   float* tail = a.backward ? a.grads + L.P_pad : a.tail;
   const float* rwS = (S > 1 && a.backward) ? w.rw : nullptr;
-  if (S > 1) {
+  if (S > 1 && S <= 64) {       // the row terms and the IWAE groups in one launch (a wave per batch row)
+    hipLaunchKernelGGL(iwae_rows_terms, dim3((B + 3) / 4), dim3(256), 0, st, w.part, nparts, w.logq, w.logp,
+                       gm ? w.nent : (const float*)nullptr, w.logpx, w.logw, a.row_terms, a.backward ? w.rw : (float*)nullptr, w.pb, B, S);
+    rowk(cx, "iwae_rows_terms");
+  } else {
+    hipLaunchKernelGGL(row_terms, dim3(grid_for(R, 256, 1 << 22)), dim3(256), 0, st, w.part, nparts, w.logq, w.logp,
+                       gm ? w.nent : (const float*)nullptr, S, w.logpx, w.logw, a.row_terms, R, S > 1 ? w.lw64 : (double*)nullptr);
+    rowk(cx, "row_terms");
+  }
+  if (S > 64) {
     hipLaunchKernelGGL(iwae_rows, dim3((B + 3) / 4), dim3(256), 0, st, w.lw64, w.logpx, w.logq, w.logp,
                        a.backward ? w.rw : (float*)nullptr, w.pb, B, S);
     rowk(cx, "iwae_rows");

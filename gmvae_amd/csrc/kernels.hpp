@@ -663,6 +663,52 @@ __global__ __launch_bounds__(256) void iwae_rows(const double* __restrict__ logw
   if (lane == 0) { pb[4 * b] = (float)(mx + (double)lrel - (double)logf((float)S)); pb[4 * b + 1] = nl; pb[4 * b + 2] = kl; pb[4 * b + 3] = 0.f; }
 }
 
+// row_terms + iwae_rows in one launch for S <= 64 (a wave per batch row, lane s owns sample row b S + s: its Bernoulli partials,
+// log w in fp64 kept in a register instead of a round trip through memory) -- the same operations in the same order as the two
+// kernels above, so the same bits; one launch less in every IWAE step and evaluation pass.
+__global__ __launch_bounds__(256) void iwae_rows_terms(const float* __restrict__ part, int nparts, const float* __restrict__ logq,
+                                                       const float* __restrict__ logp, const float* __restrict__ nent,
+                                                       float* __restrict__ logpx, float* __restrict__ logw, float* __restrict__ terms4,
+                                                       float* __restrict__ rw, float* __restrict__ pb, int B, int S) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const long long r = (long long)b * S + lane;
+  const bool sv = lane < S;
+  double lw64 = -INFINITY;
+  float a = 0.f, lq = 0.f, lp = 0.f;
+  if (sv) {
+    double a64 = 0.0;
+    for (int i = 0; i < nparts; ++i) a64 += (double)part[r * nparts + i];
+    a = (float)a64;
+    lq = logq[r]; lp = logp[r];
+    const float ne = nent ? nent[b] : 0.f;
+    lw64 = a64 + (double)lp - (double)lq - (double)ne;
+    const float lw = (float)lw64;
+    logpx[r] = a;
+    logw[r] = lw;
+    if (terms4) {
+      terms4[4 * r + 0] = a;
+      terms4[4 * r + 1] = lq;
+      terms4[4 * r + 2] = lp;
+      terms4[4 * r + 3] = lw;
+    }
+  }
+  double mx = lw64;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+  float se = 0.f, nl = 0.f, kl = 0.f;
+  if (sv) {
+    se += expf((float)(lw64 - mx));
+    nl -= a;
+    kl += lq - lp;
+  }
+  se = wave_sum(se); nl = wave_sum(nl); kl = wave_sum(kl);
+  const float lrel = logf(se);
+  if (rw && sv) rw[r] = expf((float)(lw64 - mx) - lrel);
+  if (lane == 0) { pb[4 * b] = (float)(mx + (double)lrel - (double)logf((float)S)); pb[4 * b + 1] = nl; pb[4 * b + 2] = kl; pb[4 * b + 3] = 0.f; }
+}
+
 // One workgroup: per-x IWAE bound logsumexp_s(log w) - log S, normalised row
 // weights rw = softmax_s(log w), and the tail sums
 // [sum_b loss_b, sum nll, sum kl, sum nent, B] (means over s inside a group).
