@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("GMVAE_HIP_LIB") or os.path.join(HERE, "lib", "libgmva
 
 MAX_HIDDEN = 8
 TAIL = 8
+ABI_VERSION = 6       # include/gmvae_hip.h GMVAE_ABI_VERSION: the layout of GmvaeDims below and the entry points bound in _load
 MODEL_VAE, MODEL_VAE_GMP, MODEL_GMVAE = 0, 1, 2
 MODEL_IDS = {"vae": MODEL_VAE, "vae_gmp": MODEL_VAE_GMP, "gmvae": MODEL_GMVAE}
 NET_ENCODER_Y, NET_PRIOR_GMM, NET_ENCODER_GMM, NET_DECODER, NET_ENCODER = range(5)
@@ -85,6 +86,10 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.argtypes = args
         fn.restype = res
+    got = lib.gmvae_abi_version()        # (GMVAE_HIP_LIB may name another build: an older one would ignore GmvaeDims' newer fields)
+    if got != ABI_VERSION:
+        raise GmvaeError(f"{LIB_PATH} has ABI v{got}, this binding is for v{ABI_VERSION} (include/gmvae_hip.h): rebuild with "
+                         f"`python build_hip.py --force`")
     return lib, sorted(sigs)
 
 

@@ -29,7 +29,10 @@ def activation_name(fn) -> str:
         return "relu"
     table = {"relu": (torch.relu, F.relu), "tanh": (torch.tanh, F.tanh), "sigmoid": (torch.sigmoid, F.sigmoid), "elu": (F.elu,)}
     for name, fns in table.items():
-        if fn == name or any(fn is f for f in fns) or getattr(fn, "__name__", "") == name:
+        # by NAME only for the libraries' own functions (tf.nn.relu, tf.tanh, tf.nn.elu ... of a caller that still imports
+        # TensorFlow): a user function that happens to be called `elu` may compute anything (another alpha)
+        lib_fn = getattr(fn, "__name__", "") == name and (getattr(fn, "__module__", "") or "").split(".")[0] in ("torch", "tensorflow")
+        if (isinstance(fn, str) and fn == name) or any(fn is f for f in fns) or lib_fn:
             return name
     raise NotImplementedError(f"hidden_activation_fn={fn!r}: the HIP kernels implement relu (the reference default, "
                               f"scripts/vae.py:196), tanh, sigmoid and elu")
@@ -147,7 +150,7 @@ class MixtureSameFamily:
 # -------------------------------------------------- conditional networks
 class _Conditional:
     def __init__(self, size, hidden_layer_sizes, hidden_activation_fn, name, initializers=None):
-        _check_relu(hidden_activation_fn)
+        self._act = activation_name(hidden_activation_fn)
         self._initializers = _check_initializers(initializers)
         self._name, self._size = name, size
         self._hidden = None if hidden_layer_sizes is None else list(hidden_layer_sizes)
@@ -157,6 +160,11 @@ class _Conditional:
     def bind(self, engine, net_id):
         """Attach to the flat parameter buffer (the factories do this; it stands in
         for Sonnet's lazy variable creation, scripts/base.py:47-60)."""
+        # the activation is a field of the ENGINE's dims (one for every network, as the factories pass one): a conditional built
+        # with another one would silently evaluate with the engine's
+        if self._hidden and self._act != engine.hidden_act:
+            raise ValueError(f"{self._name}: hidden_activation_fn is {self._act!r} but the Engine it is bound to was created "
+                             f"with hidden_act={engine.hidden_act!r}")
         self._engine, self._net = engine, net_id
         if self._initializers:                      # custom initializers: re-draw this network's tensors
             prefix = self._name + "_fcnet/"

@@ -249,8 +249,8 @@ __global__ __launch_bounds__(kThreads) void chain_fwd(const ChainFwdArgs a) {
   {
     const int row = tid >> 4, sub = tid & 15;
     const bool ok = row < nrow;
-    float lgv[4], av[4];
-    float mx = -INFINITY, m2 = -INFINITY;
+    float lgv[4], av[4], lpv[4];
+    float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = sub + 16 * j;
@@ -260,18 +260,16 @@ __global__ __launch_bounds__(kThreads) void chain_fwd(const ChainFwdArgs a) {
         const float uu = ok ? P_u[row * K + k] : 0.5f;
         av[j] = (lgv[j] - flog(-flog(uu))) * a.invT;
         mx = fmaxf(mx, av[j]);
-        m2 = fmaxf(m2, lgv[j]);
       }
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); m2 = fmaxf(m2, __shfl_xor(m2, o, 64)); }
-    float se = 0.f, s2 = 0.f;
+    mx = Sub16::max(mx);
+    float se = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (sub + 16 * j < K) { se += fexp(av[j] - mx); s2 += fexp(lgv[j] - m2); }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    const float lse = mx + flog(se), l2 = m2 + flog(s2);
+      if (sub + 16 * j < K) se += fexp(av[j] - mx);
+    se = Sub16::sum(se);
+    const float lse = mx + flog(se);
+    cat_log_softmax<Sub16, 4>(lgv, lpv);           // log pi (gemm.hpp: accurate for a saturated q(y|x))
     float ne = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -280,7 +278,7 @@ __global__ __launch_bounds__(kThreads) void chain_fwd(const ChainFwdArgs a) {
         float yv = 0.f;
         if (k < K) {
           yv = fexp(av[j] - lse);
-          const float lp = lgv[j] - l2;
+          const float lp = lpv[j];
           ne += fexp(lp) * lp;
           if (ok) a.y[(long long)(r0 + row) * K + k] = yv;
         }
@@ -482,32 +480,23 @@ __global__ __launch_bounds__(kThreads) void chain_bwd(const ChainBwdArgs a) {
   {
     const int row = tid >> 4, sub = tid & 15;
     const bool ok = row < nrow;
-    float lgv[4], yv[4];
-    float m2 = -INFINITY, dot = 0.f;
+    float lgv[4], yv[4], dyv[4], lpv[4], dav[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = sub + 16 * j;
-      lgv[j] = -INFINITY; yv[j] = 0.f;
+      lgv[j] = -INFINITY; yv[j] = 0.f; dyv[j] = 0.f;
       if (k < K && ok) {
         lgv[j] = P_lg[row * K + k];
         yv[j] = P_y[row * K + k];
-        m2 = fmaxf(m2, lgv[j]);
-        dot += yv[j] * P_dy[row * KP + k];
+        dyv[j] = P_dy[row * KP + k];
       }
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { m2 = fmaxf(m2, __shfl_xor(m2, o, 64)); dot += __shfl_xor(dot, o, 64); }
-    float s2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (sub + 16 * j < K && ok) s2 += fexp(lgv[j] - m2);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
-    const float l2 = m2 + flog(s2);
+    cat_log_softmax<Sub16, 4>(lgv, lpv);           // (gemm.hpp: the forms that survive a saturated softmax)
+    cat_softmax_bwd<Sub16, 4>(yv, dyv, dav);
     float ne = 0.f;                                 // nent recomputed from the logits (cheaper than a dependent load)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (sub + 16 * j < K && ok) { const float lp = lgv[j] - l2; ne += fexp(lp) * lp; }
+      if (sub + 16 * j < K && ok) { const float lp = lpv[j]; ne += fexp(lp) * lp; }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) ne += __shfl_xor(ne, o, 64);
 #pragma unroll
@@ -516,8 +505,8 @@ __global__ __launch_bounds__(kThreads) void chain_bwd(const ChainBwdArgs a) {
       if (k < K2) {
         float dl = 0.f;
         if (k < K && ok) {
-          const float lp = lgv[j] - l2;
-          dl = yv[j] * (P_dy[row * KP + k] - dot) * a.invT + fexp(lp) * (lp - ne);
+          const float lp = lpv[j];
+          dl = dav[j] * a.invT + fexp(lp) * (lp - ne);
           a.dlogits[(long long)(r0 + row) * K + k] = dl;
         }
         A_dl[k * kLDA + row] = dl;

@@ -169,11 +169,100 @@ __device__ __forceinline__ float relu_nan(const float v) { return !(v <= 0.f) ? 
 //  be denormal (probabilities below 1e-38) may flush to 0)
 __device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
-// (softplus in the one-launch / skinny / chain paths is max(v, 0) - log(rcp(1 + e)): it rounds 1 + e first, so sigma carries a
-//  relative error of 6e-8 / sigma -- 6e-6 at sigma = 0.01, and nothing is left of a sigma below 6e-8.  The compensated form
-//  (softplus_r below: log(1 + e) e / ((1 + e) - 1), 2.4e-7 everywhere) was measured there and dropped: two more dependent
-//  quarter-rate instructions per latent on the per-row chain, configs[2] 31.17 -> 31.40 us.  The general schedule's z heads use it.)
-__device__ __forceinline__ float fsoftplus(float v) { return fmaxf(v, 0.f) + flog(1.f + fexp(-fabsf(v))); }
+// softplus(v) and sigmoid(v) of the per-row chains (one-launch, skinny, chain kernels) from ONE exp, ONE rcp and ONE log:
+//   v >= -4:  max(v, 0) - log(rcp(1 + e)), e = exp(-|v|).  1 + e and the reciprocal each round at 6e-8 ABSOLUTE, so softplus
+//             carries ~1.2e-7 / softplus(v) relative: 7e-6 at v = -4 (softplus = 0.018), less above.
+//   v <  -4:  log1p(e) by its alternating series e (1 - e/2 + e^2/3 - e^3/4), e < 0.0184 (first dropped term e^4/5 = 2.3e-8
+//             relative).  Nothing rounds against 1: sigma keeps full relative precision down to exp's own range (v > -87).
+// Round 5's form took the first branch everywhere: a sigma of 3e-4 (raw = -8: a trained posterior) came out 2e-4 off -- 1 / sigma
+// carries that into every gradient behind it (tests/test_saturated.py: 1.1 - 2.7e-4 of the tensor's largest entry) -- and nothing
+// was left of a sigma below 6e-8 (raw < -16.6: log(0), NaN).  The series runs beside the rcp / log pair (four FMAs, independent of
+// both quarter-rate instructions); the select is the only instruction added to the dependent chain.
+__device__ __forceinline__ float softplus_sig(const float v, float& sig) {
+  const float e = fexp(-fabsf(v));
+  const float r = __builtin_amdgcn_rcpf(1.f + e);
+  sig = v >= 0.f ? r : e * r;
+  const float series = e * fmaf(e, fmaf(e, fmaf(e, -0.25f, 0.333333343f), -0.5f), 1.f);
+  return v < -4.f ? series : fmaxf(v, 0.f) - flog(r);
+}
+__device__ __forceinline__ float fsoftplus(const float v) { float s; return softplus_sig(v, s); }
+// log(1 + S) for S >= 0 without rounding 1 + S when S is small (the series of softplus_sig)
+__device__ __forceinline__ float flog1p(const float S) {
+  return S < 0.0184f ? S * fmaf(S, fmaf(S, fmaf(S, -0.25f, 0.333333343f), -0.5f), 1.f) : flog(1.f + S);
+}
+// ---- the categorical head's two row computations (scripts/gmvae.py:240,262-263), in forms that stay
+// accurate when ONE class takes (almost) all of the mass.  A trained q(y|x) does: logits of +-40 after 300 steps on clustered
+// pixels (tests/test_saturated.py) -- and there the textbook forms, TF's own fp32 kernels included, lose the small quantities
+// the gradient is made of against a 1:
+//   (1) log pi_k = (lg_k - m) - log(sum_j exp(lg_j - m)).  With one maximum the sum is 1 + S, S the OTHER classes' mass; rounded
+//       against the 1 it keeps 6e-8 / S of S, and log pi_top = -S, H = sum pi log pi and the entropy gradient pi (log pi - H) all
+//       inherit that (S = 2.5e-5: 2.4e-3 relative).  Here S is summed separately and log(1 + S) is log1p(S); (lg_k - m) is formed
+//       before the normaliser is subtracted (m + log1p(S) would absorb S into m's ulp).  Several equal maxima: the plain form.
+//   (2) da_k = y_k (dy_k - sum_j y_j dy_j).  With y_top -> 1 the top class's bracket is dy_top - (dy_top + small): cancellation
+//       at 6e-8 / (1 - y_top).  Since sum_j y_j = 1 any constant c may be subtracted from dy first:
+//       dy_k - dot = (dy_k - c) - sum_j y_j (dy_j - c); with c = dy at the largest y the top class's bracket is minus a sum of
+//       small terms, every other class's an O(1) difference times a small y.  O(K), two more row reductions.
+// R: the row's reduction policy (max / sum over the lanes that share the row); NJ classes per lane (absent: lg = -inf, y = dy = 0).
+struct Sub16 {                     // reduction policy of gemm.hpp's cat_* helpers: the 16 lanes of a row, by shuffles
+  static __device__ __forceinline__ float max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+  }
+  static __device__ __forceinline__ float sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  }
+};
+struct Wave64 {                    // ... the whole wave holds one row
+  static __device__ __forceinline__ float max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+  }
+  static __device__ __forceinline__ float sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  }
+};
+template <class R, int NJ, bool LIBM = false>
+__device__ __forceinline__ void cat_log_softmax(const float (&lg)[NJ], float (&lp)[NJ]) {
+  float m = lg[0];
+#pragma unroll
+  for (int j = 1; j < NJ; ++j) m = fmaxf(m, lg[j]);
+  m = R::max(m);
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const float e = LIBM ? expf(lg[j] - m) : fexp(lg[j] - m);
+    sa += e;
+    sb += lg[j] == m ? 0.f : e;
+  }
+  sa = R::sum(sa); sb = R::sum(sb);
+  const bool one = sa - sb < 1.5f;                 // ONE class holds the maximum
+  const float l = LIBM ? (one ? log1pf(sb) : logf(sa)) : (one ? flog1p(sb) : flog(sa));
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) lp[j] = (lg[j] - m) - l;
+}
+template <class R, int NJ>
+__device__ __forceinline__ void cat_softmax_bwd(const float (&y)[NJ], const float (&dy)[NJ], float (&da)[NJ]) {
+  float ym = y[0];
+#pragma unroll
+  for (int j = 1; j < NJ; ++j) ym = fmaxf(ym, y[j]);
+  ym = R::max(ym);
+  float c = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) c = fmaxf(c, y[j] == ym ? dy[j] : -INFINITY);
+  c = R::max(c);                                   // dy at (one of) the largest y
+  float dc[NJ], dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { dc[j] = dy[j] - c; dot += y[j] * dc[j]; }
+  dot = R::sum(dot);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) da[j] = y[j] * (dc[j] - dot);
+}
 // The general schedule's z heads (51,200 x 64 elements per evaluation pass: z_head_fwd was 33 us of libm softplus / log /
 // IEEE division, 17.5 us with these): the hardware forms where they are exact enough and the denormal-safe ones where they are
 // not, chosen per element -- softplus through the compensated log1p, log(1 + e) e / ((1 + e) - 1) (a few ulp for every e in

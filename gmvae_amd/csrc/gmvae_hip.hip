@@ -53,6 +53,27 @@ static int device_cus() {
   if (!cu_of[dev]) { hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); cu_of[dev] = n > 0 ? n : 256; }
   return cu_of[dev];
 }
+// The one-launch steps (mega3.hpp) read hand-off buffers with PLAIN loads behind flags: correct under the cache behaviour of the
+// architecture it was verified on (gfx950: L2s invalidated at dispatch, byte-masked write-through allocation) -- by the HIP memory
+// model it is a data race, and a stale line would give silently wrong gradients.  Anything else takes the two-launch form.
+static bool device_is_gfx950() {
+  static signed char is_of[64];              // 0 unknown, 1 yes, -1 no
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (!is_of[dev]) {
+    hipDeviceProp_t pr;
+    is_of[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && !strncmp(pr.gcnArchName, "gfx950", 6)) ? 1 : -1;
+  }
+  return is_of[dev] > 0;
+}
+// one-shot per DEVICE (hipFuncSetAttribute belongs to the device's code object; a process may drive several devices)
+static bool first_on_device(bool (&seen)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  if (seen[dev]) return false;
+  seen[dev] = true;
+  return true;
+}
 static int mega_q(const GmvaeDims& d) {
   const int panels = (d.B + 15) / 16, cus = device_cus();
   int q = panels * 4 <= cus ? 4 : panels * 2 <= cus ? 2 : 1;
@@ -1148,11 +1169,10 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
     if (getenv("GMVAE_TRACE"))
       fprintf(stderr, "[gmvae] mega_fwd_bwd: model %d B %d first_layer_inside %d workgroups_per_panel %d specialised %d\n", model, B,
               (int)fl, Qm, (int)(spec || spec_vae));
-    static bool mattr = false;
-    if (!mattr) {
+    static bool mattr[64];
+    if (first_on_device(mattr)) {
       for (int i = 0; i < 8; ++i)
         hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      mattr = true;
     }
     const bool m2 = fl && mega2_ok(d, model) && w.img2f;
     const bool m2v = fl && vk != 0;
@@ -1161,15 +1181,15 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       c.img2f = w.img2f; c.img2b = w.img2b; c.dimg2 = w.dimg2;
       c.lr = a.lr; c.b1 = a.beta1; c.b2 = a.beta2;
       c.lr_t_out = (a.adam_p && a.adam_p == a.params && a.step_dev) ? reinterpret_cast<float*>(w.sync + 2) : nullptr;
-      static bool m2attr = false;
-      if (!m2attr) {
+      static bool m2attr[64];
+      if (first_on_device(m2attr)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(mega2_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        m2attr = true;
       }
       // (B = 1024: 256 workgroups for the 241 tile slots and the register-resident contraction forms; measured at smaller
       //  batches -- fewer workgroups than slots -- the one-launch form loses: B = 512 43.2 against 33.8 us, profiles/round5_notes.md.
       //  GMVAE_FUSE=1 forces it for any batch: tools/fuse_check.py)
-      fuse_pending = (dw_upd_ || a.dp_images) && a.step_dev && !getenv("GMVAE_NO_FUSE") && (B == 1024 || getenv("GMVAE_FUSE"));
+      fuse_pending = (dw_upd_ || a.dp_images) && a.step_dev && !getenv("GMVAE_NO_FUSE") && (B == 1024 || getenv("GMVAE_FUSE")) &&
+                     device_is_gfx950();
       c3 = c;
       // (an even number of panels: the first layer works on pairs of them, mega2.hpp)
       if (!fuse_pending)
@@ -1178,15 +1198,15 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
       c.img2f = w.img2f; c.img2b = w.img2b; c.dimg2 = w.dimg2;
       c.lr = a.lr; c.b1 = a.beta1; c.b2 = a.beta2;
       c.lr_t_out = (a.adam_p && a.adam_p == a.params && a.step_dev) ? reinterpret_cast<float*>(w.sync + 2) : nullptr;
-      static bool m2vattr = false;
-      if (!m2vattr) {
+      static bool m2vattr[64];
+      if (first_on_device(m2vattr)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(mega2v_fwd_bwd<0, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(mega2v_fwd_bwd<1, 64, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        m2vattr = true;
       }
       const unsigned grid = (unsigned)((B + kPanel - 1) / kPanel * 7);
       // (mega3v_step: the step as ONE launch where the optimizer runs on this device; the data-parallel graph keeps two launches)
-      fusev_pending = dw_upd_ && a.step_dev && !getenv("GMVAE_NO_FUSE") && grid <= 256;
+      // (its grid is 256 workgroups whatever the batch -- the role-less workers --, one per CU: all of them must be resident)
+      fusev_pending = dw_upd_ && a.step_dev && !getenv("GMVAE_NO_FUSE") && grid <= 256 && n_cu >= 256 && device_is_gfx950();
       vkind = vk;
       c3 = c;
       if (fusev_pending) { /* launched below, with the tile list */ }
@@ -1288,6 +1308,7 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         m3.flags = w.m3flags;
         m3.lr_next = w.sync + 4;
         m3.dbg = getenv("GMVAE_M3_STAMPS") ? w.gstamps + 3 * 2048 * 8 : nullptr;
+        m3.fault_pnl = getenv("GMVAE_DEBUG_LEAD_FAULT") ? atoi(getenv("GMVAE_DEBUG_LEAD_FAULT")) : -1;
         const int nPr = (B + kPanel - 1) / kPanel;
         const unsigned grid3 = vfam ? 256u : m2_grid;
         {
@@ -1357,12 +1378,11 @@ static int run_step_mega(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, con
         m3.gmp_nmap = da.gmp_nmap;
         for (int i = 0; i < 3; ++i) m3.gmp_map[i] = da.gmp_map[i];
         for (int i = 0; i < kImgBufs; ++i) f3.img[i] = fa.img[i];
-        static bool m3attr = false;
-        if (!m3attr) {
+        static bool m3attr[64];
+        if (first_on_device(m3attr)) {
           hipFuncSetAttribute(reinterpret_cast<const void*>(mega3_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           hipFuncSetAttribute(reinterpret_cast<const void*>(mega3v_step<0, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           hipFuncSetAttribute(reinterpret_cast<const void*>(mega3v_step<1, 64, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          m3attr = true;
         }
         // (the meeting area of a worker's tile: 34 KB at the bottom of the dynamic LDS, whatever the per-row part's map)
         if (m3.total_slots <= kM3MaxSlots && (!gmp || da.gmp_blocks < 0xfe)) {
@@ -1454,11 +1474,10 @@ static int run_step_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, co
   const float* P = a.params;
   hipStream_t st = cx.st;
   const int NSF = fwd_splits(D);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64];
+  if (first_on_device(attr_done)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   const NetL &E = L.ency, &G = L.encg, &Dn = L.dec;
   {  // P1: X * [Wy0 | Wg0x] as single-round split-K partials

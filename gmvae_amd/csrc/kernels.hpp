@@ -145,6 +145,21 @@ __global__ __launch_bounds__(256) void rows_small_k(const SmallKArgs a) {
   }
 }
 
+// log-softmax normaliser of one row of K logits walked by a wave (any K): m = the maximum, l = log(sum_j exp(lg_j - m)) with the
+// log1p form when one class holds the maximum (gemm.hpp cat_log_softmax's statement (1)); log pi_k = (lg_k - m) - l.
+__device__ __forceinline__ void row_lse_parts(const float* __restrict__ lg, const int K, const int lane, float& m, float& l) {
+  m = -INFINITY;
+  for (int k = lane; k < K; k += 64) m = fmaxf(m, lg[k]);
+  m = wave_max(m);
+  float sa = 0.f, sb = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float e = expf(lg[k] - m);
+    sa += e;
+    sb += lg[k] == m ? 0.f : e;
+  }
+  sa = wave_sum(sa); sb = wave_sum(sb);
+  l = (sa - sb < 1.5f) ? log1pf(sb) : logf(sa);
+}
 // ------------------------------------------------ q(y|x): Gumbel-softmax head
 // RelaxedOneHotCategorical.sample (scripts/base.py:206-209, gmvae.py:240):
 //   g = -log(-log u); y = softmax((logits + g)/T)
@@ -175,13 +190,10 @@ __global__ void y_head_fwd(const float* __restrict__ logits, const float* __rest
       const float lse = mx + logf(se);
       if (kv) y[r * K + k] = expf(a - lse);
       // once per x (the row of its first sample): entropy of q(y|x)
-      float m2 = k < K ? lgk : -INFINITY;
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o, 16));
-      float s2 = k < K ? expf(lgk - m2) : 0.f;
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 16);
-      const float lp = lgk - (m2 + logf(s2));
+      const float lga[1] = {k < K ? lgk : -INFINITY};
+      float lpa[1];
+      cat_log_softmax<Sub16, 1, true>(lga, lpa);   // log pi (gemm.hpp: accurate for a saturated q(y|x))
+      const float lp = lpa[0];
       float ne = k < K ? expf(lp) * lp : 0.f;
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) ne += __shfl_xor(ne, o, 16);
@@ -221,16 +233,11 @@ __global__ void y_head_fwd(const float* __restrict__ logits, const float* __rest
     }
     }
     if (r == b * S) {       // once per x: entropy of q(y|x)
-      float m2 = -INFINITY;
-      for (int k = lane; k < K; k += 64) m2 = fmaxf(m2, lg[k]);
-      m2 = wave_max(m2);
-      float s2 = 0.f;
-      for (int k = lane; k < K; k += 64) s2 += expf(lg[k] - m2);
-      s2 = wave_sum(s2);
-      const float l2 = m2 + logf(s2);
+      float m2, l2;
+      row_lse_parts(lg, K, lane, m2, l2);
       float ne = 0.f;
       for (int k = lane; k < K; k += 64) {
-        const float lp = lg[k] - l2;
+        const float lp = (lg[k] - m2) - l2;
         ne += expf(lp) * lp;
       }
       ne = wave_sum(ne);
@@ -251,23 +258,25 @@ __global__ __launch_bounds__(512) void y_head_bwd(const float* __restrict__ logi
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const float* lg = logits + (long long)b * K;
-    float m2 = -INFINITY;
-    for (int k = lane; k < K; k += 64) m2 = fmaxf(m2, lg[k]);
-    m2 = wave_max(m2);
-    float s2 = 0.f;
-    for (int k = lane; k < K; k += 64) s2 += expf(lg[k] - m2);
-    s2 = wave_sum(s2);
-    const float l2 = m2 + logf(s2);
+    float m2, l2;
+    row_lse_parts(lg, K, lane, m2, l2);
     const float ne = nent[b];
     for (int k0 = 0; k0 < K; k0 += 64) {
       const int k = k0 + lane;
       float acc = 0.f;
       for (int s = wave; s < S; s += 8) {
         const long long r = (long long)b * S + s;
+        // y (dy - y . dy) shifted by dy at the largest y (gemm.hpp cat_softmax_bwd's statement (2))
+        float ym = 0.f;
+        for (int kk = lane; kk < K; kk += 64) ym = fmaxf(ym, y[r * K + kk]);
+        ym = wave_max(ym);
+        float c = -INFINITY;
+        for (int kk = lane; kk < K; kk += 64) c = fmaxf(c, y[r * K + kk] == ym ? dy[r * K + kk] : -INFINITY);
+        c = wave_max(c);
         float dot = 0.f;
-        for (int kk = lane; kk < K; kk += 64) dot += y[r * K + kk] * dy[r * K + kk];
+        for (int kk = lane; kk < K; kk += 64) dot += y[r * K + kk] * (dy[r * K + kk] - c);
         dot = wave_sum(dot);
-        if (k < K) acc += y[r * K + k] * (dy[r * K + k] - dot);
+        if (k < K) acc += y[r * K + k] * ((dy[r * K + k] - c) - dot);
       }
       red[wave][lane] = acc;
       __syncthreads();
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(512) void y_head_bwd(const float* __restrict__ logi
         float t = red[0][lane];                    // fixed order: the same bits whatever the timing
 #pragma unroll
         for (int w = 1; w < 8; ++w) t += red[w][lane];
-        const float lp = lg[k] - l2;
+        const float lp = (lg[k] - m2) - l2;
         dlogits[(long long)b * K + k] = t * invT + expf(lp) * (lp - ne);
       }
       __syncthreads();

@@ -127,6 +127,10 @@ __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, dpp_mov<0x128>(v)); v = fmaxf(v, dpp_mov<0x124>(v)); v = fmaxf(v, dpp_mov<0x122>(v)); v = fmaxf(v, dpp_mov<0x121>(v));
   return v;
 }
+struct Row16 {                     // reduction policy of gemm.hpp's cat_* helpers: 16 consecutive lanes share a row
+  static __device__ __forceinline__ float max(float v) { return row16_max(v); }
+  static __device__ __forceinline__ float sum(float v) { return row16_sum(v); }
+};
 __device__ __forceinline__ float row32_sum(float v) { v = row16_sum(v); return v + __shfl_xor(v, 16, 64); }
 __device__ __forceinline__ float row32_max(float v) { v = row16_max(v); return fmaxf(v, __shfl_xor(v, 16, 64)); }
 
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     const int row = tid >> 4, sub = tid & 15;
     const bool ok = row < nrow;
     float lgv[4], av[4];
-    float mx = -INFINITY, m2 = -INFINITY;
+    float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = sub + 16 * j;
@@ -626,16 +630,17 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
         const float uu = ok ? P_u[row * K + k] : 0.5f;
         av[j] = (lgv[j] - flog(-flog(uu))) * a.invT;
         mx = fmaxf(mx, av[j]);
-        m2 = fmaxf(m2, lgv[j]);
       }
     }
-    mx = row16_max(mx); m2 = row16_max(m2);
-    float se = 0.f, s2 = 0.f;
+    mx = row16_max(mx);
+    float se = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (sub + 16 * j < K) { se += fexp(av[j] - mx); s2 += fexp(lgv[j] - m2); }
-    se = row16_sum(se); s2 = row16_sum(s2);
-    const float lse = mx + flog(se), l2 = m2 + flog(s2);
+      if (sub + 16 * j < K) se += fexp(av[j] - mx);
+    se = row16_sum(se);
+    const float lse = mx + flog(se);
+    float lpv[4];
+    cat_log_softmax<Row16, 4>(lgv, lpv);           // log pi (gemm.hpp: accurate for a saturated q(y|x))
     float ne = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -644,7 +649,7 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
         float yv = 0.f;
         if (k < K) {
           yv = fexp(av[j] - lse);
-          const float lp = lgv[j] - l2;
+          const float lp = lpv[j];
           ne += fexp(lp) * lp;
           P_y[row * K + k] = yv;
           if (ok && lead) a.y[(long long)(r0 + row) * K2 + k] = yv;        // rows of pad4(K) floats
@@ -687,26 +692,24 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
     for (int l = sub; l < L; l += 32) {
       const float mu = P_qp[row * L2 + l];
       const float vq = P_qp[row * L2 + L + l] + a.c;
-      const float eq = fexp(-fabsf(vq));
-      const float rq = __builtin_amdgcn_rcpf(1.f + eq);
-      const float sg = fmaxf(fmaxf(vq, 0.f) - flog(rq), a.smin);
+      float sgq;
+      const float sg = fmaxf(softplus_sig(vq, sgq), a.smin);
       const float ee = ok ? P_eps[row * L + l] : 0.f;
       const float zz = mu + sg * ee;
       A_z[l * kLDA + row] = zz;
       if (ok && lead) a.z[(long long)(r0 + row) * L + l] = zz;
-      P_qp[row * L2 + l] = vq >= 0.f ? rq : eq * rq;
+      P_qp[row * L2 + l] = sgq;
       P_qp[row * L2 + L + l] = sg;
       aq += -0.5f * ee * ee - 0.5f * kLog2Pi - flog(sg);     // (z - mu) / sigma IS eps
       if (gm) {                                             // p(z|y): gmvae.py:258
         const float vp = P_pp[row * L2 + L + l] + a.c;
-        const float ep = fexp(-fabsf(vp));
-        const float rp = __builtin_amdgcn_rcpf(1.f + ep);
-        const float sp = fmaxf(fmaxf(vp, 0.f) - flog(rp), a.smin);
+        float sgp;
+        const float sp = fmaxf(softplus_sig(vp, sgp), a.smin);
         const float t = (zz - P_pp[row * L2 + l]) * __builtin_amdgcn_rcpf(sp);
         ap += -0.5f * t * t - 0.5f * kLog2Pi - flog(sp);
         P_pp[row * L2 + l] = t;
         P_pp[row * L2 + L + l] = sp;
-        P_z[row * L + l] = vp >= 0.f ? rp : ep * rp;
+        P_z[row * L + l] = sgp;
       } else {                                              // N(0, I): vae.py:247-250 (VAE_GMP: mixture stage below)
         P_z[row * L + l] = zz;
         ap += -0.5f * zz * zz - 0.5f * kLog2Pi;
@@ -1085,26 +1088,19 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
   if (tid < 256) {
     const int row = tid >> 4, sub = tid & 15;
     const bool ok = row < nrow;
-    float lgv[4], yv[4];
-    float m2 = -INFINITY, dot = 0.f;
+    float lgv[4], yv[4], dyv[4], lpv[4], dav[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = sub + 16 * j;
-      lgv[j] = -INFINITY; yv[j] = 0.f;
+      lgv[j] = -INFINITY; yv[j] = 0.f; dyv[j] = 0.f;
       if (k < K && ok) {
         lgv[j] = P_lg[row * KP + k];
         yv[j] = P_y[row * K + k];
-        m2 = fmaxf(m2, lgv[j]);
-        dot += yv[j] * P_dy[row * KP + k];
+        dyv[j] = P_dy[row * KP + k];
       }
     }
-    m2 = row16_max(m2); dot = row16_sum(dot);
-    float s2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (sub + 16 * j < K && ok) s2 += fexp(lgv[j] - m2);
-    s2 = row16_sum(s2);
-    const float l2 = m2 + flog(s2);
+    cat_log_softmax<Row16, 4>(lgv, lpv);           // (gemm.hpp: the forms that survive a saturated softmax)
+    cat_softmax_bwd<Row16, 4>(yv, dyv, dav);
     const float ne = nllp[3 * kPanel + row];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1112,8 +1108,8 @@ __global__ __launch_bounds__(kMT) void mega_fwd_bwd(const MegaArgs a) {
       if (k < K2) {
         float dl = 0.f;
         if (k < K && ok) {
-          const float lp = lgv[j] - l2;
-          dl = yv[j] * (P_dy[row * KP + k] - dot) * a.invT + fexp(lp) * (lp - ne);
+          const float lp = lpv[j];
+          dl = dav[j] * a.invT + fexp(lp) * (lp - ne);
           a.dlogits[(long long)(r0 + row) * K2 + k] = dl;
         }
         A_dl[k * kLDA + row] = dl;

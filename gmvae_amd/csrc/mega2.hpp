@@ -419,15 +419,18 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
            img[M2::b_y1 + k];
       const float uu = ok ? P_u[row * 16 + k] : 0.5f;
       av = (lg - flog(-flog(uu))) * a.invT;
-      P_lg[row * M2::ldk + k] = lg;
     }
-    const float mx = row16_max(av), m2 = row16_max(lg);
-    const float se = row16_sum(kv ? fexp(av - mx) : 0.f), s2 = row16_sum(kv ? fexp(lg - m2) : 0.f);
-    const float lse = mx + flog(se), l2 = m2 + flog(s2);
+    const float mx = row16_max(av);
+    const float se = row16_sum(kv ? fexp(av - mx) : 0.f);
+    const float lse = mx + flog(se);
+    const float lga[1] = {lg};
+    float lpa[1];
+    cat_log_softmax<Row16, 1>(lga, lpa);           // log pi (gemm.hpp: accurate for a saturated q(y|x)); kept for phase B
     float yv = 0.f, ne = 0.f;
     if (kv) {
       yv = fexp(av - lse);
-      const float lp = lg - l2;
+      const float lp = lpa[0];
+      P_lg[row * M2::ldk + k] = lp;
       ne = fexp(lp) * lp;
       if (ok && act) st1o(a.y + (long long)(r0 + row) * K2 + k, yv);            // rows of pad4(K) floats
     }
@@ -479,24 +482,22 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
       float* const pr = P_pp + row * M2::ld128;
       const float mu = qr[l];
       const float vq = qr[L + l] + a.c;
-      const float eq = fexp(-fabsf(vq));
-      const float rq = __builtin_amdgcn_rcpf(1.f + eq);
-      const float sg = fmaxf(fmaxf(vq, 0.f) - flog(rq), a.smin);
+      float sgq;                                             // sigmoid(raw_q + c): softplus' derivative, kept for phase B
+      const float sg = fmaxf(softplus_sig(vq, sgq), a.smin);
       const float ee = ok ? P_eps[row * 64 + l] : 0.f;
       const float zz = mu + sg * ee;
       P_z[row * M2::ld64 + l] = zz;
-      qr[l] = vq >= 0.f ? rq : eq * rq;
+      qr[l] = sgq;
       qr[L + l] = sg;
       aq += -0.5f * ee * ee - 0.5f * kLog2Pi - flog(sg);     // (z - mu) / sigma IS eps
       const float vp = pr[L + l] + a.c;                      // p(z|y): gmvae.py:258
-      const float ep = fexp(-fabsf(vp));
-      const float rp = __builtin_amdgcn_rcpf(1.f + ep);
-      const float sp = fmaxf(fmaxf(vp, 0.f) - flog(rp), a.smin);
+      float sgp;
+      const float sp = fmaxf(softplus_sig(vp, sgp), a.smin);
       const float t = (zz - pr[l]) * __builtin_amdgcn_rcpf(sp);
       ap += -0.5f * t * t - 0.5f * kLog2Pi - flog(sp);
       pr[l] = t;
       pr[L + l] = sp;
-      P_sp[row * 64 + l] = vp >= 0.f ? rp : ep * rp;
+      P_sp[row * 64 + l] = sgp;
     }
     aq = row32_sum(aq); ap = row32_sum(ap);
     if (sub == 0) {
@@ -797,17 +798,14 @@ __device__ __forceinline__ int mega2_body(const MegaArgs& a, float* const sm, un
     float dy = 0.f;
 #pragma unroll
     for (int w = 0; w < kMW; ++w) dy += red[w * 256 + (((k >> 2) * 16 + row) << 2) + (k & 3)];
-    const float lg = kv ? P_lg[row * M2::ldk + k] : -INFINITY;
-    const float yv = kv ? P_y[row * M2::ldk + k] : 0.f;
-    const float m2 = row16_max(lg);
-    const float dot = row16_sum(kv ? yv * dy : 0.f);
-    const float s2 = row16_sum(kv ? fexp(lg - m2) : 0.f);
-    const float l2 = m2 + flog(s2);
+    const float ya[1] = {kv ? P_y[row * M2::ldk + k] : 0.f}, dya[1] = {kv ? dy : 0.f};
+    float daa[1];
+    cat_softmax_bwd<Row16, 1>(ya, dya, daa);       // y (dy - y . dy), shifted (gemm.hpp)
     const float ne = nllp[3 * kPanel + row];
     float dl = 0.f;
     if (kv) {
-      const float lp = lg - l2;
-      dl = yv * (dy - dot) * a.invT + fexp(lp) * (lp - ne);
+      const float lp = P_lg[row * M2::ldk + k];    // log pi, left by S2
+      dl = daa[0] * a.invT + fexp(lp) * (lp - ne);
       st1o(a.dlogits + (long long)(r0 + row) * K2 + k, dl);
     }
     P_dl[row * M2::ldk + k] = dl;

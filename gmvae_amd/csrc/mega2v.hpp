@@ -290,15 +290,14 @@ __device__ __forceinline__ int mega2v_body(const MegaArgs& a, float* const sm) {
       if (l < L) {
         const float mu = qr[l];
         const float vq = qr[L + l] + a.c;
-        const float eq = fexp(-fabsf(vq));
-        const float rq = __builtin_amdgcn_rcpf(1.f + eq);
-        const float sg = fmaxf(fmaxf(vq, 0.f) - flog(rq), a.smin);
+        float sgq;
+        const float sg = fmaxf(softplus_sig(vq, sgq), a.smin);
         const float ee = ok ? P_eps[row * LP + l] : 0.f;
         zz = mu + sg * ee;
         aq += -0.5f * ee * ee - 0.5f * kLog2Pi - flog(sg);     // (z - mu) / sigma IS eps
         if (!gmp) ap += -0.5f * zz * zz - 0.5f * kLog2Pi;      // standard-normal prior (vae.py:247-250)
         __builtin_amdgcn_sched_barrier(0);
-        qr[l] = vq >= 0.f ? rq : eq * rq;
+        qr[l] = sgq;
         qr[L + l] = sg;
       }
       P_z[row * V::ldz + l] = zz;

@@ -87,6 +87,8 @@ struct M3Args {
   unsigned* flags;             // [kM3FlagReplicas][kM3FlagRepLd]: in each replica [4][kM3FlagLd] per-workgroup epoch tags
   unsigned* lr_next;           // [4]: {alpha_t bits, the Adam step t it is for, lr bits, alpha_key(b1, b2)}: left by the previous step's tail slot
   unsigned long long* dbg;     // diagnostic: [workgroup][8] wall-clock stamps of the worker phase (tools/m3stamps.py) or null
+  int fault_pnl;               // test hook (GMVAE_DEBUG_LEAD_FAULT=<panel>, -1: none): that panel's lead sets the error word in front of
+                               // its flag -- a hand-off that gave up DURING the launch, after phase P has started
   unsigned short perm[kM3MaxSlots];   // slot -> (tensor << 10) | tile inside the tensor (| kM3PhaseF); kM3Tail: the loss tail
   DwTensor t[kM3MaxT];
   M3Fin fa;
@@ -104,8 +106,11 @@ __device__ __forceinline__ float m3_alpha(const M3Fin& a, const unsigned long lo
 }
 
 // the loss tail (kernels.hpp finalize_tail_block) over per-row terms the leads of THIS launch stored: agent-scope loads
+// `poisoned`: a hand-off of this launch gave up waiting (the error word is set) -- the per-row terms may be a previous step's:
+// the loss leaves as NaN, exactly what finalize_tail_block's inputs were in the two-launch form, so that the host sees the
+// step as not applied (gmvae_amd/runners.py) and the data-parallel optimizer behind the all-reduce skips it on every rank
 __device__ __forceinline__ void m3_tail(const M3Fin& a, unsigned long long* step_dev, const unsigned long long step, unsigned* lr_next,
-                                        float* red) {
+                                        float* red, const bool poisoned) {
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   const int t = threadIdx.x;
   if (t < 256) {
@@ -138,6 +143,7 @@ __device__ __forceinline__ void m3_tail(const M3Fin& a, unsigned long long* step
     __syncthreads();
   }
   if (t == 0) {
+    if (poisoned) red[0] = red[256] = red[512] = red[768] = __builtin_nanf("");
     a.tail[0] = red[0]; a.tail[1] = red[256]; a.tail[2] = red[512]; a.tail[3] = red[768];
     a.tail[4] = (float)a.B; a.tail[5] = 0.f; a.tail[6] = 0.f; a.tail[7] = 0.f;
     if (a.tail_log) {
@@ -168,6 +174,7 @@ __device__ __forceinline__ void m3_worker_phase(const M3Args& aa, float* const s
   const int B = a.B, nPr = (B + kPanel - 1) / kPanel;
   M3_ST(0);
   if (role != 3) {
+    if (role == 2 && pnl == aa.fault_pnl && tid == 0) atomicExch(a.err_word, 1u);      // (vmcnt counts it: acknowledged before the flag)
     // the role's stores are acknowledged: the workgroup's flag goes out
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     M3_ST2(0);
@@ -245,7 +252,7 @@ __device__ __forceinline__ void m3_worker_phase(const M3Args& aa, float* const s
     if (pv_ == kM3Tail) {
       wait_flags(true);
       M3_ST(2);
-      m3_tail(fa, a.step_dev, step, aa.lr_next, red);
+      m3_tail(fa, a.step_dev, step, aa.lr_next, red, poisoned);
       M3_ST(5);
       if (aa.dbg && tid == 0) aa.dbg[(size_t)blockIdx.x * 8 + 6] = 99ull;
       __syncthreads();
@@ -368,6 +375,11 @@ __device__ __forceinline__ void m3_worker_phase(const M3Args& aa, float* const s
     redcs[wave * 64 + lane] = cs;
     __syncthreads();
     M3_ST(4);
+    // All or nothing: a phase-P tile contracted behind the producers' flags only, but no update may be applied before EVERY
+    // hand-off of the launch is known to have arrived -- a lead that gives up later poisons the step, and the tiles that had
+    // already applied theirs would be applied a second time when the host runs the step again.  (The leads' flags are long
+    // there when a phase-P contraction ends: one poll.)
+    if (upd && !phF) wait_flags(true);
     if (eown) {
       float g[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

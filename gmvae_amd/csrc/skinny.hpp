@@ -666,10 +666,11 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     const bool lok = l < L;
     // (hardware exp / log / rcp forms as mega2.hpp S5: ~1e-6 relative, one pass of each per head)
     const float mu = v[0] + pf[0], raw = v[1] + pf[1];
-    const float vq = raw + a.c, eq = fexp(-fabsf(vq)), rq = __builtin_amdgcn_rcpf(1.f + eq);
-    const float sg = fmaxf(fmaxf(vq, 0.f) - flog(rq), a.smin);
+    float sgq;
+    const float sg = fmaxf(softplus_sig(raw + a.c, sgq), a.smin);
     const float zz = mu + sg * pf[2];
-    const float e = (zz - mu) * __builtin_amdgcn_rcpf(sg);       // from z, not eps (A7)
+    const float e = pf[2];                        // (z - mu) / sigma IS eps (as mega2.hpp S5; formed from the rounded z it
+                                                  //  loses every bit of eps once sigma |eps| < ulp(mu))
     float aq = -0.5f * e * e - 0.5f * kLog2Pi - flog(sg);
     float ap;
     if (a.model == 1) {                           // learned mixture prior: mixture_logprob_* after this launch
@@ -677,8 +678,8 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
     } else if (vae) {                             // standard-normal prior (scripts/vae.py:247-250)
       ap = -0.5f * zz * zz - 0.5f * kLog2Pi;
     } else {
-      const float mp = pf[3], vp = pf[4] + a.c, ep = fexp(-fabsf(vp)), rp = __builtin_amdgcn_rcpf(1.f + ep);
-      const float sp = fmaxf(fmaxf(vp, 0.f) - flog(rp), a.smin);
+      float sgp;
+      const float mp = pf[3], sp = fmaxf(softplus_sig(pf[4] + a.c, sgp), a.smin);
       const float t = (zz - mp) * __builtin_amdgcn_rcpf(sp);
       ap = -0.5f * t * t - 0.5f * kLog2Pi - flog(sp);
     }
@@ -732,8 +733,8 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
   } else {                                        // B2: reverse of the two heads, per (row, latent dim)
     const int l = ct * 16 + ec;
     if (rok && l < L) {
-      const float rawq = pf[0] + a.c, eq = fexp(-fabsf(rawq)), rq = __builtin_amdgcn_rcpf(1.f + eq);
-      const float spq = fmaxf(rawq, 0.f) - flog(rq), sg = fmaxf(spq, a.smin);     // softplus, and rq / eq rq = its derivative
+      float sgq;                                  // sigmoid(raw_q + c): softplus' derivative
+      const float rawq = pf[0] + a.c, spq = softplus_sig(rawq, sgq), sg = fmaxf(spq, a.smin);
       const float zz = pf[1];
       if (a.model == 1) {                         // learned mixture prior: z_head_bwd (kernels.hpp) takes it from here
         st1o(a.dz + (long long)row * L + l, v[0]);
@@ -741,19 +742,19 @@ __global__ __launch_bounds__(kSkThreads) void sk_gemm(const SkArgs a) {
         const float dmu = v[0] + zz;
         const float dsg = dmu * pf[4] - __builtin_amdgcn_rcpf(sg);
         st1o(a.dqp + (long long)row * 2 * L + l, dmu);
-        st1o(a.dqp + (long long)row * 2 * L + L + l, (spq > a.smin) ? dsg * (rawq >= 0.f ? rq : eq * rq) : 0.f);
+        st1o(a.dqp + (long long)row * 2 * L + L + l, (spq > a.smin) ? dsg * sgq : 0.f);
       } else {
-      const float mp = pf[2], rawp = pf[3] + a.c, ep = fexp(-fabsf(rawp)), rp = __builtin_amdgcn_rcpf(1.f + ep);
-      const float spp = fmaxf(rawp, 0.f) - flog(rp), sp = fmaxf(spp, a.smin);
+      float sgp;
+      const float mp = pf[2], rawp = pf[3] + a.c, spp = softplus_sig(rawp, sgp), sp = fmaxf(spp, a.smin);
       const float isp = __builtin_amdgcn_rcpf(sp);
       const float t = (zz - mp) * isp;
       const float pterm = t * isp;
       const float dmu = v[0] + pterm;
       const float dsg = dmu * pf[4] - __builtin_amdgcn_rcpf(sg);
       st1o(a.dqp + (long long)row * 2 * L + l, dmu);
-      st1o(a.dqp + (long long)row * 2 * L + L + l, (spq > a.smin) ? dsg * (rawq >= 0.f ? rq : eq * rq) : 0.f);
+      st1o(a.dqp + (long long)row * 2 * L + L + l, (spq > a.smin) ? dsg * sgq : 0.f);
       st1o(a.dpp + (long long)row * 2 * L + l, -pterm);
-      st1o(a.dpp + (long long)row * 2 * L + L + l, (spp > a.smin) ? (1.f - t * t) * isp * (rawp >= 0.f ? rp : ep * rp) : 0.f);
+      st1o(a.dpp + (long long)row * 2 * L + L + l, (spp > a.smin) ? (1.f - t * t) * isp * sgp : 0.f);
       }
     }
   }
@@ -886,13 +887,16 @@ __global__ __launch_bounds__(256) void sk_ypath(const SkArgs a) {
     const float uu = kv ? (a.gen_u ? ush[lane] : u_ext) : 0.5f;
     // (hardware log / exp forms as mega2.hpp S2; lanes 0..15 hold the row: DPP row reductions)
     const float av = kv ? (lg - flog(-flog(uu))) * a.invT : -INFINITY;
-    const float mx = row16_max(av), m2 = row16_max(lg);
-    const float se = row16_sum(kv ? fexp(av - mx) : 0.f), s2 = row16_sum(kv ? fexp(lg - m2) : 0.f);
-    const float lse = mx + flog(se), l2 = m2 + flog(s2);
+    const float mx = row16_max(av);
+    const float se = row16_sum(kv ? fexp(av - mx) : 0.f);
+    const float lse = mx + flog(se);
+    const float lga[1] = {lg};
+    float lpa[1];
+    cat_log_softmax<Row16, 1>(lga, lpa);           // log pi (gemm.hpp: accurate for a saturated q(y|x))
     float yv = 0.f, ne = 0.f;
     if (kv) {
       yv = fexp(av - lse);
-      const float lp = lg - l2;
+      const float lp = lpa[0];
       ne = fexp(lp) * lp;
       st1o(a.logits + (long long)row * K + lane, lg);
     }
@@ -978,14 +982,14 @@ __global__ __launch_bounds__(256) void sk_ybwd(const SkArgs a) {
     const bool kv = lane < K;
     const float lg = kv ? lg_ : -INFINITY;
     const float yv = kv ? yv_ : 0.f;
-    const float m2 = row16_max(lg);
-    const float s2 = row16_sum(kv ? fexp(lg - m2) : 0.f);
-    const float l2 = m2 + flog(s2);
-    const float dot = row16_sum(kv ? yv * dy : 0.f);
+    const float lga[1] = {lg}, ya[1] = {yv}, dya[1] = {kv ? dy : 0.f};
+    float lpa[1], daa[1];
+    cat_log_softmax<Row16, 1>(lga, lpa);           // (gemm.hpp: the forms that survive a saturated softmax)
+    cat_softmax_bwd<Row16, 1>(ya, dya, daa);
     float dl = 0.f;
     if (kv) {
-      const float lp = lg - l2;
-      dl = yv * (dy - dot) * a.invT + fexp(lp) * (lp - ne);
+      const float lp = lpa[0];
+      dl = daa[0] * a.invT + fexp(lp) * (lp - ne);
     }
     if (lane < a.K4) st1o(a.dlogits + (long long)row * a.K4 + lane, dl);      // padding columns zero
     if (lane < 16) dls[lane] = dl;
@@ -1122,13 +1126,16 @@ __global__ __launch_bounds__(256) void sk_ypath_r(const SkArgs a) {
     const float lg = kv ? ptot + b1v : -INFINITY;
     const float uu = kv && rv ? (a.gen_u ? ush[sj * 16 + sk] : u_ext) : 0.5f;
     const float av = kv ? (lg - flog(-flog(uu))) * a.invT : -INFINITY;
-    const float mx = row16_max(av), m2 = row16_max(lg);
-    const float se = row16_sum(kv ? fexp(av - mx) : 0.f), s2 = row16_sum(kv ? fexp(lg - m2) : 0.f);
-    const float lse = mx + flog(se), l2 = m2 + flog(s2);
+    const float mx = row16_max(av);
+    const float se = row16_sum(kv ? fexp(av - mx) : 0.f);
+    const float lse = mx + flog(se);
+    const float lga[1] = {lg};
+    float lpa[1];
+    cat_log_softmax<Row16, 1>(lga, lpa);           // log pi (gemm.hpp: accurate for a saturated q(y|x))
     float yv = 0.f, ne = 0.f;
     if (kv) {
       yv = fexp(av - lse);
-      const float lp = lg - l2;
+      const float lp = lpa[0];
       ne = fexp(lp) * lp;
       if (rv) st1o(a.logits + srow * K + sk, lg);
     }
@@ -1226,14 +1233,14 @@ __global__ __launch_bounds__(256) void sk_ybwd_r(const SkArgs a) {
     const bool kv = sk < K;
     const float lg = kv ? lg_ : -INFINITY;
     const float yv = kv ? yv_ : 0.f;
-    const float m2 = row16_max(lg);
-    const float s2 = row16_sum(kv ? fexp(lg - m2) : 0.f);
-    const float l2 = m2 + flog(s2);
-    const float dot = row16_sum(kv ? yv * dy : 0.f);
+    const float lga[1] = {lg}, ya[1] = {yv}, dya[1] = {kv ? dy : 0.f};
+    float lpa[1], daa[1];
+    cat_log_softmax<Row16, 1>(lga, lpa);           // (gemm.hpp: the forms that survive a saturated softmax)
+    cat_softmax_bwd<Row16, 1>(ya, dya, daa);
     float dl = 0.f;
     if (kv) {
-      const float lp = lg - l2;
-      dl = yv * (dy - dot) * a.invT + fexp(lp) * (lp - ne);
+      const float lp = lpa[0];
+      dl = daa[0] * a.invT + fexp(lp) * (lp - ne);
     }
     if (rv && sk < a.K4) st1o(a.dlogits + srow * a.K4 + sk, dl);      // padding columns zero
     dls[sj * 16 + sk] = dl;

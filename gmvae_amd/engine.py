@@ -580,7 +580,7 @@ class Engine:
 
     def profile_forward(self, x, n_samples: Optional[int] = None, iters: int = 20):
         """gmvae_forward_profile: the forward-only evaluation (in-kernel Philox noise) at n_samples importance samples.
-        Returns ([(launch, usec, flops)], usec per forward of a replayed hipGraph)."""
+        Returns ([(launch, usec, flops)], usec per forward of a replayed hipGraph, the pass's [TAIL] loss sums)."""
         x = self._prep_x(x)
         S = self.S if n_samples is None else int(n_samples)
         d, ws = self._workspace(x.shape[0], S)

@@ -104,6 +104,15 @@ def test_initializers_and_device_flags_are_checked_on_the_host(monkeypatch):
         base.ConditionalNormal(4, [8], hidden_activation_fn=ok)
     with pytest.raises(NotImplementedError):
         base.ConditionalNormal(4, [8], hidden_activation_fn=torch.sin)
+
+    def elu(x, alpha=0.3):                       # a user function that merely SHARES a name with an implemented kind
+        return torch.where(x > 0, x, alpha * torch.expm1(x))
+    with pytest.raises(NotImplementedError):
+        base.ConditionalNormal(4, [8], hidden_activation_fn=elu)
+    # a conditional bound to an Engine created with another activation would silently evaluate with the engine's
+    with pytest.raises(ValueError):
+        base.ConditionalNormal(4, [8], hidden_activation_fn=torch.tanh).bind(SimpleNamespace(hidden_act="relu"), 0)
+    base.ConditionalNormal(4, None, hidden_activation_fn=torch.tanh).bind(SimpleNamespace(hidden_act="relu"), 0)   # no hidden layer: nothing to apply
     monkeypatch.delenv("LOCAL_RANK", raising=False)
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
     sel = runners.select_device

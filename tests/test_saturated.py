@@ -1,0 +1,287 @@
+"""-m gpu: every fast path OUTSIDE the Xavier regime, against the fp64 oracle.
+
+The per-row chains of the one-launch / skinny / chain kernels take their transcendentals as the bare hardware forms
+(v_exp_f32 / v_log_f32 / v_rcp_f32: csrc/gemm.hpp flog / fexp / softplus_sig).  The other parity files initialise Xavier weights
+and N(0, 0.05) biases, i.e. logits of O(1) and sigma ~ 1.  Here the same kernels run where a TRAINED model lives and beyond:
+  * decoder logits up to |lambda| ~ 60 (a trained MNIST decoder saturates its background pixels), y logits of +-15;
+  * raw_sigma spanning [-8, 8] and [-20, 20] per latent dimension in the q head and the prior head (sigma from 2e-9 to 20;
+    scripts/base.py:70 `tf.maximum(tf.nn.softplus(raw + bias), sigma_min)`), mixture-prior scales likewise;
+  * the factories' own hyper-parameter defaults sigma_min = 0.001, raw_sigma_bias = 0.25 (scripts/vae.py:197-198,
+    scripts/gmvae.py:283-286: the runner overrides them with 0.0 / 0.5, a user of create_gmvae() gets these);
+  * the uniform stream's two extreme values, u = tiny and u = 1 - 2^-24 (Gumbel noise -4.47 and +16.6): injected
+    where a path takes external noise, and REACHED THROUGH THE BATCH'S ROW OFFSET where the kernel draws its own Philox stream
+    (tools/find_extreme_u.py found the global rows; the oracle's restatement of the stream is asserted to hold the value);
+  * parameters after 304 training steps on structured pixels from DeviceDataset.
+Gates: the step's own (ELBO 1e-4 relative, each term relative to itself, every gradient tensor 1e-4 of its max) against
+oracle.loss_and_grads at the device's own parameters, on the noise the device drew."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+LR = 1e-3
+U_MAX = float(np.nextafter(np.float32(1), np.float32(0)))      # 1 - 2^-24: the largest value of the uniform stream
+# tools/find_extreme_u.py 11 0 23: global rows of the in-kernel uniform stream (seed 11, step 0, K = 10) that hold its extremes
+SEED = 11
+ROW_TINY, K_TINY = 396610, 9
+ROW_MAX, K_MAX = 261784, 3
+
+
+def saturate(model, d, p, rng, x, lam=60.0, span=8.0, logit=15.0):
+    """Xavier parameters pushed where a trained model (and a diverging one) lives: raw_sigma biases of the q head and the prior
+    head spread over [-span, span] per latent dimension, encoder_y's logits scaled to +-logit, the decoder's output layer scaled
+    so that the largest |lambda| on this batch is `lam` (measured with the fp64 oracle on standard noise)."""
+    nl = len(d.hidden)
+    p = {k: np.array(v, np.float64) for k, v in p.items()}
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    raws = lambda: rng.permutation(np.linspace(-span, span, d.L))
+    enc = "encoder_gmm" if model == O.MODEL_GMVAE else "encoder"
+    p[f"{enc}_fcnet/linear_{nl}/b"][d.L:] = raws() - d.raw_sigma_bias
+    if model == O.MODEL_GMVAE:
+        p["prior_gmm_fcnet/linear_0/b"][d.L:] = raws() - d.raw_sigma_bias
+        p[f"encoder_y_fcnet/linear_{nl}/w"] *= logit / 1.5
+    if model == O.MODEL_VAE_GMP:
+        p["raw_scale_diag"] = np.stack([raws() for _ in range(d.K)])
+        p["mixture_logits"] = rng.normal(0, 4.0, d.K)
+        p["loc"] = rng.normal(0, 2.0, (d.K, d.L))
+    B = x.shape[0]
+    rn = np.random.default_rng(1)
+    eps = rn.standard_normal((B * d.S, d.L))
+    u = rn.uniform(1e-6, 1 - 1e-6, (B * d.S, d.K))
+    m = np.abs(O.forward(model, d, p, x, eps, u if model == O.MODEL_GMVAE else None)["lam"]).max()
+    for s in ("w", "b"):
+        p[f"decoder_fcnet/linear_{nl}/{s}"] *= lam / m
+    return p
+
+
+def _check_terms(got, Cc, B, tag):
+    loss, nll, kl, nent = (got[i] / B for i in range(4))
+    assert got[4] == B, tag
+    assert np.isfinite(got[:4]).all(), (tag, got[:5])
+    assert abs(loss - Cc["loss"]) <= 1e-4 * abs(Cc["loss"]), (tag, loss, Cc["loss"])
+    assert abs(nll - Cc["nll"]) <= 1e-4 * abs(Cc["nll"]), (tag, nll, Cc["nll"])
+    assert abs(kl - Cc["kl"]) <= 1e-4 * max(abs(Cc["kl"]), 1.0), (tag, kl, Cc["kl"])
+    assert abs(nent - Cc["nent"]) <= 1e-4 * max(abs(Cc["nent"]), 1.0), (tag, nent, Cc["nent"])
+
+
+def _grad_errs(model, d, gs, g, B):
+    lay, _, _ = O.param_layout(model, d)
+    out = []
+    for name, shape, off in lay:
+        n = int(np.prod(shape))
+        ref = np.asarray(g[name]).ravel()
+        out.append((name, np.abs(gs[off:off + n] / B - ref).max() / max(np.abs(ref).max(), 1e-6)))
+    return out
+
+
+def graph_step_case(model, D, Lz, K, hidden, B, launches, row=None, k_of_row=None, want=None, span=8.0, lam=60.0, hp=None,
+                    params=None, step0=0, seed=SEED, x=None):
+    """ONE step of a one-step train graph (the kernels bench.py times: in-kernel Philox noise, TF-Adam inside) at saturated
+    parameters, against oracle.loss_and_grads at the same parameters on the noise the device drew.  `row`: a global row of the
+    uniform stream that must lie inside the batch (the engine's row offset is set to the multiple of B below it)."""
+    import hip_util as H
+    from test_timed_path import _device_masks, _noise
+    from gmvae_amd import _lib as L
+    from gmvae_amd.engine import Engine
+    mid = O.MODEL_NAMES[model]
+    hp = hp or {}
+    d = O.Dims(D=D, L=Lz, K=K, hidden=hidden, **hp)
+    e = Engine(model, D, Lz, K, list(hidden), random_seed=seed, **hp)
+    rng = np.random.default_rng(B + Lz)
+    if x is None:
+        x = (rng.random((B, D)) < 0.87).astype(np.uint8)
+    if params is None:
+        p0 = O.unpack(mid, d, e.params.detach().cpu().numpy().astype(np.float64))
+        flat = O.pack(mid, d, saturate(mid, d, p0, rng, x, lam=lam, span=span), np.float32)
+    else:
+        flat = params
+    with torch.no_grad():
+        e.params.copy_(torch.from_numpy(flat).cuda())
+    if row is not None:
+        e.rank = row // B                                   # GmvaeDims.row0 = rank * B: the Philox counters hold the global row
+    e.global_step = step0
+    e.step_dev.fill_(step0)
+    row0 = e.rank * B
+    eps, u = _noise(L, B * d.S, d.L, d.K, row0 * d.S, e.noise_seed, step0, mid == O.MODEL_GMVAE)
+    if row is not None:
+        assert u[row - row0, k_of_row] == want, (u[row - row0], want)
+        eo, uo = O.noise(B, d.L, d.K, row0, e.noise_seed, step0)
+        assert np.array_equal(uo, u)                        # the CPU restatement of the stream holds the same extreme
+    sx, replay = e.capture_train_step(B, lr=LR, n_steps=1)
+    sx.copy_(torch.from_numpy(x).cuda())
+    replay()
+    torch.cuda.synchronize()
+    assert e.handoff_timeouts() == 0
+    got = e.grads.cpu().numpy().astype(np.float64)
+    masks = _device_masks(e, mid, d, B)
+    tag = f"{model}-L{Lz}-H{hidden[0]}-B{B}-span{span}-{hp}"
+    p32 = O.unpack(mid, d, flat.astype(np.float64))
+    Cc, g = O.loss_and_grads(mid, d, p32, x, eps, u, np.float64)
+    _check_terms(got[e.P:], Cc, B, tag)
+    errs = _grad_errs(mid, d, got, g, B)
+    if max(err for _, err in errs) > 1e-4 and H.check_masks(masks, Cc["pre"], tag):
+        _, g = O.loss_and_grads(mid, d, p32, x, eps, u, np.float64, relu_masks=masks)
+        errs = _grad_errs(mid, d, got, g, B)
+    for name, err in errs:
+        assert err <= 1e-4, f"{tag} {name}: rel-to-max err {err:.3e}"
+    assert torch.isfinite(e.params).all()
+    if launches is not None:
+        names = [nm for nm, *_ in e.profile_train_levels(torch.from_numpy(x).cuda(), lr=LR, iters=2)]
+        assert names == launches, names
+    return Cc, max(err for _, err in errs)
+
+
+M3 = ["mega3_step"]
+M2 = ["mega2_fwd_bwd", "dw_adam"]
+M3V = ["mega3v_step"]
+FACTORY = dict(sigma_min=0.001, raw_sigma_bias=0.25)        # scripts/vae.py:197-198, scripts/gmvae.py:283-286
+
+
+@pytest.mark.parametrize("span,hp,row", [(8.0, None, ("tiny",)), (8.0, None, ("max",)), (20.0, None, None), (8.0, FACTORY, None),
+                                         (20.0, FACTORY, ("tiny",))], ids=["span8-u_tiny", "span8-u_max", "span20", "factory", "factory-span20-u_tiny"])
+def test_mega3_step_saturated(span, hp, row):
+    r = None if row is None else ((ROW_TINY, K_TINY, O.TINY_F32) if row[0] == "tiny" else (ROW_MAX, K_MAX, U_MAX))
+    kw = {} if r is None else dict(row=r[0], k_of_row=r[1], want=np.float32(r[2]))
+    graph_step_case("gmvae", 784, 64, 10, (64,), 1024, M3, span=span, hp=hp, **kw)
+
+
+@pytest.mark.parametrize("span,hp,row", [(8.0, None, ("tiny",)), (20.0, FACTORY, ("max",))], ids=["span8-u_tiny", "factory-span20-u_max"])
+def test_mega2_two_launch_step_saturated(span, hp, row):
+    r = (ROW_TINY, K_TINY, O.TINY_F32) if row[0] == "tiny" else (ROW_MAX, K_MAX, U_MAX)
+    graph_step_case("gmvae", 784, 64, 10, (64,), 512, M2, span=span, hp=hp, row=r[0], k_of_row=r[1], want=np.float32(r[2]))
+
+
+@pytest.mark.parametrize("model,Lz,K,B", [("vae", 2, 1, 100), ("vae_gmp", 64, 10, 256)])
+@pytest.mark.parametrize("span,hp", [(8.0, None), (20.0, None), (8.0, FACTORY)], ids=["span8", "span20", "factory"])
+def test_mega3v_step_saturated(model, Lz, K, B, span, hp):
+    graph_step_case(model, 784, Lz, K, (64,), B, M3V, span=span, hp=hp)
+
+
+SK_G = ["sk_first_layers", "sk_y_path", "sk_q_head_z", "sk_dec_hidden", "sk_dec_bernoulli", "sk_bwd_dhd", "sk_bwd_dz_heads",
+        "sk_bwd_dhg", "sk_y_path_bwd", "sk_dw_adam"]
+
+
+@pytest.mark.parametrize("Lz,B,span,hp,row", [(128, 64, 8.0, None, "tiny"), (128, 64, 20.0, FACTORY, "max"), (64, 1024, 8.0, None, "max"),
+                                              (64, 1024, 20.0, FACTORY, "tiny")])
+def test_skinny_step_saturated(Lz, B, span, hp, row):
+    """bin/run_train.sh sizes (H = 512, latent 128, batch 64) and BASELINE configs[2] at H = 512."""
+    from gmvae_amd import _lib as L
+    import hip_util as H
+    r = (ROW_TINY, K_TINY, O.TINY_F32) if row == "tiny" else (ROW_MAX, K_MAX, U_MAX)
+    d = O.Dims(D=784, L=Lz, K=10, hidden=(512,))
+    assert L.step_schedule(H.dims_of(d, B), O.MODEL_GMVAE) == "skinny"
+    graph_step_case("gmvae", 784, Lz, 10, (512,), B, None, span=span, hp=hp, row=r[0], k_of_row=r[1], want=np.float32(r[2]))
+
+
+# ------------------------------------------------------------------ external noise: gmvae_step in every schedule, both extremes injected
+EAGER = [
+    ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,)), 1024, "mega2"),
+    ("gmvae", O.Dims(D=784, L=16, K=10, hidden=(64,)), 96, "mega"),
+    ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(64,)), 256, "mega2v"),
+    ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,)), 64, "skinny"),
+    ("vae", O.Dims(D=784, L=32, K=1, hidden=(256,)), 200, "skinny"),
+    ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(512,)), 256, "skinny"),
+    ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(48,), gen_bias_init=np.linspace(-3, 3, 784)), 128, "fused"),   # the chain kernels
+    ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,), gen_bias_init=np.linspace(-3, 3, 784)), 128, "skinny"),
+    ("gmvae", O.Dims(D=300, L=24, K=7, hidden=(96, 40), S=3), 48, "general"),
+    ("vae_gmp", O.Dims(D=256, L=30, K=16, hidden=(128,), S=2), 64, "general"),
+]
+
+
+@pytest.mark.parametrize("span", [8.0, 20.0])
+@pytest.mark.parametrize("factory", [False, True], ids=["runner-hp", "factory-hp"])
+@pytest.mark.parametrize("name,d,B,sched", EAGER, ids=[f"{n}-{s}-L{d.L}-H{d.hidden[0]}-B{B}" for n, d, B, s in EAGER])
+def test_eager_step_saturated(name, d, B, sched, factory, span):
+    import dataclasses
+    import hip_util as H
+    from gmvae_amd import _lib as L
+    model = O.MODEL_NAMES[name]
+    if factory:
+        d = dataclasses.replace(d, **FACTORY)
+    assert L.step_schedule(H.dims_of(d, B), model) == sched
+    rng = np.random.default_rng(B + d.L)
+    x, eps, u = O.make_inputs(d, B, model)
+    p = saturate(model, d, O.init_params(model, d, rng), rng, x, span=span)
+    if u is not None:
+        u[0, 0], u[1, d.K - 1], u[2, :] = O.TINY_F32, U_MAX, U_MAX
+        u[3, :] = O.TINY_F32
+        u[B * d.S - 1, 1] = O.TINY_F32
+    H.compare_step(model, d, p, x, eps, u)
+
+
+FWD = [("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,), S=50), 256, True),      # R = 12,800: the logits GEMM on f16 pairs
+       ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(64,), S=40), 256, True),
+       ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,)), 512, False),           # S = 1: the chain kernels
+       ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,), S=5), 64, False)]
+
+
+@pytest.mark.parametrize("span", [8.0, 20.0])
+@pytest.mark.parametrize("name,d,B,pairs", FWD, ids=[f"{n}-L{d.L}-H{d.hidden[0]}-S{d.S}-B{B}" for n, d, B, _ in FWD])
+def test_forward_only_saturated(name, d, B, pairs, span, monkeypatch):
+    """gmvae_forward (scripts/runners.py:324-333 reuses run_model for the evaluation bound) at saturated parameters: every row's
+    log p(x|z), log w, z and the IWAE bound against the fp64 oracle -- and the f16-pair logits GEMM really ran where claimed."""
+    import hip_util as H
+    model = O.MODEL_NAMES[name]
+    rng = np.random.default_rng(B + d.S)
+    x, eps, u = O.make_inputs(d, B, model)
+    p = saturate(model, d, O.init_params(model, d, rng), rng, x, span=span)
+    if u is not None:
+        u[0, 0], u[1, d.K - 1], u[2, :], u[3, :] = O.TINY_F32, U_MAX, U_MAX, O.TINY_F32
+    flat = O.pack(model, d, p, np.float32)
+    Cc = O.forward(model, d, O.unpack(model, d, flat.astype(np.float64)), x, eps, u)
+    tail, rows, z, y, lg = H.hip_forward(model, d, flat, x, eps, u)
+    np.testing.assert_allclose(z, Cc["z"], rtol=1e-4, atol=1e-4)
+    if model == O.MODEL_GMVAE:
+        np.testing.assert_allclose(y, Cc["y"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(rows[:, 0], Cc["logpx"], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(rows[:, 3], Cc["logw"], rtol=1e-5, atol=1e-3)
+    assert abs(tail[0] / B - Cc["loss"]) <= 1e-5 * abs(Cc["loss"])
+    if pairs:
+        monkeypatch.setenv("GMVAE_NO_PLANES", "1")
+        rows32 = H.hip_forward(model, d, flat, x, eps, u)[1]
+        assert not np.array_equal(rows[:, 0], rows32[:, 0])
+
+
+def _structured_pixels(n, D, rng):
+    """MNIST-like rows: ten smooth prototypes of mostly-saturated pixels (0 / 255), 4 % of the pixels flipped, grey edges."""
+    side = int(np.sqrt(D))
+    f = rng.normal(size=(10, side + 6, side + 6))
+    for _ in range(3):
+        f = (f + np.roll(f, 1, 1) + np.roll(f, -1, 1) + np.roll(f, 1, 2) + np.roll(f, -1, 2)) / 5
+    proto = np.clip((f[:, 3:-3, 3:-3] - 0.02) * 4000 + 128, 0, 255).reshape(10, -1)[:, :D]
+    lab = rng.integers(0, 10, n)
+    pix = proto[lab]
+    flip = rng.random(pix.shape) < 0.04
+    return np.where(flip, 255 - pix, pix).astype(np.uint8), lab
+
+
+@pytest.mark.parametrize("model,Lz,K,H_,B,launches", [("gmvae", 64, 10, 64, 1024, M3), ("vae_gmp", 64, 10, 64, 256, M3V),
+                                                       ("vae", 2, 1, 64, 100, M3V), ("gmvae", 128, 10, 512, 64, None)])
+def test_step_after_300_training_steps_on_structured_pixels(model, Lz, K, H_, B, launches):
+    """304 steps of the pipeline graph (binarisation inside, scripts/runners.py:44-47) at lr = 3e-3 on structured pixels, then
+    ONE more step of the timed kernels at the parameters training arrived at, against the oracle at those parameters."""
+    from gmvae_amd.data import DeviceDataset
+    from gmvae_amd.engine import Engine
+    rng = np.random.default_rng(7)
+    pix, _ = _structured_pixels(8192, 784, rng)
+    ds = DeviceDataset(pix, shuffle=True, seed=3)
+    e = Engine(model, 784, Lz, K, [H_], random_seed=5)
+    replay = e.capture_train_pipeline(ds, B, lr=3e-3, n_steps=16)
+    for _ in range(19):
+        replay()
+    torch.cuda.synchronize()
+    assert e.handoff_timeouts() == 0 and e.global_step == 304
+    tl = replay.tail_log.cpu().numpy()
+    assert np.isfinite(tl).all()
+    flat = e.params.detach().cpu().numpy().copy()
+    assert np.isfinite(flat).all()
+    xb = (pix[:B].astype(np.float32) / 255.0 < rng.random((B, 784), dtype=np.float32)).astype(np.uint8)    # runners.py:45-46
+    Cc, _ = graph_step_case(model, 784, Lz, K, (H_,), B, launches, params=flat, step0=304, seed=5, x=xb)
+    print(f"\n[trained] {model} H={H_} B={B}: loss {tl[0, 0] / B:.1f} -> {tl[-1, 0] / B:.1f}; max |lambda| {np.abs(Cc['lam']).max():.1f}, "
+          f"sigma_q in [{Cc['sig_q'].min():.2e}, {Cc['sig_q'].max():.2e}]")

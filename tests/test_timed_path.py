@@ -541,3 +541,43 @@ def test_trajectory_parameters_within_the_measured_gradient_error():
     E = _session_grad_err()
     bad = [(tag, g[E]) for tag, _, g in PARAM_STATS if g[E][0] > 1.0 or g[E][1] < 0.5]
     assert not bad, f"at the measured gradient error (grid {E:.0e}): {bad[:5]}"
+
+
+@pytest.mark.parametrize("model,Lz,K,B,pnl,name", [("gmvae", 64, 10, 1024, 63, "mega3_step"), ("gmvae", 64, 10, 1024, 0, "mega3_step"),
+                                                   ("vae_gmp", 64, 10, 256, 5, "mega3v_step"), ("vae", 2, 1, 100, 6, "mega3v_step")])
+def test_one_launch_step_is_all_or_nothing_when_a_lead_gives_up_mid_launch(model, Lz, K, B, pnl, name, monkeypatch):
+    """A hand-off that gives up DURING a one-launch step (GMVAE_DEBUG_LEAD_FAULT: one panel's lead sets the error word in front
+    of its flag, i.e. after the producers' flags are out and phase P of the tiles has started): the step must not be applied
+    anywhere -- parameters, both Adam moments bit-unchanged, NaN loss, the explicit flag raised -- which is what run_train's
+    recovery (rewind, safe schedule) relies on (gmvae_amd/runners.py; the two-launch form had the error word final before
+    dw_adam started).  Before round 6 the phase-P tiles applied TF-Adam behind the producers' flags alone and the tail slot
+    published a finite loss."""
+    from gmvae_amd.engine import Engine
+    rng = np.random.default_rng(B)
+    xs = torch.from_numpy((rng.random((B, 784)) < 0.87).astype(np.uint8)).cuda()
+    e = Engine(model, 784, Lz, K, [64], random_seed=5)
+    sx, replay = e.capture_train_step(B, LR, n_steps=1)
+    sx.copy_(xs)
+    for _ in range(3):
+        replay()
+    torch.cuda.synchronize()
+    assert e.handoff_timeouts() == 0 and np.isfinite(replay.tail_log.cpu().numpy()).all()
+    p0, m0, v0 = e.params.detach().clone(), e.m.clone(), e.v.clone()
+    monkeypatch.setenv("GMVAE_DEBUG_LEAD_FAULT", str(pnl))
+    e.drop_graphs()
+    sx, replay = e.capture_train_step(B, LR, n_steps=1)
+    sx.copy_(xs)
+    replay()
+    torch.cuda.synchronize()
+    assert [nm for nm, *_ in e.profile_train_levels(xs, lr=LR, iters=1)] == [name]
+    assert e.handoff_timeouts() == 1
+    assert torch.isnan(replay.tail_log[0, 0])
+    assert torch.equal(e.params, p0) and torch.equal(e.m, m0) and torch.equal(e.v, v0)
+    # the same engine, fault removed: the next step applies
+    monkeypatch.delenv("GMVAE_DEBUG_LEAD_FAULT")
+    e.drop_graphs()
+    sx, replay = e.capture_train_step(B, LR, n_steps=1)
+    sx.copy_(xs)
+    replay()
+    torch.cuda.synchronize()
+    assert e.handoff_timeouts() == 0 and torch.isfinite(replay.tail_log[0, 0]) and not torch.equal(e.params, p0)
