@@ -2681,6 +2681,8 @@ int gmvae_train_profile(const GmvaeDims* dims, int model, const uint8_t* x, floa
                     seed, 0, step_dev, true};
       a.adam_p = params; a.adam_m = m; a.adam_v = v; a.lr = lr; a.imgs_ready = it > 0; a.want_spans = it > 0;
       a.span_slot = it == 2 ? 1 : 0;
+      // (diagnostic: every stamped step starts with cold instruction caches -- kernels.hpp icache_flush, tools/icache_cold.py)
+      if (it > 0 && getenv("GMVAE_ICACHE_FLUSH")) hipLaunchKernelGGL(icache_flush, dim3(2 * device_cus()), dim3(64), 0, s, w.spans ? reinterpret_cast<float*>(w.gstamps) : nullptr);
       rc = run_step(cx, a);
     }
   };

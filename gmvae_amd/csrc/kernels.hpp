@@ -22,6 +22,16 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // eps ~ N(0,1) (Box-Muller), u ~ U[tiny,1).  One thread -> 4 values (aux.hpp: noise_item).
+// Diagnostic (GMVAE_ICACHE_FLUSH=1 in gmvae_train_profile, tools/icache_cold.py): ~100 KB of straight-line code -- 12,288
+// fused multiply-adds with distinct 32-bit literals -- run by one wave on every CU, so that the launch that follows starts with
+// COLD instruction caches (64 KB shared by two CUs).  The difference of the following launch's in-kernel span with and without it
+// is what a complete refetch of its code costs: the yardstick for the handful of misses a warm launch takes.
+__global__ __launch_bounds__(64) void icache_flush(float* sink) {
+  float x = (float)threadIdx.x * 1e-3f;
+#pragma unroll
+  for (int i = 0; i < 12288; ++i) x = fmaf(x, 1.0f + (float)(i + 1) * 1.1920929e-7f, 0.25f);
+  if (x == 12345.678f) sink[blockIdx.x] = x;       // (never true: keeps the chain alive)
+}
 __global__ void noise_fill(float* eps, float* u, uint64_t rows, int L, int K, uint64_t row_base, uint64_t seed, uint64_t step,
                            const uint64_t* step_dev) {
   if (step_dev) step = *step_dev;
