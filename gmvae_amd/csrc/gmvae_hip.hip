@@ -26,6 +26,7 @@
 #include "dwadam.hpp"
 #include "mega3.hpp"
 #include "skinny.hpp"
+#include "evalf.hpp"
 
 using namespace gmvae;
 
@@ -187,6 +188,9 @@ struct WS {
   unsigned short *hd3, *g3, *w3;   // general schedule, large top decoder layer: planes of 16-bit pieces (gemm.hpp plane_rounds) of its
                                    // input activation [3][R][H], of (sigmoid - x) [3][R][D] and of its weight [3][H][D]
   int32_t* cl_pred;
+  unsigned long long* ev_dbg;           // ... its diagnostic stamps [1024][16]
+  float *ev_img, *ev_rows, *ev_slots;   // evalf.hpp (forward-only evaluation at the reference's default sizes): operand images, [R][4] row terms,
+                                        // per-workgroup sums [1024][4] + the arrival counter
   uint64_t bytes;
 };
 
@@ -280,6 +284,17 @@ static bool fused_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_FUSED");
   if (e && atoi(e)) return false;
   return fused_shape(d, model);
+}
+
+// evalf_rows (evalf.hpp): the forward-only pass of the GMVAE at the reference's default sizes, any batch, any number of samples
+static bool evalf_shape(const GmvaeDims& d, int model) {
+  return model == GMVAE_MODEL_GMVAE && d.n_hidden == 1 && d.hidden[0] == EV::H && d.L == EV::L && d.K == EV::K && d.D == EV::D &&
+         d.hidden_act == GMVAE_ACT_RELU && !d.gen_bias_vec;
+}
+static bool evalf_ok(const GmvaeDims& d, int model) {
+  const char* e = getenv("GMVAE_NO_EVALF");
+  if (e && atoi(e)) return false;
+  return evalf_shape(d, model);
 }
 
 static int num_splits(long long R) {
@@ -442,6 +457,12 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
       const uint64_t units = ((R + 15) / 16) * ((Ht + 63) / 64);        // (or kAmaxBlocks partials when amax_abs reduces h)
       w.pscale_f = take(16 + kAmaxBlocks + (units > (uint64_t)kAmaxBlocks ? units : (uint64_t)kAmaxBlocks));
     }
+  }
+  if (evalf_shape(d, model)) {                   // (at the end: no earlier offset moves)
+    w.ev_img = take(EV::total);
+    w.ev_rows = take(R * 4);
+    w.ev_slots = take(4 * 1024 + 64);
+    w.ev_dbg = reinterpret_cast<unsigned long long*>(take(2ull * 1024 * 16));
   }
   w.bytes = off;
 }
@@ -1786,6 +1807,67 @@ static int run_step_skinny(Ctx& cx, const StepArgs& a, const Layout& L, WS& w, c
   return cx.err;
 }
 
+// Forward-only evaluation at the reference's default sizes (evalf.hpp): first layers -> operand images -> ONE launch for the whole
+// per-row chain, the Bernoulli term, the IWAE bound and the batch sums.  scripts/runners.py:324-333.
+static int run_eval_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w) {
+  const GmvaeDims& d = *a.d;
+  const int B = d.B, S = d.S, D = d.D;
+  const float* P = a.params;
+  hipStream_t st = cx.st;
+  const NetL &E = L.ency, &G = L.encg, &Dn = L.dec;
+  {
+    FlxArgs f;
+    f.x = a.x; f.W0 = P + E.w[0]; f.b0 = P + E.b[0]; f.out0 = w.he[1]; f.H0 = EV::H; f.relu0 = 1;
+    f.W1 = P + G.w[0]; f.out1 = w.gx; f.H1 = EV::H;
+    f.B = B; f.D = D;
+    const int nct = 2, nrt = (B + 15) / 16;
+    int rt = 4;
+    while (rt > 1 && nct * ((nrt + rt - 1) / rt) < 256) rt >>= 1;
+    const int grid = nct * ((nrt + rt - 1) / rt);
+    if (rt == 4) hipLaunchKernelGGL(first_layers_u8bf<4>, dim3(grid), dim3(kSkThreads), 0, st, f);
+    else if (rt == 2) hipLaunchKernelGGL(first_layers_u8bf<2>, dim3(grid), dim3(kSkThreads), 0, st, f);
+    else hipLaunchKernelGGL(first_layers_u8bf<1>, dim3(grid), dim3(kSkThreads), 0, st, f);
+    cx.check();
+    cx.mark("fwd_x_first_layers", 2.0 * B * D * 2 * EV::H);
+  }
+  unsigned* const counter = reinterpret_cast<unsigned*>(w.ev_slots + 4 * 1024);
+  {
+    EvalPrepArgs pa;
+    pa.Wp = P + L.prior.w[0]; pa.bp = P + L.prior.b[0]; pa.Wg0 = P + G.w[0]; pa.bg0 = P + G.b[0]; pa.Wg1 = P + G.w[1]; pa.bg1 = P + G.b[1];
+    pa.Wd0 = P + Dn.w[0]; pa.bd0 = P + Dn.b[0]; pa.Wd1 = P + Dn.w[1]; pa.bd1 = P + Dn.b[1];
+    pa.gen_bias = d.gen_bias_init; pa.img = w.ev_img; pa.counter = counter;
+    hipLaunchKernelGGL(evalf_prep, dim3((EV::total + 255) / 256), dim3(256), 0, st, pa);
+    cx.check();
+    cx.mark("evalf_prep", 0);
+  }
+  EvalArgs ea;
+  memset(&ea, 0, sizeof(ea));
+  ea.B = B; ea.S = S; ea.x = a.x; ea.he1 = w.he[1]; ea.gx = w.gx; ea.Wy1 = P + E.w[1]; ea.by1 = P + E.b[1]; ea.img = w.ev_img;
+  ea.eps = a.eps; ea.u = a.u; ea.seed = a.seed; ea.step = a.step; ea.row_base = (unsigned long long)d.row0 * S;
+  ea.c = d.raw_sigma_bias; ea.smin = d.sigma_min; ea.invT = 1.f / d.temperature;
+  ea.rows4 = a.row_terms; ea.z_out = a.z_out; ea.y_out = a.y_out; ea.logits_out = a.logits_out;
+  ea.rows_ws = a.row_terms ? a.row_terms : w.ev_rows;
+  ea.slots = w.ev_slots; ea.counter = counter; ea.tail = a.tail;
+  ea.dbg = getenv("GMVAE_EV_STAMPS") ? w.ev_dbg : nullptr;
+  static bool eattr[64];
+  if (first_on_device(eattr)) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(evalf_rows<0>), hipFuncAttributeMaxDynamicSharedMemorySize, EV::lds * (int)sizeof(float));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(evalf_rows<1>), hipFuncAttributeMaxDynamicSharedMemorySize, EV::lds * (int)sizeof(float));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(evalf_rows<2>), hipFuncAttributeMaxDynamicSharedMemorySize, EV::lds * (int)sizeof(float));
+  }
+  int grid = device_cus();
+  if (grid > B) grid = B;
+  if (grid > 1024) grid = 1024;
+  const int ev_mode = getenv("GMVAE_EV_MODE") ? atoi(getenv("GMVAE_EV_MODE")) : 0;      // (timing experiments: wrong results)
+  if (ev_mode == 1) hipLaunchKernelGGL(evalf_rows<1>, dim3(grid), dim3(kMT), (size_t)EV::lds * sizeof(float), st, ea);
+  else if (ev_mode == 2) hipLaunchKernelGGL(evalf_rows<2>, dim3(grid), dim3(kMT), (size_t)EV::lds * sizeof(float), st, ea);
+  else hipLaunchKernelGGL(evalf_rows<0>, dim3(grid), dim3(kMT), (size_t)EV::lds * sizeof(float), st, ea);
+  cx.check();
+  const double R = (double)B * S;
+  cx.mark("evalf_rows", 2.0 * B * EV::H * EV::K + 2.0 * R * (EV::K * (EV::H + EV::L2) + EV::H * EV::L2 + EV::L * EV::H + (double)EV::H * D));
+  return cx.err;
+}
+
 static int run_step(Ctx& cx, const StepArgs& a) {
   const GmvaeDims& d = *a.d;
   const int model = a.model;
@@ -1817,6 +1899,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   tl_hact = 1 + d.hidden_act;                  // (every Problem built below for this step: its epilogue's activation kind)
   if (a.backward && mega_ok(d, model)) return run_step_mega(cx, a, L, w, eps, u, ge, gu);
   if (a.backward && skinny_ok(d, model)) return run_step_skinny(cx, a, L, w, eps, u, ge, gu);
+  if (!a.backward && evalf_ok(d, model) && w.ev_img) return run_eval_fused(cx, a, L, w);
   if (fused_ok(d, model) && !a.z_out && !a.y_out && !a.logits_out)
     return run_step_fused(cx, a, L, w, eps, u, ge, gu);
   // (general schedule: the Philox fill rides as auxiliary workgroups of the first GEMM launch below)
@@ -2967,7 +3050,7 @@ int gmvae_workspace_offset(const GmvaeDims* dims, int model, const char* name, u
       {"dy", w.dy}, {"dlogits", w.dlogits}, {"dbuf0", w.dbuf[0]}, {"dbuf1", w.dbuf[1]}, {"dbuf2", w.dbuf[2]},
       {"slabs", w.slabs}, {"s1", w.s1}, {"s4", w.s4}, {"eps", w.eps}, {"u", w.u},
       {"stamps", reinterpret_cast<float*>(w.stamps)}, {"gstamps", reinterpret_cast<float*>(w.gstamps)},
-      {"sync", reinterpret_cast<float*>(w.sync)}};
+      {"sync", reinterpret_cast<float*>(w.sync)}, {"ev_dbg", reinterpret_cast<float*>(w.ev_dbg)}};
   for (auto& t : tab)
     if (!strcmp(t.n, name)) {
       if (!t.p) return GMVAE_E_NET;

@@ -215,17 +215,22 @@ def test_eager_step_saturated(name, d, B, sched, factory, span):
     H.compare_step(model, d, p, x, eps, u)
 
 
-FWD = [("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,), S=50), 256, True),      # R = 12,800: the logits GEMM on f16 pairs
-       ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(64,), S=40), 256, True),
-       ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,)), 512, False),           # S = 1: the chain kernels
-       ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,), S=5), 64, False)]
+FWD = [("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,), S=50), 256, "evalf"),   # R = 12,800: the one-launch evaluation (csrc/evalf.hpp)
+       ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,), S=3), 100, "evalf"),    # ragged panels: 300 sample rows over 100 workgroups
+       ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,)), 512, "evalf"),         # S = 1
+       ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,), S=50, gen_bias_init=0.7, temperature=0.6), 256, "evalf"),
+       ("gmvae", O.Dims(D=784, L=32, K=10, hidden=(64,), S=50), 256, "pairs"),   # another latent size: the logits GEMM on f16 pairs
+       ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(64,), S=40), 256, "pairs"),
+       ("gmvae", O.Dims(D=784, L=32, K=10, hidden=(64,)), 512, None),            # S = 1: the chain kernels
+       ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,), S=5), 64, None)]
 
 
 @pytest.mark.parametrize("span", [8.0, 20.0])
-@pytest.mark.parametrize("name,d,B,pairs", FWD, ids=[f"{n}-L{d.L}-H{d.hidden[0]}-S{d.S}-B{B}" for n, d, B, _ in FWD])
-def test_forward_only_saturated(name, d, B, pairs, span, monkeypatch):
+@pytest.mark.parametrize("name,d,B,path", FWD, ids=[f"{n}-L{d.L}-H{d.hidden[0]}-S{d.S}-B{B}-{p}" for n, d, B, p in FWD])
+def test_forward_only_saturated(name, d, B, path, span, monkeypatch):
     """gmvae_forward (scripts/runners.py:324-333 reuses run_model for the evaluation bound) at saturated parameters: every row's
-    log p(x|z), log w, z and the IWAE bound against the fp64 oracle -- and the f16-pair logits GEMM really ran where claimed."""
+    log p(x|z), log w, z and the IWAE bound against the fp64 oracle -- and the path named (the one-launch evaluation of
+    csrc/evalf.hpp at the reference's default sizes; the f16-pair logits GEMM elsewhere) really ran where claimed."""
     import hip_util as H
     model = O.MODEL_NAMES[name]
     rng = np.random.default_rng(B + d.S)
@@ -242,10 +247,11 @@ def test_forward_only_saturated(name, d, B, pairs, span, monkeypatch):
     np.testing.assert_allclose(rows[:, 0], Cc["logpx"], rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(rows[:, 3], Cc["logw"], rtol=1e-5, atol=1e-3)
     assert abs(tail[0] / B - Cc["loss"]) <= 1e-5 * abs(Cc["loss"])
-    if pairs:
-        monkeypatch.setenv("GMVAE_NO_PLANES", "1")
+    if path:                                        # evidence that the path named ran: not the bits of the path behind it
+        monkeypatch.setenv("GMVAE_NO_PLANES" if path == "pairs" else "GMVAE_NO_EVALF", "1")
         rows32 = H.hip_forward(model, d, flat, x, eps, u)[1]
         assert not np.array_equal(rows[:, 0], rows32[:, 0])
+        np.testing.assert_allclose(rows[:, 0], rows32[:, 0], rtol=1e-5, atol=1e-3)
 
 
 def _structured_pixels(n, D, rng):
