@@ -253,11 +253,11 @@ def main_eval(a):
     gem = [l for l in levels if l[2] > 0]
     dom = max(gem, key=lambda l: l[1])
     from gmvae_amd import _lib as LIB
-    roof = {"bound": "mfma", "kernel": dom[0] if dom[0].startswith(("mega", "sk_", "dw_", "rows_", "first_")) else f"gemm_grouped<{dom[0]}>",
+    roof = {"bound": "mfma", "kernel": dom[0] if dom[0].startswith(("mega", "sk_", "dw_", "rows_", "first_", "evalf")) else f"gemm_grouped<{dom[0]}>",
             "achieved": dom[2] / dom[1] * 1e-6, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": dom[2] / dom[1] * 1e-6 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
             "usec_per_launch": dom[1], "flops_per_launch": dom[2],
-            "timing": "per launch: hipEvents around eager launches (mean); the pass: one captured forward replayed back to back",
+            "timing": "per launch: hipEvents around eager launches (mean); the pass: captured forward passes replayed back to back (passes_per_graph_launch per launch)",
             "step_flops_alg": fl_alg, "step_tflops_alg": fl_alg / us_total * 1e-6,
             "step_frac_of_mfma_peak": fl_alg / us_total * 1e-6 / PEAK_F32_MFMA_TFLOPS,
             "step_flops_executed": sum(l[2] for l in levels), "launches_per_step": len(levels),
@@ -274,12 +274,31 @@ def main_eval(a):
                      "peak_note": f"dense f16 MFMA peak 2500 TFLOP/s / {PLANE_PIECES:.0f} piece products per fp32 product; fp32 accumulation; "
                                   "K = 64 is four 16-deep rounds per tile: the launch is its Bernoulli epilogue's vector work",
                      "frac_of_f32_mfma_peak": roof["achieved"] / PEAK_F32_MFMA_TFLOPS})
+    if dom[0] == "evalf_rows":
+        # the one-launch evaluation (csrc/evalf.hpp): the output layer (64 -> D per sample row) multiplies as exact bf16 piece products
+        # (6 per fp32 product), the small layers as fp32 MFMA: priced against the time the two parts would take at their own peaks
+        f_top = 2.0 * B * S * hidden[-1] * D
+        f_small = dom[2] - f_top
+        t_ideal = f_small / (PEAK_F32_MFMA_TFLOPS * 1e6) + f_top / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e6)      # us
+        pk = dom[2] / t_ideal * 1e-6
+        roof.update({"peak": pk, "frac": roof["achieved"] / pk, "frac_of_f32_mfma_peak": roof["achieved"] / PEAK_F32_MFMA_TFLOPS,
+                     "piece_products_per_product": 6.0,
+                     "peak_note": f"blended: {f_top / dom[2]:.0%} of the launch's FLOPs (the decoder's output layer) run as 6 exact bf16 piece products per "
+                                  f"fp32 product (dense bf16 peak 2500 / 6 = 416.7 fp32-equivalent TFLOP/s), the rest as fp32 MFMA (157.3): "
+                                  f"ideal {t_ideal:.1f} us; measured (tools/evstamps.py): matrix and vector instructions of this kernel do not "
+                                  "overlap -- the dense 4-pass bf16 MFMAs leave no issue shadow -- so its time is the SUM of both"})
+        if os.environ.get("GMVAE_EVAL_GRAPH_PASSES"):
+            roof["passes_per_graph_launch"] = int(os.environ["GMVAE_EVAL_GRAPH_PASSES"])
+        else:
+            roof["passes_per_graph_launch"] = min(8, a.steps)
     try:
         import csv, glob
         stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_eval_iwae_kernel_stats.csv")))
         if stats:
             roof["rocprof_source"] = os.path.relpath(stats[-1], ROOT)
             want = "void gmvae::gemm_grouped<gmvae::Cfg<128, 128, 32, 2, 2, 1, 2>, %d>" % (3 if fwd_pairs else 0)
+            if dom[0] == "evalf_rows":
+                want = "void gmvae::evalf_rows<0>" 
             for row in csv.DictReader(open(stats[-1])):
                 if row["Name"].startswith(want):
                     roof["rocprof_usec_per_launch"] = float(row["AverageNs"]) * 1e-3

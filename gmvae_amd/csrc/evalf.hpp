@@ -195,145 +195,162 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
       ring_primed = true;
     }
     EV_ST(1);
-    for (int p0 = 0; p0 < panels; p0 += kMW) {
-      EV_ST(2 + 4 * min(p0 / kMW, 2));
-      const int p = p0 + wave;
-      const bool active = p < panels;
-      const long long row = r_begin + 16ll * p + ln;
-      const bool rv = active && row < r_end;
-      const long long rowc = rv ? row : r_end - 1;                // (clamped: lanes of absent rows compute on the last row, store nothing)
-      const int bj = (int)(rowc / S) - bb;
-      const unsigned long long grow = a.row_base + (unsigned long long)rowc;
-      const unsigned char* const xr = reinterpret_cast<const unsigned char*>(T_x) + bj * D + 4 * lk;     // this row's x bytes (LDS)
+    // A wave owns TWO panels per round (panels p0 + 2 wave, + 1): it runs the per-row chain for one, then the other, and takes
+    // both through the output layer together -- every weight piece read from LDS feeds two matrix instructions (the layer ran at the
+    // rate of the 8 waves' LDS reads: 6 KB per wave, tile and panel), the image streams through the ring once per 16 panels
+    // instead of once per 8, and a workgroup's 13 panels (200 sample rows) take one round with 7 barriers instead of two.
+    for (int p0 = 0; p0 < panels; p0 += 2 * kMW) {
+      EV_ST(2 + 4 * min(p0 / (2 * kMW), 2));
       typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 Bh[2], Bm[2], Bl[2];                   // the decoder's hidden layer as bf16 pieces (B operands of the two k32 steps)
-      float lq = 0.f, lp_ = 0.f;
-      if (active) {
-        f32x4 hd[4];
-        // ---- y = softmax((logits + Gumbel) / T) (gmvae.py:240): lane (j, lk) holds classes 4 lk + r
-        f32x4 y4;
-        {
-          const f32x4 lg4 = ev_ld(T_lg + bj * 16 + 4 * lk);
-          float u4[4] = {0.5f, 0.5f, 0.5f, 0.5f};
-          if (a.u) {
+      u32x4 Bh[2][2], Bm[2][2], Bl[2][2];          // [panel][k32 step]: the decoder's hidden layer as bf16 pieces (B operands)
+      float lqA[2] = {0.f, 0.f}, lpA[2] = {0.f, 0.f};
+      bool actv[2], rvA[2];
+      long long rowA[2];
+      int bjA[2];
+      const unsigned char* xrA[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (4 * lk + r < K) u4[r] = a.u[rowc * K + 4 * lk + r];
-          } else if (lk < (K + 3) / 4) {
-            noise_vals(grow, (unsigned)lk, true, a.seed, a.step, u4);
+      for (int pi = 0; pi < 2; ++pi) {
+        const int p = p0 + 2 * wave + pi;
+        const bool active = p < panels;
+        const long long row = r_begin + 16ll * p + ln;
+        const bool rv = active && row < r_end;
+        const long long rowc = rv ? row : r_end - 1;              // (clamped: lanes of absent rows compute on the last row, store nothing)
+        const int bj = (int)(rowc / S) - bb;
+        const unsigned long long grow = a.row_base + (unsigned long long)rowc;
+        actv[pi] = active; rvA[pi] = rv; rowA[pi] = row; bjA[pi] = bj;
+        xrA[pi] = reinterpret_cast<const unsigned char*>(T_x) + bj * D + 4 * lk;       // this row's x bytes (LDS)
+        float lq = 0.f, lp_ = 0.f;
+        if (active) {
+          f32x4 hd[4];
+          // ---- y = softmax((logits + Gumbel) / T) (gmvae.py:240): lane (j, lk) holds classes 4 lk + r
+          f32x4 y4;
+          {
+            const f32x4 lg4 = ev_ld(T_lg + bj * 16 + 4 * lk);
+            float u4[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+            if (a.u) {
+  #pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (4 * lk + r < K) u4[r] = a.u[rowc * K + 4 * lk + r];
+            } else if (lk < (K + 3) / 4) {
+              noise_vals(grow, (unsigned)lk, true, a.seed, a.step, u4);
+            }
+            float av[4], m = -INFINITY;
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) { av[r] = (lg4[r] - flog(-flog(u4[r]))) * a.invT; m = fmaxf(m, av[r]); }
+            m = ev_lk_max(m);
+            float se = 0.f;
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) se += fexp(av[r] - m);
+            se = ev_lk_sum(se);
+            const float lse = m + flog(se);
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              y4[r] = fexp(av[r] - lse);
+              if (a.y_out && rv && 4 * lk + r < K) a.y_out[row * K + 4 * lk + r] = y4[r];
+            }
           }
-          float av[4], m = -INFINITY;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { av[r] = (lg4[r] - flog(-flog(u4[r]))) * a.invT; m = fmaxf(m, av[r]); }
-          m = ev_lk_max(m);
-          float se = 0.f;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) se += fexp(av[r] - m);
-          se = ev_lk_sum(se);
-          const float lse = m + flog(se);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            y4[r] = fexp(av[r] - lse);
-            if (a.y_out && rv && 4 * lk + r < K) a.y_out[row * K + 4 * lk + r] = y4[r];
+          // ---- prior head (gmvae.py:243) and encoder_gmm's hidden layer (gmvae.py:246): contraction over y (one k tile)
+          f32x4 pp[8], hg[4], qp[8];
+  #pragma unroll
+          for (int nt = 0; nt < 8; ++nt) {
+            const float4 w4 = *reinterpret_cast<const float4*>(img + EV::Wp + ((lk * 128 + nt * 16 + ln) << 2));
+            pp[nt] = ev_mfma4(w4, y4, ev_ld(img + EV::b_p + nt * 16 + 4 * lk));
           }
-        }
-        // ---- prior head (gmvae.py:243) and encoder_gmm's hidden layer (gmvae.py:246): contraction over y (one k tile)
-        f32x4 pp[8], hg[4], qp[8];
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-          const float4 w4 = *reinterpret_cast<const float4*>(img + EV::Wp + ((lk * 128 + nt * 16 + ln) << 2));
-          pp[nt] = ev_mfma4(w4, y4, ev_ld(img + EV::b_p + nt * 16 + 4 * lk));
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const float4 w4 = *reinterpret_cast<const float4*>(img + EV::Wg0y + ((lk * 64 + nt * 16 + ln) << 2));
-          const f32x4 b0 = ev_ld(img + EV::b_g0 + nt * 16 + 4 * lk), g0 = ev_ld(T_gx + bj * 64 + nt * 16 + 4 * lk);
-          hg[nt] = ev_relu(ev_mfma4(w4, y4, b0 + g0));
-        }
-        // ---- q head
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-          f32x4 acc = ev_ld(img + EV::b_g1 + nt * 16 + 4 * lk);
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc = ev_mfma4(*reinterpret_cast<const float4*>(img + EV::Wg1 + (((t * 4 + lk) * 128 + nt * 16 + ln) << 2)), hg[t], acc);
-          qp[nt] = acc;
-        }
-        // ---- z = mu + sigma eps, log q(z|x,y), log p(z|y) (gmvae.py:248,258; base.py:66-72)
-        f32x4 z[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float e4[4];
-          if (a.eps) {
-            const float4 v = *reinterpret_cast<const float4*>(a.eps + rowc * L + 16 * t + 4 * lk);
-            e4[0] = v.x; e4[1] = v.y; e4[2] = v.z; e4[3] = v.w;
-          } else {
-            noise_vals(grow, (unsigned)(4 * t + lk), false, a.seed, a.step, e4);
+  #pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const float4 w4 = *reinterpret_cast<const float4*>(img + EV::Wg0y + ((lk * 64 + nt * 16 + ln) << 2));
+            const f32x4 b0 = ev_ld(img + EV::b_g0 + nt * 16 + 4 * lk), g0 = ev_ld(T_gx + bj * 64 + nt * 16 + 4 * lk);
+            hg[nt] = ev_relu(ev_mfma4(w4, y4, b0 + g0));
           }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float s_;
-            const float sg = fmaxf(softplus_sig(qp[t + 4][r] + a.c, s_), a.smin);
-            const float ee = e4[r];
-            const float zz = fmaf(sg, ee, qp[t][r]);
-            lq += -0.5f * ee * ee - 0.5f * kLog2Pi - flog(sg);          // (z - mu) / sigma IS eps
-            const float sp = fmaxf(softplus_sig(pp[t + 4][r] + a.c, s_), a.smin);
-            const float tt = (zz - pp[t][r]) * __builtin_amdgcn_rcpf(sp);
-            lp_ += -0.5f * tt * tt - 0.5f * kLog2Pi - flog(sp);
-            z[t][r] = zz;
+          // ---- q head
+  #pragma unroll
+          for (int nt = 0; nt < 8; ++nt) {
+            f32x4 acc = ev_ld(img + EV::b_g1 + nt * 16 + 4 * lk);
+  #pragma unroll
+            for (int t = 0; t < 4; ++t)
+              acc = ev_mfma4(*reinterpret_cast<const float4*>(img + EV::Wg1 + (((t * 4 + lk) * 128 + nt * 16 + ln) << 2)), hg[t], acc);
+            qp[nt] = acc;
           }
-          if (a.z_out && rv) *reinterpret_cast<float4*>(a.z_out + row * L + 16 * t + 4 * lk) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
-        }
-        lq = ev_lk_sum(lq); lp_ = ev_lk_sum(lp_);
-        // ---- decoder hidden layer (gmvae.py:251)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          f32x4 acc = ev_ld(img + EV::b_d0 + nt * 16 + 4 * lk);
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc = ev_mfma4(*reinterpret_cast<const float4*>(img + EV::Wd0 + (((t * 4 + lk) * 64 + nt * 16 + ln) << 2)), z[t], acc);
-          hd[nt] = ev_relu(acc);
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int jp = 0; jp < 4; ++jp) {         // elements e = 2 jp, 2 jp + 1: tile 2 m + (jp >> 1), components 2 (jp & 1), + 1
-            const float v0 = hd[2 * m + (jp >> 1)][2 * (jp & 1)], v1 = hd[2 * m + (jp >> 1)][2 * (jp & 1) + 1];
-            Bh[m][jp] = pack_hi16(v1, v0);
-            const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u), r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
-            Bm[m][jp] = pack_hi16(r1, r0);
-            const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-            Bl[m][jp] = pack_hi16(s1, s0);
+          // ---- z = mu + sigma eps, log q(z|x,y), log p(z|y) (gmvae.py:248,258; base.py:66-72)
+          f32x4 z[4];
+  #pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float e4[4];
+            if (a.eps) {
+              const float4 v = *reinterpret_cast<const float4*>(a.eps + rowc * L + 16 * t + 4 * lk);
+              e4[0] = v.x; e4[1] = v.y; e4[2] = v.z; e4[3] = v.w;
+            } else {
+              noise_vals(grow, (unsigned)(4 * t + lk), false, a.seed, a.step, e4);
+            }
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float s_;
+              const float sg = fmaxf(softplus_sig(qp[t + 4][r] + a.c, s_), a.smin);
+              const float ee = e4[r];
+              const float zz = fmaf(sg, ee, qp[t][r]);
+              lq += -0.5f * ee * ee - 0.5f * kLog2Pi - flog(sg);          // (z - mu) / sigma IS eps
+              const float sp = fmaxf(softplus_sig(pp[t + 4][r] + a.c, s_), a.smin);
+              const float tt = (zz - pp[t][r]) * __builtin_amdgcn_rcpf(sp);
+              lp_ += -0.5f * tt * tt - 0.5f * kLog2Pi - flog(sp);
+              z[t][r] = zz;
+            }
+            if (a.z_out && rv) *reinterpret_cast<float4*>(a.z_out + row * L + 16 * t + 4 * lk) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
           }
+          lqA[pi] = ev_lk_sum(lq); lpA[pi] = ev_lk_sum(lp_);
+          // ---- decoder hidden layer (gmvae.py:251)
+  #pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            f32x4 acc = ev_ld(img + EV::b_d0 + nt * 16 + 4 * lk);
+  #pragma unroll
+            for (int t = 0; t < 4; ++t)
+              acc = ev_mfma4(*reinterpret_cast<const float4*>(img + EV::Wd0 + (((t * 4 + lk) * 64 + nt * 16 + ln) << 2)), z[t], acc);
+            hd[nt] = ev_relu(acc);
+          }
+  #pragma unroll
+          for (int m = 0; m < 2; ++m)
+  #pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {         // elements e = 2 jp, 2 jp + 1: tile 2 m + (jp >> 1), components 2 (jp & 1), + 1
+              const float v0 = hd[2 * m + (jp >> 1)][2 * (jp & 1)], v1 = hd[2 * m + (jp >> 1)][2 * (jp & 1) + 1];
+              Bh[pi][m][jp] = pack_hi16(v1, v0);
+              const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u), r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
+              Bm[pi][m][jp] = pack_hi16(r1, r0);
+              const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+              Bl[pi][m][jp] = pack_hi16(s1, s0);
+            }
+        }
       }
-      EV_ST(3 + 4 * min(p0 / kMW, 2));
-      // ---- output layer + Independent(Bernoulli).log_prob (gmvae.py:254): 7 chunks of 7 column tiles through the LDS ring
-      f32x2_t brk2 = {0.f, 0.f};                   // sum of [x l - max(l, 0)] (two chains: packed fp32)
-      float lg2 = 0.f;                             // sum of log2 prod (1 + e^-|l|)
-      // a tile: 12 piece products (6 of the 9 per k32 step: the dropped ones are <= 2^-24 of the product), smallest first.
-      // Software pipeline, one tile per iteration of a ROLLED loop: the weight pieces of tile i + 1 are requested from LDS, tile i's
-      // matrix instructions (operands read an iteration ago) are issued BETWEEN the vector instructions of tile i - 1's epilogue.
-      // (A dependent chain of 12 MFMAs holds the wave's in-order issue for 192 cycles; behind the chunk barrier the SIMD's other
-      //  wave is in the same phase, so without the interleave matrix and vector pipes take turns instead of overlapping.)
-      f32x4 accp = {-1e30f, -1e30f, -1e30f, -1e30f};      // "tile -1": with x = 0 its epilogue adds exactly nothing
-      unsigned xprev = 0u;
-      f32x2_t prod2 = {1.f, 1.f};
+      EV_ST(3 + 4 * min(p0 / (2 * kMW), 2));
+      // ---- output layer + Independent(Bernoulli).log_prob (gmvae.py:254): 7 chunks of 7 column tiles through the LDS ring.
+      // A tile: 12 piece products per panel (6 of the 9 per k32 step: the dropped ones are <= 2^-24 of the product), smallest
+      // first.  One tile per iteration, software-pipelined: the weight pieces of tile i + 1 are requested from LDS while tile i's
+      // matrix instructions run, each followed by a piece of tile i - 1's epilogue (sched_barrier: nothing moves across).
+      f32x2_t brk2[2] = {{0.f, 0.f}, {0.f, 0.f}};    // per panel: sum of [x l - max(l, 0)] (two chains: packed fp32)
+      float lg2[2] = {0.f, 0.f};                   // ... sum of log2 prod (1 + e^-|l|)
+      f32x4 accp[2] = {{-1e30f, -1e30f, -1e30f, -1e30f}, {-1e30f, -1e30f, -1e30f, -1e30f}};   // "tile -1": with x = 0 its epilogue adds exactly nothing
+      unsigned xprev[2] = {0u, 0u};
+      f32x2_t prod2[2] = {{1.f, 1.f}, {1.f, 1.f}};
+      const bool any = actv[0];                    // (panel 1 is active only if panel 0 is)
 #pragma unroll 1
       for (int c = 0; c < EV::CH; ++c, ++cc) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // chunk cc has landed for every wave; everyone is done with chunk cc - 1
-        const bool more = c + 1 < EV::CH || p0 + kMW < panels || bb + EV::NB < b_end;
+        const bool more = c + 1 < EV::CH || p0 + 2 * kMW < panels || bb + EV::NB < b_end;
         if (more) dma_copy_m(ring + ((cc + 1) & 1) * (EV::CH * EV::TW), gd1 + ((c + 1) % EV::CH) * (EV::CH * EV::TW), EV::CH * EV::TW, wave, lane);
-        if (active) {
-          lg2 += __builtin_amdgcn_logf(prod2[0] * prod2[1]);      // (<= 28 factors in (1, 2] since the last one)
-          prod2 = f32x2_t{1.f, 1.f};
+        if (any) {
+#pragma unroll
+          for (int pi = 0; pi < 2; ++pi) {
+            lg2[pi] += __builtin_amdgcn_logf(prod2[pi][0] * prod2[pi][1]);      // (<= 28 factors in (1, 2] since the last one)
+            prod2[pi] = f32x2_t{1.f, 1.f};
+          }
           const float* const cb = ring + (cc & 1) * (EV::CH * EV::TW) + ((lk * 16 + ln) << 2);
           u32x4 fr[6];                             // [m][hi, mid, lo]
 #pragma unroll
           for (int q = 0; q < 6; ++q) fr[q] = *reinterpret_cast<const u32x4*>(cb + (q % 3) * 512 + (q / 3) * 256);
           f32x4 bias = ev_ld(B1 + 16 * (c * EV::CH) + 4 * lk);
-          unsigned xcur = *reinterpret_cast<const unsigned*>(xr + 16 * (c * EV::CH));
+          unsigned xcur[2];
+#pragma unroll
+          for (int pi = 0; pi < 2; ++pi) xcur[pi] = *reinterpret_cast<const unsigned*>(xrA[pi] + 16 * (c * EV::CH));
 #pragma unroll
           for (int i = 0; i < EV::CH; ++i) {       // (unrolled: the loop-carried operand registers rename instead of moving)
             const int in = min(i + 1, EV::CH - 1), Tn = c * EV::CH + in;
@@ -341,64 +358,69 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
 #pragma unroll
             for (int q = 0; q < 6; ++q) fn[q] = *reinterpret_cast<const u32x4*>(cb + in * EV::TW + (q % 3) * 512 + (q / 3) * 256);
             const f32x4 biasn = ev_ld(B1 + 16 * Tn + 4 * lk);
-            const unsigned xnext = *reinterpret_cast<const unsigned*>(xr + 16 * Tn);
-            f32x4 acc = bias;
-            // the PREVIOUS tile's epilogue in twelve pieces, one behind each matrix instruction (sched_barrier: nothing moves
-            // across, so the in-order issue alternates matrix / vector work; sched_group_barrier hints were not honoured here)
-            f32x2_t e2_[2];
-            auto piece = [&](const int k) {        // pair pr = k / 6 of the tile's four logits, stage k % 6 (packed fp32 where the ISA has it)
-              const int pr = k / 6, st = k % 6;
-              if (MODE == 1) { __builtin_amdgcn_sched_barrier(0); return; }
-              const f32x2_t lam = {accp[2 * pr], accp[2 * pr + 1]};
-              if (st == 0) {
-                const f32x2_t xf = {(float)((xprev >> (16 * pr)) & 0xffu), (float)((xprev >> (16 * pr + 8)) & 0xffu)};
-                const f32x2_t mx = {__builtin_amdgcn_fmed3f(lam[0], 0.f, INFINITY), __builtin_amdgcn_fmed3f(lam[1], 0.f, INFINITY)};
-                brk2 += xf * lam - mx;             // x l - max(l, 0): exact, <= 0
-              } else if (st == 1) {
-                e2_[pr][0] = fexp(-fabsf(lam[0]));
-              } else if (st == 2) {
-                e2_[pr][1] = fexp(-fabsf(lam[1]));
-              } else if (st == 3) {
-                prod2 = prod2 * e2_[pr] + prod2;
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            };
-            __builtin_amdgcn_sched_barrier(0);
+            unsigned xnext[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-              const bf16x8 Ah = __builtin_bit_cast(bf16x8, fr[3 * m]), Am = __builtin_bit_cast(bf16x8, fr[3 * m + 1]), Al = __builtin_bit_cast(bf16x8, fr[3 * m + 2]);
-              const bf16x8 bh = __builtin_bit_cast(bf16x8, Bh[m]), bm = __builtin_bit_cast(bf16x8, Bm[m]), bl = __builtin_bit_cast(bf16x8, Bl[m]);
-              if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, bh, acc, 0, 0, 0); piece(6 * m + 0);
-              if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, bm, acc, 0, 0, 0); piece(6 * m + 1);
-              if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bl, acc, 0, 0, 0); piece(6 * m + 2);
-              if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, bh, acc, 0, 0, 0); piece(6 * m + 3);
-              if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bm, acc, 0, 0, 0); piece(6 * m + 4);
-              if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bh, acc, 0, 0, 0); piece(6 * m + 5);
+            for (int pi = 0; pi < 2; ++pi) xnext[pi] = *reinterpret_cast<const unsigned*>(xrA[pi] + 16 * Tn);
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+              if (pi == 1 && !actv[1]) break;      // (wave-uniform)
+              f32x4 acc = bias;
+              f32x2_t e2_[2];
+              auto piece = [&](const int k) {      // pair pr = k / 6 of the previous tile's four logits, stage k % 6 (packed fp32 where the ISA has it)
+                const int pr = k / 6, st = k % 6;
+                if (MODE == 1) { __builtin_amdgcn_sched_barrier(0); return; }
+                const f32x2_t lam = {accp[pi][2 * pr], accp[pi][2 * pr + 1]};
+                if (st == 0) {
+                  const f32x2_t xf = {(float)((xprev[pi] >> (16 * pr)) & 0xffu), (float)((xprev[pi] >> (16 * pr + 8)) & 0xffu)};
+                  const f32x2_t mx = {__builtin_amdgcn_fmed3f(lam[0], 0.f, INFINITY), __builtin_amdgcn_fmed3f(lam[1], 0.f, INFINITY)};
+                  brk2[pi] += xf * lam - mx;       // x l - max(l, 0): exact, <= 0
+                } else if (st == 1) {
+                  e2_[pr][0] = fexp(-fabsf(lam[0]));
+                } else if (st == 2) {
+                  e2_[pr][1] = fexp(-fabsf(lam[1]));
+                } else if (st == 3) {
+                  prod2[pi] = prod2[pi] * e2_[pr] + prod2[pi];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              };
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int m = 0; m < 2; ++m) {
+                const bf16x8 Ah = __builtin_bit_cast(bf16x8, fr[3 * m]), Am = __builtin_bit_cast(bf16x8, fr[3 * m + 1]), Al = __builtin_bit_cast(bf16x8, fr[3 * m + 2]);
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, Bh[pi][m]), bm = __builtin_bit_cast(bf16x8, Bm[pi][m]), bl = __builtin_bit_cast(bf16x8, Bl[pi][m]);
+                if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, bh, acc, 0, 0, 0); piece(6 * m + 0);
+                if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, bm, acc, 0, 0, 0); piece(6 * m + 1);
+                if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bl, acc, 0, 0, 0); piece(6 * m + 2);
+                if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, bh, acc, 0, 0, 0); piece(6 * m + 3);
+                if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bm, acc, 0, 0, 0); piece(6 * m + 4);
+                if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bh, acc, 0, 0, 0); piece(6 * m + 5);
+              }
+              accp[pi] = acc; xprev[pi] = xcur[pi]; xcur[pi] = xnext[pi];
             }
-            accp = acc; xprev = xcur; xcur = xnext; bias = biasn;
+            bias = biasn;
 #pragma unroll
             for (int q = 0; q < 6; ++q) fr[q] = fn[q];
           }
         }
       }
-      if (active) {
+      EV_ST(4 + 4 * min(p0 / (2 * kMW), 2));
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        if (!actv[pi]) break;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {              // the last tile's epilogue
-          const float lam = accp[r];
-          const float xf = (float)((xprev >> (8 * r)) & 0xffu);
-          brk2[r & 1] += fmaf(xf, lam, -fmaxf(lam, 0.f));
-          prod2[r & 1] = fmaf(prod2[r & 1], fexp(-fabsf(lam)), prod2[r & 1]);
+          const float lam = accp[pi][r];
+          const float xf = (float)((xprev[pi] >> (8 * r)) & 0xffu);
+          brk2[pi][r & 1] += fmaf(xf, lam, -fmaxf(lam, 0.f));
+          prod2[pi][r & 1] = fmaf(prod2[pi][r & 1], fexp(-fabsf(lam)), prod2[pi][r & 1]);
         }
-        lg2 += __builtin_amdgcn_logf(prod2[0] * prod2[1]);
-      }
-      EV_ST(4 + 4 * min(p0 / kMW, 2));
-      if (active) {
-        const float lpx = ev_lk_sum((brk2[0] + brk2[1]) - 0.693147180559945309f * lg2);
-        const float lw = lpx + lp_ - lq - T_ne[bj];
-        if (lk == 0 && rv) {
-          const float4 o = make_float4(lpx, lq, lp_, lw);
-          st4o(a.rows_ws + row * 4, o);
-          if (a.rows4 && a.rows4 != a.rows_ws) *reinterpret_cast<float4*>(a.rows4 + row * 4) = o;
+        lg2[pi] += __builtin_amdgcn_logf(prod2[pi][0] * prod2[pi][1]);
+        const float lpx = ev_lk_sum((brk2[pi][0] + brk2[pi][1]) - 0.693147180559945309f * lg2[pi]);
+        const float lw = lpx + lpA[pi] - lqA[pi] - T_ne[bjA[pi]];
+        if (lk == 0 && rvA[pi]) {
+          const float4 o = make_float4(lpx, lqA[pi], lpA[pi], lw);
+          st4o(a.rows_ws + rowA[pi] * 4, o);
+          if (a.rows4 && a.rows4 != a.rows_ws) *reinterpret_cast<float4*>(a.rows4 + rowA[pi] * 4) = o;
         }
       }
     }
@@ -439,11 +461,16 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
   if (tid == 0) *last = atomicAdd(a.counter, 1u) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
   EV_ST(15);
-  if (*last && tid < 4) {
-    float s = 0.f;
-    for (unsigned g = 0; g < gridDim.x; ++g) s += ld_sc(a.slots + (long long)g * 4 + tid);
-    a.tail[tid] = s;
-    if (tid == 0) { a.tail[4] = (float)B; a.tail[5] = 0.f; a.tail[6] = 0.f; a.tail[7] = 0.f; *a.counter = 0u; }
+  if (*last) {                                     // (workgroup-uniform) every slot in flight at once, then a fixed-order sum
+    float* const sl = sm + EV::ring;               // [grid <= 1024][4] (the ring is dead)
+    for (unsigned g = tid; g < gridDim.x * 4; g += kMT) sl[g] = ld_sc(a.slots + g);
+    __syncthreads();
+    if (tid < 4) {
+      float s = 0.f;
+      for (unsigned g = 0; g < gridDim.x; ++g) s += sl[g * 4 + tid];
+      a.tail[tid] = s;
+      if (tid == 0) { a.tail[4] = (float)B; a.tail[5] = 0.f; a.tail[6] = 0.f; a.tail[7] = 0.f; *a.counter = 0u; }
+    }
   }
 }
 

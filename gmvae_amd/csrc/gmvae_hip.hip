@@ -2699,18 +2699,26 @@ int gmvae_forward_profile(const GmvaeDims* dims, int model, const uint8_t* x, co
       cx.st = cs;
       StepArgs a = {dims, model, x, nullptr, nullptr, params, nullptr, tail, nullptr, nullptr, nullptr, nullptr, workspace, seed,
                     0, nullptr, false};
-      const int r2 = run_step(cx, a);
+      // G consecutive passes per graph launch (an evaluation walks a split batch by batch, scripts/runners.py:320-333: the ~8 us
+      // the device idles between two graph launches is paid once per G batches, as in the train graphs); GMVAE_EVAL_GRAPH_PASSES=1:
+      // one pass per launch (rounds 4-5's figure)
+      int G = 8;
+      if (const char* e = getenv("GMVAE_EVAL_GRAPH_PASSES")) G = atoi(e) >= 1 && atoi(e) <= 64 ? atoi(e) : G;
+      if (G > iters) G = iters;
+      int r2 = 0;
+      for (int g = 0; g < G && r2 == 0; ++g) r2 = run_step(cx, a);
       ok = hipStreamEndCapture(cs, &graph) == hipSuccess && r2 == 0 && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-    }
-    if (ok) {
-      for (int w_ = 0; w_ < 3; ++w_) hipGraphLaunch(exec, st);
-      hipEventRecord(pr->ev[0], st);
-      for (int it = 0; it < iters; ++it) hipGraphLaunch(exec, st);
-      hipEventRecord(pr->ev[1], st);
-      hipStreamSynchronize(st);
-      float ms = 0.f;
-      hipEventElapsedTime(&ms, pr->ev[0], pr->ev[1]);
-      *usec_total = ms * 1000.f / (float)iters;
+      if (ok) {
+        const int nl = (iters + G - 1) / G;
+        for (int w_ = 0; w_ < 3; ++w_) hipGraphLaunch(exec, st);
+        hipEventRecord(pr->ev[0], st);
+        for (int it = 0; it < nl; ++it) hipGraphLaunch(exec, st);
+        hipEventRecord(pr->ev[1], st);
+        hipStreamSynchronize(st);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, pr->ev[0], pr->ev[1]);
+        *usec_total = ms * 1000.f / (float)(nl * G);
+      }
     }
     if (exec) hipGraphExecDestroy(exec);
     if (graph) hipGraphDestroy(graph);

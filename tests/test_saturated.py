@@ -291,3 +291,36 @@ def test_step_after_300_training_steps_on_structured_pixels(model, Lz, K, H_, B,
     Cc, _ = graph_step_case(model, 784, Lz, K, (H_,), B, launches, params=flat, step0=304, seed=5, x=xb)
     print(f"\n[trained] {model} H={H_} B={B}: loss {tl[0, 0] / B:.1f} -> {tl[-1, 0] / B:.1f}; max |lambda| {np.abs(Cc['lam']).max():.1f}, "
           f"sigma_q in [{Cc['sig_q'].min():.2e}, {Cc['sig_q'].max():.2e}]")
+
+
+@pytest.mark.parametrize("B,S,rank", [(256, 50, 0), (100, 7, 3), (37, 1, 5)])
+def test_one_launch_evaluation_draws_the_documented_noise_stream(B, S, rank):
+    """csrc/evalf.hpp with its OWN Philox draws (eps = u = NULL: what bench.py --config eval_iwae and run_eval time) against the
+    oracle on gmvae_noise_fill's arrays for the same (seed, step, global sample rows): a lane of the kernel asks noise_vals for
+    quad 4 t + lk of its row -- the same function, the same counters, a non-zero row offset included."""
+    from test_timed_path import _noise
+    from gmvae_amd import _lib as L
+    from gmvae_amd.engine import Engine
+    d = O.Dims(D=784, L=64, K=10, hidden=(64,), S=S)
+    e = Engine("gmvae", 784, 64, 10, [64], n_samples=S, random_seed=7)
+    e.rank = rank
+    e.global_step = 11
+    x = (np.random.default_rng(B).random((B, 784)) < 0.87).astype(np.uint8)
+    o = e.forward(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    assert L.step_schedule(e.dims(B), e.model) in ("mega2", "skinny", "general", "fused", "mega")      # (training's schedule: not what ran here)
+    eps, u = _noise(L, B * S, 64, 10, rank * B * S, e.noise_seed, 11, True)
+    flat = e.params.detach().cpu().numpy().astype(np.float64)
+    Cc = O.forward(O.MODEL_GMVAE, d, O.unpack(O.MODEL_GMVAE, d, flat), x, eps, u)
+    rows = o["rows"].cpu().numpy()
+    np.testing.assert_allclose(o["z"].cpu().numpy(), Cc["z"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(o["y"].cpu().numpy(), Cc["y"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(o["logits"].cpu().numpy(), Cc["logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rows[:, 0], Cc["logpx"], rtol=1e-5)
+    np.testing.assert_allclose(rows[:, 1], Cc["logq"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(rows[:, 2], Cc["logp"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(rows[:, 3], Cc["logw"], rtol=1e-5)
+    tail = o["tail"].cpu().numpy().astype(np.float64)
+    assert tail[4] == B and abs(tail[0] / B - Cc["loss"]) <= 1e-6 * abs(Cc["loss"])
+    assert abs(tail[1] / B - Cc["nll"]) <= 1e-5 * abs(Cc["nll"]) and abs(tail[2] / B - Cc["kl"]) <= 1e-4 * max(abs(Cc["kl"]), 1.0)
+    assert abs(tail[3] / B - Cc["nent"]) <= 1e-4 * max(abs(Cc["nent"]), 1.0)
