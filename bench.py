@@ -775,9 +775,14 @@ def main():
                     roof["traffic_ratio"] = roof["traffic_step"] / step_bytes
                     roof["traffic_per_launch"] = per
                 elif a.config == "configs4_shard":
-                    big = [v["hbm_bytes_per_launch"] for k, v in tj.items() if "gemm_grouped<gmvae::Cfg<128, 128" in k]
-                    if big and dom[0] == "bwd_dec_top":
+                    # the plane launches by their tile instance: the backward launch (weight + data gradient) runs the 256 x 128
+                    # instance on f16 pairs (the 128 x 128 one on bf16 triples), the forward launch (logits + Bernoulli) the 128 x 128
+                    # one -- round 5's line took max() over the 128 x 128 entries for both and so reported the FORWARD launch's bytes
+                    inst = "Cfg<256, 128" if (dom[0] == "bwd_dec_top" and not PLANES_EXACT) else "Cfg<128, 128"
+                    big = [v["hbm_bytes_per_launch"] for k, v in tj.items() if "gemm_grouped<gmvae::" + inst in k]
+                    if big and dom[0] in ("bwd_dec_top", "fwd_dec_bernoulli"):
                         roof["traffic"] = max(big)
+                        roof["traffic_kernel"] = "gemm_grouped<" + inst + "...> (largest entry of that instance in the PMC record)"
         except Exception as e:
             roof["evidence_error"] = f"{type(e).__name__}: {e}"
         if a.levels:
@@ -794,11 +799,34 @@ def main():
                              f"cores usable; the reference pins intra_op=inter_op=1)",
                    "value_1thread": r[1][0], "value_by_threads": {str(k): v[0] for k, v in sorted(r.items())},
                    "host_logical_cores": logical, "host_physical_cores": physical}
+        # the like-for-like number beside the f16-pair plane GEMMs' (<= 3 x 2^-22 per product): the same step on the exact bf16
+        # triples (every product exact, GMVAE_PLANES_EXACT=1), re-captured in this process and timed by HIP events
+        exact_ms = None
+        if world == 1 and use_graph and (roof or {}).get("schedule", "").endswith("+planes") and not PLANES_EXACT:
+            try:
+                os.environ["GMVAE_PLANES_EXACT"] = "1"
+                eng.drop_graphs()
+                sxe, rpe = eng.capture_train_step(B, lr=1e-3, n_steps=1)
+                sxe.copy_(x)
+                for _ in range(5):
+                    rpe()
+                torch.cuda.synchronize()
+                ee = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+                for e0, e1 in ee:
+                    e0.record(); rpe(); e1.record()
+                torch.cuda.synchronize()
+                exact_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ee)[10]
+            except Exception as e:
+                exact_ms = f"{type(e).__name__}: {e}"
+            finally:
+                del os.environ["GMVAE_PLANES_EXACT"]
+                eng.drop_graphs()
         out = {
             "metric": "ELBO-samples/sec", "value": value, "unit": "samples/sec", "n_gpus": n_gpus, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "ms_per_step_median_hip_events": ms_median_events,
             "ms_per_step_median_of_repeats": region_ms[len(region_ms) // 2] if region_ms else None,
             "ms_per_step_repeats": [round(v, 5) for v in region_ms] if region_ms else None,
+            "ms_per_step_exact_triples": exact_ms,
             "steps_per_graph_launch": unit, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if not (roof or {}).get("schedule", "").endswith("+planes") else PLANES_DTYPE, "data": "synthetic",
             "config": {"workload": f"{a.model} train step (noise+fwd+bwd+allreduce+TF-Adam), D={d.D} K={d.K} "

@@ -164,6 +164,45 @@ def _graph_steps(every: int, cap: int = 32) -> int:
     return max(g for g in range(1, max(1, min(cap, every)) + 1) if every % g == 0)
 
 
+def _verify_launch(eng, snap, batches, g, lr):
+    """GMVAE_VERIFY_EVERY=n (debug): the g steps a train-graph launch just took, replayed from a snapshot of (params, m, v,
+    step) on a SHADOW engine through the two-launch form (GMVAE_NO_FUSE=1: mega2_fwd_bwd -> dw_adam, no plain loads behind flags
+    inside a launch) on the same binarised batches and the same noise keys, and compared BIT FOR BIT.  The one-launch steps
+    (csrc/mega3.hpp) are correct under the cache behaviour they were verified on (gfx950, ROCm 7.2: INTEGRATION.md); a stale
+    line would give silently wrong gradients, not a timeout -- this is the canary for other firmware / partitions."""
+    from .engine import Engine
+    p0, m0, v0, step0 = snap
+    hp = dict(eng.hp)
+    gb = eng.gen_bias_vec if eng.gen_bias_vec is not None else hp.pop("gen_bias_init")
+    hp.pop("gen_bias_init", None)
+    sh = Engine(eng.model_name, eng.D, eng.Lz, eng.K, eng.hidden, n_samples=eng.S, gen_bias_init=gb, random_seed=0, **hp)
+    sh.rank, sh.noise_seed = eng.rank, eng.noise_seed
+    with torch.no_grad():
+        sh.params.copy_(p0); sh.m.copy_(m0); sh.v.copy_(v0)
+    sh.global_step = step0
+    sh.step_dev.fill_(step0)
+    old = os.environ.get("GMVAE_NO_FUSE")
+    os.environ["GMVAE_NO_FUSE"] = "1"
+    try:
+        sx, rp = sh.capture_train_step(batches.shape[-2], lr=lr, n_steps=g)
+        sx.copy_(batches if g > 1 else batches.reshape(sx.shape))
+        rp()
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            del os.environ["GMVAE_NO_FUSE"]
+        else:
+            os.environ["GMVAE_NO_FUSE"] = old
+        sh.drop_graphs()
+    bad = [nm for nm, a_, b_ in (("params", sh.params, eng.params), ("Adam m", sh.m, eng.m), ("Adam v", sh.v, eng.v))
+           if not torch.equal(a_.detach(), b_.detach())]
+    if bad:
+        d = (sh.params.detach() - eng.params.detach()).abs()
+        raise RuntimeError(f"GMVAE_VERIFY_EVERY: steps {step0 + 1}..{step0 + g} of the train graph differ from the two-launch form in "
+                           f"{bad} (max |d params| {d.max().item():.3e}, {int((d > 0).sum().item())} elements): the one-launch "
+                           f"step's plain loads saw stale data on this device -- run with GMVAE_NO_FUSE=1")
+
+
 def run_train(config):
     """scripts/runners.py:106-232.  One iteration = the reference's sess.run([train_op, global_step]); here
     `summarise_every`-aligned hipGraph launches of several steps each: binarisation from the resident pixels, Philox
@@ -198,6 +237,8 @@ def run_train(config):
             if rank == 0:
                 print(f"[run_train] in-library RCCL unavailable ({e}); torch.distributed all-reduce", flush=True)
     run_train.last_path = "eager" if eager else ("dp-graph" if world > 1 else "pipeline-graph")
+    verify_every = int(os.environ.get("GMVAE_VERIFY_EVERY", "0") or 0)      # debug canary: see _verify_launch
+    run_train.launches = run_train.verified_launches = 0
     run_train.degraded = False
     hook = utils.EarlyStoppingHook(config.early_stop_rounds, config.early_stop_threshold)
     last_save, t0, s0 = time.time(), time.time(), eng.global_step
@@ -216,7 +257,14 @@ def run_train(config):
                 last_x, last_rows, g = x, rows, 1
             elif world == 1:
                 replay = eng.capture_train_pipeline(ds, B, lr=lr, n_steps=g)
+                run_train.launches += 1
+                snap = None
+                if verify_every and run_train.launches % verify_every == 0:
+                    snap = (eng.params.detach().clone(), eng.m.clone(), eng.v.clone(), eng.global_step)
                 replay()
+                if snap is not None:
+                    _verify_launch(eng, snap, replay.batches.clone(), g, lr)
+                    run_train.verified_launches += 1
                 logs.append(replay.tail_log.clone())
                 last_x, last_rows = replay.batches[g - 1], replay.rows[g - 1]
             else:

@@ -247,3 +247,32 @@ def test_train_then_eval_over_the_flag_space(tmp_path, model, latent, hidden, la
     res = run_gmvae.main(["--mode=eval"] + args)
     assert res["examples"] == 1024 and math.isfinite(res["train/loss_per_example"]) and res["train/loss_per_example"] < 0.9 * start
     assert res["latent_state"].shape == (1024, latent)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,latent,batch", [("gmvae", 64, 1024), ("vae_gmp", 64, 256), ("gmvae", 128, 64)])
+def test_verify_every_replays_launches_through_the_two_launch_form(tmp_path, monkeypatch, model, latent, batch):
+    """GMVAE_VERIFY_EVERY=n (gmvae_amd/runners.py _verify_launch): every n-th train-graph launch is replayed from a snapshot on a
+    shadow engine through the two-launch form and compared bit for bit -- the canary for the one-launch steps' plain loads behind
+    flags (csrc/mega3.hpp) on firmware / partitions other than the one they were verified on.  Here: it runs, it agrees (one-launch
+    GMVAE and VAE_GMP steps; a skinny configuration, where both forms are the same kernels), and a corrupted trajectory is caught."""
+    from gmvae_amd import runners
+    monkeypatch.setenv("GMVAE_VERIFY_EVERY", "2")
+    hidden = 64 if latent == 64 else 512
+    args = ["--mode=train", f"--model={model}", f"--latent_size={latent}", f"--hidden_size={hidden}", f"--batch_size={batch}",
+            "--max_steps=59", "--summarise_every=15", f"--logdir={tmp_path}/a", "--random_seed=3", "--synthetic_size=5000"]
+    m = run_gmvae.main(args)
+    assert runners.run_train.last_path == "pipeline-graph" and runners.run_train.launches == 4 and runners.run_train.verified_launches == 2
+    assert m._engine.global_step == 60 and m._engine.handoff_timeouts() == 0
+    # a trajectory that does NOT match its replay (the snapshot is taken, then one parameter is nudged behind the launch's back)
+    real = runners._verify_launch
+
+    def nudged(eng, snap, batches, g, lr):
+        with torch.no_grad():
+            eng.params[5] += 1e-3
+        return real(eng, snap, batches, g, lr)
+
+    import torch
+    monkeypatch.setattr(runners, "_verify_launch", nudged)
+    with pytest.raises(RuntimeError, match="GMVAE_VERIFY_EVERY"):
+        run_gmvae.main([a_ if not a_.startswith("--logdir") else f"--logdir={tmp_path}/b" for a_ in args])
