@@ -836,7 +836,7 @@ def main():
                        "all_reduce": getattr(eng, "dp_mode", None) if use_graph or world == 1 else "torch.distributed (eager)",
                        "dist_backend": backend if world > 1 else None, "replicas_identical": replicas_identical},
             "fallback": bool(fallbacks), "fallback_reasons": fallbacks or None,
-            "dp_timeline_usec": dp_tl, "allreduce_usec": (dp_tl or {}).get("allreduce_window"), "rccl_nranks": world if dp else None,
+            "dp_timeline_usec": dp_tl, "allreduce_usec": (dp_tl or {}).get("allreduce_window"), "rccl_nranks": getattr(eng, "rccl_nranks", None) if dp else None,
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "final_loss": final_tail[0] / max(final_tail[4], 1.0),
         }

@@ -14,13 +14,13 @@ LIB_PATH = os.environ.get("GMVAE_HIP_LIB") or os.path.join(HERE, "lib", "libgmva
 
 MAX_HIDDEN = 8
 TAIL = 8
-ABI_VERSION = 6       # include/gmvae_hip.h GMVAE_ABI_VERSION: the layout of GmvaeDims below and the entry points bound in _load
+ABI_VERSION = 7       # include/gmvae_hip.h GMVAE_ABI_VERSION: the layout of GmvaeDims below and the entry points bound in _load
 MODEL_VAE, MODEL_VAE_GMP, MODEL_GMVAE = 0, 1, 2
 MODEL_IDS = {"vae": MODEL_VAE, "vae_gmp": MODEL_VAE_GMP, "gmvae": MODEL_GMVAE}
 NET_ENCODER_Y, NET_PRIOR_GMM, NET_ENCODER_GMM, NET_DECODER, NET_ENCODER = range(5)
 
 ERRORS = {-1: "GMVAE_E_NULL", -2: "GMVAE_E_DIMS", -3: "GMVAE_E_MODEL", -4: "GMVAE_E_ALIGN",
-          -5: "GMVAE_E_NET", -6: "GMVAE_E_SMALL"}
+          -5: "GMVAE_E_NET", -6: "GMVAE_E_SMALL", -7: "GMVAE_E_TIMEOUT"}
 
 
 class GmvaeDims(C.Structure):
@@ -69,6 +69,7 @@ def _load():
         "gmvae_comm_unique_id": ([C.c_char_p, vp], i32),
         "gmvae_comm_init": ([C.c_char_p, vp, i32, i32, C.POINTER(vp)], i32),
         "gmvae_comm_destroy": ([vp], i32),
+        "gmvae_comm_count": ([vp, C.POINTER(i32)], i32),
         "gmvae_dp_step": ([dp, i32, vp, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, vp, vp], i32),
         "gmvae_dp_graph_create": ([dp, i32, vp, i32, vp, vp, vp, vp, vp, u64, vp, f32, f32, f32, f32, vp, vp, C.POINTER(vp)], i32),
         "gmvae_workspace_offset": ([dp, i32, C.c_char_p, C.POINTER(u64)], i32),

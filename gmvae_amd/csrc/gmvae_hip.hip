@@ -9,6 +9,11 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <vector>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <memory>
+#include <chrono>
 #include <stdint.h>
 #include <math.h>
 #include <stdio.h>
@@ -3084,6 +3089,7 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, ...) = nullptr;   // (ncclComm_t*, int nranks, ncclUniqueId by value, int rank)
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
 };
 static RcclApi g_rccl;
 struct UniqueId128 { char b[128]; };
@@ -3096,6 +3102,7 @@ static int rccl_load(const char* path) {
   g_rccl.CommInitRank = reinterpret_cast<int (*)(void**, int, ...)>(dlsym(h, "ncclCommInitRank"));
   g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
   g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+  g_rccl.CommCount = reinterpret_cast<int (*)(void*, int*)>(dlsym(h, "ncclCommCount"));
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) return GMVAE_E_NULL;
   g_rccl.h = h;
   return 0;
@@ -3114,8 +3121,35 @@ int gmvae_comm_init(const char* rccl_path, const char* id128, int rank, int worl
   UniqueId128 id;
   memcpy(id.b, id128, 128);
   typedef int (*InitFn)(void**, int, UniqueId128, int);
-  const int rc = reinterpret_cast<InitFn>(g_rccl.CommInitRank)(comm, world, id, rank);
-  return rc ? 1000 + rc : 0;
+  // ncclCommInitRank blocks until EVERY rank has joined: a rank that never arrives (a crashed peer, a mismatched world size)
+  // would hang the others for ever.  Bounded: the call runs on a helper thread; after GMVAE_COMM_INIT_TIMEOUT seconds (default
+  // 180) this returns GMVAE_E_TIMEOUT and the caller exits non-zero (the helper thread stays blocked inside RCCL: the process
+  // is expected to end; nothing is re-executed).
+  double limit = 180.0;
+  if (const char* e = getenv("GMVAE_COMM_INIT_TIMEOUT")) limit = atof(e) > 0 ? atof(e) : limit;
+  struct State { std::mutex mu; std::condition_variable cv; bool done = false; int rc = 0; void* comm = nullptr; };
+  auto stp = std::make_shared<State>();
+  int dev = 0;
+  hipGetDevice(&dev);
+  const InitFn fn = reinterpret_cast<InitFn>(g_rccl.CommInitRank);
+  std::thread([stp, fn, world, id, rank, dev]() {
+    hipSetDevice(dev);                             // (the device is per thread)
+    void* c = nullptr;
+    const int rc = fn(&c, world, id, rank);
+    std::lock_guard<std::mutex> lk(stp->mu);
+    stp->rc = rc; stp->comm = c; stp->done = true;
+    stp->cv.notify_all();
+  }).detach();
+  std::unique_lock<std::mutex> lk(stp->mu);
+  if (!stp->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return stp->done; })) return GMVAE_E_TIMEOUT;
+  *comm = stp->comm;
+  return stp->rc ? 1000 + stp->rc : 0;
+}
+
+int gmvae_comm_count(void* comm, int* nranks) {
+  if (!comm || !nranks || !g_rccl.h) return GMVAE_E_NULL;
+  if (!g_rccl.CommCount) return GMVAE_E_NULL;
+  return g_rccl.CommCount(comm, nranks) ? 1000 : 0;
 }
 
 int gmvae_comm_destroy(void* comm) {

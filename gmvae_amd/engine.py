@@ -341,8 +341,14 @@ class Engine:
         torch.cuda.synchronize()
         rc = L.lib.gmvae_comm_init(L.rccl_path(), buf, rank, world, C.byref(comm))
         if not self._agree(rc == 0):
-            raise L.GmvaeError(f"gmvae_comm_init failed on some rank (this rank rc={rc})")
+            raise L.GmvaeError(f"gmvae_comm_init failed on some rank (this rank rc={rc}"
+                               f"{': a rank did not join within GMVAE_COMM_INIT_TIMEOUT seconds' if rc == -7 else ''})")
+        n = C.c_int(0)
+        rc = L.lib.gmvae_comm_count(comm, C.byref(n))
+        if not self._agree(rc == 0 and n.value == world):
+            raise L.GmvaeError(f"the RCCL communicator spans {n.value} ranks (rc={rc}), torch.distributed's world is {world}")
         self._comm = comm
+        self.rccl_nranks = n.value
         return comm
 
     def dp_step(self, x, lr: float = 1e-3):

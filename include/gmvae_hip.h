@@ -39,7 +39,7 @@ extern "C" {
 
 #define GMVAE_MAX_HIDDEN 8
 #define GMVAE_TAIL 8          /* floats appended to the gradient buffer */
-#define GMVAE_ABI_VERSION 6   /* 5: + gmvae_dp_profile, gmvae_forward_profile; 6: GmvaeDims.hidden_act appended */
+#define GMVAE_ABI_VERSION 7   /* 5: + gmvae_dp_profile, gmvae_forward_profile; 6: GmvaeDims.hidden_act appended; 7: + gmvae_comm_count, GMVAE_E_TIMEOUT */
 
 enum { GMVAE_MODEL_VAE = 0, GMVAE_MODEL_VAE_GMP = 1, GMVAE_MODEL_GMVAE = 2 };
 
@@ -49,7 +49,8 @@ enum {
   GMVAE_E_MODEL = -3,     /* unknown model id                    */
   GMVAE_E_ALIGN = -4,     /* pointer not 16-byte aligned         */
   GMVAE_E_NET = -5,       /* unknown sub-network id              */
-  GMVAE_E_SMALL = -6      /* caller array too small              */
+  GMVAE_E_SMALL = -6,     /* caller array too small              */
+  GMVAE_E_TIMEOUT = -7    /* gmvae_comm_init: a rank did not join within GMVAE_COMM_INIT_TIMEOUT seconds */
 };
 
 /* Sizes + the hyper-parameters scripts/runners.py:78-101 binds
@@ -290,7 +291,11 @@ int gmvae_train_graph_destroy(void* graph);
  * with one all-reduce of the (scratch) gradient buffer and changes no training state.
  * Return codes >= 1000 are 1000 + ncclResult_t. */
 int gmvae_comm_unique_id(const char* rccl_path, char* out128);
+/* gmvae_comm_init is BOUNDED: ncclCommInitRank runs on a helper thread and GMVAE_E_TIMEOUT comes back after
+ * GMVAE_COMM_INIT_TIMEOUT seconds (environment, default 180) if some rank never joined -- the caller should then exit non-zero
+ * (the helper thread stays inside RCCL).  gmvae_comm_count: the number of ranks the communicator actually spans (ncclCommCount). */
 int gmvae_comm_init(const char* rccl_path, const char* id128, int rank, int world, void** comm);
+int gmvae_comm_count(void* comm, int* nranks);
 int gmvae_comm_destroy(void* comm);
 int gmvae_dp_step(const GmvaeDims* dims, int model, const uint8_t* x, float* params, float* m, float* v,
                   float* grads, void* workspace, uint64_t seed, uint64_t* step_dev, float lr, float beta1,

@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol(L):
     for sym in declared:
         assert hasattr(raw, sym), f"{sym} declared in include/gmvae_hip.h but not exported"
     assert declared == set(L.EXPORTS)
-    assert L.lib.gmvae_abi_version() == 6
+    assert L.lib.gmvae_abi_version() == L.ABI_VERSION == 7
 
 
 @pytest.mark.parametrize("name,d", [

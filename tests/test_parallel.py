@@ -417,3 +417,28 @@ def test_bench_world2_branch_on_one_gpu_prints_a_marked_line(tmp_path):
     assert all(p.returncode == 3 for p in procs), [p.returncode for p in procs]
     lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["fallback"] is True
+
+
+@pytest.mark.gpu
+def test_comm_init_is_bounded_when_a_rank_never_joins():
+    """gmvae_comm_init (include/gmvae_hip.h): ncclCommInitRank blocks until every rank has joined -- the first real multi-GPU run
+    must FAIL LOUDLY, not hang, if a peer died or the world sizes disagree.  A child process plays rank 0 of a 2-rank world whose
+    rank 1 never arrives: the call comes back with GMVAE_E_TIMEOUT after GMVAE_COMM_INIT_TIMEOUT seconds and the child exits."""
+    import subprocess
+    import sys
+    import time
+    code = ("import ctypes as C, sys, torch\n"
+            "torch.cuda.set_device(0)\n"
+            "from gmvae_amd import _lib as L\n"
+            "buf = C.create_string_buffer(128)\n"
+            "assert L.lib.gmvae_comm_unique_id(L.rccl_path(), buf) == 0\n"
+            "comm = C.c_void_p()\n"
+            "rc = L.lib.gmvae_comm_init(L.rccl_path(), buf, 0, 2, C.byref(comm))\n"
+            "print('rc', rc, flush=True)\n"
+            "import os; os._exit(0 if rc == -7 else 1)\n")
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GMVAE_COMM_INIT_TIMEOUT="4", PYTHONPATH=ROOT)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "rc -7" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-600:])
+    assert 3.0 < time.time() - t0 < 100
