@@ -106,6 +106,7 @@ def check(rc: int, what: str):
 
 
 SCHED_SAFE = 1        # GmvaeDims.sched_flags: only schedules without waits between the workgroups of a launch
+SCHED_EVAL_IMAGES_VALID = 2      # ... forward-only: the images a previous gmvae_forward left in this workspace are current
 
 
 ACTS = {"relu": 0, "tanh": 1, "sigmoid": 2, "elu": 3}       # GMVAE_ACT_*: GmvaeDims.hidden_act

@@ -1836,7 +1836,7 @@ static int run_eval_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w) {
     cx.mark("fwd_x_first_layers", 2.0 * B * D * 2 * EV::H);
   }
   unsigned* const counter = reinterpret_cast<unsigned*>(w.ev_slots + 4 * 1024);
-  {
+  if (!(d.sched_flags & GMVAE_SCHED_EVAL_IMAGES_VALID)) {      // (else: a previous pass on fixed parameters left the images; its last workgroup reset the counter)
     EvalPrepArgs pa;
     pa.Wp = P + L.prior.w[0]; pa.bp = P + L.prior.b[0]; pa.Wg0 = P + G.w[0]; pa.bg0 = P + G.b[0]; pa.Wg1 = P + G.w[1]; pa.bg1 = P + G.b[1];
     pa.Wd0 = P + Dn.w[0]; pa.bd0 = P + Dn.b[0]; pa.Wd1 = P + Dn.w[1]; pa.bd1 = P + Dn.b[1];
@@ -2711,7 +2711,11 @@ int gmvae_forward_profile(const GmvaeDims* dims, int model, const uint8_t* x, co
       if (const char* e = getenv("GMVAE_EVAL_GRAPH_PASSES")) G = atoi(e) >= 1 && atoi(e) <= 64 ? atoi(e) : G;
       if (G > iters) G = iters;
       int r2 = 0;
-      for (int g = 0; g < G && r2 == 0; ++g) r2 = run_step(cx, a);
+      GmvaeDims d2 = *dims;
+      d2.sched_flags |= GMVAE_SCHED_EVAL_IMAGES_VALID;      // passes 2..G of a launch: the parameters cannot have changed in between
+      StepArgs a2 = a;
+      a2.d = &d2;
+      for (int g = 0; g < G && r2 == 0; ++g) r2 = run_step(cx, g == 0 ? a : a2);
       ok = hipStreamEndCapture(cs, &graph) == hipSuccess && r2 == 0 && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
       if (ok) {
         const int nl = (iters + G - 1) / G;

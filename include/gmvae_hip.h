@@ -93,7 +93,11 @@ typedef struct GmvaeDims {
    * a function of the kept activation -- in the data-gradient epilogue). */
   int32_t hidden_act;
 } GmvaeDims;
-enum { GMVAE_SCHED_SAFE = 1 };
+enum { GMVAE_SCHED_SAFE = 1,
+       /* forward-only calls (gmvae_forward): the operand images a previous gmvae_forward left in THIS workspace were built from
+        * the parameters as they still are (an evaluation walks a split batch by batch on fixed parameters): evalf_prep is skipped.
+        * The caller vouches for it; gmvae_amd.Engine tracks every writer of its parameter buffer. */
+       GMVAE_SCHED_EVAL_IMAGES_VALID = 2 };
 enum { GMVAE_ACT_RELU = 0, GMVAE_ACT_TANH = 1, GMVAE_ACT_SIGMOID = 2, GMVAE_ACT_ELU = 3 };
 
 /* One tensor of the flat parameter buffer.  Names are the reference's TF
