@@ -166,14 +166,22 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
     for (int i = tid; i < nb * (D / 16); i += kMT)  // (784 = 49 x 16 bytes per row; rows are 16-byte aligned: 784 % 16 = 0)
       *reinterpret_cast<float4*>(T_x + 4 * i) = *reinterpret_cast<const float4*>(a.x + (long long)bb * D + 16ll * i);
     {
-      const int b = tid >> 4, k = tid & 15;        // 16 lanes per batch row: NB = 32 rows in one pass of the 512 threads
+      // logits: the batch rows' hidden activations and encoder_y's output layer staged in the (not yet used) ring -- a 64-deep dot
+      // product per (row, class) from LDS instead of 64 dependent global loads (3 us of the pass)
+      // (the ring slot that is NOT receiving the next chunk: slot cc & 1 holds -- from the second pass on -- the prefetched chunk)
+      float* const S_h = ring + ((cc + 1) & 1) * (EV::CH * EV::TW);       // [NB][64]
+      float* const S_w = S_h + EV::NB * 64;        // [64][10] + [10]
+      for (int i = tid; i < nb * 16; i += kMT)
+        *reinterpret_cast<float4*>(S_h + 4 * i) = *reinterpret_cast<const float4*>(a.he1 + (long long)bb * H + 4 * i);
+      for (int i = tid; i < H * K + K; i += kMT) S_w[i] = i < H * K ? a.Wy1[i] : a.by1[i - H * K];
+      __syncthreads();
+      const int b = tid >> 4, k = tid & 15;        // 16 lanes per batch row (NB <= 32 rows in one pass of the 512 threads)
       const bool bv = b < nb, kv = k < K;
       float lg = -INFINITY;
       if (bv && kv) {
-        const float* const h = a.he1 + (long long)(bb + b) * H;
-        float acc = a.by1[k];
-#pragma unroll 8
-        for (int j = 0; j < H; ++j) acc = fmaf(h[j], a.Wy1[j * K + k], acc);
+        float acc = S_w[H * K + k];
+#pragma unroll 16
+        for (int j = 0; j < H; ++j) acc = fmaf(S_h[b * 64 + j], S_w[j * K + k], acc);
         lg = acc;
       }
       const float lga[1] = {bv ? lg : (kv ? 0.f : -INFINITY)};
@@ -431,14 +439,23 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
     const float logS = flog((float)S);
     for (int b = wave; b < nb; b += kMW) {
       const float* const rw = a.rows_ws + ((long long)(bb + b) * S) * 4;
-      float mx = -INFINITY;
-      for (int s = lane; s < S; s += 64) mx = fmaxf(mx, ld_sc(rw + 4 * s + 3));
-      mx = Wave64::max(mx);
-      float se = 0.f, nl = 0.f, kl = 0.f;
-      for (int s = lane; s < S; s += 64) {
-        se += fexp(ld_sc(rw + 4 * s + 3) - mx);
-        nl -= ld_sc(rw + 4 * s);
-        kl += ld_sc(rw + 4 * s + 1) - ld_sc(rw + 4 * s + 2);
+      float mx = -INFINITY, se = 0.f, nl = 0.f, kl = 0.f;
+      if (S <= 64) {                               // one sample row per lane: ONE 16-byte agent-scope load each
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (lane < S) { v = granule2_load(reinterpret_cast<const unsigned long long*>(rw + 4 * lane)); asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory"); }
+        const float lw = lane < S ? __uint_as_float(v[3]) : -INFINITY;
+        mx = Wave64::max(lw);
+        se = lane < S ? fexp(lw - mx) : 0.f;
+        nl = lane < S ? -__uint_as_float(v[0]) : 0.f;
+        kl = lane < S ? __uint_as_float(v[1]) - __uint_as_float(v[2]) : 0.f;
+      } else {
+        for (int s = lane; s < S; s += 64) mx = fmaxf(mx, ld_sc(rw + 4 * s + 3));
+        mx = Wave64::max(mx);
+        for (int s = lane; s < S; s += 64) {
+          se += fexp(ld_sc(rw + 4 * s + 3) - mx);
+          nl -= ld_sc(rw + 4 * s);
+          kl += ld_sc(rw + 4 * s + 1) - ld_sc(rw + 4 * s + 2);
+        }
       }
       se = Wave64::sum(se); nl = Wave64::sum(nl); kl = Wave64::sum(kl);
       const float bound = mx + flog(se) - logS;

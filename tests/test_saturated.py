@@ -293,7 +293,8 @@ def test_step_after_300_training_steps_on_structured_pixels(model, Lz, K, H_, B,
           f"sigma_q in [{Cc['sig_q'].min():.2e}, {Cc['sig_q'].max():.2e}]")
 
 
-@pytest.mark.parametrize("B,S,rank", [(256, 50, 0), (100, 7, 3), (37, 1, 5)])
+@pytest.mark.parametrize("B,S,rank", [(256, 50, 0), (100, 7, 3), (37, 1, 5), (9, 100, 2), (300, 64, 0),
+                                          (2100, 2, 0), (4400, 1, 1)])      # (more than 8 batch rows per workgroup: several table passes, the ring primed across them)
 def test_one_launch_evaluation_draws_the_documented_noise_stream(B, S, rank):
     """csrc/evalf.hpp with its OWN Philox draws (eps = u = NULL: what bench.py --config eval_iwae and run_eval time) against the
     oracle on gmvae_noise_fill's arrays for the same (seed, step, global sample rows): a lane of the kernel asks noise_vals for
