@@ -31,7 +31,9 @@ for k, disp in sorted(per.items(), key=lambda kv: -sum(dur.get(d, 0) for d in kv
     cyc = mean("GRBM_GUI_ACTIVE") / 8.0
     line = f"{k[0]} grid {k[1]} n {n}: {t * 1e6:9.1f} us"
     if cyc > 0:
-        line += f"  clock {cyc / t * 1e-9:5.2f} GHz"
+        # GRBM_GUI_ACTIVE also counts the dispatch's set-up and drain: over a launch of a few microseconds "cycles / duration" is not a
+        # clock (round 5's table read 4-14 GHz there) -- printed as active cycles only below 50 us
+        line += f"  clock {cyc / t * 1e-9:5.2f} GHz" if t >= 50e-6 else f"  (active cycles / 8 XCDs {cyc:.3g}: no clock estimate below 50 us)"
         if mean("SQ_VALU_MFMA_BUSY_CYCLES") > 0:
             line += f"  mfma_busy {mean('SQ_VALU_MFMA_BUSY_CYCLES') / (1024.0 * cyc):6.3f} of cycles"
     print(line)
