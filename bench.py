@@ -277,13 +277,13 @@ def main_eval(a):
     if dom[0] == "evalf_rows":
         # the one-launch evaluation (csrc/evalf.hpp): the output layer (64 -> D per sample row) multiplies as exact bf16 piece products
         # (6 per fp32 product), the small layers as fp32 MFMA: priced against the time the two parts would take at their own peaks
-        f_top = 2.0 * B * S * hidden[-1] * D
+        f_top = 2.0 * B * S * (hidden[-1] * D + hidden[0] * 2 * Lz + Lz * hidden[0])      # output layer, q head, decoder hidden layer
         f_small = dom[2] - f_top
         t_ideal = f_small / (PEAK_F32_MFMA_TFLOPS * 1e6) + f_top / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e6)      # us
         pk = dom[2] / t_ideal * 1e-6
         roof.update({"peak": pk, "frac": roof["achieved"] / pk, "frac_of_f32_mfma_peak": roof["achieved"] / PEAK_F32_MFMA_TFLOPS,
                      "piece_products_per_product": 6.0,
-                     "peak_note": f"blended: {f_top / dom[2]:.0%} of the launch's FLOPs (the decoder's output layer) run as 6 exact bf16 piece products per "
+                     "peak_note": f"blended: {f_top / dom[2]:.0%} of the launch's FLOPs (the decoder's two layers and the q head) run as 6 exact bf16 piece products per "
                                   f"fp32 product (dense bf16 peak 2500 / 6 = 416.7 fp32-equivalent TFLOP/s), the rest as fp32 MFMA (157.3): "
                                   f"ideal {t_ideal:.1f} us; measured (tools/evstamps.py): matrix and vector instructions of this kernel do not "
                                   "overlap -- the dense 4-pass bf16 MFMAs leave no issue shadow -- so its time is the SUM of both"})

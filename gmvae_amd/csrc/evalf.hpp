@@ -12,7 +12,7 @@
 // the lane that computed them; row reductions (softmax, the row sums of the log-densities) are two lane shuffles (lk pairs).
 // The Philox stream falls the same way: quad 4 t + lk of row j is the four eps values that lane needs for tile t.
 // The decoder's output layer (64 -> 784: 77 % of the matrix work) streams its 200 KB weight image through a two-chunk LDS ring
-// (LDS-DMA, 7 chunks of 7 column tiles) shared by the workgroup's 8 waves -- the only workgroup-wide synchronisation: one barrier
+// (LDS-DMA, 10 chunks of 5 column tiles) shared by the workgroup's 8 waves -- the only workgroup-wide synchronisation: one barrier
 // per chunk -- and ends in a Bernoulli epilogue of ten issue slots per logit instead of the general kernel's 36:
 //     x l - softplus(l) = [x l - max(l, 0)] - log(1 + e^-|l|)
 //   * the bracket is exact in fp32 and <= 0, small unless the pixel is mispredicted: it sums without cancellation;
@@ -23,45 +23,48 @@
 //
 // The output layer multiplies as bf16 piece products (hi + mid + lo of either operand reproduce its 24-bit significand; 6 of
 // the 9 piece products per k step, the dropped ones <= 2^-24 of the product: the arithmetic of dwadam.hpp's and gemm.hpp's triples),
-// 12 v_mfma_f32_16x16x32_bf16 (192 cycles) per tile instead of 16 v_mfma_f32_16x16x4_f32 (512): the layer then runs at the rate
-// the 8 waves can read weight pieces from LDS (6 KB per wave and tile).  The small layers stay fp32 MFMA.
+// 12 v_mfma_f32_16x16x32_bf16 (192 cycles) per tile instead of 16 v_mfma_f32_16x16x4_f32 (512); so do the q head and the decoder's
+// hidden layer (their pieces live in the LDS image); the two layers whose contraction is y (10 classes) stay fp32 MFMA.
 #pragma once
 #include "mega3.hpp"
 
 namespace gmvae {
 
 struct EV {
-  static constexpr int H = 64, L = 64, K = 10, D = 784, L2 = 128, NT = 49, CH = 7;     // 49 column tiles of 16 in 7 chunks of 7
-  // small-layer operand image (floats): element (k, n) of a [Kd x N] weight at ((k >> 2) * N + n) * 4 + (k & 3)
-  static constexpr int Wp = 0;                     // prior head:           16 (10) -> 128
-  static constexpr int Wg0y = Wp + 16 * 128;       // encoder_gmm layer 0, y rows: 16 (10) -> 64
-  static constexpr int Wg1 = Wg0y + 16 * 64;       // q head:               64 -> 128
-  static constexpr int Wd0 = Wg1 + 64 * 128;       // decoder hidden:       64 -> 64
-  static constexpr int b_p = Wd0 + 64 * 64;
+  static constexpr int H = 64, L = 64, K = 10, D = 784, L2 = 128;
+  static constexpr int NT = 49, CH = 5, NCH = 10, NTP = NCH * CH;      // 49 column tiles of 16, streamed in 10 chunks of 5 (the 50th tile is padding)
+  // A 64-deep layer's weight as THREE bf16 planes (hi, mid, lo: truncation splits with exact residuals, so hi + mid + lo is the fp32
+  // weight bit for bit), in tiles of 16 output columns: tile T at T * TW floats; plane p at + p * 512; in a plane the 16-byte unit of
+  // (k32 step m, lane group lk, column n) at ((m * 4 + lk) * 16 + n) * 4 floats holds the eight contraction indices
+  // k = 16 (2 m + (e >> 2)) + 4 lk + (e & 3), e = 0..7 -- the columns of the layer's INPUT that lane (row, lk) holds in its
+  // accumulators of tiles 2 m and 2 m + 1 (v_mfma_f32_16x16x32_bf16's eight-per-lane operands: WHICH index is (lane group,
+  // element) is free as long as A and B agree).
+  static constexpr int TW = 3 * 512;
+  // LDS-resident image (floats).  The two layers whose contraction is y (10 classes) stay fp32 MFMA: element (k, n) of a [16 x N]
+  // weight at ((k >> 2) * N + n) * 4 + (k & 3); the q head and the decoder's hidden layer as piece planes.
+  static constexpr int Wp = 0;                     // prior head:           16 (10) -> 128, fp32
+  static constexpr int Wg0y = Wp + 16 * 128;       // encoder_gmm layer 0, y rows: 16 (10) -> 64, fp32
+  static constexpr int Wg1 = Wg0y + 16 * 64;       // q head:               64 -> 128: 8 tiles of pieces
+  static constexpr int Wd0 = Wg1 + 8 * TW;         // decoder hidden:       64 -> 64: 4 tiles of pieces
+  static constexpr int b_p = Wd0 + 4 * TW;
   static constexpr int b_g0 = b_p + 128;
   static constexpr int b_g1 = b_g0 + 64;
   static constexpr int b_d0 = b_g1 + 128;
-  static constexpr int img = (b_d0 + 64 + 255) / 256 * 256;      // 15,872 floats = 62 KB, DMA'd into LDS once per workgroup
-  // global only: the output layer's weight as THREE bf16 planes (hi, mid, lo: truncation splits with exact residuals, so
-  // hi + mid + lo is the fp32 weight bit for bit).  Tile T (16 columns) at d1 + T * TW floats; plane p at + p * 512; in a plane the
-  // 16-byte unit of (k32 step m, lane group lk, column n) at ((m * 4 + lk) * 16 + n) * 4 floats holds the eight contraction
-  // indices k = 16 (2 m + (e >> 2)) + 4 lk + (e & 3), e = 0..7 -- the columns of the decoder's hidden layer that lane (row, lk)
-  // holds in its accumulators of tiles 2 m and 2 m + 1 (v_mfma_f32_16x16x32_bf16's eight-per-lane operands: WHICH index is
-  // (lane group, element) is free as long as A and B agree).
-  static constexpr int TW = 3 * 512;
+  static constexpr int img = (b_d0 + 64 + 255) / 256 * 256;      // 22,016 floats = 86 KB, DMA'd into LDS once per workgroup
+  // global only: the output layer's pieces (64 -> 784), tile T at d1 + T * TW, streamed through the ring
   static constexpr int d1 = img;
-  static constexpr int b_d1 = d1 + NT * TW;        // [784]: bias + gen_bias_init
-  static constexpr int total = b_d1 + 784;
+  static constexpr int b_d1 = d1 + NTP * TW;       // [800]: bias + gen_bias_init (zero beyond 784)
+  static constexpr int total = b_d1 + 800;
   // LDS map
   static constexpr int NB = 8;                     // batch rows per table pass
-  static constexpr int ring = img;                 // 2 x [7 tiles][TW]
+  static constexpr int ring = img;                 // 2 x [5 tiles][TW]
   static constexpr int T_lg = ring + 2 * CH * TW;  // [NB][16] logits (-inf beyond K)
   static constexpr int T_gx = T_lg + NB * 16;      // [NB][64]
   static constexpr int T_ne = T_gx + NB * 64;      // [NB]
   static constexpr int red = T_ne + NB;            // [8 waves][4]
-  static constexpr int B1 = red + 32;              // [784] the output layer's bias (+ gen_bias_init)
-  static constexpr int T_x = B1 + 784;             // [NB][784] bytes: the pass's batch rows of x
-  static constexpr int lds = T_x + NB * 784 / 4;
+  static constexpr int B1 = red + 32;              // [800] the output layer's bias (+ gen_bias_init)
+  static constexpr int T_x = B1 + 800;             // [NB][784] bytes (+ 16): the pass's batch rows of x
+  static constexpr int lds = T_x + NB * 784 / 4 + 4;
 };
 static_assert(EV::lds * 4 <= 160 * 1024, "LDS budget");
 
@@ -96,29 +99,33 @@ __global__ __launch_bounds__(256) void evalf_prep(const EvalPrepArgs a) {
   float v = 0.f;
   auto kn = [](const int idx, const int N, int& k, int& n) { const int q = idx >> 2; k = 4 * (q / N) + (idx & 3); n = q % N; };
   int k, n;
+  // one float of a piece plane = two bf16 pieces (elements el, el + 1 of a lane's eight) of W[k][16 T + n], W row-major [64][ldw]
+  auto plane = [](const float* W, const int ldw, const int ncols, const int off) -> float {
+    const int T = off / EV::TW, idx = off % EV::TW;
+    const int pl = idx >> 9, bi = (idx & 511) * 2;
+    const int m = bi >> 9, lk = (bi >> 7) & 3, ln = (bi >> 3) & 15, el = bi & 7;
+    if (16 * T + ln >= ncols) return 0.f;
+    unsigned pc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kk = 16 * (2 * m + ((el + j) >> 2)) + 4 * lk + ((el + j) & 3);
+      float r = W[kk * ldw + 16 * T + ln];
+      for (int q = 0; q < pl; ++q) r -= __uint_as_float(__float_as_uint(r) & 0xffff0000u);       // exact residuals
+      pc[j] = __float_as_uint(r) >> 16;
+    }
+    return __uint_as_float(pc[0] | (pc[1] << 16));
+  };
   if (e < EV::Wg0y) { kn(e - EV::Wp, 128, k, n); v = k < EV::K ? a.Wp[k * 128 + n] : 0.f; }
   else if (e < EV::Wg1) { kn(e - EV::Wg0y, 64, k, n); v = k < EV::K ? a.Wg0[(EV::D + k) * 64 + n] : 0.f; }
-  else if (e < EV::Wd0) { kn(e - EV::Wg1, 128, k, n); v = a.Wg1[k * 128 + n]; }
-  else if (e < EV::b_p) { kn(e - EV::Wd0, 64, k, n); v = a.Wd0[k * 64 + n]; }
+  else if (e < EV::Wd0) v = plane(a.Wg1, 128, 128, e - EV::Wg1);
+  else if (e < EV::b_p) v = plane(a.Wd0, 64, 64, e - EV::Wd0);
   else if (e < EV::b_g0) v = a.bp[e - EV::b_p];
   else if (e < EV::b_g1) v = a.bg0[e - EV::b_g0];
   else if (e < EV::b_d0) v = a.bg1[e - EV::b_g1];
   else if (e < EV::b_d0 + 64) v = a.bd0[e - EV::b_d0];
   else if (e < EV::d1) v = 0.f;
-  else if (e < EV::b_d1) {                         // one float = two bf16 pieces (elements e, e + 1 of a lane's eight)
-    const int T = (e - EV::d1) / EV::TW, idx = (e - EV::d1) % EV::TW;
-    const int pl = idx >> 9, bi = (idx & 511) * 2;
-    const int m = bi >> 9, lk = (bi >> 7) & 3, ln = (bi >> 3) & 15, el = bi & 7;
-    unsigned pc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int kk = 16 * (2 * m + ((el + j) >> 2)) + 4 * lk + ((el + j) & 3);
-      float r = a.Wd1[kk * EV::D + 16 * T + ln];
-      for (int q = 0; q < pl; ++q) r -= __uint_as_float(__float_as_uint(r) & 0xffff0000u);       // exact residuals
-      pc[j] = __float_as_uint(r) >> 16;
-    }
-    v = __uint_as_float(pc[0] | (pc[1] << 16));
-  } else v = a.bd1[e - EV::b_d1] + a.gen_bias;
+  else if (e < EV::b_d1) v = plane(a.Wd1, EV::D, EV::D, e - EV::d1);
+  else v = e - EV::b_d1 < EV::D ? a.bd1[e - EV::b_d1] + a.gen_bias : 0.f;
   a.img[e] = v;
 }
 
@@ -133,6 +140,41 @@ __device__ __forceinline__ f32x4 ev_mfma4(const float4 a, const f32x4 b, f32x4 a
 }
 __device__ __forceinline__ f32x4 ev_ld(const float* p) { const float4 v = *reinterpret_cast<const float4*>(p); return f32x4{v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ f32x4 ev_relu(f32x4 v) { return f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])}; }
+typedef __bf16 ev_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned ev_u32x4 __attribute__((ext_vector_type(4)));
+// a layer's 64-wide input (four accumulator tiles of a lane) as the B operands of the two k32 steps, in three bf16 pieces
+struct EvPieces { ev_u32x4 h[2], m[2], l[2]; };
+__device__ __forceinline__ void ev_split(const f32x4 (&v)[4], EvPieces& p) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {               // elements e = 2 jp, 2 jp + 1: tile 2 m + (jp >> 1), components 2 (jp & 1), + 1
+      const float v0 = v[2 * m + (jp >> 1)][2 * (jp & 1)], v1 = v[2 * m + (jp >> 1)][2 * (jp & 1) + 1];
+      p.h[m][jp] = pack_hi16(v1, v0);
+      const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u), r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
+      p.m[m][jp] = pack_hi16(r1, r0);
+      const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+      p.l[m][jp] = pack_hi16(s1, s0);
+    }
+}
+// one 16-column output tile of a 64-deep layer: 12 piece products (6 of the 9 per k32 step: the dropped ones are <= 2^-24 of the
+// product), smallest first; `tile` = the tile's pieces in LDS + this lane's unit offset ((lk * 16 + ln) * 4 floats)
+__device__ __forceinline__ f32x4 ev_tile6(const float* tile, const EvPieces& b, f32x4 acc) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const ev_bf16x8 Ah = __builtin_bit_cast(ev_bf16x8, *reinterpret_cast<const ev_u32x4*>(tile + m * 256));
+    const ev_bf16x8 Am = __builtin_bit_cast(ev_bf16x8, *reinterpret_cast<const ev_u32x4*>(tile + 512 + m * 256));
+    const ev_bf16x8 Al = __builtin_bit_cast(ev_bf16x8, *reinterpret_cast<const ev_u32x4*>(tile + 1024 + m * 256));
+    const ev_bf16x8 bh = __builtin_bit_cast(ev_bf16x8, b.h[m]), bm = __builtin_bit_cast(ev_bf16x8, b.m[m]), bl = __builtin_bit_cast(ev_bf16x8, b.l[m]);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bh, acc, 0, 0, 0);
+  }
+  return acc;
+}
 
 template <int MODE>      // 0: the kernel; 1 / 2: timing experiments (tools/evstamps.py): the output layer without its epilogue / without its matrix instructions
 __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
@@ -209,9 +251,9 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
     // instead of once per 8, and a workgroup's 13 panels (200 sample rows) take one round with 7 barriers instead of two.
     for (int p0 = 0; p0 < panels; p0 += 2 * kMW) {
       EV_ST(2 + 4 * min(p0 / (2 * kMW), 2));
-      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 Bh[2][2], Bm[2][2], Bl[2][2];          // [panel][k32 step]: the decoder's hidden layer as bf16 pieces (B operands)
+      typedef ev_bf16x8 bf16x8;
+      typedef ev_u32x4 u32x4;
+      EvPieces Bp[2];                              // per panel: the decoder's hidden layer as bf16 pieces (the output layer's B operands)
       float lqA[2] = {0.f, 0.f}, lpA[2] = {0.f, 0.f};
       bool actv[2], rvA[2];
       long long rowA[2];
@@ -230,7 +272,6 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
         xrA[pi] = reinterpret_cast<const unsigned char*>(T_x) + bj * D + 4 * lk;       // this row's x bytes (LDS)
         float lq = 0.f, lp_ = 0.f;
         if (active) {
-          f32x4 hd[4];
           // ---- y = softmax((logits + Gumbel) / T) (gmvae.py:240): lane (j, lk) holds classes 4 lk + r
           f32x4 y4;
           {
@@ -271,14 +312,13 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
             const f32x4 b0 = ev_ld(img + EV::b_g0 + nt * 16 + 4 * lk), g0 = ev_ld(T_gx + bj * 64 + nt * 16 + 4 * lk);
             hg[nt] = ev_relu(ev_mfma4(w4, y4, b0 + g0));
           }
-          // ---- q head
-  #pragma unroll
-          for (int nt = 0; nt < 8; ++nt) {
-            f32x4 acc = ev_ld(img + EV::b_g1 + nt * 16 + 4 * lk);
-  #pragma unroll
-            for (int t = 0; t < 4; ++t)
-              acc = ev_mfma4(*reinterpret_cast<const float4*>(img + EV::Wg1 + (((t * 4 + lk) * 128 + nt * 16 + ln) << 2)), hg[t], acc);
-            qp[nt] = acc;
+          // ---- q head (exact bf16 piece products: ev_tile6)
+          {
+            EvPieces hp;
+            ev_split(hg, hp);
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+              qp[nt] = ev_tile6(img + EV::Wg1 + nt * EV::TW + ((lk * 16 + ln) << 2), hp, ev_ld(img + EV::b_g1 + nt * 16 + 4 * lk));
           }
           // ---- z = mu + sigma eps, log q(z|x,y), log p(z|y) (gmvae.py:248,258; base.py:66-72)
           f32x4 z[4];
@@ -306,30 +346,20 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
             if (a.z_out && rv) *reinterpret_cast<float4*>(a.z_out + row * L + 16 * t + 4 * lk) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
           }
           lqA[pi] = ev_lk_sum(lq); lpA[pi] = ev_lk_sum(lp_);
-          // ---- decoder hidden layer (gmvae.py:251)
-  #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            f32x4 acc = ev_ld(img + EV::b_d0 + nt * 16 + 4 * lk);
-  #pragma unroll
-            for (int t = 0; t < 4; ++t)
-              acc = ev_mfma4(*reinterpret_cast<const float4*>(img + EV::Wd0 + (((t * 4 + lk) * 64 + nt * 16 + ln) << 2)), z[t], acc);
-            hd[nt] = ev_relu(acc);
+          // ---- decoder hidden layer (gmvae.py:251), its output as the pieces the output layer multiplies
+          {
+            EvPieces zp;
+            ev_split(z, zp);
+            f32x4 hd[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+              hd[nt] = ev_relu(ev_tile6(img + EV::Wd0 + nt * EV::TW + ((lk * 16 + ln) << 2), zp, ev_ld(img + EV::b_d0 + nt * 16 + 4 * lk)));
+            ev_split(hd, Bp[pi]);
           }
-  #pragma unroll
-          for (int m = 0; m < 2; ++m)
-  #pragma unroll
-            for (int jp = 0; jp < 4; ++jp) {         // elements e = 2 jp, 2 jp + 1: tile 2 m + (jp >> 1), components 2 (jp & 1), + 1
-              const float v0 = hd[2 * m + (jp >> 1)][2 * (jp & 1)], v1 = hd[2 * m + (jp >> 1)][2 * (jp & 1) + 1];
-              Bh[pi][m][jp] = pack_hi16(v1, v0);
-              const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffff0000u), r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffff0000u);
-              Bm[pi][m][jp] = pack_hi16(r1, r0);
-              const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-              Bl[pi][m][jp] = pack_hi16(s1, s0);
-            }
         }
       }
       EV_ST(3 + 4 * min(p0 / (2 * kMW), 2));
-      // ---- output layer + Independent(Bernoulli).log_prob (gmvae.py:254): 7 chunks of 7 column tiles through the LDS ring.
+      // ---- output layer + Independent(Bernoulli).log_prob (gmvae.py:254): 10 chunks of 5 column tiles through the LDS ring.
       // A tile: 12 piece products per panel (6 of the 9 per k32 step: the dropped ones are <= 2^-24 of the product), smallest
       // first.  One tile per iteration, software-pipelined: the weight pieces of tile i + 1 are requested from LDS while tile i's
       // matrix instructions run, each followed by a piece of tile i - 1's epilogue (sched_barrier: nothing moves across).
@@ -340,15 +370,15 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
       f32x2_t prod2[2] = {{1.f, 1.f}, {1.f, 1.f}};
       const bool any = actv[0];                    // (panel 1 is active only if panel 0 is)
 #pragma unroll 1
-      for (int c = 0; c < EV::CH; ++c, ++cc) {
+      for (int c = 0; c < EV::NCH; ++c, ++cc) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // chunk cc has landed for every wave; everyone is done with chunk cc - 1
-        const bool more = c + 1 < EV::CH || p0 + 2 * kMW < panels || bb + EV::NB < b_end;
-        if (more) dma_copy_m(ring + ((cc + 1) & 1) * (EV::CH * EV::TW), gd1 + ((c + 1) % EV::CH) * (EV::CH * EV::TW), EV::CH * EV::TW, wave, lane);
+        const bool more = c + 1 < EV::NCH || p0 + 2 * kMW < panels || bb + EV::NB < b_end;
+        if (more) dma_copy_m(ring + ((cc + 1) & 1) * (EV::CH * EV::TW), gd1 + ((c + 1) % EV::NCH) * (EV::CH * EV::TW), EV::CH * EV::TW, wave, lane);
         if (any) {
 #pragma unroll
           for (int pi = 0; pi < 2; ++pi) {
-            lg2[pi] += __builtin_amdgcn_logf(prod2[pi][0] * prod2[pi][1]);      // (<= 28 factors in (1, 2] since the last one)
+            lg2[pi] += __builtin_amdgcn_logf(prod2[pi][0] * prod2[pi][1]);      // (<= 20 factors in (1, 2] since the last one)
             prod2[pi] = f32x2_t{1.f, 1.f};
           }
           const float* const cb = ring + (cc & 1) * (EV::CH * EV::TW) + ((lk * 16 + ln) << 2);
@@ -369,6 +399,7 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
             unsigned xnext[2];
 #pragma unroll
             for (int pi = 0; pi < 2; ++pi) xnext[pi] = *reinterpret_cast<const unsigned*>(xrA[pi] + 16 * Tn);
+            if (c * EV::CH + i < EV::NT) {         // (uniform: the 50th tile is padding)
 #pragma unroll
             for (int pi = 0; pi < 2; ++pi) {
               if (pi == 1 && !actv[1]) break;      // (wave-uniform)
@@ -395,7 +426,7 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
 #pragma unroll
               for (int m = 0; m < 2; ++m) {
                 const bf16x8 Ah = __builtin_bit_cast(bf16x8, fr[3 * m]), Am = __builtin_bit_cast(bf16x8, fr[3 * m + 1]), Al = __builtin_bit_cast(bf16x8, fr[3 * m + 2]);
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, Bh[pi][m]), bm = __builtin_bit_cast(bf16x8, Bm[pi][m]), bl = __builtin_bit_cast(bf16x8, Bl[pi][m]);
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, Bp[pi].h[m]), bm = __builtin_bit_cast(bf16x8, Bp[pi].m[m]), bl = __builtin_bit_cast(bf16x8, Bp[pi].l[m]);
                 if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, bh, acc, 0, 0, 0); piece(6 * m + 0);
                 if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, bm, acc, 0, 0, 0); piece(6 * m + 1);
                 if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bl, acc, 0, 0, 0); piece(6 * m + 2);
@@ -404,6 +435,7 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
                 if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bh, acc, 0, 0, 0); piece(6 * m + 5);
               }
               accp[pi] = acc; xprev[pi] = xcur[pi]; xcur[pi] = xnext[pi];
+            }
             }
             bias = biasn;
 #pragma unroll
