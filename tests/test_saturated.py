@@ -364,3 +364,43 @@ def test_evaluation_reuses_its_operand_images_only_while_the_parameters_stand():
     e.load_state_dict(sd)
     v4 = check("load_state_dict")
     assert len({v0, v1, v2, v3, v4}) == 5
+
+
+def _evalf_random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        S = int(rng.choice([1, 2, 3, 5, 9, 16, 17, 33, 50, 64, 65, 130]))
+        B = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 40, 255, 256, 257, 300, 513, 1024])) if S <= 17 else int(rng.choice([1, 3, 8, 31, 64, 100, 256]))
+        out.append((B, S, float(rng.choice([1.0, 0.5, 2.0])), float(rng.choice([0.0, -0.4, 1.3])), bool(rng.integers(0, 2)), int(rng.integers(0, 4))))
+    return out
+
+
+EVALF_RANDOM = _evalf_random_cases(24, 20261005)
+
+
+@pytest.mark.parametrize("B,S,temp,gbias,philox,rank", EVALF_RANDOM, ids=[f"B{c[0]}-S{c[1]}-T{c[2]}-g{c[3]}-{'philox' if c[4] else 'ext'}-r{c[5]}" for c in EVALF_RANDOM])
+def test_one_launch_evaluation_equals_the_general_schedule_on_random_shapes(B, S, temp, gbias, philox, rank, monkeypatch):
+    """csrc/evalf.hpp against the general / chain schedules (GMVAE_NO_EVALF=1: kernels that meet the oracle elsewhere) on random
+    batch sizes and sample counts -- fewer batch rows than workgroups, panels that straddle batch rows, ragged last panels, more
+    than 64 samples, one row -- with its own Philox draws or external noise, a row offset, other temperatures and bias_init:
+    every output (row terms, z, y, logits, the four sums) to fp32 rounding of two different summation orders."""
+    from gmvae_amd.engine import Engine
+    e = Engine("gmvae", 784, 64, 10, [64], n_samples=S, temperature=temp, gen_bias_init=gbias, random_seed=B * 7 + S)
+    e.rank = rank
+    e.global_step = 3
+    rng = np.random.default_rng(B * 131 + S)
+    x = torch.from_numpy((rng.random((B, 784)) < 0.87).astype(np.uint8)).cuda()
+    eps = u = None
+    if not philox:
+        eps = torch.from_numpy(rng.standard_normal((B * S, 64)).astype(np.float32))
+        u = torch.from_numpy(np.clip(rng.random((B * S, 10)).astype(np.float32), O.TINY_F32, U_MAX))
+    a_ = {k: (v.cpu().numpy() if v is not None else None) for k, v in e.forward(x, eps, u).items()}
+    monkeypatch.setenv("GMVAE_NO_EVALF", "1")
+    b_ = {k: (v.cpu().numpy() if v is not None else None) for k, v in e.forward(x, eps, u).items()}
+    assert not np.array_equal(a_["rows"], b_["rows"]) or B * S < 4          # (two different kernels ran)
+    np.testing.assert_allclose(a_["z"], b_["z"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(a_["y"], b_["y"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(a_["logits"], b_["logits"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(a_["rows"], b_["rows"], rtol=2e-5, atol=2e-3)
+    np.testing.assert_allclose(a_["tail"][:5], b_["tail"][:5], rtol=2e-6, atol=1e-3)
