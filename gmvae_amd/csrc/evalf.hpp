@@ -176,6 +176,117 @@ __device__ __forceinline__ f32x4 ev_tile6(const float* tile, const EvPieces& b, 
   return acc;
 }
 
+// The decoder's output layer + Independent(Bernoulli).log_prob for the (up to) two panels of a wave; every wave of the workgroup
+// calls it (the chunk barriers), `actv` says which panels exist.  lpx[pi] = this LANE's share of sum_d x l - softplus(l) of its row
+// (the caller adds the four lk lanes).  cc: chunks streamed so far (ring slot cc & 1 holds chunk 0 on entry); more_after: another
+// call follows (the last chunk then prefetches chunk 0 again).
+template <int MODE>
+__device__ __forceinline__ void ev_output_layer(const float* const gd1, float* const ring, const float* const B1, unsigned& cc,
+                                                const bool more_after, const EvPieces (&Bp)[2], const bool (&actv)[2],
+                                                const unsigned char* const (&xrA)[2], const int wave, const int lane, float (&lpx)[2]) {
+  typedef ev_bf16x8 bf16x8;
+  typedef ev_u32x4 u32x4;
+  const int ln = lane & 15, lk = lane >> 4;
+  // ---- output layer + Independent(Bernoulli).log_prob (gmvae.py:254): 10 chunks of 5 column tiles through the LDS ring.
+  // A tile: 12 piece products per panel (6 of the 9 per k32 step: the dropped ones are <= 2^-24 of the product), smallest
+  // first.  One tile per iteration, software-pipelined: the weight pieces of tile i + 1 are requested from LDS while tile i's
+  // matrix instructions run, each followed by a piece of tile i - 1's epilogue (sched_barrier: nothing moves across).
+  f32x2_t brk2[2] = {{0.f, 0.f}, {0.f, 0.f}};    // per panel: sum of [x l - max(l, 0)] (two chains: packed fp32)
+  float lg2[2] = {0.f, 0.f};                   // ... sum of log2 prod (1 + e^-|l|)
+  f32x4 accp[2] = {{-1e30f, -1e30f, -1e30f, -1e30f}, {-1e30f, -1e30f, -1e30f, -1e30f}};   // "tile -1": with x = 0 its epilogue adds exactly nothing
+  unsigned xprev[2] = {0u, 0u};
+  f32x2_t prod2[2] = {{1.f, 1.f}, {1.f, 1.f}};
+  const bool any = actv[0];                    // (panel 1 is active only if panel 0 is)
+#pragma unroll 1
+  for (int c = 0; c < EV::NCH; ++c, ++cc) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                           // chunk cc has landed for every wave; everyone is done with chunk cc - 1
+    const bool more = c + 1 < EV::NCH || more_after;
+    if (more) dma_copy_m(ring + ((cc + 1) & 1) * (EV::CH * EV::TW), gd1 + ((c + 1) % EV::NCH) * (EV::CH * EV::TW), EV::CH * EV::TW, wave, lane);
+    if (any) {
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        lg2[pi] += __builtin_amdgcn_logf(prod2[pi][0] * prod2[pi][1]);      // (<= 20 factors in (1, 2] since the last one)
+        prod2[pi] = f32x2_t{1.f, 1.f};
+      }
+      const float* const cb = ring + (cc & 1) * (EV::CH * EV::TW) + ((lk * 16 + ln) << 2);
+      u32x4 fr[6];                             // [m][hi, mid, lo]
+#pragma unroll
+      for (int q = 0; q < 6; ++q) fr[q] = *reinterpret_cast<const u32x4*>(cb + (q % 3) * 512 + (q / 3) * 256);
+      f32x4 bias = ev_ld(B1 + 16 * (c * EV::CH) + 4 * lk);
+      unsigned xcur[2];
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) xcur[pi] = *reinterpret_cast<const unsigned*>(xrA[pi] + 16 * (c * EV::CH));
+#pragma unroll
+      for (int i = 0; i < EV::CH; ++i) {       // (unrolled: the loop-carried operand registers rename instead of moving)
+        const int in = min(i + 1, EV::CH - 1), Tn = c * EV::CH + in;
+        u32x4 fn[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) fn[q] = *reinterpret_cast<const u32x4*>(cb + in * EV::TW + (q % 3) * 512 + (q / 3) * 256);
+        const f32x4 biasn = ev_ld(B1 + 16 * Tn + 4 * lk);
+        unsigned xnext[2];
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) xnext[pi] = *reinterpret_cast<const unsigned*>(xrA[pi] + 16 * Tn);
+        if (c * EV::CH + i < EV::NT) {         // (uniform: the 50th tile is padding)
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+          if (pi == 1 && !actv[1]) break;      // (wave-uniform)
+          f32x4 acc = bias;
+          f32x2_t e2_[2];
+          auto piece = [&](const int k) {      // pair pr = k / 6 of the previous tile's four logits, stage k % 6 (packed fp32 where the ISA has it)
+            const int pr = k / 6, st = k % 6;
+            if (MODE == 1) { __builtin_amdgcn_sched_barrier(0); return; }
+            const f32x2_t lam = {accp[pi][2 * pr], accp[pi][2 * pr + 1]};
+            if (st == 0) {
+              const f32x2_t xf = {(float)((xprev[pi] >> (16 * pr)) & 0xffu), (float)((xprev[pi] >> (16 * pr + 8)) & 0xffu)};
+              const f32x2_t mx = {__builtin_amdgcn_fmed3f(lam[0], 0.f, INFINITY), __builtin_amdgcn_fmed3f(lam[1], 0.f, INFINITY)};
+              brk2[pi] += xf * lam - mx;       // x l - max(l, 0): exact, <= 0
+            } else if (st == 1) {
+              e2_[pr][0] = fexp(-fabsf(lam[0]));
+            } else if (st == 2) {
+              e2_[pr][1] = fexp(-fabsf(lam[1]));
+            } else if (st == 3) {
+              prod2[pi] = prod2[pi] * e2_[pr] + prod2[pi];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          };
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, fr[3 * m]), Am = __builtin_bit_cast(bf16x8, fr[3 * m + 1]), Al = __builtin_bit_cast(bf16x8, fr[3 * m + 2]);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, Bp[pi].h[m]), bm = __builtin_bit_cast(bf16x8, Bp[pi].m[m]), bl = __builtin_bit_cast(bf16x8, Bp[pi].l[m]);
+            if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, bh, acc, 0, 0, 0); piece(6 * m + 0);
+            if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, bm, acc, 0, 0, 0); piece(6 * m + 1);
+            if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bl, acc, 0, 0, 0); piece(6 * m + 2);
+            if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, bh, acc, 0, 0, 0); piece(6 * m + 3);
+            if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bm, acc, 0, 0, 0); piece(6 * m + 4);
+            if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bh, acc, 0, 0, 0); piece(6 * m + 5);
+          }
+          accp[pi] = acc; xprev[pi] = xcur[pi]; xcur[pi] = xnext[pi];
+        }
+        }
+        bias = biasn;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) fr[q] = fn[q];
+      }
+    }
+  }
+#pragma unroll
+  for (int pi = 0; pi < 2; ++pi) {
+    lpx[pi] = 0.f;
+    if (!actv[pi]) break;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                  // the last tile's epilogue
+      const float lam = accp[pi][r];
+      const float xf = (float)((xprev[pi] >> (8 * r)) & 0xffu);
+      brk2[pi][r & 1] += fmaf(xf, lam, -fmaxf(lam, 0.f));
+      prod2[pi][r & 1] = fmaf(prod2[pi][r & 1], fexp(-fabsf(lam)), prod2[pi][r & 1]);
+    }
+    lg2[pi] += __builtin_amdgcn_logf(prod2[pi][0] * prod2[pi][1]);
+    lpx[pi] = (brk2[pi][0] + brk2[pi][1]) - 0.693147180559945309f * lg2[pi];
+  }
+}
+
 template <int MODE>      // 0: the kernel; 1 / 2: timing experiments (tools/evstamps.py): the output layer without its epilogue / without its matrix instructions
 __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -359,103 +470,13 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
         }
       }
       EV_ST(3 + 4 * min(p0 / (2 * kMW), 2));
-      // ---- output layer + Independent(Bernoulli).log_prob (gmvae.py:254): 10 chunks of 5 column tiles through the LDS ring.
-      // A tile: 12 piece products per panel (6 of the 9 per k32 step: the dropped ones are <= 2^-24 of the product), smallest
-      // first.  One tile per iteration, software-pipelined: the weight pieces of tile i + 1 are requested from LDS while tile i's
-      // matrix instructions run, each followed by a piece of tile i - 1's epilogue (sched_barrier: nothing moves across).
-      f32x2_t brk2[2] = {{0.f, 0.f}, {0.f, 0.f}};    // per panel: sum of [x l - max(l, 0)] (two chains: packed fp32)
-      float lg2[2] = {0.f, 0.f};                   // ... sum of log2 prod (1 + e^-|l|)
-      f32x4 accp[2] = {{-1e30f, -1e30f, -1e30f, -1e30f}, {-1e30f, -1e30f, -1e30f, -1e30f}};   // "tile -1": with x = 0 its epilogue adds exactly nothing
-      unsigned xprev[2] = {0u, 0u};
-      f32x2_t prod2[2] = {{1.f, 1.f}, {1.f, 1.f}};
-      const bool any = actv[0];                    // (panel 1 is active only if panel 0 is)
-#pragma unroll 1
-      for (int c = 0; c < EV::NCH; ++c, ++cc) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                           // chunk cc has landed for every wave; everyone is done with chunk cc - 1
-        const bool more = c + 1 < EV::NCH || p0 + 2 * kMW < panels || bb + EV::NB < b_end;
-        if (more) dma_copy_m(ring + ((cc + 1) & 1) * (EV::CH * EV::TW), gd1 + ((c + 1) % EV::NCH) * (EV::CH * EV::TW), EV::CH * EV::TW, wave, lane);
-        if (any) {
-#pragma unroll
-          for (int pi = 0; pi < 2; ++pi) {
-            lg2[pi] += __builtin_amdgcn_logf(prod2[pi][0] * prod2[pi][1]);      // (<= 20 factors in (1, 2] since the last one)
-            prod2[pi] = f32x2_t{1.f, 1.f};
-          }
-          const float* const cb = ring + (cc & 1) * (EV::CH * EV::TW) + ((lk * 16 + ln) << 2);
-          u32x4 fr[6];                             // [m][hi, mid, lo]
-#pragma unroll
-          for (int q = 0; q < 6; ++q) fr[q] = *reinterpret_cast<const u32x4*>(cb + (q % 3) * 512 + (q / 3) * 256);
-          f32x4 bias = ev_ld(B1 + 16 * (c * EV::CH) + 4 * lk);
-          unsigned xcur[2];
-#pragma unroll
-          for (int pi = 0; pi < 2; ++pi) xcur[pi] = *reinterpret_cast<const unsigned*>(xrA[pi] + 16 * (c * EV::CH));
-#pragma unroll
-          for (int i = 0; i < EV::CH; ++i) {       // (unrolled: the loop-carried operand registers rename instead of moving)
-            const int in = min(i + 1, EV::CH - 1), Tn = c * EV::CH + in;
-            u32x4 fn[6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) fn[q] = *reinterpret_cast<const u32x4*>(cb + in * EV::TW + (q % 3) * 512 + (q / 3) * 256);
-            const f32x4 biasn = ev_ld(B1 + 16 * Tn + 4 * lk);
-            unsigned xnext[2];
-#pragma unroll
-            for (int pi = 0; pi < 2; ++pi) xnext[pi] = *reinterpret_cast<const unsigned*>(xrA[pi] + 16 * Tn);
-            if (c * EV::CH + i < EV::NT) {         // (uniform: the 50th tile is padding)
-#pragma unroll
-            for (int pi = 0; pi < 2; ++pi) {
-              if (pi == 1 && !actv[1]) break;      // (wave-uniform)
-              f32x4 acc = bias;
-              f32x2_t e2_[2];
-              auto piece = [&](const int k) {      // pair pr = k / 6 of the previous tile's four logits, stage k % 6 (packed fp32 where the ISA has it)
-                const int pr = k / 6, st = k % 6;
-                if (MODE == 1) { __builtin_amdgcn_sched_barrier(0); return; }
-                const f32x2_t lam = {accp[pi][2 * pr], accp[pi][2 * pr + 1]};
-                if (st == 0) {
-                  const f32x2_t xf = {(float)((xprev[pi] >> (16 * pr)) & 0xffu), (float)((xprev[pi] >> (16 * pr + 8)) & 0xffu)};
-                  const f32x2_t mx = {__builtin_amdgcn_fmed3f(lam[0], 0.f, INFINITY), __builtin_amdgcn_fmed3f(lam[1], 0.f, INFINITY)};
-                  brk2[pi] += xf * lam - mx;       // x l - max(l, 0): exact, <= 0
-                } else if (st == 1) {
-                  e2_[pr][0] = fexp(-fabsf(lam[0]));
-                } else if (st == 2) {
-                  e2_[pr][1] = fexp(-fabsf(lam[1]));
-                } else if (st == 3) {
-                  prod2[pi] = prod2[pi] * e2_[pr] + prod2[pi];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-              };
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int m = 0; m < 2; ++m) {
-                const bf16x8 Ah = __builtin_bit_cast(bf16x8, fr[3 * m]), Am = __builtin_bit_cast(bf16x8, fr[3 * m + 1]), Al = __builtin_bit_cast(bf16x8, fr[3 * m + 2]);
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, Bp[pi].h[m]), bm = __builtin_bit_cast(bf16x8, Bp[pi].m[m]), bl = __builtin_bit_cast(bf16x8, Bp[pi].l[m]);
-                if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, bh, acc, 0, 0, 0); piece(6 * m + 0);
-                if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, bm, acc, 0, 0, 0); piece(6 * m + 1);
-                if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bl, acc, 0, 0, 0); piece(6 * m + 2);
-                if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, bh, acc, 0, 0, 0); piece(6 * m + 3);
-                if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bm, acc, 0, 0, 0); piece(6 * m + 4);
-                if (MODE != 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, bh, acc, 0, 0, 0); piece(6 * m + 5);
-              }
-              accp[pi] = acc; xprev[pi] = xcur[pi]; xcur[pi] = xnext[pi];
-            }
-            }
-            bias = biasn;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) fr[q] = fn[q];
-          }
-        }
-      }
+      float lpxl[2];
+      ev_output_layer<MODE>(gd1, ring, B1, cc, p0 + 2 * kMW < panels || bb + EV::NB < b_end, Bp, actv, xrA, wave, lane, lpxl);
       EV_ST(4 + 4 * min(p0 / (2 * kMW), 2));
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
         if (!actv[pi]) break;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {              // the last tile's epilogue
-          const float lam = accp[pi][r];
-          const float xf = (float)((xprev[pi] >> (8 * r)) & 0xffu);
-          brk2[pi][r & 1] += fmaf(xf, lam, -fmaxf(lam, 0.f));
-          prod2[pi][r & 1] = fmaf(prod2[pi][r & 1], fexp(-fabsf(lam)), prod2[pi][r & 1]);
-        }
-        lg2[pi] += __builtin_amdgcn_logf(prod2[pi][0] * prod2[pi][1]);
-        const float lpx = ev_lk_sum((brk2[pi][0] + brk2[pi][1]) - 0.693147180559945309f * lg2[pi]);
+        const float lpx = ev_lk_sum(lpxl[pi]);
         const float lw = lpx + lpA[pi] - lqA[pi] - T_ne[bjA[pi]];
         if (lk == 0 && rvA[pi]) {
           const float4 o = make_float4(lpx, lqA[pi], lpA[pi], lw);
