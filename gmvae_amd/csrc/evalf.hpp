@@ -83,6 +83,9 @@ struct EvalArgs {
   unsigned* counter;             // arrived workgroups (evalf_prep zeroes it)
   float* tail;                   // [8]: sum_b -bound_b, sum nll, sum kl, sum nent, B
   unsigned long long* dbg;       // diagnostic (GMVAE_EV_STAMPS, tools/evstamps.py): [workgroup][16] device-clock stamps, or null
+  // the VAE family (evalf_rows_v): the encoder's output layer [64][2 L], [2 L] (applied once per batch row); VAE_GMP: the mixture
+  // prior's variables loc [K][L], raw_scale_diag [K][L], mixture_logits [K] (scripts/vae.py:233-244)
+  const float *We1, *be1, *loc, *raw_scale, *mixlog;
 };
 
 // evalf_prep: the operand images from the parameters (one thread per image element) and the arrival counter.
@@ -91,6 +94,7 @@ struct EvalPrepArgs {
   float gen_bias;
   float* img;
   unsigned* counter;
+  int family;                    // 0: GMVAE; 1: the VAE family (only the decoder's sections are built); 2: ... at latent size 2
 };
 __global__ __launch_bounds__(256) void evalf_prep(const EvalPrepArgs a) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -115,10 +119,15 @@ __global__ __launch_bounds__(256) void evalf_prep(const EvalPrepArgs a) {
     }
     return __uint_as_float(pc[0] | (pc[1] << 16));
   };
-  if (e < EV::Wg0y) { kn(e - EV::Wp, 128, k, n); v = k < EV::K ? a.Wp[k * 128 + n] : 0.f; }
+  if (e < EV::Wd0 && a.family) v = 0.f;           // (the VAE family has no y path and no q head over sample rows)
+  else if (e < EV::Wg0y) { kn(e - EV::Wp, 128, k, n); v = k < EV::K ? a.Wp[k * 128 + n] : 0.f; }
   else if (e < EV::Wg1) { kn(e - EV::Wg0y, 64, k, n); v = k < EV::K ? a.Wg0[(EV::D + k) * 64 + n] : 0.f; }
   else if (e < EV::Wd0) v = plane(a.Wg1, 128, 128, e - EV::Wg1);
+  else if (e < EV::b_p && a.family == 2) {         // latent size 2: the decoder's hidden layer as a [16 (2) x 64] fp32 image
+    if (e - EV::Wd0 < 16 * 64) { kn(e - EV::Wd0, 64, k, n); v = k < 2 ? a.Wd0[k * 64 + n] : 0.f; }
+  }
   else if (e < EV::b_p) v = plane(a.Wd0, 64, 64, e - EV::Wd0);
+  else if (e < EV::b_d0 && a.family) v = 0.f;
   else if (e < EV::b_g0) v = a.bp[e - EV::b_p];
   else if (e < EV::b_g1) v = a.bg0[e - EV::b_g0];
   else if (e < EV::b_d0) v = a.bg1[e - EV::b_g1];
@@ -543,6 +552,236 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
     }
   }
 }
+
+
+// evalf_rows_v: the same one-launch evaluation for the VAE family at the reference's sizes (scripts/vae.py:167-185 -- BASELINE
+// configs[0]: VAE, latent 2; configs[1]: VAE_GMP, latent 64, K = 10; also the plain VAE at latent 64).  q(z|x) depends on the batch
+// row alone: the encoder's output layer runs once per batch row (table T_qp), a sample row draws z = mu + sigma eps, takes log q,
+// log p (N(0, I), or the K-component mixture: 16 latent dimensions per lane, components reduced over the four lk lanes, logsumexp
+// in the lane) and the decoder (hidden layer: piece products at L = 64, one fp32 k tile at L = 2; output layer: ev_output_layer).
+struct EVV {
+  static constexpr int imgv = 4 * EV::TW + 64;     // the decoder's hidden layer (pieces or fp32 image) + its bias
+  static constexpr int ring = (imgv + 255) / 256 * 256;
+  static constexpr int T_qp = ring + 2 * EV::CH * EV::TW;     // [NB][128]
+  static constexpr int red = T_qp + EV::NB * 128;
+  static constexpr int B1 = red + 32;
+  static constexpr int T_x = B1 + 800;
+  static constexpr int M_loc = T_x + EV::NB * 784 / 4 + 4;    // [10][64]
+  static constexpr int M_inv = M_loc + 640;
+  static constexpr int M_c = M_inv + 640;          // [16]
+  static constexpr int lds = M_c + 16;
+};
+template <int MODEL, int L>      // MODEL 0: VAE (N(0, I) prior), 1: VAE_GMP (K = 10 mixture prior); L = 2 or 64
+__global__ __launch_bounds__(kMT) void evalf_rows_v(const EvalArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int H = EV::H, D = EV::D, K = 10, L2 = 2 * L, LT = (L + 15) / 16;
+  static_assert(L == 2 || L == 64, "latent sizes of the reference's configurations");
+  static_assert(MODEL == 0 || L == 64, "VAE_GMP: latent 64");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, lk = lane >> 4;
+  const int B = a.B, S = a.S;
+  float* const img = sm;                           // [0, 4 TW): Wd0; then b_d0
+  float* const ring = sm + EVV::ring;
+  float *T_qp = sm + EVV::T_qp, *red = sm + EVV::red, *B1 = sm + EVV::B1, *T_x = sm + EVV::T_x;
+  float *M_loc = sm + EVV::M_loc, *M_inv = sm + EVV::M_inv, *M_c = sm + EVV::M_c;
+  const int nbt = (B + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int b_begin = min(B, (int)blockIdx.x * nbt), b_end = min(B, b_begin + nbt);
+  dma_copy_m(img, a.img + EV::Wd0, 4 * EV::TW, wave, lane);
+  if (tid < 64) img[4 * EV::TW + tid] = a.img[EV::b_d0 + tid];
+  const float* const gd1 = a.img + EV::d1;
+  for (int i = tid; i < 784 / 4; i += kMT) *reinterpret_cast<float4*>(B1 + 4 * i) = *reinterpret_cast<const float4*>(a.img + EV::b_d1 + 4 * i);
+  if (MODEL == 1) {                                // mixture constants (scripts/vae.py:233-244): 1 / s, loc, log w_k - sum log s - L/2 log 2 pi
+    float lnw = 0.f;
+    {
+      float m = -INFINITY;
+      for (int k = 0; k < K; ++k) m = fmaxf(m, a.mixlog[k]);
+      float se = 0.f;
+      for (int k = 0; k < K; ++k) se += expf(a.mixlog[k] - m);
+      lnw = m + logf(se);                          // the normaliser; log w_k = mixlog[k] - lnw
+    }
+    for (int k = wave; k < K; k += kMW) {
+      const float sc = softplusf_(a.raw_scale[k * L + lane % L]);
+      const float iv = 1.f / sc;
+      M_inv[k * 64 + lane] = iv;
+      M_loc[k * 64 + lane] = a.loc[k * L + lane % L];
+      const float ls = Wave64::sum(lane < L ? logf(iv) : 0.f);
+      if (lane == 0) M_c[k] = a.mixlog[k] - lnw + ls - 0.5f * (float)L * kLog2Pi;
+    }
+  }
+  float w_loss = 0.f, w_nl = 0.f, w_kl = 0.f;
+  unsigned cc = 0;
+  bool ring_primed = false;
+  for (int bb = b_begin; bb < b_end; bb += EV::NB) {
+    const int nb = min(EV::NB, b_end - bb);
+    __syncthreads();
+    for (int i = tid; i < nb * (D / 16); i += kMT)
+      *reinterpret_cast<float4*>(T_x + 4 * i) = *reinterpret_cast<const float4*>(a.x + (long long)bb * D + 16ll * i);
+    {
+      // q's parameters of this pass's batch rows: [mu | raw] = relu(x W_e0 + b) W_e1 + b (scripts/vae.py:170, base.py:66-72)
+      float* const S_h = ring + ((cc + 1) & 1) * (EV::CH * EV::TW);       // [NB][64] (the ring slot not receiving a chunk)
+      for (int i = tid; i < nb * 16; i += kMT)
+        *reinterpret_cast<float4*>(S_h + 4 * i) = *reinterpret_cast<const float4*>(a.he1 + (long long)bb * H + 4 * i);
+      __syncthreads();
+      for (int i = tid; i < nb * L2; i += kMT) {
+        const int b = i / L2, col = i - b * L2;
+        float acc = a.be1[col];
+#pragma unroll 16
+        for (int j = 0; j < H; ++j) acc = fmaf(S_h[b * 64 + j], a.We1[j * L2 + col], acc);
+        T_qp[b * 128 + col] = acc;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const long long r_begin = (long long)bb * S, r_end = (long long)(bb + nb) * S;
+    const int panels = (int)((r_end - r_begin + 15) >> 4);
+    if (!ring_primed) { dma_copy_m(ring, gd1, EV::CH * EV::TW, wave, lane); ring_primed = true; }
+    for (int p0 = 0; p0 < panels; p0 += 2 * kMW) {
+      EvPieces Bp[2];
+      float lqA[2] = {0.f, 0.f}, lpA[2] = {0.f, 0.f};
+      bool actv[2], rvA[2];
+      long long rowA[2];
+      const unsigned char* xrA[2];
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        const int p = p0 + 2 * wave + pi;
+        const bool active = p < panels;
+        const long long row = r_begin + 16ll * p + ln;
+        const bool rv = active && row < r_end;
+        const long long rowc = rv ? row : r_end - 1;
+        const int bj = (int)(rowc / S) - bb;
+        const unsigned long long grow = a.row_base + (unsigned long long)rowc;
+        actv[pi] = active; rvA[pi] = rv; rowA[pi] = row;
+        xrA[pi] = reinterpret_cast<const unsigned char*>(T_x) + bj * D + 4 * lk;
+        if (active) {
+          // ---- z = mu + sigma eps, log q(z|x) (vae.py:171,181; base.py:66-72); lane (j, lk) holds latent dimensions 16 t + 4 lk + r
+          f32x4 z[4];
+          float lq = 0.f, lp_ = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < LT; ++t) {
+            float e4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.eps) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (16 * t + 4 * lk + r < L) e4[r] = a.eps[rowc * L + 16 * t + 4 * lk + r];
+            } else if (4 * (4 * t + lk) < L) {
+              noise_vals(grow, (unsigned)(4 * t + lk), false, a.seed, a.step, e4);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int col = 16 * t + 4 * lk + r;
+              if (col < L) {
+                float s_;
+                const float sg = fmaxf(softplus_sig(T_qp[bj * 128 + L + col] + a.c, s_), a.smin);
+                const float ee = e4[r];
+                const float zz = fmaf(sg, ee, T_qp[bj * 128 + col]);
+                lq += -0.5f * ee * ee - 0.5f * kLog2Pi - flog(sg);
+                if (MODEL == 0) lp_ += -0.5f * zz * zz - 0.5f * kLog2Pi;     // N(0, I): vae.py:247-250
+                z[t][r] = zz;
+              }
+            }
+            if (a.z_out && rv) {
+              if (L >= 16) *reinterpret_cast<float4*>(a.z_out + row * L + 16 * t + 4 * lk) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
+              else if (lk == 0) { a.z_out[row * L] = z[0][0]; a.z_out[row * L + 1] = z[0][1]; }
+            }
+          }
+          lqA[pi] = ev_lk_sum(lq);
+          if (MODEL == 0) lpA[pi] = ev_lk_sum(lp_);
+          else {                                     // MixtureSameFamily.log_prob (vae.py:240-244): logsumexp_k [log w_k + log N(z; loc_k, s_k)]
+            float comp[K], m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              float acc = 0.f;
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const f32x4 lc = ev_ld(M_loc + k * 64 + 16 * t + 4 * lk), iv = ev_ld(M_inv + k * 64 + 16 * t + 4 * lk);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float tt = (z[t][r] - lc[r]) * iv[r]; acc = fmaf(-0.5f * tt, tt, acc); }
+              }
+              comp[k] = M_c[k] + ev_lk_sum(acc);
+              m = fmaxf(m, comp[k]);
+            }
+            float se = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) se += fexp(comp[k] - m);
+            lpA[pi] = m + flog(se);
+          }
+          // ---- decoder hidden layer (vae.py:174)
+          f32x4 hd[4];
+          if (L == 64) {
+            EvPieces zp;
+            ev_split(z, zp);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+              hd[nt] = ev_relu(ev_tile6(img + nt * EV::TW + ((lk * 16 + ln) << 2), zp, ev_ld(img + 4 * EV::TW + nt * 16 + 4 * lk)));
+          } else {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+              hd[nt] = ev_relu(ev_mfma4(*reinterpret_cast<const float4*>(img + ((lk * 64 + nt * 16 + ln) << 2)), z[0], ev_ld(img + 4 * EV::TW + nt * 16 + 4 * lk)));
+          }
+          ev_split(hd, Bp[pi]);
+        }
+      }
+      float lpxl[2];
+      ev_output_layer<0>(gd1, ring, B1, cc, p0 + 2 * kMW < panels || bb + EV::NB < b_end, Bp, actv, xrA, wave, lane, lpxl);
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        if (!actv[pi]) break;
+        const float lpx = ev_lk_sum(lpxl[pi]);
+        const float lw = lpx + lpA[pi] - lqA[pi];
+        if (lk == 0 && rvA[pi]) {
+          const float4 o = make_float4(lpx, lqA[pi], lpA[pi], lw);
+          st4o(a.rows_ws + rowA[pi] * 4, o);
+          if (a.rows4 && a.rows4 != a.rows_ws) *reinterpret_cast<float4*>(a.rows4 + rowA[pi] * 4) = o;
+        }
+      }
+    }
+    // ---- the IWAE bound of this pass's batch rows
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const float logS = flog((float)S);
+    for (int b = wave; b < nb; b += kMW) {
+      const float* const rw = a.rows_ws + ((long long)(bb + b) * S) * 4;
+      float mx = -INFINITY, se = 0.f, nl = 0.f, kl = 0.f;
+      for (int s = lane; s < S; s += 64) mx = fmaxf(mx, ld_sc(rw + 4 * s + 3));
+      mx = Wave64::max(mx);
+      for (int s = lane; s < S; s += 64) {
+        se += fexp(ld_sc(rw + 4 * s + 3) - mx);
+        nl -= ld_sc(rw + 4 * s);
+        kl += ld_sc(rw + 4 * s + 1) - ld_sc(rw + 4 * s + 2);
+      }
+      se = Wave64::sum(se); nl = Wave64::sum(nl); kl = Wave64::sum(kl);
+      w_loss -= mx + flog(se) - logS; w_nl += nl / (float)S; w_kl += kl / (float)S;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) { red[wave * 4] = w_loss; red[wave * 4 + 1] = w_nl; red[wave * 4 + 2] = w_kl; red[wave * 4 + 3] = 0.f; }
+  __syncthreads();
+  if (tid < 4) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kMW; ++w) s += red[w * 4 + tid];
+    st1o(a.slots + (long long)blockIdx.x * 4 + tid, s);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned* const last = reinterpret_cast<unsigned*>(red);
+  if (tid == 0) *last = atomicAdd(a.counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (*last) {
+    float* const sl = ring;
+    for (unsigned g = tid; g < gridDim.x * 4; g += kMT) sl[g] = ld_sc(a.slots + g);
+    __syncthreads();
+    if (tid < 4) {
+      float s = 0.f;
+      for (unsigned g = 0; g < gridDim.x; ++g) s += sl[g * 4 + tid];
+      a.tail[tid] = s;
+      if (tid == 0) { a.tail[4] = (float)B; a.tail[5] = 0.f; a.tail[6] = 0.f; a.tail[7] = 0.f; *a.counter = 0u; }
+    }
+  }
+}
+static_assert(EVV::lds * 4 <= 160 * 1024, "LDS budget");
 
 #undef EV_ST
 

@@ -293,8 +293,10 @@ static bool fused_ok(const GmvaeDims& d, int model) {
 
 // evalf_rows (evalf.hpp): the forward-only pass of the GMVAE at the reference's default sizes, any batch, any number of samples
 static bool evalf_shape(const GmvaeDims& d, int model) {
-  return model == GMVAE_MODEL_GMVAE && d.n_hidden == 1 && d.hidden[0] == EV::H && d.L == EV::L && d.K == EV::K && d.D == EV::D &&
-         d.hidden_act == GMVAE_ACT_RELU && !d.gen_bias_vec;
+  if (d.n_hidden != 1 || d.hidden[0] != EV::H || d.D != EV::D || d.hidden_act != GMVAE_ACT_RELU || d.gen_bias_vec) return false;
+  if (model == GMVAE_MODEL_GMVAE) return d.L == EV::L && d.K == EV::K;
+  if (model == GMVAE_MODEL_VAE) return d.L == 2 || d.L == 64;          // (evalf_rows_v: BASELINE configs[0]'s latent size, and 64)
+  return d.L == 64 && d.K == 10;                                       // VAE_GMP: configs[1]
 }
 static bool evalf_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_EVALF");
@@ -1819,13 +1821,14 @@ static int run_eval_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w) {
   const int B = d.B, S = d.S, D = d.D;
   const float* P = a.params;
   hipStream_t st = cx.st;
-  const NetL &E = L.ency, &G = L.encg, &Dn = L.dec;
+  const bool gm = a.model == GMVAE_MODEL_GMVAE;
+  const NetL &E = gm ? L.ency : L.enc, &G = L.encg, &Dn = L.dec;
   {
     FlxArgs f;
     f.x = a.x; f.W0 = P + E.w[0]; f.b0 = P + E.b[0]; f.out0 = w.he[1]; f.H0 = EV::H; f.relu0 = 1;
-    f.W1 = P + G.w[0]; f.out1 = w.gx; f.H1 = EV::H;
+    f.W1 = gm ? P + G.w[0] : nullptr; f.out1 = gm ? w.gx : nullptr; f.H1 = gm ? EV::H : 0;
     f.B = B; f.D = D;
-    const int nct = 2, nrt = (B + 15) / 16;
+    const int nct = gm ? 2 : 1, nrt = (B + 15) / 16;
     int rt = 4;
     while (rt > 1 && nct * ((nrt + rt - 1) / rt) < 256) rt >>= 1;
     const int grid = nct * ((nrt + rt - 1) / rt);
@@ -1833,12 +1836,14 @@ static int run_eval_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w) {
     else if (rt == 2) hipLaunchKernelGGL(first_layers_u8bf<2>, dim3(grid), dim3(kSkThreads), 0, st, f);
     else hipLaunchKernelGGL(first_layers_u8bf<1>, dim3(grid), dim3(kSkThreads), 0, st, f);
     cx.check();
-    cx.mark("fwd_x_first_layers", 2.0 * B * D * 2 * EV::H);
+    cx.mark("fwd_x_first_layers", 2.0 * B * D * nct * EV::H);
   }
   unsigned* const counter = reinterpret_cast<unsigned*>(w.ev_slots + 4 * 1024);
   if (!(d.sched_flags & GMVAE_SCHED_EVAL_IMAGES_VALID)) {      // (else: a previous pass on fixed parameters left the images; its last workgroup reset the counter)
     EvalPrepArgs pa;
-    pa.Wp = P + L.prior.w[0]; pa.bp = P + L.prior.b[0]; pa.Wg0 = P + G.w[0]; pa.bg0 = P + G.b[0]; pa.Wg1 = P + G.w[1]; pa.bg1 = P + G.b[1];
+    memset(&pa, 0, sizeof(pa));
+    if (gm) { pa.Wp = P + L.prior.w[0]; pa.bp = P + L.prior.b[0]; pa.Wg0 = P + G.w[0]; pa.bg0 = P + G.b[0]; pa.Wg1 = P + G.w[1]; pa.bg1 = P + G.b[1]; }
+    pa.family = gm ? 0 : (d.L == 2 ? 2 : 1);
     pa.Wd0 = P + Dn.w[0]; pa.bd0 = P + Dn.b[0]; pa.Wd1 = P + Dn.w[1]; pa.bd1 = P + Dn.b[1];
     pa.gen_bias = d.gen_bias_init; pa.img = w.ev_img; pa.counter = counter;
     hipLaunchKernelGGL(evalf_prep, dim3((EV::total + 255) / 256), dim3(256), 0, st, pa);
@@ -1847,7 +1852,12 @@ static int run_eval_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w) {
   }
   EvalArgs ea;
   memset(&ea, 0, sizeof(ea));
-  ea.B = B; ea.S = S; ea.x = a.x; ea.he1 = w.he[1]; ea.gx = w.gx; ea.Wy1 = P + E.w[1]; ea.by1 = P + E.b[1]; ea.img = w.ev_img;
+  ea.B = B; ea.S = S; ea.x = a.x; ea.he1 = w.he[1]; ea.gx = w.gx; ea.img = w.ev_img;
+  if (gm) { ea.Wy1 = P + E.w[1]; ea.by1 = P + E.b[1]; }
+  else {
+    ea.We1 = P + E.w[1]; ea.be1 = P + E.b[1];
+    if (a.model == GMVAE_MODEL_VAE_GMP) { ea.loc = P + L.loc; ea.raw_scale = P + L.rawscale; ea.mixlog = P + L.mixlog; }
+  }
   ea.eps = a.eps; ea.u = a.u; ea.seed = a.seed; ea.step = a.step; ea.row_base = (unsigned long long)d.row0 * S;
   ea.c = d.raw_sigma_bias; ea.smin = d.sigma_min; ea.invT = 1.f / d.temperature;
   ea.rows4 = a.row_terms; ea.z_out = a.z_out; ea.y_out = a.y_out; ea.logits_out = a.logits_out;
@@ -1859,11 +1869,24 @@ static int run_eval_fused(Ctx& cx, const StepArgs& a, const Layout& L, WS& w) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(evalf_rows<0>), hipFuncAttributeMaxDynamicSharedMemorySize, EV::lds * (int)sizeof(float));
     hipFuncSetAttribute(reinterpret_cast<const void*>(evalf_rows<1>), hipFuncAttributeMaxDynamicSharedMemorySize, EV::lds * (int)sizeof(float));
     hipFuncSetAttribute(reinterpret_cast<const void*>(evalf_rows<2>), hipFuncAttributeMaxDynamicSharedMemorySize, EV::lds * (int)sizeof(float));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(evalf_rows_v<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, EVV::lds * (int)sizeof(float));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(evalf_rows_v<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, EVV::lds * (int)sizeof(float));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(evalf_rows_v<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, EVV::lds * (int)sizeof(float));
   }
   int grid = device_cus();
   if (grid > B) grid = B;
   if (grid > 1024) grid = 1024;
   const int ev_mode = getenv("GMVAE_EV_MODE") ? atoi(getenv("GMVAE_EV_MODE")) : 0;      // (timing experiments: wrong results)
+  const size_t shv = (size_t)EVV::lds * sizeof(float);
+  if (!gm) {
+    if (a.model == GMVAE_MODEL_VAE_GMP) hipLaunchKernelGGL((evalf_rows_v<1, 64>), dim3(grid), dim3(kMT), shv, st, ea);
+    else if (d.L == 2) hipLaunchKernelGGL((evalf_rows_v<0, 2>), dim3(grid), dim3(kMT), shv, st, ea);
+    else hipLaunchKernelGGL((evalf_rows_v<0, 64>), dim3(grid), dim3(kMT), shv, st, ea);
+    cx.check();
+    const double Rv = (double)B * S;
+    cx.mark("evalf_rows_v", 2.0 * B * EV::H * 2 * d.L + 2.0 * Rv * ((double)d.L * EV::H + (double)EV::H * D));
+    return cx.err;
+  }
   if (ev_mode == 1) hipLaunchKernelGGL(evalf_rows<1>, dim3(grid), dim3(kMT), (size_t)EV::lds * sizeof(float), st, ea);
   else if (ev_mode == 2) hipLaunchKernelGGL(evalf_rows<2>, dim3(grid), dim3(kMT), (size_t)EV::lds * sizeof(float), st, ea);
   else hipLaunchKernelGGL(evalf_rows<0>, dim3(grid), dim3(kMT), (size_t)EV::lds * sizeof(float), st, ea);

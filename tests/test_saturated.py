@@ -220,7 +220,10 @@ FWD = [("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,), S=50), 256, "evalf"),  
        ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,)), 512, "evalf"),         # S = 1
        ("gmvae", O.Dims(D=784, L=64, K=10, hidden=(64,), S=50, gen_bias_init=0.7, temperature=0.6), 256, "evalf"),
        ("gmvae", O.Dims(D=784, L=32, K=10, hidden=(64,), S=50), 256, "pairs"),   # another latent size: the logits GEMM on f16 pairs
-       ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(64,), S=40), 256, "pairs"),
+       ("vae_gmp", O.Dims(D=784, L=64, K=10, hidden=(64,), S=40), 256, "evalf"), # BASELINE configs[1]'s model: evalf_rows_v
+       ("vae", O.Dims(D=784, L=2, K=1, hidden=(64,), S=50), 100, "evalf"),       # configs[0]'s
+       ("vae", O.Dims(D=784, L=64, K=1, hidden=(64,), S=7), 33, "evalf"),
+       ("vae_gmp", O.Dims(D=784, L=32, K=10, hidden=(64,), S=40), 256, "pairs"),
        ("gmvae", O.Dims(D=784, L=32, K=10, hidden=(64,)), 512, None),            # S = 1: the chain kernels
        ("gmvae", O.Dims(D=784, L=128, K=10, hidden=(512,), S=5), 64, None)]
 
@@ -377,6 +380,7 @@ def _evalf_random_cases(n, seed):
 
 
 EVALF_RANDOM = _evalf_random_cases(24, 20261005)
+EVALF_RANDOM_V = [(m,) + c for m, c in zip(["vae2", "vae64", "vae_gmp"] * 6, _evalf_random_cases(18, 20261006))]
 
 
 @pytest.mark.parametrize("B,S,temp,gbias,philox,rank", EVALF_RANDOM, ids=[f"B{c[0]}-S{c[1]}-T{c[2]}-g{c[3]}-{'philox' if c[4] else 'ext'}-r{c[5]}" for c in EVALF_RANDOM])
@@ -402,5 +406,41 @@ def test_one_launch_evaluation_equals_the_general_schedule_on_random_shapes(B, S
     np.testing.assert_allclose(a_["z"], b_["z"], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(a_["y"], b_["y"], rtol=2e-5, atol=1e-7)
     np.testing.assert_allclose(a_["logits"], b_["logits"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(a_["rows"], b_["rows"], rtol=2e-5, atol=2e-3)
+    np.testing.assert_allclose(a_["tail"][:5], b_["tail"][:5], rtol=2e-6, atol=1e-3)
+
+
+@pytest.mark.parametrize("mname,B,S,temp,gbias,philox,rank", EVALF_RANDOM_V,
+                         ids=[f"{c[0]}-B{c[1]}-S{c[2]}-g{c[4]}-{'philox' if c[5] else 'ext'}-r{c[6]}" for c in EVALF_RANDOM_V])
+def test_one_launch_evaluation_of_the_vae_family_equals_the_general_schedule(mname, B, S, temp, gbias, philox, rank, monkeypatch):
+    """evalf_rows_v (csrc/evalf.hpp: the VAE at latent 2 and 64, VAE_GMP at latent 64 / K = 10 -- BASELINE configs[0] / [1]'s
+    models) against the general schedule on random batch sizes and sample counts, and against the fp64 oracle on the noise drawn."""
+    from test_timed_path import _noise
+    from gmvae_amd import _lib as L
+    from gmvae_amd.engine import Engine
+    model, Lz, K = {"vae2": ("vae", 2, 1), "vae64": ("vae", 64, 1), "vae_gmp": ("vae_gmp", 64, 10)}[mname]
+    mid = O.MODEL_NAMES[model]
+    e = Engine(model, 784, Lz, K, [64], n_samples=S, gen_bias_init=gbias, random_seed=B * 7 + S)
+    e.rank = rank
+    e.global_step = 3
+    rng = np.random.default_rng(B * 131 + S)
+    xn = (rng.random((B, 784)) < 0.87).astype(np.uint8)
+    x = torch.from_numpy(xn).cuda()
+    eps = None
+    if not philox:
+        eps = torch.from_numpy(rng.standard_normal((B * S, Lz)).astype(np.float32))
+    a_ = {k: (v.cpu().numpy() if v is not None else None) for k, v in e.forward(x, eps).items()}
+    en = eps.numpy() if eps is not None else _noise(L, B * S, Lz, K, rank * B * S, e.noise_seed, 3, False)[0]
+    d = O.Dims(D=784, L=Lz, K=K, hidden=(64,), S=S, gen_bias_init=gbias)
+    Cc = O.forward(mid, d, O.unpack(mid, d, e.params.detach().cpu().numpy().astype(np.float64)), xn, en, None)
+    np.testing.assert_allclose(a_["z"], Cc["z"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(a_["rows"][:, 0], Cc["logpx"], rtol=1e-5)
+    np.testing.assert_allclose(a_["rows"][:, 1], Cc["logq"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(a_["rows"][:, 2], Cc["logp"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(a_["rows"][:, 3], Cc["logw"], rtol=1e-5)
+    assert abs(a_["tail"][0] / B - Cc["loss"]) <= 1e-6 * abs(Cc["loss"])
+    monkeypatch.setenv("GMVAE_NO_EVALF", "1")
+    b_ = {k: (v.cpu().numpy() if v is not None else None) for k, v in e.forward(x, eps).items()}
+    assert not np.array_equal(a_["rows"], b_["rows"]) or B * S < 4
     np.testing.assert_allclose(a_["rows"], b_["rows"], rtol=2e-5, atol=2e-3)
     np.testing.assert_allclose(a_["tail"][:5], b_["tail"][:5], rtol=2e-6, atol=1e-3)
