@@ -49,6 +49,11 @@ CONFIGS = {
     # on configs[2]'s model and batch (scripts/runners.py:324-333 reuses the model's loss for evaluation): 51,200 sample rows
     "eval_iwae": dict(model="gmvae", batch=1024, latent=64, components=10, hidden=64, layers=1, data_dim=784, n_samples=50,
                       eval_only=True),
+    # the same bound for BASELINE configs[1]'s and configs[0]'s models at their batches (csrc/evalf.hpp evalf_rows_v)
+    "eval_iwae_vae_gmp": dict(model="vae_gmp", batch=256, latent=64, components=10, hidden=64, layers=1, data_dim=784, n_samples=50,
+                              eval_only=True),
+    "eval_iwae_vae": dict(model="vae", batch=100, latent=2, components=1, hidden=64, layers=1, data_dim=784, n_samples=50,
+                          eval_only=True),
     "configs3_dp1": dict(model="gmvae", batch=1024, latent=64, components=10, hidden=64, layers=1, data_dim=784, n_samples=1,
                          dp_world1=True),
 }
@@ -274,10 +279,10 @@ def main_eval(a):
                      "peak_note": f"dense f16 MFMA peak 2500 TFLOP/s / {PLANE_PIECES:.0f} piece products per fp32 product; fp32 accumulation; "
                                   "K = 64 is four 16-deep rounds per tile: the launch is its Bernoulli epilogue's vector work",
                      "frac_of_f32_mfma_peak": roof["achieved"] / PEAK_F32_MFMA_TFLOPS})
-    if dom[0] == "evalf_rows":
+    if dom[0] in ("evalf_rows", "evalf_rows_v"):
         # the one-launch evaluation (csrc/evalf.hpp): the output layer (64 -> D per sample row) multiplies as exact bf16 piece products
         # (6 per fp32 product), the small layers as fp32 MFMA: priced against the time the two parts would take at their own peaks
-        f_top = 2.0 * B * S * (hidden[-1] * D + hidden[0] * 2 * Lz + Lz * hidden[0])      # output layer, q head, decoder hidden layer
+        f_top = 2.0 * B * S * (hidden[-1] * D + (hidden[0] * 2 * Lz if a.model == "gmvae" else 0) + (Lz * hidden[0] if Lz >= 16 else 0))   # output layer, q head, decoder hidden layer
         f_small = dom[2] - f_top
         t_ideal = f_small / (PEAK_F32_MFMA_TFLOPS * 1e6) + f_top / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e6)      # us
         pk = dom[2] / t_ideal * 1e-6
@@ -297,7 +302,7 @@ def main_eval(a):
         if stats:
             roof["rocprof_source"] = os.path.relpath(stats[-1], ROOT)
             want = "void gmvae::gemm_grouped<gmvae::Cfg<128, 128, 32, 2, 2, 1, 2>, %d>" % (3 if fwd_pairs else 0)
-            if dom[0] == "evalf_rows":
+            if dom[0] in ("evalf_rows", "evalf_rows_v"):
                 want = "void gmvae::evalf_rows<0>" 
             for row in csv.DictReader(open(stats[-1])):
                 if row["Name"].startswith(want):

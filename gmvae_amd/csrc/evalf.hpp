@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kMT) void evalf_rows(const EvalArgs a) {
       const unsigned char* xrA[2];
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
-        const int p = p0 + 2 * wave + pi;
+        const int p = p0 + wave + kMW * pi;       // (panels w and w + 8: a round of <= 8 panels puts one on every wave)
         const bool active = p < panels;
         const long long row = r_begin + 16ll * p + ln;
         const bool rv = active && row < r_end;
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(kMT) void evalf_rows_v(const EvalArgs a) {
       const unsigned char* xrA[2];
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
-        const int p = p0 + 2 * wave + pi;
+        const int p = p0 + wave + kMW * pi;       // (panels w and w + 8: a round of <= 8 panels puts one on every wave)
         const bool active = p < panels;
         const long long row = r_begin + 16ll * p + ln;
         const bool rv = active && row < r_end;
