@@ -301,7 +301,14 @@ static bool evalf_shape(const GmvaeDims& d, int model) {
 static bool evalf_ok(const GmvaeDims& d, int model) {
   const char* e = getenv("GMVAE_NO_EVALF");
   if (e && atoi(e)) return false;
-  return evalf_shape(d, model);
+  if (!evalf_shape(d, model)) return false;
+  // a workgroup stages 8 batch rows per table pass: with ONE sample per row and more than 8 batch rows per workgroup a pass is half
+  // a panel on one wave (measured, tools/eval_time.py: B = 8192, S = 1: 110 / 139 us against 115 / 81 on the chain / general
+  // schedules; every other shape tried is 1.0 - 2.4x faster here)
+  int grid = device_cus();
+  if (grid > d.B) grid = d.B;
+  if (grid > 1024) grid = 1024;
+  return !(d.S == 1 && (d.B + grid - 1) / grid > EV::NB);
 }
 
 static int num_splits(long long R) {
