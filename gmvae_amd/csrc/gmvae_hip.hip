@@ -31,6 +31,7 @@
 #include "dwadam.hpp"
 #include "mega3.hpp"
 #include "skinny.hpp"
+#include "rowsws.hpp"
 #include "evalf.hpp"
 
 using namespace gmvae;
@@ -456,7 +457,8 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
       // f16 pairs: [0], [1] bits of max |h|, max |W| of the step; [2], [3] 1 / scale of either; [16..] partial maxima: kAmaxBlocks
       // words for W, then one per wave of the launch that produces h (rows_nn_bf6: a wave per 16 rows x 64 columns at least)
       {
-        const uint64_t units = ((R + 15) / 16) * ((Ht + 63) / 64);      // (or kAmaxBlocks partials when amax_abs reduces h)
+        uint64_t units = ((R + 15) / 16) * ((Ht + 63) / 64);            // (or kAmaxBlocks partials when amax_abs reduces h,
+        if (units < (uint64_t)kRwsMaxWaves) units = kRwsMaxWaves;       //  or one per wave of rows_ws)
         w.pscale = take(16 + kAmaxBlocks + (units > (uint64_t)kAmaxBlocks ? units : (uint64_t)kAmaxBlocks));
       }
     }
@@ -468,7 +470,8 @@ static void carve(const GmvaeDims& d, int model, const Layout& L, void* base, WS
     if (L.dec.nl >= 2 && R % 128 == 0 && Ht % 32 == 0 && D % 8 == 0 && R * Dp < (1ull << 32)) {
       w.hd2f = reinterpret_cast<unsigned short*>(take(R * Ht));
       w.w2f = reinterpret_cast<unsigned short*>(take(Ht * Dp));
-      const uint64_t units = ((R + 15) / 16) * ((Ht + 63) / 64);        // (or kAmaxBlocks partials when amax_abs reduces h)
+      uint64_t units = ((R + 15) / 16) * ((Ht + 63) / 64);              // (or kAmaxBlocks partials when amax_abs reduces h,
+      if (units < (uint64_t)kRwsMaxWaves) units = kRwsMaxWaves;         //  or one per wave of rows_ws)
       w.pscale_f = take(16 + kAmaxBlocks + (units > (uint64_t)kAmaxBlocks ? units : (uint64_t)kAmaxBlocks));
     }
   }
@@ -1962,6 +1965,34 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     for (int i = 0; i < ra.np; ++i) fl += 2.0 * R * ra.K * ra.p[i].N;
     cx.mark(name, fl);
   };
+  // the same layers with the weight stationary (rowsws.hpp) where a wave's slice of it fits 96 registers: K = 64 (NN) / 128 (NT)
+  // in a wave, K = 512 x N = 64 (NT) over the eight waves of a workgroup; one resident wave of workgroups
+  const bool rws_on = relu_act && R >= 2048 && !getenv("GMVAE_NO_RWS");
+  auto rws_grid = [&]() { const int cu = device_cus(); return cu * kSkWaves > kRwsMaxWaves ? kRwsMaxWaves / kSkWaves : cu; };
+  auto rws_prob = [&](const float* W, int ldw, const float* bias, float* out, int N, bool relu) {
+    RwsProb q;
+    memset(&q, 0, sizeof(q));
+    q.W = W; q.ldw = ldw; q.bias = bias; q.out = out; q.N = N; q.relu = relu ? 1 : 0; q.add_div = 1;
+    return q;
+  };
+  auto launch_rws = [&](RwsArgs& ra, const int form, const char* name, const int K) {      // form 0: NN K = 64; 1: NT K = 128; 2: NT K = 512, N = 64
+    const int grid = rws_grid();
+    if (form == 0) {
+      ra.ns0 = ra.p[0].N / 64; ra.ns = ra.ns0 + (ra.np > 1 ? ra.p[1].N / 64 : 0);
+      hipLaunchKernelGGL((rows_ws<2, 4, false>), dim3(grid), dim3(kSkThreads), 0, st, ra);
+    } else if (form == 1) {
+      ra.ns0 = ra.p[0].N / 32; ra.ns = ra.ns0 + (ra.np > 1 ? ra.p[1].N / 32 : 0);
+      hipLaunchKernelGGL((rows_ws<4, 2, true>), dim3(grid), dim3(kSkThreads), 0, st, ra);
+    } else {
+      ra.ns0 = ra.ns = 1;
+      hipLaunchKernelGGL(rows_ws_k8, dim3(grid), dim3(kSkThreads), 0, st, ra);
+    }
+    rows_units = grid * kSkWaves;
+    cx.check();
+    double fl = 0;
+    for (int i = 0; i < ra.np; ++i) fl += 2.0 * R * K * ra.p[i].N;
+    cx.mark(name, fl);
+  };
   auto rows_prob = [&](const float* W, const float* bias, float* out, int N, bool relu) {
     RowsProb q;
     memset(&q, 0, sizeof(q));
@@ -2027,7 +2058,15 @@ static int run_step(Ctx& cx, const StepArgs& a) {
                        1.f / d.temperature);
     rowk(cx, "y_head_fwd");
     const NetL& G = L.encg;
-    if (rows_ok(K, G.dim[1], 2 * Lz)) {
+    if (rws_on && K == 64 && G.dim[1] % 64 == 0 && (2 * Lz) % 64 == 0) {
+      RwsArgs ra;
+      memset(&ra, 0, sizeof(ra));
+      ra.A = w.y; ra.lda = K; ra.R = R; ra.np = 2;
+      ra.p[0] = rws_prob(P + G.w[0] + (uint64_t)D * G.dim[1], G.dim[1], P + G.b[0], (G.nl == 1) ? w.qp : w.hg[1], G.dim[1], G.nl > 1);
+      ra.p[0].addsrc = w.gx; ra.p[0].ld_add = G.dim[1]; ra.p[0].add_div = S;
+      ra.p[1] = rws_prob(P + L.prior.w[0], 2 * Lz, P + L.prior.b[0], w.pp, 2 * Lz, false);
+      launch_rws(ra, 0, "fwd_y_layers", K);
+    } else if (rows_ok(K, G.dim[1], 2 * Lz)) {
       RowsArgs ra;
       memset(&ra, 0, sizeof(ra));
       ra.A = w.y; ra.R = R; ra.K = K; ra.np = 2;
@@ -2091,7 +2130,15 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   for (int i = 0; i < Dn.nl; ++i) {
     Group g;
     const float* in = (i == 0) ? w.z : w.hd[i];
-    if (i < Dn.nl - 1 && rows_ok(Dn.dim[i], Dn.dim[i + 1], 64)) {
+    if (i < Dn.nl - 1 && rws_on && Dn.dim[i] == 64 && Dn.dim[i + 1] % 64 == 0 && !(planes && !pairs && i == Dn.nl - 2)) {
+      RwsArgs ra;
+      memset(&ra, 0, sizeof(ra));
+      ra.A = in; ra.lda = Dn.dim[i]; ra.R = R; ra.np = 1;
+      ra.p[0] = rws_prob(P + Dn.w[i], Dn.dim[i + 1], P + Dn.b[i], w.hd[i + 1], Dn.dim[i + 1], true);
+      if ((pairs || fwdp) && i == Dn.nl - 2) ra.p[0].amax = reinterpret_cast<unsigned*>(pairs ? w.pscale : w.pscale_f) + 16 + kAmaxBlocks;
+      launch_rws(ra, 0, "fwd_dec", Dn.dim[i]);
+      if (ra.p[0].amax) hmax_n = rows_units;
+    } else if (i < Dn.nl - 1 && rows_ok(Dn.dim[i], Dn.dim[i + 1], 64)) {
       RowsArgs ra;
       memset(&ra, 0, sizeof(ra));
       ra.A = in; ra.R = R; ra.K = Dn.dim[i]; ra.np = 1;
@@ -2221,7 +2268,21 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     Group g;
     const bool top = (i == Dn.nl - 1);
     const float* act = (i == 0) ? w.z : w.hd[i];
-    const int nsd = small_ns((long long)Dn.dim[i] * Dn.dim[i + 1]);
+    int nsd = small_ns((long long)Dn.dim[i] * Dn.dim[i + 1]);
+    if (top && planes && sxb.n + 2 <= kSlabRanges) {
+      // The plane launch's weight gradient: as many slabs as put its tiles on the chip ONCE with a few CUs to spare -- tiles per
+      // slab x slabs just under the resident workgroups (256-row tiles: one per CU).  Measured at the config-5 shard (48 tiles per
+      // slab, tools/ab/ns_top.sh, us per step on one box): 16 slabs 1315, 12 1283, 8 1308, 7 1314, 6 1283, **5 1228**, 4 1252,
+      // 3 1273, 2 1469 -- bwd_dec_top 526 -> 454 (the slabs it writes 100 -> 31 MB, and no second round of weight-gradient tiles
+      // behind the data gradient's), finalize_grads 40 -> 27; D = 2048 (32 per slab): 7 slabs; hidden 1024 (96): 2; B = 1024: 5.
+      const bool x256 = pairs && Dn.dim[i] % 256 == 0 && R % 256 == 0;
+      const int tps = (Dn.dim[i] / (x256 ? 256 : 128)) * (int)(D / 128), cap = device_cus() * (x256 ? 1 : 2);
+      int nst = (cap - cap / 16) / (tps > 0 ? tps : 1);
+      nst = nst < 1 ? 1 : (nst > NS ? NS : nst);
+      const char* e = getenv("GMVAE_NSPLIT_TOP");      // (A/B)
+      if (e && atoi(e) >= 1 && atoi(e) <= NS) nst = atoi(e);
+      nsd = nst;
+    }
     if (nsd != NS) { brange(Dn.w[i], (uint64_t)Dn.dim[i] * Dn.dim[i + 1], nsd); brange(Dn.b[i], Dn.dim[i + 1], nsd); }
     const Problem pw = p_tn(act, false, Dn.dim[i], 1, dcur, Dn.dim[i + 1], Dn.dim[i], Dn.dim[i + 1], R, sl + Dn.w[i], sl + Dn.b[i],
                             nsd, PP, top ? rwS : nullptr);
@@ -2250,8 +2311,17 @@ static int run_step(Ctx& cx, const StepArgs& a) {
     } else {
       g.add(pw);
     }
-    g.add(p);
+    // a thin data gradient behind a wide layer (dz = dhd Wd0^T: 512 -> 64) with the weight stationary, in a launch of its own
+    const bool rws_dz = !top && rws_on && i == 0 && Dn.dim[1] == 512 && Dn.dim[0] == 64;
+    if (!rws_dz) g.add(p);
     launch_group(cx, g, top ? "bwd_dec_top" : "bwd_dec");
+    if (rws_dz) {
+      RwsArgs ra;
+      memset(&ra, 0, sizeof(ra));
+      ra.A = dcur; ra.lda = Dn.dim[1]; ra.R = R; ra.np = 1;
+      ra.p[0] = rws_prob(P + Dn.w[0], Dn.dim[1], nullptr, out, Dn.dim[0], false);
+      launch_rws(ra, 2, "bwd_dec_dz", Dn.dim[1]);
+    }
     dcur = out;
     pb ^= 1;
   }
@@ -2275,11 +2345,22 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       g.add(p_tn(w.hg[i], false, G.dim[i], 1, dcur, G.dim[i + 1], G.dim[i], G.dim[i + 1], R, sl + G.w[i], sl + G.b[i],
                  nsg, PP, nullptr));
       float* out = w.dbuf[pb];
-      g.add(p_nt(dcur, G.dim[i + 1], P + G.w[i], G.dim[i + 1], R, G.dim[i], G.dim[i + 1], out, G.dim[i], w.hg[i],
-                 G.dim[i]));
+      // (dhg = dqp Wg1^T under the ReLU mask, K = 128: the weight stationary, in a launch of its own)
+      const bool rws_dh = rws_on && G.dim[i + 1] == 128 && G.dim[i] % 32 == 0;
+      if (!rws_dh)
+        g.add(p_nt(dcur, G.dim[i + 1], P + G.w[i], G.dim[i + 1], R, G.dim[i], G.dim[i + 1], out, G.dim[i], w.hg[i],
+                   G.dim[i]));
       // (the prior's small weight gradient rides on the layer-0 launch below: here it would be the one problem that keeps
       // a launch of 128-aligned problems off the big-round GEMM instance)
       launch_group(cx, g, "bwd_enc_gmm");
+      if (rws_dh) {
+        RwsArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.A = dcur; ra.lda = G.dim[i + 1]; ra.R = R; ra.np = 1;
+        ra.p[0] = rws_prob(P + G.w[i], G.dim[i + 1], nullptr, out, G.dim[i], false);
+        ra.p[0].mask = w.hg[i]; ra.p[0].ld_mask = G.dim[i];
+        launch_rws(ra, 1, "bwd_enc_gmm_dh", G.dim[i + 1]);
+      }
       dcur = out;
       pb ^= 1;
     }
@@ -2309,9 +2390,23 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       p.seg[1].b = opnd(P + L.prior.w[0], 2 * Lz, K, false, true);
       p.seg[1].K = 2 * Lz;
       p.seg[1].kscale = nullptr;
-      g.add(p);
+      // (dy = dpp Wp^T + d_g0 Wg0[D:,:]^T, 128 + 512 -> 64: two launches with the weights stationary, the second adding to the first)
+      const bool rws_dy = rws_on && G.dim[1] == 512 && K == 64 && 2 * Lz == 128;
+      if (!rws_dy) g.add(p);
       if (!prior_done) { g.add(prior_dw()); prior_done = true; }
       launch_group(cx, g, "bwd_enc_gmm_l0");
+      if (rws_dy) {
+        RwsArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.A = w.dpp; ra.lda = 2 * Lz; ra.R = R; ra.np = 1;
+        ra.p[0] = rws_prob(P + L.prior.w[0], 2 * Lz, nullptr, w.dy, K, false);
+        launch_rws(ra, 1, "bwd_dy_prior", 2 * Lz);
+        memset(&ra, 0, sizeof(ra));
+        ra.A = dcur; ra.lda = G.dim[1]; ra.R = R; ra.np = 1;
+        ra.p[0] = rws_prob(Wy, G.dim[1], nullptr, w.dy, K, false);
+        ra.p[0].addsrc = w.dy; ra.p[0].ld_add = K;
+        launch_rws(ra, 2, "bwd_dy_enc", G.dim[1]);
+      }
     }
     hipLaunchKernelGGL(y_head_bwd, dim3(grid_for(B, 1)), dim3(512), 0, st, w.logits, w.y, w.dy, w.nent, w.dlogits, B,
                        S, K, 1.f / d.temperature);
@@ -2626,6 +2721,34 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
     p.a_pstride = (long long)na; p.b_pstride = (long long)nb;
     g.add(p);
     launch_group(cx, g, "gemm_test_planes", 2);
+    return cx.err;
+  }
+  if (cfg == 8) {
+    // the weight-stationary row kernels (rowsws.hpp): NN K = 64 (N % 64 = 0); NT K = 128 (N % 32 = 0; `bias` = a ReLU mask [M][N]
+    // or NULL) and K = 512, N = 64 (`bias` = an addend [M][N] or NULL)
+    if (a_is_u8 || trans > 1) return GMVAE_E_DIMS;
+    RwsArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.A = static_cast<const float*>(A); ra.lda = K; ra.R = M; ra.np = 1;
+    RwsProb& q = ra.p[0];
+    q.W = W; q.out = C; q.N = N; q.add_div = 1;
+    const int cu = device_cus(), grid = cu * kSkWaves > kRwsMaxWaves ? kRwsMaxWaves / kSkWaves : cu;
+    if (trans == 0 && K == 64 && N % 64 == 0) {
+      q.ldw = N; q.bias = bias; q.relu = relu != 0;
+      ra.ns0 = ra.ns = N / 64;
+      hipLaunchKernelGGL((rows_ws<2, 4, false>), dim3(grid), dim3(kSkThreads), 0, cx.st, ra);
+    } else if (trans == 1 && K == 128 && N % 32 == 0) {
+      q.ldw = K; q.mask = bias; q.ld_mask = N;
+      ra.ns0 = ra.ns = N / 32;
+      hipLaunchKernelGGL((rows_ws<4, 2, true>), dim3(grid), dim3(kSkThreads), 0, cx.st, ra);
+    } else if (trans == 1 && K == 512 && N == 64) {
+      q.ldw = K; q.addsrc = bias; q.ld_add = N;
+      ra.ns0 = ra.ns = 1;
+      hipLaunchKernelGGL(rows_ws_k8, dim3(grid), dim3(kSkThreads), 0, cx.st, ra);
+    } else {
+      return GMVAE_E_DIMS;
+    }
+    cx.check();
     return cx.err;
   }
   if (trans == 0) {

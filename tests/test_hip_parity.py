@@ -61,6 +61,46 @@ def test_gemm_nt(H, cfg, M, N, K):
     np.testing.assert_allclose(Cd.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * math.sqrt(K))
 
 
+@pytest.mark.parametrize("form,M,N,K", [("nn", 4096, 512, 64), ("nn", 2050, 64, 64), ("nn", 37, 128, 64), ("nt_mask", 4096, 512, 128),
+                                         ("nt_mask", 2061, 96, 128), ("nt", 519, 64, 128), ("nt_k8", 4096, 64, 512), ("nt_k8_add", 2057, 64, 512),
+                                         ("nt_k8", 5, 64, 512)])
+def test_rows_weight_stationary(H, form, M, N, K):
+    """The row-panel layers with the weight stationary (csrc/rowsws.hpp; `cfg` 8 of gmvae_gemm_test) against fp64: exact bf16 piece
+    products, so the distance is fp32 accumulation's.  Ragged row counts (the last tile's rows are clamped loads, predicated
+    stores), more waves than units (M = 37 / 5), the ReLU mask incl. zeros and negative zeros, the accumulate form."""
+    L = _L()
+    rng = np.random.default_rng(M * 7 + N + K)
+    A = rng.normal(size=(M, K)).astype(np.float32)
+    A[rng.random((M, K)) < 0.1] = 0.0
+    if form == "nn":
+        W = rng.normal(size=(K, N)).astype(np.float32)
+        side = rng.normal(size=N).astype(np.float32)
+        ref = np.maximum(A.astype(np.float64) @ W.astype(np.float64) + side, 0)
+        trans, relu = 0, 1
+    else:
+        W = rng.normal(size=(N, K)).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64).T
+        trans, relu, side = 1, 0, None
+        if form == "nt_mask":
+            side = rng.normal(size=(M, N)).astype(np.float32)
+            side[rng.random((M, N)) < 0.2] = 0.0
+            side[rng.random((M, N)) < 0.05] = -0.0
+            ref = np.where(side > 0, ref, 0.0)
+        elif form == "nt_k8_add":
+            side = rng.normal(size=(M, N)).astype(np.float32)
+            ref = ref + side
+    Ad, Wd = H.dev(A), H.dev(W)
+    Sd = H.dev(side) if side is not None else None
+    Cd = torch.full((M + 3, N), float("nan"), dtype=torch.float32, device="cuda")
+    L.check(L.lib.gmvae_gemm_test(L.ptr(Ad), 0, L.ptr(Wd), L.ptr(Sd) if Sd is not None else None, L.ptr(Cd), M, N, K, trans, relu, 8, 1,
+                                  L.current_stream()), "gemm_test")
+    out = Cd.cpu().numpy()
+    assert np.isnan(out[M:]).all()                     # nothing stored past the last row
+    np.testing.assert_allclose(out[:M], ref, rtol=2e-6, atol=2e-6 * math.sqrt(K))
+    # shapes outside the three forms are refused, not mis-run
+    assert L.lib.gmvae_gemm_test(L.ptr(Ad), 0, L.ptr(Wd), None, L.ptr(Cd), M, N, K + 32, trans, relu, 8, 1, L.current_stream()) != 0
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K,u8,ns", [(64, 64, 256, False, 1), (784, 64, 300, True, 4), (10, 128, 1000, False, 3),
                                           (65, 33, 70, False, 16)])
