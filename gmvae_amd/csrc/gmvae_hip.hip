@@ -2390,23 +2390,9 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       p.seg[1].b = opnd(P + L.prior.w[0], 2 * Lz, K, false, true);
       p.seg[1].K = 2 * Lz;
       p.seg[1].kscale = nullptr;
-      // (dy = dpp Wp^T + d_g0 Wg0[D:,:]^T, 128 + 512 -> 64: two launches with the weights stationary, the second adding to the first)
-      const bool rws_dy = rws_on && G.dim[1] == 512 && K == 64 && 2 * Lz == 128;
-      if (!rws_dy) g.add(p);
+      g.add(p);
       if (!prior_done) { g.add(prior_dw()); prior_done = true; }
       launch_group(cx, g, "bwd_enc_gmm_l0");
-      if (rws_dy) {
-        RwsArgs ra;
-        memset(&ra, 0, sizeof(ra));
-        ra.A = w.dpp; ra.lda = 2 * Lz; ra.R = R; ra.np = 1;
-        ra.p[0] = rws_prob(P + L.prior.w[0], 2 * Lz, nullptr, w.dy, K, false);
-        launch_rws(ra, 1, "bwd_dy_prior", 2 * Lz);
-        memset(&ra, 0, sizeof(ra));
-        ra.A = dcur; ra.lda = G.dim[1]; ra.R = R; ra.np = 1;
-        ra.p[0] = rws_prob(Wy, G.dim[1], nullptr, w.dy, K, false);
-        ra.p[0].addsrc = w.dy; ra.p[0].ld_add = K;
-        launch_rws(ra, 2, "bwd_dy_enc", G.dim[1]);
-      }
     }
     hipLaunchKernelGGL(y_head_bwd, dim3(grid_for(B, 1)), dim3(512), 0, st, w.logits, w.y, w.dy, w.nent, w.dlogits, B,
                        S, K, 1.f / d.temperature);
