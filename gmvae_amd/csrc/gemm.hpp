@@ -1629,22 +1629,30 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_EU) void gemm_grouped(const La
         for (int q = 0; q < PASSES; ++q) {
           if (q == PASSES / 2) { GMVAE_GSTAMP(7); }
           const int row = r0 + RPP * q;
-          float v[4] = {vv[q].x, vv[q].y, vv[q].z, vv[q].w};
-          float rsum = 0.f;
+          // Per element ONE exp and ONE rcp: x l - softplus(l) = [x l - max(l, 0)] - log(1 + e), e = exp(-|l|), and the four
+          // logs of a pass are one log of the product of the (1 + e) (each in [1, 2]) -- the bracket sums and the product run as
+          // two chains of packed fp32 (v_pk_add / v_pk_fma / v_pk_mul_f32).  (The bare hardware forms: v_exp_f32 of an argument
+          // <= 0 and v_log_f32 of a value in [1, 16] need none of the denormal-range fix-ups __expf / __logf wrap around them; e
+          // flushes to 0 below 2^-126: sigmoid and softplus are exact to 1e-38 there.  Before: exp, rcp and log per element, 27
+          // scalar-fp32 instructions -- the forward launch of the config-5 shard spent as many vector-pipe cycles in this epilogue
+          // as matrix-pipe cycles in its 32 rounds, and the two do not overlap on a SIMD.)
+          float v[4];
+          f32x2_t brk = {0.f, 0.f}, prod = {1.f, 1.f};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            // (the bare hardware forms: v_exp_f32 of an argument <= 0 and v_log_f32 of a value in [0.5, 1] need none of the
-            //  denormal-range fix-ups __expf / __logf wrap around them -- 10 of 38 vector instructions per element; e flushes to
-            //  0 below 2^-126: sigmoid and softplus are exact to 1e-38 there)
-            const float lam = v[j] + bc[j];
-            const float xv = (float)((xw[q] >> (8 * j)) & 0xffu);
-            const float e = __builtin_amdgcn_exp2f(fabsf(lam) * -1.44269504088896341f);
-            const float ope = 1.f + e;
-            const float rcp = __builtin_amdgcn_rcpf(ope);       // (only the sigmoid needs it: a forward-only pass drops it)
-            const float sp = fmaf(__builtin_amdgcn_logf(ope), 0.693147180559945309f, fmaxf(lam, 0.f));
-            rsum += xv * lam - sp;
-            v[j] = (lam >= 0.f ? rcp : e * rcp) - xv;
+          for (int h = 0; h < 2; ++h) {
+            const f32x2_t lam = f32x2_t{vv[q][2 * h], vv[q][2 * h + 1]} + f32x2_t{bc[2 * h], bc[2 * h + 1]};
+            const f32x2_t xf = {(float)((xw[q] >> (16 * h)) & 0xffu), (float)((xw[q] >> (16 * h + 8)) & 0xffu)};
+            const f32x2_t mx = {fmaxf(lam[0], 0.f), fmaxf(lam[1], 0.f)};
+            brk += xf * lam - mx;
+            const f32x2_t e = {__builtin_amdgcn_exp2f(fabsf(lam[0]) * -1.44269504088896341f), __builtin_amdgcn_exp2f(fabsf(lam[1]) * -1.44269504088896341f)};
+            const f32x2_t ope = e + 1.f;
+            prod *= ope;
+            const f32x2_t rcp = {__builtin_amdgcn_rcpf(ope[0]), __builtin_amdgcn_rcpf(ope[1])};       // (only the sigmoid needs it)
+            const f32x2_t er = e * rcp;
+            const f32x2_t sg = f32x2_t{lam[0] >= 0.f ? rcp[0] : er[0], lam[1] >= 0.f ? rcp[1] : er[1]} - xf;
+            v[2 * h] = sg[0]; v[2 * h + 1] = sg[1];
           }
+          const float rsum = (brk[0] + brk[1]) - __builtin_amdgcn_logf(prod[0] * prod[1]) * 0.693147180559945309f;
           if constexpr (CO) { if (nv) *reinterpret_cast<float4*>(Cout + (long long)(m0 + row) * ldc + nb) = make_float4(v[0], v[1], v[2], v[3]); }
           if constexpr (MODE == 2) {                  // f16 pairs of (sigmoid - x) x c3_scale (|.| <= 1: a fixed scale), two planes
             unsigned q1[2], q2[2];
