@@ -715,6 +715,9 @@ __device__ __forceinline__ float f16hi(const unsigned w) { return (float)__built
 // overlap only in part (both slow down with the clock the matrix pipes throttle to: 2.05 GHz in the step), so fewer bytes per
 // product is what shortens the loop: the 256-row tile.
 constexpr int kP2Ring = 4;
+#ifndef GMVAE_P2_MFMA16
+#define GMVAE_P2_MFMA16 1      // the pairs' loop on v_mfma_f32_16x16x32_f16 (plane_rounds2h); 0: the 32 x 32 x 16 loop (plane_rounds2)
+#endif
 template <int BM> struct P2 {
   static constexpr int PA = BM * 16;            // 16-bit elements per plane image of a (BM x 16 k); b's: 2048
   static constexpr int OpA = 2 * PA, Buf = OpA + 4096;
@@ -877,6 +880,201 @@ __device__ __forceinline__ void plane_rounds2(unsigned short* __restrict__ img, 
 #undef GMVAE_P2_SG
 }
 
+
+// ---- the same loop on v_mfma_f32_16x16x32_f16 (round 6) ------------------------------------------------------------------------
+// Same images, same LDS-DMA staging, same piece products; the matrix instruction is the 16 x 16 x 32 shape, which this part
+// sustains at a higher clock than 32 x 32 x 16 at equal cycles per product (MI355X_MICROARCH.md, DVFS item 7: 1.12 - 1.15x on random
+// data; timing experiment here with the operands of the loop above pushed through two 16x16x32 per instruction, results discarded:
+// forward launch 290 -> 274 us, backward 455 -> 416).  An instruction contracts 32 k = the images of TWO 16-deep rounds; which 8
+// k a lane group holds is free as long as both operands agree, and the choice here -- lane group lk: k 4 lk .. 4 lk + 3 of the
+// first image, then the same four of the second -- makes every fragment two 8-byte reads that are bank-conflict-free on the
+// EXISTING images (k-contiguous [rows][16 k] with its half swap: groups 0 / 1 and 2 / 3 of a 32-lane pass read different halves of
+// 16 rows; mn-contiguous [blocks][16 k][16 mn] with its rotated rows: the four groups of ds_read_b64_tr_b16 read rows 4 lk ..
+// 4 lk + 3).  A wave's 64 x 64 block is 4 x 4 tiles, 48 instructions per 32 k.  Registers: the accumulators (128), this 32-k step's
+// 8 b fragments and the next step's (64), two a fragments of the row block being multiplied and of the next (16).  Order of a step:
+// row blocks 0, 1, 2 (the next block's a fragment read behind the first instructions of each), then ONE wait + barrier per 48
+// instructions (the next step's images have landed, this step's are read), the LDS-DMA requests of the step after next between the
+// first instructions of row block 3 (as in the loop above), the next step's b fragments and first a fragment behind the rest.
+// pairs of image buffers: three where the workgroup has the CU's LDS to itself (256-row tiles: 6 x 24 KB), two otherwise
+template <int BM> struct P2H_PAIRS { static constexpr int v = BM == 256 ? 3 : 2; };
+template <bool MC>
+__device__ __forceinline__ f16x8_t p2h_frag(const unsigned short* __restrict__ i0, const unsigned short* __restrict__ i1) {
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  if (!MC) {
+    const s16x4_t lo = *reinterpret_cast<const s16x4_t*>(i0), hi = *reinterpret_cast<const s16x4_t*>(i1);
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8_t, v);
+  } else {
+    typedef __attribute__((address_space(3))) s16x4_t* lp;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(i0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(i1));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8_t, v);
+  }
+}
+
+template <bool AMC, bool BMC, int BM>
+__device__ __forceinline__ void plane_rounds2h(unsigned short* __restrict__ img, const unsigned short* __restrict__ A,
+                                               const uint32_t a_rows, const long long a_ps, const unsigned short* __restrict__ Bp,
+                                               const uint32_t b_rows, const long long b_ps, const float* __restrict__ kscale,
+                                               const bool do_cs, const int m0, const int n0, const int kb, const int NC16,
+                                               const int tid, const int lane, const int wave, const int wm0, const int wn0,
+                                               f32x16 (&acc)[2][2], f32x16 (&accx)[2][2], float (&cs8)[8]) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef P2<BM> G;
+  constexpr int NP = P2H_PAIRS<BM>::v;             // pairs of image buffers in the ring (a pair = one 32-k step)
+  uint32_t ea = p3_src<AMC>(wave, lane, a_rows, m0, kb), eb = p3_src<BMC>(wave & 3, lane, b_rows, n0, kb);
+  const uint32_t a_round = AMC ? 256u : 16u * a_rows, b_round = BMC ? 256u : 16u * b_rows;
+  const unsigned short* const Bw = Bp + (G::NW == 8 ? (wave >> 2) * b_ps : 0);
+  const int b_dst = G::OpA + (G::NW == 8 ? (wave >> 2) * 2048 : 0) + (wave & 3) * 512;
+  const int ln = lane & 15, lk = lane >> 4;
+  // fragment bases inside an operand image of one plane, for even and odd 16-blocks (+ 256 per block)
+  // both operands k-contiguous (a data gradient): lane group lk takes k 8 (lk & 1) .. + 7 of image lk >> 1 -- ONE 16-byte read per
+  // fragment, as the loop above reads them (with the 8-byte halves of two images such a launch was 15 % slower than there:
+  // twice the LDS instructions)
+  constexpr bool K8 = !AMC && !BMC;
+  const int kcn = K8 ? (lk >> 1) * G::Buf + 8 * ((lk & 1) ^ ((ln >> 3) & 1)) : 8 * ((lk >> 1) ^ ((ln >> 3) & 1)) + 4 * (lk & 1);
+  const int rE = ((4 * lk + (ln >> 2)) & 15) * 16 + 4 * (ln & 3), rO = ((4 * lk + (ln >> 2) + 4) & 15) * 16 + 4 * (ln & 3);
+  const int faE = AMC ? (wm0 >> 4) * 256 + rE : (wm0 + ln) * 16 + kcn, faO = AMC ? (wm0 >> 4) * 256 + rO : faE;
+  const int fbE = G::OpA + (BMC ? (wn0 >> 4) * 256 + rE : (wn0 + ln) * 16 + kcn), fbO = G::OpA + (BMC ? (wn0 >> 4) * 256 + rO : (wn0 + ln) * 16 + kcn);
+  const bool cs_on = BMC && do_cs && tid < 256;
+  const int cs_k = (tid >> 4) & 15, cs_ch = tid & 15;
+  const int cs_off = (cs_ch >> 1) * 256 + ((cs_k + 4 * ((cs_ch >> 1) & 1)) & 15) * 16 + 8 * (cs_ch & 1);
+  int kk = kb + cs_k;
+  f32x4 m[4][4], x[4][4];
+  // the LDS-DMA requests of one image (q = 0, 1: a's planes; 2: b; 3: b's second plane at four waves) into buffer buf
+  auto dma = [&](const int buf, const int q, const uint32_t oa, const uint32_t ob) {
+    unsigned short* const d_ = img + buf * G::Buf;
+    if (q == 0) __builtin_amdgcn_global_load_lds(A + oa, d_ + wave * 512, 16, 0, 0);
+    else if (q == 1) __builtin_amdgcn_global_load_lds(A + a_ps + oa, d_ + G::PA + wave * 512, 16, 0, 0);
+    else if (q == 2) __builtin_amdgcn_global_load_lds(Bw + ob, d_ + b_dst, 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds(Bw + b_ps + ob, d_ + b_dst + 2048, 16, 0, 0);
+  };
+  auto dma_pair_all = [&](const int pair) {
+#pragma unroll
+    for (int im = 0; im < 2; ++im) {
+#pragma unroll
+      for (int q = 0; q < G::DPW; ++q) dma(2 * pair + im, q, ea, eb);
+      ea += a_round; eb += b_round;
+    }
+  };
+  // fragments of the step whose images lie at ic (elements from img): block i / j, plane pl
+  auto rd_a = [&](const unsigned short* ic, const int i, const int pl) {
+    const unsigned short* const p0 = ic + pl * G::PA + 256 * i + ((i & 1) ? faO : faE);
+    if constexpr (K8) return *reinterpret_cast<const f16x8_t*>(p0);
+    else return p2h_frag<AMC>(p0, p0 + G::Buf);
+  };
+  auto rd_b = [&](const unsigned short* ic, const int j, const int pl) {
+    const unsigned short* const p0 = ic + pl * 2048 + 256 * j + ((j & 1) ? fbO : fbE);
+    if constexpr (K8) return *reinterpret_cast<const f16x8_t*>(p0);
+    else return p2h_frag<BMC>(p0, p0 + G::Buf);
+  };
+  // the 12 instructions of row block i_: main terms, a's second piece x b's first, then a's first x b's SECOND piece (whose
+  // fragments are read at the top of the step itself: single-buffered); HOOK_(k) behind the k-th instruction
+#define GMVAE_P2H_BLOCK(i_, FA_, FB0_, HOOK_)                                                              \
+  {                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                        \
+      m[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FA_[0], FB0_[j], m[i_][j], 0, 0, 0);               \
+      HOOK_(j) __builtin_amdgcn_sched_barrier(0);                                                          \
+    }                                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                        \
+      x[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FA_[1], FB0_[j], x[i_][j], 0, 0, 0);               \
+      HOOK_(4 + j) __builtin_amdgcn_sched_barrier(0);                                                      \
+    }                                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                        \
+      x[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FA_[0], FB1[j], x[i_][j], 0, 0, 0);                \
+      HOOK_(8 + j) __builtin_amdgcn_sched_barrier(0);                                                      \
+    }                                                                                                      \
+  }
+  // hooks.  Row block 0: b's second-piece fragments of THIS step (needed from its ninth instruction on), then row block 1's a
+  // fragment; row blocks 1, 2: the next block's a fragment; row block 3 (behind the barrier): the LDS-DMA requests of the step NP
+  // ahead, one per instruction (first: MI355X_MICROARCH.md's issue cost of such a request is lowest among bare matrix
+  // instructions; measured both ways), then the next step's first-piece b fragments and its first a fragment
+#define H_B0(k) if ((k) < 4) FB1[k] = rd_b(ic, (k), 1); else if ((k) < 6) FO[(k) - 4] = rd_a(ic, 1, (k) - 4);
+#define H_B1(k) if ((k) < 2) FE[k] = rd_a(ic, 2, (k));
+#define H_B2(k) if ((k) < 2) FO[k] = rd_a(ic, 3, (k));
+#define H_B3(k)                                                                                            \
+  if ((k) < 2 * G::DPW) { if (dmaon) dma(2 * pc + (k) / G::DPW, (k) % G::DPW, ea + ((k) / G::DPW ? a_round : 0u), eb + ((k) / G::DPW ? b_round : 0u)); }   \
+  else if (G::DPW == 3 && (k) < 10) FN[(k) - 6] = rd_b(in, (k) - 6, 0);                                    \
+  else if (G::DPW == 3) FE[(k) - 10] = rd_a(in, 0, (k) - 10);                                              \
+  else if ((k) < 10) { FN[2 * ((k) - 8)] = rd_b(in, 2 * ((k) - 8), 0); FN[2 * ((k) - 8) + 1] = rd_b(in, 2 * ((k) - 8) + 1, 0); }   \
+  else FE[(k) - 10] = rd_a(in, 0, (k) - 10);
+  // one 32-k step d_: its images in pair pc (b's first-piece fragments FBC_ and row block 0's a fragment FE in registers)
+#define GMVAE_P2H_STEP(FBC_, d_)                                                                           \
+  {                                                                                                        \
+    const int pn = pc + 1 == NP ? 0 : pc + 1;                                                              \
+    const unsigned short* const ic = img + 2 * pc * G::Buf;                                                \
+    const unsigned short* const in = img + 2 * pn * G::Buf;                                                \
+    if (cs_on) {                                                                                           \
+      _Pragma("unroll") for (int im = 0; im < 2; ++im) {                                                   \
+        const unsigned short* const ib_ = ic + im * G::Buf + G::OpA + cs_off;                              \
+        const u32x4 h_ = *reinterpret_cast<const u32x4*>(ib_), l_ = *reinterpret_cast<const u32x4*>(ib_ + 2048);   \
+        const float sc = kscale ? kscale[kk] : 1.f;                                                        \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
+          cs8[2 * q] += sc * (f16lo(h_[q]) + 0x1p-11f * f16lo(l_[q]));                                     \
+          cs8[2 * q + 1] += sc * (f16hi(h_[q]) + 0x1p-11f * f16hi(l_[q]));                                 \
+        }                                                                                                  \
+        kk += 16;                                                                                          \
+      }                                                                                                    \
+    }                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    GMVAE_P2H_BLOCK(0, FE, FBC_, H_B0)                                                                     \
+    GMVAE_P2H_BLOCK(1, FO, FBC_, H_B1)                                                                     \
+    GMVAE_P2H_BLOCK(2, FE, FBC_, H_B2)                                                                     \
+    /* the next step's images have landed (NP = 3: the step after it may still be in flight); this step's are read */ \
+    if (NP == 3 && (d_) + 2 < ND) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * G::DPW) : "memory");   \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
+    const bool dmaon = (d_) + NP < ND;                                                                     \
+    GMVAE_P2H_BLOCK(3, FO, FBC_, H_B3)                                                                     \
+    if (dmaon) { ea += 2 * a_round; eb += 2 * b_round; }                                                   \
+    pc = pn;                                                                                               \
+  }
+  f16x8_t FE[2], FO[2], F0[4], F1[4], FB1[4];
+  const int ND = NC16 >> 1;                        // 32-k steps (NC16 is even)
+  dma_pair_all(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { m[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; x[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  if (ND > 1) dma_pair_all(1);
+  if (NP == 3 && ND > 2) dma_pair_all(2);
+  // the first step's images have landed
+  if (NP == 3 && ND > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * G::DPW) : "memory");
+  else if (ND > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G::DPW) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 4; ++j) F0[j] = rd_b(img, j, 0);
+  FE[0] = rd_a(img, 0, 0); FE[1] = rd_a(img, 0, 1);
+  int pc = 0;
+#pragma unroll 1
+  for (int d = 0; d < ND; d += 2) {
+    {
+      auto& FN = F1;
+      GMVAE_P2H_STEP(F0, d)
+    }
+    if (d + 1 < ND) {
+      auto& FN = F0;
+      GMVAE_P2H_STEP(F1, d + 1)
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (the caller reuses LDS)
+  // into the caller's registers: tile (i, j) = quarter 2 (i & 1) + (j & 1) of block (i >> 1, j >> 1) -- gemm_grouped's staging knows
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[i >> 1][j >> 1][4 * (2 * (i & 1) + (j & 1)) + r] = m[i][j][r];
+        accx[i >> 1][j >> 1][4 * (2 * (i & 1) + (j & 1)) + r] = x[i][j][r];
+      }
+#undef GMVAE_P2H_BLOCK
+#undef GMVAE_P2H_STEP
+#undef H_B0
+#undef H_B1
+#undef H_B2
+#undef H_B3
+}
 
 // ---- the 128x128x32 configuration's interior rounds ("big rounds") -----------------------------------------------
 // For tiles completely inside both fp32 operands and k ranges that are whole 32-deep rounds.  LDS image of an operand
@@ -1339,12 +1537,19 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_EU) void gemm_grouped(const La
       const unsigned short* const Bh = static_cast<const unsigned short*>(b_ptr);
       const long long a_ps = L.p[pi].a_pstride, b_ps = L.p[pi].b_pstride;
       static_assert(kP2Ring * P2<C::BM>::Buf * 2 <= C::LDS_FLOATS * 4, "plane_rounds2's ring must fit the kernel's LDS");
+      static_assert(2 * P2H_PAIRS<C::BM>::v * P2<C::BM>::Buf * 2 <= C::LDS_FLOATS * 4, "plane_rounds2h's ring must fit the kernel's LDS");
       f32x16 accx[2][2];                          // (plane_rounds2 zeroes both sets: nseg == 1)
       {
         const uint32_t a_rows = a_mc ? (uint32_t)K : (uint32_t)a_n, b_rows = b_mc ? (uint32_t)K : (uint32_t)b_n;
+#if GMVAE_P2_MFMA16
+#define GMVAE_PL2(AMC_, BMC_) \
+  plane_rounds2h<AMC_, BMC_, C::BM>(reinterpret_cast<unsigned short*>(lds), Ah, a_rows, a_ps, Bh, b_rows, b_ps, kscale, do_colsum, m0, n0, kb, \
+                            2 * NC, tid, lane, wave, wm0, wn0, acc, accx, cs8)
+#else
 #define GMVAE_PL2(AMC_, BMC_) \
   plane_rounds2<AMC_, BMC_, C::BM>(reinterpret_cast<unsigned short*>(lds), Ah, a_rows, a_ps, Bh, b_rows, b_ps, kscale, do_colsum, m0, n0, kb, \
                             2 * NC, tid, lane, wave, wm0, wn0, acc, accx, cs8)
+#endif
         if (!b_mc) {
           if (a_mc) GMVAE_PL2(true, false); else GMVAE_PL2(false, false);
         } else {
@@ -1440,8 +1645,14 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES_EU) void gemm_grouped(const La
       for (int j = 0; j < C::TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-          Cs[row * C::LDC + wn0 + j * 32 + l31] = acc[i][j][r];
+          if constexpr (BIG == 3 && GMVAE_P2_MFMA16) {
+            // (plane_rounds2h: register r of block (i, j) is row r & 3 of the lane group's four in 16 x 16 tile r >> 2 of the block)
+            const int row = wm0 + i * 32 + 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3);
+            Cs[row * C::LDC + wn0 + j * 32 + 16 * ((r >> 2) & 1) + (lane & 15)] = acc[i][j][r];
+          } else {
+            const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            Cs[row * C::LDC + wn0 + j * 32 + l31] = acc[i][j][r];
+          }
         }
     if (do_colsum) {
       if (did_planes) {                            // (k rows tid >> 4 + 16 i, columns 8 (tid & 15)..)
