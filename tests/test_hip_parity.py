@@ -162,7 +162,8 @@ def test_gemm_big_rounds_instance(H, monkeypatch, trans, M, N, K, ns):
 def test_gemm_plane_rounds_instance(H, monkeypatch, trans, M, N, K, ns):
     """Operands split ONCE into planes of 16-bit pieces (blocked by 16) and multiplied as piece products with fp32 accumulation
     through the LDS-DMA rings of gemm.hpp: f16 PAIRS under per-tensor power-of-two scales, three piece products per product
-    (plane_rounds2, `cfg` 6 of gmvae_gemm_test: amax_abs + amax_final + split_pairs_b16 first) and bf16 TRIPLES, six exact
+    (plane_rounds2h -- 32-k steps of v_mfma_f32_16x16x32_f16 over two images: the K values here give 1, 2, 3, 4, 5, 16, 32
+    and 64 steps per tile, on both ring depths -- `cfg` 6 of gmvae_gemm_test: amax_abs + amax_final + split_pairs_b16 first) and bf16 TRIPLES, six exact
     piece products (plane_rounds3, `cfg` 4) -- every operand orientation (NN / NT / TN with split-K and the bias-gradient
     column sums) to fp32-GEMM accuracy against fp64, and no further from it than the fp32 MFMA instance is."""
     L = _L()
