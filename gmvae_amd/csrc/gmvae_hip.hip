@@ -2390,9 +2390,21 @@ static int run_step(Ctx& cx, const StepArgs& a) {
       p.seg[1].b = opnd(P + L.prior.w[0], 2 * Lz, K, false, true);
       p.seg[1].K = 2 * Lz;
       p.seg[1].kscale = nullptr;
-      g.add(p);
+      // (dy = dhg Wg0[D:,:]^T + dpp Wp^T, 512 + 128 -> 64, with both weights stationary in one launch of its own: rows_ws_k8's
+      //  second segment)
+      const bool rws_dy = rws_on && G.dim[1] == 512 && K == 64 && 2 * Lz == 128;      // (interleaved on one box: 1219.4 -> 1214.1 us per step)
+      if (!rws_dy) g.add(p);
       if (!prior_done) { g.add(prior_dw()); prior_done = true; }
       launch_group(cx, g, "bwd_enc_gmm_l0");
+      if (rws_dy) {
+        RwsArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.A = dcur; ra.lda = G.dim[1]; ra.R = R; ra.np = 1;
+        ra.A2 = w.dpp; ra.lda2 = 2 * Lz;
+        ra.p[0] = rws_prob(Wy, G.dim[1], nullptr, w.dy, K, false);
+        ra.p[0].W2 = P + L.prior.w[0]; ra.p[0].ldw2 = 2 * Lz;
+        launch_rws(ra, 2, "bwd_dy", G.dim[1] + 2 * Lz);
+      }
     }
     hipLaunchKernelGGL(y_head_bwd, dim3(grid_for(B, 1)), dim3(512), 0, st, w.logits, w.y, w.dy, w.nent, w.dlogits, B,
                        S, K, 1.f / d.temperature);

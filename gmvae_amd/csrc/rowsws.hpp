@@ -14,7 +14,7 @@
 // g / ns + nw / ns, ...; the launch is ONE resident wave of workgroups (a workgroup per CU).
 //   rows_ws<2, 4, false>: K = 64, slices of 64 columns (y / z -> 512 hidden units; the prior net beside them: np = 2)
 //   rows_ws<4, 2, true>:  K = 128, slices of 32 columns (dhg = dqp Wg1^T under the ReLU mask; dy's prior part dpp Wp^T)
-// rows_ws_k8: K = 512, N = 64 (dz = dhd Wd0^T, dy += dhg Wg0y^T): a WORKGROUP walks the row tiles, wave w owns contraction slice
+// rows_ws_k8: K = 512 (+ a second segment of 128), N = 64 (dz = dhd Wd0^T; dy = dhg Wg0y^T + dpp Wp^T): a WORKGROUP walks the row tiles, wave w owns contraction slice
 // [64 w, 64 w + 64) with its [64 x 64] weight block as fragments; the eight partial tiles meet in LDS in wave order (two buffers:
 // one barrier per tile).
 #pragma once
@@ -26,6 +26,8 @@ constexpr int kRwsMaxWaves = 4096;     // waves of a rows_ws launch (a partial m
 
 struct RwsProb {
   const float* W;                   // NN: [K][ldw]; NT: [N][ldw]
+  const float* W2;                  // rows_ws_k8 only: a second NT weight [N][ldw2] over 128 more contraction steps (A2), or null
+  int ldw2;
   const float *bias, *addsrc, *mask;   // [N] or null; [R / add_div][ld_add] or null; [R][ld_mask] (keep where > 0) or null
   float* out;                       // [R][N]
   unsigned* amax;                   // or null: word [global wave] receives the bits of the largest |out| that wave wrote (gemm.hpp amax_final)
@@ -33,6 +35,8 @@ struct RwsProb {
 };
 struct RwsArgs {
   const float* A;                   // [R][lda]
+  const float* A2;                  // rows_ws_k8 only: [R][lda2], 128 columns (with p[0].W2), or null
+  int lda2;
   int lda, R, np;
   int ns0, ns;                      // column slices of p[0]; of both problems
   RwsProb p[2];
@@ -193,15 +197,30 @@ __global__ __launch_bounds__(kSkThreads) void rows_ws_k8(const RwsArgs a) {
   const RwsProb& P = a.p[0];
   sk_bf16x8 Wp[2][4][3];
   rws_weight<2, 4, true>(P.W, P.ldw, 64 * wave, 4 * ln, lk, Wp);
+  // a second segment of 128 contraction steps (dy's prior part: dpp Wp^T beside dhg Wg0y^T): k-step wave & 3 of it is a THIRD k-step
+  // of waves 0..3; waves 4..7 run the same instructions on a zero block, so that every wave issues the same loads and multiplies
+  // (the loop's counted waits and the barrier need that) -- 24 of 72 instructions per tile idle in half the waves
+  const bool seg2 = a.A2 != nullptr;
+  sk_bf16x8 Wq[1][4][3];
+  if (seg2 && wave < 4) {
+    rws_weight<1, 4, true>(P.W2, P.ldw2, 32 * wave, 4 * ln, lk, Wq);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) Wq[0][t][q] = __builtin_bit_cast(sk_bf16x8, sk_u32x4{0u, 0u, 0u, 0u});
+  }
+  const float* const A2b = seg2 ? a.A2 + 32 * (wave & 3) + 8 * lk : a.A + 8 * lk;      // (no second segment: a resident line, multiplied by zeros)
+  const long long lda2 = seg2 ? a.lda2 : 0;
   const int ntile = (R + 15) >> 4, nfull = R >> 4, nwg = (int)gridDim.x;
   const int frow = tid >> 5, fcp = tid & 31;       // the pair this thread finishes
   const int foff = ((frow & 3) * 64 + (frow >> 2) * 16 + (fcp >> 1)) * 4 + 2 * (fcp & 1);
   const bool is_add = P.addsrc != nullptr;
   const float* const side = is_add ? P.addsrc : P.W;        // (as rows_ws: the same number of loads with or without an addend)
   const int ld_side = is_add ? P.ld_add : 0, div_side = is_add ? P.add_div : 1;
-  float4 an[2][2];
+  float4 an[3][2];
   float2 sn, sc;
-  sk_bf16x8 Ap[2][3];
+  sk_bf16x8 Ap[3][3];
   auto fetch = [&](const int rt_) {
     const int rt = min(rt_, ntile - 1);
     const float* const ar = a.A + (long long)min(16 * rt + ln, R - 1) * lda + 64 * wave + 8 * lk;
@@ -210,11 +229,14 @@ __global__ __launch_bounds__(kSkThreads) void rows_ws_k8(const RwsArgs a) {
       an[ks][0] = *reinterpret_cast<const float4*>(ar + 32 * ks);
       an[ks][1] = *reinterpret_cast<const float4*>(ar + 32 * ks + 4);
     }
+    const float* const a2 = A2b + (long long)min(16 * rt + ln, R - 1) * lda2;
+    an[2][0] = *reinterpret_cast<const float4*>(a2);
+    an[2][1] = *reinterpret_cast<const float4*>(a2 + 4);
     sn = *reinterpret_cast<const float2*>(side + (long long)(min(16 * rt + frow, R - 1) / div_side) * ld_side + 2 * fcp);
   };
   auto split = [&]() {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 3; ++ks) {
       const float v[8] = {an[ks][0].x, an[ks][0].y, an[ks][0].z, an[ks][0].w, an[ks][1].x, an[ks][1].y, an[ks][1].z, an[ks][1].w};
       sk_pieces(v, Ap[ks]);
     }
@@ -230,6 +252,10 @@ __global__ __launch_bounds__(kSkThreads) void rows_ws_k8(const RwsArgs a) {
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int t = 0; t < 4; ++t) sk_mma6(Ap[ks], Wp[ks][t], acc[t]);
+    if (seg2) {                                    // (uniform over the launch)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) sk_mma6(Ap[2], Wq[0][t], acc[t]);
+    }
     float* const rb = red[buf];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
