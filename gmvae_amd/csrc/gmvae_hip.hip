@@ -1969,6 +1969,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   // in a wave, K = 512 x N = 64 (NT) over the eight waves of a workgroup; one resident wave of workgroups
   const bool rws_on = relu_act && R >= 2048 && !getenv("GMVAE_NO_RWS");
   auto rws_grid = [&]() { const int cu = device_cus(); return cu * kSkWaves > kRwsMaxWaves ? kRwsMaxWaves / kSkWaves : cu; };
+  auto rws_fits = [&](long long slices) { return slices >= 1 && slices <= (long long)rws_grid() * kSkWaves; };      // (a wave per column slice at least)
   auto rws_prob = [&](const float* W, int ldw, const float* bias, float* out, int N, bool relu) {
     RwsProb q;
     memset(&q, 0, sizeof(q));
@@ -2058,7 +2059,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
                        1.f / d.temperature);
     rowk(cx, "y_head_fwd");
     const NetL& G = L.encg;
-    if (rws_on && K == 64 && G.dim[1] % 64 == 0 && (2 * Lz) % 64 == 0) {
+    if (rws_on && K == 64 && G.dim[1] % 64 == 0 && (2 * Lz) % 64 == 0 && rws_fits((G.dim[1] + 2 * Lz) / 64)) {
       RwsArgs ra;
       memset(&ra, 0, sizeof(ra));
       ra.A = w.y; ra.lda = K; ra.R = R; ra.np = 2;
@@ -2130,7 +2131,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
   for (int i = 0; i < Dn.nl; ++i) {
     Group g;
     const float* in = (i == 0) ? w.z : w.hd[i];
-    if (i < Dn.nl - 1 && rws_on && Dn.dim[i] == 64 && Dn.dim[i + 1] % 64 == 0 && !(planes && !pairs && i == Dn.nl - 2)) {
+    if (i < Dn.nl - 1 && rws_on && Dn.dim[i] == 64 && Dn.dim[i + 1] % 64 == 0 && rws_fits(Dn.dim[i + 1] / 64) && !(planes && !pairs && i == Dn.nl - 2)) {
       RwsArgs ra;
       memset(&ra, 0, sizeof(ra));
       ra.A = in; ra.lda = Dn.dim[i]; ra.R = R; ra.np = 1;
@@ -2346,7 +2347,7 @@ static int run_step(Ctx& cx, const StepArgs& a) {
                  nsg, PP, nullptr));
       float* out = w.dbuf[pb];
       // (dhg = dqp Wg1^T under the ReLU mask, K = 128: the weight stationary, in a launch of its own)
-      const bool rws_dh = rws_on && G.dim[i + 1] == 128 && G.dim[i] % 32 == 0;
+      const bool rws_dh = rws_on && G.dim[i + 1] == 128 && G.dim[i] % 32 == 0 && rws_fits(G.dim[i] / 32);
       if (!rws_dh)
         g.add(p_nt(dcur, G.dim[i + 1], P + G.w[i], G.dim[i + 1], R, G.dim[i], G.dim[i + 1], out, G.dim[i], w.hg[i],
                    G.dim[i]));
