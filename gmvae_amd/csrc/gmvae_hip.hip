@@ -2732,11 +2732,11 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
     RwsProb& q = ra.p[0];
     q.W = W; q.out = C; q.N = N; q.add_div = 1;
     const int cu = device_cus(), grid = cu * kSkWaves > kRwsMaxWaves ? kRwsMaxWaves / kSkWaves : cu;
-    if (trans == 0 && K == 64 && N % 64 == 0) {
+    if (trans == 0 && K == 64 && N % 64 == 0 && N / 64 <= grid * kSkWaves) {
       q.ldw = N; q.bias = bias; q.relu = relu != 0;
       ra.ns0 = ra.ns = N / 64;
       hipLaunchKernelGGL((rows_ws<2, 4, false>), dim3(grid), dim3(kSkThreads), 0, cx.st, ra);
-    } else if (trans == 1 && K == 128 && N % 32 == 0) {
+    } else if (trans == 1 && K == 128 && N % 32 == 0 && N / 32 <= grid * kSkWaves) {
       q.ldw = K; q.mask = bias; q.ld_mask = N;
       ra.ns0 = ra.ns = N / 32;
       hipLaunchKernelGGL((rows_ws<4, 2, true>), dim3(grid), dim3(kSkThreads), 0, cx.st, ra);
