@@ -2724,7 +2724,7 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
   }
   if (cfg == 8) {
     // the weight-stationary row kernels (rowsws.hpp): NN K = 64 (N % 64 = 0); NT K = 128 (N % 32 = 0; `bias` = a ReLU mask [M][N]
-    // or NULL) and K = 512, N = 64 (`bias` = an addend [M][N] or NULL)
+    // or NULL) and K = 512 or 512 + 128, N = 64 (`bias` = an addend [M][N] or NULL)
     if (a_is_u8 || trans > 1) return GMVAE_E_DIMS;
     RwsArgs ra;
     memset(&ra, 0, sizeof(ra));
@@ -2742,6 +2742,12 @@ int gmvae_gemm_test(const void* A, int a_is_u8, const float* W, const float* bia
       hipLaunchKernelGGL((rows_ws<4, 2, true>), dim3(grid), dim3(kSkThreads), 0, cx.st, ra);
     } else if (trans == 1 && K == 512 && N == 64) {
       q.ldw = K; q.addsrc = bias; q.ld_add = N;
+      ra.ns0 = ra.ns = 1;
+      hipLaunchKernelGGL(rows_ws_k8, dim3(grid), dim3(kSkThreads), 0, cx.st, ra);
+    } else if (trans == 1 && K == 640 && N == 64) {      // the two-segment form: columns 0..511 and 512..639 of A [M][640] against W [N][640]
+      ra.lda = 640; q.ldw = 640; q.addsrc = bias; q.ld_add = N;
+      ra.A2 = static_cast<const float*>(A) + 512; ra.lda2 = 640;
+      q.W2 = W + 512; q.ldw2 = 640;
       ra.ns0 = ra.ns = 1;
       hipLaunchKernelGGL(rows_ws_k8, dim3(grid), dim3(kSkThreads), 0, cx.st, ra);
     } else {

@@ -211,7 +211,10 @@ int gmvae_cluster_acc(const float* logits, const int64_t* labels, int B, int K, 
 /* ---- measurement / test hooks (not used by the reference-facing API) ---- */
 
 /* One GEMM through the same grouped fp32-MFMA kernel the step uses.
- * cfg: tile configuration (0 small 32x32, 1 medium 64x64, 2 large 128x128, -1 auto).
+ * cfg: tile configuration (0 small 32x32, 1 medium 64x64, 2 large 128x128, -1 auto); 4 / 5: the pre-split bf16-triple planes
+ *      (5 reuses the planes of the previous cfg-4 call); 6 / 7: the f16-pair planes likewise; 8: the weight-stationary row
+ *      kernels (NN K = 64; NT K = 128 with `bias` as a ReLU mask [M][N]; NT K = 512 or 640 = 512 + 128, N = 64, with `bias`
+ *      as an addend [M][N]); shapes a form does not take are refused (GMVAE_E_DIMS).
  * trans 0 (NN): C[M,N] = act(A[M,K] W[K,N] + bias)
  * trans 1 (NT): C[M,N] = A[M,K] W[N,K]^T
  * trans 2 (TN): C[s][M(+1),N] = A[K,M]^T W[K,N] split over K into `splitk` slabs

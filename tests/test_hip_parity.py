@@ -63,7 +63,7 @@ def test_gemm_nt(H, cfg, M, N, K):
 
 @pytest.mark.parametrize("form,M,N,K", [("nn", 4096, 512, 64), ("nn", 2050, 64, 64), ("nn", 37, 128, 64), ("nt_mask", 4096, 512, 128),
                                          ("nt_mask", 2061, 96, 128), ("nt", 519, 64, 128), ("nt_k8", 4096, 64, 512), ("nt_k8_add", 2057, 64, 512),
-                                         ("nt_k8", 5, 64, 512)])
+                                         ("nt_k8", 5, 64, 512), ("nt_k8", 4096, 64, 640), ("nt_k8_add", 2051, 64, 640)])
 def test_rows_weight_stationary(H, form, M, N, K):
     """The row-panel layers with the weight stationary (csrc/rowsws.hpp; `cfg` 8 of gmvae_gemm_test) against fp64: exact bf16 piece
     products, so the distance is fp32 accumulation's.  Ragged row counts (the last tile's rows are clamped loads, predicated
@@ -97,7 +97,7 @@ def test_rows_weight_stationary(H, form, M, N, K):
     out = Cd.cpu().numpy()
     assert np.isnan(out[M:]).all()                     # nothing stored past the last row
     np.testing.assert_allclose(out[:M], ref, rtol=2e-6, atol=2e-6 * math.sqrt(K))
-    # shapes outside the three forms are refused, not mis-run
+    # shapes outside the forms are refused, not mis-run (K = 640: the two-segment form, 512 + 128 contraction steps from one matrix)
     assert L.lib.gmvae_gemm_test(L.ptr(Ad), 0, L.ptr(Wd), None, L.ptr(Cd), M, N, K + 32, trans, relu, 8, 1, L.current_stream()) != 0
 
 
