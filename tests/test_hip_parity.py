@@ -459,7 +459,8 @@ def test_plane_gemms_at_config5_dims_under_natural_gating(H, monkeypatch):
     batch that passes every gate of planes_ok by itself: R = B * S must be >= 4096 AND a multiple of 128 (whole 128-row
     tiles), i.e. B a multiple of 64 -- B = 128, R = 6,400 sample rows.  The step then runs "general+planes" exactly as the
     25,600-row shard of the benchmark does -- logits + Bernoulli epilogue, the data gradient and the 6-of-9-piece weight
-    gradient over a 6,400-long contraction with 16 split-K slabs, the IWAE row weights on the activation's pieces -- and every
+    gradient over a 6,400-long contraction in 5 split-K slabs (the rule of DESIGN.md 3.5), the IWAE row weights on the activation's
+    pieces, the thin layers and data gradients on the weight-stationary row kernels (csrc/rowsws.hpp) -- and every
     loss term and every gradient tensor is compared with the fp64 oracle at the step's gates (NumPy needs ~20 s there)."""
     for k in ("GMVAE_PLANES_MINROWS", "GMVAE_NO_PLANES", "GMVAE_NSPLIT_SMALL", "GMVAE_FORCE_CFG", "GMVAE_NO_BIG"):
         monkeypatch.delenv(k, raising=False)
@@ -473,6 +474,27 @@ def test_plane_gemms_at_config5_dims_under_natural_gating(H, monkeypatch):
             p[k] = rng.normal(0, 0.05, p[k].shape)
     x, eps, u = O.make_inputs(d, B)
     H.compare_step(O.MODEL_GMVAE, d, p, x, eps, u)
+
+
+@pytest.mark.parametrize("ns", [1, 3, 16])
+def test_top_weight_gradient_is_the_same_sum_in_any_number_of_slabs(H, monkeypatch, ns):
+    """The plane launch's weight gradient is split over the rows into a number of slabs chosen by a rule (gmvae_hip.hip: as many
+    as put its tiles on the chip once); finalize_grads sums whatever count the launch wrote.  D = 256, hidden 128, S = 32, B = 128
+    (R = 4,096 rows: up to 16 slabs), planes forced: gradients with 1, 3 and 16 slabs against the rule's own count -- the same sums
+    in another order, so equal to fp32 summation error -- and the losses bit-identical (the forward pass does not depend on it)."""
+    monkeypatch.setenv("GMVAE_PLANES_MINROWS", "128")
+    monkeypatch.setenv("GMVAE_NO_SKINNY", "1")
+    monkeypatch.delenv("GMVAE_NSPLIT_TOP", raising=False)
+    d = O.Dims(D=256, L=16, K=10, hidden=(128,), S=32)
+    rng = np.random.default_rng(5)
+    p = O.init_params(O.MODEL_GMVAE, d, rng)
+    flat = O.pack(O.MODEL_GMVAE, d, p, np.float32)
+    x, eps, u = O.make_inputs(d, 128)
+    g0, t0 = H.hip_step(O.MODEL_GMVAE, d, flat, x, eps, u)
+    monkeypatch.setenv("GMVAE_NSPLIT_TOP", str(ns))
+    g1, t1 = H.hip_step(O.MODEL_GMVAE, d, flat, x, eps, u)
+    assert np.isfinite(g1).all() and np.array_equal(t0[:4], t1[:4])
+    np.testing.assert_allclose(g1, g0, rtol=0, atol=3e-6 * np.abs(g0).max())
 
 
 def _random_plane_cases(n, seed):
