@@ -476,6 +476,32 @@ def test_plane_gemms_at_config5_dims_under_natural_gating(H, monkeypatch):
     H.compare_step(O.MODEL_GMVAE, d, p, x, eps, u)
 
 
+@pytest.mark.parametrize("B,S", [(41, 50), (2049, 1)])
+def test_weight_stationary_rows_inside_the_step_with_a_ragged_last_tile(H, monkeypatch, B, S):
+    """The general schedule at >= 2048 sample rows with 64 components, 64 latents and a 512-wide hidden layer takes every form of
+    csrc/rowsws.hpp -- y / z -> 512 units (K = 64), dz = dhd Wd0^T (K = 512 over eight waves), dhg = dqp Wg1^T under the ReLU mask
+    (K = 128), dy = dhg Wg0y^T + dpp Wp^T (two segments) -- here with R = 2,050 / 2,049 rows: the last row tile has 2 / 1 rows
+    (clamped loads, predicated stores, run once behind the loops), D = 80 keeps the oracle quick.  Against the fp64 oracle at the
+    step's gates, and against the same step with GMVAE_NO_RWS=1."""
+    for k in ("GMVAE_NO_RWS", "GMVAE_PLANES_MINROWS", "GMVAE_NO_PLANES"):
+        monkeypatch.delenv(k, raising=False)
+    d = O.Dims(D=80, L=64, K=64, hidden=(512,), S=S)
+    rng = np.random.default_rng(B)
+    p = O.init_params(O.MODEL_GMVAE, d, rng)
+    for k in p:
+        if k.endswith("/b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape)
+    x, eps, u = O.make_inputs(d, B)
+    H.compare_step(O.MODEL_GMVAE, d, p, x, eps, u)
+    flat = O.pack(O.MODEL_GMVAE, d, p, np.float32)
+    g_ws, t_ws = H.hip_step(O.MODEL_GMVAE, d, flat, x, eps, u)
+    monkeypatch.setenv("GMVAE_NO_RWS", "1")
+    g_old, t_old = H.hip_step(O.MODEL_GMVAE, d, flat, x, eps, u)
+    assert not np.array_equal(g_ws, g_old)                       # (the switch did switch)
+    np.testing.assert_allclose(g_ws, g_old, rtol=0, atol=2e-5 * np.abs(g_old).max())
+    np.testing.assert_allclose(t_ws[:4], t_old[:4], rtol=1e-6)
+
+
 @pytest.mark.parametrize("ns", [1, 3, 16])
 def test_top_weight_gradient_is_the_same_sum_in_any_number_of_slabs(H, monkeypatch, ns):
     """The plane launch's weight gradient is split over the rows into a number of slabs chosen by a rule (gmvae_hip.hip: as many
