@@ -243,6 +243,55 @@ def test_virtual_ranks_with_row_offsets_sum_to_the_full_batch_philox_step(model,
 
 
 @pytest.mark.gpu
+def test_config5_full_shard_is_the_sum_of_its_row_shards():
+    """BASELINE configs[4]'s per-GPU shard at FULL size (D = 3072, K = 64, hidden 512, S = 50, B = 512: 25,600 sample rows -- far past
+    what the oracle finishes in seconds), through a property that does not depend on size: with in-kernel Philox noise keyed by the
+    GLOBAL row, the step on 512 rows leaves the sum of the steps on its four 128-row shards (row0 = 0, 128, 256, 384) -- gradient
+    sums, loss sum and row count -- although the two runs take different slab counts, tile grids and per-tensor pair scales; and
+    the full-size step is bit-identical when repeated.  (The 128-row shard itself is compared with the oracle in
+    tests/test_hip_parity.py::test_plane_gemms_at_config5_dims_under_natural_gating.)"""
+    import ctypes as C
+    import hip_util as H
+    from gmvae_amd import _lib as L
+    mid = O.MODEL_GMVAE
+    d = O.Dims(D=3072, L=64, K=64, hidden=(512,), S=50)
+    Bg, G = 512, 4
+    flat = O.pack(mid, d, O.init_params(mid, d, np.random.default_rng(1)), np.float32)
+    x = (np.random.default_rng(2).random((Bg, 3072)) < 0.3).astype(np.uint8)
+    params = H.dev(flat, torch.float32)
+    lay, _, _ = O.param_layout(mid, d)
+    real = np.zeros(flat.size + L.TAIL, bool)
+    for _, shape, off in lay:
+        real[off:off + int(np.prod(shape))] = True
+    real[flat.size:] = True
+
+    def run(xs, row0):
+        cd = H.dims_of(d, xs.shape[0])
+        cd.row0 = row0
+        assert L.step_schedule(cd, mid) == "general+planes"
+        P, _ = L.param_count(cd, mid)
+        grads = torch.full((P + L.TAIL,), float("nan"), dtype=torch.float32, device="cuda")
+        ws = H.workspace(cd, mid)
+        xd = H.dev(xs, torch.uint8)
+        L.check(L.lib.gmvae_step(C.byref(cd), mid, L.ptr(xd), None, None, L.ptr(params), L.ptr(grads), L.ptr(ws), 7, 3, None,
+                                 L.current_stream()), "gmvae_step")
+        torch.cuda.synchronize()
+        g = grads.cpu().numpy().astype(np.float64)
+        assert np.isfinite(g[real]).all()
+        return np.where(real, g, 0.0)
+
+    full = run(x, 0)
+    assert np.array_equal(full, run(x, 0))
+    acc = 0.0
+    for r in range(G):
+        acc = acc + run(x[128 * r:128 * (r + 1)], 128 * r)
+    P = full.size - L.TAIL
+    assert acc[P + 4] == full[P + 4] == Bg
+    assert abs(acc[P] - full[P]) <= 2e-6 * abs(full[P])
+    assert np.abs(acc[:P] - full[:P]).max() <= 2e-5 * np.abs(full[:P]).max()
+
+
+@pytest.mark.gpu
 def test_rccl_in_library_world1_matches_plain_step():
     """The C-side RCCL path (communicator of one rank on this GPU): gmvae_dp_step and the captured DP graph
     give the same trajectory as step + Adam without any collective."""
