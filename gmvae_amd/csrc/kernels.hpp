@@ -271,6 +271,40 @@ __global__ __launch_bounds__(512) void y_head_bwd(const float* __restrict__ logi
     float m2, l2;
     row_lse_parts(lg, K, lane, m2, l2);
     const float ne = nent[b];
+    if (K <= 64 && S <= 64) {
+      // One pass with every load in flight first: a wave's (up to) 8 samples were 8 dependent rounds of load -> three wave
+      // reductions (at the config-5 sizes, 7 samples per wave: 18 us for 13 MB).  Same operations in the same order as the loop below.
+      const bool kv = lane < K;
+      float ys[8], ds[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int sidx = wave + 8 * j;
+        const long long r = (long long)b * S + (sidx < S ? sidx : 0);
+        ys[j] = (kv && sidx < S) ? y[r * K + lane] : 0.f;
+        ds[j] = (kv && sidx < S) ? dy[r * K + lane] : 0.f;
+      }
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (wave + 8 * j < S) {                    // (uniform per wave)
+          const float ym = wave_max(kv ? fmaxf(0.f, ys[j]) : 0.f);
+          const float c = wave_max((kv && ys[j] == ym) ? ds[j] : -INFINITY);
+          const float dot = wave_sum(kv ? ys[j] * (ds[j] - c) : 0.f);
+          if (kv) acc += ys[j] * ((ds[j] - c) - dot);
+        }
+      }
+      red[wave][lane] = acc;
+      __syncthreads();
+      if (wave == 0 && kv) {
+        float t = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) t += red[w][lane];
+        const float lp = (lg[lane] - m2) - l2;
+        dlogits[(long long)b * K + lane] = t * invT + expf(lp) * (lp - ne);
+      }
+      __syncthreads();
+      continue;
+    }
     for (int k0 = 0; k0 < K; k0 += 64) {
       const int k = k0 + lane;
       float acc = 0.f;
